@@ -1,0 +1,60 @@
+/*
+ * strom_datastore.h -- C ABI for building / converting chunks on the host
+ *
+ * Role in the reference: datastore.c -- init_kern_data_store (312-380),
+ * pgstrom_create_data_store_row / _row_flat / _tupslot (382-529),
+ * pgstrom_data_store_insert_block (556-710) and _insert_tuple (718-828).
+ * Those read PostgreSQL heap pages and TupleTableSlots; here the rows
+ * arrive as plain column arrays and the functions lay them out in the
+ * same bytes: real heap pages with line pointers for ROW, packed heap
+ * tuples growing from the tail for ROW_FLAT, Datum/isnull pairs for
+ * TUPSLOT, and the column-major arrays of KDS_FORMAT_COLUMN.
+ */
+#ifndef STROM_DATASTORE_H
+#define STROM_DATASTORE_H
+
+#include "strom_kds.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct {
+	int32_t			type_oid;	/* STROM_*OID */
+	int16_t			attlen;		/* 1,2,4,8 */
+	int8_t			attalign;	/* 1,2,4,8 */
+	int8_t			attbyval;
+	const void	   *values;		/* nrows * attlen bytes */
+	const uint8_t  *isnull;		/* nrows bytes, 1 = NULL; may be NULL */
+} strom_column_input;
+
+/* bytes a chunk of 'nrows' rows needs in 'format' (0 on bad input) */
+size_t	strom_kds_required_length(int format, int ncols,
+								  const strom_column_input *cols,
+								  uint32_t nrows);
+/*
+ * Lay the rows out.  'buffer' must hold strom_kds_required_length() bytes
+ * and be 16-byte aligned.  The image is contiguous -- for ROW the heap
+ * pages follow the row items at the BLCKSZ-aligned offset the device
+ * expects (KERN_DATA_STORE_ROWBLOCK), i.e. what clserv_dmasend_data_store
+ * assembles on the device.  Returns 0 or a StromError code.
+ */
+int		strom_kds_build(int format, int ncols,
+						const strom_column_input *cols,
+						uint32_t nrows, void *buffer, size_t buflen);
+
+/*
+ * ROW / ROW_FLAT / TUPSLOT -> COLUMN on the host (the ingest step).
+ * Returns required length when dst == NULL.
+ */
+size_t	strom_kds_to_column(const kern_data_store *src, void *dst, size_t dstlen);
+
+/* fetch one datum on the host: pgstrom_fetch_data_store (datastore.c:169-242).
+ * Returns 1 when NULL, 0 otherwise with up to 8 bytes stored in *value. */
+int		strom_kds_fetch(const kern_data_store *kds, uint32_t rowidx, uint32_t colidx,
+						uint64_t *value);
+
+#ifdef __cplusplus
+}
+#endif
+#endif	/* STROM_DATASTORE_H */

@@ -1,0 +1,182 @@
+/*
+ * strom_hip.h -- C ABI of libstrom_hip.so, the HIP device runtime that
+ * stands where the reference's OpenCL server stands.
+ *
+ * Every entry point names the reference interface it replaces.  The
+ * reference's boundary is a message protocol (pgstrom_message,
+ * pg_strom.h:238-248; mqueue.c): a backend fills a request object, the
+ * server thread runs msg->cb_process() which must only *enqueue* device
+ * work, and a runtime thread later stores msg->errcode and replies.  The
+ * same contract is kept here as plain functions:
+ *
+ *     strom_submit_*()   ==  pgstrom_enqueue_message() + clserv_process_*()
+ *     strom_done_cb      ==  clserv_respond_*() + pgstrom_reply_message()
+ *
+ * No torch / C++ types cross this boundary; pointers are host pointers to
+ * the wire structs of strom_kds.h unless named strom_dstore (a chunk kept
+ * resident in HBM).
+ */
+#ifndef STROM_HIP_H
+#define STROM_HIP_H
+
+#include "strom_kds.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ------------------------------------------------------------------ *
+ * extra_flags of a device program (pg_strom.h:263-274)
+ * ------------------------------------------------------------------ */
+#define DEVINFO_IS_NEGATIVE			0x0001
+#define DEVTYPE_IS_VARLENA			0x0002
+#define DEVTYPE_IS_BUILTIN			0x0004
+#define DEVFUNC_NEEDS_TIMELIB		0x0008
+#define DEVFUNC_NEEDS_TEXTLIB		0x0010
+#define DEVFUNC_NEEDS_NUMERIC		0x0020
+#define DEVFUNC_NEEDS_MATHLIB		0x0040
+#define DEVFUNC_INCL_FLAGS			0x0078
+#define DEVKERNEL_DISABLE_OPTIMIZE	0x0100
+#define DEVKERNEL_NEEDS_GPUSCAN		0x0200
+#define DEVKERNEL_NEEDS_HASHJOIN	0x0400
+#define DEVKERNEL_NEEDS_GPUPREAGG	0x0800
+
+/* ------------------------------------------------------------------ *
+ * perfmon: same fields as pgstrom_perfmon (pg_strom.h:177-213); times in
+ * microseconds like the reference (gettimeofday / CL profiling -> usec)
+ * ------------------------------------------------------------------ */
+typedef struct {
+	cl_bool		enabled;
+	cl_uint		num_samples;
+	cl_ulong	time_inner_load;
+	cl_ulong	time_outer_load;
+	cl_ulong	time_materialize;
+	cl_ulong	time_in_sendq;
+	cl_ulong	time_in_recvq;
+	cl_ulong	time_kern_build;
+	cl_uint		num_dma_send;
+	cl_uint		num_dma_recv;
+	cl_ulong	bytes_dma_send;
+	cl_ulong	bytes_dma_recv;
+	cl_ulong	time_dma_send;
+	cl_ulong	time_dma_recv;
+	cl_uint		num_kern_exec;
+	cl_ulong	time_kern_exec;
+	cl_uint		num_kern_proj;
+	cl_ulong	time_kern_proj;
+	cl_uint		num_kern_prep;
+	cl_uint		num_kern_sort;
+	cl_ulong	time_kern_prep;
+	cl_ulong	time_kern_sort;
+	/* extension: kernel time in nanoseconds (HIP events resolve < 1us) */
+	cl_ulong	time_kern_exec_ns;
+	cl_ulong	time_kern_prep_ns;
+	cl_ulong	time_kern_proj_ns;
+} strom_perfmon;
+
+/* ------------------------------------------------------------------ *
+ * life cycle  (opencl_serv.c:156-215 init_opencl_context_and_shmem,
+ *              224-305 pgstrom_opencl_main; shutdown 412-430)
+ * device_ids == NULL: use the device HIP reports as current (one process
+ * per GPU under torch.distributed sets it through LOCAL_RANK).
+ * ------------------------------------------------------------------ */
+int			strom_init(const int *device_ids, int ndevices);
+void		strom_shutdown(void);
+int			strom_num_devices(void);
+/* round-robin device pick (opencl_serv.c:100-106) */
+int			strom_device_schedule(void);
+/* pgstrom_strerror (main.c:288-328) */
+const char *strom_strerror(int errcode);
+/* pin a host range so DMA is direct (opencl_serv.c:115-137) */
+int			strom_pin_host_range(void *ptr, size_t length);
+int			strom_unpin_host_range(void *ptr);
+/* device properties the reference prints via pgstrom_opencl_device_info */
+int			strom_device_info(int dindex, char *buf, size_t buflen);
+/* GUC-like switch: pg_strom.perfmon (main.c:116-123) */
+void		strom_set_perfmon(int enabled);
+
+/* ------------------------------------------------------------------ *
+ * device program cache  (opencl_devprog.c)
+ *   strom_get_devprog_key      <- pgstrom_get_devprog_key      (580-659)
+ *   strom_retain/put           <- pgstrom_retain/put_devprog_key (669-697)
+ *   strom_get_devprog_errmsg   <- pgstrom_get_devprog_errmsg   (708-720)
+ *   strom_lookup_device_program<- clserv_lookup_device_program (270-569)
+ * A key is the handle the reference stores as 'Datum dprog_key'.  The
+ * build (hiprtc, --offload-arch=gfx950) starts asynchronously on first
+ * reference; requests submitted while it runs are parked and re-issued
+ * when it ends, as the reference parks messages on the program's wait
+ * queue.
+ * ------------------------------------------------------------------ */
+typedef uint64_t strom_devprog_key;
+
+#define STROM_DEVPROG_READY		1
+#define STROM_DEVPROG_PENDING	0
+#define STROM_DEVPROG_BAD		(-1)	/* BAD_OPENCL_PROGRAM, pg_strom.h:587 */
+
+strom_devprog_key strom_get_devprog_key(const char *source, int32_t extra_flags);
+void		strom_retain_devprog_key(strom_devprog_key key);
+void		strom_put_devprog_key(strom_devprog_key key);
+const char *strom_get_devprog_errmsg(strom_devprog_key key);
+int			strom_lookup_device_program(strom_devprog_key key, int wait);
+/* the full text handed to the compiler: pg_strom.show_device_kernel */
+const char *strom_get_devprog_source(strom_devprog_key key);
+
+/* ------------------------------------------------------------------ *
+ * device-resident chunks.  The reference re-sends a chunk for every
+ * request (clserv_dmasend_data_store, datastore.c:837-973); a strom_dstore
+ * is the same bytes kept in HBM so that a table can be scanned again (and
+ * chained operators can share it) without crossing PCIe.
+ * ------------------------------------------------------------------ */
+typedef struct strom_dstore strom_dstore;
+
+strom_dstore *strom_dstore_upload(const kern_data_store *kds, int dindex);
+/* adopt device memory somebody else filled (e.g. a torch tensor): no copy,
+ * not freed on release */
+strom_dstore *strom_dstore_wrap(void *devptr, size_t length, int dindex);
+void	   *strom_dstore_devptr(strom_dstore *ds);
+size_t		strom_dstore_length(strom_dstore *ds);
+void		strom_dstore_release(strom_dstore *ds);
+
+/* ------------------------------------------------------------------ *
+ * requests
+ * ------------------------------------------------------------------ */
+typedef void (*strom_done_cb)(void *arg, int errcode, const strom_perfmon *pfm);
+typedef struct strom_task strom_task;
+
+/* request flags */
+#define STROM_RESULTS_ON_DEVICE		0x0001	/* leave results[] in HBM; copy
+											 * back only the resultbuf head */
+
+/*
+ * GpuScan on one chunk.
+ *   <- clserv_process_gpuscan (gpuscan.c:1895-2182) + clserv_respond_gpuscan
+ *      (1760-1888).  'kgpuscan' is the host image {kern_parambuf,
+ *      kern_resultbuf}; the head up to results[] is sent, and
+ *      kern_resultbuf{nitems, errcode, results[0..nitems)} is written back
+ *      into the same host memory before done() runs.
+ * Exactly one of kds (host chunk, uploaded for this request) or kds_dev
+ * (resident chunk) is non-NULL.  Returns NULL and sets *p_errcode when the
+ * request cannot be queued.  'done' may be NULL; the task must then be
+ * collected with strom_task_wait().
+ */
+strom_task *strom_submit_gpuscan(strom_devprog_key key,
+								 kern_gpuscan *kgpuscan,
+								 const kern_data_store *kds,
+								 strom_dstore *kds_dev,
+								 const kern_row_map *krowmap,
+								 uint32_t flags,
+								 strom_done_cb done, void *arg,
+								 int *p_errcode);
+
+/* block until the request finished; returns its errcode.  Frees the task. */
+int			strom_task_wait(strom_task *task, strom_perfmon *pfm_out);
+/* device address of the kern_gpuscan / kern_hashjoin image of a task that
+ * asked for STROM_RESULTS_ON_DEVICE (valid until strom_task_wait) */
+void	   *strom_task_devptr(strom_task *task);
+/* drain everything queued on every device */
+void		strom_synchronize(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif	/* STROM_HIP_H */

@@ -1,0 +1,58 @@
+/*
+ * codegen_internal.h -- shared between codegen.cpp and the per-operator
+ * emitters (codegen_hashjoin.cpp, codegen_preagg.cpp)
+ */
+#ifndef STROM_CODEGEN_INTERNAL_H
+#define STROM_CODEGEN_INTERNAL_H
+
+#include <string>
+#include <vector>
+#include "strom_codegen.h"
+
+namespace strom {
+
+struct devtype_info {
+	int			type_oid;
+	const char *sql_name;
+	const char *dev_name;		/* pg_<dev_name>_t */
+	int			type_length;
+	int			type_flags;		/* DEVFUNC_NEEDS_* of the declaring library */
+};
+
+struct sexpr {
+	bool				is_list = false;
+	std::string			atom;
+	std::vector<sexpr>	items;
+};
+
+/* codegen_context (pg_strom.h:406-419) */
+struct codegen_context {
+	std::string						var_label;		/* "KVAR" */
+	std::string						var_struct;		/* "KV" */
+	std::vector<strom_kparam_desc>	used_params;
+	std::vector<strom_kvar_desc>	used_vars;
+	int								extra_flags = 0;
+
+	int		track_param(const strom_kparam_desc &d);
+	void	track_var(int attno, int type_oid);
+};
+
+[[noreturn]] void codegen_error(const char *fmt, ...);
+sexpr		sexpr_parse(const char *text);
+const devtype_info *devtype_lookup(int oid);
+const devtype_info *devtype_lookup_by_name(const std::string &name);
+const char *devtype_eqfunc(int oid);
+const char *devtype_cmpfunc(int oid);
+/* emits the expression text, returns its type oid */
+int			codegen_expression(const sexpr &n, codegen_context &ctx, std::string &out);
+std::string	codegen_param_list(const codegen_context &ctx);
+std::string	codegen_var_list(const codegen_context &ctx, const char *macro_name);
+std::string	codegen_includes(int extra_flags);
+void		codegen_fill_result(const codegen_context &ctx, const std::string &source,
+								strom_codegen_result *out);
+/* device function name (without pgfn_) for name+argtypes, or empty */
+std::string	devfunc_devname(const std::string &name, const std::vector<int> &argtypes,
+							int *rettype, int *flags);
+
+}	/* namespace strom */
+#endif

@@ -1,0 +1,545 @@
+/*
+ * datastore.cpp -- host-side chunk builders and converters
+ *
+ * Role in the reference: datastore.c (see strom_datastore.h).  Byte layout
+ * of heap pages / tuples follows PostgreSQL 9.4's bufpage.h / htup_details.h
+ * as re-declared for the device in opencl_common.h:156-264.
+ */
+#include <cstdlib>
+#include <cstring>
+#include <cmath>
+#include <vector>
+
+#include "strom_datastore.h"
+
+namespace {
+
+const size_t PAGE_HEADER = 24;			/* offsetof(PageHeaderData, pd_linp) */
+const uint32_t LP_NORMAL = 1;
+
+inline size_t maxalign(size_t v) { return STROM_TYPEALIGN(STROM_MAXIMUM_ALIGNOF, v); }
+
+void
+init_kds_head(kern_data_store *kds, int format, int ncols,
+			  const strom_column_input *cols, uint32_t nrooms,
+			  uint32_t maxblocks, size_t length)
+{
+	memset(kds, 0, KDS_HEAD_LENGTH(ncols));
+	kds->hostptr = (hostptr_t)(uintptr_t)&kds->hostptr;
+	kds->length = (cl_uint)length;
+	kds->usage = 0;
+	kds->ncols = ncols;
+	kds->nitems = 0;
+	kds->nrooms = nrooms;
+	kds->nblocks = 0;
+	kds->maxblocks = maxblocks;
+	kds->format = (cl_char)format;
+	kds->tdhasoid = 0;
+	kds->tdtypeid = 2249;		/* RECORDOID */
+	kds->tdtypmod = -1;
+
+	/* attcacheoff: init_kern_data_store (datastore.c:336-379) */
+	int		attcacheoff = (int)maxalign(HEAPTUPLE_HEADER_FIXED);
+	for (int i = 0; i < ncols; i++)
+	{
+		kern_colmeta *cm = &kds->colmeta[i];
+		if (attcacheoff > 0)
+		{
+			if (cols[i].attlen > 0)
+				attcacheoff = (int)STROM_TYPEALIGN(cols[i].attalign, attcacheoff);
+			else
+				attcacheoff = -1;
+		}
+		cm->attbyval = cols[i].attbyval;
+		cm->attalign = cols[i].attalign;
+		cm->attlen = cols[i].attlen;
+		cm->attnum = (cl_short)(i + 1);
+		cm->attcacheoff = (cl_short)attcacheoff;
+		if (attcacheoff >= 0)
+			attcacheoff += cols[i].attlen;
+	}
+}
+
+inline bool
+is_null(const strom_column_input &c, uint32_t row)
+{
+	return c.isnull != nullptr && c.isnull[row] != 0;
+}
+
+/* size of the heap tuple for 'row': header, optional bitmap, aligned data */
+size_t
+heap_tuple_size(int ncols, const strom_column_input *cols, uint32_t row, size_t *p_hoff)
+{
+	bool	hasnull = false;
+	for (int i = 0; i < ncols; i++)
+		if (is_null(cols[i], row))
+			hasnull = true;
+	size_t	hoff = HEAPTUPLE_HEADER_FIXED;
+	if (hasnull)
+		hoff += (ncols + 7) / 8;
+	hoff = maxalign(hoff);
+	size_t	off = hoff;
+	for (int i = 0; i < ncols; i++)
+	{
+		if (is_null(cols[i], row))
+			continue;
+		off = STROM_TYPEALIGN(cols[i].attalign, off);
+		off += cols[i].attlen;
+	}
+	*p_hoff = hoff;
+	return off;
+}
+
+void
+heap_tuple_form(char *dest, int ncols, const strom_column_input *cols, uint32_t row,
+				size_t t_len, size_t hoff, uint32_t blkno, uint16_t posid)
+{
+	HeapTupleHeaderData *htup = (HeapTupleHeaderData *)dest;
+	bool	hasnull = false;
+
+	memset(dest, 0, t_len);
+	for (int i = 0; i < ncols; i++)
+		if (is_null(cols[i], row))
+			hasnull = true;
+	htup->t_xmin = 2;							/* FrozenTransactionId */
+	htup->bi_hi = (cl_ushort)(blkno >> 16);
+	htup->bi_lo = (cl_ushort)(blkno & 0xffff);
+	htup->ip_posid = posid;
+	htup->t_infomask2 = (cl_ushort)(ncols & HEAP_NATTS_MASK);
+	htup->t_infomask = (cl_ushort)((hasnull ? HEAP_HASNULL : 0) | 0x0800 /* XMAX_INVALID */
+								   | 0x0100 /* XMIN_COMMITTED */);
+	htup->t_hoff = (cl_uchar)hoff;
+	size_t	off = hoff;
+	for (int i = 0; i < ncols; i++)
+	{
+		if (is_null(cols[i], row))
+			continue;
+		if (hasnull)
+			htup->t_bits[i >> 3] |= (cl_uchar)(1 << (i & 7));
+		off = STROM_TYPEALIGN(cols[i].attalign, off);
+		memcpy(dest + off, (const char *)cols[i].values + (size_t)cols[i].attlen * row,
+			   cols[i].attlen);
+		off += cols[i].attlen;
+	}
+}
+
+/* ---- ROW: how many pages do nrows rows need ------------------------- */
+uint32_t
+row_count_pages(int ncols, const strom_column_input *cols, uint32_t nrows)
+{
+	uint32_t npages = 0;
+	size_t	lower = PAGE_HEADER, upper = BLCKSZ;
+	bool	open = false;
+	for (uint32_t r = 0; r < nrows; r++)
+	{
+		size_t hoff, t_len = heap_tuple_size(ncols, cols, r, &hoff);
+		size_t need = maxalign(t_len) + sizeof(cl_uint);
+		if (!open || upper - lower < need)
+		{
+			npages++;
+			lower = PAGE_HEADER;
+			upper = BLCKSZ;
+			open = true;
+		}
+		lower += sizeof(cl_uint);
+		upper -= maxalign(t_len);
+	}
+	return npages;
+}
+
+bool
+cols_valid(int ncols, const strom_column_input *cols)
+{
+	if (ncols < 1 || !cols)
+		return false;
+	for (int i = 0; i < ncols; i++)
+	{
+		int l = cols[i].attlen;
+		if (!(l == 1 || l == 2 || l == 4 || l == 8) || !cols[i].values)
+			return false;
+	}
+	return true;
+}
+
+size_t
+column_layout(int ncols, const strom_column_input *cols, uint32_t nrooms,
+			  std::vector<size_t> *values_off, std::vector<size_t> *nulls_off)
+{
+	size_t	off = KDS_COLUMN_HEAD_LENGTH(ncols);
+	for (int i = 0; i < ncols; i++)
+	{
+		if (values_off)
+			(*values_off)[i] = off;
+		off += KDS_COLUMN_VALUES_LENGTH(cols[i].attlen, nrooms);
+		bool anynull = false;
+		if (cols[i].isnull)
+			for (uint32_t r = 0; r < nrooms && !anynull; r++)
+				anynull = (cols[i].isnull[r] != 0);
+		if (nulls_off)
+			(*nulls_off)[i] = anynull ? off : 0;
+		if (anynull)
+			off += KDS_COLUMN_NULLS_LENGTH(nrooms);
+	}
+	return off;
+}
+
+void
+column_minmax(const strom_column_input &c, uint32_t nrows, kern_coldir *cd)
+{
+	bool	isfloat = (c.type_oid == STROM_FLOAT4OID || c.type_oid == STROM_FLOAT8OID);
+	bool	any = false;
+
+	cd->stat_flags = 0;
+	if (c.type_oid == 0)
+		return;				/* type unknown (converted chunk): no zone map */
+	int64_t	imin = 0, imax = 0;
+	double	fmin = 0, fmax = 0;
+
+	for (uint32_t r = 0; r < nrows; r++)
+	{
+		if (is_null(c, r))
+			continue;
+		const char *p = (const char *)c.values + (size_t)c.attlen * r;
+		if (isfloat)
+		{
+			double v;
+			if (c.attlen == 4) { float f; memcpy(&f, p, 4); v = f; }
+			else memcpy(&v, p, 8);
+			if (std::isnan(v))
+				continue;
+			if (!any || v < fmin) fmin = v;
+			if (!any || v > fmax) fmax = v;
+		}
+		else
+		{
+			int64_t v;
+			switch (c.attlen)
+			{
+				case 1: { int8_t x; memcpy(&x, p, 1); v = x; } break;
+				case 2: { int16_t x; memcpy(&x, p, 2); v = x; } break;
+				case 4: { int32_t x; memcpy(&x, p, 4); v = x; } break;
+				default: memcpy(&v, p, 8); break;
+			}
+			if (!any || v < imin) imin = v;
+			if (!any || v > imax) imax = v;
+		}
+		any = true;
+	}
+	cd->stat_flags = 0;
+	if (any)
+	{
+		cd->stat_flags = KDS_COLSTAT_MINMAX | (isfloat ? KDS_COLSTAT_ISFLOAT : 0);
+		if (isfloat)
+		{
+			memcpy(&cd->minval, &fmin, 8);
+			memcpy(&cd->maxval, &fmax, 8);
+		}
+		else
+		{
+			cd->minval = imin;
+			cd->maxval = imax;
+		}
+	}
+}
+
+}	/* namespace */
+
+extern "C" size_t
+strom_kds_required_length(int format, int ncols, const strom_column_input *cols, uint32_t nrows)
+{
+	if (!cols_valid(ncols, cols))
+		return 0;
+	switch (format)
+	{
+		case KDS_FORMAT_ROW:
+			{
+				uint32_t npages = row_count_pages(ncols, cols, nrows);
+				size_t	head = KDS_HEAD_LENGTH(ncols)
+					+ STROMALIGN(sizeof(kern_blkitem) * (size_t)npages)
+					+ STROMALIGN(sizeof(kern_rowitem) * (size_t)nrows);
+				return STROM_TYPEALIGN(BLCKSZ, head) + (size_t)BLCKSZ * npages;
+			}
+		case KDS_FORMAT_ROW_FLAT:
+			{
+				size_t	len = KDS_HEAD_LENGTH(ncols) + STROMALIGN(sizeof(kern_rowitem) * (size_t)nrows);
+				for (uint32_t r = 0; r < nrows; r++)
+				{
+					size_t hoff;
+					len += STROM_LONGALIGN(heap_tuple_size(ncols, cols, r, &hoff));
+				}
+				return STROMALIGN(len);
+			}
+		case KDS_FORMAT_TUPSLOT:
+			return STROMALIGN(KDS_HEAD_LENGTH(ncols) + KDS_TUPSLOT_STRIDE(ncols) * (size_t)nrows);
+		case KDS_FORMAT_COLUMN:
+			return column_layout(ncols, cols, nrows, nullptr, nullptr);
+	}
+	return 0;
+}
+
+extern "C" int
+strom_kds_build(int format, int ncols, const strom_column_input *cols,
+				uint32_t nrows, void *buffer, size_t buflen)
+{
+	size_t	required = strom_kds_required_length(format, ncols, cols, nrows);
+	if (required == 0 || !buffer || ((uintptr_t)buffer & 15) != 0)
+		return StromError_BadRequestMessage;
+	if (buflen < required)
+		return StromError_DataStoreNoSpace;
+	if (required > 0xffffffffUL)
+		return StromError_DataStoreOutOfRange;		/* 'length' is 32 bit */
+	kern_data_store *kds = (kern_data_store *)buffer;
+	char   *base = (char *)buffer;
+
+	if (format == KDS_FORMAT_ROW)
+	{
+		uint32_t npages = row_count_pages(ncols, cols, nrows);
+		if (npages > 0xffff)
+			return StromError_DataStoreOutOfRange;	/* blk_index is 16 bit */
+		init_kds_head(kds, format, ncols, cols, nrows, npages, required);
+		kds->nitems = nrows;
+		kds->nblocks = npages;
+		memset(base + KDS_HEAD_LENGTH(ncols), 0,
+			   KERN_DATA_STORE_ROWBLOCK_OFFSET(kds) - KDS_HEAD_LENGTH(ncols));
+		int32_t	blk = -1;
+		char   *page = nullptr;
+		size_t	lower = 0, upper = 0;
+		for (uint32_t r = 0; r < nrows; r++)
+		{
+			size_t hoff, t_len = heap_tuple_size(ncols, cols, r, &hoff);
+			size_t need = maxalign(t_len) + sizeof(cl_uint);
+			if (blk < 0 || upper - lower < need)
+			{
+				if (page)
+				{
+					*(cl_ushort *)(page + 12) = (cl_ushort)lower;
+					*(cl_ushort *)(page + 14) = (cl_ushort)upper;
+				}
+				blk++;
+				page = KERN_DATA_STORE_ROWBLOCK(kds, blk);
+				memset(page, 0, BLCKSZ);
+				*(cl_ushort *)(page + 16) = BLCKSZ;			/* pd_special */
+				*(cl_ushort *)(page + 18) = BLCKSZ | 4;		/* pagesize | layout version */
+				lower = PAGE_HEADER;
+				upper = BLCKSZ;
+				kern_blkitem *bitem = KERN_DATA_STORE_BLKITEM(kds, blk);
+				bitem->buffer = 0;							/* InvalidBuffer */
+				bitem->page = (hostptr_t)(uintptr_t)page;
+			}
+			upper -= maxalign(t_len);
+			uint32_t linenum = (uint32_t)((lower - PAGE_HEADER) / sizeof(cl_uint)) + 1;
+			heap_tuple_form(page + upper, ncols, cols, r, t_len, hoff, blk, (uint16_t)linenum);
+			cl_uint itemid = (cl_uint)upper | (LP_NORMAL << 15) | ((cl_uint)t_len << 17);
+			memcpy(page + lower, &itemid, sizeof(itemid));
+			lower += sizeof(cl_uint);
+			kern_rowitem *ritem = KERN_DATA_STORE_ROWITEM(kds, r);
+			ritem->blk_index = (cl_ushort)blk;
+			ritem->item_offset = (cl_ushort)linenum;
+		}
+		if (page)
+		{
+			*(cl_ushort *)(page + 12) = (cl_ushort)lower;
+			*(cl_ushort *)(page + 14) = (cl_ushort)upper;
+		}
+		return 0;
+	}
+	if (format == KDS_FORMAT_ROW_FLAT)
+	{
+		init_kds_head(kds, format, ncols, cols, nrows, 0, required);
+		size_t	tail = required;
+		for (uint32_t r = 0; r < nrows; r++)
+		{
+			size_t hoff, t_len = heap_tuple_size(ncols, cols, r, &hoff);
+			tail -= STROM_LONGALIGN(t_len);
+			heap_tuple_form(base + tail, ncols, cols, r, t_len, hoff, 0, (uint16_t)(r & 0xffff));
+			KERN_DATA_STORE_ROWITEM(kds, r)->htup_offset = (cl_uint)tail;
+		}
+		kds->nitems = nrows;
+		kds->usage = (cl_uint)(required - tail);
+		return 0;
+	}
+	if (format == KDS_FORMAT_TUPSLOT)
+	{
+		init_kds_head(kds, format, ncols, cols, nrows, 0, required);
+		for (uint32_t r = 0; r < nrows; r++)
+		{
+			Datum	   *values = KERN_DATA_STORE_VALUES(kds, r);
+			cl_char	   *isnull = KERN_DATA_STORE_ISNULL(kds, r);
+			memset(values, 0, KDS_TUPSLOT_STRIDE(ncols));
+			for (int i = 0; i < ncols; i++)
+			{
+				if (is_null(cols[i], r))
+					isnull[i] = 1;
+				else
+					memcpy(&values[i], (const char *)cols[i].values + (size_t)cols[i].attlen * r,
+						   cols[i].attlen);
+			}
+		}
+		kds->nitems = nrows;
+		return 0;
+	}
+	if (format == KDS_FORMAT_COLUMN)
+	{
+		std::vector<size_t> voff(ncols), noff(ncols);
+		column_layout(ncols, cols, nrows, &voff, &noff);
+		init_kds_head(kds, format, ncols, cols, nrows, 0, required);
+		kern_coldir *cd = KERN_DATA_STORE_COLDIR(kds);
+		memset(cd, 0, KDS_COLUMN_HEAD_LENGTH(ncols) - KDS_HEAD_LENGTH(ncols));
+		for (int i = 0; i < ncols; i++)
+		{
+			size_t	vbytes = (size_t)cols[i].attlen * nrows;
+			cd[i].values_off = (cl_uint)voff[i];
+			cd[i].nulls_off = (cl_uint)noff[i];
+			cd[i].extra_off = 0;
+			memcpy(base + voff[i], cols[i].values, vbytes);
+			memset(base + voff[i] + vbytes, 0,
+				   KDS_COLUMN_VALUES_LENGTH(cols[i].attlen, nrows) - vbytes);
+			if (noff[i])
+			{
+				cl_uint *nn = (cl_uint *)(base + noff[i]);
+				memset(nn, 0, KDS_COLUMN_NULLS_LENGTH(nrows));
+				for (uint32_t r = 0; r < nrows; r++)
+					if (!cols[i].isnull[r])
+						nn[r >> 5] |= (1u << (r & 31));
+				/* a NULL slot holds zero so that reads are deterministic */
+				for (uint32_t r = 0; r < nrows; r++)
+					if (cols[i].isnull[r])
+						memset(base + voff[i] + (size_t)cols[i].attlen * r, 0, cols[i].attlen);
+			}
+			column_minmax(cols[i], nrows, &cd[i]);
+		}
+		kds->nitems = nrows;
+		return 0;
+	}
+	return StromError_BadRequestMessage;
+}
+
+/* ---- host-side datum fetch -------------------------------------------- */
+namespace {
+
+const char *
+host_get_datum_tuple(const kern_colmeta *colmeta, const HeapTupleHeaderData *htup, uint32_t colidx)
+{
+	bool	hasnull = (htup->t_infomask & HEAP_HASNULL) != 0;
+	uint32_t natts = htup->t_infomask2 & HEAP_NATTS_MASK;
+	size_t	off = htup->t_hoff;
+
+	if (colidx >= natts)
+		return nullptr;
+	for (uint32_t i = 0; i < natts; i++)
+	{
+		if (hasnull && !(htup->t_bits[i >> 3] & (1 << (i & 7))))
+		{
+			if (i == colidx)
+				return nullptr;
+			continue;
+		}
+		if (colmeta[i].attlen <= 0)
+			return nullptr;			/* fixed-width only on this path */
+		off = STROM_TYPEALIGN(colmeta[i].attalign, off);
+		if (i == colidx)
+			return (const char *)htup + off;
+		off += colmeta[i].attlen;
+	}
+	return nullptr;
+}
+
+const char *
+host_get_datum(const kern_data_store *kds, uint32_t rowidx, uint32_t colidx)
+{
+	if (colidx >= kds->ncols || rowidx >= kds->nitems)
+		return nullptr;
+	switch (kds->format)
+	{
+		case KDS_FORMAT_ROW:
+			{
+				const kern_rowitem *ri = KERN_DATA_STORE_ROWITEM(kds, rowidx);
+				if (ri->blk_index >= kds->nblocks)
+					return nullptr;
+				const char *page = KERN_DATA_STORE_ROWBLOCK(kds, ri->blk_index);
+				cl_uint itemid;
+				memcpy(&itemid, page + PAGE_HEADER + sizeof(cl_uint) * (ri->item_offset - 1), 4);
+				return host_get_datum_tuple(kds->colmeta,
+											(const HeapTupleHeaderData *)(page + (itemid & 0x7fff)),
+											colidx);
+			}
+		case KDS_FORMAT_ROW_FLAT:
+			return host_get_datum_tuple(kds->colmeta,
+										(const HeapTupleHeaderData *)
+										((const char *)kds + KERN_DATA_STORE_ROWITEM(kds, rowidx)->htup_offset),
+										colidx);
+		case KDS_FORMAT_TUPSLOT:
+			if (KERN_DATA_STORE_ISNULL(kds, rowidx)[colidx])
+				return nullptr;
+			return (const char *)(KERN_DATA_STORE_VALUES(kds, rowidx) + colidx);
+		case KDS_FORMAT_COLUMN:
+			{
+				const kern_coldir *cd = KERN_DATA_STORE_COLDIR(kds) + colidx;
+				if (cd->nulls_off)
+				{
+					const cl_uint *nn = (const cl_uint *)((const char *)kds + cd->nulls_off);
+					if (!((nn[rowidx >> 5] >> (rowidx & 31)) & 1))
+						return nullptr;
+				}
+				return (const char *)kds + cd->values_off +
+					(size_t)kds->colmeta[colidx].attlen * rowidx;
+			}
+	}
+	return nullptr;
+}
+
+}	/* namespace */
+
+extern "C" int
+strom_kds_fetch(const kern_data_store *kds, uint32_t rowidx, uint32_t colidx, uint64_t *value)
+{
+	const char *p = host_get_datum(kds, rowidx, colidx);
+	if (!p)
+		return 1;
+	*value = 0;
+	memcpy(value, p, kds->colmeta[colidx].attlen);
+	return 0;
+}
+
+extern "C" size_t
+strom_kds_to_column(const kern_data_store *src, void *dst, size_t dstlen)
+{
+	uint32_t nrows = src->nitems;
+	int		ncols = (int)src->ncols;
+	std::vector<std::vector<char>> values(ncols);
+	std::vector<std::vector<uint8_t>> nulls(ncols);
+	std::vector<strom_column_input> cols(ncols);
+
+	for (int i = 0; i < ncols; i++)
+	{
+		int	attlen = src->colmeta[i].attlen;
+		if (!(attlen == 1 || attlen == 2 || attlen == 4 || attlen == 8))
+			return 0;
+		values[i].assign((size_t)attlen * nrows + 8, 0);
+		nulls[i].assign(nrows + 1, 0);
+	}
+	for (uint32_t r = 0; r < nrows; r++)
+		for (int i = 0; i < ncols; i++)
+		{
+			const char *p = host_get_datum(src, r, i);
+			if (!p)
+				nulls[i][r] = 1;
+			else
+				memcpy(&values[i][(size_t)src->colmeta[i].attlen * r], p, src->colmeta[i].attlen);
+		}
+	for (int i = 0; i < ncols; i++)
+	{
+		cols[i].type_oid = 0;
+		cols[i].attlen = src->colmeta[i].attlen;
+		cols[i].attalign = src->colmeta[i].attalign;
+		cols[i].attbyval = src->colmeta[i].attbyval;
+		cols[i].values = values[i].data();
+		cols[i].isnull = nulls[i].data();
+	}
+	size_t	required = strom_kds_required_length(KDS_FORMAT_COLUMN, ncols, cols.data(), nrows);
+	if (!dst)
+		return required;
+	if (strom_kds_build(KDS_FORMAT_COLUMN, ncols, cols.data(), nrows, dst, dstlen) != 0)
+		return 0;
+	return required;
+}

@@ -1,0 +1,347 @@
+/*
+ * strom_gpuscan.h -- GpuScan kernels (HIP, gfx950)
+ *
+ * Role in the reference: opencl_gpuscan.h:98-177 (gpuscan_qual +
+ * gpuscan_writeback_row_error).  Per row i of the chunk:
+ *     errcode = Success; rc = gpuscan_qual_eval(&errcode, ...);
+ *     STROM_SET_ERROR(&errcode, rc is TRUE ? Success : RowFiltered);
+ *     Success    -> results[] gets  +(i+1)
+ *     CpuReCheck -> results[] gets  -(i+1)   (host re-evaluates the row)
+ *     significant-> chunk errcode, first one wins
+ * and kresults->nitems counts the entries written.  The reference leaves
+ * the order of results[] undefined across work-groups; so does this.
+ *
+ * What is different is how a chunk is walked.  The generated code supplies
+ *     STROM_KVAR_LIST(X)    X(attno, colidx, NAME)  one per referenced Var
+ *     STROM_KPARAM_LIST(X)  X(index, NAME)          one per Const/Param
+ *     gpuscan_qual_eval(errcode, KP, KV)
+ * and this file supplies two kernels around it:
+ *
+ *   gpuscan_qual_column  KDS_FORMAT_COLUMN, no row map.  Persistent blocks
+ *       walk tiles of BLOCK*4*QUADS rows; each thread fetches its quads with
+ *       16-byte vector loads straight from the column arrays (no LDS on the
+ *       read side: every byte is used exactly once), evaluates 4*QUADS rows
+ *       in registers, and the survivors are compacted in row order with
+ *       ballot+mbcnt (no LDS scan) into an LDS stage of STAGE entries.  The
+ *       stage is flushed with one global atomic per flush -- a few thousand
+ *       per 1e8-row chunk instead of one per work-group per 256 rows --
+ *       and the flush itself is a contiguous coalesced store.
+ *
+ *   gpuscan_qual_generic  any format, optional kern_row_map.  Same
+ *       compaction, rows fetched one datum at a time through kern_get_datum
+ *       (this is the heap-tuple walk the reference does for every row).
+ */
+#ifndef STROM_GPUSCAN_DEVICE_H
+#define STROM_GPUSCAN_DEVICE_H
+
+#ifndef GPUSCAN_BLOCK
+#define GPUSCAN_BLOCK		256
+#endif
+#ifndef GPUSCAN_QUADS
+#define GPUSCAN_QUADS		2			/* 8 rows per thread and tile */
+#endif
+#ifndef GPUSCAN_STAGE
+#define GPUSCAN_STAGE		8192		/* LDS entries (32 KB) */
+#endif
+#define GPUSCAN_NWAVES		(GPUSCAN_BLOCK / STROM_WAVE)
+#define GPUSCAN_TILE_ROWS	(GPUSCAN_BLOCK * 4 * GPUSCAN_QUADS)
+
+/* ---- what the generated code declares -------------------------------- */
+struct strom_kparams {
+#define X(idx,NAME)	pg_##NAME##_t KPARAM_##idx;
+	STROM_KPARAM_LIST(X)
+#undef X
+	int __dummy;
+};
+struct strom_kvars {
+#define X(attno,colidx,NAME)	pg_##NAME##_t KVAR_##attno;
+	STROM_KVAR_LIST(X)
+#undef X
+	int __dummy;
+};
+
+STROM_DEVICE pg_bool_t
+gpuscan_qual_eval(cl_int *errcode,
+				  const strom_kparams &KP,
+				  const strom_kvars &KV);
+
+STROM_DEVICE void
+gpuscan_load_kparams(strom_kparams &KP, const kern_parambuf *kparams, cl_int *errcode)
+{
+#define X(idx,NAME)	KP.KPARAM_##idx = pg_##NAME##_param(kparams, errcode, idx);
+	STROM_KPARAM_LIST(X)
+#undef X
+	KP.__dummy = 0;
+}
+
+/* row status -> +1 pass, -1 recheck, 0 drop; significant errors accumulate */
+STROM_DEVICE int
+gpuscan_row_status(pg_bool_t rc, cl_int errcode, cl_int *chunk_error)
+{
+	STROM_SET_ERROR(&errcode, (!rc.isnull && rc.value != 0)
+					? StromError_Success : StromError_RowFiltered);
+	if (errcode == StromError_Success)
+		return 1;
+	if (errcode == StromError_CpuReCheck)
+		return -1;
+	if (StromErrorIsSignificant(errcode))
+		STROM_SET_ERROR(chunk_error, errcode);
+	return 0;
+}
+
+/* ---- LDS stage shared by both kernels ---------------------------------- */
+struct gpuscan_stage {
+	cl_int		entries[GPUSCAN_STAGE];
+	cl_uint		wave_total[GPUSCAN_QUADS][GPUSCAN_NWAVES];
+	cl_uint		flush_base;
+};
+
+STROM_DEVICE void
+gpuscan_stage_flush(gpuscan_stage &stage, kern_resultbuf *kresults, cl_uint fill)
+{
+	/* caller guarantees a barrier since the last write into the stage */
+	if (fill == 0)
+		return;
+	if (threadIdx.x == 0)
+		stage.flush_base = atomicAdd(&kresults->nitems, fill);
+	__syncthreads();
+	cl_uint		base = stage.flush_base;
+	cl_int	   *dest = kresults->results + base;
+	for (cl_uint i = threadIdx.x; i < fill; i += GPUSCAN_BLOCK)
+		dest[i] = stage.entries[i];
+	__syncthreads();
+}
+
+/*
+ * Compaction of one tile.  st[k][j] is the status of row
+ * (tile_base + (k*BLOCK + tid)*4 + j).  Entries land in the stage in row
+ * order: (k, wave, lane, j).  Returns the number of entries appended; the
+ * value is identical in every thread.
+ */
+STROM_DEVICE cl_uint
+gpuscan_stage_append(gpuscan_stage &stage, cl_uint fill,
+					 cl_uint tile_base, const int (&st)[GPUSCAN_QUADS][4])
+{
+	cl_uint		lane = threadIdx.x & (STROM_WAVE - 1);
+	cl_uint		wave = threadIdx.x / STROM_WAVE;
+	cl_uint		my_prefix[GPUSCAN_QUADS];
+
+#pragma unroll
+	for (int k = 0; k < GPUSCAN_QUADS; k++)
+	{
+		cl_uint	prefix = 0, total = 0;
+#pragma unroll
+		for (int j = 0; j < 4; j++)
+		{
+			strom_lanemask_t m = __ballot(st[k][j] != 0);
+			prefix += strom_mbcnt(m);
+			total += __popcll(m);
+		}
+		my_prefix[k] = prefix;
+		if (lane == 0)
+			stage.wave_total[k][wave] = total;
+	}
+	__syncthreads();
+
+	cl_uint		appended = 0;
+#pragma unroll
+	for (int k = 0; k < GPUSCAN_QUADS; k++)
+	{
+		cl_uint	before = 0, all = 0;
+#pragma unroll
+		for (int w = 0; w < GPUSCAN_NWAVES; w++)
+		{
+			cl_uint	t = stage.wave_total[k][w];
+			before += (w < (int)wave ? t : 0);
+			all += t;
+		}
+		cl_uint	pos = fill + appended + before + my_prefix[k];
+		cl_uint	row0 = tile_base + (k * GPUSCAN_BLOCK + threadIdx.x) * 4;
+#pragma unroll
+		for (int j = 0; j < 4; j++)
+		{
+			if (st[k][j] != 0)
+			{
+				cl_int	rowid = (cl_int)(row0 + j + 1);
+				stage.entries[pos++] = (st[k][j] > 0 ? rowid : -rowid);
+			}
+		}
+		appended += all;
+	}
+	/* the next append rewrites wave_total[]; entries[] are read by flush */
+	__syncthreads();
+	return appended;
+}
+
+/* ====================================================================== *
+ * COLUMN format, streaming
+ * ====================================================================== */
+struct gpuscan_column_tile {
+#define X(attno,colidx,NAME)											\
+	pg_##NAME##_base_t	v_##attno[GPUSCAN_QUADS][4];						\
+	cl_uint				nn_##attno[GPUSCAN_QUADS];
+	STROM_KVAR_LIST(X)
+#undef X
+	int __dummy;
+};
+
+extern "C" __global__ void
+__launch_bounds__(GPUSCAN_BLOCK)
+gpuscan_qual_column(kern_gpuscan *kgpuscan, const kern_data_store *kds)
+{
+	__shared__ gpuscan_stage stage;
+	const kern_parambuf *kparams = KERN_GPUSCAN_PARAMBUF(kgpuscan);
+	kern_resultbuf *kresults = KERN_GPUSCAN_RESULTBUF(kgpuscan);
+	const kern_coldir *coldir = KERN_DATA_STORE_COLDIR(kds);
+	cl_uint		nitems = kds->nitems;
+	cl_uint		ntiles = (nitems + GPUSCAN_TILE_ROWS - 1) / GPUSCAN_TILE_ROWS;
+	cl_int		chunk_error = StromError_Success;
+	cl_int		param_error = StromError_Success;
+	cl_uint		fill = 0;
+	strom_kparams KP;
+
+	gpuscan_load_kparams(KP, kparams, &param_error);
+
+	/* column base pointers, hoisted */
+#define X(attno,colidx,NAME)													\
+	const char *col_##attno = (const char *)kds + coldir[colidx].values_off;	\
+	const cl_uint *nul_##attno = (coldir[colidx].nulls_off != 0					\
+		? (const cl_uint *)((const char *)kds + coldir[colidx].nulls_off) : NULL);
+	STROM_KVAR_LIST(X)
+#undef X
+
+	for (cl_uint tile = blockIdx.x; tile < ntiles; tile += gridDim.x)
+	{
+		cl_uint		tile_base = tile * GPUSCAN_TILE_ROWS;
+		gpuscan_column_tile T;
+		int			st[GPUSCAN_QUADS][4];
+
+		/* issue every load of the tile before the first use */
+#pragma unroll
+		for (int k = 0; k < GPUSCAN_QUADS; k++)
+		{
+			cl_uint	row0 = tile_base + (k * GPUSCAN_BLOCK + threadIdx.x) * 4;
+#define X(attno,colidx,NAME)													\
+			strom_column_load_quad<pg_##NAME##_base_t>(col_##attno, nul_##attno,	\
+													   row0, nitems,				\
+													   T.v_##attno[k], T.nn_##attno[k]);
+			STROM_KVAR_LIST(X)
+#undef X
+		}
+		if (fill + GPUSCAN_TILE_ROWS > GPUSCAN_STAGE)
+		{
+			gpuscan_stage_flush(stage, kresults, fill);
+			fill = 0;
+		}
+#pragma unroll
+		for (int k = 0; k < GPUSCAN_QUADS; k++)
+		{
+			cl_uint	row0 = tile_base + (k * GPUSCAN_BLOCK + threadIdx.x) * 4;
+#pragma unroll
+			for (int j = 0; j < 4; j++)
+			{
+				strom_kvars	KV;
+				cl_int		errcode = param_error;
+#define X(attno,colidx,NAME)													\
+				KV.KVAR_##attno = pg_##NAME##_make(T.v_##attno[k][j],				\
+												   !((T.nn_##attno[k] >> j) & 1));
+				STROM_KVAR_LIST(X)
+#undef X
+				KV.__dummy = 0;
+				pg_bool_t rc = gpuscan_qual_eval(&errcode, KP, KV);
+				st[k][j] = (row0 + j < nitems
+							? gpuscan_row_status(rc, errcode, &chunk_error) : 0);
+			}
+		}
+		fill += gpuscan_stage_append(stage, fill, tile_base, st);
+	}
+	gpuscan_stage_flush(stage, kresults, fill);
+	kern_writeback_error_status(&kresults->errcode, chunk_error);
+}
+
+/* ====================================================================== *
+ * any format, optional row map: one datum at a time
+ * ====================================================================== */
+extern "C" __global__ void
+__launch_bounds__(GPUSCAN_BLOCK)
+gpuscan_qual_generic(kern_gpuscan *kgpuscan,
+					 const kern_data_store *kds,
+					 const kern_data_store *ktoast,
+					 const kern_row_map *krowmap)
+{
+	__shared__ gpuscan_stage stage;
+	const kern_parambuf *kparams = KERN_GPUSCAN_PARAMBUF(kgpuscan);
+	kern_resultbuf *kresults = KERN_GPUSCAN_RESULTBUF(kgpuscan);
+	bool		use_map = (krowmap != NULL && krowmap->nvalids >= 0);
+	cl_uint		nrows = (use_map ? (cl_uint)krowmap->nvalids : kds->nitems);
+	cl_uint		ntiles = (nrows + GPUSCAN_TILE_ROWS - 1) / GPUSCAN_TILE_ROWS;
+	cl_int		chunk_error = StromError_Success;
+	cl_int		param_error = StromError_Success;
+	cl_uint		fill = 0;
+	strom_kparams KP;
+
+	gpuscan_load_kparams(KP, kparams, &param_error);
+
+	for (cl_uint tile = blockIdx.x; tile < ntiles; tile += gridDim.x)
+	{
+		cl_uint		tile_base = tile * GPUSCAN_TILE_ROWS;
+		int			st[GPUSCAN_QUADS][4];
+
+		if (fill + GPUSCAN_TILE_ROWS > GPUSCAN_STAGE)
+		{
+			gpuscan_stage_flush(stage, kresults, fill);
+			fill = 0;
+		}
+#pragma unroll
+		for (int k = 0; k < GPUSCAN_QUADS; k++)
+		{
+			cl_uint	row0 = tile_base + (k * GPUSCAN_BLOCK + threadIdx.x) * 4;
+#pragma unroll
+			for (int j = 0; j < 4; j++)
+			{
+				cl_uint		r = row0 + j;
+
+				st[k][j] = 0;
+				if (r < nrows)
+				{
+					cl_uint		kds_index = (use_map ? (cl_uint)krowmap->rindex[r] : r);
+					strom_kvars	KV;
+					cl_int		errcode = param_error;
+#define X(attno,colidx,NAME)													\
+					KV.KVAR_##attno = pg_##NAME##_vref(kds, ktoast, &errcode,		\
+													   colidx, kds_index);
+					STROM_KVAR_LIST(X)
+#undef X
+					KV.__dummy = 0;
+					pg_bool_t rc = gpuscan_qual_eval(&errcode, KP, KV);
+					st[k][j] = gpuscan_row_status(rc, errcode, &chunk_error);
+				}
+			}
+		}
+		/*
+		 * with a row map the reported id is the position in the map's
+		 * input order translated back to the chunk's row: patch below
+		 */
+		if (!use_map)
+			fill += gpuscan_stage_append(stage, fill, tile_base, st);
+		else
+		{
+			cl_uint	before = fill;
+			cl_uint	n = gpuscan_stage_append(stage, fill, tile_base, st);
+			/* translate map positions -> chunk rows, in place */
+			for (cl_uint i = before + threadIdx.x; i < before + n; i += GPUSCAN_BLOCK)
+			{
+				cl_int	e = stage.entries[i];
+				cl_int	pos = (e > 0 ? e : -e) - 1;
+				cl_int	rowid = krowmap->rindex[pos] + 1;
+				stage.entries[i] = (e > 0 ? rowid : -rowid);
+			}
+			__syncthreads();
+			fill += n;
+		}
+	}
+	gpuscan_stage_flush(stage, kresults, fill);
+	kern_writeback_error_status(&kresults->errcode, chunk_error);
+}
+
+#endif	/* STROM_GPUSCAN_DEVICE_H */

@@ -1,0 +1,258 @@
+/*
+ * gpuscan.cpp -- host side of one GpuScan request
+ *
+ * Role in the reference: clserv_process_gpuscan (gpuscan.c:1895-2182) and
+ * clserv_respond_gpuscan (1760-1888): look the program up (park if the
+ * build is in flight), pick a device, send {kern_parambuf, kern_resultbuf
+ * head} and the chunk, run the qual kernel, read the result buffer back,
+ * fill errcode + perfmon, reply.
+ *
+ * Differences that matter for speed: buffers come from a per-device pool
+ * instead of clCreateBuffer/clReleaseMemObject per chunk; a chunk can
+ * already be resident (strom_dstore); only results[0..nitems) travels
+ * back, not nrooms entries.
+ */
+#include <cstring>
+#include <cstdio>
+
+#include "runtime.h"
+
+using namespace strom;
+
+namespace {
+
+struct gpuscan_request {
+	strom_devprog_key	key;
+	kern_gpuscan	   *kgpuscan;		/* host image */
+	const kern_data_store *kds;			/* host chunk or NULL */
+	strom_dstore	   *kds_dev;
+	const kern_row_map *krowmap;
+	uint32_t			flags;
+	uint32_t			nrows;			/* rows the kernel walks */
+	uint32_t			format;
+};
+
+#define REQ_CHECK(call, what)												\
+	do {																	\
+		hipError_t __rc = (call);											\
+		if (__rc != hipSuccess)												\
+		{																	\
+			task_fail(task, hip_errcode(__rc, what));						\
+			return;															\
+		}																	\
+	} while (0)
+
+void
+gpuscan_launch(strom_task_impl *task, Program *prog, gpuscan_request req)
+{
+	Device	   *dev = task->dev;
+	kern_gpuscan *kgs = req.kgpuscan;
+	kern_resultbuf *kres_host = KERN_GPUSCAN_RESULTBUF(kgs);
+	size_t		head_len = KERN_GPUSCAN_DMASEND_LENGTH(kgs);
+	size_t		total_len = KERN_GPUSCAN_LENGTH(kgs);
+	size_t		res_offset = KERN_GPUSCAN_PARAMBUF_LENGTH(kgs);
+	int			errcode = 0;
+
+	(void)hipSetDevice(dev->hip_id);
+	if (prog->state != STROM_DEVPROG_READY)
+	{
+		task_fail(task, StromError_ProgramBuildFailure);
+		return;
+	}
+	task->pfm.time_kern_build = (cl_ulong)prog->build_usec;
+	task->stream = dev->pick_stream();
+
+	bool		use_column = (req.format == KDS_FORMAT_COLUMN && req.krowmap == nullptr);
+	hipFunction_t fn = prog->get_function(dev, use_column ? "gpuscan_qual_column"
+										  : "gpuscan_qual_generic", &errcode);
+	if (!fn)
+	{
+		task_fail(task, errcode);
+		return;
+	}
+	char	   *d_kgs = (char *)dev->pool.alloc(total_len);
+	if (!d_kgs)
+	{
+		task_fail(task, StromError_OutOfMemory);
+		return;
+	}
+	task->main_devptr = d_kgs;
+	task->keep_main = (!task->detached && (req.flags & STROM_RESULTS_ON_DEVICE) != 0);
+
+	task_event(task);									/* ev[0] */
+	REQ_CHECK(hipMemcpyAsync(d_kgs, kgs, head_len, hipMemcpyHostToDevice, task->stream),
+			  "send kern_gpuscan");
+	task->pfm.num_dma_send++;
+	task->pfm.bytes_dma_send += head_len;
+
+	const void *d_kds;
+	if (req.kds_dev)
+		d_kds = req.kds_dev->devptr;
+	else
+	{
+		size_t	kds_len = req.kds->length;
+		if (req.kds->format == KDS_FORMAT_ROW)
+			kds_len = KERN_DATA_STORE_ROWBLOCK_OFFSET(req.kds) +
+				(size_t)BLCKSZ * req.kds->nblocks;
+		void   *p = dev->pool.alloc(kds_len);
+		if (!p)
+		{
+			task_fail(task, StromError_OutOfMemory);
+			return;
+		}
+		task->devbufs.push_back(p);
+		REQ_CHECK(hipMemcpyAsync(p, req.kds, kds_len, hipMemcpyHostToDevice, task->stream),
+				  "send kern_data_store");
+		task->pfm.num_dma_send++;
+		task->pfm.bytes_dma_send += kds_len;
+		d_kds = p;
+	}
+	const void *d_rowmap = nullptr;
+	if (req.krowmap && req.krowmap->nvalids >= 0)
+	{
+		size_t	len = offsetof(kern_row_map, rindex) + sizeof(cl_int) * (size_t)req.krowmap->nvalids;
+		void   *p = dev->pool.alloc(len);
+		if (!p)
+		{
+			task_fail(task, StromError_OutOfMemory);
+			return;
+		}
+		task->devbufs.push_back(p);
+		REQ_CHECK(hipMemcpyAsync(p, req.krowmap, len, hipMemcpyHostToDevice, task->stream),
+				  "send kern_row_map");
+		task->pfm.num_dma_send++;
+		task->pfm.bytes_dma_send += len;
+		d_rowmap = p;
+	}
+	task_event(task);									/* ev[1] */
+
+	/*
+	 * grid: enough persistent work-groups to fill every CU at the
+	 * occupancy the kernel's LDS stage allows, never more than tiles
+	 * (clserv_compute_workgroup_size's job, opencl_devinfo.c:1126-1231)
+	 */
+	{
+		int		block = 256;
+		if (const char *v = getenv("STROM_GPUSCAN_BLOCK"))
+			block = atoi(v);
+		int		quads = 2;
+		if (const char *v = getenv("STROM_GPUSCAN_QUADS"))
+			quads = atoi(v);
+		size_t	tile_rows = (size_t)block * 4 * quads;
+		size_t	ntiles = (req.nrows + tile_rows - 1) / tile_rows;
+		int		per_cu = 0;
+		if (hipModuleOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, block, 0) != hipSuccess
+			|| per_cu < 1)
+			per_cu = 1;
+		if (const char *v = getenv("STROM_GPUSCAN_BLOCKS_PER_CU"))
+			per_cu = std::max(1, atoi(v));
+		size_t	grid = (size_t)dev->prop.multiProcessorCount * per_cu;
+		if (grid > ntiles)
+			grid = ntiles;
+		if (grid < 1)
+			grid = 1;
+		void   *a_kgs = d_kgs;
+		const void *a_kds = d_kds;
+		const void *a_toast = nullptr;
+		const void *a_map = d_rowmap;
+		void   *args_col[] = { &a_kgs, &a_kds };
+		void   *args_gen[] = { &a_kgs, &a_kds, &a_toast, &a_map };
+		REQ_CHECK(hipModuleLaunchKernel(fn, (unsigned)grid, 1, 1, block, 1, 1, 0, task->stream,
+										use_column ? args_col : args_gen, nullptr),
+				  "launch gpuscan kernel");
+		task->pfm.num_kern_exec++;
+	}
+	task_event(task);									/* ev[2] */
+	/* result head first; results[0..nitems) follow once nitems is known */
+	REQ_CHECK(hipMemcpyAsync(kres_host, d_kgs + res_offset, offsetof(kern_resultbuf, results),
+							 hipMemcpyDeviceToHost, task->stream),
+			  "recv kern_resultbuf head");
+	task->pfm.num_dma_recv++;
+	task->pfm.bytes_dma_recv += offsetof(kern_resultbuf, results);
+	task_event(task);									/* ev[3] */
+
+	bool	results_on_device = (req.flags & STROM_RESULTS_ON_DEVICE) != 0;
+	task->finish = [kres_host, d_kgs, res_offset, results_on_device](strom_task_impl *t)
+	{
+		if (StromErrorIsSignificant(kres_host->errcode))
+			t->errcode = kres_host->errcode;
+		if (results_on_device || kres_host->nitems == 0)
+			return;
+		size_t	len = sizeof(cl_int) * (size_t)kres_host->nitems;
+		auto	t0 = std::chrono::steady_clock::now();
+		hipError_t rc = hipMemcpyAsync(kres_host->results,
+									   d_kgs + res_offset + offsetof(kern_resultbuf, results),
+									   len, hipMemcpyDeviceToHost, t->stream);
+		if (rc == hipSuccess)
+			rc = hipStreamSynchronize(t->stream);
+		if (rc != hipSuccess)
+			t->errcode = hip_errcode(rc, "recv results[]");
+		t->pfm.num_dma_recv++;
+		t->pfm.bytes_dma_recv += len;
+		t->pfm.time_dma_recv += (cl_ulong)std::chrono::duration<double, std::micro>
+			(std::chrono::steady_clock::now() - t0).count();
+	};
+	task_enqueue(task);
+}
+
+}	/* namespace */
+
+extern "C" strom_task *
+strom_submit_gpuscan(strom_devprog_key key,
+					 kern_gpuscan *kgpuscan,
+					 const kern_data_store *kds,
+					 strom_dstore *kds_dev,
+					 const kern_row_map *krowmap,
+					 uint32_t flags,
+					 strom_done_cb done, void *arg,
+					 int *p_errcode)
+{
+	int		dummy;
+	if (!p_errcode)
+		p_errcode = &dummy;
+	*p_errcode = 0;
+	Program *prog = lookup_program(key);
+	if (!prog || !kgpuscan || (!kds) == (!kds_dev))
+	{
+		*p_errcode = StromError_BadRequestMessage;
+		return nullptr;
+	}
+	int		dindex = kds_dev ? kds_dev->dindex : strom_device_schedule();
+	Device *dev = get_device(dindex);
+	if (!dev)
+	{
+		*p_errcode = StromError_ServerNotReady;
+		return nullptr;
+	}
+	gpuscan_request req;
+	req.key = key;
+	req.kgpuscan = kgpuscan;
+	req.kds = kds;
+	req.kds_dev = kds_dev;
+	req.krowmap = (krowmap && krowmap->nvalids >= 0) ? krowmap : nullptr;
+	req.flags = flags;
+	/*
+	 * the kernel needs nitems / format to size its grid; a resident chunk
+	 * keeps a host snapshot of its head
+	 */
+	kern_data_store head;
+	if (kds)
+		memcpy(&head, kds, offsetof(kern_data_store, colmeta));
+	else
+		head = kds_dev->head;
+	req.format = head.format;
+	req.nrows = req.krowmap ? (uint32_t)req.krowmap->nvalids : head.nitems;
+	kern_resultbuf *kres = KERN_GPUSCAN_RESULTBUF(kgpuscan);
+	if (kres->nrels != 1 || kres->nrooms < req.nrows)
+	{
+		*p_errcode = StromError_BadRequestMessage;
+		return nullptr;
+	}
+	/* "kernel code assumes all the fields shall be initialized to zero" */
+	kres->nitems = 0;
+	kres->errcode = StromError_Success;
+
+	strom_task_impl *task = task_create(dev, done, arg);
+	program_run_or_park(prog, [task, prog, req]() { gpuscan_launch(task, prog, req); });
+	return task;
+}

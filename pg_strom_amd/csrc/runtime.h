@@ -1,0 +1,151 @@
+/*
+ * runtime.h -- internals of the HIP device runtime (libstrom_hip.so)
+ *
+ * Stands where opencl_serv.c / opencl_devprog.c / opencl_devinfo.c /
+ * opencl_entry.c and the clserv_* halves of the three operators stand in
+ * the reference.
+ */
+#ifndef STROM_RUNTIME_H
+#define STROM_RUNTIME_H
+
+#include <hip/hip_runtime.h>
+#include <atomic>
+#include <condition_variable>
+#include <deque>
+#include <functional>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "strom_hip.h"
+
+namespace strom {
+
+struct Device;
+
+/* ---- pooled device memory: no hipMalloc/hipFree per chunk (the reference
+ * creates and releases 2-6 cl_mem objects per request) ------------------ */
+class BufferPool {
+public:
+	void   *alloc(size_t nbytes);
+	void	release(void *ptr);
+	void	drain();
+	int		hip_id = 0;
+private:
+	std::mutex						lock_;
+	std::map<size_t, std::vector<void *>>	free_;	/* by size class */
+	std::map<void *, size_t>		live_;
+	static size_t size_class(size_t nbytes);
+};
+
+struct Program {
+	strom_devprog_key	key = 0;
+	std::string			source;
+	int32_t				extra_flags = 0;
+	std::mutex			lock;
+	std::condition_variable cond;
+	int					state = STROM_DEVPROG_PENDING;
+	int					refcnt = 1;
+	std::string			errmsg;
+	std::vector<char>	code;			/* gfx950 code object */
+	double				build_usec = 0;
+	std::map<int, hipModule_t> modules;	/* per device index */
+	std::vector<std::function<void()>> parked;	/* requests waiting for the build */
+
+	hipFunction_t	get_function(Device *dev, const char *name, int *p_errcode);
+};
+
+struct strom_task_impl;
+
+struct Device {
+	int					dindex = 0;
+	int					hip_id = 0;
+	hipDeviceProp_t		prop;
+	std::vector<hipStream_t> streams;
+	std::atomic<unsigned> next_stream{0};
+	BufferPool			pool;
+	/* completion side: one thread per device plays the role of the OpenCL
+	 * runtime's callback thread (clSetEventCallback -> clserv_respond_*) */
+	std::thread			completer;
+	std::mutex			cq_lock;
+	std::condition_variable cq_cond;
+	std::deque<strom_task_impl *> cq;
+	bool				shutting_down = false;
+	size_t				inflight = 0;
+
+	hipStream_t pick_stream() { return streams[next_stream++ % streams.size()]; }
+};
+
+}	/* namespace strom */
+
+struct strom_dstore {
+	void	   *devptr;
+	size_t		length;
+	int			dindex;
+	bool		owned;
+	kern_data_store head;		/* host snapshot of the fixed head (no colmeta) */
+};
+
+struct strom_task {
+	/* the public handle is the impl itself */
+};
+
+namespace strom {
+
+struct strom_task_impl : public strom_task {
+	Device	   *dev = nullptr;
+	hipStream_t	stream = nullptr;
+	int			errcode = 0;
+	strom_perfmon pfm;
+	strom_done_cb done = nullptr;
+	void	   *done_arg = nullptr;
+	/* events: [0] start, [1] after send, [2] after main kernel(s),
+	 * [3] after recv; extra pairs for prep/proj kernels */
+	hipEvent_t	ev[8] = {};
+	int			nev = 0;
+	bool		has_ev_prep = false, has_ev_proj = false;
+	/* device buffers to hand back to the pool at completion */
+	std::vector<void *> devbufs;
+	void	   *main_devptr = nullptr;	/* kern_gpuscan / kern_hashjoin image */
+	bool		keep_main = false;		/* released by strom_task_wait */
+	/* operator-specific second half, runs on the completer thread after the
+	 * first event fired; may issue further copies on 'stream' and must
+	 * leave the stream idle when it returns */
+	std::function<void(strom_task_impl *)> finish;
+	/* waiter side */
+	std::mutex	lock;
+	std::condition_variable cond;
+	bool		completed = false;
+	bool		detached = false;		/* callback style: free at completion */
+	std::chrono::steady_clock::time_point t_enqueue;
+};
+
+/* runtime.cpp */
+Device	   *get_device(int dindex);
+int			num_devices();
+Program	   *lookup_program(strom_devprog_key key);
+bool		perfmon_enabled();
+strom_task_impl *task_create(Device *dev, strom_done_cb done, void *arg);
+void		task_enqueue(strom_task_impl *task);
+void		task_fail(strom_task_impl *task, int errcode);
+hipEvent_t	task_event(strom_task_impl *task);
+int			hip_errcode(hipError_t rc, const char *what);
+/* run 'fn' now if the program is ready, park it if the build is in
+ * flight; returns the program state */
+int			program_run_or_park(Program *prog, std::function<void()> fn);
+
+#define STROM_HIP_CHECK(call, task)										\
+	do {																\
+		hipError_t __rc = (call);										\
+		if (__rc != hipSuccess)											\
+		{																\
+			(task)->errcode = hip_errcode(__rc, #call);					\
+			goto hip_error;												\
+		}																\
+	} while (0)
+
+}	/* namespace strom */
+#endif

@@ -1,0 +1,161 @@
+"""
+Host-side helpers around the chunk formats of include/strom_kds.h.
+
+These wrap the C builders of libstrom_hip.so (strom_datastore.h) for numpy
+callers and decode the wire structs the operators exchange
+(kern_data_store head, kern_gpuscan = {kern_parambuf, kern_resultbuf}).
+Reference: datastore.c:312-529 (builders), opencl_common.h:335-486 (structs),
+opencl_gpuscan.h:63-90 (kern_gpuscan packing).
+"""
+import ctypes
+
+import numpy as np
+
+from ._lib import lib, strom_column_input
+
+KDS_FORMAT_ROW = 1
+KDS_FORMAT_ROW_FLAT = 2
+KDS_FORMAT_TUPSLOT = 3
+KDS_FORMAT_COLUMN = 4
+FORMAT_NAMES = {"row": 1, "row_flat": 2, "tupslot": 3, "column": 4}
+
+STROMALIGN_LEN = 16
+KDS_HEAD_FIXED = 48            # offsetof(kern_data_store, colmeta)
+RESULTBUF_HEAD = 20            # offsetof(kern_resultbuf, results)
+
+# name -> (pg_type oid, attlen, numpy dtype)
+SQL_TYPES = {
+    "bool": (16, 1, np.int8),
+    "int2": (21, 2, np.int16),
+    "int4": (23, 4, np.int32),
+    "int8": (20, 8, np.int64),
+    "float4": (700, 4, np.float32),
+    "float8": (701, 8, np.float64),
+    "date": (1082, 4, np.int32),
+    "time": (1083, 8, np.int64),
+    "timestamp": (1114, 8, np.int64),
+    "numeric": (1700, 8, np.uint64),   # 64-bit device form
+    "char1": (1042, 1, np.int8),
+}
+
+
+def stromalign(n):
+    return (n + STROMALIGN_LEN - 1) & ~(STROMALIGN_LEN - 1)
+
+
+def aligned_buffer(nbytes, align=256):
+    """uint8 array of nbytes whose data pointer is 'align'-aligned"""
+    raw = np.empty(nbytes + align, dtype=np.uint8)
+    off = (-raw.ctypes.data) % align
+    buf = raw[off:off + nbytes]
+    assert buf.ctypes.data % align == 0
+    return buf
+
+
+class Column(object):
+    """one input column: SQL type name, values, optional null mask"""
+
+    def __init__(self, sqltype, values, isnull=None):
+        oid, attlen, dtype = SQL_TYPES[sqltype]
+        self.sqltype = sqltype
+        self.type_oid = oid
+        self.attlen = attlen
+        self.values = np.ascontiguousarray(values, dtype=dtype)
+        self.isnull = None
+        if isnull is not None:
+            self.isnull = np.ascontiguousarray(isnull, dtype=np.uint8)
+            assert self.isnull.shape == self.values.shape
+
+    def __len__(self):
+        return len(self.values)
+
+
+def _column_inputs(columns):
+    arr = (strom_column_input * len(columns))()
+    for i, c in enumerate(columns):
+        arr[i].type_oid = c.type_oid
+        arr[i].attlen = c.attlen
+        arr[i].attalign = c.attlen
+        arr[i].attbyval = 1
+        arr[i].values = c.values.ctypes.data
+        arr[i].isnull = c.isnull.ctypes.data if c.isnull is not None else None
+    return arr
+
+
+def build_kds(fmt, columns):
+    """lay 'columns' out as one chunk of format 'fmt'; returns uint8 array"""
+    if isinstance(fmt, str):
+        fmt = FORMAT_NAMES[fmt]
+    nrows = len(columns[0])
+    assert all(len(c) == nrows for c in columns)
+    inputs = _column_inputs(columns)
+    need = lib.strom_kds_required_length(fmt, len(columns), inputs, nrows)
+    if need == 0:
+        raise ValueError("strom_kds_required_length: bad column description")
+    buf = aligned_buffer(need)
+    rc = lib.strom_kds_build(fmt, len(columns), inputs, nrows, buf.ctypes.data, need)
+    if rc != 0:
+        raise RuntimeError("strom_kds_build failed: %s" % lib.strom_strerror(rc).decode())
+    return buf
+
+
+def kds_to_column(kds_buf):
+    need = lib.strom_kds_to_column(kds_buf.ctypes.data, None, 0)
+    if need == 0:
+        raise ValueError("chunk cannot be converted to COLUMN format")
+    out = aligned_buffer(need)
+    got = lib.strom_kds_to_column(kds_buf.ctypes.data, out.ctypes.data, need)
+    assert got == need
+    return out
+
+
+class KdsHead(object):
+    """decoded fixed head of a kern_data_store image"""
+
+    def __init__(self, buf):
+        u32 = np.frombuffer(buf[:KDS_HEAD_FIXED].tobytes(), dtype=np.uint32)
+        self.length = int(u32[2])
+        self.usage = int(u32[3])
+        self.ncols = int(u32[4])
+        self.nitems = int(u32[5])
+        self.nrooms = int(u32[6])
+        self.nblocks = int(u32[7])
+        self.maxblocks = int(u32[8])
+        self.format = int(np.frombuffer(buf[36:37].tobytes(), dtype=np.int8)[0])
+        meta = np.frombuffer(buf[KDS_HEAD_FIXED:KDS_HEAD_FIXED + 8 * self.ncols].tobytes(),
+                             dtype=np.dtype([("attbyval", "i1"), ("attalign", "i1"),
+                                             ("attlen", "<i2"), ("attnum", "<i2"),
+                                             ("attcacheoff", "<i2")]))
+        self.colmeta = meta
+
+
+def kds_fetch(kds_buf, row, col):
+    """(isnull, raw 64-bit datum image) of one cell, host side"""
+    v = ctypes.c_uint64(0)
+    isnull = lib.strom_kds_fetch(kds_buf.ctypes.data, row, col, ctypes.byref(v))
+    return bool(isnull), v.value
+
+
+# ---------------------------------------------------------------------
+# kern_gpuscan = kern_parambuf followed by kern_resultbuf
+# ---------------------------------------------------------------------
+def make_kern_gpuscan(parambuf_bytes, nrooms, nrels=1):
+    plen = stromalign(len(parambuf_bytes))
+    rlen = stromalign(RESULTBUF_HEAD + 4 * nrels * nrooms)
+    buf = aligned_buffer(plen + rlen, 64)
+    buf[:plen] = 0
+    buf[:len(parambuf_bytes)] = np.frombuffer(parambuf_bytes, dtype=np.uint8)
+    head = np.zeros(5, dtype=np.uint32)
+    head[0] = nrels
+    head[1] = nrooms
+    buf[plen:plen + RESULTBUF_HEAD] = head.view(np.uint8)
+    return buf, plen
+
+
+def read_resultbuf(buf, res_offset):
+    head = np.frombuffer(buf[res_offset:res_offset + RESULTBUF_HEAD].tobytes(), dtype=np.int32)
+    nrels, nrooms, nitems, errcode = int(head[0]), int(head[1]), int(head[2]), int(head[3])
+    n = nitems * nrels
+    start = res_offset + RESULTBUF_HEAD
+    results = np.frombuffer(buf[start:start + 4 * n].tobytes(), dtype=np.int32)
+    return nitems, errcode, results
