@@ -1,0 +1,234 @@
+#!/usr/bin/env python3
+"""
+bench.py -- headline measurement of the GpuScan path (BASELINE.json configs[1]).
+
+A "step" is one pass of GpuScan over the rank's resident table: 1e8 rows of
+(a int4, b float8) in KDS_FORMAT_COLUMN chunks, WHERE a < k AND b > c, every
+chunk submitted through the C ABI (strom_submit_gpuscan) with the results left
+in HBM.  Inputs are resident in HBM before the timed region starts.  With N
+GPUs the table is N x 1e8 rows sharded by row range, one process per GPU,
+no data-path collective (weak scaling).
+
+Output: ONE JSON line on rank 0 (see the driver contract), with
+  roofline     algorithmic bytes per launch / mean kernel time per launch,
+               kernel time from HIP events recorded on the launch stream by
+               the runtime (strom_perfmon.time_kern_exec_ns)
+  cpu_baseline the CPU oracle (oracle/, a port: tuple-at-a-time over ROW
+               format heap pages, expression tree interpreted per row, the
+               shape of PostgreSQL's SeqScan+ExecQual) timed on a bounded
+               sample of the same workload on this host, rank 0, N=1 only
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+C2_QUAL = "(and (int4lt (var 1 int4) (param 0 int4)) (float8gt (var 2 float8) (param 1 float8)))"
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+
+def make_columns(nrows, seed):
+    rng = np.random.default_rng(seed)
+    a = rng.integers(0, 2**31, nrows, dtype=np.int64).astype(np.int32)
+    b = rng.random(nrows)
+    return a, b
+
+
+def cpu_baseline(k, c, budget_s=12.0):
+    """time the CPU oracle on ROW-format chunks of the same distribution"""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_binding as oracle
+    from pg_strom_amd import kds
+    oracle.build_oracle()
+    chunk_rows = 325_000            # the reference's 15MB ROW chunk
+    a, b = make_columns(chunk_rows, 0x5eed0002)
+    buf = kds.build_kds("row", [kds.Column("int4", a), kds.Column("float8", b)])
+    t0 = time.perf_counter()
+    oracle.gpuscan(C2_QUAL, buf, [k, c])
+    t1 = time.perf_counter() - t0
+    reps = int(max(1, min(400, budget_s / max(t1, 1e-6))))
+    t0 = time.perf_counter()
+    sel = 0
+    for _ in range(reps):
+        _, res = oracle.gpuscan(C2_QUAL, buf, [k, c])
+        sel += len(res)
+    dt = time.perf_counter() - t0
+    rows = reps * chunk_rows
+    return {
+        "value": rows / dt / 1e6,
+        "unit": "Mrows/s",
+        "cores": 1,
+        "kind": "port",
+        "sample": "%d x %d-row KDS_FORMAT_ROW chunks (heap pages, 185 rows/page), "
+                  "tuple-at-a-time deform + interpreted qual, %.1f s" % (reps, chunk_rows, dt),
+    }
+
+
+def load_traffic(chunk_rows):
+    """per-launch HBM bytes from the committed rocprofv3 --pmc passes, if any"""
+    path = os.path.join(ROOT, "profiles", "gpuscan_traffic.json")
+    try:
+        rec = json.load(open(path))
+        if rec.get("chunk_rows") == chunk_rows:
+            return rec.get("hbm_bytes_per_launch")
+    except Exception:
+        pass
+    return None
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--rows", type=int, default=100_000_000, help="rows per GPU")
+    ap.add_argument("--chunk-rows", type=int, default=25_000_000)
+    ap.add_argument("--selectivity", type=float, default=0.10)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        print("bench.py needs a GPU (the product has no CPU path)", file=sys.stderr)
+        sys.exit(2)
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    ngpus = world
+
+    from pg_strom_amd import kds, runtime
+    from pg_strom_amd._lib import lib, strom_perfmon
+    from pg_strom_amd.gpuscan import GpuScan, STROM_RESULTS_ON_DEVICE
+    import ctypes
+
+    runtime.init([local_rank])
+    # selectivity s = s1 * s2 with s1 = sqrt-ish split: a<k passes 50%, b>c the rest
+    s1 = 0.5
+    s2 = args.selectivity / s1
+    k = np.int32(int(2**31 * s1))
+    c = float(1.0 - s2)
+
+    # resident table: row range [rank*rows, (rank+1)*rows) in COLUMN chunks
+    nrows = args.rows
+    chunks = []
+    nsel_expect = 0
+    off = 0
+    ci = 0
+    while off < nrows:
+        n = min(args.chunk_rows, nrows - off)
+        a, b = make_columns(n, 0x5eed0002 + 1000 * rank + ci)
+        nsel_expect += int(np.count_nonzero((a < k) & (b > c)))
+        buf = kds.build_kds("column", [kds.Column("int4", a), kds.Column("float8", b)])
+        chunks.append(runtime.DeviceStore.upload(buf, 0))
+        del a, b, buf
+        off += n
+        ci += 1
+
+    scan = GpuScan(C2_QUAL).begin(ext_params=[k, c])
+    scan.program.wait()
+
+    kern_ns = []
+    nitems_seen = []
+
+    def one_step(record):
+        pend = [scan.submit(ds, flags=STROM_RESULTS_ON_DEVICE) for ds in chunks]
+        total = 0
+        for p in pend:
+            res = scan.collect(p)
+            total += res.nitems
+            if record:
+                kern_ns.append(res.perfmon["time_kern_exec_ns"])
+                nitems_seen.append(res.nitems)
+        return total
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        got = one_step(False)
+        assert got == nsel_expect, "row count mismatch: %d != %d" % (got, nsel_expect)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        got = one_step(True)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    assert got == nsel_expect
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        per_step = elapsed / args.steps
+        value = ngpus * nrows / per_step / 1e6
+        # dominant kernel: gpuscan_qual_column, one launch per chunk
+        launches = len(kern_ns)
+        mean_ns = float(np.mean(kern_ns))
+        rows_per_launch = nrows / len(chunks)
+        alg_bytes = 12.0 * rows_per_launch + 4.0 * float(np.mean(nitems_seen))
+        achieved = alg_bytes / (mean_ns * 1e-9) / 1e9
+        out = {
+            "metric": "GpuScan Mrows/s (WHERE a<k AND b>c over int4,float8 COLUMN chunks), "
+                      "achieved HBM GB/s vs peak",
+            "value": value,
+            "unit": "Mrows/s",
+            "n_gpus": ngpus,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": per_step * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "int32+f64",
+            "data": "synthetic",
+            "config": {
+                "workload": "GpuScan: %d-row int4+float8 kern_data_store per GPU, "
+                            "WHERE a<k AND b>c (BASELINE configs[1])" % nrows,
+                "rows_per_gpu": nrows,
+                "chunk_rows": args.chunk_rows,
+                "chunks_per_gpu": len(chunks),
+                "selectivity": nsel_expect / nrows,
+                "format": "KDS_FORMAT_COLUMN",
+                "parallelism": "row-range x%d" % ngpus,
+            },
+            "roofline": {
+                "bound": "hbm",
+                "kernel": "gpuscan_qual_column",
+                "achieved": achieved,
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS,
+                "traffic": load_traffic(args.chunk_rows),
+                "bytes_per_launch": alg_bytes,
+                "launch_us": mean_ns * 1e-3,
+                "launches_timed": launches,
+            },
+            "whole_job_gbs": 12.0 * ngpus * nrows / per_step / 1e9,
+        }
+        if ngpus == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(k, c)
+        print(json.dumps(out), flush=True)
+
+    scan.end()
+    for ds in chunks:
+        ds.release()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,1256 @@
+/*
+ * strom_oracle.c -- CPU restatement of the per-chunk algorithms
+ *
+ * TEST INFRASTRUCTURE ONLY (see strom_oracle.h).  Single thread, one tuple
+ * at a time, interpreting the expression tree per row -- the shape of
+ * PostgreSQL's SeqScan + ExecQual, which is what the reference's own tests
+ * compare against.
+ */
+#define _GNU_SOURCE
+#include <ctype.h>
+#include <math.h>
+#include <stdarg.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "strom_oracle.h"
+
+/* ====================================================================== *
+ * tuple access: restates opencl_common.h:817-981
+ * ====================================================================== */
+#define PAGE_HEADER_SIZE	24
+#define ITEMID_OFFSET(x)	((x) & 0x7fff)			/* shift 0  */
+#define ITEMID_LENGTH(x)	(((x) >> 17) & 0x7fff)	/* shift 17 */
+
+static unsigned
+varsize_any(const unsigned char *p)
+{
+	if (p[0] == 0x01)
+		return 2 + (p[1] == 18 ? 16 : 8);			/* external TOAST pointer */
+	if (p[0] & 0x01)
+		return (p[0] >> 1) & 0x7f;					/* 1-byte header */
+	return ((unsigned)p[0] | ((unsigned)p[1] << 8) |
+			((unsigned)p[2] << 16) | ((unsigned)p[3] << 24)) >> 2;
+}
+
+/* kern_get_datum_tuple (opencl_common.h:817-864) */
+static const void *
+get_datum_tuple(const kern_colmeta *colmeta, const HeapTupleHeaderData *htup, uint32_t colidx)
+{
+	int			hasnull = (htup->t_infomask & HEAP_HASNULL) != 0;
+	uint32_t	offset = htup->t_hoff;
+	uint32_t	natts = htup->t_infomask2 & HEAP_NATTS_MASK;
+	uint32_t	i;
+
+	if (colidx >= natts)
+		return NULL;
+	if (!hasnull && colmeta[colidx].attcacheoff >= 0)
+		return (const char *)htup + colmeta[colidx].attcacheoff;
+	for (i = 0; i < natts; i++)
+	{
+		if (hasnull && !(htup->t_bits[i >> 3] & (1 << (i & 7))))
+		{
+			if (i == colidx)
+				return NULL;
+		}
+		else
+		{
+			const char *addr;
+
+			if (colmeta[i].attlen > 0)
+				offset = STROM_TYPEALIGN(colmeta[i].attalign, offset);
+			else if (((const unsigned char *)htup)[offset] == 0)
+				offset = STROM_TYPEALIGN(colmeta[i].attalign, offset);
+			addr = (const char *)htup + offset;
+			if (i == colidx)
+				return addr;
+			offset += (colmeta[i].attlen > 0 ? (uint32_t)colmeta[i].attlen
+					   : varsize_any((const unsigned char *)addr));
+		}
+	}
+	return NULL;
+}
+
+const void *
+oracle_get_datum(const kern_data_store *kds, uint32_t colidx, uint32_t rowidx)
+{
+	if (colidx >= kds->ncols || rowidx >= kds->nitems)
+		return NULL;
+	switch (kds->format)
+	{
+		case KDS_FORMAT_ROW:		/* kern_get_tuple_rs (866-903) */
+			{
+				const kern_rowitem *ri = KERN_DATA_STORE_ROWITEM(kds, rowidx);
+				const char *page;
+				uint16_t	pd_lower;
+				uint32_t	item_max, itemid;
+
+				if (ri->blk_index >= kds->nblocks)
+					return NULL;
+				page = KERN_DATA_STORE_ROWBLOCK(kds, ri->blk_index);
+				memcpy(&pd_lower, page + 12, 2);
+				item_max = (pd_lower <= PAGE_HEADER_SIZE ? 0
+							: (pd_lower - PAGE_HEADER_SIZE) / 4);
+				if (PAGE_HEADER_SIZE + 4 * (item_max + 1) >= BLCKSZ ||
+					ri->item_offset == 0 || ri->item_offset > item_max)
+					return NULL;
+				memcpy(&itemid, page + PAGE_HEADER_SIZE + 4 * (ri->item_offset - 1), 4);
+				if (ITEMID_OFFSET(itemid) + HEAPTUPLE_HEADER_FIXED >= BLCKSZ)
+					return NULL;
+				return get_datum_tuple(kds->colmeta,
+									   (const HeapTupleHeaderData *)(page + ITEMID_OFFSET(itemid)),
+									   colidx);
+			}
+		case KDS_FORMAT_ROW_FLAT:	/* kern_get_tuple_rsflat (919-933) */
+			{
+				uint32_t off = KERN_DATA_STORE_ROWITEM(kds, rowidx)->htup_offset;
+				if (off >= kds->length)
+					return NULL;
+				return get_datum_tuple(kds->colmeta,
+									   (const HeapTupleHeaderData *)((const char *)kds + off),
+									   colidx);
+			}
+		case KDS_FORMAT_TUPSLOT:	/* kern_get_datum_tupslot (949-963) */
+			if (KERN_DATA_STORE_ISNULL(kds, rowidx)[colidx])
+				return NULL;
+			return KERN_DATA_STORE_VALUES(kds, rowidx) + colidx;
+		case KDS_FORMAT_COLUMN:		/* this build's layout, strom_kds.h */
+			{
+				const kern_coldir *cd = KERN_DATA_STORE_COLDIR(kds) + colidx;
+				if (cd->nulls_off)
+				{
+					const uint32_t *nn = (const uint32_t *)((const char *)kds + cd->nulls_off);
+					if (!((nn[rowidx >> 5] >> (rowidx & 31)) & 1))
+						return NULL;
+				}
+				return (const char *)kds + cd->values_off +
+					(size_t)kds->colmeta[colidx].attlen * rowidx;
+			}
+	}
+	return NULL;
+}
+
+/* ====================================================================== *
+ * expression tree
+ * ====================================================================== */
+enum {
+	N_CONST, N_PARAM, N_VAR, N_FUNC, N_AND, N_OR, N_NOT, N_ISNULL, N_ISNOTNULL,
+	N_BOOLTEST, N_CASE, N_RELABEL
+};
+/* operator classes of N_FUNC */
+enum {
+	OP_ADD, OP_SUB, OP_MUL, OP_DIV, OP_MOD,
+	OP_EQ, OP_NE, OP_LT, OP_LE, OP_GT, OP_GE, OP_CMP,
+	OP_UMINUS, OP_UPLUS, OP_ABS, OP_BITNOT, OP_BITAND, OP_BITOR, OP_BITXOR,
+	OP_SHL, OP_SHR, OP_CAST,
+	OP_CEIL, OP_FLOOR, OP_ROUND, OP_TRUNC, OP_SIGN, OP_SQRT, OP_PI,
+	OP_DATE_PLI, OP_DATE_MII, OP_DATE_MI, OP_INT_PL_DATE,
+	OP_DATE_TO_TS, OP_TS_TO_DATE, OP_TS_TO_TIME, OP_DATETIME_PL, OP_TIMEDATE_PL
+};
+enum { BT_TRUE, BT_NOT_TRUE, BT_FALSE, BT_NOT_FALSE, BT_UNKNOWN, BT_NOT_UNKNOWN };
+
+struct oracle_expr {
+	int			kind;
+	int			type_oid;		/* result type */
+	int			op;				/* OP_* / BT_* */
+	int			attno;			/* N_VAR (1-based) / N_PARAM id */
+	oracle_value cval;			/* N_CONST */
+	int			nargs;
+	struct oracle_expr **args;	/* N_CASE: cond0,res0,cond1,res1,...,[else] */
+	int			has_else;
+	struct oracle_expr *case_arg;	/* simple CASE subject */
+};
+
+typedef struct { const char *p; char *err; size_t errlen; int failed; } parser;
+
+static void
+perr(parser *ps, const char *fmt, ...)
+{
+	va_list ap;
+	if (ps->failed)
+		return;
+	ps->failed = 1;
+	if (ps->err && ps->errlen)
+	{
+		va_start(ap, fmt);
+		vsnprintf(ps->err, ps->errlen, fmt, ap);
+		va_end(ap);
+	}
+}
+
+static void skip_ws(parser *ps) { while (isspace((unsigned char)*ps->p)) ps->p++; }
+
+static int
+read_atom(parser *ps, char *buf, size_t buflen)
+{
+	size_t n = 0;
+	skip_ws(ps);
+	if (*ps->p == '\'')
+	{
+		ps->p++;
+		while (*ps->p && *ps->p != '\'' && n + 1 < buflen)
+			buf[n++] = *ps->p++;
+		if (*ps->p != '\'')
+			return 0;
+		ps->p++;
+		buf[n] = 0;
+		return 1;
+	}
+	while (*ps->p && !isspace((unsigned char)*ps->p) && *ps->p != '(' && *ps->p != ')' && n + 1 < buflen)
+		buf[n++] = *ps->p++;
+	buf[n] = 0;
+	return n > 0;
+}
+
+static int
+type_by_name(const char *s)
+{
+	static const struct { const char *n; int oid; } t[] = {
+		{"bool", STROM_BOOLOID}, {"int2", STROM_INT2OID}, {"int4", STROM_INT4OID},
+		{"int8", STROM_INT8OID}, {"float4", STROM_FLOAT4OID}, {"float8", STROM_FLOAT8OID},
+		{"date", STROM_DATEOID}, {"time", STROM_TIMEOID}, {"timestamp", STROM_TIMESTAMPOID},
+		{"numeric", STROM_NUMERICOID}, {"char1", STROM_BPCHAROID},
+		{"integer", STROM_INT4OID}, {"int", STROM_INT4OID}, {"smallint", STROM_INT2OID},
+		{"bigint", STROM_INT8OID}, {"real", STROM_FLOAT4OID}, {"double", STROM_FLOAT8OID},
+		{"float", STROM_FLOAT8OID}, {"bpchar", STROM_BPCHAROID},
+	};
+	size_t i;
+	for (i = 0; i < sizeof(t) / sizeof(t[0]); i++)
+		if (strcmp(t[i].n, s) == 0)
+			return t[i].oid;
+	return 0;
+}
+
+static int type_is_int(int t)
+{ return t == STROM_INT2OID || t == STROM_INT4OID || t == STROM_INT8OID; }
+static int type_is_float(int t)
+{ return t == STROM_FLOAT4OID || t == STROM_FLOAT8OID; }
+
+static int
+type_len(int t)
+{
+	switch (t)
+	{
+		case STROM_BOOLOID: case STROM_BPCHAROID: return 1;
+		case STROM_INT2OID: return 2;
+		case STROM_INT4OID: case STROM_FLOAT4OID: case STROM_DATEOID: return 4;
+		default: return 8;
+	}
+}
+
+/* days from civil date, PostgreSQL date2j (timelib date2j, opencl_timelib.h:125-160) */
+static int
+oracle_date2j(int y, int m, int d)
+{
+	int julian, century;
+	if (m > 2) { m += 1; y += 4800; } else { m += 13; y += 4799; }
+	century = y / 100;
+	julian = y * 365 - 32167;
+	julian += y / 4 - century + century / 4;
+	julian += 7834 * m / 256 + d;
+	return julian;
+}
+#define POSTGRES_EPOCH_JDATE 2451545
+
+static int
+parse_literal(parser *ps, int type, const char *lit, oracle_value *out)
+{
+	char *end = NULL;
+	memset(out, 0, sizeof(*out));
+	out->type_oid = type;
+	if (strcmp(lit, "null") == 0 || strcmp(lit, "NULL") == 0)
+	{
+		out->isnull = 1;
+		return 1;
+	}
+	switch (type)
+	{
+		case STROM_BOOLOID:
+			if (!strcmp(lit, "t") || !strcmp(lit, "true") || !strcmp(lit, "1")) out->v.i = 1;
+			else if (!strcmp(lit, "f") || !strcmp(lit, "false") || !strcmp(lit, "0")) out->v.i = 0;
+			else { perr(ps, "bad bool literal %s", lit); return 0; }
+			return 1;
+		case STROM_INT2OID: case STROM_INT4OID: case STROM_INT8OID: case STROM_TIMEOID:
+			out->v.i = strtoll(lit, &end, 10);
+			if (end == lit || *end) { perr(ps, "bad integer literal %s", lit); return 0; }
+			return 1;
+		case STROM_FLOAT4OID:
+			out->v.f = strtof(lit, &end);
+			if (end == lit || *end) { perr(ps, "bad float literal %s", lit); return 0; }
+			return 1;
+		case STROM_FLOAT8OID:
+			out->v.d = strtod(lit, &end);
+			if (end == lit || *end) { perr(ps, "bad float literal %s", lit); return 0; }
+			return 1;
+		case STROM_DATEOID:
+			{
+				int y, m, d;
+				if (sscanf(lit, "%d-%d-%d", &y, &m, &d) == 3 && strchr(lit + 1, '-'))
+					out->v.i = oracle_date2j(y, m, d) - POSTGRES_EPOCH_JDATE;
+				else
+				{
+					out->v.i = strtoll(lit, &end, 10);
+					if (end == lit || *end) { perr(ps, "bad date literal %s", lit); return 0; }
+				}
+				return 1;
+			}
+		case STROM_TIMESTAMPOID:
+			{
+				int y, m, d, hh = 0, mi = 0; double ss = 0;
+				int n = sscanf(lit, "%d-%d-%d %d:%d:%lf", &y, &m, &d, &hh, &mi, &ss);
+				if (n >= 3 && strchr(lit + 1, '-'))
+					out->v.i = (int64_t)(oracle_date2j(y, m, d) - POSTGRES_EPOCH_JDATE) * 86400000000LL
+						+ ((int64_t)hh * 3600 + mi * 60) * 1000000LL + (int64_t)llround(ss * 1e6);
+				else
+				{
+					out->v.i = strtoll(lit, &end, 10);
+					if (end == lit || *end) { perr(ps, "bad timestamp literal %s", lit); return 0; }
+				}
+				return 1;
+			}
+		case STROM_BPCHAROID:
+			if (strlen(lit) != 1) { perr(ps, "char1 literal must be one byte"); return 0; }
+			out->v.i = (signed char)lit[0];
+			return 1;
+	}
+	perr(ps, "no literal syntax for type %d", type);
+	return 0;
+}
+
+static oracle_expr *
+new_node(int kind)
+{
+	oracle_expr *e = calloc(1, sizeof(*e));
+	e->kind = kind;
+	return e;
+}
+
+static void
+add_arg(oracle_expr *e, oracle_expr *a)
+{
+	e->args = realloc(e->args, sizeof(oracle_expr *) * (e->nargs + 1));
+	e->args[e->nargs++] = a;
+}
+
+void
+oracle_expr_free(oracle_expr *e)
+{
+	int i;
+	if (!e)
+		return;
+	for (i = 0; i < e->nargs; i++)
+		oracle_expr_free(e->args[i]);
+	oracle_expr_free(e->case_arg);
+	free(e->args);
+	free(e);
+}
+
+/* ---- function resolution: pg_proc name + argument types ------------- */
+static int
+family_types(const char *sfx, const char *pfx, int *x, int *y, const char **rest)
+{
+	/* sfx examples: "4pl", "24lt", "82mi" after the "int"/"float" prefix */
+	static const struct { const char *s; int x, y; } ints[] = {
+		{"24", STROM_INT2OID, STROM_INT4OID}, {"28", STROM_INT2OID, STROM_INT8OID},
+		{"42", STROM_INT4OID, STROM_INT2OID}, {"48", STROM_INT4OID, STROM_INT8OID},
+		{"82", STROM_INT8OID, STROM_INT2OID}, {"84", STROM_INT8OID, STROM_INT4OID},
+		{"2", STROM_INT2OID, STROM_INT2OID}, {"4", STROM_INT4OID, STROM_INT4OID},
+		{"8", STROM_INT8OID, STROM_INT8OID},
+	};
+	static const struct { const char *s; int x, y; } flts[] = {
+		{"48", STROM_FLOAT4OID, STROM_FLOAT8OID}, {"84", STROM_FLOAT8OID, STROM_FLOAT4OID},
+		{"4", STROM_FLOAT4OID, STROM_FLOAT4OID}, {"8", STROM_FLOAT8OID, STROM_FLOAT8OID},
+	};
+	size_t i;
+	if (strcmp(pfx, "int") == 0)
+	{
+		for (i = 0; i < sizeof(ints) / sizeof(ints[0]); i++)
+			if (strncmp(sfx, ints[i].s, strlen(ints[i].s)) == 0)
+			{
+				*x = ints[i].x; *y = ints[i].y; *rest = sfx + strlen(ints[i].s);
+				return 1;
+			}
+	}
+	else
+	{
+		for (i = 0; i < sizeof(flts) / sizeof(flts[0]); i++)
+			if (strncmp(sfx, flts[i].s, strlen(flts[i].s)) == 0)
+			{
+				*x = flts[i].x; *y = flts[i].y; *rest = sfx + strlen(flts[i].s);
+				return 1;
+			}
+	}
+	return 0;
+}
+
+static int
+wider_type(int x, int y)
+{
+	int rank_x = type_len(x), rank_y = type_len(y);
+	if (type_is_float(x) || type_is_float(y))
+		return (rank_x == 8 || rank_y == 8) ? STROM_FLOAT8OID : STROM_FLOAT4OID;
+	return rank_x >= rank_y ? x : y;
+}
+
+static int
+binop_by_suffix(const char *s)
+{
+	static const struct { const char *s; int op; } t[] = {
+		{"pl", OP_ADD}, {"mi", OP_SUB}, {"mul", OP_MUL}, {"div", OP_DIV}, {"mod", OP_MOD},
+		{"eq", OP_EQ}, {"ne", OP_NE}, {"lt", OP_LT}, {"le", OP_LE}, {"gt", OP_GT}, {"ge", OP_GE},
+		{"and", OP_BITAND}, {"or", OP_BITOR}, {"xor", OP_BITXOR}, {"shl", OP_SHL}, {"shr", OP_SHR},
+	};
+	size_t i;
+	for (i = 0; i < sizeof(t) / sizeof(t[0]); i++)
+		if (strcmp(t[i].s, s) == 0)
+			return t[i].op;
+	return -1;
+}
+
+/* fills e->op / e->type_oid for a function call; 0 when unknown */
+static int
+resolve_func(oracle_expr *e, const char *name)
+{
+	int		nargs = e->nargs;
+	int		a0 = nargs > 0 ? e->args[0]->type_oid : 0;
+	int		a1 = nargs > 1 ? e->args[1]->type_oid : 0;
+	int		x, y, op;
+	const char *rest;
+
+	/* casts */
+	if (nargs == 1)
+	{
+		int target = 0;
+		if (!strcmp(name, "int2")) target = STROM_INT2OID;
+		else if (!strcmp(name, "int4")) target = STROM_INT4OID;
+		else if (!strcmp(name, "int8")) target = STROM_INT8OID;
+		else if (!strcmp(name, "float4")) target = STROM_FLOAT4OID;
+		else if (!strcmp(name, "float8")) target = STROM_FLOAT8OID;
+		if (target && target != a0 &&
+			(type_is_int(a0) || type_is_float(a0) || (a0 == STROM_BOOLOID && target == STROM_INT4OID)))
+		{
+			e->op = OP_CAST;
+			e->type_oid = target;
+			return 1;
+		}
+	}
+	/* bt<family>cmp */
+	if (strncmp(name, "bt", 2) == 0 && nargs == 2)
+	{
+		const char *n = name + 2;
+		if (!strcmp(n, "boolcmp") && a0 == STROM_BOOLOID && a1 == STROM_BOOLOID)
+		{ e->op = OP_CMP; e->type_oid = STROM_INT4OID; return 1; }
+		if (!strncmp(n, "int", 3) && family_types(n + 3, "int", &x, &y, &rest) &&
+			!strcmp(rest, "cmp") && a0 == x && a1 == y)
+		{ e->op = OP_CMP; e->type_oid = STROM_INT4OID; return 1; }
+		if (!strncmp(n, "float", 5) && family_types(n + 5, "float", &x, &y, &rest) &&
+			!strcmp(rest, "cmp") && a0 == x && a1 == y)
+		{ e->op = OP_CMP; e->type_oid = STROM_INT4OID; return 1; }
+	}
+	/* int / float families */
+	if ((!strncmp(name, "int", 3) && family_types(name + 3, "int", &x, &y, &rest)) ||
+		(!strncmp(name, "float", 5) && family_types(name + 5, "float", &x, &y, &rest)))
+	{
+		int isint = (name[0] == 'i');
+		if (nargs == 2 && (op = binop_by_suffix(rest)) >= 0)
+		{
+			if (op == OP_SHL || op == OP_SHR)
+			{
+				if (isint && x == y && a0 == x && a1 == STROM_INT4OID)
+				{ e->op = op; e->type_oid = x; return 1; }
+				return 0;
+			}
+			if (a0 != x || a1 != y)
+				return 0;
+			if (op == OP_MOD && (!isint || x != y))
+				return 0;
+			if ((op == OP_BITAND || op == OP_BITOR || op == OP_BITXOR) && (!isint || x != y))
+				return 0;
+			e->op = op;
+			e->type_oid = (op >= OP_EQ && op <= OP_GE) ? STROM_BOOLOID : wider_type(x, y);
+			return 1;
+		}
+		if (nargs == 1 && x == y && a0 == x)
+		{
+			if (!strcmp(rest, "um"))  { e->op = OP_UMINUS; e->type_oid = x; return 1; }
+			if (!strcmp(rest, "up"))  { e->op = OP_UPLUS;  e->type_oid = x; return 1; }
+			if (!strcmp(rest, "abs")) { e->op = OP_ABS;    e->type_oid = x; return 1; }
+			if (!strcmp(rest, "not") && isint) { e->op = OP_BITNOT; e->type_oid = x; return 1; }
+		}
+		return 0;
+	}
+	if (!strcmp(name, "abs") && nargs == 1 && (type_is_int(a0) || type_is_float(a0)))
+	{ e->op = OP_ABS; e->type_oid = a0; return 1; }
+	if ((!strcmp(name, "booleq") || !strcmp(name, "boolne")) && nargs == 2 &&
+		a0 == STROM_BOOLOID && a1 == STROM_BOOLOID)
+	{ e->op = name[4] == 'e' ? OP_EQ : OP_NE; e->type_oid = STROM_BOOLOID; return 1; }
+	if (nargs == 1 && a0 == STROM_FLOAT8OID)
+	{
+		static const struct { const char *n; int op; } f[] = {
+			{"ceil", OP_CEIL}, {"ceiling", OP_CEIL}, {"floor", OP_FLOOR},
+			{"round", OP_ROUND}, {"dround", OP_ROUND}, {"trunc", OP_TRUNC}, {"dtrunc", OP_TRUNC},
+			{"sign", OP_SIGN}, {"sqrt", OP_SQRT}, {"dsqrt", OP_SQRT},
+		};
+		size_t i;
+		for (i = 0; i < sizeof(f) / sizeof(f[0]); i++)
+			if (!strcmp(f[i].n, name))
+			{ e->op = f[i].op; e->type_oid = STROM_FLOAT8OID; return 1; }
+	}
+	if (!strcmp(name, "pi") && nargs == 0)
+	{ e->op = OP_PI; e->type_oid = STROM_FLOAT8OID; return 1; }
+	/* date / time / timestamp and bpchar(1): comparisons on the raw value */
+	{
+		static const struct { const char *pfx; int x, y; } cmpfam[] = {
+			{"date_", STROM_DATEOID, STROM_DATEOID}, {"time_", STROM_TIMEOID, STROM_TIMEOID},
+			{"timestamp_", STROM_TIMESTAMPOID, STROM_TIMESTAMPOID},
+			{"bpchar", STROM_BPCHAROID, STROM_BPCHAROID},
+		};
+		size_t i;
+		for (i = 0; i < sizeof(cmpfam) / sizeof(cmpfam[0]); i++)
+		{
+			size_t l = strlen(cmpfam[i].pfx);
+			if (nargs == 2 && !strncmp(name, cmpfam[i].pfx, l) &&
+				a0 == cmpfam[i].x && a1 == cmpfam[i].y)
+			{
+				const char *s = name + l;
+				if (!strcmp(s, "cmp")) { e->op = OP_CMP; e->type_oid = STROM_INT4OID; return 1; }
+				op = binop_by_suffix(s);
+				if (op >= OP_EQ && op <= OP_GE) { e->op = op; e->type_oid = STROM_BOOLOID; return 1; }
+			}
+		}
+		/* date <op> timestamp and the mirror image: the date is promoted */
+		if (nargs == 2 && !strncmp(name, "date_", 5) && strstr(name, "_timestamp") &&
+			a0 == STROM_DATEOID && a1 == STROM_TIMESTAMPOID)
+		{
+			char opn[8] = {0};
+			size_t ol = strcspn(name + 5, "_");
+			memcpy(opn, name + 5, ol < 7 ? ol : 7);
+			if (!strcmp(opn, "cmp")) { e->op = OP_CMP; e->type_oid = STROM_INT4OID; return 1; }
+			op = binop_by_suffix(opn);
+			if (op >= OP_EQ && op <= OP_GE) { e->op = op; e->type_oid = STROM_BOOLOID; return 1; }
+		}
+		if (nargs == 2 && !strncmp(name, "timestamp_", 10) && strstr(name, "_date") &&
+			a0 == STROM_TIMESTAMPOID && a1 == STROM_DATEOID)
+		{
+			char opn[8] = {0};
+			size_t ol = strcspn(name + 10, "_");
+			memcpy(opn, name + 10, ol < 7 ? ol : 7);
+			if (!strcmp(opn, "cmp")) { e->op = OP_CMP; e->type_oid = STROM_INT4OID; return 1; }
+			op = binop_by_suffix(opn);
+			if (op >= OP_EQ && op <= OP_GE) { e->op = op; e->type_oid = STROM_BOOLOID; return 1; }
+		}
+	}
+	if (nargs == 2 && !strcmp(name, "date_pli") && a0 == STROM_DATEOID && a1 == STROM_INT4OID)
+	{ e->op = OP_DATE_PLI; e->type_oid = STROM_DATEOID; return 1; }
+	if (nargs == 2 && !strcmp(name, "date_mii") && a0 == STROM_DATEOID && a1 == STROM_INT4OID)
+	{ e->op = OP_DATE_MII; e->type_oid = STROM_DATEOID; return 1; }
+	if (nargs == 2 && !strcmp(name, "date_mi") && a0 == STROM_DATEOID && a1 == STROM_DATEOID)
+	{ e->op = OP_DATE_MI; e->type_oid = STROM_INT4OID; return 1; }
+	if (nargs == 2 && !strcmp(name, "integer_pl_date") && a0 == STROM_INT4OID && a1 == STROM_DATEOID)
+	{ e->op = OP_INT_PL_DATE; e->type_oid = STROM_DATEOID; return 1; }
+	if (nargs == 1 && !strcmp(name, "timestamp") && a0 == STROM_DATEOID)
+	{ e->op = OP_DATE_TO_TS; e->type_oid = STROM_TIMESTAMPOID; return 1; }
+	if (nargs == 1 && !strcmp(name, "date") && a0 == STROM_TIMESTAMPOID)
+	{ e->op = OP_TS_TO_DATE; e->type_oid = STROM_DATEOID; return 1; }
+	if (nargs == 1 && !strcmp(name, "time") && a0 == STROM_TIMESTAMPOID)
+	{ e->op = OP_TS_TO_TIME; e->type_oid = STROM_TIMEOID; return 1; }
+	if (nargs == 2 && !strcmp(name, "datetime_pl") && a0 == STROM_DATEOID && a1 == STROM_TIMEOID)
+	{ e->op = OP_DATETIME_PL; e->type_oid = STROM_TIMESTAMPOID; return 1; }
+	if (nargs == 2 && !strcmp(name, "timedate_pl") && a0 == STROM_TIMEOID && a1 == STROM_DATEOID)
+	{ e->op = OP_TIMEDATE_PL; e->type_oid = STROM_TIMESTAMPOID; return 1; }
+	return 0;
+}
+
+static oracle_expr *parse_expr(parser *ps);
+
+static int
+expect_char(parser *ps, char c)
+{
+	skip_ws(ps);
+	if (*ps->p != c)
+	{
+		perr(ps, "expected '%c' near \"%.16s\"", c, ps->p);
+		return 0;
+	}
+	ps->p++;
+	return 1;
+}
+
+static int
+peek_close(parser *ps)
+{
+	skip_ws(ps);
+	return *ps->p == ')';
+}
+
+static oracle_expr *
+parse_expr(parser *ps)
+{
+	char		head[64], buf[128];
+	oracle_expr *e = NULL;
+
+	if (!expect_char(ps, '(') || !read_atom(ps, head, sizeof(head)))
+	{
+		perr(ps, "expression expected");
+		return NULL;
+	}
+	if (!strcmp(head, "const"))
+	{
+		int t;
+		e = new_node(N_CONST);
+		if (!read_atom(ps, buf, sizeof(buf)) || !(t = type_by_name(buf)))
+		{ perr(ps, "bad type in const"); goto fail; }
+		if (!read_atom(ps, buf, sizeof(buf)) || !parse_literal(ps, t, buf, &e->cval))
+		{ perr(ps, "bad literal in const"); goto fail; }
+		e->type_oid = t;
+	}
+	else if (!strcmp(head, "param") || !strcmp(head, "var"))
+	{
+		e = new_node(head[0] == 'p' ? N_PARAM : N_VAR);
+		if (!read_atom(ps, buf, sizeof(buf)))
+		{ perr(ps, "number expected"); goto fail; }
+		e->attno = atoi(buf);
+		if (!read_atom(ps, buf, sizeof(buf)) || !(e->type_oid = type_by_name(buf)))
+		{ perr(ps, "bad type"); goto fail; }
+	}
+	else if (!strcmp(head, "and") || !strcmp(head, "or"))
+	{
+		e = new_node(head[0] == 'a' ? N_AND : N_OR);
+		e->type_oid = STROM_BOOLOID;
+		while (!peek_close(ps) && !ps->failed)
+		{
+			oracle_expr *a = parse_expr(ps);
+			if (!a) goto fail;
+			add_arg(e, a);
+		}
+		if (e->nargs < 1) { perr(ps, "empty and/or"); goto fail; }
+	}
+	else if (!strcmp(head, "not") || !strcmp(head, "isnull") || !strcmp(head, "isnotnull") ||
+			 !strncmp(head, "is_", 3))
+	{
+		oracle_expr *a;
+		if (!strcmp(head, "not")) e = new_node(N_NOT);
+		else if (!strcmp(head, "isnull")) e = new_node(N_ISNULL);
+		else if (!strcmp(head, "isnotnull")) e = new_node(N_ISNOTNULL);
+		else
+		{
+			e = new_node(N_BOOLTEST);
+			if (!strcmp(head, "is_true")) e->op = BT_TRUE;
+			else if (!strcmp(head, "is_not_true")) e->op = BT_NOT_TRUE;
+			else if (!strcmp(head, "is_false")) e->op = BT_FALSE;
+			else if (!strcmp(head, "is_not_false")) e->op = BT_NOT_FALSE;
+			else if (!strcmp(head, "is_unknown")) e->op = BT_UNKNOWN;
+			else if (!strcmp(head, "is_not_unknown")) e->op = BT_NOT_UNKNOWN;
+			else { perr(ps, "unknown test %s", head); goto fail; }
+		}
+		e->type_oid = STROM_BOOLOID;
+		a = parse_expr(ps);
+		if (!a) goto fail;
+		add_arg(e, a);
+	}
+	else if (!strcmp(head, "relabel"))
+	{
+		oracle_expr *a;
+		e = new_node(N_RELABEL);
+		if (!read_atom(ps, buf, sizeof(buf)) || !type_by_name(buf))
+		{ perr(ps, "bad type in relabel"); goto fail; }
+		a = parse_expr(ps);
+		if (!a) goto fail;
+		add_arg(e, a);
+		e->type_oid = a->type_oid;
+	}
+	else if (!strcmp(head, "case") || !strcmp(head, "case_eq"))
+	{
+		e = new_node(N_CASE);
+		if (!strcmp(head, "case_eq"))
+		{
+			e->case_arg = parse_expr(ps);
+			if (!e->case_arg) goto fail;
+		}
+		while (!peek_close(ps) && !ps->failed)
+		{
+			char arm[16];
+			if (!expect_char(ps, '(') || !read_atom(ps, arm, sizeof(arm))) goto fail;
+			if (!strcmp(arm, "when"))
+			{
+				oracle_expr *c = parse_expr(ps), *r;
+				if (!c) goto fail;
+				add_arg(e, c);
+				r = parse_expr(ps);
+				if (!r) goto fail;
+				add_arg(e, r);
+				e->type_oid = r->type_oid;
+			}
+			else if (!strcmp(arm, "else"))
+			{
+				oracle_expr *r = parse_expr(ps);
+				if (!r) goto fail;
+				add_arg(e, r);
+				e->has_else = 1;
+				e->type_oid = r->type_oid;
+			}
+			else { perr(ps, "bad case arm %s", arm); goto fail; }
+			if (!expect_char(ps, ')')) goto fail;
+		}
+	}
+	else
+	{
+		e = new_node(N_FUNC);
+		while (!peek_close(ps) && !ps->failed)
+		{
+			oracle_expr *a = parse_expr(ps);
+			if (!a) goto fail;
+			add_arg(e, a);
+		}
+		if (!resolve_func(e, head))
+		{ perr(ps, "function %s is not known to the oracle for these argument types", head); goto fail; }
+	}
+	if (!expect_char(ps, ')'))
+		goto fail;
+	return e;
+fail:
+	oracle_expr_free(e);
+	return NULL;
+}
+
+oracle_expr *
+oracle_expr_parse(const char *text, char *errbuf, size_t errlen)
+{
+	parser ps = { text, errbuf, errlen, 0 };
+	oracle_expr *e = parse_expr(&ps);
+	if (e)
+	{
+		skip_ws(&ps);
+		if (*ps.p)
+		{
+			perr(&ps, "trailing characters");
+			oracle_expr_free(e);
+			return NULL;
+		}
+	}
+	return e;
+}
+
+/* ====================================================================== *
+ * evaluation
+ * ====================================================================== */
+static void
+set_error(int32_t *p_error, int32_t errcode)
+{
+	int32_t oldcode = *p_error;
+	if (StromErrorIsSignificant(errcode))
+	{
+		if (!StromErrorIsSignificant(oldcode))
+			*p_error = errcode;
+	}
+	else if (errcode > oldcode)
+		*p_error = errcode;
+}
+
+static oracle_value
+make_null(int type)
+{
+	oracle_value r;
+	memset(&r, 0, sizeof(r));
+	r.type_oid = type;
+	r.isnull = 1;
+	return r;
+}
+
+static oracle_value
+recheck(int type, int32_t *errcode)
+{
+	set_error(errcode, StromError_CpuReCheck);
+	return make_null(type);
+}
+
+static oracle_value
+load_datum(int type, const void *addr)
+{
+	oracle_value r;
+	memset(&r, 0, sizeof(r));
+	r.type_oid = type;
+	if (!addr)
+	{
+		r.isnull = 1;
+		return r;
+	}
+	switch (type)
+	{
+		case STROM_BOOLOID: case STROM_BPCHAROID:
+			{ int8_t x; memcpy(&x, addr, 1); r.v.i = x; } break;
+		case STROM_INT2OID:
+			{ int16_t x; memcpy(&x, addr, 2); r.v.i = x; } break;
+		case STROM_INT4OID: case STROM_DATEOID:
+			{ int32_t x; memcpy(&x, addr, 4); r.v.i = x; } break;
+		case STROM_FLOAT4OID:
+			memcpy(&r.v.f, addr, 4); break;
+		case STROM_FLOAT8OID:
+			memcpy(&r.v.d, addr, 8); break;
+		default:
+			memcpy(&r.v.i, addr, 8); break;
+	}
+	return r;
+}
+
+static double
+as_double(oracle_value v)
+{
+	if (v.type_oid == STROM_FLOAT4OID) return (double)v.v.f;
+	if (v.type_oid == STROM_FLOAT8OID) return v.v.d;
+	return (double)v.v.i;
+}
+
+static void
+int_range(int type, __int128 *lo, __int128 *hi)
+{
+	switch (type)
+	{
+		case STROM_INT2OID: *lo = -32768; *hi = 32767; break;
+		case STROM_INT4OID: case STROM_DATEOID: *lo = -2147483648LL; *hi = 2147483647LL; break;
+		default: *lo = -(__int128)9223372036854775807LL - 1; *hi = 9223372036854775807LL; break;
+	}
+}
+
+/* PostgreSQL float ordering: NaN sorts above everything, equals itself */
+static int
+float_cmp(double x, double y)
+{
+	if (isnan(x))
+		return isnan(y) ? 0 : 1;
+	if (isnan(y))
+		return -1;
+	return x < y ? -1 : (x > y ? 1 : 0);
+}
+
+static oracle_value
+store_float(int type, double v)
+{
+	oracle_value r;
+	memset(&r, 0, sizeof(r));
+	r.type_oid = type;
+	if (type == STROM_FLOAT4OID) r.v.f = (float)v; else r.v.d = v;
+	return r;
+}
+
+/* CHECKFLOATVAL (opencl_mathlib.h:24-28) */
+static int
+float_bad(double val, int inf_is_valid, int zero_is_valid)
+{
+	return (isinf(val) && !inf_is_valid) || (val == 0.0 && !zero_is_valid);
+}
+
+static oracle_value
+eval_func(const oracle_expr *e, oracle_value *a, int32_t *errcode)
+{
+	int		rt = e->type_oid;
+	int		i;
+	oracle_value r;
+
+	memset(&r, 0, sizeof(r));
+	r.type_oid = rt;
+	/* strict functions: any NULL argument -> NULL */
+	for (i = 0; i < e->nargs; i++)
+		if (a[i].isnull)
+			return make_null(rt);
+
+	switch (e->op)
+	{
+		case OP_ADD: case OP_SUB: case OP_MUL: case OP_DIV:
+			if (type_is_float(rt))
+			{
+				/* computed in the result type, like the device code */
+				double x = as_double(a[0]), y = as_double(a[1]), z;
+				if (rt == STROM_FLOAT4OID)
+				{
+					float fx = (float)x, fy = (float)y, fz;
+					if (e->op == OP_DIV && fy == 0.0f) return recheck(rt, errcode);
+					fz = e->op == OP_ADD ? fx + fy : e->op == OP_SUB ? fx - fy :
+						e->op == OP_MUL ? fx * fy : fx / fy;
+					z = fz;
+				}
+				else
+				{
+					if (e->op == OP_DIV && y == 0.0) return recheck(rt, errcode);
+					z = e->op == OP_ADD ? x + y : e->op == OP_SUB ? x - y :
+						e->op == OP_MUL ? x * y : x / y;
+				}
+				if (float_bad(z, isinf(x) || isinf(y),
+							  e->op == OP_MUL ? (x == 0.0 || y == 0.0) :
+							  e->op == OP_DIV ? (x == 0.0) : 1))
+					return recheck(rt, errcode);
+				return store_float(rt, z);
+			}
+			else
+			{
+				__int128 x = a[0].v.i, y = a[1].v.i, z, lo, hi;
+				int_range(rt, &lo, &hi);
+				if (e->op == OP_DIV)
+				{
+					if (y == 0) return recheck(rt, errcode);
+					z = x / y;
+				}
+				else
+					z = e->op == OP_ADD ? x + y : e->op == OP_SUB ? x - y : x * y;
+				if (z < lo || z > hi)
+					return recheck(rt, errcode);
+				r.v.i = (int64_t)z;
+				return r;
+			}
+		case OP_MOD:
+			if (a[1].v.i == 0) return recheck(rt, errcode);
+			r.v.i = (a[1].v.i == -1 ? 0 : a[0].v.i % a[1].v.i);
+			return r;
+		case OP_EQ: case OP_NE: case OP_LT: case OP_LE: case OP_GT: case OP_GE: case OP_CMP:
+			{
+				int c;
+				int t0 = a[0].type_oid, t1 = a[1].type_oid;
+				if (type_is_float(t0) || type_is_float(t1))
+					c = float_cmp(as_double(a[0]), as_double(a[1]));
+				else if ((t0 == STROM_DATEOID && t1 == STROM_TIMESTAMPOID) ||
+						 (t0 == STROM_TIMESTAMPOID && t1 == STROM_DATEOID))
+				{
+					/* the date is promoted (pgfn_date_timestamp,
+					 * opencl_timelib.h:289-320): +-infinity kept, a
+					 * product outside int64 goes back to the CPU */
+					int64_t l, rr, ts;
+					int		di = (t0 == STROM_DATEOID ? 0 : 1);
+					int64_t	dv = a[di].v.i;
+					if (dv == INT32_MIN) ts = INT64_MIN;
+					else if (dv == INT32_MAX) ts = INT64_MAX;
+					else if (__builtin_mul_overflow(dv, (int64_t)86400000000LL, &ts))
+						return recheck(rt, errcode);
+					l = (di == 0 ? ts : a[0].v.i);
+					rr = (di == 0 ? a[1].v.i : ts);
+					c = l < rr ? -1 : l > rr ? 1 : 0;
+				}
+				else if (t0 == STROM_BOOLOID)
+					c = ((a[0].v.i != 0) > (a[1].v.i != 0)) - ((a[0].v.i != 0) < (a[1].v.i != 0));
+				else if (t0 == STROM_BPCHAROID)
+					c = ((uint8_t)a[0].v.i > (uint8_t)a[1].v.i) - ((uint8_t)a[0].v.i < (uint8_t)a[1].v.i);
+				else
+					c = (a[0].v.i > a[1].v.i) - (a[0].v.i < a[1].v.i);
+				switch (e->op)
+				{
+					case OP_EQ: r.v.i = (c == 0); break;
+					case OP_NE: r.v.i = (c != 0); break;
+					case OP_LT: r.v.i = (c < 0); break;
+					case OP_LE: r.v.i = (c <= 0); break;
+					case OP_GT: r.v.i = (c > 0); break;
+					case OP_GE: r.v.i = (c >= 0); break;
+					default:    r.v.i = c; break;
+				}
+				return r;
+			}
+		case OP_UPLUS:
+			r = a[0];
+			return r;
+		case OP_UMINUS: case OP_ABS:
+			if (type_is_float(rt))
+			{
+				double x = as_double(a[0]);
+				return store_float(rt, e->op == OP_UMINUS ? -x : fabs(x));
+			}
+			else
+			{
+				__int128 x = a[0].v.i, lo, hi;
+				int_range(rt, &lo, &hi);
+				if (e->op == OP_UMINUS || x < 0)
+					x = -x;
+				if (x < lo || x > hi)
+					return recheck(rt, errcode);
+				r.v.i = (int64_t)x;
+				return r;
+			}
+		case OP_BITNOT:
+			r.v.i = (rt == STROM_INT2OID ? (int16_t)~a[0].v.i :
+					 rt == STROM_INT4OID ? (int32_t)~a[0].v.i : ~a[0].v.i);
+			return r;
+		case OP_BITAND: r.v.i = a[0].v.i & a[1].v.i; return r;
+		case OP_BITOR:  r.v.i = a[0].v.i | a[1].v.i; return r;
+		case OP_BITXOR: r.v.i = a[0].v.i ^ a[1].v.i; return r;
+		case OP_SHL:
+			if (rt == STROM_INT2OID) r.v.i = (int16_t)((int32_t)a[0].v.i << (a[1].v.i & 31));
+			else if (rt == STROM_INT4OID) r.v.i = (int32_t)((uint32_t)a[0].v.i << (a[1].v.i & 31));
+			else r.v.i = (int64_t)((uint64_t)a[0].v.i << (a[1].v.i & 63));
+			return r;
+		case OP_SHR:
+			if (rt == STROM_INT8OID) r.v.i = a[0].v.i >> (a[1].v.i & 63);
+			else r.v.i = a[0].v.i >> (a[1].v.i & 31);
+			if (rt == STROM_INT2OID) r.v.i = (int16_t)r.v.i;
+			return r;
+		case OP_CAST:
+			{
+				int st = a[0].type_oid;
+				if (type_is_float(rt))
+				{
+					if (st == STROM_FLOAT8OID && rt == STROM_FLOAT4OID)
+					{
+						float f = (float)a[0].v.d;
+						if (float_bad(f, isinf(a[0].v.d), a[0].v.d == 0.0))
+							return recheck(rt, errcode);
+						r.v.f = f;
+						return r;
+					}
+					return store_float(rt, as_double(a[0]));
+				}
+				else
+				{
+					__int128 lo, hi;
+					int_range(rt, &lo, &hi);
+					if (type_is_float(st))
+					{
+						/* dtoi4 / dtoi8: rint() then range check */
+						double x = rint(as_double(a[0]));
+						if (isnan(x) || x < (double)lo || x >= (double)hi + 1.0)
+							return recheck(rt, errcode);
+						r.v.i = (int64_t)x;
+						return r;
+					}
+					if (a[0].v.i < lo || a[0].v.i > hi)
+						return recheck(rt, errcode);
+					r.v.i = (st == STROM_BOOLOID ? (a[0].v.i != 0) : a[0].v.i);
+					return r;
+				}
+			}
+		case OP_CEIL:  r.v.d = ceil(a[0].v.d); return r;
+		case OP_FLOOR: r.v.d = floor(a[0].v.d); return r;
+		case OP_ROUND: r.v.d = rint(a[0].v.d); return r;
+		case OP_TRUNC: r.v.d = trunc(a[0].v.d); return r;
+		case OP_SIGN:  r.v.d = (a[0].v.d > 0) - (a[0].v.d < 0); return r;
+		case OP_SQRT:
+			if (a[0].v.d < 0) return recheck(rt, errcode);
+			r.v.d = sqrt(a[0].v.d);
+			return r;
+		case OP_PI:    r.v.d = 3.14159265358979323846; return r;
+		case OP_DATE_PLI: case OP_DATE_MII: case OP_INT_PL_DATE: case OP_DATE_MI:
+			{
+				__int128 x = a[0].v.i, y = a[1].v.i, z, lo, hi;
+				int_range(STROM_INT4OID, &lo, &hi);
+				z = (e->op == OP_DATE_MII || e->op == OP_DATE_MI) ? x - y : x + y;
+				if (z < lo || z > hi)
+					return recheck(rt, errcode);
+				r.v.i = (int64_t)z;
+				return r;
+			}
+		case OP_DATE_TO_TS:
+			if (a[0].v.i == INT32_MIN) r.v.i = INT64_MIN;
+			else if (a[0].v.i == INT32_MAX) r.v.i = INT64_MAX;
+			else if (__builtin_mul_overflow(a[0].v.i, (int64_t)86400000000LL, &r.v.i))
+				return recheck(rt, errcode);
+			return r;
+		case OP_TS_TO_DATE:
+			if (a[0].v.i == INT64_MIN) { r.v.i = INT32_MIN; return r; }
+			if (a[0].v.i == INT64_MAX) { r.v.i = INT32_MAX; return r; }
+			{
+				int64_t t = a[0].v.i, d = t / 86400000000LL;
+				if (t % 86400000000LL < 0) d--;
+				r.v.i = d;
+				return r;
+			}
+		case OP_TS_TO_TIME:
+			if (a[0].v.i == INT64_MIN || a[0].v.i == INT64_MAX)
+				return make_null(rt);
+			{
+				int64_t t = a[0].v.i % 86400000000LL;
+				if (t < 0) t += 86400000000LL;
+				r.v.i = t;
+				return r;
+			}
+		case OP_DATETIME_PL: case OP_TIMEDATE_PL:
+			{
+				int64_t dv = (e->op == OP_DATETIME_PL ? a[0].v.i : a[1].v.i);
+				int64_t tv = (e->op == OP_DATETIME_PL ? a[1].v.i : a[0].v.i);
+				if (dv == INT32_MIN) { r.v.i = INT64_MIN; return r; }
+				if (dv == INT32_MAX) { r.v.i = INT64_MAX; return r; }
+				if (__builtin_mul_overflow(dv, (int64_t)86400000000LL, &r.v.i) ||
+					__builtin_add_overflow(r.v.i, tv, &r.v.i))
+					return recheck(rt, errcode);
+				return r;
+			}
+	}
+	return make_null(rt);
+}
+
+typedef struct {
+	const kern_data_store *kds;
+	uint32_t		rowidx;
+	const uint64_t *ext_values;
+	const uint8_t  *ext_isnull;
+	int				n_ext;
+} eval_ctx;
+
+static oracle_value
+eval_node(const oracle_expr *e, const eval_ctx *cx, int32_t *errcode)
+{
+	oracle_value r, a[4];
+	int		i;
+
+	switch (e->kind)
+	{
+		case N_CONST:
+			return e->cval;
+		case N_PARAM:
+			if (e->attno < 0 || e->attno >= cx->n_ext ||
+				(cx->ext_isnull && cx->ext_isnull[e->attno]))
+				return make_null(e->type_oid);
+			return load_datum(e->type_oid, &cx->ext_values[e->attno]);
+		case N_VAR:
+			return load_datum(e->type_oid, oracle_get_datum(cx->kds, e->attno - 1, cx->rowidx));
+		case N_RELABEL:
+			return eval_node(e->args[0], cx, errcode);
+		case N_FUNC:
+			for (i = 0; i < e->nargs && i < 4; i++)
+				a[i] = eval_node(e->args[i], cx, errcode);
+			return eval_func(e, a, errcode);
+		case N_AND: case N_OR:
+			{
+				/* SQL three-valued logic; every argument is evaluated (the
+				 * device code does not short-circuit either, so error side
+				 * effects of later arguments are kept) */
+				int anynull = 0, decided = 0;
+				for (i = 0; i < e->nargs; i++)
+				{
+					oracle_value x = eval_node(e->args[i], cx, errcode);
+					if (x.isnull) anynull = 1;
+					else if (e->kind == N_AND ? !x.v.i : x.v.i != 0) decided = 1;
+				}
+				memset(&r, 0, sizeof(r));
+				r.type_oid = STROM_BOOLOID;
+				if (decided) r.v.i = (e->kind == N_OR);
+				else if (anynull) r.isnull = 1;
+				else r.v.i = (e->kind == N_AND);
+				return r;
+			}
+		case N_NOT:
+			r = eval_node(e->args[0], cx, errcode);
+			if (!r.isnull) r.v.i = !r.v.i;
+			return r;
+		case N_ISNULL: case N_ISNOTNULL:
+			{
+				oracle_value x = eval_node(e->args[0], cx, errcode);
+				memset(&r, 0, sizeof(r));
+				r.type_oid = STROM_BOOLOID;
+				r.v.i = (e->kind == N_ISNULL ? x.isnull : !x.isnull);
+				return r;
+			}
+		case N_BOOLTEST:
+			{
+				oracle_value x = eval_node(e->args[0], cx, errcode);
+				int t = (!x.isnull && x.v.i), f = (!x.isnull && !x.v.i);
+				memset(&r, 0, sizeof(r));
+				r.type_oid = STROM_BOOLOID;
+				switch (e->op)
+				{
+					case BT_TRUE: r.v.i = t; break;
+					case BT_NOT_TRUE: r.v.i = !t; break;
+					case BT_FALSE: r.v.i = f; break;
+					case BT_NOT_FALSE: r.v.i = !f; break;
+					case BT_UNKNOWN: r.v.i = x.isnull; break;
+					default: r.v.i = !x.isnull; break;
+				}
+				return r;
+			}
+		case N_CASE:
+			{
+				int npairs = (e->nargs - e->has_else) / 2;
+				oracle_value subj;
+				memset(&subj, 0, sizeof(subj));
+				if (e->case_arg)
+					subj = eval_node(e->case_arg, cx, errcode);
+				for (i = 0; i < npairs; i++)
+				{
+					oracle_value c = eval_node(e->args[2 * i], cx, errcode);
+					int hit;
+					if (e->case_arg)
+					{
+						if (subj.isnull || c.isnull) hit = 0;
+						else if (type_is_float(subj.type_oid) || type_is_float(c.type_oid))
+							hit = float_cmp(as_double(subj), as_double(c)) == 0;
+						else hit = (subj.v.i == c.v.i);
+					}
+					else
+						hit = (!c.isnull && c.v.i);
+					if (hit)
+						return eval_node(e->args[2 * i + 1], cx, errcode);
+				}
+				if (e->has_else)
+					return eval_node(e->args[e->nargs - 1], cx, errcode);
+				return make_null(e->type_oid);
+			}
+	}
+	return make_null(e->type_oid);
+}
+
+oracle_value
+oracle_expr_eval(const oracle_expr *expr, const kern_data_store *kds, uint32_t rowidx,
+				 const uint64_t *ext_values, const uint8_t *ext_isnull, int n_ext,
+				 int32_t *errcode)
+{
+	eval_ctx cx = { kds, rowidx, ext_values, ext_isnull, n_ext };
+	return eval_node(expr, &cx, errcode);
+}
+
+/* ====================================================================== *
+ * GpuScan: gpuscan_qual + gpuscan_writeback_row_error
+ *          (opencl_gpuscan.h:98-177)
+ * ====================================================================== */
+int32_t
+oracle_gpuscan(const char *qual,
+			   const uint64_t *ext_values, const uint8_t *ext_isnull, int n_ext,
+			   const kern_data_store *kds, const kern_row_map *krowmap,
+			   int32_t *results, uint32_t *p_nitems,
+			   char *errbuf, size_t errlen)
+{
+	oracle_expr *expr = oracle_expr_parse(qual, errbuf, errlen);
+	int32_t		chunk_error = StromError_Success;
+	uint32_t	nitems = 0, i, nrows;
+	int			use_map = (krowmap && krowmap->nvalids >= 0);
+
+	if (!expr)
+		return StromError_BadRequestMessage;
+	if (expr->type_oid != STROM_BOOLOID)
+	{
+		snprintf(errbuf, errlen, "qualifier is not boolean");
+		oracle_expr_free(expr);
+		return StromError_BadRequestMessage;
+	}
+	nrows = use_map ? (uint32_t)krowmap->nvalids : kds->nitems;
+	for (i = 0; i < nrows; i++)
+	{
+		uint32_t	row = use_map ? (uint32_t)krowmap->rindex[i] : i;
+		int32_t		errcode = StromError_Success;
+		oracle_value rc = oracle_expr_eval(expr, kds, row, ext_values, ext_isnull, n_ext, &errcode);
+
+		set_error(&errcode, (!rc.isnull && rc.v.i != 0)
+				  ? StromError_Success : StromError_RowFiltered);
+		if (errcode == StromError_Success)
+			results[nitems++] = (int32_t)(row + 1);
+		else if (errcode == StromError_CpuReCheck)
+			results[nitems++] = -(int32_t)(row + 1);
+		else if (StromErrorIsSignificant(errcode) && chunk_error == StromError_Success)
+			chunk_error = errcode;
+	}
+	*p_nitems = nitems;
+	oracle_expr_free(expr);
+	return chunk_error;
+}
+
+void
+oracle_get_layout(oracle_layout *out)
+{
+	out->sizeof_kern_data_store_head = offsetof(kern_data_store, colmeta);
+	out->sizeof_kern_colmeta = sizeof(kern_colmeta);
+	out->sizeof_kern_rowitem = sizeof(kern_rowitem);
+	out->sizeof_kern_blkitem = sizeof(kern_blkitem);
+	out->offsetof_resultbuf_results = offsetof(kern_resultbuf, results);
+	out->sizeof_kern_parambuf_head = offsetof(kern_parambuf, poffset);
+	out->sizeof_kern_hashentry = sizeof(kern_hashentry);
+	out->offsetof_hashentry_htup = offsetof(kern_hashentry, htup);
+	out->offsetof_htup_t_bits = offsetof(HeapTupleHeaderData, t_bits);
+	out->sizeof_kern_multihash_head = offsetof(kern_multihash, htable_offset);
+	out->offsetof_gpupreagg_kparams = offsetof(kern_gpupreagg, kparams);
+	out->sizeof_kern_coldir = sizeof(kern_coldir);
+}

@@ -1,0 +1,92 @@
+/*
+ * strom_oracle.h -- CPU oracle for the GpuScan / GpuHashJoin / GpuPreAgg path
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under oracle/ is linked into, loaded
+ * by or called from the product (pg_strom_amd/, libstrom_hip.so).  Only
+ * tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg use it,
+ * as the checker / the timed CPU baseline.
+ *
+ * It restates, in plain single-threaded C, what the reference computes for
+ * one chunk -- tuple-at-a-time over the reference's own chunk formats,
+ * the way PostgreSQL's executor (the reference's test oracle,
+ * input/make_expected.sh:22-28) and the reference's device code do:
+ *
+ *   oracle_get_datum      kern_get_datum*        opencl_common.h:817-981
+ *   expression evaluator  generated device code  codegen.c:1065-1392 with
+ *                         the arithmetic rules of opencl_mathlib.h:34-812
+ *   oracle_gpuscan        gpuscan_qual +         opencl_gpuscan.h:98-177
+ *                         gpuscan_writeback_row_error
+ *
+ * Pinning: see oracle/README.md -- struct sizes/offsets against SURVEY.md
+ * Appendix A (compiled from the reference headers), aggregate results
+ * against the reference's expected/<suite>.out files (tests/golden/).
+ */
+#ifndef STROM_ORACLE_H
+#define STROM_ORACLE_H
+
+#include "strom_kds.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* one SQL value */
+typedef struct {
+	int32_t		type_oid;
+	int32_t		isnull;
+	union {
+		int64_t		i;
+		double		d;
+		float		f;
+		uint64_t	u;
+	} v;
+} oracle_value;
+
+typedef struct oracle_expr oracle_expr;
+
+/* parse the S-expression IR of include/strom_codegen.h; NULL + message on error */
+oracle_expr *oracle_expr_parse(const char *text, char *errbuf, size_t errlen);
+void		 oracle_expr_free(oracle_expr *expr);
+/* evaluate on row 'rowidx' of kds; *errcode accumulates with the
+ * STROM_SET_ERROR priority rule */
+oracle_value oracle_expr_eval(const oracle_expr *expr,
+							  const kern_data_store *kds, uint32_t rowidx,
+							  const uint64_t *ext_values, const uint8_t *ext_isnull,
+							  int n_ext, int32_t *errcode);
+
+/* address of a datum or NULL (SQL NULL / out of range), any format */
+const void  *oracle_get_datum(const kern_data_store *kds, uint32_t colidx, uint32_t rowidx);
+
+/*
+ * GpuScan over one chunk.  results[] must have room for nitems (or
+ * nvalids) entries; it receives +(row+1) for passing rows and -(row+1)
+ * for rows that need a CPU recheck, in ascending row order.  Returns the
+ * chunk errcode (0 or the first significant error).
+ */
+int32_t		oracle_gpuscan(const char *qual,
+						   const uint64_t *ext_values, const uint8_t *ext_isnull, int n_ext,
+						   const kern_data_store *kds, const kern_row_map *krowmap,
+						   int32_t *results, uint32_t *p_nitems,
+						   char *errbuf, size_t errlen);
+
+/* sizes / offsets of the wire structs, for the layout tests */
+typedef struct {
+	uint32_t	sizeof_kern_data_store_head;
+	uint32_t	sizeof_kern_colmeta;
+	uint32_t	sizeof_kern_rowitem;
+	uint32_t	sizeof_kern_blkitem;
+	uint32_t	offsetof_resultbuf_results;
+	uint32_t	sizeof_kern_parambuf_head;
+	uint32_t	sizeof_kern_hashentry;
+	uint32_t	offsetof_hashentry_htup;
+	uint32_t	offsetof_htup_t_bits;
+	uint32_t	sizeof_kern_multihash_head;
+	uint32_t	offsetof_gpupreagg_kparams;
+	uint32_t	sizeof_kern_coldir;
+} oracle_layout;
+void		oracle_get_layout(oracle_layout *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,92 @@
+"""ctypes binding of oracle/liboracle.so -- the CPU checker.  Imported by
+tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg only."""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+LIB_PATH = os.path.join(ORACLE_DIR, "liboracle.so")
+
+
+def build_oracle():
+    subprocess.check_call(["make", "-s", "-C", ORACLE_DIR, "liboracle.so"])
+    return LIB_PATH
+
+
+class oracle_layout(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_uint32) for n in (
+        "sizeof_kern_data_store_head", "sizeof_kern_colmeta", "sizeof_kern_rowitem",
+        "sizeof_kern_blkitem", "offsetof_resultbuf_results", "sizeof_kern_parambuf_head",
+        "sizeof_kern_hashentry", "offsetof_hashentry_htup", "offsetof_htup_t_bits",
+        "sizeof_kern_multihash_head", "offsetof_gpupreagg_kparams", "sizeof_kern_coldir")]
+
+
+_lib = None
+
+
+def load():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            build_oracle()
+        lib = ctypes.CDLL(LIB_PATH)
+        lib.oracle_gpuscan.restype = ctypes.c_int32
+        lib.oracle_gpuscan.argtypes = [ctypes.c_char_p, ctypes.c_void_p, ctypes.c_void_p,
+                                       ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
+                                       ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint32),
+                                       ctypes.c_char_p, ctypes.c_size_t]
+        lib.oracle_get_layout.argtypes = [ctypes.POINTER(oracle_layout)]
+        _lib = lib
+    return _lib
+
+
+def datum_image(v):
+    if v is None:
+        return 0
+    if isinstance(v, np.float32):
+        return int(np.array([v], dtype=np.float32).view(np.uint32)[0])
+    if isinstance(v, (float, np.floating)):
+        return int(np.array([v], dtype=np.float64).view(np.uint64)[0])
+    return int(v) & 0xFFFFFFFFFFFFFFFF
+
+
+def ext_arrays(ext_params):
+    n = len(ext_params)
+    vals = np.zeros(max(n, 1), dtype=np.uint64)
+    nulls = np.zeros(max(n, 1), dtype=np.uint8)
+    for i, v in enumerate(ext_params):
+        vals[i] = datum_image(v)
+        nulls[i] = 1 if v is None else 0
+    return vals, nulls, n
+
+
+def gpuscan(qual, kds_buf, ext_params=(), row_map=None, nitems=None):
+    """returns (errcode, results int32 array) in ascending row order"""
+    lib = load()
+    vals, nulls, n = ext_arrays(ext_params)
+    if nitems is None:
+        nitems = int(np.frombuffer(kds_buf[20:24].tobytes(), dtype=np.uint32)[0])
+    rm = None
+    room = nitems
+    if row_map is not None:
+        rm = np.concatenate([np.array([len(row_map)], dtype=np.int32),
+                             np.ascontiguousarray(row_map, dtype=np.int32)])
+        room = len(row_map)
+    results = np.zeros(max(room, 1), dtype=np.int32)
+    cnt = ctypes.c_uint32(0)
+    err = ctypes.create_string_buffer(256)
+    rc = lib.oracle_gpuscan(qual.encode(), vals.ctypes.data, nulls.ctypes.data, n,
+                            kds_buf.ctypes.data, rm.ctypes.data if rm is not None else None,
+                            results.ctypes.data, ctypes.byref(cnt), err, 256)
+    if rc == 101 and err.value:
+        raise ValueError("oracle: " + err.value.decode())
+    return rc, results[:cnt.value].copy()
+
+
+def layout():
+    out = oracle_layout()
+    load().oracle_get_layout(ctypes.byref(out))
+    return {n: getattr(out, n) for n, _ in oracle_layout._fields_}
