@@ -88,7 +88,9 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--rows", type=int, default=100_000_000, help="rows per GPU")
-    ap.add_argument("--chunk-rows", type=int, default=25_000_000)
+    ap.add_argument("--chunk-rows", type=int, default=100_000_000)
+    ap.add_argument("--window", type=int, default=2,
+                    help="requests kept in flight (pg_strom.max_async_chunks)")
     ap.add_argument("--selectivity", type=float, default=0.10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -141,32 +143,45 @@ def main():
     kern_ns = []
     nitems_seen = []
 
-    def one_step(record):
-        pend = [scan.submit(ds, flags=STROM_RESULTS_ON_DEVICE) for ds in chunks]
-        total = 0
-        for p in pend:
-            res = scan.collect(p)
-            total += res.nitems
+    import collections
+
+    def run_steps(nsteps, record):
+        """nsteps passes over the table; up to --window requests in flight,
+        the way pgstrom_fetch_gpuscan keeps chunks in flight (gpuscan.c:
+        1087-1108).  Returns rows selected per step (must be identical)."""
+        window = collections.deque()
+        totals = [0] * nsteps
+
+        def retire():
+            step, pend = window.popleft()
+            res = scan.collect(pend)
+            totals[step] += res.nitems
             if record:
                 kern_ns.append(res.perfmon["time_kern_exec_ns"])
                 nitems_seen.append(res.nitems)
-        return total
+
+        for step in range(nsteps):
+            for ds in chunks:
+                window.append((step, scan.submit(ds, flags=STROM_RESULTS_ON_DEVICE)))
+                if len(window) > args.window:
+                    retire()
+        while window:
+            retire()
+        return totals
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        got = one_step(False)
+    for got in run_steps(args.warmup, False):
         assert got == nsel_expect, "row count mismatch: %d != %d" % (got, nsel_expect)
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        got = one_step(True)
+    totals = run_steps(args.steps, True)
     barrier()
     elapsed = time.perf_counter() - t0
-    assert got == nsel_expect
+    assert all(t == nsel_expect for t in totals)
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -201,6 +216,7 @@ def main():
                 "rows_per_gpu": nrows,
                 "chunk_rows": args.chunk_rows,
                 "chunks_per_gpu": len(chunks),
+                "requests_in_flight": args.window,
                 "selectivity": nsel_expect / nrows,
                 "format": "KDS_FORMAT_COLUMN",
                 "parallelism": "row-range x%d" % ngpus,

@@ -68,6 +68,37 @@ typedef struct {
 int		strom_codegen_gpuscan(const char *qual, strom_codegen_result *out);
 
 /*
+ * GpuPreAgg: gpupreagg_codegen (gpupreagg.c:1902-1943) -- qual_eval
+ * (1851-1900), the per-target projection of partial-aggregate inputs
+ * (1450-1837) and the key / aggregate catalogue the kernels switch on
+ * (keycomp 1181-1284, aggcalc 1320-1440).  The target list is written
+ *
+ *   (gpupreagg [(qual BOOL-EXPR)] TARGET ...)
+ *   TARGET := (key EXPR)                     grouping key (a Var in the reference)
+ *           | (nrows BOOL-EXPR ...)          1 when every argument is TRUE, else 0
+ *           | (psum EXPR) | (pmin EXPR) | (pmax EXPR)
+ *           | (psum_x2 EXPR)                 EXPR*EXPR as float8
+ *           | (pcov_x F X Y) (pcov_y ..) (pcov_x2 ..) (pcov_y2 ..) (pcov_xy ..)
+ *
+ * in output-column order; these are the pgstrom.* partial functions of
+ * pg_strom--1.0.sql:232-246.  targets[] describes each output column.
+ */
+#define STROM_PREAGG_KEY		1
+#define STROM_PREAGG_NROWS		2
+#define STROM_PREAGG_PSUM		3
+#define STROM_PREAGG_PMIN		4
+#define STROM_PREAGG_PMAX		5
+
+typedef struct {
+	int32_t		kind;			/* STROM_PREAGG_* (psum_x2 / pcov_* are PSUM) */
+	int32_t		type_oid;		/* type of the partial value */
+} strom_preagg_target;
+
+int		strom_codegen_gpupreagg(const char *spec, strom_codegen_result *out,
+								strom_preagg_target *targets, int max_targets,
+								int *p_ntargets);
+
+/*
  * Can this expression run on the device?  (pgstrom_codegen_available_
  * expression, codegen.c:1631-1759.)  1 yes, 0 no; errmsg (if not NULL)
  * receives a malloc'ed reason.

@@ -20,6 +20,7 @@
 #define STROM_HIP_H
 
 #include "strom_kds.h"
+#include "strom_codegen.h"
 
 #ifdef __cplusplus
 extern "C" {
@@ -167,6 +168,71 @@ strom_task *strom_submit_gpuscan(strom_devprog_key key,
 								 uint32_t flags,
 								 strom_done_cb done, void *arg,
 								 int *p_errcode);
+
+/* ------------------------------------------------------------------ *
+ * GpuPreAgg
+ *
+ * The reference reduces one chunk per request and ships one partial row
+ * per (work-group, group) back to the backend, whose Agg node finishes
+ * with the pgstrom.* final aggregates (gpupreagg.c:2665-2776, 3849-4240;
+ * pg_strom--1.0.sql:247-401).  Here a strom_gpupreagg is a reduction in
+ * progress on one GPU: chunks are folded into a table that stays in HBM
+ * and strom_gpupreagg_fetch() returns ONE partial row per group in the
+ * reference's result format (TUPSLOT kern_data_store, group keys and
+ * partial values in target-list order).  Those rows feed the same final
+ * aggregates, so the final result is the reference's.  With several GPUs
+ * the per-GPU tables have identical layout and are merged with an RCCL
+ * all-reduce on the table itself (strom_gpupreagg_table_devptr).
+ *
+ * nrows() partials are int8 in the fetched rows (the reference's are
+ * int4 per chunk; a whole-table count does not fit int4).
+ * ------------------------------------------------------------------ */
+typedef struct strom_gpupreagg strom_gpupreagg;
+
+#define STROM_PREAGG_MAXKEYS	8
+typedef struct {
+	int32_t		nkeys;
+	int64_t		key_min[STROM_PREAGG_MAXKEYS];
+	uint32_t	key_range[STROM_PREAGG_MAXKEYS];	/* max - min + 1 */
+} strom_preagg_domain;
+
+/* domain == NULL: taken from the first chunk's zone maps (COLUMN) or a
+ * min/max pre-pass (other formats).  table_devptr == NULL: the runtime
+ * allocates the resident table; otherwise the caller's buffer of
+ * strom_gpupreagg_table_length() bytes is used (e.g. a torch tensor that
+ * RCCL reduces in place). */
+strom_gpupreagg *strom_gpupreagg_create(strom_devprog_key key,
+										const strom_preagg_target *targets, int ntargets,
+										const kern_parambuf *kparams,
+										const strom_preagg_domain *domain,
+										int dindex, int *p_errcode);
+size_t		strom_gpupreagg_table_length(strom_gpupreagg *sess);
+int			strom_gpupreagg_bind_table(strom_gpupreagg *sess, void *table_devptr);
+void	   *strom_gpupreagg_table_devptr(strom_gpupreagg *sess);
+uint32_t	strom_gpupreagg_num_groups(strom_gpupreagg *sess);
+/* byte offset / element kind of target 'resno' inside the table:
+ * *p_bits_off  offset of its has-value bitmap (seen bitmap for keys)
+ * *p_vals_off  offset of its 8-byte value array (0 for keys)          */
+int			strom_gpupreagg_table_layout(strom_gpupreagg *sess, int resno,
+										 size_t *p_bits_off, size_t *p_vals_off);
+/*
+ * fold one chunk  <- clserv_process_gpupreagg (gpupreagg.c:3849-4240).
+ * The task's errcode is 0, StromError_CpuReCheck (the chunk was NOT folded:
+ * the caller re-does it on the CPU like gpupreagg_next_tuple_fallback,
+ * gpupreagg.c:2507-2607) or a significant error.
+ */
+strom_task *strom_submit_gpupreagg(strom_gpupreagg *sess,
+								   const kern_data_store *kds,
+								   strom_dstore *kds_dev,
+								   const kern_row_map *krowmap,
+								   strom_done_cb done, void *arg,
+								   int *p_errcode);
+/* partial rows, one per group, as a TUPSLOT kern_data_store.  Returns the
+ * bytes needed when dest == NULL; the number of groups (>= 0) otherwise;
+ * a negative StromError on failure. */
+long		strom_gpupreagg_fetch(strom_gpupreagg *sess, kern_data_store *dest, size_t destlen);
+void		strom_gpupreagg_reset(strom_gpupreagg *sess);
+void		strom_gpupreagg_release(strom_gpupreagg *sess);
 
 /* block until the request finished; returns its errcode.  Frees the task. */
 int			strom_task_wait(strom_task *task, strom_perfmon *pfm_out);

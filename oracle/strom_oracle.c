@@ -1254,3 +1254,340 @@ oracle_get_layout(oracle_layout *out)
 	out->offsetof_gpupreagg_kparams = offsetof(kern_gpupreagg, kparams);
 	out->sizeof_kern_coldir = sizeof(kern_coldir);
 }
+
+/* ====================================================================== *
+ * GpuPreAgg: one chunk -> one partial row per group
+ *
+ * Restates the net effect of gpupreagg_preparation + sort + reduction
+ * (opencl_gpupreagg.h:380-608) for one chunk: rows failing the pulled-up
+ * qual are dropped; per surviving row the partial inputs are
+ *     nrows(args..)  1 when every argument is TRUE else 0   -> summed
+ *     psum(x)        x, NULLs ignored, NULL when no input    -> summed
+ *     pmin/pmax(x)   likewise                                -> min / max
+ * (gpupreagg.c:1495-1748; PSUM/PMIN/PMAX rules opencl_gpupreagg.h:862-987);
+ * groups are formed on the key values with NULL keys grouped together
+ * (keycomp, gpupreagg.c:1230-1249).  Any CpuReCheck raised by a row makes
+ * the whole chunk CpuReCheck (gpupreagg.c:2746-2750): status 2, no rows.
+ * Sums are accumulated sequentially in row order: int8 exactly (with the
+ * reference's overflow -> CpuReCheck rule), floats in double.
+ * ====================================================================== */
+enum { T_KEY = 1, T_NROWS, T_PSUM, T_PMIN, T_PMAX };
+
+typedef struct {
+	int			kind;
+	int			type_oid;
+	int			nexprs;
+	oracle_expr *exprs[4];
+	int			pcov;			/* 0 none, 1 x, 2 y, 3 x2, 4 y2, 5 xy */
+	int			x2;				/* psum_x2 */
+} preagg_target;
+
+typedef struct {
+	oracle_expr *qual;
+	int			ntargets;
+	preagg_target targets[64];
+} preagg_spec;
+
+static void
+preagg_spec_free(preagg_spec *sp)
+{
+	int i, j;
+	oracle_expr_free(sp->qual);
+	for (i = 0; i < sp->ntargets; i++)
+		for (j = 0; j < sp->targets[i].nexprs; j++)
+			oracle_expr_free(sp->targets[i].exprs[j]);
+}
+
+static int
+preagg_spec_parse(const char *text, preagg_spec *sp, char *errbuf, size_t errlen)
+{
+	parser ps = { text, errbuf, errlen, 0 };
+	char	head[32];
+
+	memset(sp, 0, sizeof(*sp));
+	if (!expect_char(&ps, '(') || !read_atom(&ps, head, sizeof(head)) || strcmp(head, "gpupreagg"))
+	{
+		perr(&ps, "(gpupreagg ...) expected");
+		return 0;
+	}
+	while (!peek_close(&ps) && !ps.failed)
+	{
+		preagg_target *t;
+		if (!expect_char(&ps, '(') || !read_atom(&ps, head, sizeof(head)))
+			break;
+		if (!strcmp(head, "qual"))
+		{
+			sp->qual = parse_expr(&ps);
+			if (!sp->qual || !expect_char(&ps, ')'))
+				break;
+			continue;
+		}
+		if (sp->ntargets >= 64)
+		{
+			perr(&ps, "too many targets");
+			break;
+		}
+		t = &sp->targets[sp->ntargets++];
+		if (!strcmp(head, "key")) t->kind = T_KEY;
+		else if (!strcmp(head, "nrows")) t->kind = T_NROWS;
+		else if (!strcmp(head, "psum")) t->kind = T_PSUM;
+		else if (!strcmp(head, "pmin")) t->kind = T_PMIN;
+		else if (!strcmp(head, "pmax")) t->kind = T_PMAX;
+		else if (!strcmp(head, "psum_x2")) { t->kind = T_PSUM; t->x2 = 1; }
+		else if (!strncmp(head, "pcov_", 5))
+		{
+			t->kind = T_PSUM;
+			t->pcov = !strcmp(head + 5, "x") ? 1 : !strcmp(head + 5, "y") ? 2 :
+				!strcmp(head + 5, "x2") ? 3 : !strcmp(head + 5, "y2") ? 4 :
+				!strcmp(head + 5, "xy") ? 5 : -1;
+			if (t->pcov < 0) { perr(&ps, "unknown target %s", head); break; }
+		}
+		else { perr(&ps, "unknown target %s", head); break; }
+		while (!peek_close(&ps) && !ps.failed && t->nexprs < 4)
+		{
+			t->exprs[t->nexprs] = parse_expr(&ps);
+			if (!t->exprs[t->nexprs])
+				break;
+			t->nexprs++;
+		}
+		if (ps.failed || !expect_char(&ps, ')'))
+			break;
+		if (t->kind == T_NROWS) t->type_oid = STROM_INT4OID;
+		else if (t->x2 || t->pcov) t->type_oid = STROM_FLOAT8OID;
+		else if (t->nexprs == 1) t->type_oid = t->exprs[0]->type_oid;
+		else { perr(&ps, "%s takes one argument", head); break; }
+		if (t->pcov && t->nexprs != 3) { perr(&ps, "pcov takes (filter x y)"); break; }
+	}
+	if (!ps.failed)
+		expect_char(&ps, ')');
+	if (ps.failed)
+	{
+		preagg_spec_free(sp);
+		return 0;
+	}
+	return 1;
+}
+
+typedef struct {
+	int64_t	   *keyval;		/* [nkeys] */
+	uint8_t	   *keynull;
+	oracle_value *acc;		/* [naggs] */
+} preagg_group;
+
+static double
+float_of(oracle_value v)
+{
+	return v.type_oid == STROM_FLOAT4OID ? (double)v.v.f : v.v.d;
+}
+
+int32_t
+oracle_gpupreagg(const char *spec_text,
+				 const uint64_t *ext_values, const uint8_t *ext_isnull, int n_ext,
+				 const kern_data_store *kds, const kern_row_map *krowmap,
+				 uint32_t max_groups,
+				 uint64_t *out_values,	/* [max_groups * ntargets] raw 8-byte images */
+				 uint8_t *out_isnull,	/* [max_groups * ntargets] */
+				 uint32_t *p_ngroups,
+				 char *errbuf, size_t errlen)
+{
+	preagg_spec	sp;
+	int			nkeys = 0, naggs = 0, key_of[64], agg_of[64];
+	preagg_group *groups = NULL;
+	uint32_t	ngroups = 0, cap = 0, i, nrows;
+	int			t, use_map = (krowmap && krowmap->nvalids >= 0);
+	int32_t		status = StromError_Success;
+
+	*p_ngroups = 0;
+	if (!preagg_spec_parse(spec_text, &sp, errbuf, errlen))
+		return StromError_BadRequestMessage;
+	for (t = 0; t < sp.ntargets; t++)
+	{
+		if (sp.targets[t].kind == T_KEY) key_of[nkeys++] = t;
+		else agg_of[naggs++] = t;
+	}
+	nrows = use_map ? (uint32_t)krowmap->nvalids : kds->nitems;
+	for (i = 0; i < nrows && status == StromError_Success; i++)
+	{
+		uint32_t	row = use_map ? (uint32_t)krowmap->rindex[i] : i;
+		int32_t		errcode = StromError_Success;
+		int64_t		kv[64];
+		uint8_t		kn[64];
+		oracle_value av[64];
+		uint32_t	g;
+		int			k, a;
+
+		if (sp.qual)
+		{
+			oracle_value rc = oracle_expr_eval(sp.qual, kds, row, ext_values, ext_isnull, n_ext, &errcode);
+			if (errcode == StromError_Success && (rc.isnull || !rc.v.i))
+				continue;
+		}
+		for (k = 0; k < nkeys; k++)
+		{
+			oracle_value v = oracle_expr_eval(sp.targets[key_of[k]].exprs[0], kds, row,
+											  ext_values, ext_isnull, n_ext, &errcode);
+			kn[k] = (uint8_t)v.isnull;
+			kv[k] = v.isnull ? 0 : (type_is_float(v.type_oid) ? (int64_t)v.v.u : v.v.i);
+		}
+		for (a = 0; a < naggs; a++)
+		{
+			preagg_target *tg = &sp.targets[agg_of[a]];
+			oracle_value r;
+			memset(&r, 0, sizeof(r));
+			r.type_oid = tg->type_oid;
+			if (tg->kind == T_NROWS)
+			{
+				int ok = 1, j;
+				for (j = 0; j < tg->nexprs; j++)
+				{
+					oracle_value x = oracle_expr_eval(tg->exprs[j], kds, row, ext_values, ext_isnull, n_ext, &errcode);
+					ok &= (!x.isnull && x.v.i != 0);
+				}
+				r.v.i = ok;
+			}
+			else if (tg->pcov)
+			{
+				oracle_value f = oracle_expr_eval(tg->exprs[0], kds, row, ext_values, ext_isnull, n_ext, &errcode);
+				oracle_value x = oracle_expr_eval(tg->exprs[1], kds, row, ext_values, ext_isnull, n_ext, &errcode);
+				oracle_value y = oracle_expr_eval(tg->exprs[2], kds, row, ext_values, ext_isnull, n_ext, &errcode);
+				if (f.isnull || !f.v.i || x.isnull || y.isnull)
+					r.isnull = 1;
+				else
+				{
+					double p = (tg->pcov == 1 ? x.v.d : tg->pcov == 2 ? y.v.d :
+								tg->pcov == 3 ? x.v.d * x.v.d : tg->pcov == 4 ? y.v.d * y.v.d :
+								x.v.d * y.v.d);
+					if (tg->pcov >= 3 && float_bad(p, isinf(x.v.d) || isinf(y.v.d),
+												   x.v.d == 0.0 || y.v.d == 0.0))
+					{
+						set_error(&errcode, StromError_CpuReCheck);
+						r.isnull = 1;
+					}
+					r.v.d = p;
+				}
+			}
+			else
+			{
+				r = oracle_expr_eval(tg->exprs[0], kds, row, ext_values, ext_isnull, n_ext, &errcode);
+				if (tg->x2 && !r.isnull)
+				{
+					double x = r.v.d, p = x * x;
+					if (float_bad(p, isinf(x), x == 0.0))
+					{
+						set_error(&errcode, StromError_CpuReCheck);
+						r.isnull = 1;
+					}
+					r.v.d = p;
+				}
+			}
+			av[a] = r;
+		}
+		if (errcode != StromError_Success)
+		{
+			set_error(&status, errcode);
+			break;
+		}
+		/* find or create the group (linear search: fixtures have few groups) */
+		for (g = 0; g < ngroups; g++)
+		{
+			int same = 1;
+			for (k = 0; k < nkeys && same; k++)
+				same = (groups[g].keynull[k] == kn[k] && (kn[k] || groups[g].keyval[k] == kv[k]));
+			if (same)
+				break;
+		}
+		if (g == ngroups)
+		{
+			if (ngroups == cap)
+			{
+				cap = cap ? cap * 2 : 64;
+				groups = realloc(groups, sizeof(preagg_group) * cap);
+			}
+			groups[g].keyval = malloc(sizeof(int64_t) * (nkeys + 1));
+			groups[g].keynull = malloc(nkeys + 1);
+			groups[g].acc = calloc(naggs + 1, sizeof(oracle_value));
+			memcpy(groups[g].keyval, kv, sizeof(int64_t) * nkeys);
+			memcpy(groups[g].keynull, kn, nkeys);
+			for (a = 0; a < naggs; a++)
+			{
+				groups[g].acc[a].type_oid = sp.targets[agg_of[a]].type_oid;
+				groups[g].acc[a].isnull = (sp.targets[agg_of[a]].kind != T_NROWS);
+			}
+			ngroups++;
+		}
+		for (a = 0; a < naggs; a++)
+		{
+			preagg_target *tg = &sp.targets[agg_of[a]];
+			oracle_value *acc = &groups[g].acc[a];
+			if (tg->kind == T_NROWS)
+			{
+				acc->v.i += av[a].v.i;
+				continue;
+			}
+			if (av[a].isnull)
+				continue;
+			if (type_is_float(tg->type_oid))
+			{
+				double x = float_of(av[a]);
+				if (acc->isnull) acc->v.d = x;
+				else if (tg->kind == T_PSUM) acc->v.d += x;
+				else if (tg->kind == T_PMIN) { if (float_cmp(x, acc->v.d) < 0) acc->v.d = x; }
+				else { if (float_cmp(x, acc->v.d) > 0) acc->v.d = x; }
+			}
+			else
+			{
+				int64_t x = av[a].v.i;
+				if (acc->isnull) acc->v.i = x;
+				else if (tg->kind == T_PSUM)
+				{
+					if (__builtin_add_overflow(acc->v.i, x, &acc->v.i))
+						set_error(&status, StromError_CpuReCheck);
+				}
+				else if (tg->kind == T_PMIN) { if (x < acc->v.i) acc->v.i = x; }
+				else { if (x > acc->v.i) acc->v.i = x; }
+				/* the device screens |partial| >= 2^62 conservatively */
+				if (tg->kind == T_PSUM && (x >= (1LL << 62) || x <= -(1LL << 62)))
+					set_error(&status, StromError_CpuReCheck);
+			}
+			acc->isnull = 0;
+		}
+	}
+	if (status == StromError_Success)
+	{
+		if (ngroups > max_groups)
+			status = StromError_DataStoreNoSpace;
+		else
+		{
+			uint32_t g;
+			for (g = 0; g < ngroups; g++)
+			{
+				int k, a;
+				for (k = 0; k < nkeys; k++)
+				{
+					size_t o = (size_t)g * sp.ntargets + key_of[k];
+					out_isnull[o] = groups[g].keynull[k];
+					out_values[o] = (uint64_t)groups[g].keyval[k];
+				}
+				for (a = 0; a < naggs; a++)
+				{
+					size_t o = (size_t)g * sp.ntargets + agg_of[a];
+					oracle_value *acc = &groups[g].acc[a];
+					out_isnull[o] = (uint8_t)acc->isnull;
+					if (acc->isnull) out_values[o] = 0;
+					else if (type_is_float(acc->type_oid)) memcpy(&out_values[o], &acc->v.d, 8);
+					else out_values[o] = (uint64_t)acc->v.i;
+				}
+			}
+			*p_ngroups = ngroups;
+		}
+	}
+	for (i = 0; i < ngroups; i++)
+	{
+		free(groups[i].keyval);
+		free(groups[i].keynull);
+		free(groups[i].acc);
+	}
+	free(groups);
+	preagg_spec_free(&sp);
+	return status;
+}

@@ -69,6 +69,21 @@ int32_t		oracle_gpuscan(const char *qual,
 						   int32_t *results, uint32_t *p_nitems,
 						   char *errbuf, size_t errlen);
 
+/*
+ * GpuPreAgg over one chunk: one partial row per group.  out_values /
+ * out_isnull are [max_groups x ntargets] in target-list order; values are
+ * raw 8-byte images (int64, or the bits of a double for float partials;
+ * float4 partials are carried as double).  Returns 0, StromError_CpuReCheck
+ * (nothing produced) or another error.
+ */
+int32_t		oracle_gpupreagg(const char *spec,
+							 const uint64_t *ext_values, const uint8_t *ext_isnull, int n_ext,
+							 const kern_data_store *kds, const kern_row_map *krowmap,
+							 uint32_t max_groups,
+							 uint64_t *out_values, uint8_t *out_isnull,
+							 uint32_t *p_ngroups,
+							 char *errbuf, size_t errlen);
+
 /* sizes / offsets of the wire structs, for the layout tests */
 typedef struct {
 	uint32_t	sizeof_kern_data_store_head;

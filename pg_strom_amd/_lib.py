@@ -76,6 +76,15 @@ class strom_codegen_result(ctypes.Structure):
     ]
 
 
+class strom_preagg_target(ctypes.Structure):
+    _fields_ = [("kind", c_int32), ("type_oid", c_int32)]
+
+
+class strom_preagg_domain(ctypes.Structure):
+    _fields_ = [("nkeys", c_int32), ("key_min", ctypes.c_int64 * 8),
+                ("key_range", c_uint32 * 8)]
+
+
 class strom_column_input(ctypes.Structure):
     _fields_ = [
         ("type_oid", c_int32),
@@ -114,11 +123,28 @@ PROTOTYPES = {
     "strom_dstore_release": (None, [c_void_p]),
     "strom_submit_gpuscan": (c_void_p, [c_uint64, c_void_p, c_void_p, c_void_p, c_void_p,
                                         c_uint32, c_void_p, c_void_p, ctypes.POINTER(c_int)]),
+    "strom_gpupreagg_create": (c_void_p, [c_uint64, ctypes.POINTER(strom_preagg_target), c_int,
+                                          c_void_p, ctypes.POINTER(strom_preagg_domain), c_int,
+                                          ctypes.POINTER(c_int)]),
+    "strom_gpupreagg_table_length": (c_size_t, [c_void_p]),
+    "strom_gpupreagg_bind_table": (c_int, [c_void_p, c_void_p]),
+    "strom_gpupreagg_table_devptr": (c_void_p, [c_void_p]),
+    "strom_gpupreagg_num_groups": (c_uint32, [c_void_p]),
+    "strom_gpupreagg_table_layout": (c_int, [c_void_p, c_int, ctypes.POINTER(c_size_t),
+                                             ctypes.POINTER(c_size_t)]),
+    "strom_submit_gpupreagg": (c_void_p, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                          c_void_p, ctypes.POINTER(c_int)]),
+    "strom_gpupreagg_fetch": (ctypes.c_long, [c_void_p, c_void_p, c_size_t]),
+    "strom_gpupreagg_reset": (None, [c_void_p]),
+    "strom_gpupreagg_release": (None, [c_void_p]),
     "strom_task_wait": (c_int, [c_void_p, ctypes.POINTER(strom_perfmon)]),
     "strom_task_devptr": (c_void_p, [c_void_p]),
     "strom_synchronize": (None, []),
     # strom_codegen.h
     "strom_codegen_gpuscan": (c_int, [c_char_p, ctypes.POINTER(strom_codegen_result)]),
+    "strom_codegen_gpupreagg": (c_int, [c_char_p, ctypes.POINTER(strom_codegen_result),
+                                        ctypes.POINTER(strom_preagg_target), c_int,
+                                        ctypes.POINTER(c_int)]),
     "strom_codegen_available_expression": (c_int, [c_char_p, ctypes.POINTER(c_void_p)]),
     "strom_codegen_release": (None, [ctypes.POINTER(strom_codegen_result)]),
     "strom_create_kern_parambuf": (c_void_p, [ctypes.POINTER(strom_codegen_result),

@@ -1,0 +1,212 @@
+/*
+ * codegen_preagg.cpp -- GpuPreAgg program text
+ *
+ * Role in the reference: gpupreagg_codegen and friends (gpupreagg.c:
+ * 1180-1943).  The reference emits qual_eval, keycomp (for its bitonic
+ * sort), aggcalc (a switch over GPUPREAGG_AGGCALC_* macros) and a
+ * projection that stores partial inputs into a TUPSLOT scratch store.
+ * This build reduces by group id in LDS instead of sorting, so the
+ * generated part is smaller: one function per target that yields the
+ * per-row partial input in registers, plus X-macro catalogues of keys and
+ * aggregates that strom_gpupreagg.h expands into typed LDS accumulators.
+ */
+#include <cstring>
+#include <cstdio>
+#include <string>
+#include <vector>
+
+#include "strom_codegen.h"
+#include "strom_hip.h"
+#include "codegen_internal.h"
+
+using namespace strom;
+
+namespace {
+
+struct target {
+	int			kind;
+	int			type_oid;
+	std::string	body;		/* function body text */
+};
+
+std::string
+fn_header(const char *rettype, const char *name, int idx)
+{
+	char buf[256];
+	snprintf(buf, sizeof(buf),
+			 "STROM_DEVICE pg_%s_t\n%s_%d(cl_int *errcode, const strom_kparams &KP, const strom_kvars &KV)\n",
+			 rettype, name, idx);
+	return buf;
+}
+
+}	/* namespace */
+
+extern "C" int
+strom_codegen_gpupreagg(const char *spec, strom_codegen_result *out,
+						strom_preagg_target *targets_out, int max_targets, int *p_ntargets)
+{
+	memset(out, 0, sizeof(*out));
+	try {
+		codegen_context ctx;
+		ctx.var_label = "KVAR";
+		ctx.var_struct = "KV";
+		ctx.extra_flags = DEVKERNEL_NEEDS_GPUPREAGG | DEVFUNC_NEEDS_MATHLIB;
+		sexpr tree = sexpr_parse(spec);
+		if (!tree.is_list || tree.items.empty() || tree.items[0].is_list ||
+			tree.items[0].atom != "gpupreagg")
+			codegen_error("(gpupreagg ...) expected");
+		std::string qual_body = "  pg_bool_t r; r.isnull = false; r.value = true; return r;\n";
+		std::vector<target> targets;
+		for (size_t i = 1; i < tree.items.size(); i++)
+		{
+			const sexpr &t = tree.items[i];
+			if (!t.is_list || t.items.empty() || t.items[0].is_list)
+				codegen_error("target must be a list");
+			const std::string &head = t.items[0].atom;
+			size_t	nargs = t.items.size() - 1;
+			if (head == "qual")
+			{
+				if (nargs != 1)
+					codegen_error("(qual EXPR) expected");
+				std::string e;
+				if (codegen_expression(t.items[1], ctx, e) != STROM_BOOLOID)
+					codegen_error("qual is not boolean");
+				qual_body = "  return " + e + ";\n";
+				continue;
+			}
+			target tg;
+			if (head == "key")
+			{
+				if (nargs != 1)
+					codegen_error("(key EXPR) expected");
+				std::string e;
+				tg.kind = STROM_PREAGG_KEY;
+				tg.type_oid = codegen_expression(t.items[1], ctx, e);
+				tg.body = "  return " + e + ";\n";
+			}
+			else if (head == "nrows")
+			{
+				tg.kind = STROM_PREAGG_NROWS;
+				tg.type_oid = STROM_INT4OID;
+				std::string cond;
+				for (size_t a = 1; a <= nargs; a++)
+				{
+					std::string e;
+					if (codegen_expression(t.items[a], ctx, e) != STROM_BOOLOID)
+						codegen_error("nrows() argument is not boolean");
+					/* every argument is evaluated: no short circuit, so a
+					 * CpuReCheck raised by a later argument is not lost */
+					cond += "  ok &= EVAL(" + e + ");\n";
+				}
+				tg.body = "  pg_int4_t r; bool ok = true;\n" + cond +
+					"  r.isnull = false; r.value = ok ? 1 : 0; return r;\n";
+			}
+			else if (head == "psum" || head == "pmin" || head == "pmax")
+			{
+				if (nargs != 1)
+					codegen_error("(%s EXPR) expected", head.c_str());
+				std::string e;
+				tg.kind = (head == "psum" ? STROM_PREAGG_PSUM :
+						   head == "pmin" ? STROM_PREAGG_PMIN : STROM_PREAGG_PMAX);
+				tg.type_oid = codegen_expression(t.items[1], ctx, e);
+				if (tg.kind == STROM_PREAGG_PSUM &&
+					!(tg.type_oid == STROM_INT8OID || tg.type_oid == STROM_FLOAT8OID ||
+					  tg.type_oid == STROM_FLOAT4OID || tg.type_oid == STROM_NUMERICOID))
+					codegen_error("psum() takes int8, float4, float8 or numeric (cast the argument)");
+				tg.body = "  return " + e + ";\n";
+			}
+			else if (head == "psum_x2")
+			{
+				if (nargs != 1)
+					codegen_error("(psum_x2 EXPR) expected");
+				std::string e;
+				tg.kind = STROM_PREAGG_PSUM;
+				if (codegen_expression(t.items[1], ctx, e) != STROM_FLOAT8OID)
+					codegen_error("psum_x2() takes float8");
+				tg.type_oid = STROM_FLOAT8OID;
+				tg.body = "  pg_float8_t x = " + e + ";\n  return pgfn_float8mul(errcode, x, x);\n";
+			}
+			else if (head == "pcov_x" || head == "pcov_y" || head == "pcov_x2" ||
+					 head == "pcov_y2" || head == "pcov_xy")
+			{
+				if (nargs != 3)
+					codegen_error("(%s FILTER X Y) expected", head.c_str());
+				std::string f, x, y;
+				if (codegen_expression(t.items[1], ctx, f) != STROM_BOOLOID ||
+					codegen_expression(t.items[2], ctx, x) != STROM_FLOAT8OID ||
+					codegen_expression(t.items[3], ctx, y) != STROM_FLOAT8OID)
+					codegen_error("%s(bool, float8, float8) expected", head.c_str());
+				tg.kind = STROM_PREAGG_PSUM;
+				tg.type_oid = STROM_FLOAT8OID;
+				std::string val = (head == "pcov_x" ? "x" : head == "pcov_y" ? "y" :
+								   head == "pcov_x2" ? "pgfn_float8mul(errcode, x, x)" :
+								   head == "pcov_y2" ? "pgfn_float8mul(errcode, y, y)" :
+								   "pgfn_float8mul(errcode, x, y)");
+				tg.body = "  pg_bool_t f = " + f + ";\n  pg_float8_t x = " + x +
+					";\n  pg_float8_t y = " + y + ";\n"
+					"  if (!EVAL(f) || x.isnull || y.isnull) return pg_float8_make(0.0, true);\n"
+					"  return " + val + ";\n";
+			}
+			else
+				codegen_error("unknown GpuPreAgg target \"%s\"", head.c_str());
+			const devtype_info *dt = devtype_lookup(tg.type_oid);
+			ctx.extra_flags |= dt->type_flags;
+			targets.push_back(tg);
+		}
+		if (targets.empty())
+			codegen_error("GpuPreAgg needs at least one target");
+		if ((int)targets.size() > max_targets)
+			codegen_error("too many targets");
+
+		std::string key_list = "#define GPUPREAGG_KEY_LIST(X)";
+		std::string agg_list = "#define GPUPREAGG_AGG_LIST(X)";
+		std::string funcs;
+		int		nkeys = 0, naggs = 0;
+		char	tmp[160];
+		for (size_t i = 0; i < targets.size(); i++)
+		{
+			const target &tg = targets[i];
+			const char *tname = devtype_lookup(tg.type_oid)->dev_name;
+			if (tg.kind == STROM_PREAGG_KEY)
+			{
+				snprintf(tmp, sizeof(tmp), " X(%d,%zu,%s)", nkeys, i, tname);
+				key_list += tmp;
+				funcs += fn_header(tname, "gpupreagg_key", nkeys) + "{\n" + tg.body + "}\n";
+				nkeys++;
+			}
+			else
+			{
+				const char *op = (tg.kind == STROM_PREAGG_NROWS ? "NROWS" :
+								  tg.kind == STROM_PREAGG_PSUM ? "PSUM" :
+								  tg.kind == STROM_PREAGG_PMIN ? "PMIN" : "PMAX");
+				snprintf(tmp, sizeof(tmp), " X(%d,%zu,%s,%s)", naggs, i, op, tname);
+				agg_list += tmp;
+				funcs += fn_header(tname, "gpupreagg_agg", naggs) + "{\n" + tg.body + "}\n";
+				naggs++;
+			}
+			targets_out[i].kind = tg.kind;
+			targets_out[i].type_oid = tg.type_oid;
+		}
+		*p_ntargets = (int)targets.size();
+
+		std::string src = "/* generated by strom_codegen_gpupreagg */\n";
+		src += codegen_includes(ctx.extra_flags);
+		src += codegen_param_list(ctx);
+		src += codegen_var_list(ctx, "STROM_KVAR_LIST");
+		snprintf(tmp, sizeof(tmp),
+				 "#define GPUPREAGG_NTARGETS %zu\n#define GPUPREAGG_NKEYS %d\n#define GPUPREAGG_NAGGS %d\n",
+				 targets.size(), nkeys, naggs);
+		src += tmp;
+		src += key_list + "\n" + agg_list + "\n";
+		src += "#include \"strom_gpupreagg.h\"\n";
+		src += "STROM_DEVICE pg_bool_t\n"
+			"gpupreagg_qual_eval(cl_int *errcode, const strom_kparams &KP, const strom_kvars &KV)\n{\n" +
+			qual_body + "}\n";
+		src += funcs;
+		codegen_fill_result(ctx, src, out);
+		return 0;
+	} catch (const std::exception &e) {
+		out->errmsg = strdup(e.what());
+		return -1;
+	}
+}

@@ -438,7 +438,12 @@ strom_column_load_quad(const char *values, const cl_uint *notnull,
 
 	if (row0 + 4 <= nitems)
 	{
+#if !defined(COLUMN_LOAD_NT) || COLUMN_LOAD_NT
+		/* streamed once: do not keep the lines in L2 / Infinity Cache */
 		vec_t	q = __builtin_nontemporal_load((const vec_t *)(values + (size_t)row0 * sizeof(BASE)));
+#else
+		vec_t	q = *(const vec_t *)(values + (size_t)row0 * sizeof(BASE));
+#endif
 		v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
 		nnbits = (notnull ? (notnull[row0 >> 5] >> (row0 & 31)) & 0xf : 0xf);
 	}

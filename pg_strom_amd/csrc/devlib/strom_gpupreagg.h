@@ -1,0 +1,640 @@
+/*
+ * strom_gpupreagg.h -- GpuPreAgg kernels (HIP, gfx950)
+ *
+ * Role in the reference: opencl_gpupreagg.h -- gpupreagg_preparation
+ * (380-447: qual + projection of per-row partial inputs),
+ * gpupreagg_set_rindex / bitonic_local / bitonic_step / bitonic_merge
+ * (620-856: order rows by group key) and gpupreagg_reduction (459-608:
+ * per-work-group segmented tree reduction, one partial row per
+ * (work-group, group)), with the PMIN/PMAX/PSUM rules of 862-987.
+ *
+ * What this build does instead (every partial
+ * function is an associative merge, so any reduction order that ends in
+ * the same partial->final merge is a legal replacement):
+ *
+ *   no sort, no scratch TUPSLOT store.  A row's partial inputs stay in
+ *   registers; its group id is computed directly from the key values
+ *   (dense id = sum_k (key_k - min_k) * stride_k, NULL gets its own slot;
+ *   min/range come from the chunk zone maps of KDS_FORMAT_COLUMN) and the
+ *   inputs are folded into typed accumulators in LDS with LDS atomics
+ *   (ds_add_u32 / ds_add_u64 / ds_add_f64 / ds_min/max).  Rows are read
+ *   once, coalesced, 16 bytes per lane per column.
+ *
+ *   small group counts replicate the table NREP times inside LDS (lane ->
+ *   replica) so that a wave does not serialise on one hot address; large
+ *   group counts (state > LDS budget) split the dense id range over
+ *   NSPLIT work-group roles, each role keeping its slice.
+ *
+ *   at the end a work-group folds its replicas and writes ONE slab
+ *   (plain coalesced stores); gpupreagg_dense_merge then adds the slabs
+ *   into the resident per-GPU table in a fixed order -- float sums are
+ *   reproducible run to run, and nothing is merged when the chunk
+ *   raised CpuReCheck (the reference re-does such a chunk on the CPU,
+ *   gpupreagg.c:2746-2750).
+ *
+ * Generated code supplies STROM_KPARAM_LIST / STROM_KVAR_LIST and
+ *   GPUPREAGG_KEY_LIST(X)  X(kidx, resno, NAME)
+ *   GPUPREAGG_AGG_LIST(X)  X(aidx, resno, OP, NAME)   OP in NROWS PSUM PMIN PMAX
+ *   gpupreagg_qual_eval / gpupreagg_key_<k> / gpupreagg_agg_<a>
+ */
+#ifndef STROM_GPUPREAGG_DEVICE_H
+#define STROM_GPUPREAGG_DEVICE_H
+
+#ifndef GPUPREAGG_BLOCK
+#define GPUPREAGG_BLOCK		1024
+#endif
+#ifndef GPUPREAGG_QUADS
+#define GPUPREAGG_QUADS		2
+#endif
+#define GPUPREAGG_TILE_ROWS	(GPUPREAGG_BLOCK * 4 * GPUPREAGG_QUADS)
+#define GPUPREAGG_MAXKEYS	8
+
+struct strom_kparams {
+#define X(idx,NAME)	pg_##NAME##_t KPARAM_##idx;
+	STROM_KPARAM_LIST(X)
+#undef X
+	int __dummy;
+};
+struct strom_kvars {
+#define X(attno,colidx,NAME)	pg_##NAME##_t KVAR_##attno;
+	STROM_KVAR_LIST(X)
+#undef X
+	int __dummy;
+};
+
+STROM_DEVICE pg_bool_t
+gpupreagg_qual_eval(cl_int *errcode, const strom_kparams &KP, const strom_kvars &KV);
+#define X(kidx,resno,NAME)													\
+	STROM_DEVICE pg_##NAME##_t												\
+	gpupreagg_key_##kidx(cl_int *errcode, const strom_kparams &KP, const strom_kvars &KV);
+GPUPREAGG_KEY_LIST(X)
+#undef X
+#define X(aidx,resno,OP,NAME)												\
+	STROM_DEVICE pg_##NAME##_t												\
+	gpupreagg_agg_##aidx(cl_int *errcode, const strom_kparams &KP, const strom_kvars &KV);
+GPUPREAGG_AGG_LIST(X)
+#undef X
+
+/* control block written by the host (gpupreagg.cpp mirrors this struct) */
+struct gpupreagg_dense_ctl {
+	cl_uint		ngroups;			/* dense ids in the whole domain */
+	cl_uint		nsplits;			/* work-group roles over the id range */
+	cl_uint		groups_per_split;
+	cl_uint		nrep;				/* LDS replicas, power of two */
+	cl_uint		nslabs;				/* == gridDim.x */
+	cl_uint		nkeys;
+	cl_ulong	slab_bytes;
+	cl_long		key_min[GPUPREAGG_MAXKEYS];
+	cl_uint		key_range[GPUPREAGG_MAXKEYS];	/* max-min+1; NULL slot == key_range */
+	cl_uint		key_stride[GPUPREAGG_MAXKEYS];
+};
+
+/* ---- accumulator encodings ------------------------------------------ *
+ * NROWS   : u32 in LDS / slab, i64 in the resident table
+ * others  : 8 bytes.  int-like values as i64; float8 PSUM as f64; float8
+ *           PMIN/PMAX as an order-preserving u64 (NaN above +inf, the
+ *           PostgreSQL float ordering)
+ */
+STROM_DEVICE cl_ulong
+gpupreagg_f64_ordered(cl_double v)
+{
+	cl_ulong bits = __builtin_isnan(v) ? 0x7ff8000000000000UL : (cl_ulong)__double_as_longlong(v);
+	return (bits & 0x8000000000000000UL) ? ~bits : (bits | 0x8000000000000000UL);
+}
+STROM_DEVICE cl_double
+gpupreagg_f64_unordered(cl_ulong key)
+{
+	cl_ulong bits = (key & 0x8000000000000000UL) ? (key & 0x7fffffffffffffffUL) : ~key;
+	return __longlong_as_double((long long)bits);
+}
+
+#define GPUPREAGG_OP_NROWS	0
+#define GPUPREAGG_OP_PSUM	1
+#define GPUPREAGG_OP_PMIN	2
+#define GPUPREAGG_OP_PMAX	3
+
+template <typename T> struct gpupreagg_is_float { static const bool value = false; };
+template <> struct gpupreagg_is_float<cl_double> { static const bool value = true; };
+template <> struct gpupreagg_is_float<cl_float> { static const bool value = true; };
+
+STROM_DEVICE size_t gpupreagg_align16(size_t v) { return (v + 15) & ~(size_t)15; }
+
+/* byte offset of section 'sec' in a [bits | per-agg (bits, values)] image
+ * for G groups, REP replicas.  sec = 0: seen bits; 1+2a: has-value bits of
+ * agg a; 2+2a: values of agg a; 1+2*NAGGS: total size */
+STROM_DEVICE size_t
+gpupreagg_image_offset(int sec, cl_uint G, cl_uint REP)
+{
+	size_t	off = 0;
+	size_t	bits = gpupreagg_align16(sizeof(cl_uint) * (((size_t)G + 31) / 32));
+	int		cur = 0;
+
+	if (sec == cur) return off;
+	off += bits; cur++;
+#define X(aidx,resno,OP,NAME)																\
+	if (sec == cur) return off;																\
+	if (GPUPREAGG_OP_##OP != GPUPREAGG_OP_NROWS) off += bits;								\
+	cur++;																					\
+	if (sec == cur) return off;																\
+	off += gpupreagg_align16((GPUPREAGG_OP_##OP == GPUPREAGG_OP_NROWS ? 4 : 8) * (size_t)G * REP);	\
+	cur++;
+	GPUPREAGG_AGG_LIST(X)
+#undef X
+	return off;
+}
+
+/* resident table: the same sections, NROWS widened to 8 bytes, 256-byte aligned */
+STROM_DEVICE size_t
+gpupreagg_table_offset(int sec, cl_uint N)
+{
+	size_t	off = 0;
+	size_t	bits = STROM_TYPEALIGN(256, sizeof(cl_uint) * (((size_t)N + 31) / 32));
+	size_t	vals = STROM_TYPEALIGN(256, 8 * (size_t)N);
+	int		cur = 0;
+
+	if (sec == cur) return off;
+	off += bits; cur++;
+#define X(aidx,resno,OP,NAME)						\
+	if (sec == cur) return off;						\
+	off += bits; cur++;								\
+	if (sec == cur) return off;						\
+	off += vals; cur++;
+	GPUPREAGG_AGG_LIST(X)
+#undef X
+	return off;
+}
+
+STROM_DEVICE void
+gpupreagg_set_bit(cl_uint *bits, cl_uint idx)
+{
+	cl_uint	mask = 1u << (idx & 31);
+	/* test first: after warm-up no atomic traffic remains */
+	if (!(bits[idx >> 5] & mask))
+		__hip_atomic_fetch_or(&bits[idx >> 5], mask, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+/* fold one row's partial value into the LDS accumulator of (lgid, rep) */
+template <int OP, typename PGT>
+STROM_DEVICE void
+gpupreagg_lds_accum(char *lds, size_t bits_off, size_t vals_off,
+					cl_uint lgid, cl_uint slot, PGT v)
+{
+	if (OP == GPUPREAGG_OP_NROWS)
+	{
+		if (!v.isnull && v.value != 0)
+			__hip_atomic_fetch_add((cl_uint *)(lds + vals_off) + slot, (cl_uint)v.value,
+								   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+		return;
+	}
+	if (v.isnull)
+		return;
+	gpupreagg_set_bit((cl_uint *)(lds + bits_off), lgid);
+	typedef decltype(v.value) base_t;
+	if (gpupreagg_is_float<base_t>::value)
+	{
+		if (OP == GPUPREAGG_OP_PSUM)
+			__hip_atomic_fetch_add((cl_double *)(lds + vals_off) + slot, (cl_double)v.value,
+								   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+		else if (OP == GPUPREAGG_OP_PMIN)
+			__hip_atomic_fetch_min((cl_ulong *)(lds + vals_off) + slot,
+								   gpupreagg_f64_ordered((cl_double)v.value),
+								   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+		else
+			__hip_atomic_fetch_max((cl_ulong *)(lds + vals_off) + slot,
+								   gpupreagg_f64_ordered((cl_double)v.value),
+								   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+	}
+	else
+	{
+		if (OP == GPUPREAGG_OP_PSUM)
+			__hip_atomic_fetch_add((cl_long *)(lds + vals_off) + slot, (cl_long)v.value,
+								   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+		else if (OP == GPUPREAGG_OP_PMIN)
+			__hip_atomic_fetch_min((cl_long *)(lds + vals_off) + slot, (cl_long)v.value,
+								   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+		else
+			__hip_atomic_fetch_max((cl_long *)(lds + vals_off) + slot, (cl_long)v.value,
+								   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+	}
+}
+
+/* identity element of an 8-byte accumulator */
+template <int OP, typename BASE>
+STROM_DEVICE cl_ulong
+gpupreagg_identity(void)
+{
+	if (OP == GPUPREAGG_OP_PMIN)
+		return gpupreagg_is_float<BASE>::value ? 0xffffffffffffffffUL : 0x7fffffffffffffffUL;
+	if (OP == GPUPREAGG_OP_PMAX)
+		return gpupreagg_is_float<BASE>::value ? 0UL : 0x8000000000000000UL;
+	return 0UL;		/* PSUM: +0 / 0.0 */
+}
+
+/* merge two 8-byte accumulators (b into a) */
+template <int OP, typename BASE>
+STROM_DEVICE cl_ulong
+gpupreagg_merge8(cl_ulong a, cl_ulong b)
+{
+	if (OP == GPUPREAGG_OP_PSUM)
+	{
+		if (gpupreagg_is_float<BASE>::value)
+			return (cl_ulong)__double_as_longlong(__longlong_as_double((long long)a) +
+												  __longlong_as_double((long long)b));
+		return a + b;
+	}
+	if (gpupreagg_is_float<BASE>::value)
+		return (OP == GPUPREAGG_OP_PMIN) ? (a < b ? a : b) : (a > b ? a : b);
+	return (OP == GPUPREAGG_OP_PMIN) ? ((cl_long)a < (cl_long)b ? a : b)
+									 : ((cl_long)a > (cl_long)b ? a : b);
+}
+
+/* conservative overflow screen for int8 sums: a partial sum at or beyond
+ * 2^62 in magnitude sends the chunk to the CPU before int64 can wrap
+ * (CHECK_OVERFLOW_INT, opencl_gpupreagg.h:142-143) */
+STROM_DEVICE bool
+gpupreagg_int8_near_overflow(cl_long v)
+{
+	return v >= (1L << 62) || v <= -(1L << 62);
+}
+
+/* ---------------------------------------------------------------------- *
+ * one row: qual, group id, fold.  Returns false when the row raised
+ * CpuReCheck or a significant error (recorded in *chunk_status)
+ * ---------------------------------------------------------------------- */
+STROM_DEVICE void
+gpupreagg_dense_row(char *lds, const gpupreagg_dense_ctl *ctl,
+					const strom_kparams &KP, const strom_kvars &KV,
+					cl_uint split, cl_uint G, cl_uint NREP, cl_uint rep,
+					cl_int param_error, cl_int *chunk_status)
+{
+	cl_int		errcode = param_error;
+	pg_bool_t	rc = gpupreagg_qual_eval(&errcode, KP, KV);
+	cl_ulong	gid = 0;
+	bool		out_of_domain = false;
+
+	if (errcode == StromError_Success && !EVAL(rc))
+		return;
+	/* group id */
+#define X(kidx,resno,NAME)															\
+	{																				\
+		pg_##NAME##_t kv = gpupreagg_key_##kidx(&errcode, KP, KV);					\
+		cl_long off;																\
+		if (kv.isnull)																\
+			off = ctl->key_range[kidx];												\
+		else																		\
+		{																			\
+			off = (cl_long)kv.value - ctl->key_min[kidx];							\
+			if (off < 0 || off >= (cl_long)ctl->key_range[kidx])					\
+				out_of_domain = true;												\
+		}																			\
+		gid += (cl_ulong)off * ctl->key_stride[kidx];								\
+	}
+	GPUPREAGG_KEY_LIST(X)
+#undef X
+	/* partial inputs (evaluated for every surviving row so that arithmetic
+	 * errors are seen before anything is folded) */
+#define X(aidx,resno,OP,NAME)														\
+	pg_##NAME##_t av_##aidx = gpupreagg_agg_##aidx(&errcode, KP, KV);
+	GPUPREAGG_AGG_LIST(X)
+#undef X
+	if (errcode != StromError_Success)
+	{
+		/* CpuReCheck (or worse) anywhere in the row: the chunk goes back */
+		STROM_SET_ERROR(chunk_status, errcode);
+		return;
+	}
+	if (out_of_domain)
+	{
+		STROM_SET_ERROR(chunk_status, StromError_DataStoreOutOfRange);
+		return;
+	}
+	if (gid / G != split)
+		return;
+	cl_uint		lgid = (cl_uint)(gid - (cl_ulong)split * G);
+	cl_uint		slot = lgid * NREP + rep;
+
+	gpupreagg_set_bit((cl_uint *)lds, lgid);
+	{
+		int sec = 1;
+#define X(aidx,resno,OP,NAME)														\
+		{																			\
+			size_t boff = gpupreagg_image_offset(sec, G, NREP);						\
+			size_t voff = gpupreagg_image_offset(sec + 1, G, NREP);					\
+			if (GPUPREAGG_OP_##OP == GPUPREAGG_OP_PSUM &&							\
+				!gpupreagg_is_float<pg_##NAME##_base_t>::value &&					\
+				!av_##aidx.isnull && gpupreagg_int8_near_overflow((cl_long)av_##aidx.value))	\
+				STROM_SET_ERROR(chunk_status, StromError_CpuReCheck);				\
+			gpupreagg_lds_accum<GPUPREAGG_OP_##OP>(lds, boff, voff, lgid, slot, av_##aidx);	\
+			sec += 2;																\
+		}
+		GPUPREAGG_AGG_LIST(X)
+#undef X
+	}
+}
+
+/* initialise the LDS image */
+STROM_DEVICE void
+gpupreagg_lds_init(char *lds, cl_uint G, cl_uint NREP)
+{
+	size_t	total = gpupreagg_image_offset(1 + 2 * GPUPREAGG_NAGGS, G, NREP);
+	int		sec = 1;
+
+	for (size_t i = threadIdx.x * 16; i < total; i += GPUPREAGG_BLOCK * 16)
+		*(uint4 *)(lds + i) = make_uint4(0, 0, 0, 0);
+	__syncthreads();
+#define X(aidx,resno,OP,NAME)															\
+	if (GPUPREAGG_OP_##OP == GPUPREAGG_OP_PMIN || GPUPREAGG_OP_##OP == GPUPREAGG_OP_PMAX)	\
+	{																					\
+		cl_ulong   *vals = (cl_ulong *)(lds + gpupreagg_image_offset(sec + 1, G, NREP));	\
+		cl_ulong	ident = gpupreagg_identity<GPUPREAGG_OP_##OP, pg_##NAME##_base_t>();	\
+		for (size_t i = threadIdx.x; i < (size_t)G * NREP; i += GPUPREAGG_BLOCK)		\
+			vals[i] = ident;															\
+	}																					\
+	sec += 2;
+	GPUPREAGG_AGG_LIST(X)
+#undef X
+	__syncthreads();
+}
+
+/* fold replicas and store the work-group's slab (REP = 1 image) */
+STROM_DEVICE void
+gpupreagg_store_slab(const char *lds, char *slab, cl_uint G, cl_uint NREP)
+{
+	size_t	nbits = ((size_t)G + 31) / 32;
+	int		sec = 1;
+
+	__syncthreads();
+	for (size_t i = threadIdx.x; i < nbits; i += GPUPREAGG_BLOCK)
+		((cl_uint *)slab)[i] = ((const cl_uint *)lds)[i];
+#define X(aidx,resno,OP,NAME)																\
+	{																						\
+		const char *lbits = lds + gpupreagg_image_offset(sec, G, NREP);						\
+		const char *lvals = lds + gpupreagg_image_offset(sec + 1, G, NREP);					\
+		char	   *sbits = slab + gpupreagg_image_offset(sec, G, 1);							\
+		char	   *svals = slab + gpupreagg_image_offset(sec + 1, G, 1);						\
+		if (GPUPREAGG_OP_##OP == GPUPREAGG_OP_NROWS)											\
+		{																					\
+			for (size_t g = threadIdx.x; g < G; g += GPUPREAGG_BLOCK)						\
+			{																				\
+				cl_uint sum = 0;															\
+				for (cl_uint r = 0; r < NREP; r++)											\
+					sum += ((const cl_uint *)lvals)[g * NREP + r];							\
+				((cl_uint *)svals)[g] = sum;												\
+			}																				\
+		}																					\
+		else																				\
+		{																					\
+			for (size_t i = threadIdx.x; i < nbits; i += GPUPREAGG_BLOCK)					\
+				((cl_uint *)sbits)[i] = ((const cl_uint *)lbits)[i];						\
+			for (size_t g = threadIdx.x; g < G; g += GPUPREAGG_BLOCK)						\
+			{																				\
+				cl_ulong acc = ((const cl_ulong *)lvals)[g * NREP];							\
+				for (cl_uint r = 1; r < NREP; r++)											\
+					acc = gpupreagg_merge8<GPUPREAGG_OP_##OP, pg_##NAME##_base_t>			\
+						(acc, ((const cl_ulong *)lvals)[g * NREP + r]);						\
+				((cl_ulong *)svals)[g] = acc;												\
+			}																				\
+		}																					\
+		sec += 2;																			\
+	}
+	GPUPREAGG_AGG_LIST(X)
+#undef X
+}
+
+/*
+ * chunk status.  Device code only raises positive codes, so "worst wins"
+ * is a max: significant (>=100) > CpuReCheck (2) > Success (0).
+ */
+STROM_DEVICE void
+gpupreagg_writeback_status(cl_int *status, cl_int chunk_status)
+{
+	cl_int worst = strom_wave_max_i32(chunk_status);
+	if (strom_lane_id() == 0 && worst != StromError_Success)
+		atomicMax(status, worst);
+}
+
+struct gpupreagg_column_tile {
+#define X(attno,colidx,NAME)											\
+	pg_##NAME##_base_t	v_##attno[GPUPREAGG_QUADS][4];					\
+	cl_uint				nn_##attno[GPUPREAGG_QUADS];
+	STROM_KVAR_LIST(X)
+#undef X
+	int __dummy;
+};
+
+STROM_DEVICE void
+gpupreagg_load_kparams(strom_kparams &KP, const kern_parambuf *kparams, cl_int *errcode)
+{
+#define X(idx,NAME)	KP.KPARAM_##idx = pg_##NAME##_param(kparams, errcode, idx);
+	STROM_KPARAM_LIST(X)
+#undef X
+	KP.__dummy = 0;
+}
+
+/* ====================================================================== *
+ * dense-id reduction, COLUMN format
+ * ====================================================================== */
+extern "C" __global__ void
+__launch_bounds__(GPUPREAGG_BLOCK)
+gpupreagg_dense_column(kern_gpupreagg *kgpreagg,
+					   const kern_data_store *kds,
+					   const gpupreagg_dense_ctl *ctl,
+					   char *slabs)
+{
+	extern __shared__ __attribute__((aligned(16))) char lds[];
+	const kern_parambuf *kparams = KERN_GPUPREAGG_PARAMBUF(kgpreagg);
+	const kern_coldir *coldir = KERN_DATA_STORE_COLDIR(kds);
+	cl_uint		nitems = kds->nitems;
+	cl_uint		ntiles = (nitems + GPUPREAGG_TILE_ROWS - 1) / GPUPREAGG_TILE_ROWS;
+	cl_uint		nsplits = ctl->nsplits;
+	cl_uint		G = ctl->groups_per_split;
+	cl_uint		NREP = ctl->nrep;
+	cl_uint		split = blockIdx.x % nsplits;
+	cl_uint		wg_in_split = blockIdx.x / nsplits;
+	cl_uint		wgs_per_split = gridDim.x / nsplits;
+	cl_uint		rep = threadIdx.x & (NREP - 1);
+	cl_int		chunk_status = StromError_Success;
+	cl_int		param_error = StromError_Success;
+	strom_kparams KP;
+
+	gpupreagg_load_kparams(KP, kparams, &param_error);
+	gpupreagg_lds_init(lds, G, NREP);
+
+#define X(attno,colidx,NAME)													\
+	const char *col_##attno = (const char *)kds + coldir[colidx].values_off;	\
+	const cl_uint *nul_##attno = (coldir[colidx].nulls_off != 0					\
+		? (const cl_uint *)((const char *)kds + coldir[colidx].nulls_off) : NULL);
+	STROM_KVAR_LIST(X)
+#undef X
+
+	for (cl_uint tile = wg_in_split; tile < ntiles; tile += wgs_per_split)
+	{
+		cl_uint		tile_base = tile * GPUPREAGG_TILE_ROWS;
+		gpupreagg_column_tile T;
+
+#pragma unroll
+		for (int k = 0; k < GPUPREAGG_QUADS; k++)
+		{
+			cl_uint	row0 = tile_base + (k * GPUPREAGG_BLOCK + threadIdx.x) * 4;
+#define X(attno,colidx,NAME)													\
+			strom_column_load_quad<pg_##NAME##_base_t>(col_##attno, nul_##attno,	\
+													   row0, nitems,				\
+													   T.v_##attno[k], T.nn_##attno[k]);
+			STROM_KVAR_LIST(X)
+#undef X
+		}
+#pragma unroll
+		for (int k = 0; k < GPUPREAGG_QUADS; k++)
+		{
+			cl_uint	row0 = tile_base + (k * GPUPREAGG_BLOCK + threadIdx.x) * 4;
+#pragma unroll
+			for (int j = 0; j < 4; j++)
+			{
+				if (row0 + j < nitems)
+				{
+					strom_kvars	KV;
+#define X(attno,colidx,NAME)													\
+					KV.KVAR_##attno = pg_##NAME##_make(T.v_##attno[k][j],			\
+													   !((T.nn_##attno[k] >> j) & 1));
+					STROM_KVAR_LIST(X)
+#undef X
+					KV.__dummy = 0;
+					gpupreagg_dense_row(lds, ctl, KP, KV, split, G, NREP, rep,
+										param_error, &chunk_status);
+				}
+			}
+		}
+	}
+	gpupreagg_store_slab(lds, slabs + (size_t)blockIdx.x * ctl->slab_bytes, G, NREP);
+	gpupreagg_writeback_status(&kgpreagg->status, chunk_status);
+}
+
+/* ====================================================================== *
+ * dense-id reduction, any format / row map (one datum at a time)
+ * ====================================================================== */
+extern "C" __global__ void
+__launch_bounds__(GPUPREAGG_BLOCK)
+gpupreagg_dense_generic(kern_gpupreagg *kgpreagg,
+						const kern_data_store *kds,
+						const kern_data_store *ktoast,
+						const kern_row_map *krowmap,
+						const gpupreagg_dense_ctl *ctl,
+						char *slabs)
+{
+	extern __shared__ __attribute__((aligned(16))) char lds[];
+	const kern_parambuf *kparams = KERN_GPUPREAGG_PARAMBUF(kgpreagg);
+	bool		use_map = (krowmap != NULL && krowmap->nvalids >= 0);
+	cl_uint		nrows = (use_map ? (cl_uint)krowmap->nvalids : kds->nitems);
+	cl_uint		nsplits = ctl->nsplits;
+	cl_uint		G = ctl->groups_per_split;
+	cl_uint		NREP = ctl->nrep;
+	cl_uint		split = blockIdx.x % nsplits;
+	cl_uint		wg_in_split = blockIdx.x / nsplits;
+	cl_uint		wgs_per_split = gridDim.x / nsplits;
+	cl_uint		rep = threadIdx.x & (NREP - 1);
+	cl_int		chunk_status = StromError_Success;
+	cl_int		param_error = StromError_Success;
+	strom_kparams KP;
+
+	gpupreagg_load_kparams(KP, kparams, &param_error);
+	gpupreagg_lds_init(lds, G, NREP);
+	for (size_t r = (size_t)wg_in_split * GPUPREAGG_BLOCK + threadIdx.x;
+		 r < nrows;
+		 r += (size_t)wgs_per_split * GPUPREAGG_BLOCK)
+	{
+		cl_uint		kds_index = (use_map ? (cl_uint)krowmap->rindex[r] : (cl_uint)r);
+		strom_kvars	KV;
+		cl_int		errcode = param_error;
+#define X(attno,colidx,NAME)													\
+		KV.KVAR_##attno = pg_##NAME##_vref(kds, ktoast, &errcode, colidx, kds_index);
+		STROM_KVAR_LIST(X)
+#undef X
+		KV.__dummy = 0;
+		gpupreagg_dense_row(lds, ctl, KP, KV, split, G, NREP, rep, errcode, &chunk_status);
+	}
+	gpupreagg_store_slab(lds, slabs + (size_t)blockIdx.x * ctl->slab_bytes, G, NREP);
+	gpupreagg_writeback_status(&kgpreagg->status, chunk_status);
+}
+
+/* ====================================================================== *
+ * slabs -> resident table, fixed order; skipped when the chunk failed
+ * ====================================================================== */
+extern "C" __global__ void
+__launch_bounds__(256)
+gpupreagg_dense_merge(const kern_gpupreagg *kgpreagg,
+					  const gpupreagg_dense_ctl *ctl,
+					  const char *slabs,
+					  char *table)
+{
+	cl_uint		N = ctl->ngroups;
+	cl_uint		G = ctl->groups_per_split;
+	cl_uint		nsplits = ctl->nsplits;
+	cl_uint		wgs_per_split = ctl->nslabs / nsplits;
+
+	if (kgpreagg->status != StromError_Success)
+		return;
+	for (cl_uint gid = blockIdx.x * blockDim.x + threadIdx.x;
+		 gid < N;
+		 gid += gridDim.x * blockDim.x)
+	{
+		cl_uint		split = gid / G;
+		cl_uint		lgid = gid - split * G;
+		cl_uint		word = lgid >> 5, mask = 1u << (lgid & 31);
+		bool		seen = false;
+		int			sec = 1;
+
+		for (cl_uint w = 0; w < wgs_per_split; w++)
+		{
+			const char *slab = slabs + (size_t)(w * nsplits + split) * ctl->slab_bytes;
+			if (((const cl_uint *)slab)[word] & mask)
+				seen = true;
+		}
+		if (!seen)
+			continue;
+		atomicOr((cl_uint *)table + (gid >> 5), 1u << (gid & 31));
+#define X(aidx,resno,OP,NAME)																	\
+		{																						\
+			size_t	s_bits = gpupreagg_image_offset(sec, G, 1);									\
+			size_t	s_vals = gpupreagg_image_offset(sec + 1, G, 1);								\
+			cl_uint *t_bits = (cl_uint *)(table + gpupreagg_table_offset(sec, N));				\
+			cl_ulong *t_vals = (cl_ulong *)(table + gpupreagg_table_offset(sec + 1, N));		\
+			if (GPUPREAGG_OP_##OP == GPUPREAGG_OP_NROWS)										\
+			{																					\
+				cl_ulong sum = 0;																\
+				for (cl_uint w = 0; w < wgs_per_split; w++)										\
+					sum += ((const cl_uint *)(slabs + (size_t)(w * nsplits + split) *			\
+											  ctl->slab_bytes + s_vals))[lgid];					\
+				t_vals[gid] += sum;																\
+			}																					\
+			else																				\
+			{																					\
+				cl_ulong acc = gpupreagg_identity<GPUPREAGG_OP_##OP, pg_##NAME##_base_t>();		\
+				bool	 has = false;															\
+				for (cl_uint w = 0; w < wgs_per_split; w++)										\
+				{																				\
+					const char *slab = slabs + (size_t)(w * nsplits + split) * ctl->slab_bytes;	\
+					if (((const cl_uint *)(slab + s_bits))[word] & mask)						\
+					{																			\
+						acc = gpupreagg_merge8<GPUPREAGG_OP_##OP, pg_##NAME##_base_t>			\
+							(acc, ((const cl_ulong *)(slab + s_vals))[lgid]);					\
+						has = true;																\
+					}																			\
+				}																				\
+				if (has)																		\
+				{																				\
+					bool had = (t_bits[gid >> 5] >> (gid & 31)) & 1;							\
+					t_vals[gid] = had															\
+						? gpupreagg_merge8<GPUPREAGG_OP_##OP, pg_##NAME##_base_t>(t_vals[gid], acc)	\
+						: acc;																	\
+					if (!had)																	\
+						atomicOr(&t_bits[gid >> 5], 1u << (gid & 31));							\
+				}																				\
+			}																					\
+			sec += 2;																			\
+		}
+		GPUPREAGG_AGG_LIST(X)
+#undef X
+	}
+}
+
+#endif	/* STROM_GPUPREAGG_DEVICE_H */

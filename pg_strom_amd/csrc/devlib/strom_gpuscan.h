@@ -38,7 +38,7 @@
 #define GPUSCAN_BLOCK		256
 #endif
 #ifndef GPUSCAN_QUADS
-#define GPUSCAN_QUADS		2			/* 8 rows per thread and tile */
+#define GPUSCAN_QUADS		1			/* 4 rows per thread and tile (swept: profiles/r01_gpuscan_tune.txt) */
 #endif
 #ifndef GPUSCAN_STAGE
 #define GPUSCAN_STAGE		8192		/* LDS entries (32 KB) */

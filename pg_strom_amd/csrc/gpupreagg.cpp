@@ -1,0 +1,651 @@
+/*
+ * gpupreagg.cpp -- host side of GpuPreAgg
+ *
+ * Role in the reference: clserv_process_gpupreagg (gpupreagg.c:3849-4240)
+ * and clserv_respond_gpupreagg (3009-3194): send the chunk, run
+ * preparation -> (set_rindex | bitonic sort) -> reduction, read back the
+ * partial rows; plus pgstrom_create_gpupreagg (2329-2416) which sizes the
+ * buffers.  Here a request folds its chunk into a per-GPU table that stays
+ * in HBM (see strom_hip.h) using strom_gpupreagg.h's dense-id kernels; the
+ * geometry decisions -- how many LDS replicas, how many id-range roles,
+ * how many work-groups -- are made below from the group domain, which is
+ * the job clserv_compute_workgroup_size + the sort-size heuristics
+ * (gpupreagg.c:4105-4141) do in the reference.
+ */
+#include <cstring>
+#include <cstdio>
+#include <algorithm>
+
+#include "runtime.h"
+
+using namespace strom;
+
+namespace {
+
+/* mirrors struct gpupreagg_dense_ctl of strom_gpupreagg.h */
+struct dense_ctl {
+	cl_uint		ngroups;
+	cl_uint		nsplits;
+	cl_uint		groups_per_split;
+	cl_uint		nrep;
+	cl_uint		nslabs;
+	cl_uint		nkeys;
+	cl_ulong	slab_bytes;
+	cl_long		key_min[STROM_PREAGG_MAXKEYS];
+	cl_uint		key_range[STROM_PREAGG_MAXKEYS];
+	cl_uint		key_stride[STROM_PREAGG_MAXKEYS];
+};
+
+inline size_t align16(size_t v) { return (v + 15) & ~(size_t)15; }
+
+}	/* namespace */
+
+struct strom_gpupreagg {
+	strom_devprog_key	key = 0;
+	Program			   *prog = nullptr;
+	Device			   *dev = nullptr;
+	std::vector<strom_preagg_target> targets;
+	std::vector<int>	agg_resno, key_resno;
+	std::vector<char>	kparams;			/* kern_parambuf image */
+	bool				has_domain = false;
+	dense_ctl			ctl;
+	size_t				lds_bytes = 0;
+	size_t				table_bytes = 0;
+	char			   *table = nullptr;	/* resident table (device) */
+	bool				table_owned = false;
+	char			   *d_ctl = nullptr;	/* device copy of ctl */
+	char			   *d_slabs = nullptr;
+	int					block = 1024, quads = 2;
+	std::mutex			lock;
+
+	/* byte offset of a section inside an [bits | per agg (bits, values)] image */
+	size_t image_offset(int sec, cl_uint G, cl_uint REP) const
+	{
+		size_t	off = 0, bits = align16(sizeof(cl_uint) * (((size_t)G + 31) / 32));
+		int		cur = 0;
+		if (sec == cur) return off;
+		off += bits; cur++;
+		for (int resno : agg_resno)
+		{
+			bool nrows = (targets[resno].kind == STROM_PREAGG_NROWS);
+			if (sec == cur) return off;
+			if (!nrows) off += bits;
+			cur++;
+			if (sec == cur) return off;
+			off += align16((nrows ? 4 : 8) * (size_t)G * REP);
+			cur++;
+		}
+		return off;
+	}
+	size_t table_offset(int sec, cl_uint N) const
+	{
+		size_t	off = 0;
+		size_t	bits = STROM_TYPEALIGN(256, sizeof(cl_uint) * (((size_t)N + 31) / 32));
+		size_t	vals = STROM_TYPEALIGN(256, 8 * (size_t)N);
+		int		cur = 0;
+		if (sec == cur) return off;
+		off += bits; cur++;
+		for (size_t a = 0; a < agg_resno.size(); a++)
+		{
+			if (sec == cur) return off;
+			off += bits; cur++;
+			if (sec == cur) return off;
+			off += vals; cur++;
+		}
+		return off;
+	}
+	int nsections() const { return 1 + 2 * (int)agg_resno.size(); }
+};
+
+namespace {
+
+int
+type_length(int type_oid)
+{
+	switch (type_oid)
+	{
+		case STROM_BOOLOID: case STROM_BPCHAROID:	return 1;
+		case STROM_INT2OID:							return 2;
+		case STROM_INT4OID: case STROM_FLOAT4OID: case STROM_DATEOID:	return 4;
+		default:									return 8;
+	}
+}
+
+bool
+type_is_float(int type_oid)
+{
+	return type_oid == STROM_FLOAT4OID || type_oid == STROM_FLOAT8OID;
+}
+
+/*
+ * geometry for a domain: how the dense ids are laid over LDS
+ */
+int
+setup_geometry(strom_gpupreagg *sess, const strom_preagg_domain *dom)
+{
+	Device	   *dev = sess->dev;
+	dense_ctl  &ctl = sess->ctl;
+	size_t		lds_budget = std::min<size_t>(dev->prop.sharedMemPerBlock, 160 * 1024) - 4096;
+
+	if (const char *v = getenv("STROM_GPUPREAGG_LDS_BUDGET"))
+		lds_budget = (size_t)atol(v);
+	if (dom->nkeys != (int)sess->key_resno.size() || dom->nkeys > STROM_PREAGG_MAXKEYS)
+		return StromError_BadRequestMessage;
+	memset(&ctl, 0, sizeof(ctl));
+	ctl.nkeys = dom->nkeys;
+	cl_ulong	ngroups = 1;
+	for (int k = 0; k < dom->nkeys; k++)
+	{
+		ctl.key_min[k] = dom->key_min[k];
+		ctl.key_range[k] = dom->key_range[k];
+		ctl.key_stride[k] = (cl_uint)ngroups;
+		ngroups *= (cl_ulong)dom->key_range[k] + 1;		/* + NULL slot */
+		if (ngroups > (1UL << 26))
+			return StromError_DataStoreOutOfRange;		/* too sparse for dense ids */
+	}
+	ctl.ngroups = (cl_uint)ngroups;
+	/* bytes of LDS per group at one replica (bitmaps are ~1 bit each) */
+	size_t	per_group = 0;
+	for (int resno : sess->agg_resno)
+		per_group += (sess->targets[resno].kind == STROM_PREAGG_NROWS ? 4 : 8);
+	if (per_group == 0)
+		per_group = 1;
+	size_t	one = sess->image_offset(sess->nsections(), ctl.ngroups, 1);
+	if (one <= lds_budget)
+	{
+		ctl.nsplits = 1;
+		ctl.groups_per_split = ctl.ngroups;
+		/* replicas: as many as fit, power of two, at most one per lane of
+		 * a wave -- a wave's 64 lanes then never share an address */
+		cl_uint rep = 1;
+		while (rep < 64 &&
+			   sess->image_offset(sess->nsections(), ctl.ngroups, rep * 2) <= lds_budget / 2)
+			rep *= 2;
+		ctl.nrep = rep;
+	}
+	else
+	{
+		cl_uint nsplits = (cl_uint)((one + lds_budget - 1) / lds_budget);
+		for (;;)
+		{
+			cl_uint G = (ctl.ngroups + nsplits - 1) / nsplits;
+			if (sess->image_offset(sess->nsections(), G, 1) <= lds_budget)
+			{
+				ctl.groups_per_split = G;
+				break;
+			}
+			nsplits++;
+		}
+		ctl.nsplits = nsplits;
+		ctl.nrep = 1;
+		if (nsplits > 64)
+			return StromError_DataStoreOutOfRange;
+	}
+	if (const char *v = getenv("STROM_GPUPREAGG_NREP"))
+		ctl.nrep = std::max(1, atoi(v));
+	sess->lds_bytes = sess->image_offset(sess->nsections(), ctl.groups_per_split, ctl.nrep);
+	ctl.slab_bytes = STROM_TYPEALIGN(256, sess->image_offset(sess->nsections(), ctl.groups_per_split, 1));
+	sess->table_bytes = sess->table_offset(sess->nsections(), ctl.ngroups);
+	/* work-groups: fill the CUs at the occupancy LDS allows */
+	size_t	per_cu = std::max<size_t>(1, std::min<size_t>((size_t)dev->prop.sharedMemPerBlock / std::max<size_t>(sess->lds_bytes, 1),
+														  2048 / sess->block));
+	if (const char *v = getenv("STROM_GPUPREAGG_BLOCKS_PER_CU"))
+		per_cu = std::max(1, atoi(v));
+	size_t	wgs = (size_t)dev->prop.multiProcessorCount * per_cu;
+	wgs = std::max<size_t>(ctl.nsplits, wgs - wgs % ctl.nsplits);
+	ctl.nslabs = (cl_uint)wgs;
+	sess->has_domain = true;
+	return 0;
+}
+
+int
+alloc_session_buffers(strom_gpupreagg *sess)
+{
+	Device *dev = sess->dev;
+	(void)hipSetDevice(dev->hip_id);
+	if (!sess->table)
+	{
+		sess->table = (char *)dev->pool.alloc(sess->table_bytes);
+		if (!sess->table)
+			return StromError_OutOfMemory;
+		sess->table_owned = true;
+		if (hipMemset(sess->table, 0, sess->table_bytes) != hipSuccess)
+			return StromError_HipInternal;
+	}
+	sess->d_ctl = (char *)dev->pool.alloc(sizeof(dense_ctl));
+	sess->d_slabs = (char *)dev->pool.alloc((size_t)sess->ctl.nslabs * sess->ctl.slab_bytes);
+	if (!sess->d_ctl || !sess->d_slabs)
+		return StromError_OutOfMemory;
+	if (hipMemcpy(sess->d_ctl, &sess->ctl, sizeof(dense_ctl), hipMemcpyHostToDevice) != hipSuccess)
+		return StromError_HipInternal;
+	return 0;
+}
+
+#define REQ_CHECK(call, what)												\
+	do {																	\
+		hipError_t __rc = (call);											\
+		if (__rc != hipSuccess)												\
+		{																	\
+			task_fail(task, hip_errcode(__rc, what));						\
+			return;															\
+		}																	\
+	} while (0)
+
+struct preagg_request {
+	strom_gpupreagg	   *sess;
+	const kern_data_store *kds;
+	strom_dstore	   *kds_dev;
+	const kern_row_map *krowmap;
+	uint32_t			format;
+	uint32_t			nrows;
+};
+
+void
+gpupreagg_launch(strom_task_impl *task, preagg_request req)
+{
+	strom_gpupreagg *sess = req.sess;
+	Device	   *dev = task->dev;
+	Program	   *prog = sess->prog;
+	int			errcode = 0;
+
+	(void)hipSetDevice(dev->hip_id);
+	if (prog->state != STROM_DEVPROG_READY)
+	{
+		task_fail(task, StromError_ProgramBuildFailure);
+		return;
+	}
+	task->pfm.time_kern_build = (cl_ulong)prog->build_usec;
+	/* chunks fold into one table: keep them in order on one stream */
+	task->stream = dev->streams[0];
+
+	bool	use_column = (req.format == KDS_FORMAT_COLUMN && req.krowmap == nullptr);
+	hipFunction_t fn = prog->get_function(dev, use_column ? "gpupreagg_dense_column"
+										  : "gpupreagg_dense_generic", &errcode);
+	hipFunction_t fn_merge = fn ? prog->get_function(dev, "gpupreagg_dense_merge", &errcode) : nullptr;
+	if (!fn || !fn_merge)
+	{
+		task_fail(task, errcode);
+		return;
+	}
+	/* kern_gpupreagg image: {status, sortbuf_len, pad, kern_parambuf} */
+	size_t	kg_len = STROMALIGN(offsetof(kern_gpupreagg, kparams) + sess->kparams.size());
+	char   *stage = dev->pinned.alloc();
+	char   *d_kg = (char *)dev->pool.alloc(kg_len);
+	if (!stage || !d_kg || kg_len + 64 > PinnedPool::BLOCK)
+	{
+		if (stage) dev->pinned.release(stage);
+		if (d_kg) dev->pool.release(d_kg);
+		task_fail(task, StromError_OutOfMemory);
+		return;
+	}
+	task->pinned_blocks.push_back(stage);
+	task->main_devptr = d_kg;
+	memset(stage, 0, kg_len);
+	memcpy(stage + offsetof(kern_gpupreagg, kparams), sess->kparams.data(), sess->kparams.size());
+
+	task_event(task);									/* ev[0] */
+	REQ_CHECK(hipMemcpyAsync(d_kg, stage, kg_len, hipMemcpyHostToDevice, task->stream),
+			  "send kern_gpupreagg");
+	task->pfm.num_dma_send++;
+	task->pfm.bytes_dma_send += kg_len;
+	const void *d_kds;
+	if (req.kds_dev)
+		d_kds = req.kds_dev->devptr;
+	else
+	{
+		size_t	kds_len = req.kds->length;
+		if (req.kds->format == KDS_FORMAT_ROW)
+			kds_len = KERN_DATA_STORE_ROWBLOCK_OFFSET(req.kds) + (size_t)BLCKSZ * req.kds->nblocks;
+		void   *p = dev->pool.alloc(kds_len);
+		if (!p)
+		{
+			task_fail(task, StromError_OutOfMemory);
+			return;
+		}
+		task->devbufs.push_back(p);
+		REQ_CHECK(hipMemcpyAsync(p, req.kds, kds_len, hipMemcpyHostToDevice, task->stream),
+				  "send kern_data_store");
+		task->pfm.num_dma_send++;
+		task->pfm.bytes_dma_send += kds_len;
+		d_kds = p;
+	}
+	const void *d_rowmap = nullptr;
+	if (req.krowmap)
+	{
+		size_t	len = offsetof(kern_row_map, rindex) + sizeof(cl_int) * (size_t)req.krowmap->nvalids;
+		void   *p = dev->pool.alloc(len);
+		if (!p)
+		{
+			task_fail(task, StromError_OutOfMemory);
+			return;
+		}
+		task->devbufs.push_back(p);
+		REQ_CHECK(hipMemcpyAsync(p, req.krowmap, len, hipMemcpyHostToDevice, task->stream),
+				  "send kern_row_map");
+		d_rowmap = p;
+	}
+	task_event(task);									/* ev[1] */
+	{
+		void	   *a_kg = d_kg;
+		const void *a_kds = d_kds;
+		const void *a_toast = nullptr;
+		const void *a_map = d_rowmap;
+		void	   *a_ctl = sess->d_ctl;
+		void	   *a_slabs = sess->d_slabs;
+		void	   *a_table = sess->table;
+		void	   *args_col[] = { &a_kg, &a_kds, &a_ctl, &a_slabs };
+		void	   *args_gen[] = { &a_kg, &a_kds, &a_toast, &a_map, &a_ctl, &a_slabs };
+		void	   *args_mrg[] = { &a_kg, &a_ctl, &a_slabs, &a_table };
+		REQ_CHECK(hipModuleLaunchKernel(fn, sess->ctl.nslabs, 1, 1, sess->block, 1, 1,
+										(unsigned)sess->lds_bytes, task->stream,
+										use_column ? args_col : args_gen, nullptr),
+				  "launch gpupreagg reduction");
+		unsigned mgrid = std::min<unsigned>((sess->ctl.ngroups + 255) / 256,
+											(unsigned)dev->prop.multiProcessorCount * 4);
+		REQ_CHECK(hipModuleLaunchKernel(fn_merge, std::max(1u, mgrid), 1, 1, 256, 1, 1, 0,
+										task->stream, args_mrg, nullptr),
+				  "launch gpupreagg merge");
+		task->pfm.num_kern_exec += 2;
+	}
+	task_event(task);									/* ev[2] */
+	char   *stage_status = stage + kg_len;
+	REQ_CHECK(hipMemcpyAsync(stage_status, d_kg + offsetof(kern_gpupreagg, status), sizeof(cl_int),
+							 hipMemcpyDeviceToHost, task->stream),
+			  "recv status");
+	task->pfm.num_dma_recv++;
+	task->pfm.bytes_dma_recv += sizeof(cl_int);
+	task_event(task);									/* ev[3] */
+	task->finish = [stage_status](strom_task_impl *t)
+	{
+		cl_int status;
+		memcpy(&status, stage_status, sizeof(status));
+		t->errcode = status;		/* 0, CpuReCheck, or significant */
+	};
+	task_enqueue(task);
+}
+
+}	/* namespace */
+
+/* ================================================================== *
+ * C ABI
+ * ================================================================== */
+extern "C" strom_gpupreagg *
+strom_gpupreagg_create(strom_devprog_key key,
+					   const strom_preagg_target *targets, int ntargets,
+					   const kern_parambuf *kparams,
+					   const strom_preagg_domain *domain,
+					   int dindex, int *p_errcode)
+{
+	int		dummy;
+	if (!p_errcode)
+		p_errcode = &dummy;
+	*p_errcode = 0;
+	Program *prog = lookup_program(key);
+	Device *dev = get_device(dindex);
+	if (!prog || !dev || !targets || ntargets < 1 || !kparams)
+	{
+		*p_errcode = (!dev ? StromError_ServerNotReady : StromError_BadRequestMessage);
+		return nullptr;
+	}
+	strom_gpupreagg *sess = new strom_gpupreagg();
+	sess->key = key;
+	sess->prog = prog;
+	sess->dev = dev;
+	sess->targets.assign(targets, targets + ntargets);
+	for (int i = 0; i < ntargets; i++)
+	{
+		if (targets[i].kind == STROM_PREAGG_KEY)
+		{
+			if (type_is_float(targets[i].type_oid) || targets[i].type_oid == STROM_NUMERICOID)
+			{
+				/* dense ids need integer-like keys */
+				*p_errcode = StromError_DataStoreOutOfRange;
+				delete sess;
+				return nullptr;
+			}
+			sess->key_resno.push_back(i);
+		}
+		else
+			sess->agg_resno.push_back(i);
+	}
+	sess->kparams.assign((const char *)kparams, (const char *)kparams + kparams->length);
+	if (const char *v = getenv("STROM_GPUPREAGG_BLOCK"))
+		sess->block = atoi(v);
+	if (const char *v = getenv("STROM_GPUPREAGG_QUADS"))
+		sess->quads = atoi(v);
+	strom_retain_devprog_key(key);
+	if (domain)
+	{
+		int rc = setup_geometry(sess, domain);
+		if (rc == 0)
+			rc = alloc_session_buffers(sess);
+		if (rc != 0)
+		{
+			*p_errcode = rc;
+			strom_gpupreagg_release(sess);
+			return nullptr;
+		}
+	}
+	return sess;
+}
+
+extern "C" size_t
+strom_gpupreagg_table_length(strom_gpupreagg *sess)
+{
+	return (sess && sess->has_domain) ? sess->table_bytes : 0;
+}
+
+extern "C" int
+strom_gpupreagg_bind_table(strom_gpupreagg *sess, void *table_devptr)
+{
+	if (!sess || !sess->has_domain || !table_devptr)
+		return StromError_BadRequestMessage;
+	std::lock_guard<std::mutex> g(sess->lock);
+	(void)hipSetDevice(sess->dev->hip_id);
+	if (hipMemcpy(table_devptr, sess->table, sess->table_bytes, hipMemcpyDeviceToDevice) != hipSuccess)
+		return StromError_HipInternal;
+	if (sess->table_owned)
+		sess->dev->pool.release(sess->table);
+	sess->table = (char *)table_devptr;
+	sess->table_owned = false;
+	return 0;
+}
+
+extern "C" void *
+strom_gpupreagg_table_devptr(strom_gpupreagg *sess) { return sess ? sess->table : nullptr; }
+
+extern "C" uint32_t
+strom_gpupreagg_num_groups(strom_gpupreagg *sess) { return (sess && sess->has_domain) ? sess->ctl.ngroups : 0; }
+
+extern "C" int
+strom_gpupreagg_table_layout(strom_gpupreagg *sess, int resno, size_t *p_bits_off, size_t *p_vals_off)
+{
+	if (!sess || !sess->has_domain || resno < 0 || resno >= (int)sess->targets.size())
+		return StromError_BadRequestMessage;
+	if (sess->targets[resno].kind == STROM_PREAGG_KEY)
+	{
+		*p_bits_off = 0;
+		*p_vals_off = 0;
+		return 0;
+	}
+	int a = (int)(std::find(sess->agg_resno.begin(), sess->agg_resno.end(), resno) - sess->agg_resno.begin());
+	*p_bits_off = sess->table_offset(1 + 2 * a, sess->ctl.ngroups);
+	*p_vals_off = sess->table_offset(2 + 2 * a, sess->ctl.ngroups);
+	return 0;
+}
+
+extern "C" strom_task *
+strom_submit_gpupreagg(strom_gpupreagg *sess,
+					   const kern_data_store *kds, strom_dstore *kds_dev,
+					   const kern_row_map *krowmap,
+					   strom_done_cb done, void *arg, int *p_errcode)
+{
+	int		dummy;
+	if (!p_errcode)
+		p_errcode = &dummy;
+	*p_errcode = 0;
+	if (!sess || (!kds) == (!kds_dev))
+	{
+		*p_errcode = StromError_BadRequestMessage;
+		return nullptr;
+	}
+	if (kds_dev && kds_dev->dindex != sess->dev->dindex)
+	{
+		*p_errcode = StromError_BadRequestMessage;
+		return nullptr;
+	}
+	if (!sess->has_domain)
+	{
+		/* first chunk fixes the dense domain (see strom_hip.h) */
+		*p_errcode = StromError_DataStoreOutOfRange;
+		return nullptr;
+	}
+	preagg_request req;
+	req.sess = sess;
+	req.kds = kds;
+	req.kds_dev = kds_dev;
+	req.krowmap = (krowmap && krowmap->nvalids >= 0) ? krowmap : nullptr;
+	kern_data_store head;
+	if (kds)
+		memcpy(&head, kds, offsetof(kern_data_store, colmeta));
+	else
+		head = kds_dev->head;
+	req.format = head.format;
+	req.nrows = req.krowmap ? (uint32_t)req.krowmap->nvalids : head.nitems;
+	strom_task_impl *task = task_create(sess->dev, done, arg);
+	program_run_or_park(sess->prog, [task, req]() { gpupreagg_launch(task, req); });
+	return task;
+}
+
+extern "C" void
+strom_gpupreagg_reset(strom_gpupreagg *sess)
+{
+	if (!sess || !sess->table)
+		return;
+	(void)hipSetDevice(sess->dev->hip_id);
+	(void)hipStreamSynchronize(sess->dev->streams[0]);
+	(void)hipMemset(sess->table, 0, sess->table_bytes);
+}
+
+extern "C" void
+strom_gpupreagg_release(strom_gpupreagg *sess)
+{
+	if (!sess)
+		return;
+	Device *dev = sess->dev;
+	(void)hipSetDevice(dev->hip_id);
+	(void)hipStreamSynchronize(dev->streams[0]);
+	if (sess->table_owned && sess->table)
+		dev->pool.release(sess->table);
+	if (sess->d_ctl)
+		dev->pool.release(sess->d_ctl);
+	if (sess->d_slabs)
+		dev->pool.release(sess->d_slabs);
+	strom_put_devprog_key(sess->key);
+	delete sess;
+}
+
+/*
+ * partial rows out: TUPSLOT, one row per group seen so far
+ */
+extern "C" long
+strom_gpupreagg_fetch(strom_gpupreagg *sess, kern_data_store *dest, size_t destlen)
+{
+	if (!sess || !sess->has_domain)
+		return -StromError_BadRequestMessage;
+	Device *dev = sess->dev;
+	int		ncols = (int)sess->targets.size();
+	cl_uint	N = sess->ctl.ngroups;
+	std::vector<char> host(sess->table_bytes);
+
+	(void)hipSetDevice(dev->hip_id);
+	if (hipStreamSynchronize(dev->streams[0]) != hipSuccess ||
+		hipMemcpy(host.data(), sess->table, sess->table_bytes, hipMemcpyDeviceToHost) != hipSuccess)
+		return -StromError_HipInternal;
+	const cl_uint *seen = (const cl_uint *)host.data();
+	size_t	ngroups = 0;
+	for (cl_uint g = 0; g < N; g++)
+		if ((seen[g >> 5] >> (g & 31)) & 1)
+			ngroups++;
+	size_t	need = STROMALIGN(KDS_HEAD_LENGTH(ncols) + KDS_TUPSLOT_STRIDE(ncols) * ngroups);
+	if (!dest)
+		return (long)need;
+	if (destlen < need)
+		return -StromError_DataStoreNoSpace;
+	memset(dest, 0, KDS_HEAD_LENGTH(ncols));
+	dest->hostptr = (hostptr_t)(uintptr_t)&dest->hostptr;
+	dest->length = (cl_uint)need;
+	dest->ncols = ncols;
+	dest->nrooms = (cl_uint)ngroups;
+	dest->format = KDS_FORMAT_TUPSLOT;
+	dest->tdtypeid = 2249;
+	dest->tdtypmod = -1;
+	for (int i = 0; i < ncols; i++)
+	{
+		const strom_preagg_target &t = sess->targets[i];
+		int len = (t.kind == STROM_PREAGG_NROWS ? 8 : type_length(t.type_oid));
+		dest->colmeta[i].attbyval = 1;
+		dest->colmeta[i].attalign = (cl_char)len;
+		dest->colmeta[i].attlen = (cl_short)len;
+		dest->colmeta[i].attnum = (cl_short)(i + 1);
+		dest->colmeta[i].attcacheoff = -1;
+	}
+	cl_uint	row = 0;
+	for (cl_uint g = 0; g < N; g++)
+	{
+		if (!((seen[g >> 5] >> (g & 31)) & 1))
+			continue;
+		Datum	   *values = KERN_DATA_STORE_VALUES(dest, row);
+		cl_char	   *isnull = KERN_DATA_STORE_ISNULL(dest, row);
+		memset(values, 0, KDS_TUPSLOT_STRIDE(ncols));
+		for (size_t k = 0; k < sess->key_resno.size(); k++)
+		{
+			int		resno = sess->key_resno[k];
+			cl_uint	off = (g / sess->ctl.key_stride[k]) % (sess->ctl.key_range[k] + 1);
+			if (off == sess->ctl.key_range[k])
+				isnull[resno] = 1;
+			else
+			{
+				cl_long v = sess->ctl.key_min[k] + off;
+				memcpy(&values[resno], &v, type_length(sess->targets[resno].type_oid));
+			}
+		}
+		for (size_t a = 0; a < sess->agg_resno.size(); a++)
+		{
+			int		resno = sess->agg_resno[a];
+			const strom_preagg_target &t = sess->targets[resno];
+			const cl_uint  *bits = (const cl_uint *)(host.data() + sess->table_offset(1 + 2 * (int)a, N));
+			const cl_ulong *vals = (const cl_ulong *)(host.data() + sess->table_offset(2 + 2 * (int)a, N));
+			if (t.kind == STROM_PREAGG_NROWS)
+				values[resno] = vals[g];
+			else if (!((bits[g >> 5] >> (g & 31)) & 1))
+				isnull[resno] = 1;
+			else
+			{
+				cl_ulong raw = vals[g];
+				if (type_is_float(t.type_oid))
+				{
+					if (t.kind != STROM_PREAGG_PSUM)
+					{
+						/* order-preserving key -> IEEE bits */
+						raw = (raw & 0x8000000000000000UL) ? (raw & 0x7fffffffffffffffUL) : ~raw;
+					}
+					if (t.type_oid == STROM_FLOAT4OID)
+					{
+						double d; float f;
+						memcpy(&d, &raw, 8);
+						f = (float)d;
+						raw = 0;
+						memcpy(&raw, &f, 4);
+					}
+					values[resno] = raw;
+				}
+				else
+					memcpy(&values[resno], &raw, type_length(t.type_oid));
+			}
+		}
+		row++;
+	}
+	dest->nitems = row;
+	return (long)row;
+}

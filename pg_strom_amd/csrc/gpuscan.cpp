@@ -60,7 +60,17 @@ gpuscan_launch(strom_task_impl *task, Program *prog, gpuscan_request req)
 		return;
 	}
 	task->pfm.time_kern_build = (cl_ulong)prog->build_usec;
-	task->stream = dev->pick_stream();
+	/*
+	 * A resident chunk needs no bulk DMA, so nothing is gained by letting
+	 * two bandwidth-bound kernels share the chip: such requests run in
+	 * order on stream 0 (their event pairs then time the kernel alone).
+	 * Requests that upload their chunk rotate over the other streams so
+	 * that the next chunk's DMA overlaps this chunk's kernel.
+	 */
+	if (req.kds_dev || dev->streams.size() < 2)
+		task->stream = dev->streams[0];
+	else
+		task->stream = dev->streams[1 + dev->next_stream++ % (dev->streams.size() - 1)];
 
 	bool		use_column = (req.format == KDS_FORMAT_COLUMN && req.krowmap == nullptr);
 	hipFunction_t fn = prog->get_function(dev, use_column ? "gpuscan_qual_column"
@@ -79,8 +89,17 @@ gpuscan_launch(strom_task_impl *task, Program *prog, gpuscan_request req)
 	task->main_devptr = d_kgs;
 	task->keep_main = (!task->detached && (req.flags & STROM_RESULTS_ON_DEVICE) != 0);
 
+	/* request head goes down (and the result head comes back) through a
+	 * pinned staging block so that both copies are truly asynchronous */
+	char	   *stage = (head_len + 64 <= PinnedPool::BLOCK ? dev->pinned.alloc() : nullptr);
+	if (stage)
+	{
+		task->pinned_blocks.push_back(stage);
+		memcpy(stage, kgs, head_len);
+	}
 	task_event(task);									/* ev[0] */
-	REQ_CHECK(hipMemcpyAsync(d_kgs, kgs, head_len, hipMemcpyHostToDevice, task->stream),
+	REQ_CHECK(hipMemcpyAsync(d_kgs, stage ? (void *)stage : (void *)kgs, head_len,
+							 hipMemcpyHostToDevice, task->stream),
 			  "send kern_gpuscan");
 	task->pfm.num_dma_send++;
 	task->pfm.bytes_dma_send += head_len;
@@ -135,7 +154,7 @@ gpuscan_launch(strom_task_impl *task, Program *prog, gpuscan_request req)
 		int		block = 256;
 		if (const char *v = getenv("STROM_GPUSCAN_BLOCK"))
 			block = atoi(v);
-		int		quads = 2;
+		int		quads = 1;
 		if (const char *v = getenv("STROM_GPUSCAN_QUADS"))
 			quads = atoi(v);
 		size_t	tile_rows = (size_t)block * 4 * quads;
@@ -164,7 +183,9 @@ gpuscan_launch(strom_task_impl *task, Program *prog, gpuscan_request req)
 	}
 	task_event(task);									/* ev[2] */
 	/* result head first; results[0..nitems) follow once nitems is known */
-	REQ_CHECK(hipMemcpyAsync(kres_host, d_kgs + res_offset, offsetof(kern_resultbuf, results),
+	char	   *stage_res = (stage ? stage + STROMALIGN(head_len) : nullptr);
+	REQ_CHECK(hipMemcpyAsync(stage_res ? (void *)stage_res : (void *)kres_host,
+							 d_kgs + res_offset, offsetof(kern_resultbuf, results),
 							 hipMemcpyDeviceToHost, task->stream),
 			  "recv kern_resultbuf head");
 	task->pfm.num_dma_recv++;
@@ -172,8 +193,10 @@ gpuscan_launch(strom_task_impl *task, Program *prog, gpuscan_request req)
 	task_event(task);									/* ev[3] */
 
 	bool	results_on_device = (req.flags & STROM_RESULTS_ON_DEVICE) != 0;
-	task->finish = [kres_host, d_kgs, res_offset, results_on_device](strom_task_impl *t)
+	task->finish = [kres_host, d_kgs, res_offset, results_on_device, stage_res](strom_task_impl *t)
 	{
+		if (stage_res)
+			memcpy(kres_host, stage_res, offsetof(kern_resultbuf, results));
 		if (StromErrorIsSignificant(kres_host->errcode))
 			t->errcode = kres_host->errcode;
 		if (results_on_device || kres_host->nitems == 0)

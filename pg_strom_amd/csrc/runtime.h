@@ -41,6 +41,19 @@ private:
 	static size_t size_class(size_t nbytes);
 };
 
+/* ---- pinned host staging blocks for the small per-request DMA (request
+ * head down, result head up): a copy from/to pageable memory would make
+ * hipMemcpyAsync synchronous ------------------------------------------- */
+class PinnedPool {
+public:
+	static const size_t BLOCK = 16384;
+	char   *alloc();
+	void	release(char *blk);
+private:
+	std::mutex				lock_;
+	std::vector<char *>		free_;
+};
+
 struct Program {
 	strom_devprog_key	key = 0;
 	std::string			source;
@@ -67,6 +80,9 @@ struct Device {
 	std::vector<hipStream_t> streams;
 	std::atomic<unsigned> next_stream{0};
 	BufferPool			pool;
+	PinnedPool			pinned;
+	std::mutex			ev_lock;
+	std::vector<hipEvent_t> ev_free_timing, ev_free_plain;
 	/* completion side: one thread per device plays the role of the OpenCL
 	 * runtime's callback thread (clSetEventCallback -> clserv_respond_*) */
 	std::thread			completer;
@@ -109,6 +125,7 @@ struct strom_task_impl : public strom_task {
 	bool		has_ev_prep = false, has_ev_proj = false;
 	/* device buffers to hand back to the pool at completion */
 	std::vector<void *> devbufs;
+	std::vector<char *> pinned_blocks;
 	void	   *main_devptr = nullptr;	/* kern_gpuscan / kern_hashjoin image */
 	bool		keep_main = false;		/* released by strom_task_wait */
 	/* operator-specific second half, runs on the completer thread after the

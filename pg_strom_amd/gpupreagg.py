@@ -1,0 +1,195 @@
+"""
+GpuPreAgg operator, host side -- mirrors the executor half of gpupreagg.c:
+    gpupreagg_begin (2189-2327)      codegen, program key, parambuf
+    gpupreagg_load_next_outer / pgstrom_create_gpupreagg (2329-2498)
+                                     one request per chunk
+    gpupreagg_next_tuple (2609-2663) partial rows out (TUPSLOT)
+and the partial -> final merge the reference leaves to PostgreSQL's Agg node
+with the pgstrom.* final aggregates (gpupreagg.c:4430-4773,
+pg_strom--1.0.sql:247-401): see finalize().
+
+Aggregates are rewritten to partial functions exactly as
+gpupreagg_rewrite_expr does (gpupreagg.c:134-333, 729-1166):
+    count(*)      -> sum(nrows())
+    count(x)      -> sum(nrows(x is not null))
+    sum(int2/4)   -> sum(psum(x::int8))            (int8 result)
+    avg(int2/4/8) -> psum(x::int8) / nrows(x is not null)
+    avg/sum(float)-> psum(x::float8) [/ nrows]
+    min/max       -> min/max(pmin/pmax(x))
+    stddev/var    -> (nrows, psum(x), psum_x2(x))  float only
+"""
+import ctypes
+
+import numpy as np
+
+from ._lib import lib, strom_perfmon, strom_codegen_result, strom_preagg_target, \
+    strom_preagg_domain
+from . import runtime
+from .kds import KdsHead, aligned_buffer, KDS_HEAD_FIXED
+
+KIND_KEY, KIND_NROWS, KIND_PSUM, KIND_PMIN, KIND_PMAX = 1, 2, 3, 4, 5
+FLOAT_OIDS = (700, 701)
+TYPE_DTYPES = {16: np.int8, 21: np.int16, 23: np.int32, 20: np.int64, 700: np.float32,
+               701: np.float64, 1082: np.int32, 1083: np.int64, 1114: np.int64,
+               1042: np.int8, 1700: np.uint64}
+
+
+def codegen_gpupreagg(spec):
+    res = strom_codegen_result()
+    targets = (strom_preagg_target * 64)()
+    n = ctypes.c_int(0)
+    rc = lib.strom_codegen_gpupreagg(spec.encode(), ctypes.byref(res), targets, 64, ctypes.byref(n))
+    if rc != 0:
+        msg = ctypes.string_at(res.errmsg).decode() if res.errmsg else "?"
+        lib.strom_codegen_release(ctypes.byref(res))
+        raise ValueError("codegen: " + msg)
+    cg = runtime.Codegen(res)
+    cg.targets = [(targets[i].kind, targets[i].type_oid) for i in range(n.value)]
+    cg._targets_c = targets
+    return cg
+
+
+def domain_of(chunks, key_columns):
+    """dense group domain (min, range per key) from the zone maps of COLUMN
+    chunks; chunks are uint8 kds images, key_columns 0-based column numbers"""
+    mins, maxs = [None] * len(key_columns), [None] * len(key_columns)
+    for buf in chunks:
+        head = KdsHead(buf)
+        assert head.format == 4, "zone maps exist in KDS_FORMAT_COLUMN only"
+        off = (KDS_HEAD_FIXED + 8 * head.ncols + 15) & ~15
+        for i, col in enumerate(key_columns):
+            cd = buf[off + 32 * col: off + 32 * col + 32]
+            flags = int(np.frombuffer(cd[12:16].tobytes(), dtype=np.uint32)[0])
+            if not flags & 1:
+                continue                      # all NULL in this chunk
+            mn, mx = np.frombuffer(cd[16:32].tobytes(), dtype=np.int64)
+            mins[i] = mn if mins[i] is None else min(mins[i], mn)
+            maxs[i] = mx if maxs[i] is None else max(maxs[i], mx)
+    dom = []
+    for mn, mx in zip(mins, maxs):
+        dom.append((0, 0) if mn is None else (int(mn), int(mx - mn + 1)))
+    return dom
+
+
+class PartialRows(object):
+    """decoded TUPSLOT result: one partial row per group"""
+
+    def __init__(self, targets, values, isnull):
+        self.targets = targets
+        self.values = values        # uint64 [nrows, ncols] raw datum images
+        self.isnull = isnull        # bool   [nrows, ncols]
+
+    def __len__(self):
+        return self.values.shape[0]
+
+    def column(self, resno):
+        kind, oid = self.targets[resno]
+        raw = np.ascontiguousarray(self.values[:, resno])
+        if kind == KIND_NROWS:
+            return raw.view(np.int64), self.isnull[:, resno]
+        dt = np.dtype(TYPE_DTYPES[oid])
+        if dt.itemsize == 8:
+            return raw.view(dt), self.isnull[:, resno]
+        return raw.view(np.uint8).reshape(-1, 8)[:, :dt.itemsize].copy().view(dt).reshape(-1), \
+            self.isnull[:, resno]
+
+
+class GpuPreAgg(object):
+    def __init__(self, spec):
+        self.spec = spec
+        self.codegen = codegen_gpupreagg(spec)
+        self.targets = self.codegen.targets
+        self.program = None
+        self.session = None
+
+    def begin(self, domain, ext_params=(), ext_isnull=None, dindex=0):
+        """domain: [(min, range)] per key in target order (see domain_of)"""
+        runtime.init()
+        self.program = runtime.DevProgram(self.codegen.source, self.codegen.extra_flags)
+        self.parambuf = self.codegen.parambuf(ext_params, ext_isnull)
+        dom = strom_preagg_domain()
+        dom.nkeys = len(domain)
+        for i, (mn, rng) in enumerate(domain):
+            dom.key_min[i] = mn
+            dom.key_range[i] = rng
+        err = ctypes.c_int(0)
+        pb = ctypes.create_string_buffer(self.parambuf, len(self.parambuf))
+        self.session = lib.strom_gpupreagg_create(self.program.key, self.codegen._targets_c,
+                                                  len(self.targets), pb, ctypes.byref(dom),
+                                                  dindex, ctypes.byref(err))
+        if not self.session:
+            raise runtime.StromError(err.value, "strom_gpupreagg_create")
+        return self
+
+    # requests -------------------------------------------------------------
+    def submit(self, chunk, row_map=None):
+        if isinstance(chunk, runtime.DeviceStore):
+            kds_host, kds_dev = None, chunk.handle
+        else:
+            kds_host, kds_dev = chunk.ctypes.data, None
+        rm = None
+        if row_map is not None:
+            r = np.ascontiguousarray(row_map, dtype=np.int32)
+            rm = np.concatenate([np.array([len(r)], dtype=np.int32), r])
+        err = ctypes.c_int(0)
+        task = lib.strom_submit_gpupreagg(self.session, kds_host, kds_dev,
+                                          rm.ctypes.data if rm is not None else None,
+                                          None, None, ctypes.byref(err))
+        if not task:
+            raise runtime.StromError(err.value, "strom_submit_gpupreagg")
+        return (task, chunk, rm)
+
+    def collect(self, pending):
+        """returns (status, perfmon): status 0 folded, 2 CpuReCheck (not folded)"""
+        pfm = strom_perfmon()
+        rc = lib.strom_task_wait(pending[0], ctypes.byref(pfm))
+        if rc == -11:
+            raise runtime.StromError(rc, "GpuPreAgg kernel build:\n" + self.program.errmsg())
+        if rc not in (0, 2):
+            raise runtime.StromError(rc, "GpuPreAgg")
+        return rc, runtime.perfmon_dict(pfm)
+
+    def fold(self, chunk, row_map=None):
+        return self.collect(self.submit(chunk, row_map))
+
+    # results ---------------------------------------------------------------
+    def fetch(self):
+        need = lib.strom_gpupreagg_fetch(self.session, None, 0)
+        if need < 0:
+            raise runtime.StromError(-need, "strom_gpupreagg_fetch")
+        buf = aligned_buffer(need, 64)
+        n = lib.strom_gpupreagg_fetch(self.session, buf.ctypes.data, need)
+        if n < 0:
+            raise runtime.StromError(-n, "strom_gpupreagg_fetch")
+        ncols = len(self.targets)
+        head = (KDS_HEAD_FIXED + 8 * ncols + 15) & ~15
+        stride = (9 * ncols + 7) & ~7
+        body = np.frombuffer(buf[head:head + stride * n].tobytes(), dtype=np.uint8).reshape(n, stride)
+        values = body[:, :8 * ncols].copy().view(np.uint64).reshape(n, ncols)
+        isnull = body[:, 8 * ncols:9 * ncols] != 0
+        return PartialRows(self.targets, values, isnull)
+
+    def table_tensor_info(self):
+        """(device pointer, nbytes, ngroups) of the resident table -- what an
+        RCCL all-reduce operates on"""
+        return (lib.strom_gpupreagg_table_devptr(self.session),
+                lib.strom_gpupreagg_table_length(self.session),
+                lib.strom_gpupreagg_num_groups(self.session))
+
+    def table_layout(self, resno):
+        b, v = ctypes.c_size_t(0), ctypes.c_size_t(0)
+        rc = lib.strom_gpupreagg_table_layout(self.session, resno, ctypes.byref(b), ctypes.byref(v))
+        if rc != 0:
+            raise runtime.StromError(rc, "strom_gpupreagg_table_layout")
+        return b.value, v.value
+
+    def reset(self):
+        lib.strom_gpupreagg_reset(self.session)
+
+    def end(self):
+        if self.session:
+            lib.strom_gpupreagg_release(self.session)
+            self.session = None
+        if self.program is not None:
+            self.program.release()
+            self.program = None

@@ -78,7 +78,8 @@ class GpuScan(object):
             rm = np.ascontiguousarray(row_map, dtype=np.int32)
             rowmap_buf = np.concatenate([np.array([len(rm)], dtype=np.int32), rm])
             nrooms = len(rm)
-        kgs, res_off = make_kern_gpuscan(self.parambuf, max(nrooms, 1))
+        kgs, res_off = make_kern_gpuscan(self.parambuf, max(nrooms, 1),
+                                         host_results=not (flags & STROM_RESULTS_ON_DEVICE))
         err = ctypes.c_int(0)
         task = lib.strom_submit_gpuscan(self.program.key, kgs.ctypes.data, kds_host, kds_dev,
                                         rowmap_buf.ctypes.data if rowmap_buf is not None else None,
@@ -95,7 +96,11 @@ class GpuScan(object):
             if rc == -11:
                 raise runtime.StromError(rc, "GpuScan kernel build:\n" + self.program.errmsg())
             raise runtime.StromError(rc, "GpuScan")
-        nitems, errcode, results = read_resultbuf(kgs, res_off)
+        if len(kgs) - res_off <= 32:     # head only (results stayed on the device)
+            head = np.frombuffer(kgs[res_off:res_off + 20].tobytes(), dtype=np.int32)
+            nitems, errcode, results = int(head[2]), int(head[3]), np.zeros(0, dtype=np.int32)
+        else:
+            nitems, errcode, results = read_resultbuf(kgs, res_off)
         return GpuScanResult(nitems, errcode, results, runtime.perfmon_dict(pfm))
 
     def scan_chunk(self, chunk, **kw):

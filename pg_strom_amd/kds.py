@@ -139,9 +139,11 @@ def kds_fetch(kds_buf, row, col):
 # ---------------------------------------------------------------------
 # kern_gpuscan = kern_parambuf followed by kern_resultbuf
 # ---------------------------------------------------------------------
-def make_kern_gpuscan(parambuf_bytes, nrooms, nrels=1):
+def make_kern_gpuscan(parambuf_bytes, nrooms, nrels=1, host_results=True):
+    """host image of kern_gpuscan.  host_results=False: results[] stay on the
+    device (STROM_RESULTS_ON_DEVICE), only the head is backed by host memory"""
     plen = stromalign(len(parambuf_bytes))
-    rlen = stromalign(RESULTBUF_HEAD + 4 * nrels * nrooms)
+    rlen = stromalign(RESULTBUF_HEAD + 4 * nrels * (nrooms if host_results else 0))
     buf = aligned_buffer(plen + rlen, 64)
     buf[:plen] = 0
     buf[:len(parambuf_bytes)] = np.frombuffer(parambuf_bytes, dtype=np.uint8)

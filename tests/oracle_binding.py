@@ -39,6 +39,12 @@ def load():
                                        ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint32),
                                        ctypes.c_char_p, ctypes.c_size_t]
         lib.oracle_get_layout.argtypes = [ctypes.POINTER(oracle_layout)]
+        lib.oracle_gpupreagg.restype = ctypes.c_int32
+        lib.oracle_gpupreagg.argtypes = [ctypes.c_char_p, ctypes.c_void_p, ctypes.c_void_p,
+                                         ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
+                                         ctypes.c_uint32, ctypes.c_void_p, ctypes.c_void_p,
+                                         ctypes.POINTER(ctypes.c_uint32), ctypes.c_char_p,
+                                         ctypes.c_size_t]
         _lib = lib
     return _lib
 
@@ -84,6 +90,27 @@ def gpuscan(qual, kds_buf, ext_params=(), row_map=None, nitems=None):
     if rc == 101 and err.value:
         raise ValueError("oracle: " + err.value.decode())
     return rc, results[:cnt.value].copy()
+
+
+def gpupreagg(spec, kds_buf, ntargets, ext_params=(), row_map=None, max_groups=1 << 16):
+    """one chunk -> (status, values uint64 [ngroups, ntargets], isnull bool [...])"""
+    lib = load()
+    vals, nulls, n = ext_arrays(ext_params)
+    rm = None
+    if row_map is not None:
+        rm = np.concatenate([np.array([len(row_map)], dtype=np.int32),
+                             np.ascontiguousarray(row_map, dtype=np.int32)])
+    out_v = np.zeros((max_groups, ntargets), dtype=np.uint64)
+    out_n = np.zeros((max_groups, ntargets), dtype=np.uint8)
+    cnt = ctypes.c_uint32(0)
+    err = ctypes.create_string_buffer(256)
+    rc = lib.oracle_gpupreagg(spec.encode(), vals.ctypes.data, nulls.ctypes.data, n,
+                              kds_buf.ctypes.data, rm.ctypes.data if rm is not None else None,
+                              max_groups, out_v.ctypes.data, out_n.ctypes.data,
+                              ctypes.byref(cnt), err, 256)
+    if rc == 101 and err.value:
+        raise ValueError("oracle: " + err.value.decode())
+    return rc, out_v[:cnt.value].copy(), out_n[:cnt.value].astype(bool)
 
 
 def layout():

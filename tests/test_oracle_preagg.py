@@ -1,0 +1,76 @@
+"""
+CPU oracle for GpuPreAgg against the reference's own regression results
+(no GPU).  This is the pin that keeps the oracle honest: 300+ queries whose
+answers were printed by stock PostgreSQL (expected/*.out), over the
+regenerated gpupreagg_test fixture -- integer aggregates exact, avg(int)
+exact as numeric text, float aggregates at the precision PostgreSQL printed
+(extra_float_digits = -3).
+"""
+import numpy as np
+import pytest
+
+import agg_golden
+import oracle_binding as oracle
+from pg_strom_amd import kds
+
+
+def decode_oracle_column(values, isnull, kind):
+    if kind == "float":
+        return values.view(np.float64) if values.flags.c_contiguous else \
+            np.ascontiguousarray(values).view(np.float64), isnull
+    return np.ascontiguousarray(values).view(np.int64), isnull
+
+
+def oracle_runner(chunks):
+    def run(plan):
+        vals, nulls = [], []
+        for buf, rows in chunks[plan["table"]]:
+            rc, v, n = oracle.gpupreagg(plan["spec"], buf, plan["ntargets"])
+            assert rc in (0, 2)
+            if rc == 2:
+                # int8 partial sum overflowed: the chunk goes to the CPU path
+                assert plan["type"] == "int8"
+                v, n = agg_golden.cpu_fallback_rows(plan, rows)
+            vals.append(v)
+            nulls.append(n)
+        return np.concatenate(vals), np.concatenate(nulls)
+    return run
+
+
+@pytest.mark.parametrize("fmt,nchunks", [("row", 1), ("column", 3), ("tupslot", 2)])
+def test_reference_regression_suites(fmt, nchunks):
+    chunks = {"gpupreagg_test": agg_golden.fixture_chunks(fmt, nchunks),
+              "gpupreagg_zero_test": agg_golden.fixture_chunks(fmt, 1, empty=True)}
+    run = oracle_runner(chunks)
+    total = 0
+    for suite in ("nogrp_agg", "group_agg", "where_agg", "zero_agg"):
+        checked, skipped = agg_golden.check_suite(suite, run, decode_oracle_column)
+        assert checked >= 50, (suite, checked, skipped)
+        total += checked
+    assert total >= 200        # 50 in-catalog aggregates x 4 suites
+
+
+def test_partial_semantics_small():
+    k = np.array([1, 1, 2, 2, 2, 0, 0], dtype=np.int32)
+    kn = np.array([0, 0, 0, 0, 0, 1, 1], dtype=np.uint8)
+    x = np.array([10, 20, 5, 0, 7, 1, 2], dtype=np.int32)
+    xn = np.array([0, 1, 0, 1, 0, 1, 1], dtype=np.uint8)
+    buf = kds.build_kds("row", [kds.Column("int4", k, kn), kds.Column("int4", x, xn)])
+    spec = ("(gpupreagg (key (var 1 int4)) (nrows) (nrows (isnotnull (var 2 int4)))"
+            " (psum (int8 (var 2 int4))) (pmin (var 2 int4)) (pmax (var 2 int4)))")
+    rc, v, n = oracle.gpupreagg(spec, buf, 6)
+    assert rc == 0 and len(v) == 3
+    rows = {(None if n[i, 0] else int(v[i, 0])): i for i in range(3)}
+    i = rows[1]
+    assert list(v[i, 1:].view(np.int64)) == [2, 1, 10, 10, 10] and not n[i, 1:].any()
+    i = rows[2]
+    assert list(v[i, 1:].view(np.int64)) == [3, 2, 12, 5, 7]
+    i = rows[None]                       # NULL keys form one group; all inputs NULL
+    assert list(v[i, 1:3].view(np.int64)) == [2, 0] and list(n[i, 3:]) == [True, True, True]
+
+
+def test_recheck_makes_the_chunk_recheck():
+    x = np.array([1, 2**31 - 1, 3], dtype=np.int32)
+    buf = kds.build_kds("column", [kds.Column("int4", x)])
+    rc, v, n = oracle.gpupreagg("(gpupreagg (psum (int8 (int4pl (var 1 int4) (const int4 1)))))", buf, 1)
+    assert rc == 2 and len(v) == 0
