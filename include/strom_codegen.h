@@ -99,6 +99,15 @@ int		strom_codegen_gpupreagg(const char *spec, strom_codegen_result *out,
 								int *p_ntargets);
 
 /*
+ * GpuHashJoin: gpuhashjoin_codegen (gpuhashjoin.c:1353-1460).
+ *   (gpuhashjoin (rel (hashkey OUTER-EXPR INNER-ATTNO TYPE) ... [(qual BOOL-EXPR)]) ...)
+ * One (rel ..) per inner relation, in join order.  OUTER-EXPR may use
+ * (var ..) of the outer chunk and (ivar DEPTH ATTNO TYPE) of a relation
+ * matched earlier; a qual may also use the current depth.
+ */
+int		strom_codegen_gpuhashjoin(const char *spec, strom_codegen_result *out, int *p_nrels);
+
+/*
  * Can this expression run on the device?  (pgstrom_codegen_available_
  * expression, codegen.c:1631-1759.)  1 yes, 0 no; errmsg (if not NULL)
  * receives a malloc'ed reason.

@@ -54,6 +54,22 @@ size_t	strom_kds_to_column(const kern_data_store *src, void *dst, size_t dstlen)
 int		strom_kds_fetch(const kern_data_store *kds, uint32_t rowidx, uint32_t colidx,
 						uint64_t *value);
 
+/*
+ * Inner side of a hash join: multihash_preload_khashtable
+ * (gpuhashjoin.c:3614-3816).  One kern_hashtable per inner relation inside
+ * one kern_multihash; each entry owns the inner row as a heap tuple,
+ * rowid = row number in 'inner', hash = pg_crc32 of the key datums.
+ */
+typedef struct {
+	const kern_data_store *inner;	/* any format */
+	int32_t			nkeys;
+	int32_t			key_attnos[8];	/* 1-based */
+} strom_hashtable_input;
+
+size_t	strom_multihash_required_length(int ntables, const strom_hashtable_input *tables);
+int		strom_multihash_build(int ntables, const strom_hashtable_input *tables,
+							  void *buffer, size_t buflen);
+
 #ifdef __cplusplus
 }
 #endif

@@ -234,6 +234,47 @@ long		strom_gpupreagg_fetch(strom_gpupreagg *sess, kern_data_store *dest, size_t
 void		strom_gpupreagg_reset(strom_gpupreagg *sess);
 void		strom_gpupreagg_release(strom_gpupreagg *sess);
 
+/* ------------------------------------------------------------------ *
+ * GpuHashJoin
+ *
+ * strom_hashjoin_table  <- the kern_multihash the reference uploads once
+ *   per device and shares between the chunks of a join by a count under
+ *   mhtables->lock (gpuhashjoin.c:4498-4557, released 4311-4320).  Create
+ *   uploads a private copy and builds the probe index with kernels of the
+ *   join's own program (so the key must be ready or becomes ready here).
+ * strom_submit_gpuhashjoin <- clserv_process_gpuhashjoin (4430-5073).
+ *   'khashjoin' is the host image {kern_parambuf, kern_resultbuf}; result
+ *   records are nrels ints: outer_row + 1, then per inner relation the byte
+ *   offset of the matched kern_hashentry inside its kern_hashtable.
+ *   errcode StromError_DataStoreNoSpace: kern_resultbuf.nitems holds the
+ *   number of records a retry needs room for (the reference re-enqueues
+ *   with an exactly-sized buffer, 4330-4425).  A row-level CpuReCheck is
+ *   reported as the chunk errcode: the reference has no CPU path for join
+ *   rows ("CPU Recheck not implemented yet", 2948-2952).
+ * ------------------------------------------------------------------ */
+typedef struct strom_hashjoin_table strom_hashjoin_table;
+
+strom_hashjoin_table *strom_hashjoin_table_create(strom_devprog_key key,
+												  const kern_multihash *kmhash, size_t length,
+												  int dindex, int *p_errcode);
+void		strom_hashjoin_table_release(strom_hashjoin_table *tbl);
+/* index form chosen for inner relation 'depth' (1-based): mode 1 = direct
+ * (dense integer key), 0 = hashed */
+int			strom_hashjoin_table_info(strom_hashjoin_table *tbl, int depth,
+									  int *p_mode, uint32_t *p_nslots,
+									  int *p_unique, uint32_t *p_nentries);
+/* the device copy of the kern_multihash (entry offsets in result records
+ * index into it; rowid / htup of an entry are unchanged) */
+int			strom_hashjoin_table_download(strom_hashjoin_table *tbl, void *buffer, size_t buflen);
+strom_task *strom_submit_gpuhashjoin(strom_hashjoin_table *tbl,
+									 kern_hashjoin *khashjoin,
+									 const kern_data_store *kds,
+									 strom_dstore *kds_dev,
+									 const kern_row_map *krowmap,
+									 uint32_t flags,
+									 strom_done_cb done, void *arg,
+									 int *p_errcode);
+
 /* block until the request finished; returns its errcode.  Frees the task. */
 int			strom_task_wait(strom_task *task, strom_perfmon *pfm_out);
 /* device address of the kern_gpuscan / kern_hashjoin image of a task that

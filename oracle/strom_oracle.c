@@ -137,7 +137,7 @@ oracle_get_datum(const kern_data_store *kds, uint32_t colidx, uint32_t rowidx)
  * ====================================================================== */
 enum {
 	N_CONST, N_PARAM, N_VAR, N_FUNC, N_AND, N_OR, N_NOT, N_ISNULL, N_ISNOTNULL,
-	N_BOOLTEST, N_CASE, N_RELABEL
+	N_BOOLTEST, N_CASE, N_RELABEL, N_IVAR
 };
 /* operator classes of N_FUNC */
 enum {
@@ -156,6 +156,7 @@ struct oracle_expr {
 	int			type_oid;		/* result type */
 	int			op;				/* OP_* / BT_* */
 	int			attno;			/* N_VAR (1-based) / N_PARAM id */
+	int			depth;			/* N_IVAR: which inner relation (1-based) */
 	oracle_value cval;			/* N_CONST */
 	int			nargs;
 	struct oracle_expr **args;	/* N_CASE: cond0,res0,cond1,res1,...,[else] */
@@ -611,6 +612,17 @@ parse_expr(parser *ps)
 		e = new_node(head[0] == 'p' ? N_PARAM : N_VAR);
 		if (!read_atom(ps, buf, sizeof(buf)))
 		{ perr(ps, "number expected"); goto fail; }
+		e->attno = atoi(buf);
+		if (!read_atom(ps, buf, sizeof(buf)) || !(e->type_oid = type_by_name(buf)))
+		{ perr(ps, "bad type"); goto fail; }
+	}
+	else if (!strcmp(head, "ivar"))
+	{
+		/* (ivar DEPTH ATTNO TYPE): column of the matched inner tuple */
+		e = new_node(N_IVAR);
+		if (!read_atom(ps, buf, sizeof(buf))) { perr(ps, "depth expected"); goto fail; }
+		e->depth = atoi(buf);
+		if (!read_atom(ps, buf, sizeof(buf))) { perr(ps, "attno expected"); goto fail; }
 		e->attno = atoi(buf);
 		if (!read_atom(ps, buf, sizeof(buf)) || !(e->type_oid = type_by_name(buf)))
 		{ perr(ps, "bad type"); goto fail; }
@@ -1080,6 +1092,9 @@ typedef struct {
 	const uint64_t *ext_values;
 	const uint8_t  *ext_isnull;
 	int				n_ext;
+	/* hash join: the inner relations and the inner row matched so far */
+	const kern_data_store *const *inner_kds;
+	const uint32_t *inner_row;
 } eval_ctx;
 
 static oracle_value
@@ -1099,6 +1114,10 @@ eval_node(const oracle_expr *e, const eval_ctx *cx, int32_t *errcode)
 			return load_datum(e->type_oid, &cx->ext_values[e->attno]);
 		case N_VAR:
 			return load_datum(e->type_oid, oracle_get_datum(cx->kds, e->attno - 1, cx->rowidx));
+		case N_IVAR:
+			return load_datum(e->type_oid,
+							  oracle_get_datum(cx->inner_kds[e->depth - 1], e->attno - 1,
+											   cx->inner_row[e->depth - 1]));
 		case N_RELABEL:
 			return eval_node(e->args[0], cx, errcode);
 		case N_FUNC:
@@ -1189,7 +1208,7 @@ oracle_expr_eval(const oracle_expr *expr, const kern_data_store *kds, uint32_t r
 				 const uint64_t *ext_values, const uint8_t *ext_isnull, int n_ext,
 				 int32_t *errcode)
 {
-	eval_ctx cx = { kds, rowidx, ext_values, ext_isnull, n_ext };
+	eval_ctx cx = { kds, rowidx, ext_values, ext_isnull, n_ext, NULL, NULL };
 	return eval_node(expr, &cx, errcode);
 }
 
@@ -1590,4 +1609,383 @@ oracle_gpupreagg(const char *spec_text,
 	free(groups);
 	preagg_spec_free(&sp);
 	return status;
+}
+
+/* ====================================================================== *
+ * GpuHashJoin
+ *
+ * Restates kern_gpuhashjoin_main + the generated gpuhashjoin_execute
+ * (opencl_hashjoin.h:284-416; template gpuhashjoin.c:1184-1317): for every
+ * outer row (optionally through a kern_row_map), depth by depth, every
+ * inner tuple whose hash keys are equal (NULL never matches) and whose
+ * join qual is TRUE; one result record {outer_row+1, inner_1, .., inner_n}
+ * per complete match.  The inner side is identified here by its ROW INDEX
+ * in the inner chunk (the device reports the byte offset of the
+ * kern_hashentry, whose rowid field is that index).
+ *
+ * Deliberately independent of the hash table the product builds: the
+ * inner rows are indexed with a private bucket array on the key images.
+ * A row-level CpuReCheck in a join expression is a hard error in the
+ * reference ("CPU Recheck not implemented yet", gpuhashjoin.c:2948-2952):
+ * reported as chunk errcode CpuReCheck.
+ * ====================================================================== */
+#define HJ_MAXDEPTH	8
+#define HJ_MAXKEYS	8
+
+typedef struct {
+	int			nkeys;
+	oracle_expr *outer_key[HJ_MAXKEYS];
+	int			inner_attno[HJ_MAXKEYS];
+	int			key_type[HJ_MAXKEYS];
+	oracle_expr *qual;
+	/* private index over the inner rows */
+	uint32_t	nbuckets;
+	int32_t	   *bucket;		/* head row or -1 */
+	int32_t	   *next;
+	uint64_t   *keyhash;
+} hj_rel;
+
+static uint64_t
+hj_mix(uint64_t h, uint64_t v)
+{
+	h ^= v + 0x9e3779b97f4a7c15ULL + (h << 6) + (h >> 2);
+	return h;
+}
+
+/* canonical 64-bit image of a key value for hashing/equality */
+static uint64_t
+hj_key_image(oracle_value v)
+{
+	if (v.type_oid == STROM_FLOAT4OID)
+	{
+		double d = v.v.f;
+		if (d == 0.0) d = 0.0;			/* -0 == +0 */
+		if (isnan(d)) return 0x7ff8000000000000ULL;
+		{ uint64_t u; memcpy(&u, &d, 8); return u; }
+	}
+	if (v.type_oid == STROM_FLOAT8OID)
+	{
+		double d = v.v.d;
+		if (d == 0.0) d = 0.0;
+		if (isnan(d)) return 0x7ff8000000000000ULL;
+		{ uint64_t u; memcpy(&u, &d, 8); return u; }
+	}
+	return (uint64_t)v.v.i;
+}
+
+typedef struct {
+	int			ndepth;
+	hj_rel		rel[HJ_MAXDEPTH];
+} hj_spec;
+
+static void
+hj_spec_free(hj_spec *sp)
+{
+	int d, k;
+	for (d = 0; d < sp->ndepth; d++)
+	{
+		for (k = 0; k < sp->rel[d].nkeys; k++)
+			oracle_expr_free(sp->rel[d].outer_key[k]);
+		oracle_expr_free(sp->rel[d].qual);
+		free(sp->rel[d].bucket);
+		free(sp->rel[d].next);
+		free(sp->rel[d].keyhash);
+	}
+}
+
+static int
+hj_spec_parse(const char *text, hj_spec *sp, char *errbuf, size_t errlen)
+{
+	parser ps = { text, errbuf, errlen, 0 };
+	char	head[32], buf[64];
+
+	memset(sp, 0, sizeof(*sp));
+	if (!expect_char(&ps, '(') || !read_atom(&ps, head, sizeof(head)) || strcmp(head, "gpuhashjoin"))
+	{
+		perr(&ps, "(gpuhashjoin ...) expected");
+		return 0;
+	}
+	while (!peek_close(&ps) && !ps.failed)
+	{
+		hj_rel *rel;
+		if (!expect_char(&ps, '(') || !read_atom(&ps, head, sizeof(head)) || strcmp(head, "rel"))
+		{ perr(&ps, "(rel ...) expected"); break; }
+		if (sp->ndepth >= HJ_MAXDEPTH) { perr(&ps, "too many inner relations"); break; }
+		rel = &sp->rel[sp->ndepth++];
+		while (!peek_close(&ps) && !ps.failed)
+		{
+			if (!expect_char(&ps, '(') || !read_atom(&ps, head, sizeof(head)))
+				break;
+			if (!strcmp(head, "hashkey"))
+			{
+				int k = rel->nkeys;
+				if (k >= HJ_MAXKEYS) { perr(&ps, "too many hash keys"); break; }
+				rel->outer_key[k] = parse_expr(&ps);
+				if (!rel->outer_key[k]) break;
+				if (!read_atom(&ps, buf, sizeof(buf))) { perr(&ps, "inner attno expected"); break; }
+				rel->inner_attno[k] = atoi(buf);
+				if (!read_atom(&ps, buf, sizeof(buf)) || !(rel->key_type[k] = type_by_name(buf)))
+				{ perr(&ps, "bad hashkey type"); break; }
+				rel->nkeys++;
+			}
+			else if (!strcmp(head, "qual"))
+			{
+				rel->qual = parse_expr(&ps);
+				if (!rel->qual) break;
+			}
+			else { perr(&ps, "unknown item %s in rel", head); break; }
+			if (!expect_char(&ps, ')')) break;
+		}
+		if (ps.failed || !expect_char(&ps, ')')) break;
+		if (rel->nkeys < 1) { perr(&ps, "a rel needs at least one hashkey"); break; }
+	}
+	if (!ps.failed)
+		expect_char(&ps, ')');
+	if (ps.failed || sp->ndepth < 1)
+	{
+		if (!ps.failed) perr(&ps, "no inner relation");
+		hj_spec_free(sp);
+		return 0;
+	}
+	return 1;
+}
+
+typedef struct {
+	hj_spec	   *sp;
+	eval_ctx	cx;
+	uint32_t	inner_row[HJ_MAXDEPTH];
+	int32_t	   *results;
+	uint32_t	nrooms;
+	uint32_t	nitems;
+	int32_t		errcode;
+	uint32_t	outer_row;
+} hj_state;
+
+static void
+hj_probe(hj_state *st, int d)
+{
+	hj_spec	   *sp = st->sp;
+	hj_rel	   *rel = &sp->rel[d];
+	const kern_data_store *ikds = st->cx.inner_kds[d];
+	oracle_value kv[HJ_MAXKEYS];
+	uint64_t	h = 0;
+	int			k;
+	int32_t		r;
+
+	for (k = 0; k < rel->nkeys; k++)
+	{
+		kv[k] = eval_node(rel->outer_key[k], &st->cx, &st->errcode);
+		if (kv[k].isnull)
+			return;					/* NULL = anything is never TRUE */
+		h = hj_mix(h, hj_key_image(kv[k]));
+	}
+	for (r = rel->bucket[h % rel->nbuckets]; r >= 0; r = rel->next[r])
+	{
+		int same = (rel->keyhash[r] == h);
+		for (k = 0; k < rel->nkeys && same; k++)
+		{
+			oracle_value iv = load_datum(rel->key_type[k],
+										 oracle_get_datum(ikds, rel->inner_attno[k] - 1, (uint32_t)r));
+			same = (!iv.isnull && hj_key_image(iv) == hj_key_image(kv[k]));
+		}
+		if (!same)
+			continue;
+		st->inner_row[d] = (uint32_t)r;
+		if (rel->qual)
+		{
+			oracle_value q = eval_node(rel->qual, &st->cx, &st->errcode);
+			if (q.isnull || !q.v.i)
+				continue;
+		}
+		if (d + 1 < sp->ndepth)
+			hj_probe(st, d + 1);
+		else
+		{
+			if (st->nitems < st->nrooms)
+			{
+				int32_t *rb = st->results + (size_t)st->nitems * (sp->ndepth + 1);
+				int		i;
+				rb[0] = (int32_t)(st->outer_row + 1);
+				for (i = 0; i < sp->ndepth; i++)
+					rb[i + 1] = (int32_t)st->inner_row[i];
+			}
+			st->nitems++;
+		}
+	}
+}
+
+int32_t
+oracle_gpuhashjoin(const char *spec_text,
+				   const uint64_t *ext_values, const uint8_t *ext_isnull, int n_ext,
+				   const kern_data_store *outer, const kern_row_map *krowmap,
+				   const kern_data_store *const *inner, int ninner,
+				   int32_t *results, uint32_t nrooms, uint32_t *p_nitems,
+				   char *errbuf, size_t errlen)
+{
+	hj_spec		sp;
+	hj_state	st;
+	int			d, use_map = (krowmap && krowmap->nvalids >= 0);
+	uint32_t	i, nrows;
+
+	*p_nitems = 0;
+	if (!hj_spec_parse(spec_text, &sp, errbuf, errlen))
+		return StromError_BadRequestMessage;
+	if (sp.ndepth != ninner)
+	{
+		snprintf(errbuf, errlen, "spec has %d inner relations, %d given", sp.ndepth, ninner);
+		hj_spec_free(&sp);
+		return StromError_BadRequestMessage;
+	}
+	/* private index per inner relation */
+	for (d = 0; d < sp.ndepth; d++)
+	{
+		hj_rel *rel = &sp.rel[d];
+		uint32_t n = inner[d]->nitems, r;
+		int		k;
+		rel->nbuckets = n * 2 + 1;
+		rel->bucket = malloc(sizeof(int32_t) * rel->nbuckets);
+		rel->next = malloc(sizeof(int32_t) * (n + 1));
+		rel->keyhash = malloc(sizeof(uint64_t) * (n + 1));
+		for (r = 0; r < rel->nbuckets; r++)
+			rel->bucket[r] = -1;
+		for (r = 0; r < n; r++)
+		{
+			uint64_t h = 0;
+			int		 isnull = 0;
+			for (k = 0; k < rel->nkeys; k++)
+			{
+				oracle_value iv = load_datum(rel->key_type[k],
+											 oracle_get_datum(inner[d], rel->inner_attno[k] - 1, r));
+				if (iv.isnull) isnull = 1;
+				h = hj_mix(h, hj_key_image(iv));
+			}
+			rel->keyhash[r] = h;
+			rel->next[r] = -1;
+			if (isnull)
+				continue;			/* a NULL key never joins */
+			rel->next[r] = rel->bucket[h % rel->nbuckets];
+			rel->bucket[h % rel->nbuckets] = (int32_t)r;
+		}
+	}
+	memset(&st, 0, sizeof(st));
+	st.sp = &sp;
+	st.cx.kds = outer;
+	st.cx.ext_values = ext_values;
+	st.cx.ext_isnull = ext_isnull;
+	st.cx.n_ext = n_ext;
+	st.cx.inner_kds = inner;
+	st.cx.inner_row = st.inner_row;
+	st.results = results;
+	st.nrooms = nrooms;
+	nrows = use_map ? (uint32_t)krowmap->nvalids : outer->nitems;
+	for (i = 0; i < nrows; i++)
+	{
+		st.outer_row = use_map ? (uint32_t)krowmap->rindex[i] : i;
+		st.cx.rowidx = st.outer_row;
+		hj_probe(&st, 0);
+	}
+	*p_nitems = st.nitems;
+	d = st.errcode;
+	hj_spec_free(&sp);
+	if (StromErrorIsSignificant(d) || d == StromError_CpuReCheck)
+		return d;
+	return st.nitems > nrooms ? StromError_DataStoreNoSpace : StromError_Success;
+}
+
+/*
+ * PostgreSQL 9.4's pg_crc32 as the reference uses it for hash keys
+ * (gpuhashjoin.c:3758-3788; opencl_hashjoin.h:907-953): the reflected
+ * 0xEDB88320 table driven MSB-first.
+ */
+static uint32_t oracle_crc_table[256];
+static void
+oracle_crc_init(void)
+{
+	uint32_t i, j, c;
+	if (oracle_crc_table[1])
+		return;
+	for (i = 0; i < 256; i++)
+	{
+		c = i;
+		for (j = 0; j < 8; j++)
+			c = (c & 1) ? (0xEDB88320U ^ (c >> 1)) : (c >> 1);
+		oracle_crc_table[i] = c;
+	}
+}
+
+uint32_t
+oracle_pg_crc32(uint32_t crc, const void *data, size_t len)
+{
+	const unsigned char *p = data;
+	oracle_crc_init();
+	while (len-- > 0)
+		crc = oracle_crc_table[((crc >> 24) ^ *p++) & 0xFF] ^ (crc << 8);
+	return crc;
+}
+
+/*
+ * Walk a kern_multihash the way the reference's device code does
+ * (KERN_HASH_FIRST_ENTRY / NEXT_ENTRY, opencl_hashjoin.h:167-192) and check
+ * it against the inner chunk it was built from: every row reachable exactly
+ * once from slot (hash % nslots), hash == pg_crc32 of its non-NULL key
+ * images, tuple bytes identical.  Returns the number of entries, or a
+ * negative number naming the first defect.
+ */
+long
+oracle_check_hashtable(const kern_multihash *kmhash, int depth,
+					   const kern_data_store *inner,
+					   const int *key_attnos, const int *key_lens, int nkeys)
+{
+	const kern_hashtable *kht;
+	const uint32_t *slots;
+	uint8_t	   *seen;
+	uint32_t	s;
+	long		count = 0;
+
+	oracle_crc_init();
+	if (depth < 1 || (uint32_t)depth > kmhash->ntables)
+		return -1;
+	if (memcmp(kmhash->pg_crc32_table, oracle_crc_table, sizeof(oracle_crc_table)) != 0)
+		return -2;
+	kht = KERN_HASHTABLE(kmhash, depth - 1);
+	if (kht->ncols != inner->ncols || kht->nslots == 0)
+		return -3;
+	slots = KERN_HASHTABLE_SLOT(kht);
+	seen = calloc(inner->nitems + 1, 1);
+	for (s = 0; s < kht->nslots; s++)
+	{
+		uint32_t off = slots[s];
+		while (off != 0)
+		{
+			const kern_hashentry *he = (const kern_hashentry *)((const char *)kht + off);
+			uint32_t crc = 0xFFFFFFFFU;
+			int		k;
+			if (off >= kht->length || he->rowid >= inner->nitems || seen[he->rowid])
+			{ free(seen); return -4; }
+			seen[he->rowid] = 1;
+			for (k = 0; k < nkeys; k++)
+			{
+				const void *p = oracle_get_datum(inner, key_attnos[k] - 1, he->rowid);
+				const void *q = get_datum_tuple(kht->colmeta, &he->htup, key_attnos[k] - 1);
+				if ((p == NULL) != (q == NULL) || (p && memcmp(p, q, key_lens[k]) != 0))
+				{ free(seen); return -5; }
+				if (p)
+				{
+					uint64_t datum = 0;
+					memcpy(&datum, p, key_lens[k]);
+					crc = oracle_pg_crc32(crc, &datum, key_lens[k]);
+				}
+			}
+			crc ^= 0xFFFFFFFFU;
+			if (he->hash != crc || crc % kht->nslots != s)
+			{ free(seen); return -6; }
+			count++;
+			off = he->next;
+		}
+	}
+	for (s = 0; s < inner->nitems; s++)
+		if (!seen[s])
+		{ free(seen); return -7; }
+	free(seen);
+	return count;
 }

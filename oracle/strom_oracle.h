@@ -84,6 +84,23 @@ int32_t		oracle_gpupreagg(const char *spec,
 							 uint32_t *p_ngroups,
 							 char *errbuf, size_t errlen);
 
+/*
+ * GpuHashJoin over one outer chunk.  results[] receives (ninner+1) ints per
+ * match: outer_row+1, then the ROW INDEX of the matched tuple of each inner
+ * relation.  Returns 0, StromError_DataStoreNoSpace (*p_nitems = required),
+ * or an error.
+ */
+int32_t		oracle_gpuhashjoin(const char *spec,
+							   const uint64_t *ext_values, const uint8_t *ext_isnull, int n_ext,
+							   const kern_data_store *outer, const kern_row_map *krowmap,
+							   const kern_data_store *const *inner, int ninner,
+							   int32_t *results, uint32_t nrooms, uint32_t *p_nitems,
+							   char *errbuf, size_t errlen);
+uint32_t	oracle_pg_crc32(uint32_t crc, const void *data, size_t len);
+long		oracle_check_hashtable(const kern_multihash *kmhash, int depth,
+								   const kern_data_store *inner,
+								   const int *key_attnos, const int *key_lens, int nkeys);
+
 /* sizes / offsets of the wire structs, for the layout tests */
 typedef struct {
 	uint32_t	sizeof_kern_data_store_head;

@@ -85,6 +85,10 @@ class strom_preagg_domain(ctypes.Structure):
                 ("key_range", c_uint32 * 8)]
 
 
+class strom_hashtable_input(ctypes.Structure):
+    _fields_ = [("inner", c_void_p), ("nkeys", c_int32), ("key_attnos", c_int32 * 8)]
+
+
 class strom_column_input(ctypes.Structure):
     _fields_ = [
         ("type_oid", c_int32),
@@ -137,6 +141,15 @@ PROTOTYPES = {
     "strom_gpupreagg_fetch": (ctypes.c_long, [c_void_p, c_void_p, c_size_t]),
     "strom_gpupreagg_reset": (None, [c_void_p]),
     "strom_gpupreagg_release": (None, [c_void_p]),
+    "strom_hashjoin_table_create": (c_void_p, [c_uint64, c_void_p, c_size_t, c_int,
+                                               ctypes.POINTER(c_int)]),
+    "strom_hashjoin_table_release": (None, [c_void_p]),
+    "strom_hashjoin_table_info": (c_int, [c_void_p, c_int, ctypes.POINTER(c_int),
+                                          ctypes.POINTER(c_uint32), ctypes.POINTER(c_int),
+                                          ctypes.POINTER(c_uint32)]),
+    "strom_hashjoin_table_download": (c_int, [c_void_p, c_void_p, c_size_t]),
+    "strom_submit_gpuhashjoin": (c_void_p, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                            c_uint32, c_void_p, c_void_p, ctypes.POINTER(c_int)]),
     "strom_task_wait": (c_int, [c_void_p, ctypes.POINTER(strom_perfmon)]),
     "strom_task_devptr": (c_void_p, [c_void_p]),
     "strom_synchronize": (None, []),
@@ -145,6 +158,8 @@ PROTOTYPES = {
     "strom_codegen_gpupreagg": (c_int, [c_char_p, ctypes.POINTER(strom_codegen_result),
                                         ctypes.POINTER(strom_preagg_target), c_int,
                                         ctypes.POINTER(c_int)]),
+    "strom_codegen_gpuhashjoin": (c_int, [c_char_p, ctypes.POINTER(strom_codegen_result),
+                                          ctypes.POINTER(c_int)]),
     "strom_codegen_available_expression": (c_int, [c_char_p, ctypes.POINTER(c_void_p)]),
     "strom_codegen_release": (None, [ctypes.POINTER(strom_codegen_result)]),
     "strom_create_kern_parambuf": (c_void_p, [ctypes.POINTER(strom_codegen_result),
@@ -155,6 +170,9 @@ PROTOTYPES = {
                                              c_uint32]),
     "strom_kds_build": (c_int, [c_int, c_int, ctypes.POINTER(strom_column_input), c_uint32,
                                 c_void_p, c_size_t]),
+    "strom_multihash_required_length": (c_size_t, [c_int, ctypes.POINTER(strom_hashtable_input)]),
+    "strom_multihash_build": (c_int, [c_int, ctypes.POINTER(strom_hashtable_input), c_void_p,
+                                      c_size_t]),
     "strom_kds_to_column": (c_size_t, [c_void_p, c_void_p, c_size_t]),
     "strom_kds_fetch": (c_int, [c_void_p, c_uint32, c_uint32, ctypes.POINTER(c_uint64)]),
 }

@@ -692,6 +692,32 @@ emit_expr(const sexpr &n, codegen_context &ctx, std::string &out)
 		out += tmp;
 		return t->type_oid;
 	}
+	if (head == "ivar")
+	{
+		if (nargs != 3 || n.items[1].is_list || n.items[2].is_list)
+			codegen_error("(ivar DEPTH ATTNO TYPE) expected");
+		const devtype_info *t = type_atom(n.items[3]);
+		int		depth = atoi(n.items[1].atom.c_str());
+		int		attno = atoi(n.items[2].atom.c_str());
+		if (depth < 1 || depth > ctx.ivar_max_depth)
+			codegen_error("(ivar %d ..) is not visible here", depth);
+		if (attno < 1)
+			codegen_error("attribute numbers start at 1");
+		bool known = false;
+		for (auto &iv : ctx.used_ivars)
+			if (iv.depth == depth && iv.attno == attno)
+			{
+				if (iv.type_oid != t->type_oid)
+					codegen_error("inner attribute referenced as two different types");
+				known = true;
+			}
+		if (!known)
+			ctx.used_ivars.push_back({depth, attno, t->type_oid});
+		ctx.extra_flags |= t->type_flags;
+		snprintf(tmp, sizeof(tmp), "IVAR_%d_%d", depth, attno);
+		out += tmp;
+		return t->type_oid;
+	}
 	if (head == "and" || head == "or")
 	{
 		emit_bool_chain(n, ctx, out, head == "and" ? "pgfn_boolop_and2" : "pgfn_boolop_or2");

@@ -32,6 +32,10 @@ struct codegen_context {
 	std::vector<strom_kparam_desc>	used_params;
 	std::vector<strom_kvar_desc>	used_vars;
 	int								extra_flags = 0;
+	/* hash join: (ivar depth attno type) refers to a matched inner tuple */
+	struct ivar_ref { int depth, attno, type_oid; };
+	int								ivar_max_depth = 0;	/* 0: ivar not allowed here */
+	std::vector<ivar_ref>			used_ivars;
 
 	int		track_param(const strom_kparam_desc &d);
 	void	track_var(int attno, int type_oid);

@@ -543,3 +543,188 @@ strom_kds_to_column(const kern_data_store *src, void *dst, size_t dstlen)
 		return 0;
 	return required;
 }
+
+/* ====================================================================== *
+ * kern_multihash builder: multihash_preload_khashtable
+ * (gpuhashjoin.c:3614-3816).  Every inner row becomes a kern_hashentry that
+ * owns the whole heap tuple; hash = PostgreSQL 9.4 pg_crc32 over the datum
+ * images of the non-NULL key columns; entries are pushed on
+ * hash_slots[hash % nslots].
+ * ====================================================================== */
+namespace {
+
+uint32_t	crc_table[256];
+bool		crc_ready = false;
+
+void
+crc_init(void)
+{
+	if (crc_ready)
+		return;
+	for (uint32_t i = 0; i < 256; i++)
+	{
+		uint32_t c = i;
+		for (int j = 0; j < 8; j++)
+			c = (c & 1) ? (0xEDB88320U ^ (c >> 1)) : (c >> 1);
+		crc_table[i] = c;
+	}
+	crc_ready = true;
+}
+
+/* COMP_CRC32 of PostgreSQL 9.4: reflected table, MSB-first update */
+uint32_t
+legacy_crc32(uint32_t crc, const void *data, size_t len)
+{
+	const unsigned char *p = (const unsigned char *)data;
+	while (len-- > 0)
+		crc = crc_table[((crc >> 24) ^ *p++) & 0xFF] ^ (crc << 8);
+	return crc;
+}
+
+/* columns of one row of any kds, as strom_column_input over 1-row buffers */
+struct row_image {
+	std::vector<uint64_t>	values;
+	std::vector<uint8_t>	nulls;
+	std::vector<strom_column_input> cols;
+};
+
+void
+row_image_init(row_image &ri, const kern_data_store *kds)
+{
+	int ncols = (int)kds->ncols;
+	ri.values.assign(ncols, 0);
+	ri.nulls.assign(ncols, 0);
+	ri.cols.resize(ncols);
+	for (int i = 0; i < ncols; i++)
+	{
+		ri.cols[i].type_oid = 0;
+		ri.cols[i].attlen = kds->colmeta[i].attlen;
+		ri.cols[i].attalign = kds->colmeta[i].attalign;
+		ri.cols[i].attbyval = kds->colmeta[i].attbyval;
+		ri.cols[i].values = &ri.values[i];
+		ri.cols[i].isnull = &ri.nulls[i];
+	}
+}
+
+void
+row_image_load(row_image &ri, const kern_data_store *kds, uint32_t row)
+{
+	for (uint32_t i = 0; i < kds->ncols; i++)
+	{
+		const char *p = host_get_datum(kds, row, i);
+		ri.nulls[i] = (p == nullptr);
+		ri.values[i] = 0;
+		if (p)
+			memcpy(&ri.values[i], p, kds->colmeta[i].attlen);
+	}
+}
+
+size_t
+hashtable_head_length(uint32_t ncols, uint32_t nslots)
+{
+	return STROM_LONGALIGN(STROM_LONGALIGN(offsetof(kern_hashtable, colmeta) +
+										   sizeof(kern_colmeta) * ncols) +
+						   sizeof(cl_uint) * (size_t)nslots);
+}
+
+uint32_t
+hashtable_nslots(uint32_t ntuples)
+{
+	/* the planner sizes nslots from its row estimate (gpuhashjoin.c:366,958) */
+	return (uint32_t)((double)ntuples * 1.15) + 1;
+}
+
+}	/* namespace */
+
+extern "C" size_t
+strom_multihash_required_length(int ntables, const strom_hashtable_input *tables)
+{
+	if (ntables < 1 || !tables)
+		return 0;
+	size_t	len = STROM_LONGALIGN(offsetof(kern_multihash, htable_offset) + sizeof(cl_uint) * ntables);
+	for (int t = 0; t < ntables; t++)
+	{
+		const kern_data_store *kds = tables[t].inner;
+		if (!kds || tables[t].nkeys < 1 || tables[t].nkeys > 8)
+			return 0;
+		for (uint32_t c = 0; c < kds->ncols; c++)
+		{
+			int l = kds->colmeta[c].attlen;
+			if (!(l == 1 || l == 2 || l == 4 || l == 8))
+				return 0;
+		}
+		len += hashtable_head_length(kds->ncols, hashtable_nslots(kds->nitems));
+		row_image ri;
+		row_image_init(ri, kds);
+		for (uint32_t r = 0; r < kds->nitems; r++)
+		{
+			size_t hoff;
+			row_image_load(ri, kds, r);
+			len += KERN_HASHENTRY_SIZE_BY_TLEN(heap_tuple_size((int)kds->ncols, ri.cols.data(), 0, &hoff));
+		}
+	}
+	return STROMALIGN(len);
+}
+
+extern "C" int
+strom_multihash_build(int ntables, const strom_hashtable_input *tables, void *buffer, size_t buflen)
+{
+	size_t	required = strom_multihash_required_length(ntables, tables);
+	if (required == 0 || !buffer || ((uintptr_t)buffer & 7) != 0)
+		return StromError_BadRequestMessage;
+	if (buflen < required)
+		return StromError_DataStoreNoSpace;
+	if (required > 0xffffffffUL)
+		return StromError_DataStoreOutOfRange;
+	crc_init();
+	memset(buffer, 0, required);
+	kern_multihash *kmhash = (kern_multihash *)buffer;
+	kmhash->hostptr = (hostptr_t)(uintptr_t)&kmhash->hostptr;
+	memcpy(kmhash->pg_crc32_table, crc_table, sizeof(crc_table));
+	kmhash->ntables = ntables;
+	size_t	usage = STROM_LONGALIGN(offsetof(kern_multihash, htable_offset) + sizeof(cl_uint) * ntables);
+	for (int t = 0; t < ntables; t++)
+	{
+		const kern_data_store *kds = tables[t].inner;
+		kern_hashtable *kht = (kern_hashtable *)((char *)buffer + usage);
+		uint32_t nslots = hashtable_nslots(kds->nitems);
+
+		kmhash->htable_offset[t] = (cl_uint)usage;
+		kht->ncols = kds->ncols;
+		kht->nslots = nslots;
+		kht->is_outer = 0;
+		memcpy(kht->colmeta, kds->colmeta, sizeof(kern_colmeta) * kds->ncols);
+		cl_uint *slots = KERN_HASHTABLE_SLOT(kht);
+		size_t	consumed = hashtable_head_length(kds->ncols, nslots);
+		row_image ri;
+		row_image_init(ri, kds);
+		for (uint32_t r = 0; r < kds->nitems; r++)
+		{
+			size_t	hoff, t_len;
+			row_image_load(ri, kds, r);
+			t_len = heap_tuple_size((int)kds->ncols, ri.cols.data(), 0, &hoff);
+			kern_hashentry *he = (kern_hashentry *)((char *)kht + consumed);
+			uint32_t crc = 0xFFFFFFFFU;
+			for (int k = 0; k < tables[t].nkeys; k++)
+			{
+				int col = tables[t].key_attnos[k] - 1;
+				if (col < 0 || col >= (int)kds->ncols)
+					return StromError_BadRequestMessage;
+				if (ri.nulls[col])
+					continue;			/* NULL keys are not hashed */
+				crc = legacy_crc32(crc, &ri.values[col], kds->colmeta[col].attlen);
+			}
+			crc ^= 0xFFFFFFFFU;
+			he->hash = crc;
+			he->rowid = r;
+			he->t_len = (cl_uint)t_len;
+			heap_tuple_form((char *)&he->htup, (int)kds->ncols, ri.cols.data(), 0, t_len, hoff, 0, 0);
+			he->next = slots[crc % nslots];
+			slots[crc % nslots] = (cl_uint)consumed;
+			consumed += KERN_HASHENTRY_SIZE_BY_TLEN(t_len);
+		}
+		kht->length = (cl_uint)consumed;
+		usage += consumed;
+	}
+	return 0;
+}

@@ -287,6 +287,17 @@ STROM_DEVICE BASE strom_fetch(const void *addr)
 		}																	\
 		return result;														\
 	}																		\
+	/* attribute of a bare heap tuple (inner tuple of a hash entry) */		\
+	STROM_DEVICE pg_##NAME##_t												\
+	pg_##NAME##_tupref(const kern_colmeta *colmeta,							\
+					   const HeapTupleHeaderData *htup, cl_uint colidx)		\
+	{																		\
+		pg_##NAME##_t	result;												\
+		const void	   *addr = kern_get_datum_tuple(colmeta, htup, colidx);	\
+		result.isnull = (addr == NULL);										\
+		result.value = (addr ? strom_fetch<pg_##NAME##_base_t>(addr) : 0);	\
+		return result;														\
+	}																		\
 	STROM_DEVICE pg_##NAME##_t												\
 	pg_##NAME##_make(pg_##NAME##_base_t value, bool isnull)					\
 	{																		\

@@ -117,78 +117,80 @@ template <typename T> struct gpupreagg_is_float { static const bool value = fals
 template <> struct gpupreagg_is_float<cl_double> { static const bool value = true; };
 template <> struct gpupreagg_is_float<cl_float> { static const bool value = true; };
 
-STROM_DEVICE size_t gpupreagg_align16(size_t v) { return (v + 15) & ~(size_t)15; }
+STROM_DEVICE cl_uint gpupreagg_align16(cl_uint v) { return (v + 15u) & ~15u; }
 
-/* byte offset of section 'sec' in a [bits | per-agg (bits, values)] image
- * for G groups, REP replicas.  sec = 0: seen bits; 1+2a: has-value bits of
- * agg a; 2+2a: values of agg a; 1+2*NAGGS: total size */
-STROM_DEVICE size_t
+/*
+ * Per-group flags: bit 0 = a row of this group passed the qual ("seen"),
+ * bit 1+a = aggregate a received a non-NULL input.  One word per (group,
+ * replica) so that a row updates all its flags with ONE LDS operation, and
+ * after the first row of a group only a read remains.
+ */
+#if GPUPREAGG_NAGGS <= 7
+typedef cl_uchar	gpupreagg_flags_t;
+#elif GPUPREAGG_NAGGS <= 15
+typedef cl_ushort	gpupreagg_flags_t;
+#else
+typedef cl_uint		gpupreagg_flags_t;
+#endif
+#define GPUPREAGG_FLAG_SEEN		1u
+
+/*
+ * LDS / slab image for G groups and REP replicas:
+ *   section 0        flags[G*REP]
+ *   section 1+a      values of aggregate a: u32[G*REP] (NROWS) or 8 bytes[G*REP]
+ *   section 1+NAGGS  total size
+ * 32-bit offsets: the image lives in LDS (<= 160 KB) or in a slab of the
+ * same shape.
+ */
+STROM_DEVICE cl_uint
 gpupreagg_image_offset(int sec, cl_uint G, cl_uint REP)
 {
-	size_t	off = 0;
-	size_t	bits = gpupreagg_align16(sizeof(cl_uint) * (((size_t)G + 31) / 32));
+	cl_uint	off = 0;
 	int		cur = 0;
 
 	if (sec == cur) return off;
-	off += bits; cur++;
+	off += gpupreagg_align16((cl_uint)sizeof(gpupreagg_flags_t) * G * REP); cur++;
 #define X(aidx,resno,OP,NAME)																\
 	if (sec == cur) return off;																\
-	if (GPUPREAGG_OP_##OP != GPUPREAGG_OP_NROWS) off += bits;								\
-	cur++;																					\
-	if (sec == cur) return off;																\
-	off += gpupreagg_align16((GPUPREAGG_OP_##OP == GPUPREAGG_OP_NROWS ? 4 : 8) * (size_t)G * REP);	\
+	off += gpupreagg_align16((GPUPREAGG_OP_##OP == GPUPREAGG_OP_NROWS ? 4u : 8u) * G * REP);	\
 	cur++;
 	GPUPREAGG_AGG_LIST(X)
 #undef X
 	return off;
 }
 
-/* resident table: the same sections, NROWS widened to 8 bytes, 256-byte aligned */
+/*
+ * resident table for N groups, 256-byte aligned sections:
+ *   section 0        flags as u32[N]
+ *   section 1+a      8-byte values[N] (NROWS widened to i64)
+ */
 STROM_DEVICE size_t
 gpupreagg_table_offset(int sec, cl_uint N)
 {
 	size_t	off = 0;
-	size_t	bits = STROM_TYPEALIGN(256, sizeof(cl_uint) * (((size_t)N + 31) / 32));
+	size_t	flags = STROM_TYPEALIGN(256, sizeof(cl_uint) * (size_t)N);
 	size_t	vals = STROM_TYPEALIGN(256, 8 * (size_t)N);
-	int		cur = 0;
 
-	if (sec == cur) return off;
-	off += bits; cur++;
-#define X(aidx,resno,OP,NAME)						\
-	if (sec == cur) return off;						\
-	off += bits; cur++;								\
-	if (sec == cur) return off;						\
-	off += vals; cur++;
-	GPUPREAGG_AGG_LIST(X)
-#undef X
-	return off;
+	if (sec == 0) return off;
+	off += flags;
+	return off + vals * (size_t)(sec - 1);
 }
 
-STROM_DEVICE void
-gpupreagg_set_bit(cl_uint *bits, cl_uint idx)
-{
-	cl_uint	mask = 1u << (idx & 31);
-	/* test first: after warm-up no atomic traffic remains */
-	if (!(bits[idx >> 5] & mask))
-		__hip_atomic_fetch_or(&bits[idx >> 5], mask, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-}
-
-/* fold one row's partial value into the LDS accumulator of (lgid, rep) */
-template <int OP, typename PGT>
-STROM_DEVICE void
-gpupreagg_lds_accum(char *lds, size_t bits_off, size_t vals_off,
-					cl_uint lgid, cl_uint slot, PGT v)
+/* fold one row's partial value into the LDS accumulator at 'slot';
+ * returns the flag bit to raise (0 when the input was NULL) */
+template <int OP, int AIDX, typename PGT>
+STROM_DEVICE cl_uint
+gpupreagg_lds_accum(char *lds, cl_uint vals_off, cl_uint slot, PGT v)
 {
 	if (OP == GPUPREAGG_OP_NROWS)
 	{
 		if (!v.isnull && v.value != 0)
 			__hip_atomic_fetch_add((cl_uint *)(lds + vals_off) + slot, (cl_uint)v.value,
 								   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-		return;
+		return 0;
 	}
 	if (v.isnull)
-		return;
-	gpupreagg_set_bit((cl_uint *)(lds + bits_off), lgid);
+		return 0;
 	typedef decltype(v.value) base_t;
 	if (gpupreagg_is_float<base_t>::value)
 	{
@@ -216,6 +218,7 @@ gpupreagg_lds_accum(char *lds, size_t bits_off, size_t vals_off,
 			__hip_atomic_fetch_max((cl_long *)(lds + vals_off) + slot, (cl_long)v.value,
 								   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 	}
+	return 2u << AIDX;
 }
 
 /* identity element of an 8-byte accumulator */
@@ -257,37 +260,47 @@ gpupreagg_int8_near_overflow(cl_long v)
 	return v >= (1L << 62) || v <= -(1L << 62);
 }
 
+/* LDS section offsets, computed once per kernel */
+struct gpupreagg_lds_layout {
+	cl_uint		vals_off[GPUPREAGG_NAGGS + 1];
+	cl_uint		total;
+};
+
+STROM_DEVICE void
+gpupreagg_lds_layout_init(gpupreagg_lds_layout &L, cl_uint G, cl_uint NREP)
+{
+#define X(aidx,resno,OP,NAME)	L.vals_off[aidx] = gpupreagg_image_offset(1 + aidx, G, NREP);
+	GPUPREAGG_AGG_LIST(X)
+#undef X
+	L.total = gpupreagg_image_offset(1 + GPUPREAGG_NAGGS, G, NREP);
+}
+
 /* ---------------------------------------------------------------------- *
- * one row: qual, group id, fold.  Returns false when the row raised
- * CpuReCheck or a significant error (recorded in *chunk_status)
+ * one row: qual, group id, fold
  * ---------------------------------------------------------------------- */
 STROM_DEVICE void
-gpupreagg_dense_row(char *lds, const gpupreagg_dense_ctl *ctl,
+gpupreagg_dense_row(char *lds, const gpupreagg_dense_ctl *ctl, const gpupreagg_lds_layout &L,
 					const strom_kparams &KP, const strom_kvars &KV,
-					cl_uint split, cl_uint G, cl_uint NREP, cl_uint rep,
+					cl_uint gid_lo, cl_uint G, cl_uint NREP, cl_uint rep,
 					cl_int param_error, cl_int *chunk_status)
 {
 	cl_int		errcode = param_error;
 	pg_bool_t	rc = gpupreagg_qual_eval(&errcode, KP, KV);
-	cl_ulong	gid = 0;
+	cl_uint		gid = 0;
 	bool		out_of_domain = false;
 
 	if (errcode == StromError_Success && !EVAL(rc))
 		return;
-	/* group id */
+	/* group id: dense, NULL key in its own slot */
 #define X(kidx,resno,NAME)															\
 	{																				\
 		pg_##NAME##_t kv = gpupreagg_key_##kidx(&errcode, KP, KV);					\
-		cl_long off;																\
-		if (kv.isnull)																\
-			off = ctl->key_range[kidx];												\
-		else																		\
-		{																			\
-			off = (cl_long)kv.value - ctl->key_min[kidx];							\
-			if (off < 0 || off >= (cl_long)ctl->key_range[kidx])					\
-				out_of_domain = true;												\
-		}																			\
-		gid += (cl_ulong)off * ctl->key_stride[kidx];								\
+		cl_long		off64 = (cl_long)kv.value - ctl->key_min[kidx];					\
+		cl_uint		range = ctl->key_range[kidx];									\
+		cl_uint		off = (kv.isnull ? range : (cl_uint)off64);						\
+		if (!kv.isnull && (off64 < 0 || off64 >= (cl_long)range))					\
+			out_of_domain = true;													\
+		gid += off * ctl->key_stride[kidx];											\
 	}
 	GPUPREAGG_KEY_LIST(X)
 #undef X
@@ -308,49 +321,45 @@ gpupreagg_dense_row(char *lds, const gpupreagg_dense_ctl *ctl,
 		STROM_SET_ERROR(chunk_status, StromError_DataStoreOutOfRange);
 		return;
 	}
-	if (gid / G != split)
+	cl_uint		lgid = gid - gid_lo;
+	if (lgid >= G)				/* another role's slice of the id range */
 		return;
-	cl_uint		lgid = (cl_uint)(gid - (cl_ulong)split * G);
 	cl_uint		slot = lgid * NREP + rep;
+	cl_uint		need = GPUPREAGG_FLAG_SEEN;
 
-	gpupreagg_set_bit((cl_uint *)lds, lgid);
-	{
-		int sec = 1;
 #define X(aidx,resno,OP,NAME)														\
-		{																			\
-			size_t boff = gpupreagg_image_offset(sec, G, NREP);						\
-			size_t voff = gpupreagg_image_offset(sec + 1, G, NREP);					\
-			if (GPUPREAGG_OP_##OP == GPUPREAGG_OP_PSUM &&							\
-				!gpupreagg_is_float<pg_##NAME##_base_t>::value &&					\
-				!av_##aidx.isnull && gpupreagg_int8_near_overflow((cl_long)av_##aidx.value))	\
-				STROM_SET_ERROR(chunk_status, StromError_CpuReCheck);				\
-			gpupreagg_lds_accum<GPUPREAGG_OP_##OP>(lds, boff, voff, lgid, slot, av_##aidx);	\
-			sec += 2;																\
-		}
-		GPUPREAGG_AGG_LIST(X)
+	if (GPUPREAGG_OP_##OP == GPUPREAGG_OP_PSUM &&									\
+		!gpupreagg_is_float<pg_##NAME##_base_t>::value &&							\
+		!av_##aidx.isnull && gpupreagg_int8_near_overflow((cl_long)av_##aidx.value))	\
+		STROM_SET_ERROR(chunk_status, StromError_CpuReCheck);						\
+	need |= gpupreagg_lds_accum<GPUPREAGG_OP_##OP, aidx>(lds, L.vals_off[aidx], slot, av_##aidx);
+	GPUPREAGG_AGG_LIST(X)
 #undef X
+	/* flags: read, and only touch the word when something is missing */
+	gpupreagg_flags_t *flags = (gpupreagg_flags_t *)lds;
+	if ((flags[slot] & need) != need)
+	{
+		cl_uint *word = (cl_uint *)(lds + ((slot * (cl_uint)sizeof(gpupreagg_flags_t)) & ~3u));
+		cl_uint	 shift = ((slot * (cl_uint)sizeof(gpupreagg_flags_t)) & 3u) * 8u;
+		__hip_atomic_fetch_or(word, need << shift, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 	}
 }
 
 /* initialise the LDS image */
 STROM_DEVICE void
-gpupreagg_lds_init(char *lds, cl_uint G, cl_uint NREP)
+gpupreagg_lds_init(char *lds, const gpupreagg_lds_layout &L, cl_uint G, cl_uint NREP)
 {
-	size_t	total = gpupreagg_image_offset(1 + 2 * GPUPREAGG_NAGGS, G, NREP);
-	int		sec = 1;
-
-	for (size_t i = threadIdx.x * 16; i < total; i += GPUPREAGG_BLOCK * 16)
+	for (cl_uint i = threadIdx.x * 16; i < L.total; i += GPUPREAGG_BLOCK * 16)
 		*(uint4 *)(lds + i) = make_uint4(0, 0, 0, 0);
 	__syncthreads();
 #define X(aidx,resno,OP,NAME)															\
 	if (GPUPREAGG_OP_##OP == GPUPREAGG_OP_PMIN || GPUPREAGG_OP_##OP == GPUPREAGG_OP_PMAX)	\
 	{																					\
-		cl_ulong   *vals = (cl_ulong *)(lds + gpupreagg_image_offset(sec + 1, G, NREP));	\
+		cl_ulong   *vals = (cl_ulong *)(lds + L.vals_off[aidx]);						\
 		cl_ulong	ident = gpupreagg_identity<GPUPREAGG_OP_##OP, pg_##NAME##_base_t>();	\
-		for (size_t i = threadIdx.x; i < (size_t)G * NREP; i += GPUPREAGG_BLOCK)		\
+		for (cl_uint i = threadIdx.x; i < G * NREP; i += GPUPREAGG_BLOCK)				\
 			vals[i] = ident;															\
-	}																					\
-	sec += 2;
+	}
 	GPUPREAGG_AGG_LIST(X)
 #undef X
 	__syncthreads();
@@ -358,23 +367,26 @@ gpupreagg_lds_init(char *lds, cl_uint G, cl_uint NREP)
 
 /* fold replicas and store the work-group's slab (REP = 1 image) */
 STROM_DEVICE void
-gpupreagg_store_slab(const char *lds, char *slab, cl_uint G, cl_uint NREP)
+gpupreagg_store_slab(const char *lds, const gpupreagg_lds_layout &L, char *slab,
+					 cl_uint G, cl_uint NREP)
 {
-	size_t	nbits = ((size_t)G + 31) / 32;
-	int		sec = 1;
+	const gpupreagg_flags_t *lflags = (const gpupreagg_flags_t *)lds;
 
 	__syncthreads();
-	for (size_t i = threadIdx.x; i < nbits; i += GPUPREAGG_BLOCK)
-		((cl_uint *)slab)[i] = ((const cl_uint *)lds)[i];
+	for (cl_uint g = threadIdx.x; g < G; g += GPUPREAGG_BLOCK)
+	{
+		cl_uint f = 0;
+		for (cl_uint r = 0; r < NREP; r++)
+			f |= lflags[g * NREP + r];
+		((gpupreagg_flags_t *)slab)[g] = (gpupreagg_flags_t)f;
+	}
 #define X(aidx,resno,OP,NAME)																\
 	{																						\
-		const char *lbits = lds + gpupreagg_image_offset(sec, G, NREP);						\
-		const char *lvals = lds + gpupreagg_image_offset(sec + 1, G, NREP);					\
-		char	   *sbits = slab + gpupreagg_image_offset(sec, G, 1);							\
-		char	   *svals = slab + gpupreagg_image_offset(sec + 1, G, 1);						\
+		const char *lvals = lds + L.vals_off[aidx];											\
+		char	   *svals = slab + gpupreagg_image_offset(1 + aidx, G, 1);					\
 		if (GPUPREAGG_OP_##OP == GPUPREAGG_OP_NROWS)											\
 		{																					\
-			for (size_t g = threadIdx.x; g < G; g += GPUPREAGG_BLOCK)						\
+			for (cl_uint g = threadIdx.x; g < G; g += GPUPREAGG_BLOCK)						\
 			{																				\
 				cl_uint sum = 0;															\
 				for (cl_uint r = 0; r < NREP; r++)											\
@@ -384,9 +396,7 @@ gpupreagg_store_slab(const char *lds, char *slab, cl_uint G, cl_uint NREP)
 		}																					\
 		else																				\
 		{																					\
-			for (size_t i = threadIdx.x; i < nbits; i += GPUPREAGG_BLOCK)					\
-				((cl_uint *)sbits)[i] = ((const cl_uint *)lbits)[i];						\
-			for (size_t g = threadIdx.x; g < G; g += GPUPREAGG_BLOCK)						\
+			for (cl_uint g = threadIdx.x; g < G; g += GPUPREAGG_BLOCK)						\
 			{																				\
 				cl_ulong acc = ((const cl_ulong *)lvals)[g * NREP];							\
 				for (cl_uint r = 1; r < NREP; r++)											\
@@ -395,7 +405,6 @@ gpupreagg_store_slab(const char *lds, char *slab, cl_uint G, cl_uint NREP)
 				((cl_ulong *)svals)[g] = acc;												\
 			}																				\
 		}																					\
-		sec += 2;																			\
 	}
 	GPUPREAGG_AGG_LIST(X)
 #undef X
@@ -450,15 +459,18 @@ gpupreagg_dense_column(kern_gpupreagg *kgpreagg,
 	cl_uint		G = ctl->groups_per_split;
 	cl_uint		NREP = ctl->nrep;
 	cl_uint		split = blockIdx.x % nsplits;
+	cl_uint		gid_lo = split * G;
 	cl_uint		wg_in_split = blockIdx.x / nsplits;
 	cl_uint		wgs_per_split = gridDim.x / nsplits;
 	cl_uint		rep = threadIdx.x & (NREP - 1);
 	cl_int		chunk_status = StromError_Success;
 	cl_int		param_error = StromError_Success;
 	strom_kparams KP;
+	gpupreagg_lds_layout L;
 
 	gpupreagg_load_kparams(KP, kparams, &param_error);
-	gpupreagg_lds_init(lds, G, NREP);
+	gpupreagg_lds_layout_init(L, G, NREP);
+	gpupreagg_lds_init(lds, L, G, NREP);
 
 #define X(attno,colidx,NAME)													\
 	const char *col_##attno = (const char *)kds + coldir[colidx].values_off;	\
@@ -470,6 +482,7 @@ gpupreagg_dense_column(kern_gpupreagg *kgpreagg,
 	for (cl_uint tile = wg_in_split; tile < ntiles; tile += wgs_per_split)
 	{
 		cl_uint		tile_base = tile * GPUPREAGG_TILE_ROWS;
+		bool		full_tile = (tile_base + GPUPREAGG_TILE_ROWS <= nitems);
 		gpupreagg_column_tile T;
 
 #pragma unroll
@@ -490,7 +503,7 @@ gpupreagg_dense_column(kern_gpupreagg *kgpreagg,
 #pragma unroll
 			for (int j = 0; j < 4; j++)
 			{
-				if (row0 + j < nitems)
+				if (full_tile || row0 + j < nitems)
 				{
 					strom_kvars	KV;
 #define X(attno,colidx,NAME)													\
@@ -499,13 +512,13 @@ gpupreagg_dense_column(kern_gpupreagg *kgpreagg,
 					STROM_KVAR_LIST(X)
 #undef X
 					KV.__dummy = 0;
-					gpupreagg_dense_row(lds, ctl, KP, KV, split, G, NREP, rep,
+					gpupreagg_dense_row(lds, ctl, L, KP, KV, gid_lo, G, NREP, rep,
 										param_error, &chunk_status);
 				}
 			}
 		}
 	}
-	gpupreagg_store_slab(lds, slabs + (size_t)blockIdx.x * ctl->slab_bytes, G, NREP);
+	gpupreagg_store_slab(lds, L, slabs + (size_t)blockIdx.x * ctl->slab_bytes, G, NREP);
 	gpupreagg_writeback_status(&kgpreagg->status, chunk_status);
 }
 
@@ -529,15 +542,18 @@ gpupreagg_dense_generic(kern_gpupreagg *kgpreagg,
 	cl_uint		G = ctl->groups_per_split;
 	cl_uint		NREP = ctl->nrep;
 	cl_uint		split = blockIdx.x % nsplits;
+	cl_uint		gid_lo = split * G;
 	cl_uint		wg_in_split = blockIdx.x / nsplits;
 	cl_uint		wgs_per_split = gridDim.x / nsplits;
 	cl_uint		rep = threadIdx.x & (NREP - 1);
 	cl_int		chunk_status = StromError_Success;
 	cl_int		param_error = StromError_Success;
 	strom_kparams KP;
+	gpupreagg_lds_layout L;
 
 	gpupreagg_load_kparams(KP, kparams, &param_error);
-	gpupreagg_lds_init(lds, G, NREP);
+	gpupreagg_lds_layout_init(L, G, NREP);
+	gpupreagg_lds_init(lds, L, G, NREP);
 	for (size_t r = (size_t)wg_in_split * GPUPREAGG_BLOCK + threadIdx.x;
 		 r < nrows;
 		 r += (size_t)wgs_per_split * GPUPREAGG_BLOCK)
@@ -550,9 +566,9 @@ gpupreagg_dense_generic(kern_gpupreagg *kgpreagg,
 		STROM_KVAR_LIST(X)
 #undef X
 		KV.__dummy = 0;
-		gpupreagg_dense_row(lds, ctl, KP, KV, split, G, NREP, rep, errcode, &chunk_status);
+		gpupreagg_dense_row(lds, ctl, L, KP, KV, gid_lo, G, NREP, rep, errcode, &chunk_status);
 	}
-	gpupreagg_store_slab(lds, slabs + (size_t)blockIdx.x * ctl->slab_bytes, G, NREP);
+	gpupreagg_store_slab(lds, L, slabs + (size_t)blockIdx.x * ctl->slab_bytes, G, NREP);
 	gpupreagg_writeback_status(&kgpreagg->status, chunk_status);
 }
 
@@ -570,6 +586,7 @@ gpupreagg_dense_merge(const kern_gpupreagg *kgpreagg,
 	cl_uint		G = ctl->groups_per_split;
 	cl_uint		nsplits = ctl->nsplits;
 	cl_uint		wgs_per_split = ctl->nslabs / nsplits;
+	cl_uint	   *t_flags = (cl_uint *)table;
 
 	if (kgpreagg->status != StromError_Success)
 		return;
@@ -579,25 +596,20 @@ gpupreagg_dense_merge(const kern_gpupreagg *kgpreagg,
 	{
 		cl_uint		split = gid / G;
 		cl_uint		lgid = gid - split * G;
-		cl_uint		word = lgid >> 5, mask = 1u << (lgid & 31);
-		bool		seen = false;
-		int			sec = 1;
+		cl_uint		flags = 0;
 
 		for (cl_uint w = 0; w < wgs_per_split; w++)
 		{
 			const char *slab = slabs + (size_t)(w * nsplits + split) * ctl->slab_bytes;
-			if (((const cl_uint *)slab)[word] & mask)
-				seen = true;
+			flags |= ((const gpupreagg_flags_t *)slab)[lgid];
 		}
-		if (!seen)
+		if (flags == 0)
 			continue;
-		atomicOr((cl_uint *)table + (gid >> 5), 1u << (gid & 31));
+		cl_uint		had = t_flags[gid];
 #define X(aidx,resno,OP,NAME)																	\
 		{																						\
-			size_t	s_bits = gpupreagg_image_offset(sec, G, 1);									\
-			size_t	s_vals = gpupreagg_image_offset(sec + 1, G, 1);								\
-			cl_uint *t_bits = (cl_uint *)(table + gpupreagg_table_offset(sec, N));				\
-			cl_ulong *t_vals = (cl_ulong *)(table + gpupreagg_table_offset(sec + 1, N));		\
+			cl_uint		s_vals = gpupreagg_image_offset(1 + aidx, G, 1);						\
+			cl_ulong   *t_vals = (cl_ulong *)(table + gpupreagg_table_offset(1 + aidx, N));	\
 			if (GPUPREAGG_OP_##OP == GPUPREAGG_OP_NROWS)										\
 			{																					\
 				cl_ulong sum = 0;																\
@@ -606,34 +618,24 @@ gpupreagg_dense_merge(const kern_gpupreagg *kgpreagg,
 											  ctl->slab_bytes + s_vals))[lgid];					\
 				t_vals[gid] += sum;																\
 			}																					\
-			else																				\
+			else if (flags & (2u << aidx))														\
 			{																					\
 				cl_ulong acc = gpupreagg_identity<GPUPREAGG_OP_##OP, pg_##NAME##_base_t>();		\
-				bool	 has = false;															\
 				for (cl_uint w = 0; w < wgs_per_split; w++)										\
 				{																				\
 					const char *slab = slabs + (size_t)(w * nsplits + split) * ctl->slab_bytes;	\
-					if (((const cl_uint *)(slab + s_bits))[word] & mask)						\
-					{																			\
+					if (((const gpupreagg_flags_t *)slab)[lgid] & (2u << aidx))					\
 						acc = gpupreagg_merge8<GPUPREAGG_OP_##OP, pg_##NAME##_base_t>			\
 							(acc, ((const cl_ulong *)(slab + s_vals))[lgid]);					\
-						has = true;																\
-					}																			\
 				}																				\
-				if (has)																		\
-				{																				\
-					bool had = (t_bits[gid >> 5] >> (gid & 31)) & 1;							\
-					t_vals[gid] = had															\
-						? gpupreagg_merge8<GPUPREAGG_OP_##OP, pg_##NAME##_base_t>(t_vals[gid], acc)	\
-						: acc;																	\
-					if (!had)																	\
-						atomicOr(&t_bits[gid >> 5], 1u << (gid & 31));							\
-				}																				\
+				t_vals[gid] = (had & (2u << aidx))												\
+					? gpupreagg_merge8<GPUPREAGG_OP_##OP, pg_##NAME##_base_t>(t_vals[gid], acc)	\
+					: acc;																		\
 			}																					\
-			sec += 2;																			\
 		}
 		GPUPREAGG_AGG_LIST(X)
 #undef X
+		t_flags[gid] = had | flags;
 	}
 }
 

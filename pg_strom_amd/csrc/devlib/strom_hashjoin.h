@@ -1,0 +1,656 @@
+/*
+ * strom_hashjoin.h -- GpuHashJoin kernels (HIP, gfx950)
+ *
+ * Role in the reference: opencl_hashjoin.h -- kern_hashentry /
+ * kern_hashtable / kern_multihash accessors (102-192), kern_gpuhashjoin_main
+ * (284-416: count pass, reserve result slots with one atomic per work-group,
+ * emit pass, StromError_DataStoreNoSpace when the buffer is short) and the
+ * CRC32 hash-key templates (844-953).
+ *
+ * What is different:
+ *   - the inner side arrives as the reference's kern_multihash (whole
+ *     inner heap tuples in kern_hashentry chains).  The runtime keeps a
+ *     private copy in HBM and RE-LINKS it once per join
+ *     (hashjoin_build_index): entries are chained from a probe index of its
+ *     own instead of slot = crc32 % nslots.  Two index forms:
+ *       DIRECT  one integer-like key whose value range is dense:
+ *               slots[key - min] -> first entry.  4 bytes per key value:
+ *               a 1e6-key dimension is a 4 MB table that lives in L2; no
+ *               hashing, no key compare, no touch of the 48-byte entries.
+ *       HASH    anything else: slots[mix(key images) & mask], entry->hash
+ *               rewritten to the same mix, chain walked with key compare.
+ *   - result records keep the reference's meaning: {outer_row + 1, byte
+ *     offset of the matched kern_hashentry inside its kern_hashtable}.
+ *   - gpuhashjoin_main_fast: DIRECT + no duplicate keys + COLUMN outer: one
+ *     pass (a row matches at most once), rows streamed with 16-byte loads,
+ *     all slot reads of a tile issued before the first use, ballot/mbcnt
+ *     compaction into an LDS stage flushed with one atomic -- the GpuScan
+ *     structure with 8-byte records.
+ *   - gpuhashjoin_main: any format / row map / duplicates / several inner
+ *     relations: two passes per tile like the reference, but one result
+ *     reservation per 2048 rows instead of one per work-group of rows.
+ */
+#ifndef STROM_HASHJOIN_DEVICE_H
+#define STROM_HASHJOIN_DEVICE_H
+
+#ifndef HASHJOIN_BLOCK
+#define HASHJOIN_BLOCK		256
+#endif
+#ifndef HASHJOIN_QUADS
+#define HASHJOIN_QUADS		2
+#endif
+#ifndef HASHJOIN_STAGE
+#define HASHJOIN_STAGE		4096		/* records (8 bytes each) */
+#endif
+#define HASHJOIN_NWAVES		(HASHJOIN_BLOCK / STROM_WAVE)
+#define HASHJOIN_TILE_ROWS	(HASHJOIN_BLOCK * 4 * HASHJOIN_QUADS)
+#define HASHJOIN_MAXRELS	8
+
+#define HASHJOIN_MODE_HASH		0
+#define HASHJOIN_MODE_DIRECT	1
+
+/* probe index; gpuhashjoin.cpp mirrors these structs */
+struct hashjoin_index_rel {
+	cl_uint		mode;
+	cl_uint		nslots;			/* HASH: power of two; DIRECT: key range */
+	cl_long		key_min;
+	cl_uint		unique;			/* no chain longer than one entry */
+	cl_uint		slots_off;		/* bytes from the index base to cl_uint slots[] */
+	cl_uint		nentries;
+	cl_uint		__pad;
+};
+struct hashjoin_index {
+	cl_uint		nrels;
+	cl_uint		__pad[3];
+	hashjoin_index_rel rel[HASHJOIN_MAXRELS];
+};
+struct hashjoin_build_stats {
+	cl_long		key_min;
+	cl_long		key_max;
+	cl_uint		nentries;
+	cl_uint		intlike;
+};
+
+struct strom_kparams {
+#define X(idx,NAME)	pg_##NAME##_t KPARAM_##idx;
+	STROM_KPARAM_LIST(X)
+#undef X
+	int __dummy;
+};
+struct strom_kvars {
+#define X(attno,colidx,NAME)	pg_##NAME##_t KVAR_##attno;
+	STROM_KVAR_LIST(X)
+#undef X
+	int __dummy;
+};
+
+/* canonical 64-bit image of a key value: equal values <=> equal images */
+STROM_DEVICE cl_ulong hashjoin_key_image(cl_bool v)		{ return (cl_ulong)(v != 0); }
+STROM_DEVICE cl_ulong hashjoin_key_image(cl_short v)	{ return (cl_ulong)(cl_long)v; }
+STROM_DEVICE cl_ulong hashjoin_key_image(cl_int v)		{ return (cl_ulong)(cl_long)v; }
+STROM_DEVICE cl_ulong hashjoin_key_image(cl_long v)		{ return (cl_ulong)v; }
+STROM_DEVICE cl_ulong hashjoin_key_image(cl_ulong v)	{ return v; }
+STROM_DEVICE cl_ulong hashjoin_key_image(cl_double v)
+{
+	if (__builtin_isnan(v))
+		return 0x7ff8000000000000UL;
+	if (v == 0.0)
+		v = 0.0;				/* -0 == +0 */
+	return (cl_ulong)__double_as_longlong(v);
+}
+STROM_DEVICE cl_ulong hashjoin_key_image(cl_float v)	{ return hashjoin_key_image((cl_double)v); }
+
+STROM_DEVICE cl_uint
+hashjoin_hash_images(const cl_ulong *images, int nkeys)
+{
+	cl_ulong h = 0x9e3779b97f4a7c15UL;
+	for (int k = 0; k < nkeys; k++)
+	{
+		h ^= images[k];
+		h *= 0xff51afd7ed558ccdUL;
+		h ^= h >> 33;
+	}
+	h *= 0xc4ceb9fe1a85ec53UL;
+	h ^= h >> 29;
+	return (cl_uint)h;
+}
+
+STROM_DEVICE cl_uint
+hashjoin_first(const hashjoin_index *hjidx, int d0, const cl_ulong *images, int nkeys, cl_uint *p_hash)
+{
+	const hashjoin_index_rel *ir = &hjidx->rel[d0];
+	const cl_uint *slots = (const cl_uint *)((const char *)hjidx + ir->slots_off);
+
+	if (ir->mode == HASHJOIN_MODE_DIRECT)
+	{
+		cl_long	idx = (cl_long)images[0] - ir->key_min;
+		*p_hash = 0;
+		if (idx < 0 || idx >= (cl_long)ir->nslots)
+			return 0;
+		return slots[idx];
+	}
+	cl_uint h = hashjoin_hash_images(images, nkeys);
+	*p_hash = h;
+	return slots[h & (ir->nslots - 1)];
+}
+
+STROM_DEVICE bool
+hashjoin_candidate(const hashjoin_index *hjidx, int d0, const kern_hashentry *ent, cl_uint hash)
+{
+	return hjidx->rel[d0].mode == HASHJOIN_MODE_DIRECT || ent->hash == hash;
+}
+
+/* generated */
+STROM_DEVICE bool
+hashjoin_inner_key_images(int depth, const kern_hashtable *kht, const kern_hashentry *ent,
+						  cl_ulong *images);
+STROM_DEVICE bool
+hashjoin_fast_outer_key(cl_int *errcode, const strom_kparams &KP, const strom_kvars &KV,
+						cl_long *p_key);
+STROM_DEVICE cl_uint
+gpuhashjoin_execute(cl_int *errcode, const strom_kparams &KP, const strom_kvars &KV,
+					const kern_multihash *kmhash, const hashjoin_index *hjidx,
+					cl_uint kds_index, cl_int *rbuffer);
+
+STROM_DEVICE int
+hashjoin_nkeys_of(int depth)
+{
+	switch (depth)
+	{
+#ifdef HASHJOIN_NKEYS_1
+		case 1: return HASHJOIN_NKEYS_1;
+#endif
+#ifdef HASHJOIN_NKEYS_2
+		case 2: return HASHJOIN_NKEYS_2;
+#endif
+#ifdef HASHJOIN_NKEYS_3
+		case 3: return HASHJOIN_NKEYS_3;
+#endif
+#ifdef HASHJOIN_NKEYS_4
+		case 4: return HASHJOIN_NKEYS_4;
+#endif
+#ifdef HASHJOIN_NKEYS_5
+		case 5: return HASHJOIN_NKEYS_5;
+#endif
+#ifdef HASHJOIN_NKEYS_6
+		case 6: return HASHJOIN_NKEYS_6;
+#endif
+#ifdef HASHJOIN_NKEYS_7
+		case 7: return HASHJOIN_NKEYS_7;
+#endif
+#ifdef HASHJOIN_NKEYS_8
+		case 8: return HASHJOIN_NKEYS_8;
+#endif
+	}
+	return 0;
+}
+
+STROM_DEVICE int
+hashjoin_key0_intlike(int depth)
+{
+	switch (depth)
+	{
+#ifdef HASHJOIN_KEY0_INTLIKE_1
+		case 1: return HASHJOIN_KEY0_INTLIKE_1;
+#endif
+#ifdef HASHJOIN_KEY0_INTLIKE_2
+		case 2: return HASHJOIN_KEY0_INTLIKE_2;
+#endif
+#ifdef HASHJOIN_KEY0_INTLIKE_3
+		case 3: return HASHJOIN_KEY0_INTLIKE_3;
+#endif
+#ifdef HASHJOIN_KEY0_INTLIKE_4
+		case 4: return HASHJOIN_KEY0_INTLIKE_4;
+#endif
+#ifdef HASHJOIN_KEY0_INTLIKE_5
+		case 5: return HASHJOIN_KEY0_INTLIKE_5;
+#endif
+#ifdef HASHJOIN_KEY0_INTLIKE_6
+		case 6: return HASHJOIN_KEY0_INTLIKE_6;
+#endif
+#ifdef HASHJOIN_KEY0_INTLIKE_7
+		case 7: return HASHJOIN_KEY0_INTLIKE_7;
+#endif
+#ifdef HASHJOIN_KEY0_INTLIKE_8
+		case 8: return HASHJOIN_KEY0_INTLIKE_8;
+#endif
+	}
+	return 0;
+}
+
+/* ====================================================================== *
+ * index build, step 1: entry count and key range of one inner relation.
+ * One thread per slot of the HOST-built table walks that slot's chain.
+ * ====================================================================== */
+extern "C" __global__ void
+hashjoin_build_stats_kernel(const kern_multihash *kmhash, int depth,
+							hashjoin_build_stats *stats)
+{
+	const kern_hashtable *kht = KERN_HASHTABLE(kmhash, depth - 1);
+	const cl_uint *slots = KERN_HASHTABLE_SLOT(kht);
+	cl_long		kmin = 0x7fffffffffffffffL, kmax = -0x7fffffffffffffffL - 1;
+	cl_uint		count = 0;
+
+	for (cl_uint s = blockIdx.x * blockDim.x + threadIdx.x;
+		 s < kht->nslots;
+		 s += gridDim.x * blockDim.x)
+	{
+		for (cl_uint off = slots[s]; off != 0; )
+		{
+			const kern_hashentry *ent = (const kern_hashentry *)((const char *)kht + off);
+			cl_ulong	images[8];
+
+			if (off >= kht->length)
+				break;			/* corrupt chain: stop rather than fault */
+			count++;
+			if (hashjoin_inner_key_images(depth, kht, ent, images))
+			{
+				cl_long v = (cl_long)images[0];
+				kmin = (v < kmin ? v : kmin);
+				kmax = (v > kmax ? v : kmax);
+			}
+			off = ent->next;
+		}
+	}
+	if (count > 0)
+	{
+		atomicAdd(&stats->nentries, count);
+		atomicMin((long long *)&stats->key_min, (long long)kmin);
+		atomicMax((long long *)&stats->key_max, (long long)kmax);
+	}
+	if (blockIdx.x == 0 && threadIdx.x == 0)
+		stats->intlike = hashjoin_key0_intlike(depth);
+}
+
+/* ====================================================================== *
+ * index build, step 2: re-link the entries of the private table copy
+ * ====================================================================== */
+extern "C" __global__ void
+hashjoin_build_index_kernel(kern_multihash *kmhash, int depth, hashjoin_index *hjidx)
+{
+	kern_hashtable *kht = KERN_HASHTABLE(kmhash, depth - 1);
+	const cl_uint *old_slots = KERN_HASHTABLE_SLOT(kht);
+	hashjoin_index_rel *ir = &hjidx->rel[depth - 1];
+	cl_uint	   *slots = (cl_uint *)((char *)hjidx + ir->slots_off);
+	int			nkeys = hashjoin_nkeys_of(depth);
+
+	for (cl_uint s = blockIdx.x * blockDim.x + threadIdx.x;
+		 s < kht->nslots;
+		 s += gridDim.x * blockDim.x)
+	{
+		for (cl_uint off = old_slots[s]; off != 0; )
+		{
+			kern_hashentry *ent = (kern_hashentry *)((char *)kht + off);
+			cl_ulong	images[8];
+			cl_uint		next_old;
+
+			if (off >= kht->length)
+				break;
+			next_old = ent->next;		/* read before the entry is re-linked */
+			if (!hashjoin_inner_key_images(depth, kht, ent, images))
+			{
+				ent->next = 0;			/* a NULL key can never join */
+				ent->hash = 0;
+			}
+			else
+			{
+				cl_uint	h = 0, idx;
+				if (ir->mode == HASHJOIN_MODE_DIRECT)
+					idx = (cl_uint)((cl_long)images[0] - ir->key_min);
+				else
+				{
+					h = hashjoin_hash_images(images, nkeys);
+					idx = h & (ir->nslots - 1);
+				}
+				ent->hash = h;
+				cl_uint prev = atomicExch(&slots[idx], off);
+				ent->next = prev;
+				if (prev != 0)
+					ir->unique = 0;		/* benign race: every writer stores 0 */
+			}
+			off = next_old;
+		}
+	}
+}
+
+STROM_DEVICE void
+hashjoin_load_kparams(strom_kparams &KP, const kern_parambuf *kparams, cl_int *errcode)
+{
+#define X(idx,NAME)	KP.KPARAM_##idx = pg_##NAME##_param(kparams, errcode, idx);
+	STROM_KPARAM_LIST(X)
+#undef X
+	KP.__dummy = 0;
+}
+
+/* exclusive prefix of v over the work-group; *p_total = sum */
+STROM_DEVICE cl_uint
+hashjoin_block_scan(cl_uint v, cl_uint *lds_wave_totals, cl_uint *p_total)
+{
+	cl_uint	lane = threadIdx.x & (STROM_WAVE - 1);
+	cl_uint	wave = threadIdx.x / STROM_WAVE;
+	cl_uint	incl = v;
+
+#pragma unroll
+	for (int off = 1; off < STROM_WAVE; off <<= 1)
+	{
+		cl_uint o = __shfl_up(incl, off, STROM_WAVE);
+		if ((int)lane >= off)
+			incl += o;
+	}
+	if (lane == STROM_WAVE - 1)
+		lds_wave_totals[wave] = incl;
+	__syncthreads();
+	cl_uint before = 0, total = 0;
+#pragma unroll
+	for (int w = 0; w < HASHJOIN_NWAVES; w++)
+	{
+		cl_uint t = lds_wave_totals[w];
+		before += (w < (int)wave ? t : 0);
+		total += t;
+	}
+	__syncthreads();
+	*p_total = total;
+	return before + incl - v;
+}
+
+/* ====================================================================== *
+ * general probe: any format, row map, duplicates, several relations
+ * ====================================================================== */
+#define HASHJOIN_GENERIC_ROWS	8
+
+extern "C" __global__ void
+__launch_bounds__(HASHJOIN_BLOCK)
+gpuhashjoin_main(kern_hashjoin *khashjoin,
+				 const kern_multihash *kmhash,
+				 const hashjoin_index *hjidx,
+				 const kern_data_store *kds,
+				 const kern_data_store *ktoast,
+				 const kern_row_map *krowmap)
+{
+	__shared__ cl_uint	wave_totals[HASHJOIN_NWAVES];
+	__shared__ cl_uint	tile_base_slot;
+	const kern_parambuf *kparams = KERN_HASHJOIN_PARAMBUF(khashjoin);
+	kern_resultbuf *kresults = KERN_HASHJOIN_RESULTBUF(khashjoin);
+	bool		use_map = (krowmap != NULL && krowmap->nvalids >= 0);
+	cl_uint		nrows = (use_map ? (cl_uint)krowmap->nvalids : kds->nitems);
+	cl_uint		tile_rows = HASHJOIN_BLOCK * HASHJOIN_GENERIC_ROWS;
+	cl_uint		ntiles = (nrows + tile_rows - 1) / tile_rows;
+	cl_uint		nrels = kresults->nrels;
+	cl_int		chunk_error = StromError_Success;
+	cl_int		param_error = StromError_Success;
+	strom_kparams KP;
+
+	hashjoin_load_kparams(KP, kparams, &param_error);
+	if (nrels != kmhash->ntables + 1 || nrels != HASHJOIN_NRELS + 1)
+	{
+		/* uniform: every thread leaves (opencl_hashjoin.h:305-309) */
+		if (threadIdx.x == 0)
+			atomicMax(&kresults->errcode, StromError_DataStoreCorruption);
+		return;
+	}
+	/* chunk_error is per thread: the tile loop must not end divergently */
+	for (cl_uint tile = blockIdx.x; tile < ntiles; tile += gridDim.x)
+	{
+		cl_uint		counts[HASHJOIN_GENERIC_ROWS];
+		cl_uint		mine = 0;
+
+		/* pass 1: count */
+#pragma unroll
+		for (int j = 0; j < HASHJOIN_GENERIC_ROWS; j++)
+		{
+			cl_uint	r = tile * tile_rows + j * HASHJOIN_BLOCK + threadIdx.x;
+			counts[j] = 0;
+			if (r < nrows)
+			{
+				cl_uint		kds_index = (use_map ? (cl_uint)krowmap->rindex[r] : r);
+				cl_int		errcode = param_error;
+				strom_kvars	KV;
+#define X(attno,colidx,NAME)													\
+				KV.KVAR_##attno = pg_##NAME##_vref(kds, ktoast, &errcode, colidx, kds_index);
+				STROM_KVAR_LIST(X)
+#undef X
+				KV.__dummy = 0;
+				counts[j] = gpuhashjoin_execute(&errcode, KP, KV, kmhash, hjidx, kds_index, NULL);
+				if (errcode != StromError_Success)
+				{
+					/* the reference cannot re-check a join row on the CPU
+					 * (gpuhashjoin.c:2948-2952): surface it as the chunk status */
+					STROM_SET_ERROR(&chunk_error, errcode);
+					counts[j] = 0;
+				}
+			}
+			mine += counts[j];
+		}
+		cl_uint		total;
+		cl_uint		offset = hashjoin_block_scan(mine, wave_totals, &total);
+		if (threadIdx.x == 0)
+			tile_base_slot = (total > 0 ? atomicAdd(&kresults->nitems, total) : 0);
+		__syncthreads();
+		cl_uint		base = tile_base_slot;
+		__syncthreads();
+		if ((cl_ulong)base + total > (cl_ulong)kresults->nrooms)
+		{
+			/* keep counting so that nitems ends up as the room required */
+			if (threadIdx.x == 0)
+				atomicMax(&kresults->errcode, StromError_DataStoreNoSpace);
+			continue;
+		}
+		/* pass 2: emit */
+		cl_uint		pos = base + offset;
+#pragma unroll
+		for (int j = 0; j < HASHJOIN_GENERIC_ROWS; j++)
+		{
+			if (counts[j] > 0)
+			{
+				cl_uint		r = tile * tile_rows + j * HASHJOIN_BLOCK + threadIdx.x;
+				cl_uint		kds_index = (use_map ? (cl_uint)krowmap->rindex[r] : r);
+				cl_int		errcode = param_error;
+				strom_kvars	KV;
+#define X(attno,colidx,NAME)													\
+				KV.KVAR_##attno = pg_##NAME##_vref(kds, ktoast, &errcode, colidx, kds_index);
+				STROM_KVAR_LIST(X)
+#undef X
+				KV.__dummy = 0;
+				gpuhashjoin_execute(&errcode, KP, KV, kmhash, hjidx, kds_index,
+									kresults->results + (size_t)nrels * pos);
+				pos += counts[j];
+			}
+		}
+	}
+	/* significant errors and CpuReCheck alike end up in kresults->errcode */
+	{
+		cl_int worst = strom_wave_max_i32(chunk_error);
+		if (strom_lane_id() == 0 && worst != StromError_Success)
+			atomicMax(&kresults->errcode, worst);
+	}
+}
+
+/* ====================================================================== *
+ * fast probe: DIRECT index, unique keys, COLUMN outer, no row map
+ * ====================================================================== */
+struct hashjoin_stage {
+	cl_int		entries[HASHJOIN_STAGE][2];
+	cl_uint		wave_total[HASHJOIN_QUADS][HASHJOIN_NWAVES];
+	cl_uint		flush_base;
+};
+
+struct hashjoin_column_tile {
+#define X(attno,colidx,NAME)											\
+	pg_##NAME##_base_t	v_##attno[HASHJOIN_QUADS][4];					\
+	cl_uint				nn_##attno[HASHJOIN_QUADS];
+	STROM_KVAR_LIST(X)
+#undef X
+	int __dummy;
+};
+
+extern "C" __global__ void
+__launch_bounds__(HASHJOIN_BLOCK)
+gpuhashjoin_main_fast(kern_hashjoin *khashjoin,
+					  const hashjoin_index *hjidx,
+					  const kern_data_store *kds)
+{
+	__shared__ hashjoin_stage stage;
+	const kern_parambuf *kparams = KERN_HASHJOIN_PARAMBUF(khashjoin);
+	kern_resultbuf *kresults = KERN_HASHJOIN_RESULTBUF(khashjoin);
+	const kern_coldir *coldir = KERN_DATA_STORE_COLDIR(kds);
+	const hashjoin_index_rel *ir = &hjidx->rel[0];
+	const cl_uint *slots = (const cl_uint *)((const char *)hjidx + ir->slots_off);
+	cl_long		key_min = ir->key_min;
+	cl_uint		key_range = ir->nslots;
+	cl_uint		nitems = kds->nitems;
+	cl_uint		nrooms = kresults->nrooms;
+	cl_uint		ntiles = (nitems + HASHJOIN_TILE_ROWS - 1) / HASHJOIN_TILE_ROWS;
+	cl_uint		lane = threadIdx.x & (STROM_WAVE - 1);
+	cl_uint		wave = threadIdx.x / STROM_WAVE;
+	cl_int		chunk_error = StromError_Success;
+	cl_int		param_error = StromError_Success;
+	cl_uint		fill = 0;
+	strom_kparams KP;
+
+	hashjoin_load_kparams(KP, kparams, &param_error);
+#define X(attno,colidx,NAME)													\
+	const char *col_##attno = (const char *)kds + coldir[colidx].values_off;	\
+	const cl_uint *nul_##attno = (coldir[colidx].nulls_off != 0					\
+		? (const cl_uint *)((const char *)kds + coldir[colidx].nulls_off) : NULL);
+	STROM_KVAR_LIST(X)
+#undef X
+
+	for (cl_uint tile = blockIdx.x; tile < ntiles; tile += gridDim.x)
+	{
+		cl_uint		tile_base = tile * HASHJOIN_TILE_ROWS;
+		hashjoin_column_tile T;
+		cl_uint		match[HASHJOIN_QUADS][4];
+		cl_uint		my_prefix[HASHJOIN_QUADS];
+
+#pragma unroll
+		for (int k = 0; k < HASHJOIN_QUADS; k++)
+		{
+			cl_uint	row0 = tile_base + (k * HASHJOIN_BLOCK + threadIdx.x) * 4;
+#define X(attno,colidx,NAME)													\
+			strom_column_load_quad<pg_##NAME##_base_t>(col_##attno, nul_##attno,	\
+													   row0, nitems,				\
+													   T.v_##attno[k], T.nn_##attno[k]);
+			STROM_KVAR_LIST(X)
+#undef X
+		}
+		/* every slot read of the tile is issued before the first is used */
+#pragma unroll
+		for (int k = 0; k < HASHJOIN_QUADS; k++)
+		{
+			cl_uint	row0 = tile_base + (k * HASHJOIN_BLOCK + threadIdx.x) * 4;
+#pragma unroll
+			for (int j = 0; j < 4; j++)
+			{
+				strom_kvars	KV;
+				cl_int		errcode = param_error;
+				cl_long		key;
+#define X(attno,colidx,NAME)													\
+				KV.KVAR_##attno = pg_##NAME##_make(T.v_##attno[k][j],				\
+												   !((T.nn_##attno[k] >> j) & 1));
+				STROM_KVAR_LIST(X)
+#undef X
+				KV.__dummy = 0;
+				match[k][j] = 0;
+				if (row0 + j < nitems &&
+					hashjoin_fast_outer_key(&errcode, KP, KV, &key))
+				{
+					cl_ulong idx = (cl_ulong)(key - key_min);
+					if (idx < key_range)
+						match[k][j] = slots[idx];
+				}
+				if (errcode != StromError_Success)
+				{
+					STROM_SET_ERROR(&chunk_error, errcode);
+					match[k][j] = 0;
+				}
+			}
+		}
+		if (fill + HASHJOIN_TILE_ROWS > HASHJOIN_STAGE)
+		{
+			/* flush: one reservation, contiguous store */
+			if (fill > 0)
+			{
+				if (threadIdx.x == 0)
+					stage.flush_base = atomicAdd(&kresults->nitems, fill);
+				__syncthreads();
+				cl_uint	base = stage.flush_base;
+				if ((cl_ulong)base + fill <= nrooms)
+				{
+					cl_long *dest = (cl_long *)(kresults->results + 2 * (size_t)base);
+					for (cl_uint i = threadIdx.x; i < fill; i += HASHJOIN_BLOCK)
+						__builtin_memcpy(&dest[i], stage.entries[i], 8);
+				}
+				else
+					STROM_SET_ERROR(&chunk_error, StromError_DataStoreNoSpace);
+				__syncthreads();
+			}
+			fill = 0;
+		}
+#pragma unroll
+		for (int k = 0; k < HASHJOIN_QUADS; k++)
+		{
+			cl_uint	prefix = 0, total = 0;
+#pragma unroll
+			for (int j = 0; j < 4; j++)
+			{
+				strom_lanemask_t m = __ballot(match[k][j] != 0);
+				prefix += strom_mbcnt(m);
+				total += __popcll(m);
+			}
+			my_prefix[k] = prefix;
+			if (lane == 0)
+				stage.wave_total[k][wave] = total;
+		}
+		__syncthreads();
+		cl_uint		appended = 0;
+#pragma unroll
+		for (int k = 0; k < HASHJOIN_QUADS; k++)
+		{
+			cl_uint	before = 0, all = 0;
+#pragma unroll
+			for (int w = 0; w < HASHJOIN_NWAVES; w++)
+			{
+				cl_uint	t = stage.wave_total[k][w];
+				before += (w < (int)wave ? t : 0);
+				all += t;
+			}
+			cl_uint	pos = fill + appended + before + my_prefix[k];
+			cl_uint	row0 = tile_base + (k * HASHJOIN_BLOCK + threadIdx.x) * 4;
+#pragma unroll
+			for (int j = 0; j < 4; j++)
+			{
+				if (match[k][j] != 0)
+				{
+					stage.entries[pos][0] = (cl_int)(row0 + j + 1);
+					stage.entries[pos][1] = (cl_int)match[k][j];
+					pos++;
+				}
+			}
+			appended += all;
+		}
+		__syncthreads();
+		fill += appended;
+	}
+	if (fill > 0)
+	{
+		if (threadIdx.x == 0)
+			stage.flush_base = atomicAdd(&kresults->nitems, fill);
+		__syncthreads();
+		cl_uint	base = stage.flush_base;
+		if ((cl_ulong)base + fill <= nrooms)
+		{
+			cl_long *dest = (cl_long *)(kresults->results + 2 * (size_t)base);
+			for (cl_uint i = threadIdx.x; i < fill; i += HASHJOIN_BLOCK)
+				__builtin_memcpy(&dest[i], stage.entries[i], 8);
+		}
+		else
+			STROM_SET_ERROR(&chunk_error, StromError_DataStoreNoSpace);
+	}
+	{
+		cl_int worst = strom_wave_max_i32(chunk_error);
+		if (strom_lane_id() == 0 && worst != StromError_Success)
+			atomicMax(&kresults->errcode, worst);
+	}
+}
+
+#endif	/* STROM_HASHJOIN_DEVICE_H */

@@ -1,0 +1,463 @@
+/*
+ * gpuhashjoin.cpp -- host side of GpuHashJoin
+ *
+ * Role in the reference: clserv_process_gpuhashjoin (gpuhashjoin.c:4430-5073)
+ * and clserv_respond_hashjoin (4132-4428).  The reference uploads the
+ * kern_multihash once per device and shares it between the chunks of a
+ * join by a count under a spinlock (4498-4557); here that shared object
+ * is a strom_hashjoin_table: a private copy of the kern_multihash in HBM
+ * plus the probe index built from it (strom_hashjoin.h).
+ */
+#include <cstring>
+#include <cstdio>
+#include <algorithm>
+
+#include "runtime.h"
+
+using namespace strom;
+
+namespace {
+
+/* mirror strom_hashjoin.h */
+struct index_rel {
+	cl_uint		mode;
+	cl_uint		nslots;
+	cl_long		key_min;
+	cl_uint		unique;
+	cl_uint		slots_off;
+	cl_uint		nentries;
+	cl_uint		__pad;
+};
+struct index_head {
+	cl_uint		nrels;
+	cl_uint		__pad[3];
+	index_rel	rel[8];
+};
+struct build_stats {
+	cl_long		key_min;
+	cl_long		key_max;
+	cl_uint		nentries;
+	cl_uint		intlike;
+};
+
+}	/* namespace */
+
+struct strom_hashjoin_table {
+	strom_devprog_key	key = 0;
+	Program			   *prog = nullptr;
+	Device			   *dev = nullptr;
+	char			   *d_kmhash = nullptr;
+	size_t				kmhash_len = 0;
+	char			   *d_index = nullptr;
+	size_t				index_len = 0;
+	index_head			head;
+	int					ntables = 0;
+	std::atomic<int>	refcnt{1};
+};
+
+extern "C" strom_hashjoin_table *
+strom_hashjoin_table_create(strom_devprog_key key, const kern_multihash *kmhash, size_t length,
+							int dindex, int *p_errcode)
+{
+	int		dummy;
+	if (!p_errcode)
+		p_errcode = &dummy;
+	*p_errcode = 0;
+	Program *prog = lookup_program(key);
+	Device *dev = get_device(dindex);
+	if (!prog || !dev || !kmhash || kmhash->ntables < 1 || kmhash->ntables > 8 ||
+		length < sizeof(kern_multihash))
+	{
+		*p_errcode = (!dev ? StromError_ServerNotReady : StromError_BadRequestMessage);
+		return nullptr;
+	}
+	/* the index is built by kernels of the join's own program */
+	{
+		std::unique_lock<std::mutex> g(prog->lock);
+		prog->cond.wait(g, [&]{ return prog->state != STROM_DEVPROG_PENDING; });
+		if (prog->state != STROM_DEVPROG_READY)
+		{
+			*p_errcode = StromError_ProgramBuildFailure;
+			return nullptr;
+		}
+	}
+	(void)hipSetDevice(dev->hip_id);
+	int		errcode = 0;
+	hipFunction_t fn_stats = prog->get_function(dev, "hashjoin_build_stats_kernel", &errcode);
+	hipFunction_t fn_index = fn_stats ? prog->get_function(dev, "hashjoin_build_index_kernel", &errcode) : nullptr;
+	if (!fn_stats || !fn_index)
+	{
+		*p_errcode = errcode;
+		return nullptr;
+	}
+	std::unique_ptr<strom_hashjoin_table> tbl(new strom_hashjoin_table());
+	tbl->key = key;
+	tbl->prog = prog;
+	tbl->dev = dev;
+	tbl->ntables = (int)kmhash->ntables;
+	tbl->kmhash_len = length;
+	hipStream_t stream = dev->streams[0];
+	auto fail = [&](int code) -> strom_hashjoin_table * {
+		if (tbl->d_kmhash) dev->pool.release(tbl->d_kmhash);
+		if (tbl->d_index) dev->pool.release(tbl->d_index);
+		*p_errcode = code;
+		return nullptr;
+	};
+	tbl->d_kmhash = (char *)dev->pool.alloc(length);
+	if (!tbl->d_kmhash)
+		return fail(StromError_OutOfMemory);
+	if (hipMemcpyAsync(tbl->d_kmhash, kmhash, length, hipMemcpyHostToDevice, stream) != hipSuccess)
+		return fail(StromError_HipInternal);
+	/* step 1: per relation entry count and key range */
+	build_stats *d_stats = (build_stats *)dev->pool.alloc(sizeof(build_stats) * 8);
+	if (!d_stats)
+		return fail(StromError_OutOfMemory);
+	build_stats h_stats[8];
+	for (int t = 0; t < 8; t++)
+	{
+		h_stats[t].key_min = 0x7fffffffffffffffL;
+		h_stats[t].key_max = -0x7fffffffffffffffL - 1;
+		h_stats[t].nentries = 0;
+		h_stats[t].intlike = 0;
+	}
+	bool	ok = (hipMemcpyAsync(d_stats, h_stats, sizeof(h_stats), hipMemcpyHostToDevice, stream) == hipSuccess);
+	unsigned grid = (unsigned)dev->prop.multiProcessorCount * 8;
+	for (int t = 0; ok && t < tbl->ntables; t++)
+	{
+		void   *a_km = tbl->d_kmhash;
+		int		a_depth = t + 1;
+		void   *a_st = d_stats + t;
+		void   *args[] = { &a_km, &a_depth, &a_st };
+		ok = (hipModuleLaunchKernel(fn_stats, grid, 1, 1, 256, 1, 1, 0, stream, args, nullptr) == hipSuccess);
+	}
+	ok = ok && hipMemcpyAsync(h_stats, d_stats, sizeof(h_stats), hipMemcpyDeviceToHost, stream) == hipSuccess
+		&& hipStreamSynchronize(stream) == hipSuccess;
+	dev->pool.release(d_stats);
+	if (!ok)
+		return fail(StromError_HipInternal);
+	/* step 2: choose the index form per relation, lay the slots out */
+	memset(&tbl->head, 0, sizeof(tbl->head));
+	tbl->head.nrels = tbl->ntables;
+	size_t	off = STROM_TYPEALIGN(256, sizeof(index_head));
+	bool	force_hash = (getenv("STROM_HASHJOIN_FORCE_HASH") != nullptr);
+	for (int t = 0; t < tbl->ntables; t++)
+	{
+		index_rel  &ir = tbl->head.rel[t];
+		cl_ulong	n = h_stats[t].nentries;
+		bool		direct = false;
+		if (!force_hash && h_stats[t].intlike && n > 0 && h_stats[t].key_max >= h_stats[t].key_min)
+		{
+			/* dense enough?  4 bytes per key value against ~8 bytes per
+			 * entry of an open hash at load 0.5 */
+			unsigned __int128 range = (unsigned __int128)((__int128)h_stats[t].key_max - h_stats[t].key_min) + 1;
+			if (range <= (1UL << 27) && range <= std::max<cl_ulong>(8 * n, 1UL << 16))
+			{
+				direct = true;
+				ir.mode = 1;
+				ir.nslots = (cl_uint)range;
+				ir.key_min = h_stats[t].key_min;
+			}
+		}
+		if (!direct)
+		{
+			cl_ulong slots = 1024;
+			while (slots < 2 * n)
+				slots <<= 1;
+			ir.mode = 0;
+			ir.nslots = (cl_uint)slots;
+			ir.key_min = 0;
+		}
+		ir.unique = 1;
+		ir.nentries = (cl_uint)n;
+		ir.slots_off = (cl_uint)off;
+		off += STROM_TYPEALIGN(256, sizeof(cl_uint) * (size_t)ir.nslots);
+	}
+	tbl->index_len = off;
+	tbl->d_index = (char *)dev->pool.alloc(off);
+	if (!tbl->d_index)
+		return fail(StromError_OutOfMemory);
+	ok = (hipMemsetAsync(tbl->d_index, 0, off, stream) == hipSuccess &&
+		  hipMemcpyAsync(tbl->d_index, &tbl->head, sizeof(index_head), hipMemcpyHostToDevice, stream) == hipSuccess);
+	for (int t = 0; ok && t < tbl->ntables; t++)
+	{
+		void   *a_km = tbl->d_kmhash;
+		int		a_depth = t + 1;
+		void   *a_ix = tbl->d_index;
+		void   *args[] = { &a_km, &a_depth, &a_ix };
+		ok = (hipModuleLaunchKernel(fn_index, grid, 1, 1, 256, 1, 1, 0, stream, args, nullptr) == hipSuccess);
+	}
+	ok = ok && hipMemcpyAsync(&tbl->head, tbl->d_index, sizeof(index_head), hipMemcpyDeviceToHost, stream) == hipSuccess
+		&& hipStreamSynchronize(stream) == hipSuccess;
+	if (!ok)
+		return fail(StromError_HipInternal);
+	strom_retain_devprog_key(key);
+	return tbl.release();
+}
+
+extern "C" void
+strom_hashjoin_table_release(strom_hashjoin_table *tbl)
+{
+	if (!tbl || --tbl->refcnt > 0)
+		return;
+	Device *dev = tbl->dev;
+	(void)hipSetDevice(dev->hip_id);
+	for (auto st : dev->streams)
+		(void)hipStreamSynchronize(st);
+	dev->pool.release(tbl->d_kmhash);
+	dev->pool.release(tbl->d_index);
+	strom_put_devprog_key(tbl->key);
+	delete tbl;
+}
+
+extern "C" int
+strom_hashjoin_table_info(strom_hashjoin_table *tbl, int depth,
+						  int *p_mode, uint32_t *p_nslots, int *p_unique, uint32_t *p_nentries)
+{
+	if (!tbl || depth < 1 || depth > tbl->ntables)
+		return StromError_BadRequestMessage;
+	const index_rel &ir = tbl->head.rel[depth - 1];
+	if (p_mode) *p_mode = (int)ir.mode;
+	if (p_nslots) *p_nslots = ir.nslots;
+	if (p_unique) *p_unique = (int)ir.unique;
+	if (p_nentries) *p_nentries = ir.nentries;
+	return 0;
+}
+
+/* copy the (re-linked) table back, for callers that resolve entry offsets */
+extern "C" int
+strom_hashjoin_table_download(strom_hashjoin_table *tbl, void *buffer, size_t buflen)
+{
+	if (!tbl || !buffer || buflen < tbl->kmhash_len)
+		return StromError_BadRequestMessage;
+	(void)hipSetDevice(tbl->dev->hip_id);
+	return hip_errcode(hipMemcpy(buffer, tbl->d_kmhash, tbl->kmhash_len, hipMemcpyDeviceToHost),
+					   "download kern_multihash");
+}
+
+namespace {
+
+#define REQ_CHECK(call, what)												\
+	do {																	\
+		hipError_t __rc = (call);											\
+		if (__rc != hipSuccess)												\
+		{																	\
+			task_fail(task, hip_errcode(__rc, what));						\
+			return;															\
+		}																	\
+	} while (0)
+
+struct hashjoin_request {
+	strom_hashjoin_table *tbl;
+	kern_hashjoin	   *khj;
+	const kern_data_store *kds;
+	strom_dstore	   *kds_dev;
+	const kern_row_map *krowmap;
+	uint32_t			flags;
+	uint32_t			format;
+	uint32_t			nrows;
+};
+
+void
+gpuhashjoin_launch(strom_task_impl *task, hashjoin_request req)
+{
+	strom_hashjoin_table *tbl = req.tbl;
+	Device	   *dev = task->dev;
+	Program	   *prog = tbl->prog;
+	kern_hashjoin *khj = req.khj;
+	kern_resultbuf *kres_host = KERN_HASHJOIN_RESULTBUF(khj);
+	size_t		res_offset = KERN_HASHJOIN_PARAMBUF_LENGTH(khj);
+	size_t		head_len = res_offset + offsetof(kern_resultbuf, results);
+	size_t		total_len = res_offset + KERN_RESULTBUF_LENGTH(kres_host->nrels, kres_host->nrooms);
+	int			errcode = 0;
+
+	(void)hipSetDevice(dev->hip_id);
+	task->pfm.time_kern_build = (cl_ulong)prog->build_usec;
+	if (req.kds_dev || dev->streams.size() < 2)
+		task->stream = dev->streams[0];
+	else
+		task->stream = dev->streams[1 + dev->next_stream++ % (dev->streams.size() - 1)];
+	bool	fast = (tbl->ntables == 1 && tbl->head.rel[0].mode == 1 && tbl->head.rel[0].unique &&
+					req.format == KDS_FORMAT_COLUMN && req.krowmap == nullptr &&
+					!getenv("STROM_HASHJOIN_NO_FAST"));
+	hipFunction_t fn = nullptr;
+	if (fast)
+	{
+		/* only programs whose single clause is "int key = inner key" have it */
+		int e2 = 0;
+		fn = prog->get_function(dev, "gpuhashjoin_main_fast", &e2);
+	}
+	/* a program that is not fast-eligible still exports the symbol; the
+	 * eligibility is baked into hashjoin_fast_outer_key() returning false,
+	 * so ask the generated code */
+	if (fn && !strstr(prog->source.c_str(), "#define HASHJOIN_FAST_ELIGIBLE 1"))
+		fn = nullptr;
+	fast = (fn != nullptr);
+	if (!fn)
+		fn = prog->get_function(dev, "gpuhashjoin_main", &errcode);
+	if (!fn)
+	{
+		task_fail(task, errcode);
+		return;
+	}
+	char	   *d_khj = (char *)dev->pool.alloc(total_len);
+	if (!d_khj)
+	{
+		task_fail(task, StromError_OutOfMemory);
+		return;
+	}
+	task->main_devptr = d_khj;
+	task->keep_main = (!task->detached && (req.flags & STROM_RESULTS_ON_DEVICE) != 0);
+	char	   *stage = (head_len + 64 <= PinnedPool::BLOCK ? dev->pinned.alloc() : nullptr);
+	if (stage)
+	{
+		task->pinned_blocks.push_back(stage);
+		memcpy(stage, khj, head_len);
+	}
+	task_event(task);									/* ev[0] */
+	REQ_CHECK(hipMemcpyAsync(d_khj, stage ? (void *)stage : (void *)khj, head_len,
+							 hipMemcpyHostToDevice, task->stream), "send kern_hashjoin");
+	task->pfm.num_dma_send++;
+	task->pfm.bytes_dma_send += head_len;
+	const void *d_kds;
+	if (req.kds_dev)
+		d_kds = req.kds_dev->devptr;
+	else
+	{
+		size_t	kds_len = req.kds->length;
+		if (req.kds->format == KDS_FORMAT_ROW)
+			kds_len = KERN_DATA_STORE_ROWBLOCK_OFFSET(req.kds) + (size_t)BLCKSZ * req.kds->nblocks;
+		void   *p = dev->pool.alloc(kds_len);
+		if (!p)
+		{
+			task_fail(task, StromError_OutOfMemory);
+			return;
+		}
+		task->devbufs.push_back(p);
+		REQ_CHECK(hipMemcpyAsync(p, req.kds, kds_len, hipMemcpyHostToDevice, task->stream),
+				  "send kern_data_store");
+		task->pfm.num_dma_send++;
+		task->pfm.bytes_dma_send += kds_len;
+		d_kds = p;
+	}
+	const void *d_rowmap = nullptr;
+	if (req.krowmap)
+	{
+		size_t	len = offsetof(kern_row_map, rindex) + sizeof(cl_int) * (size_t)req.krowmap->nvalids;
+		void   *p = dev->pool.alloc(len);
+		if (!p)
+		{
+			task_fail(task, StromError_OutOfMemory);
+			return;
+		}
+		task->devbufs.push_back(p);
+		REQ_CHECK(hipMemcpyAsync(p, req.krowmap, len, hipMemcpyHostToDevice, task->stream),
+				  "send kern_row_map");
+		d_rowmap = p;
+	}
+	task_event(task);									/* ev[1] */
+	{
+		int		block = 256;
+		size_t	tile_rows = fast ? (size_t)block * 4 * 2 : (size_t)block * 8;
+		size_t	ntiles = (req.nrows + tile_rows - 1) / tile_rows;
+		int		per_cu = 0;
+		if (hipModuleOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, block, 0) != hipSuccess || per_cu < 1)
+			per_cu = 1;
+		if (const char *v = getenv("STROM_HASHJOIN_BLOCKS_PER_CU"))
+			per_cu = std::max(1, atoi(v));
+		size_t	grid = std::max<size_t>(1, std::min<size_t>(ntiles, (size_t)dev->prop.multiProcessorCount * per_cu));
+		void	   *a_khj = d_khj;
+		const void *a_km = tbl->d_kmhash;
+		const void *a_ix = tbl->d_index;
+		const void *a_kds = d_kds;
+		const void *a_toast = nullptr;
+		const void *a_map = d_rowmap;
+		void	   *args_fast[] = { &a_khj, &a_ix, &a_kds };
+		void	   *args_gen[] = { &a_khj, &a_km, &a_ix, &a_kds, &a_toast, &a_map };
+		REQ_CHECK(hipModuleLaunchKernel(fn, (unsigned)grid, 1, 1, block, 1, 1, 0, task->stream,
+										fast ? args_fast : args_gen, nullptr),
+				  "launch gpuhashjoin kernel");
+		task->pfm.num_kern_exec++;
+	}
+	task_event(task);									/* ev[2] */
+	char	   *stage_res = (stage ? stage + STROMALIGN(head_len) : nullptr);
+	REQ_CHECK(hipMemcpyAsync(stage_res ? (void *)stage_res : (void *)kres_host,
+							 d_khj + res_offset, offsetof(kern_resultbuf, results),
+							 hipMemcpyDeviceToHost, task->stream),
+			  "recv kern_resultbuf head");
+	task->pfm.num_dma_recv++;
+	task->pfm.bytes_dma_recv += offsetof(kern_resultbuf, results);
+	task_event(task);									/* ev[3] */
+	bool	results_on_device = (req.flags & STROM_RESULTS_ON_DEVICE) != 0;
+	task->finish = [kres_host, d_khj, res_offset, results_on_device, stage_res](strom_task_impl *t)
+	{
+		if (stage_res)
+			memcpy(kres_host, stage_res, offsetof(kern_resultbuf, results));
+		if (kres_host->errcode != StromError_Success)
+		{
+			/* DataStoreNoSpace: nitems holds the room a retry needs
+			 * (gpuhashjoin.c:4330-4425); CpuReCheck: no CPU path for joins */
+			t->errcode = kres_host->errcode;
+			return;
+		}
+		if (results_on_device || kres_host->nitems == 0)
+			return;
+		size_t	len = sizeof(cl_int) * (size_t)kres_host->nitems * kres_host->nrels;
+		hipError_t rc = hipMemcpyAsync(kres_host->results,
+									   d_khj + res_offset + offsetof(kern_resultbuf, results),
+									   len, hipMemcpyDeviceToHost, t->stream);
+		if (rc == hipSuccess)
+			rc = hipStreamSynchronize(t->stream);
+		if (rc != hipSuccess)
+			t->errcode = hip_errcode(rc, "recv results[]");
+		t->pfm.num_dma_recv++;
+		t->pfm.bytes_dma_recv += len;
+	};
+	task_enqueue(task);
+}
+
+}	/* namespace */
+
+extern "C" strom_task *
+strom_submit_gpuhashjoin(strom_hashjoin_table *tbl,
+						 kern_hashjoin *khashjoin,
+						 const kern_data_store *kds, strom_dstore *kds_dev,
+						 const kern_row_map *krowmap,
+						 uint32_t flags,
+						 strom_done_cb done, void *arg, int *p_errcode)
+{
+	int		dummy;
+	if (!p_errcode)
+		p_errcode = &dummy;
+	*p_errcode = 0;
+	if (!tbl || !khashjoin || (!kds) == (!kds_dev) ||
+		(kds_dev && kds_dev->dindex != tbl->dev->dindex))
+	{
+		*p_errcode = StromError_BadRequestMessage;
+		return nullptr;
+	}
+	kern_resultbuf *kres = KERN_HASHJOIN_RESULTBUF(khashjoin);
+	if ((int)kres->nrels != tbl->ntables + 1)
+	{
+		*p_errcode = StromError_BadRequestMessage;
+		return nullptr;
+	}
+	kres->nitems = 0;
+	kres->errcode = StromError_Success;
+	hashjoin_request req;
+	req.tbl = tbl;
+	req.khj = khashjoin;
+	req.kds = kds;
+	req.kds_dev = kds_dev;
+	req.krowmap = (krowmap && krowmap->nvalids >= 0) ? krowmap : nullptr;
+	req.flags = flags;
+	kern_data_store head;
+	if (kds)
+		memcpy(&head, kds, offsetof(kern_data_store, colmeta));
+	else
+		head = kds_dev->head;
+	req.format = head.format;
+	req.nrows = req.krowmap ? (uint32_t)req.krowmap->nvalids : head.nitems;
+	strom_task_impl *task = task_create(tbl->dev, done, arg);
+	gpuhashjoin_launch(task, req);		/* the program is ready: the table needed it */
+	return task;
+}

@@ -58,19 +58,23 @@ struct strom_gpupreagg {
 	int					block = 1024, quads = 2;
 	std::mutex			lock;
 
-	/* byte offset of a section inside an [bits | per agg (bits, values)] image */
+	/* mirrors gpupreagg_image_offset / gpupreagg_table_offset of
+	 * strom_gpupreagg.h: section 0 = flags, 1+a = values of aggregate a,
+	 * 1+naggs = total */
+	size_t flag_width() const
+	{
+		size_t n = agg_resno.size();
+		return n <= 7 ? 1 : (n <= 15 ? 2 : 4);
+	}
 	size_t image_offset(int sec, cl_uint G, cl_uint REP) const
 	{
-		size_t	off = 0, bits = align16(sizeof(cl_uint) * (((size_t)G + 31) / 32));
+		size_t	off = 0;
 		int		cur = 0;
 		if (sec == cur) return off;
-		off += bits; cur++;
+		off += align16(flag_width() * (size_t)G * REP); cur++;
 		for (int resno : agg_resno)
 		{
 			bool nrows = (targets[resno].kind == STROM_PREAGG_NROWS);
-			if (sec == cur) return off;
-			if (!nrows) off += bits;
-			cur++;
 			if (sec == cur) return off;
 			off += align16((nrows ? 4 : 8) * (size_t)G * REP);
 			cur++;
@@ -79,22 +83,12 @@ struct strom_gpupreagg {
 	}
 	size_t table_offset(int sec, cl_uint N) const
 	{
-		size_t	off = 0;
-		size_t	bits = STROM_TYPEALIGN(256, sizeof(cl_uint) * (((size_t)N + 31) / 32));
+		size_t	flags = STROM_TYPEALIGN(256, sizeof(cl_uint) * (size_t)N);
 		size_t	vals = STROM_TYPEALIGN(256, 8 * (size_t)N);
-		int		cur = 0;
-		if (sec == cur) return off;
-		off += bits; cur++;
-		for (size_t a = 0; a < agg_resno.size(); a++)
-		{
-			if (sec == cur) return off;
-			off += bits; cur++;
-			if (sec == cur) return off;
-			off += vals; cur++;
-		}
-		return off;
+		if (sec == 0) return 0;
+		return flags + vals * (size_t)(sec - 1);
 	}
-	int nsections() const { return 1 + 2 * (int)agg_resno.size(); }
+	int nsections() const { return 1 + (int)agg_resno.size(); }
 };
 
 namespace {
@@ -144,12 +138,6 @@ setup_geometry(strom_gpupreagg *sess, const strom_preagg_domain *dom)
 			return StromError_DataStoreOutOfRange;		/* too sparse for dense ids */
 	}
 	ctl.ngroups = (cl_uint)ngroups;
-	/* bytes of LDS per group at one replica (bitmaps are ~1 bit each) */
-	size_t	per_group = 0;
-	for (int resno : sess->agg_resno)
-		per_group += (sess->targets[resno].kind == STROM_PREAGG_NROWS ? 4 : 8);
-	if (per_group == 0)
-		per_group = 1;
 	size_t	one = sess->image_offset(sess->nsections(), ctl.ngroups, 1);
 	if (one <= lds_budget)
 	{
@@ -469,8 +457,8 @@ strom_gpupreagg_table_layout(strom_gpupreagg *sess, int resno, size_t *p_bits_of
 		return 0;
 	}
 	int a = (int)(std::find(sess->agg_resno.begin(), sess->agg_resno.end(), resno) - sess->agg_resno.begin());
-	*p_bits_off = sess->table_offset(1 + 2 * a, sess->ctl.ngroups);
-	*p_vals_off = sess->table_offset(2 + 2 * a, sess->ctl.ngroups);
+	*p_bits_off = 0;			/* flags word: bit 0 seen, bit 1+a has-value */
+	*p_vals_off = sess->table_offset(1 + a, sess->ctl.ngroups);
 	return 0;
 }
 
@@ -562,10 +550,10 @@ strom_gpupreagg_fetch(strom_gpupreagg *sess, kern_data_store *dest, size_t destl
 	if (hipStreamSynchronize(dev->streams[0]) != hipSuccess ||
 		hipMemcpy(host.data(), sess->table, sess->table_bytes, hipMemcpyDeviceToHost) != hipSuccess)
 		return -StromError_HipInternal;
-	const cl_uint *seen = (const cl_uint *)host.data();
+	const cl_uint *gflags = (const cl_uint *)host.data();
 	size_t	ngroups = 0;
 	for (cl_uint g = 0; g < N; g++)
-		if ((seen[g >> 5] >> (g & 31)) & 1)
+		if (gflags[g] & 1)
 			ngroups++;
 	size_t	need = STROMALIGN(KDS_HEAD_LENGTH(ncols) + KDS_TUPSLOT_STRIDE(ncols) * ngroups);
 	if (!dest)
@@ -593,7 +581,7 @@ strom_gpupreagg_fetch(strom_gpupreagg *sess, kern_data_store *dest, size_t destl
 	cl_uint	row = 0;
 	for (cl_uint g = 0; g < N; g++)
 	{
-		if (!((seen[g >> 5] >> (g & 31)) & 1))
+		if (!(gflags[g] & 1))
 			continue;
 		Datum	   *values = KERN_DATA_STORE_VALUES(dest, row);
 		cl_char	   *isnull = KERN_DATA_STORE_ISNULL(dest, row);
@@ -614,11 +602,10 @@ strom_gpupreagg_fetch(strom_gpupreagg *sess, kern_data_store *dest, size_t destl
 		{
 			int		resno = sess->agg_resno[a];
 			const strom_preagg_target &t = sess->targets[resno];
-			const cl_uint  *bits = (const cl_uint *)(host.data() + sess->table_offset(1 + 2 * (int)a, N));
-			const cl_ulong *vals = (const cl_ulong *)(host.data() + sess->table_offset(2 + 2 * (int)a, N));
+			const cl_ulong *vals = (const cl_ulong *)(host.data() + sess->table_offset(1 + (int)a, N));
 			if (t.kind == STROM_PREAGG_NROWS)
 				values[resno] = vals[g];
-			else if (!((bits[g >> 5] >> (g & 31)) & 1))
+			else if (!(gflags[g] & (2u << a)))
 				isnull[resno] = 1;
 			else
 			{

@@ -113,6 +113,53 @@ def gpupreagg(spec, kds_buf, ntargets, ext_params=(), row_map=None, max_groups=1
     return rc, out_v[:cnt.value].copy(), out_n[:cnt.value].astype(bool)
 
 
+def gpuhashjoin(spec, outer_buf, inner_bufs, ext_params=(), row_map=None, nrooms=None):
+    """returns (errcode, nitems, records int32 [n, 1+ninner]) with the inner side
+    identified by ROW INDEX in its inner chunk"""
+    lib = load()
+    lib.oracle_gpuhashjoin.restype = ctypes.c_int32
+    lib.oracle_gpuhashjoin.argtypes = [ctypes.c_char_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int,
+                                       ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int,
+                                       ctypes.c_void_p, ctypes.c_uint32, ctypes.POINTER(ctypes.c_uint32),
+                                       ctypes.c_char_p, ctypes.c_size_t]
+    vals, nulls, n = ext_arrays(ext_params)
+    rm = None
+    if row_map is not None:
+        rm = np.concatenate([np.array([len(row_map)], dtype=np.int32),
+                             np.ascontiguousarray(row_map, dtype=np.int32)])
+    ninner = len(inner_bufs)
+    ptrs = (ctypes.c_void_p * ninner)(*[b.ctypes.data for b in inner_bufs])
+    if nrooms is None:
+        nrooms = 1 << 22
+    results = np.zeros((nrooms, ninner + 1), dtype=np.int32)
+    cnt = ctypes.c_uint32(0)
+    err = ctypes.create_string_buffer(256)
+    rc = lib.oracle_gpuhashjoin(spec.encode(), vals.ctypes.data, nulls.ctypes.data, n,
+                                outer_buf.ctypes.data, rm.ctypes.data if rm is not None else None,
+                                ptrs, ninner, results.ctypes.data, nrooms, ctypes.byref(cnt), err, 256)
+    if rc == 101 and err.value:
+        raise ValueError("oracle: " + err.value.decode())
+    return rc, cnt.value, results[:min(cnt.value, nrooms)].copy()
+
+
+def check_hashtable(kmhash_buf, depth, inner_buf, key_attnos, key_lens):
+    lib = load()
+    lib.oracle_check_hashtable.restype = ctypes.c_long
+    lib.oracle_check_hashtable.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p,
+                                           ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
+    a = np.array(key_attnos, dtype=np.int32)
+    l = np.array(key_lens, dtype=np.int32)
+    return lib.oracle_check_hashtable(kmhash_buf.ctypes.data, depth, inner_buf.ctypes.data,
+                                      a.ctypes.data, l.ctypes.data, len(a))
+
+
+def pg_crc32(data):
+    lib = load()
+    lib.oracle_pg_crc32.restype = ctypes.c_uint32
+    lib.oracle_pg_crc32.argtypes = [ctypes.c_uint32, ctypes.c_char_p, ctypes.c_size_t]
+    return lib.oracle_pg_crc32(0xFFFFFFFF, data, len(data)) ^ 0xFFFFFFFF
+
+
 def layout():
     out = oracle_layout()
     load().oracle_get_layout(ctypes.byref(out))

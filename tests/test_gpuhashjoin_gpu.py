@@ -1,0 +1,161 @@
+"""
+GpuHashJoin parity, HIP path vs CPU oracle (needs an MI355X: -m gpu), through
+strom_hashjoin_table_create / strom_submit_gpuhashjoin.  Integer work: the
+set of (outer row, inner row per relation) records must be identical; the
+order of records is unspecified (as in the reference).
+"""
+import numpy as np
+import pytest
+
+import oracle_binding as oracle
+from pg_strom_amd import kds, runtime
+from pg_strom_amd.gpuhashjoin import GpuHashJoin, build_multihash, entry_rowids, STROM_RESULTS_ON_DEVICE
+
+pytestmark = pytest.mark.gpu
+
+C3_SPEC = "(gpuhashjoin (rel (hashkey (var 1 int4) 1 int4)))"
+
+
+def run_and_compare(spec, outer, inners, keys, ext=(), row_map=None, expect_mode=None, ratio=1.0):
+    rc, n, want = oracle.gpuhashjoin(spec, outer, inners, ext, row_map=row_map)
+    assert rc == 0
+    km = build_multihash(list(zip(inners, keys)))
+    join = GpuHashJoin(spec, row_population_ratio=ratio).begin(km, ext_params=ext)
+    try:
+        if expect_mode:
+            assert join.table_info(1)["mode"] == expect_mode
+        res = join.join_chunk(outer, row_map=row_map)
+        dkm = join.device_kmhash()
+        info = [join.table_info(d + 1) for d in range(len(inners))]
+    finally:
+        join.end()
+    assert res.errcode == 0 and res.nitems == n
+    got = np.empty_like(res.records)
+    got[:, 0] = res.records[:, 0]
+    for d in range(len(inners)):
+        got[:, d + 1] = entry_rowids(dkm, d + 1, res.records[:, d + 1])
+    a = got[np.lexsort(got.T[::-1])]
+    b = want[np.lexsort(want.T[::-1])]
+    assert np.array_equal(a, b)
+    return res, info
+
+
+def fact_dim(nfact, ndim, seed, dup=False, nulls=0.02, key_span=None):
+    rng = np.random.default_rng(seed)
+    span = key_span or int(ndim * 1.25)
+    pk = rng.permutation(span)[:ndim].astype(np.int32)
+    if dup:
+        pk[ndim // 3:2 * (ndim // 3)] = pk[:ndim // 3]
+    payload = rng.integers(0, 1000, ndim).astype(np.int32)
+    pkn = (rng.random(ndim) < nulls) if nulls else None
+    fk = rng.integers(0, span, nfact).astype(np.int32)
+    fkn = (rng.random(nfact) < nulls) if nulls else None
+    return pk, payload, pkn, fk, fkn
+
+
+@pytest.mark.parametrize("ofmt", ["column", "row", "row_flat", "tupslot"])
+@pytest.mark.parametrize("dup", [False, True])
+def test_single_key_all_outer_formats(ofmt, dup):
+    pk, payload, pkn, fk, fkn = fact_dim(30011, 2000, 5, dup=dup)
+    inner = kds.build_kds("row", [kds.Column("int4", pk, pkn), kds.Column("int4", payload)])
+    outer = kds.build_kds(ofmt, [kds.Column("int4", fk, fkn), kds.Column("float8", np.zeros(len(fk)))])
+    res, info = run_and_compare(C3_SPEC, outer, [inner], [[1]], expect_mode="direct",
+                                ratio=2.0 if dup else 1.0)
+    assert info[0]["unique"] == (not dup)
+
+
+def test_sparse_keys_use_the_hashed_index():
+    rng = np.random.default_rng(11)
+    pk = rng.integers(-2**31, 2**31, 3000, dtype=np.int64).astype(np.int32)
+    fk = np.concatenate([pk[rng.integers(0, 3000, 20000)],
+                         rng.integers(-2**31, 2**31, 20000, dtype=np.int64).astype(np.int32)])
+    inner = kds.build_kds("row_flat", [kds.Column("int4", pk), kds.Column("int4", np.arange(3000, dtype=np.int32))])
+    for ofmt in ("column", "row"):
+        outer = kds.build_kds(ofmt, [kds.Column("int4", fk)])
+        run_and_compare(C3_SPEC, outer, [inner], [[1]], expect_mode="hash", ratio=1.2)
+
+
+def test_result_overflow_is_retried_with_exact_room():
+    pk, payload, pkn, fk, fkn = fact_dim(20000, 50, 21, dup=True, nulls=0)
+    inner = kds.build_kds("row", [kds.Column("int4", pk), kds.Column("int4", payload)])
+    outer = kds.build_kds("column", [kds.Column("int4", fk)])
+    rc, n, want = oracle.gpuhashjoin(C3_SPEC, outer, [inner])
+    km = build_multihash([(inner, [1])])
+    join = GpuHashJoin(C3_SPEC).begin(km)
+    first = join.collect(join.submit(outer, nrooms=100))
+    assert first.errcode == 301 and first.nitems == n          # DataStoreNoSpace + room needed
+    res = join.join_chunk(outer, nrooms=100)
+    join.end()
+    assert res.errcode == 0 and res.nitems == n and getattr(res, "retried", False)
+
+
+def test_two_relations_multi_key_quals_and_row_map():
+    rng = np.random.default_rng(31)
+    n1, n2, nf = 3000, 500, 40000
+    a = rng.integers(0, 60, n1).astype(np.int32)
+    b = rng.integers(0, 5, n1).astype(np.int64)
+    c = rng.random(n1)
+    link = rng.integers(0, 700, n1).astype(np.int32)
+    t1 = kds.build_kds("row", [kds.Column("int4", a), kds.Column("int8", b), kds.Column("float8", c),
+                               kds.Column("int4", link, rng.random(n1) < 0.05)])
+    pk2 = rng.permutation(700)[:n2].astype(np.int32)
+    t2 = kds.build_kds("row_flat", [kds.Column("int4", pk2), kds.Column("int2", rng.integers(0, 9, n2).astype(np.int16))])
+    fa = rng.integers(0, 70, nf).astype(np.int32)
+    fb = rng.integers(0, 6, nf).astype(np.int16)
+    fc = rng.random(nf)
+    spec = ("(gpuhashjoin (rel (hashkey (var 1 int4) 1 int4) (hashkey (int8 (var 2 int2)) 2 int8)"
+            " (qual (float8gt (ivar 1 3 float8) (var 3 float8))))"
+            " (rel (hashkey (ivar 1 4 int4) 1 int4) (qual (int2lt (ivar 2 2 int2) (param 0 int2)))))")
+    for ofmt in ("column", "row"):
+        outer = kds.build_kds(ofmt, [kds.Column("int4", fa, rng.random(nf) < 0.02), kds.Column("int2", fb),
+                                     kds.Column("float8", fc)])
+        run_and_compare(spec, outer, [t1, t2], [[1, 2], [1]], ext=[np.int16(6)], ratio=30.0)
+        rmap = rng.permutation(nf)[:7000].astype(np.int32)
+        run_and_compare(spec, outer, [t1, t2], [[1, 2], [1]], ext=[np.int16(6)], row_map=rmap, ratio=30.0)
+
+
+def test_float_and_int8_keys():
+    rng = np.random.default_rng(41)
+    k = np.round(rng.random(800) * 50, 1)
+    k[5] = np.nan
+    k[6] = -0.0
+    inner = kds.build_kds("row", [kds.Column("float8", k), kds.Column("int4", np.arange(800, dtype=np.int32))])
+    f = np.round(rng.random(20000) * 50, 1)
+    f[::97] = np.nan
+    f[::89] = 0.0
+    outer = kds.build_kds("column", [kds.Column("float8", f)])
+    run_and_compare("(gpuhashjoin (rel (hashkey (var 1 float8) 1 float8)))", outer, [inner], [[1]],
+                    expect_mode="hash", ratio=30.0)
+    big = rng.integers(-2**62, 2**62, 1000)
+    inner = kds.build_kds("row", [kds.Column("int8", big)])
+    outer = kds.build_kds("row_flat", [kds.Column("int8", np.concatenate([big[::3], big[::7] + 1]))])
+    run_and_compare("(gpuhashjoin (rel (hashkey (var 1 int8) 1 int8)))", outer, [inner], [[1]], expect_mode="hash")
+
+
+def test_c3_shape_properties_at_1e8():
+    """BASELINE configs[2] shape: 1e8 fact x 1e6 dim on int4, 80% hit.
+    Properties instead of the tuple-at-a-time oracle: every record's keys are
+    equal, outer rows are unique (dim keys are unique) and the count equals an
+    independent numpy membership count."""
+    nf, nd = 100_000_000, 1_000_000
+    rng = np.random.default_rng(2025)
+    pk = rng.permutation(nd).astype(np.int32)
+    payload = rng.integers(0, 2**31, nd, dtype=np.int64).astype(np.int32)
+    inner = kds.build_kds("row_flat", [kds.Column("int4", pk), kds.Column("int4", payload)])
+    km = build_multihash([(inner, [1])])
+    fk = rng.integers(0, int(nd * 1.25), nf, dtype=np.int64).astype(np.int32)
+    outer = runtime.DeviceStore.upload(kds.build_kds("column", [kds.Column("int4", fk)]))
+    join = GpuHashJoin(C3_SPEC).begin(km)
+    info = join.table_info(1)
+    assert info["mode"] == "direct" and info["unique"] and info["nentries"] == nd
+    res = join.join_chunk(outer)
+    dkm = join.device_kmhash()
+    join.end()
+    outer.release()
+    assert res.errcode == 0
+    assert res.nitems == int(np.count_nonzero(fk < nd))
+    orow = res.records[:, 0].astype(np.int64) - 1
+    irow = entry_rowids(dkm, 1, res.records[:, 1])
+    assert np.array_equal(fk[orow], pk[irow])
+    srt = np.sort(orow)
+    assert np.all(np.diff(srt) > 0)

@@ -158,7 +158,10 @@ def compare_with_oracle(spec, bufs, domain, ext=(), float_tol=1e-12):
                 want = sum(vals) if not isfloat else float(np.sum(np.array(vals)))
                 if isfloat:
                     tol = 2e-3 if oid == 700 else float_tol
-                    assert abs(g - want) <= tol * max(abs(want), 1e-300), (key, t, g, want)
+                    if np.isnan(want):
+                        assert np.isnan(g), (key, t, g, want)
+                    else:
+                        assert abs(g - want) <= tol * max(abs(want), 1e-300), (key, t, g, want)
                 else:
                     assert int(g) == int(want)
             else:
