@@ -76,7 +76,7 @@ int		strom_codegen_gpuscan(const char *qual, strom_codegen_result *out);
  *   (gpupreagg [(qual BOOL-EXPR)] TARGET ...)
  *   TARGET := (key EXPR)                     grouping key (a Var in the reference)
  *           | (nrows BOOL-EXPR ...)          1 when every argument is TRUE, else 0
- *           | (psum EXPR) | (pmin EXPR) | (pmax EXPR)
+ *           | (psum EXPR) | (pmin EXPR) | (pmax EXPR)   numeric: (psum EXPR SCALE)
  *           | (psum_x2 EXPR)                 EXPR*EXPR as float8
  *           | (pcov_x F X Y) (pcov_y ..) (pcov_x2 ..) (pcov_y2 ..) (pcov_xy ..)
  *
@@ -92,6 +92,8 @@ int		strom_codegen_gpuscan(const char *qual, strom_codegen_result *out);
 typedef struct {
 	int32_t		kind;			/* STROM_PREAGG_* (psum_x2 / pcov_* are PSUM) */
 	int32_t		type_oid;		/* type of the partial value */
+	int32_t		scale;			/* numeric partials: accumulated as fixed-point int8
+								 * at 10^-scale; -1 otherwise.  Written (psum EXPR SCALE) */
 } strom_preagg_target;
 
 int		strom_codegen_gpupreagg(const char *spec, strom_codegen_result *out,

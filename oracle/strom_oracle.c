@@ -147,7 +147,9 @@ enum {
 	OP_SHL, OP_SHR, OP_CAST,
 	OP_CEIL, OP_FLOOR, OP_ROUND, OP_TRUNC, OP_SIGN, OP_SQRT, OP_PI,
 	OP_DATE_PLI, OP_DATE_MII, OP_DATE_MI, OP_INT_PL_DATE,
-	OP_DATE_TO_TS, OP_TS_TO_DATE, OP_TS_TO_TIME, OP_DATETIME_PL, OP_TIMEDATE_PL
+	OP_DATE_TO_TS, OP_TS_TO_DATE, OP_TS_TO_TIME, OP_DATETIME_PL, OP_TIMEDATE_PL,
+	OP_NUM_ADD, OP_NUM_SUB, OP_NUM_MUL, OP_NUM_UMINUS, OP_NUM_UPLUS, OP_NUM_ABS,
+	OP_NUM_FROM_INT, OP_NUM_TO_INT, OP_NUM_TO_FLOAT
 };
 enum { BT_TRUE, BT_NOT_TRUE, BT_FALSE, BT_NOT_FALSE, BT_UNKNOWN, BT_NOT_UNKNOWN };
 
@@ -255,6 +257,150 @@ oracle_date2j(int y, int m, int d)
 }
 #define POSTGRES_EPOCH_JDATE 2451545
 
+
+/* ---------------------------------------------------------------------- *
+ * 64-bit NUMERIC (opencl_numeric.h:122-162): exponent 63..58 (signed, base
+ * 10), sign 57, mantissa 56..0.  The operations below restate
+ * opencl_numeric.h:816-1234 with its overflow rules: an intermediate that
+ * leaves 64 bits, a mantissa beyond 57 bits or an exponent outside
+ * [-32, 31] is a CpuReCheck.
+ * ---------------------------------------------------------------------- */
+#define NUM_EXPO(u)		((int)((int64_t)(u) >> 58))
+#define NUM_SIGN(u)		((int)(((u) >> 57) & 1))
+#define NUM_MANT(u)		((u) & ((1ULL << 57) - 1))
+
+static int
+num_pack(int expo, int sign, uint64_t mant, uint64_t *out)
+{
+	if (mant == 0) { *out = 0; return 1; }
+	while (mant % 10 == 0 && expo < 31) { mant /= 10; expo++; }
+	while (expo > 31)
+	{
+		if (mant > ((1ULL << 57) - 1) / 10) return 0;
+		mant *= 10; expo--;
+	}
+	if (expo < -32 || mant >= (1ULL << 57)) return 0;
+	*out = ((uint64_t)((int64_t)expo << 58)) | ((uint64_t)(sign != 0) << 57) | mant;
+	return 1;
+}
+
+static uint64_t
+num_pow10(int n)
+{
+	uint64_t m = 1;
+	int i;
+	if (n < 0 || n > 19) return 0;
+	for (i = 0; i < n; i++) m *= 10;
+	return m;
+}
+
+int
+oracle_numeric_from_text(const char *lit, uint64_t *out)
+{
+	const char *p = lit;
+	int		neg = 0, expo = 0, seen = 0, dot = 0;
+	unsigned __int128 mant = 0;
+
+	if (*p == '+' || *p == '-') neg = (*p++ == '-');
+	for (; *p; p++)
+	{
+		if (*p >= '0' && *p <= '9')
+		{
+			mant = mant * 10 + (unsigned)(*p - '0');
+			if (mant >> 100) return 0;
+			if (dot) expo--;
+			seen = 1;
+		}
+		else if (*p == '.' && !dot) dot = 1;
+		else break;
+	}
+	if (!seen) return 0;
+	if (*p == 'e' || *p == 'E')
+	{
+		char *end;
+		long e = strtol(p + 1, &end, 10);
+		if (end == p + 1 || *end) return 0;
+		expo += (int)e;
+	}
+	else if (*p) return 0;
+	if (mant == 0) { *out = 0; return 1; }
+	while (mant % 10 == 0) { mant /= 10; expo++; }
+	while (expo > 31 && mant < ((unsigned __int128)1 << 57) / 10) { mant *= 10; expo--; }
+	if (mant >= ((unsigned __int128)1 << 57) || expo < -32 || expo > 31) return 0;
+	*out = ((uint64_t)((int64_t)expo << 58)) | ((uint64_t)neg << 57) | (uint64_t)mant;
+	return 1;
+}
+
+static int
+num_add(uint64_t a, uint64_t b, uint64_t *out)
+{
+	int			e1 = NUM_EXPO(a), e2 = NUM_EXPO(b), s1 = NUM_SIGN(a), s2 = NUM_SIGN(b);
+	uint64_t	m1 = NUM_MANT(a), m2 = NUM_MANT(b);
+
+	if (m1 == 0) { *out = b; return 1; }
+	if (m2 == 0) { *out = a; return 1; }
+	if (e1 != e2)
+	{
+		int diff = e1 > e2 ? e1 - e2 : e2 - e1;
+		uint64_t mag = num_pow10(diff);
+		uint64_t *big = e1 > e2 ? &m1 : &m2;
+		if (mag == 0 || __builtin_mul_overflow(*big, mag, big)) return 0;
+		e1 = e2 = (e1 < e2 ? e1 : e2);
+	}
+	if (s1 != s2)
+	{
+		if (m1 < m2) { s1 = s2; m1 = m2 - m1; }
+		else m1 -= m2;
+	}
+	else if (__builtin_add_overflow(m1, m2, &m1)) return 0;
+	return num_pack(e1, s1, m1, out);
+}
+
+static int
+num_mul(uint64_t a, uint64_t b, uint64_t *out)
+{
+	uint64_t m1 = NUM_MANT(a), m2 = NUM_MANT(b), prod;
+	if (m1 == 0 || m2 == 0) { *out = 0; return 1; }
+	if (__builtin_mul_overflow(m1, m2, &prod)) return 0;
+	return num_pack(NUM_EXPO(a) + NUM_EXPO(b), NUM_SIGN(a) != NUM_SIGN(b), prod, out);
+}
+
+static int
+num_cmp(uint64_t a, uint64_t b)
+{
+	int			e1 = NUM_EXPO(a), e2 = NUM_EXPO(b), s1 = NUM_SIGN(a), s2 = NUM_SIGN(b), ret;
+	uint64_t	m1 = NUM_MANT(a), m2 = NUM_MANT(b);
+	/* exact: compare sign * mant * 10^expo with 128-bit headroom where it fits */
+	if (m1 == 0 && m2 == 0) return 0;
+	if (m1 == 0) return s2 ? 1 : -1;
+	if (m2 == 0) return s1 ? -1 : 1;
+	if (s1 != s2) return s1 ? -1 : 1;
+	if (e1 == e2) ret = m1 < m2 ? -1 : m1 > m2 ? 1 : 0;
+	else
+	{
+		int first_big = e1 > e2, diff = first_big ? e1 - e2 : e2 - e1, c;
+		uint64_t mag = num_pow10(diff), big = first_big ? m1 : m2, small = first_big ? m2 : m1, scaled;
+		if (mag == 0 || __builtin_mul_overflow(big, mag, &scaled)) c = 1;
+		else c = scaled < small ? -1 : scaled > small ? 1 : 0;
+		ret = first_big ? c : -c;
+	}
+	return s1 ? -ret : ret;
+}
+
+/* numeric -> fixed point int64 at 10^-scale, exact or fail */
+static int
+num_to_fixed(uint64_t a, int scale, int64_t *out)
+{
+	int			shift = NUM_EXPO(a) + scale;
+	uint64_t	mant = NUM_MANT(a), mag = num_pow10(shift);
+	if (mant == 0) { *out = 0; return 1; }
+	if (shift < 0 || mag == 0 || __builtin_mul_overflow(mant, mag, &mant) ||
+		mant > 9223372036854775807ULL)
+		return 0;
+	*out = NUM_SIGN(a) ? -(int64_t)mant : (int64_t)mant;
+	return 1;
+}
+
 static int
 parse_literal(parser *ps, int type, const char *lit, oracle_value *out)
 {
@@ -311,6 +457,10 @@ parse_literal(parser *ps, int type, const char *lit, oracle_value *out)
 				}
 				return 1;
 			}
+		case STROM_NUMERICOID:
+			if (!oracle_numeric_from_text(lit, &out->v.u))
+			{ perr(ps, "numeric literal %s does not fit the 64-bit device form", lit); return 0; }
+			return 1;
 		case STROM_BPCHAROID:
 			if (strlen(lit) != 1) { perr(ps, "char1 literal must be one byte"); return 0; }
 			out->v.i = (signed char)lit[0];
@@ -437,6 +587,30 @@ resolve_func(oracle_expr *e, const char *name)
 			return 1;
 		}
 	}
+	/* numeric */
+	if (nargs == 2 && a0 == STROM_NUMERICOID && a1 == STROM_NUMERICOID && !strncmp(name, "numeric_", 8))
+	{
+		const char *sfx = name + 8;
+		if (!strcmp(sfx, "add")) { e->op = OP_NUM_ADD; e->type_oid = STROM_NUMERICOID; return 1; }
+		if (!strcmp(sfx, "sub")) { e->op = OP_NUM_SUB; e->type_oid = STROM_NUMERICOID; return 1; }
+		if (!strcmp(sfx, "mul")) { e->op = OP_NUM_MUL; e->type_oid = STROM_NUMERICOID; return 1; }
+		if (!strcmp(sfx, "cmp")) { e->op = OP_CMP; e->type_oid = STROM_INT4OID; return 1; }
+		op = binop_by_suffix(sfx);
+		if (op >= OP_EQ && op <= OP_GE) { e->op = op; e->type_oid = STROM_BOOLOID; return 1; }
+	}
+	if (nargs == 1 && a0 == STROM_NUMERICOID)
+	{
+		if (!strcmp(name, "numeric_uminus")) { e->op = OP_NUM_UMINUS; e->type_oid = a0; return 1; }
+		if (!strcmp(name, "numeric_uplus"))  { e->op = OP_NUM_UPLUS;  e->type_oid = a0; return 1; }
+		if (!strcmp(name, "numeric_abs") || !strcmp(name, "abs")) { e->op = OP_NUM_ABS; e->type_oid = a0; return 1; }
+		if (!strcmp(name, "int2")) { e->op = OP_NUM_TO_INT; e->type_oid = STROM_INT2OID; return 1; }
+		if (!strcmp(name, "int4")) { e->op = OP_NUM_TO_INT; e->type_oid = STROM_INT4OID; return 1; }
+		if (!strcmp(name, "int8")) { e->op = OP_NUM_TO_INT; e->type_oid = STROM_INT8OID; return 1; }
+		if (!strcmp(name, "float4")) { e->op = OP_NUM_TO_FLOAT; e->type_oid = STROM_FLOAT4OID; return 1; }
+		if (!strcmp(name, "float8")) { e->op = OP_NUM_TO_FLOAT; e->type_oid = STROM_FLOAT8OID; return 1; }
+	}
+	if (nargs == 1 && !strcmp(name, "numeric") && type_is_int(a0))
+	{ e->op = OP_NUM_FROM_INT; e->type_oid = STROM_NUMERICOID; return 1; }
 	/* bt<family>cmp */
 	if (strncmp(name, "bt", 2) == 0 && nargs == 2)
 	{
@@ -919,7 +1093,9 @@ eval_func(const oracle_expr *e, oracle_value *a, int32_t *errcode)
 			{
 				int c;
 				int t0 = a[0].type_oid, t1 = a[1].type_oid;
-				if (type_is_float(t0) || type_is_float(t1))
+				if (t0 == STROM_NUMERICOID)
+					c = num_cmp(a[0].v.u, a[1].v.u);
+				else if (type_is_float(t0) || type_is_float(t1))
 					c = float_cmp(as_double(a[0]), as_double(a[1]));
 				else if ((t0 == STROM_DATEOID && t1 == STROM_TIMESTAMPOID) ||
 						 (t0 == STROM_TIMESTAMPOID && t1 == STROM_DATEOID))
@@ -1069,6 +1245,74 @@ eval_func(const oracle_expr *e, oracle_value *a, int32_t *errcode)
 				int64_t t = a[0].v.i % 86400000000LL;
 				if (t < 0) t += 86400000000LL;
 				r.v.i = t;
+				return r;
+			}
+		case OP_NUM_ADD: case OP_NUM_SUB:
+			{
+				uint64_t b = a[1].v.u;
+				if (e->op == OP_NUM_SUB && NUM_MANT(b) != 0) b ^= (1ULL << 57);
+				if (!num_add(a[0].v.u, b, &r.v.u)) return recheck(rt, errcode);
+				return r;
+			}
+		case OP_NUM_MUL:
+			if (!num_mul(a[0].v.u, a[1].v.u, &r.v.u)) return recheck(rt, errcode);
+			return r;
+		case OP_NUM_UPLUS:
+			r.v.u = a[0].v.u;
+			return r;
+		case OP_NUM_UMINUS:
+			r.v.u = a[0].v.u;
+			if (NUM_MANT(r.v.u) != 0) r.v.u ^= (1ULL << 57);
+			return r;
+		case OP_NUM_ABS:
+			r.v.u = a[0].v.u & ~(1ULL << 57);
+			return r;
+		case OP_NUM_FROM_INT:
+			{
+				int64_t v = a[0].v.i;
+				uint64_t mant = v < 0 ? (uint64_t)0 - (uint64_t)v : (uint64_t)v;
+				if (!num_pack(0, v < 0, mant, &r.v.u)) return recheck(rt, errcode);
+				return r;
+			}
+		case OP_NUM_TO_INT:
+			{
+				/* round half away from zero, then range check
+				 * (numeric_to_integer, opencl_numeric.h:400-460) */
+				uint64_t u = a[0].v.u, mant = NUM_MANT(u);
+				int expo = NUM_EXPO(u);
+				__int128 lo, hi, val;
+				int_range(rt, &lo, &hi);
+				if (expo < 0)
+				{
+					uint64_t mag = num_pow10(-expo);
+					mant = mag ? (mant + mag / 2) / mag : 0;
+				}
+				else if (expo > 0)
+				{
+					uint64_t mag = num_pow10(expo);
+					if (mag == 0 || __builtin_mul_overflow(mant, mag, &mant)) return recheck(rt, errcode);
+				}
+				val = NUM_SIGN(u) ? -(__int128)mant : (__int128)mant;
+				if (val < lo || val > hi) return recheck(rt, errcode);
+				r.v.i = (int64_t)val;
+				return r;
+			}
+		case OP_NUM_TO_FLOAT:
+			{
+				uint64_t u = a[0].v.u;
+				int expo = NUM_EXPO(u), k;
+				double m = (double)NUM_MANT(u), p = 1.0, d;
+				for (k = 0; k < (expo < 0 ? -expo : expo); k++) p *= 10.0;
+				d = expo < 0 ? m / p : m * p;
+				if (NUM_SIGN(u)) d = -d;
+				if (rt == STROM_FLOAT4OID)
+				{
+					float f = (float)d;
+					if (float_bad(f, 0, d == 0.0)) return recheck(rt, errcode);
+					r.v.f = f;
+				}
+				else
+					r.v.d = d;
 				return r;
 			}
 		case OP_DATETIME_PL: case OP_TIMEDATE_PL:
@@ -1299,6 +1543,7 @@ typedef struct {
 	oracle_expr *exprs[4];
 	int			pcov;			/* 0 none, 1 x, 2 y, 3 x2, 4 y2, 5 xy */
 	int			x2;				/* psum_x2 */
+	int			numeric_scale;	/* >= 0: numeric partial kept as int8 at 10^-scale */
 } preagg_target;
 
 typedef struct {
@@ -1362,8 +1607,18 @@ preagg_spec_parse(const char *text, preagg_spec *sp, char *errbuf, size_t errlen
 			if (t->pcov < 0) { perr(&ps, "unknown target %s", head); break; }
 		}
 		else { perr(&ps, "unknown target %s", head); break; }
+		t->numeric_scale = -1;
 		while (!peek_close(&ps) && !ps.failed && t->nexprs < 4)
 		{
+			skip_ws(&ps);
+			if (*ps.p != '(')
+			{
+				/* trailing atom: the scale of a numeric partial */
+				char sb[16];
+				if (!read_atom(&ps, sb, sizeof(sb))) { perr(&ps, "scale expected"); break; }
+				t->numeric_scale = atoi(sb);
+				continue;
+			}
 			t->exprs[t->nexprs] = parse_expr(&ps);
 			if (!t->exprs[t->nexprs])
 				break;
@@ -1375,6 +1630,14 @@ preagg_spec_parse(const char *text, preagg_spec *sp, char *errbuf, size_t errlen
 		else if (t->x2 || t->pcov) t->type_oid = STROM_FLOAT8OID;
 		else if (t->nexprs == 1) t->type_oid = t->exprs[0]->type_oid;
 		else { perr(&ps, "%s takes one argument", head); break; }
+		if (t->type_oid == STROM_NUMERICOID && t->kind != T_KEY)
+		{
+			if (t->numeric_scale < 0 || t->numeric_scale > 32)
+			{ perr(&ps, "numeric partial needs a scale: (%s EXPR SCALE)", head); break; }
+			t->type_oid = STROM_INT8OID;	/* accumulated as fixed point */
+		}
+		else
+			t->numeric_scale = -1;
 		if (t->pcov && t->nexprs != 3) { perr(&ps, "pcov takes (filter x y)"); break; }
 	}
 	if (!ps.failed)
@@ -1488,6 +1751,18 @@ oracle_gpupreagg(const char *spec_text,
 			else
 			{
 				r = oracle_expr_eval(tg->exprs[0], kds, row, ext_values, ext_isnull, n_ext, &errcode);
+				if (tg->numeric_scale >= 0)
+				{
+					/* strom_numeric_to_fixed: exact or CpuReCheck */
+					int64_t fx = 0;
+					if (!r.isnull && !num_to_fixed(r.v.u, tg->numeric_scale, &fx))
+					{
+						set_error(&errcode, StromError_CpuReCheck);
+						r.isnull = 1;
+					}
+					r.type_oid = STROM_INT8OID;
+					r.v.i = fx;
+				}
 				if (tg->x2 && !r.isnull)
 				{
 					double x = r.v.d, p = x * x;
@@ -1988,4 +2263,39 @@ oracle_check_hashtable(const kern_multihash *kmhash, int depth,
 		{ free(seen); return -7; }
 	free(seen);
 	return count;
+}
+
+/*
+ * Evaluate one expression on every row: raw 8-byte value image, isnull and
+ * the row's errcode (0 or CpuReCheck).  Lets tests look at scalar results
+ * the device only ever consumes inside quals and aggregates.
+ */
+int32_t
+oracle_eval_rows(const char *expr_text,
+				 const uint64_t *ext_values, const uint8_t *ext_isnull, int n_ext,
+				 const kern_data_store *kds,
+				 uint64_t *out_values, uint8_t *out_isnull, int32_t *out_errcode,
+				 int32_t *p_type_oid, char *errbuf, size_t errlen)
+{
+	oracle_expr *expr = oracle_expr_parse(expr_text, errbuf, errlen);
+	uint32_t	i;
+
+	if (!expr)
+		return StromError_BadRequestMessage;
+	*p_type_oid = expr->type_oid;
+	for (i = 0; i < kds->nitems; i++)
+	{
+		int32_t		errcode = StromError_Success;
+		oracle_value v = oracle_expr_eval(expr, kds, i, ext_values, ext_isnull, n_ext, &errcode);
+		out_isnull[i] = (uint8_t)v.isnull;
+		out_errcode[i] = errcode;
+		out_values[i] = 0;
+		if (!v.isnull)
+		{
+			if (v.type_oid == STROM_FLOAT4OID) memcpy(&out_values[i], &v.v.f, 4);
+			else out_values[i] = v.v.u;
+		}
+	}
+	oracle_expr_free(expr);
+	return StromError_Success;
 }

@@ -101,6 +101,13 @@ long		oracle_check_hashtable(const kern_multihash *kmhash, int depth,
 								   const kern_data_store *inner,
 								   const int *key_attnos, const int *key_lens, int nkeys);
 
+int32_t		oracle_eval_rows(const char *expr,
+							 const uint64_t *ext_values, const uint8_t *ext_isnull, int n_ext,
+							 const kern_data_store *kds,
+							 uint64_t *out_values, uint8_t *out_isnull, int32_t *out_errcode,
+							 int32_t *p_type_oid, char *errbuf, size_t errlen);
+int			oracle_numeric_from_text(const char *lit, uint64_t *out);
+
 /* sizes / offsets of the wire structs, for the layout tests */
 typedef struct {
 	uint32_t	sizeof_kern_data_store_head;

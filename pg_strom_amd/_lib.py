@@ -77,7 +77,7 @@ class strom_codegen_result(ctypes.Structure):
 
 
 class strom_preagg_target(ctypes.Structure):
-    _fields_ = [("kind", c_int32), ("type_oid", c_int32)]
+    _fields_ = [("kind", c_int32), ("type_oid", c_int32), ("scale", c_int32)]
 
 
 class strom_preagg_domain(ctypes.Structure):

@@ -23,11 +23,23 @@ INT_TYPES = ("int2", "int4", "int8")
 FLOAT_TYPES = ("float4", "float8")
 
 
-def rewrite(func, coltype, var):
+def rewrite(func, coltype, var, scale=None):
     """(targets, final) for aggregate `func` over expression text `var` of
     SQL type `coltype`; None when the reference's catalog has no entry
-    (the aggregate then stays on the CPU)."""
+    (the aggregate then stays on the CPU).  numeric needs `scale`, the
+    number of fractional digits partial sums are kept with."""
     notnull = "(isnotnull %s)" % var
+    if coltype == "numeric" and func != "count":
+        if func == "avg":
+            return ["(nrows %s)" % notnull, "(psum %s %d)" % (var, scale)], "avg_numeric"
+        if func == "sum":
+            return ["(psum %s %d)" % (var, scale)], "sum_numeric"
+        if func in ("min", "max"):
+            return ["(p%s %s %d)" % (func, var, scale)], func + "_numeric"
+        if func in ("stddev", "stddev_samp", "stddev_pop", "variance", "var_samp", "var_pop"):
+            return ["(nrows %s)" % notnull, "(psum %s %d)" % (var, scale),
+                    "(psum (numeric_mul %s %s) %d)" % (var, var, 2 * scale)], func + "_numeric"
+        return None
     if func == "count":
         return (["(nrows %s)" % notnull] if var else ["(nrows)"]), "count"
     if coltype in INT_TYPES:
@@ -102,6 +114,8 @@ def finalize(final, cols):
 
     if final == "count":
         return int(np.sum(cols[0][0].astype(object))) if len(cols[0][0]) else 0
+    if final.endswith("_numeric"):
+        return _finalize_numeric(final[:-8], cols)
     if final == "sum_int8":
         return sum_nonnull(cols[0])
     if final in ("sum_float8", "sum_float4"):
@@ -141,3 +155,36 @@ def finalize(final, cols):
         return 0.0
     var = numer / (n * (n - 1.0)) if samp else numer / (n * float(n))
     return math.sqrt(var) if final.startswith("stddev") else var
+
+
+def _finalize_numeric(final, cols):
+    """numeric aggregates: cols hold python Decimals (object arrays)"""
+    def nonnull(c):
+        v, n = c
+        return [x for x, isn in zip(v, n) if not isn]
+    if final in ("sum", "min", "max"):
+        v = nonnull(cols[0])
+        if not v:
+            return None
+        return sum(v, Decimal(0)) if final == "sum" else (min(v) if final == "min" else max(v))
+    n = int(np.sum(cols[0][0].astype(object))) if len(cols[0][0]) else 0
+    sx = nonnull(cols[1])
+    if n == 0 or not sx:
+        return None
+    sx = sum(sx, Decimal(0))
+    if final == "avg":
+        return numeric_div(sx, Decimal(n))
+    sxx = sum(nonnull(cols[2]), Decimal(0))
+    samp = final in ("stddev", "stddev_samp", "variance", "var_samp")
+    if samp and n <= 1:
+        return None
+    # numeric_stddev_internal (numeric.c): N*sumX2 - sumX^2 over N*(N-1) or N*N
+    numer = n * sxx - sx * sx
+    if numer <= 0:
+        return Decimal(0)
+    denom = Decimal(n) * (n - 1 if samp else n)
+    var = numeric_div(numer, denom)
+    if final.startswith("stddev"):
+        rscale = max(-var.as_tuple().exponent, 0)
+        return var.sqrt().quantize(Decimal(1).scaleb(-max(rscale, 16)))
+    return var

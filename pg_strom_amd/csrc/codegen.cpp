@@ -225,8 +225,7 @@ build_catalog(void)
 	add_func("numeric", {I2}, NU, "int2_numeric", N);
 	add_func("numeric", {I4}, NU, "int4_numeric", N);
 	add_func("numeric", {I8}, NU, "int8_numeric", N);
-	add_func("numeric", {F4}, NU, "float4_numeric", N);
-	add_func("numeric", {F8}, NU, "float8_numeric", N);
+	/* float -> numeric needs PostgreSQL's shortest-decimal conversion: stays on the CPU */
 	for (const char *op : {"add","sub","mul"})
 		add_func(std::string("numeric_") + op, {NU,NU}, NU, std::string("numeric_") + op, N);
 	add_func("numeric_uplus",  {NU}, NU, "numeric_uplus", N);
@@ -920,7 +919,8 @@ std::string
 codegen_includes(int extra_flags)
 {
 	std::string s = "#include \"strom_kds.h\"\n#include \"strom_common.h\"\n";
-	if (extra_flags & DEVFUNC_NEEDS_MATHLIB)	s += "#include \"strom_mathlib.h\"\n";
+	if (extra_flags & (DEVFUNC_NEEDS_MATHLIB | DEVFUNC_NEEDS_NUMERIC))
+		s += "#include \"strom_mathlib.h\"\n";
 	if (extra_flags & DEVFUNC_NEEDS_TIMELIB)	s += "#include \"strom_timelib.h\"\n";
 	if (extra_flags & DEVFUNC_NEEDS_NUMERIC)	s += "#include \"strom_numeric.h\"\n";
 	return s;

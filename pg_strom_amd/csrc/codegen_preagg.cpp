@@ -25,7 +25,9 @@ namespace {
 
 struct target {
 	int			kind;
-	int			type_oid;
+	int			type_oid;	/* type of the partial value as the caller sees it */
+	int			acc_oid;	/* type of the device accumulator */
+	int			scale;		/* numeric partials: fixed point at 10^-scale, else -1 */
 	std::string	body;		/* function body text */
 };
 
@@ -75,6 +77,8 @@ strom_codegen_gpupreagg(const char *spec, strom_codegen_result *out,
 				continue;
 			}
 			target tg;
+			tg.scale = -1;
+			tg.acc_oid = 0;
 			if (head == "key")
 			{
 				if (nargs != 1)
@@ -103,8 +107,8 @@ strom_codegen_gpupreagg(const char *spec, strom_codegen_result *out,
 			}
 			else if (head == "psum" || head == "pmin" || head == "pmax")
 			{
-				if (nargs != 1)
-					codegen_error("(%s EXPR) expected", head.c_str());
+				if (nargs != 1 && nargs != 2)
+					codegen_error("(%s EXPR [SCALE]) expected", head.c_str());
 				std::string e;
 				tg.kind = (head == "psum" ? STROM_PREAGG_PSUM :
 						   head == "pmin" ? STROM_PREAGG_PMIN : STROM_PREAGG_PMAX);
@@ -113,7 +117,31 @@ strom_codegen_gpupreagg(const char *spec, strom_codegen_result *out,
 					!(tg.type_oid == STROM_INT8OID || tg.type_oid == STROM_FLOAT8OID ||
 					  tg.type_oid == STROM_FLOAT4OID || tg.type_oid == STROM_NUMERICOID))
 					codegen_error("psum() takes int8, float4, float8 or numeric (cast the argument)");
-				tg.body = "  return " + e + ";\n";
+				if (tg.type_oid == STROM_NUMERICOID)
+				{
+					/*
+					 * numeric partials are folded as fixed-point int8 at
+					 * 10^-SCALE (integer LDS atomics; exact or CpuReCheck).
+					 * The reference adds 64-bit numerics pairwise in its
+					 * reduction tree and re-checks on overflow
+					 * (opencl_gpupreagg.h:933-948).
+					 */
+					if (nargs != 2 || t.items[2].is_list)
+						codegen_error("numeric partial needs a scale: (%s EXPR SCALE)", head.c_str());
+					tg.scale = atoi(t.items[2].atom.c_str());
+					if (tg.scale < 0 || tg.scale > 32)
+						codegen_error("numeric scale out of range");
+					tg.acc_oid = STROM_INT8OID;
+					char sb[16];
+					snprintf(sb, sizeof(sb), "%d", tg.scale);
+					tg.body = "  return strom_numeric_to_fixed(errcode, " + e + ", " + sb + ");\n";
+				}
+				else
+				{
+					if (nargs != 1)
+						codegen_error("only numeric partials take a scale");
+					tg.body = "  return " + e + ";\n";
+				}
 			}
 			else if (head == "psum_x2")
 			{
@@ -151,6 +179,8 @@ strom_codegen_gpupreagg(const char *spec, strom_codegen_result *out,
 				codegen_error("unknown GpuPreAgg target \"%s\"", head.c_str());
 			const devtype_info *dt = devtype_lookup(tg.type_oid);
 			ctx.extra_flags |= dt->type_flags;
+			if (tg.acc_oid == 0)
+				tg.acc_oid = tg.type_oid;
 			targets.push_back(tg);
 		}
 		if (targets.empty())
@@ -166,7 +196,7 @@ strom_codegen_gpupreagg(const char *spec, strom_codegen_result *out,
 		for (size_t i = 0; i < targets.size(); i++)
 		{
 			const target &tg = targets[i];
-			const char *tname = devtype_lookup(tg.type_oid)->dev_name;
+			const char *tname = devtype_lookup(tg.acc_oid)->dev_name;
 			if (tg.kind == STROM_PREAGG_KEY)
 			{
 				snprintf(tmp, sizeof(tmp), " X(%d,%zu,%s)", nkeys, i, tname);
@@ -186,6 +216,7 @@ strom_codegen_gpupreagg(const char *spec, strom_codegen_result *out,
 			}
 			targets_out[i].kind = tg.kind;
 			targets_out[i].type_oid = tg.type_oid;
+			targets_out[i].scale = tg.scale;
 		}
 		*p_ntargets = (int)targets.size();
 

@@ -330,6 +330,16 @@ STROM_INT_COMPARE_FAMILY(int8,  int8, int8)
 STROM_SIMPLE_BINARY(booleq, bool, bool, bool, (x != 0) == (y != 0))
 STROM_SIMPLE_BINARY(boolne, bool, bool, bool, (x != 0) != (y != 0))
 
+/* bpchar(1) carried by value: bytewise (unsigned) comparison, the role of
+ * opencl_textlib.h's bpchar* functions for one-byte keys */
+STROM_SIMPLE_BINARY(char1eq, bool, char1, char1, (cl_uchar)x == (cl_uchar)y)
+STROM_SIMPLE_BINARY(char1ne, bool, char1, char1, (cl_uchar)x != (cl_uchar)y)
+STROM_SIMPLE_BINARY(char1lt, bool, char1, char1, (cl_uchar)x <  (cl_uchar)y)
+STROM_SIMPLE_BINARY(char1le, bool, char1, char1, (cl_uchar)x <= (cl_uchar)y)
+STROM_SIMPLE_BINARY(char1gt, bool, char1, char1, (cl_uchar)x >  (cl_uchar)y)
+STROM_SIMPLE_BINARY(char1ge, bool, char1, char1, (cl_uchar)x >= (cl_uchar)y)
+STROM_SIMPLE_BINARY(char1cmp, int4, char1, char1, devfunc_int_comp((cl_uchar)x, (cl_uchar)y))
+
 /* float comparison through a 3-way compare that places NaN last */
 STROM_DEVICE int strom_float_cmp(double x, double y)
 {

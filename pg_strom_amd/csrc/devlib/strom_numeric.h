@@ -1,0 +1,400 @@
+/*
+ * strom_numeric.h -- 64-bit in-kernel NUMERIC (device)
+ *
+ * Role in the reference: opencl_numeric.h.  Same value format
+ * (122-162): bits 63..58 signed base-10 exponent, bit 57 sign, bits 56..0
+ * mantissa; value = (-1)^sign * mantissa * 10^exponent, kept normalised
+ * (no trailing decimal zero in the mantissa while the exponent can still
+ * grow; zero is all-zero).  Same contract: whatever does not fit -- an
+ * exponent outside [-32, 31], a mantissa beyond 57 bits, an intermediate
+ * product beyond 64 bits -- yields NULL + StromError_CpuReCheck and
+ * PostgreSQL's arbitrary-precision numeric finishes the row
+ * (casts 399-779, add/sub/mul 816-1027, compare 1035-1234).
+ *
+ * Not here yet: decoding PostgreSQL's varlena numeric from heap tuples
+ * (166-307; chunks carry the 8-byte form, the reference's
+ * "internal_format", datastore.c:355-363) and float -> numeric casts.
+ */
+#ifndef STROM_NUMERIC_DEVICE_H
+#define STROM_NUMERIC_DEVICE_H
+
+#define PG_NUMERIC_EXPONENT_MAX		31
+#define PG_NUMERIC_EXPONENT_MIN		(-32)
+#define PG_NUMERIC_SIGN_MASK		(1UL << 57)
+#define PG_NUMERIC_MANTISSA_MASK	((1UL << 57) - 1)
+#define PG_NUMERIC_EXPONENT(num)	((cl_int)((cl_long)(num) >> 58))
+#define PG_NUMERIC_SIGN(num)		(((num) & PG_NUMERIC_SIGN_MASK) != 0)
+#define PG_NUMERIC_MANTISSA(num)	((num) & PG_NUMERIC_MANTISSA_MASK)
+#define PG_NUMERIC_SET(expo,sign,mant)							\
+	((cl_ulong)((cl_long)(expo) << 58) |						\
+	 ((sign) ? PG_NUMERIC_SIGN_MASK : 0UL) |					\
+	 ((mant) & PG_NUMERIC_MANTISSA_MASK))
+
+STROM_DECLARE_SIMPLE_TYPE(numeric, cl_ulong)
+STROM_DECLARE_VARREF(numeric)
+
+STROM_DEVICE pg_numeric_t
+strom_numeric_recheck(cl_int *errcode)
+{
+	pg_numeric_t v;
+	v.isnull = true;
+	v.value = 0;
+	STROM_SET_ERROR(errcode, StromError_CpuReCheck);
+	return v;
+}
+
+/* 10^n for 0 <= n <= 19, 0 when it does not fit 64 bits */
+STROM_DEVICE cl_ulong
+strom_pow10_u64(int n)
+{
+	cl_ulong m = 1;
+	if (n < 0 || n > 19)
+		return 0;
+	for (int i = 0; i < n; i++)
+		m *= 10;
+	return m;
+}
+
+/* normalise and pack; anything out of range goes back to the CPU */
+STROM_DEVICE pg_numeric_t
+strom_numeric_pack(cl_int *errcode, int expo, bool sign, cl_ulong mant)
+{
+	pg_numeric_t v;
+
+	if (mant == 0)
+	{
+		v.isnull = false;
+		v.value = 0;
+		return v;
+	}
+	while (mant % 10 == 0 && expo < PG_NUMERIC_EXPONENT_MAX)
+	{
+		mant /= 10;
+		expo++;
+	}
+	/* an exponent above the field can be traded for mantissa digits */
+	while (expo > PG_NUMERIC_EXPONENT_MAX)
+	{
+		if (mant > PG_NUMERIC_MANTISSA_MASK / 10)
+			return strom_numeric_recheck(errcode);
+		mant *= 10;
+		expo--;
+	}
+	if (expo < PG_NUMERIC_EXPONENT_MIN || (mant & ~PG_NUMERIC_MANTISSA_MASK))
+		return strom_numeric_recheck(errcode);
+	v.isnull = false;
+	v.value = PG_NUMERIC_SET(expo, sign, mant);
+	return v;
+}
+
+STROM_DEVICE pg_numeric_t pgfn_numeric_uplus(cl_int *errcode, pg_numeric_t arg)
+{ return arg; }
+STROM_DEVICE pg_numeric_t pgfn_numeric_uminus(cl_int *errcode, pg_numeric_t arg)
+{
+	if (!arg.isnull && PG_NUMERIC_MANTISSA(arg.value) != 0)
+		arg.value ^= PG_NUMERIC_SIGN_MASK;
+	return arg;
+}
+STROM_DEVICE pg_numeric_t pgfn_numeric_abs(cl_int *errcode, pg_numeric_t arg)
+{
+	arg.value &= ~PG_NUMERIC_SIGN_MASK;
+	return arg;
+}
+
+STROM_DEVICE pg_numeric_t
+pgfn_numeric_add(cl_int *errcode, pg_numeric_t arg1, pg_numeric_t arg2)
+{
+	pg_numeric_t v;
+
+	if (arg1.isnull || arg2.isnull)
+	{
+		v.isnull = true;
+		v.value = 0;
+		return v;
+	}
+	int			expo1 = PG_NUMERIC_EXPONENT(arg1.value), expo2 = PG_NUMERIC_EXPONENT(arg2.value);
+	bool		sign1 = PG_NUMERIC_SIGN(arg1.value), sign2 = PG_NUMERIC_SIGN(arg2.value);
+	cl_ulong	mant1 = PG_NUMERIC_MANTISSA(arg1.value), mant2 = PG_NUMERIC_MANTISSA(arg2.value);
+
+	if (mant1 == 0)
+		return arg2;
+	if (mant2 == 0)
+		return arg1;
+	/* bring both to the smaller exponent */
+	if (expo1 != expo2)
+	{
+		int			diff = (expo1 > expo2 ? expo1 - expo2 : expo2 - expo1);
+		cl_ulong	mag = strom_pow10_u64(diff);
+		cl_ulong   *big = (expo1 > expo2 ? &mant1 : &mant2);
+
+		if (mag == 0 || __builtin_mul_overflow(*big, mag, big))
+			return strom_numeric_recheck(errcode);
+		expo1 = expo2 = (expo1 < expo2 ? expo1 : expo2);
+	}
+	if (sign1 != sign2)
+	{
+		if (mant1 < mant2)
+		{
+			sign1 = sign2;
+			mant1 = mant2 - mant1;
+		}
+		else
+			mant1 -= mant2;
+	}
+	else if (__builtin_add_overflow(mant1, mant2, &mant1))
+		return strom_numeric_recheck(errcode);
+	return strom_numeric_pack(errcode, expo1, sign1, mant1);
+}
+
+STROM_DEVICE pg_numeric_t
+pgfn_numeric_sub(cl_int *errcode, pg_numeric_t arg1, pg_numeric_t arg2)
+{
+	return pgfn_numeric_add(errcode, arg1, pgfn_numeric_uminus(errcode, arg2));
+}
+
+STROM_DEVICE pg_numeric_t
+pgfn_numeric_mul(cl_int *errcode, pg_numeric_t arg1, pg_numeric_t arg2)
+{
+	pg_numeric_t v;
+
+	if (arg1.isnull || arg2.isnull)
+	{
+		v.isnull = true;
+		v.value = 0;
+		return v;
+	}
+	cl_ulong	mant1 = PG_NUMERIC_MANTISSA(arg1.value), mant2 = PG_NUMERIC_MANTISSA(arg2.value);
+	cl_ulong	prod;
+
+	if (mant1 == 0 || mant2 == 0)
+	{
+		v.isnull = false;
+		v.value = 0;
+		return v;
+	}
+	if (__builtin_mul_overflow(mant1, mant2, &prod))
+		return strom_numeric_recheck(errcode);
+	return strom_numeric_pack(errcode,
+							  PG_NUMERIC_EXPONENT(arg1.value) + PG_NUMERIC_EXPONENT(arg2.value),
+							  PG_NUMERIC_SIGN(arg1.value) != PG_NUMERIC_SIGN(arg2.value), prod);
+}
+
+/* three-way compare of two non-NULL values */
+STROM_DEVICE int
+strom_numeric_cmp(pg_numeric_t arg1, pg_numeric_t arg2)
+{
+	int			expo1 = PG_NUMERIC_EXPONENT(arg1.value), expo2 = PG_NUMERIC_EXPONENT(arg2.value);
+	bool		sign1 = PG_NUMERIC_SIGN(arg1.value), sign2 = PG_NUMERIC_SIGN(arg2.value);
+	cl_ulong	mant1 = PG_NUMERIC_MANTISSA(arg1.value), mant2 = PG_NUMERIC_MANTISSA(arg2.value);
+	int			ret;
+
+	if (mant1 == 0 && mant2 == 0)
+		return 0;
+	if (mant1 == 0)
+		return sign2 ? 1 : -1;
+	if (mant2 == 0)
+		return sign1 ? -1 : 1;
+	if (sign1 != sign2)
+		return sign1 ? -1 : 1;
+	/* same sign: compare magnitudes at the smaller exponent */
+	if (expo1 == expo2)
+		ret = (mant1 < mant2 ? -1 : (mant1 > mant2 ? 1 : 0));
+	else
+	{
+		bool		first_big = (expo1 > expo2);
+		int			diff = (first_big ? expo1 - expo2 : expo2 - expo1);
+		cl_ulong	mag = strom_pow10_u64(diff);
+		cl_ulong	big = (first_big ? mant1 : mant2), small = (first_big ? mant2 : mant1);
+		cl_ulong	scaled;
+		int			c;		/* compare(big side, small side) */
+
+		if (mag == 0 || __builtin_mul_overflow(big, mag, &scaled))
+			c = 1;			/* does not even fit 64 bits: it is the larger */
+		else
+			c = (scaled < small ? -1 : (scaled > small ? 1 : 0));
+		ret = (first_big ? c : -c);
+	}
+	return sign1 ? -ret : ret;
+}
+
+#define STROM_NUMERIC_COMPARE(name,EXPR)										\
+	STROM_DEVICE pg_bool_t														\
+	pgfn_numeric_##name(cl_int *errcode, pg_numeric_t arg1, pg_numeric_t arg2)	\
+	{																			\
+		pg_bool_t r;															\
+		r.isnull = arg1.isnull | arg2.isnull;									\
+		r.value = false;														\
+		if (!r.isnull)															\
+		{																		\
+			int c = strom_numeric_cmp(arg1, arg2);								\
+			r.value = (EXPR);													\
+		}																		\
+		return r;																\
+	}
+STROM_NUMERIC_COMPARE(eq, c == 0)
+STROM_NUMERIC_COMPARE(ne, c != 0)
+STROM_NUMERIC_COMPARE(lt, c <  0)
+STROM_NUMERIC_COMPARE(le, c <= 0)
+STROM_NUMERIC_COMPARE(gt, c >  0)
+STROM_NUMERIC_COMPARE(ge, c >= 0)
+STROM_DEVICE pg_int4_t
+pgfn_numeric_cmp(cl_int *errcode, pg_numeric_t arg1, pg_numeric_t arg2)
+{
+	pg_int4_t r;
+	r.isnull = arg1.isnull | arg2.isnull;
+	r.value = (r.isnull ? 0 : strom_numeric_cmp(arg1, arg2));
+	return r;
+}
+
+/* ---- casts -------------------------------------------------------------- */
+STROM_DEVICE pg_numeric_t
+strom_integer_to_numeric(cl_int *errcode, cl_long value, bool isnull)
+{
+	pg_numeric_t v;
+	if (isnull)
+	{
+		v.isnull = true;
+		v.value = 0;
+		return v;
+	}
+	bool		sign = (value < 0);
+	cl_ulong	mant = (sign ? (cl_ulong)0 - (cl_ulong)value : (cl_ulong)value);
+	return strom_numeric_pack(errcode, 0, sign, mant);
+}
+STROM_DEVICE pg_numeric_t pgfn_int2_numeric(cl_int *e, pg_int2_t a)
+{ return strom_integer_to_numeric(e, a.value, a.isnull); }
+STROM_DEVICE pg_numeric_t pgfn_int4_numeric(cl_int *e, pg_int4_t a)
+{ return strom_integer_to_numeric(e, a.value, a.isnull); }
+STROM_DEVICE pg_numeric_t pgfn_int8_numeric(cl_int *e, pg_int8_t a)
+{ return strom_integer_to_numeric(e, a.value, a.isnull); }
+
+/* numeric -> integer: round half away from zero, then range check */
+STROM_DEVICE bool
+strom_numeric_to_int64(pg_numeric_t arg, cl_long lo, cl_long hi, cl_long *p_value)
+{
+	int			expo = PG_NUMERIC_EXPONENT(arg.value);
+	bool		sign = PG_NUMERIC_SIGN(arg.value);
+	cl_ulong	mant = PG_NUMERIC_MANTISSA(arg.value);
+
+	if (expo < 0)
+	{
+		cl_ulong mag = strom_pow10_u64(-expo);
+		if (mag == 0)
+			mant = 0;			/* |value| < 1e-19 ... rounds to zero */
+		else
+			mant = (mant + mag / 2) / mag;
+	}
+	else if (expo > 0)
+	{
+		cl_ulong mag = strom_pow10_u64(expo);
+		if (mag == 0 || __builtin_mul_overflow(mant, mag, &mant))
+			return false;
+	}
+	if (!sign)
+	{
+		if (mant > (cl_ulong)hi)
+			return false;
+		*p_value = (cl_long)mant;
+	}
+	else
+	{
+		if (mant > (cl_ulong)0 - (cl_ulong)lo)
+			return false;
+		*p_value = (cl_long)((cl_ulong)0 - mant);
+	}
+	return true;
+}
+#define STROM_NUMERIC_TO_INT(name,r_type,LO,HI)									\
+	STROM_DEVICE pg_##r_type##_t												\
+	pgfn_numeric_##name(cl_int *errcode, pg_numeric_t arg)						\
+	{																			\
+		pg_##r_type##_t r;														\
+		cl_long		v = 0;														\
+		r.isnull = arg.isnull;													\
+		r.value = 0;															\
+		if (!r.isnull)															\
+		{																		\
+			if (!strom_numeric_to_int64(arg, (LO), (HI), &v))					\
+			{																	\
+				r.isnull = true;												\
+				STROM_SET_ERROR(errcode, StromError_CpuReCheck);				\
+			}																	\
+			else																\
+				r.value = (pg_##r_type##_base_t)v;								\
+		}																		\
+		return r;																\
+	}
+STROM_NUMERIC_TO_INT(int2, int2, -32768L, 32767L)
+STROM_NUMERIC_TO_INT(int4, int4, -2147483648L, 2147483647L)
+STROM_NUMERIC_TO_INT(int8, int8, (-9223372036854775807L - 1), 9223372036854775807L)
+
+STROM_DEVICE pg_float8_t
+pgfn_numeric_float8(cl_int *errcode, pg_numeric_t arg)
+{
+	pg_float8_t r;
+	r.isnull = arg.isnull;
+	r.value = 0.0;
+	if (!r.isnull)
+	{
+		int			expo = PG_NUMERIC_EXPONENT(arg.value);
+		cl_ulong	mant = PG_NUMERIC_MANTISSA(arg.value);
+		double		m = (double)mant, p = 1.0;
+		/* 10^|expo| is exact in double up to 1e22; one correctly rounded
+		 * multiply or divide follows */
+		for (int i = 0; i < (expo < 0 ? -expo : expo); i++)
+			p *= 10.0;
+		r.value = (expo < 0 ? m / p : m * p);
+		if (PG_NUMERIC_SIGN(arg.value))
+			r.value = -r.value;
+	}
+	return r;
+}
+STROM_DEVICE pg_float4_t
+pgfn_numeric_float4(cl_int *errcode, pg_numeric_t arg)
+{
+	pg_float8_t d = pgfn_numeric_float8(errcode, arg);
+	pg_float4_t r;
+	r.isnull = d.isnull;
+	r.value = (cl_float)d.value;
+	if (!r.isnull && STROM_CHECKFLOATVAL(r.value, false, d.value == 0.0))
+	{
+		r.isnull = true;
+		STROM_SET_ERROR(errcode, StromError_CpuReCheck);
+	}
+	return r;
+}
+
+/*
+ * numeric -> fixed-point int8 at 10^-scale, exact or CpuReCheck.  GpuPreAgg
+ * accumulates numeric partials in this form (integer LDS atomics); the
+ * scale comes from the target (column typmod / expression scale).
+ */
+STROM_DEVICE pg_int8_t
+strom_numeric_to_fixed(cl_int *errcode, pg_numeric_t arg, int scale)
+{
+	pg_int8_t r;
+
+	r.isnull = arg.isnull;
+	r.value = 0;
+	if (!r.isnull)
+	{
+		int			shift = PG_NUMERIC_EXPONENT(arg.value) + scale;
+		cl_ulong	mant = PG_NUMERIC_MANTISSA(arg.value);
+		cl_ulong	mag = strom_pow10_u64(shift);
+
+		if (mant == 0)
+			return r;
+		if (shift < 0 || mag == 0 || __builtin_mul_overflow(mant, mag, &mant) ||
+			mant > 9223372036854775807UL)
+		{
+			/* finer than the accumulator's scale, or too large */
+			r.isnull = true;
+			STROM_SET_ERROR(errcode, StromError_CpuReCheck);
+			return r;
+		}
+		r.value = (PG_NUMERIC_SIGN(arg.value) ? -(cl_long)mant : (cl_long)mant);
+	}
+	return r;
+}
+
+#endif	/* STROM_NUMERIC_DEVICE_H */

@@ -533,8 +533,46 @@ strom_gpupreagg_release(strom_gpupreagg *sess)
 	delete sess;
 }
 
+namespace {
+
+/* int64 fixed point at 10^-scale -> 64-bit device numeric; false when the
+ * mantissa does not fit 57 bits */
+bool
+fixed_to_numeric(cl_long v, int scale, cl_ulong *out)
+{
+	bool		sign = (v < 0);
+	cl_ulong	mant = (sign ? (cl_ulong)0 - (cl_ulong)v : (cl_ulong)v);
+	int			expo = -scale;
+
+	if (mant == 0)
+	{
+		*out = 0;
+		return true;
+	}
+	while (mant % 10 == 0 && expo < 31)
+	{
+		mant /= 10;
+		expo++;
+	}
+	if (mant >= (1UL << 57) || expo < -32 || expo > 31)
+		return false;
+	*out = ((cl_ulong)((cl_long)expo << 58)) | (sign ? (1UL << 57) : 0) | mant;
+	return true;
+}
+
+struct numeric_spill {
+	cl_uint		gid;
+	int			resno;
+	cl_ulong	image;
+};
+
+}	/* namespace */
+
 /*
- * partial rows out: TUPSLOT, one row per group seen so far
+ * partial rows out: TUPSLOT, one row per group seen so far (plus, for a
+ * numeric sum too wide for the 64-bit numeric form, one extra partial row
+ * of the same group carrying the high part: partial rows add up, so the
+ * final aggregate is unchanged)
  */
 extern "C" long
 strom_gpupreagg_fetch(strom_gpupreagg *sess, kern_data_store *dest, size_t destlen)
@@ -552,9 +590,30 @@ strom_gpupreagg_fetch(strom_gpupreagg *sess, kern_data_store *dest, size_t destl
 		return -StromError_HipInternal;
 	const cl_uint *gflags = (const cl_uint *)host.data();
 	size_t	ngroups = 0;
+	std::vector<numeric_spill> spills;
+	const cl_long P17 = 100000000000000000L;
 	for (cl_uint g = 0; g < N; g++)
-		if (gflags[g] & 1)
-			ngroups++;
+	{
+		if (!(gflags[g] & 1))
+			continue;
+		ngroups++;
+		for (size_t a = 0; a < sess->agg_resno.size(); a++)
+		{
+			const strom_preagg_target &t = sess->targets[sess->agg_resno[a]];
+			if (t.type_oid != STROM_NUMERICOID || t.kind == STROM_PREAGG_NROWS || !(gflags[g] & (2u << a)))
+				continue;
+			cl_long v = ((const cl_long *)(host.data() + sess->table_offset(1 + (int)a, N)))[g];
+			cl_ulong img;
+			if (!fixed_to_numeric(v, t.scale, &img))
+			{
+				cl_long hi = (v / P17) * P17;
+				if (!fixed_to_numeric(hi, t.scale, &img))
+					return -StromError_DataStoreOutOfRange;
+				spills.push_back(numeric_spill{g, sess->agg_resno[a], img});
+			}
+		}
+	}
+	ngroups += spills.size();
 	size_t	need = STROMALIGN(KDS_HEAD_LENGTH(ncols) + KDS_TUPSLOT_STRIDE(ncols) * ngroups);
 	if (!dest)
 		return (long)need;
@@ -610,7 +669,17 @@ strom_gpupreagg_fetch(strom_gpupreagg *sess, kern_data_store *dest, size_t destl
 			else
 			{
 				cl_ulong raw = vals[g];
-				if (type_is_float(t.type_oid))
+				if (t.type_oid == STROM_NUMERICOID)
+				{
+					cl_long v = (cl_long)raw;
+					if (!fixed_to_numeric(v, t.scale, &raw))
+					{
+						cl_long lo = v - (v / P17) * P17;	/* high part: spill row */
+						(void)fixed_to_numeric(lo, t.scale, &raw);
+					}
+					values[resno] = raw;
+				}
+				else if (type_is_float(t.type_oid))
 				{
 					if (t.kind != STROM_PREAGG_PSUM)
 					{
@@ -631,6 +700,28 @@ strom_gpupreagg_fetch(strom_gpupreagg *sess, kern_data_store *dest, size_t destl
 					memcpy(&values[resno], &raw, type_length(t.type_oid));
 			}
 		}
+		row++;
+	}
+	for (const numeric_spill &sp : spills)
+	{
+		Datum	   *values = KERN_DATA_STORE_VALUES(dest, row);
+		cl_char	   *isnull = KERN_DATA_STORE_ISNULL(dest, row);
+		memset(values, 0, KDS_TUPSLOT_STRIDE(ncols));
+		for (int i = 0; i < ncols; i++)
+			isnull[i] = (sess->targets[i].kind != STROM_PREAGG_NROWS);	/* nrows = 0 */
+		for (size_t k = 0; k < sess->key_resno.size(); k++)
+		{
+			int		resno = sess->key_resno[k];
+			cl_uint	off = (sp.gid / sess->ctl.key_stride[k]) % (sess->ctl.key_range[k] + 1);
+			if (off != sess->ctl.key_range[k])
+			{
+				cl_long v = sess->ctl.key_min[k] + off;
+				isnull[resno] = 0;
+				memcpy(&values[resno], &v, type_length(sess->targets[resno].type_oid));
+			}
+		}
+		isnull[sp.resno] = 0;
+		values[sp.resno] = sp.image;
 		row++;
 	}
 	dest->nitems = row;

@@ -183,6 +183,31 @@ class GpuPreAgg(object):
             raise runtime.StromError(rc, "strom_gpupreagg_table_layout")
         return b.value, v.value
 
+    # multi-GPU ------------------------------------------------------------
+    def bind_torch_table(self):
+        """move the resident table into a torch uint8 tensor (same device) so
+        that torch.distributed can reduce it in place; returns the tensor"""
+        import torch
+        nbytes = lib.strom_gpupreagg_table_length(self.session)
+        t = torch.zeros(nbytes, dtype=torch.uint8, device="cuda")
+        rc = lib.strom_gpupreagg_bind_table(self.session, t.data_ptr())
+        if rc != 0:
+            raise runtime.StromError(rc, "strom_gpupreagg_bind_table")
+        self._table_tensor = t
+        return t
+
+    def allreduce(self, group=None):
+        """merge the per-GPU partial tables over RCCL (pg_strom_amd.parallel)"""
+        import torch
+        from . import parallel
+        if getattr(self, "_table_tensor", None) is None:
+            self.bind_torch_table()
+        lib.strom_synchronize()                 # every fold has landed in the table
+        layout = parallel.TableLayout(self.targets, lib.strom_gpupreagg_num_groups(self.session))
+        assert layout.nbytes == self._table_tensor.numel()
+        parallel.allreduce_table(self._table_tensor, layout, group)
+        torch.cuda.synchronize()
+
     def reset(self):
         lib.strom_gpupreagg_reset(self.session)
 

@@ -161,3 +161,52 @@ def read_resultbuf(buf, res_offset):
     start = res_offset + RESULTBUF_HEAD
     results = np.frombuffer(buf[start:start + 4 * n].tobytes(), dtype=np.int32)
     return nitems, errcode, results
+
+
+# ---------------------------------------------------------------------
+# 64-bit device NUMERIC (opencl_numeric.h:122-162): exponent 63..58 (signed,
+# base 10), sign 57, mantissa 56..0; normalised (no trailing decimal zero)
+# ---------------------------------------------------------------------
+def numeric_encode(value):
+    """Decimal / str / int -> uint64 image, or None when it does not fit"""
+    from decimal import Decimal
+    d = Decimal(value)
+    sign, digits, exp = d.as_tuple()
+    mant = int("".join(map(str, digits))) if digits else 0
+    if mant == 0:
+        return 0
+    while mant % 10 == 0:
+        mant //= 10
+        exp += 1
+    while exp > 31 and mant < (1 << 57) // 10:
+        mant *= 10
+        exp -= 1
+    if mant >= (1 << 57) or exp < -32 or exp > 31:
+        return None
+    return ((exp & 0x3f) << 58) | (sign << 57) | mant
+
+
+def numeric_decode(image):
+    """uint64 image -> Decimal"""
+    from decimal import Decimal
+    image = int(image)
+    exp = image >> 58
+    if exp >= 32:
+        exp -= 64
+    mant = image & ((1 << 57) - 1)
+    d = Decimal(mant).scaleb(exp)
+    return -d if (image >> 57) & 1 else d
+
+
+def numeric_column(strings, isnull=None):
+    """decimal strings -> Column('numeric'); values that do not fit the
+    64-bit form raise (a real ingest would leave such rows to the CPU)"""
+    vals = np.zeros(len(strings), dtype=np.uint64)
+    for i, s in enumerate(strings):
+        if isnull is not None and isnull[i]:
+            continue
+        img = numeric_encode(s)
+        if img is None:
+            raise ValueError("numeric %r does not fit the 64-bit device form" % (s,))
+        vals[i] = img
+    return Column("numeric", vals, isnull)

@@ -1,0 +1,169 @@
+"""
+Multi-GPU merge of GpuPreAgg partial tables (one process per GPU,
+torch.distributed; backend "nccl" is RCCL on ROCm, xGMI between the GPUs of
+a node; "gloo" for the CPU rehearsal in tests/).
+
+The reference has no collective anywhere: one
+backend merges partial rows in PostgreSQL's Agg node.  Here every rank
+folds its row range into a resident table with an identical dense layout
+(strom_gpupreagg.h: section 0 = u32 flags per group, section 1+a = 8-byte
+values of aggregate a), so the merge is an all-reduce on the table itself,
+one collective per section:
+
+    nrows, psum(int8)   SUM on int64     exact, order independent
+    psum(float8)        SUM on float64   tolerance: summation order
+    pmin / pmax         MIN / MAX on int64 (float keys are order-preserving
+                        u64; the sign bit is flipped so that signed MIN/MAX
+                        orders them)
+    flags               OR, done as a SUM over unpacked bits (NCCL has no BOR)
+
+Entries a rank never touched hold 0; for MIN/MAX they are replaced by the
+identity before the collective.  With ~1e4 groups a section is 80 KB: the
+collectives are latency bound, which is why they are few and whole-section.
+"""
+import numpy as np
+
+KIND_KEY, KIND_NROWS, KIND_PSUM, KIND_PMIN, KIND_PMAX = 1, 2, 3, 4, 5
+FLOAT_OIDS = (700, 701)
+SIGN = np.int64(-2**63)
+
+
+def align(v, a):
+    return (v + a - 1) // a * a
+
+
+class TableLayout(object):
+    """byte layout of the resident table for `ngroups` dense ids"""
+
+    def __init__(self, targets, ngroups):
+        self.targets = list(targets)
+        self.ngroups = ngroups
+        self.aggs = [(i, k, oid) for i, (k, oid) in enumerate(self.targets) if k != KIND_KEY]
+        self.flags_bytes = align(4 * ngroups, 256)
+        self.vals_bytes = align(8 * ngroups, 256)
+        self.nbytes = self.flags_bytes + self.vals_bytes * len(self.aggs)
+
+    def vals_offset(self, a):
+        return self.flags_bytes + self.vals_bytes * a
+
+
+def allreduce_table(table, layout, group=None):
+    """in-place all-reduce of a table held in a torch uint8 tensor"""
+    import torch
+    import torch.distributed as dist
+    n = layout.ngroups
+    flags = table[:4 * n].view(torch.int32)
+    nbits = len(layout.aggs) + 1
+    shifts = torch.arange(nbits, device=table.device, dtype=torch.int32)
+    bits = ((flags[:, None] >> shifts[None, :]) & 1).to(torch.int32)
+    for a, (_, kind, oid) in enumerate(layout.aggs):
+        off = layout.vals_offset(a)
+        vals = table[off:off + 8 * n]
+        has = bits[:, a + 1] != 0
+        if kind == KIND_NROWS or (kind == KIND_PSUM and oid not in FLOAT_OIDS):
+            v = vals.view(torch.int64)
+            v.mul_(has.to(torch.int64) if kind != KIND_NROWS else 1)
+            dist.all_reduce(v, op=dist.ReduceOp.SUM, group=group)
+        elif kind == KIND_PSUM:
+            v = vals.view(torch.float64)
+            v.copy_(torch.where(has, v, torch.zeros_like(v)))
+            dist.all_reduce(v, op=dist.ReduceOp.SUM, group=group)
+        else:
+            v = vals.view(torch.int64)
+            isfloat = oid in FLOAT_OIDS
+            is_min = (kind == KIND_PMIN)
+            w = v ^ int(SIGN) if isfloat else v.clone()   # unsigned order -> signed order
+            ident = torch.iinfo(torch.int64).max if is_min else torch.iinfo(torch.int64).min
+            w = torch.where(has, w, torch.full_like(w, ident))
+            dist.all_reduce(w, op=dist.ReduceOp.MIN if is_min else dist.ReduceOp.MAX, group=group)
+            v.copy_(w ^ int(SIGN) if isfloat else w)
+    dist.all_reduce(bits, op=dist.ReduceOp.SUM, group=group)
+    merged = ((bits > 0).to(torch.int32) << shifts[None, :]).sum(dim=1).to(torch.int32)
+    flags.copy_(merged)
+    return table
+
+
+# ---- numpy helpers (tests, CPU rehearsal, decoding on the host) ------------
+def pack_rows(layout, domain, values, isnull):
+    """partial rows (uint64 images [n, ntargets], bool isnull) -> table bytes.
+    domain: [(min, range)] per key; float partials are float64 images."""
+    tbl = np.zeros(layout.nbytes, dtype=np.uint8)
+    flags = tbl[:4 * layout.ngroups].view(np.uint32)
+    keys = [i for i, (k, _) in enumerate(layout.targets) if k == KIND_KEY]
+    for r in range(len(values)):
+        gid, stride = 0, 1
+        for (mn, rng), t in zip(domain, keys):
+            off = rng if isnull[r, t] else int(values[r, t].view(np.int64)) - mn
+            gid += off * stride
+            stride *= rng + 1
+        flags[gid] |= 1
+        for a, (t, kind, oid) in enumerate(layout.aggs):
+            vals = tbl[layout.vals_offset(a):layout.vals_offset(a) + 8 * layout.ngroups].view(np.uint64)
+            if kind == KIND_NROWS:
+                vals[gid] += values[r, t]
+                continue
+            if isnull[r, t]:
+                continue
+            had = bool(flags[gid] & (2 << a))
+            x = values[r, t]
+            if kind == KIND_PSUM:
+                if oid in FLOAT_OIDS:
+                    cur = vals[gid:gid + 1].view(np.float64)
+                    cur[0] = (cur[0] if had else 0.0) + x.view(np.float64)
+                else:
+                    vals[gid] = np.uint64((int(vals[gid]) + int(x)) & 0xFFFFFFFFFFFFFFFF)
+            else:
+                if oid in FLOAT_OIDS:
+                    x = f64_ordered(x.view(np.float64))
+                    cmp_new, cmp_old = int(x), int(vals[gid])
+                else:
+                    cmp_new, cmp_old = int(x.view(np.int64)), int(vals[gid:gid + 1].view(np.int64)[0])
+                if not had or (cmp_new < cmp_old if kind == KIND_PMIN else cmp_new > cmp_old):
+                    vals[gid] = x
+            flags[gid] |= np.uint32(2 << a)
+    return tbl
+
+
+def f64_ordered(d):
+    bits = np.array([d], dtype=np.float64).view(np.uint64)[0]
+    if np.isnan(d):
+        bits = np.uint64(0x7ff8000000000000)
+    if bits & np.uint64(1 << 63):
+        return np.uint64(~bits & np.uint64(0xFFFFFFFFFFFFFFFF))
+    return np.uint64(bits | np.uint64(1 << 63))
+
+
+def f64_unordered(k):
+    k = np.uint64(k)
+    bits = (k & np.uint64(0x7FFFFFFFFFFFFFFF)) if (k & np.uint64(1 << 63)) else np.uint64(~k & np.uint64(0xFFFFFFFFFFFFFFFF))
+    return np.array([bits], dtype=np.uint64).view(np.float64)[0]
+
+
+def unpack_rows(layout, domain, tbl):
+    """table bytes -> (values uint64 [n, ntargets], isnull), one row per seen group"""
+    flags = tbl[:4 * layout.ngroups].view(np.uint32)
+    keys = [i for i, (k, _) in enumerate(layout.targets) if k == KIND_KEY]
+    gids = np.nonzero(flags & 1)[0]
+    nt = len(layout.targets)
+    values = np.zeros((len(gids), nt), dtype=np.uint64)
+    isnull = np.zeros((len(gids), nt), dtype=bool)
+    for r, gid in enumerate(gids):
+        rest = int(gid)
+        for (mn, rng), t in zip(domain, keys):
+            off = rest % (rng + 1)
+            rest //= (rng + 1)
+            if off == rng:
+                isnull[r, t] = True
+            else:
+                values[r, t] = np.array([mn + off], dtype=np.int64).view(np.uint64)[0]
+        for a, (t, kind, oid) in enumerate(layout.aggs):
+            vals = tbl[layout.vals_offset(a):layout.vals_offset(a) + 8 * layout.ngroups].view(np.uint64)
+            if kind == KIND_NROWS:
+                values[r, t] = vals[gid]
+            elif not (flags[gid] & (2 << a)):
+                isnull[r, t] = True
+            elif kind != KIND_PSUM and oid in FLOAT_OIDS:
+                values[r, t] = np.array([f64_unordered(vals[gid])], dtype=np.float64).view(np.uint64)[0]
+            else:
+                values[r, t] = vals[gid]
+    return values, isnull

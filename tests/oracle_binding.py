@@ -160,6 +160,27 @@ def pg_crc32(data):
     return lib.oracle_pg_crc32(0xFFFFFFFF, data, len(data)) ^ 0xFFFFFFFF
 
 
+def eval_rows(expr, kds_buf, ext_params=()):
+    """(type oid, values uint64[n], isnull bool[n], errcode int32[n])"""
+    lib = load()
+    lib.oracle_eval_rows.restype = ctypes.c_int32
+    lib.oracle_eval_rows.argtypes = [ctypes.c_char_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int,
+                                     ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                     ctypes.POINTER(ctypes.c_int32), ctypes.c_char_p, ctypes.c_size_t]
+    vals, nulls, n = ext_arrays(ext_params)
+    nitems = int(np.frombuffer(kds_buf[20:24].tobytes(), dtype=np.uint32)[0])
+    ov = np.zeros(max(nitems, 1), dtype=np.uint64)
+    on = np.zeros(max(nitems, 1), dtype=np.uint8)
+    oe = np.zeros(max(nitems, 1), dtype=np.int32)
+    oid = ctypes.c_int32(0)
+    err = ctypes.create_string_buffer(256)
+    rc = lib.oracle_eval_rows(expr.encode(), vals.ctypes.data, nulls.ctypes.data, n, kds_buf.ctypes.data,
+                              ov.ctypes.data, on.ctypes.data, oe.ctypes.data, ctypes.byref(oid), err, 256)
+    if rc != 0:
+        raise ValueError("oracle: " + err.value.decode())
+    return oid.value, ov[:nitems], on[:nitems].astype(bool), oe[:nitems]
+
+
 def layout():
     out = oracle_layout()
     load().oracle_get_layout(ctypes.byref(out))

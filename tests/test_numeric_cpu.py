@@ -1,0 +1,109 @@
+"""
+64-bit in-kernel NUMERIC, CPU side: the oracle's numeric arithmetic against
+Python's Decimal (exact), the representable range the reference's
+recheck_agg suite pins (expected/recheck_agg.out:23-51: sum(1E+48) and
+sum(1E-32) stay on the device, 1E+49 / 1E-33 / 1E+-1000 go back to the CPU),
+and fixed-point partial sums.
+"""
+from decimal import Decimal
+
+import numpy as np
+import pytest
+
+import oracle_binding as oracle
+from pg_strom_amd import kds, runtime
+
+
+def test_representable_range_matches_recheck_suite():
+    assert kds.numeric_encode("1E+48") is not None
+    assert kds.numeric_encode("1E-32") is not None
+    assert kds.numeric_encode("1E+49") is None
+    assert kds.numeric_encode("1E-33") is None
+    assert kds.numeric_encode("1E+1000") is None and kds.numeric_encode("1E-1000") is None
+    for s in ("0", "1", "-1", "123.4500", "0.0001", "-987654321098.76543", "144115188075855871"):
+        assert kds.numeric_decode(kds.numeric_encode(s)) == Decimal(s)
+    assert kds.numeric_encode("144115188075855872") is None      # 2^57 does not fit
+    # the expression IR's literal parser agrees
+    assert runtime.expression_available("(numeric_gt (var 1 numeric) (const numeric 1E+48))")[0]
+    assert not runtime.expression_available("(numeric_gt (var 1 numeric) (const numeric 1E+49))")[0]
+
+
+def random_numerics(n, seed):
+    rng = np.random.default_rng(seed)
+    out = []
+    for i in range(n):
+        digits = int(rng.integers(1, 17))
+        mant = int(rng.integers(0, 10 ** digits))
+        scale = int(rng.integers(0, 12))
+        sign = -1 if rng.random() < 0.4 else 1
+        out.append(Decimal(sign * mant).scaleb(-scale))
+    return out
+
+
+@pytest.mark.parametrize("op,fn", [("numeric_add", lambda a, b: a + b),
+                                   ("numeric_sub", lambda a, b: a - b),
+                                   ("numeric_mul", lambda a, b: a * b)])
+def test_arithmetic_is_exact_or_recheck(op, fn):
+    a, b = random_numerics(3000, 1), random_numerics(3000, 2)
+    buf = kds.build_kds("column", [kds.numeric_column(a), kds.numeric_column(b)])
+    oid, v, isn, err = oracle.eval_rows("(%s (var 1 numeric) (var 2 numeric))" % op, buf)
+    assert oid == 1700
+    nre = 0
+    for i in range(3000):
+        exact = fn(a[i], b[i])
+        if err[i] == 2:
+            assert isn[i]
+            nre += 1
+        else:
+            assert err[i] == 0 and not isn[i]
+            assert kds.numeric_decode(v[i]) == exact, (a[i], b[i], exact)
+            assert kds.numeric_encode(exact) == int(v[i])        # canonical image
+    if op != "numeric_mul":
+        assert nre < 1000         # rechecks are the exception, not the rule
+    assert nre > 0 or op != "numeric_mul"
+
+
+def test_compare_and_casts():
+    a, b = random_numerics(2000, 3), random_numerics(2000, 4)
+    b[:200] = a[:200]
+    buf = kds.build_kds("row", [kds.numeric_column(a), kds.numeric_column(b)])
+    for op, fn in (("lt", lambda x, y: x < y), ("le", lambda x, y: x <= y), ("eq", lambda x, y: x == y),
+                   ("ne", lambda x, y: x != y), ("ge", lambda x, y: x >= y), ("gt", lambda x, y: x > y)):
+        rc, res = oracle.gpuscan("(numeric_%s (var 1 numeric) (var 2 numeric))" % op, buf)
+        want = [i + 1 for i in range(2000) if fn(a[i], b[i])]
+        assert rc == 0 and list(res) == want
+    # numeric -> int4 rounds half away from zero; out of range -> recheck
+    vals = [Decimal("0.5"), Decimal("1.5"), Decimal("-0.5"), Decimal("-2.5"), Decimal("2.49"),
+            Decimal("3000000000"), Decimal("12345.678")]
+    buf = kds.build_kds("column", [kds.numeric_column(vals)])
+    oid, v, isn, err = oracle.eval_rows("(int4 (var 1 numeric))", buf)
+    got = [None if e else int(np.int64(x)) for x, e in zip(v.view(np.int64), err)]
+    assert got == [1, 2, -1, -3, 2, None, 12346]
+    oid, v, isn, err = oracle.eval_rows("(float8 (var 1 numeric))", buf)
+    assert np.allclose(v.view(np.float64), [float(x) for x in vals], rtol=1e-15)
+    oid, v, isn, err = oracle.eval_rows("(numeric (int4 (var 1 numeric)))", buf)
+    assert kds.numeric_decode(v[6]) == Decimal(12346)
+
+
+def test_fixed_point_partial_sums():
+    rng = np.random.default_rng(9)
+    price = [Decimal(int(rng.integers(90000, 10494950))).scaleb(-2) for _ in range(5000)]
+    disc = [Decimal(int(rng.integers(0, 11))).scaleb(-2) for _ in range(5000)]
+    flag = rng.integers(0, 3, 5000).astype(np.int8)
+    buf = kds.build_kds("column", [kds.Column("char1", flag), kds.numeric_column(price),
+                                   kds.numeric_column(disc)])
+    spec = ("(gpupreagg (key (var 1 char1)) (nrows) (psum (var 2 numeric) 2)"
+            " (psum (numeric_mul (var 2 numeric) (numeric_sub (const numeric 1) (var 3 numeric))) 4)"
+            " (pmax (var 2 numeric) 2))")
+    rc, v, isn = oracle.gpupreagg(spec, buf, 5)
+    assert rc == 0 and len(v) == 3
+    for i in range(3):
+        k = int(v[i, 0].view(np.int64))
+        rows = [j for j in range(5000) if flag[j] == k]
+        assert int(v[i, 1]) == len(rows)
+        assert Decimal(int(v[i, 2].view(np.int64))).scaleb(-2) == sum(price[j] for j in rows)
+        assert Decimal(int(v[i, 3].view(np.int64))).scaleb(-4) == sum(price[j] * (1 - disc[j]) for j in rows)
+        assert Decimal(int(v[i, 4].view(np.int64))).scaleb(-2) == max(price[j] for j in rows)
+    # a value finer than the accumulator's scale sends the chunk back
+    rc, v, isn = oracle.gpupreagg("(gpupreagg (psum (var 2 numeric) 1))", buf, 1)
+    assert rc == 2

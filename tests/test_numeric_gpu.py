@@ -1,0 +1,175 @@
+"""
+64-bit NUMERIC on the device (needs an MI355X: -m gpu): scalar functions,
+numeric quals in GpuScan, fixed-point numeric partials in GpuPreAgg and the
+TPC-H Q1-shaped aggregation (BASELINE configs[4] shape at test size).
+Exact arithmetic: every result must equal the oracle's bit for bit; the
+oracle is checked against Python's Decimal in tests/test_numeric_cpu.py.
+"""
+from decimal import Decimal
+
+import numpy as np
+import pytest
+
+import oracle_binding as oracle
+from pg_strom_amd import kds
+from pg_strom_amd.gpupreagg import GpuPreAgg
+from pg_strom_amd.gpuscan import GpuScan
+from test_numeric_cpu import random_numerics
+
+pytestmark = pytest.mark.gpu
+
+
+def scan_parity(qual, buf, ext=()):
+    rc, want = oracle.gpuscan(qual, buf, ext)
+    scan = GpuScan(qual).begin(ext_params=ext)
+    res = scan.scan_chunk(buf)
+    scan.end()
+    assert res.errcode == rc
+    assert np.array_equal(np.sort(res.results), np.sort(want))
+    return res
+
+
+@pytest.mark.parametrize("fmt", ["column", "row", "tupslot"])
+def test_numeric_quals(fmt):
+    a, b = random_numerics(20000, 11), random_numerics(20000, 12)
+    an = np.random.default_rng(1).random(20000) < 0.03
+    i4 = np.random.default_rng(2).integers(-1000, 1000, 20000).astype(np.int32)
+    buf = kds.build_kds(fmt, [kds.numeric_column(a, an), kds.numeric_column(b), kds.Column("int4", i4)])
+    for qual in ("(numeric_lt (var 1 numeric) (var 2 numeric))",
+                 "(numeric_ge (numeric_add (var 1 numeric) (var 2 numeric)) (const numeric 0.5))",
+                 "(numeric_gt (numeric_mul (var 1 numeric) (numeric (var 3 int4))) (const numeric -12.50))",
+                 "(numeric_eq (numeric_sub (var 1 numeric) (var 1 numeric)) (const numeric 0))",
+                 "(int4gt (int4 (numeric_abs (var 2 numeric))) (var 3 int4))",
+                 "(float8lt (float8 (numeric_uminus (var 1 numeric))) (const float8 0.25))",
+                 "(numeric_ne (var 1 numeric) (param 0 numeric))"):
+        ext = [np.uint64(kds.numeric_encode("12.5"))] if "param" in qual else ()
+        res = scan_parity(qual, buf, ext)
+    assert res is not None
+
+
+def test_device_arithmetic_equals_oracle_values():
+    """device result == oracle result for every row that is not a recheck"""
+    a, b = random_numerics(30000, 21), random_numerics(30000, 22)
+    base = [kds.numeric_column(a), kds.numeric_column(b)]
+    buf = kds.build_kds("column", base)
+    for op in ("numeric_add", "numeric_sub", "numeric_mul"):
+        expr = "(%s (var 1 numeric) (var 2 numeric))" % op
+        oid, v, isn, err = oracle.eval_rows(expr, buf)
+        exp_col = kds.Column("numeric", v, isn)
+        buf3 = kds.build_kds("column", base + [exp_col])
+        scan = GpuScan("(numeric_eq %s (var 3 numeric))" % expr).begin()
+        res = scan.scan_chunk(buf3)
+        scan.end()
+        ok_rows = np.nonzero(err == 0)[0]
+        re_rows = np.nonzero(err == 2)[0]
+        assert np.array_equal(res.passed_rows(), ok_rows)
+        assert np.array_equal(res.recheck_rows(), re_rows)
+
+
+def fetch_rows(agg):
+    pr = agg.fetch()
+    out = []
+    for i in range(len(pr)):
+        row = []
+        for t, (kind, oid) in enumerate(pr.targets):
+            v, n = pr.column(t)
+            row.append(None if n[i] else (kds.numeric_decode(v[i]) if oid == 1700 and kind != 2 else v[i].item()))
+        out.append(row)
+    return out
+
+
+def test_fixed_point_numeric_partials_and_wide_sums():
+    rng = np.random.default_rng(5)
+    n = 40000
+    price = [Decimal(int(rng.integers(90000, 10494950))).scaleb(-2) for _ in range(n)]
+    disc = [Decimal(int(rng.integers(0, 11))).scaleb(-2) for _ in range(n)]
+    flag = rng.integers(0, 3, n).astype(np.int8)
+    pn = rng.random(n) < 0.02
+    buf = kds.build_kds("column", [kds.Column("char1", flag), kds.numeric_column(price, pn),
+                                   kds.numeric_column(disc)])
+    spec = ("(gpupreagg (key (var 1 char1)) (nrows (isnotnull (var 2 numeric))) (psum (var 2 numeric) 2)"
+            " (psum (numeric_mul (var 2 numeric) (numeric_sub (const numeric 1) (var 3 numeric))) 4)"
+            " (pmin (var 2 numeric) 2) (pmax (var 2 numeric) 2))")
+    agg = GpuPreAgg(spec).begin([(0, 3)])
+    assert agg.fold(buf)[0] == 0
+    rows = {r[0]: r for r in fetch_rows(agg)}
+    agg.end()
+    assert sorted(rows) == [0, 1, 2]
+    for k in range(3):
+        idx = [j for j in range(n) if flag[j] == k and not pn[j]]
+        r = rows[k]
+        assert r[1] == len(idx)
+        assert r[2] == sum(price[j] for j in idx)
+        assert r[3] == sum(price[j] * (1 - disc[j]) for j in idx)
+        assert r[4] == min(price[j] for j in idx) and r[5] == max(price[j] for j in idx)
+    # a sum wider than the 57-bit mantissa comes back as two partial rows that add up
+    big = [Decimal(123456789012345678 + i) for i in range(10)]
+    buf = kds.build_kds("column", [kds.numeric_column(big)])
+    agg = GpuPreAgg("(gpupreagg (nrows) (psum (var 1 numeric) 0))").begin([])
+    assert agg.fold(buf)[0] == 0
+    rows = fetch_rows(agg)
+    agg.end()
+    assert len(rows) == 2
+    assert sum(r[0] for r in rows) == 10
+    assert sum(r[1] for r in rows if r[1] is not None) == sum(big)
+
+
+def test_tpch_q1_shape():
+    """returnflag, linestatus, sum(qty), sum(price), sum(price*(1-disc)),
+    sum(price*(1-disc)*(1+tax)), avg(qty), avg(price), avg(disc), count(*)
+    WHERE shipdate <= date '1998-09-02' (SURVEY.md section 8d, C5 columns)"""
+    rng = np.random.default_rng(1998)
+    n = 200000
+    rf = rng.choice(np.array([65, 78, 82], dtype=np.int8), n)          # A N R
+    ls = rng.choice(np.array([70, 79], dtype=np.int8), n)              # F O
+    qty = [Decimal(int(x)) for x in rng.integers(1, 51, n)]
+    price = [Decimal(int(x)).scaleb(-2) for x in rng.integers(90000, 10494951, n)]
+    disc = [Decimal(int(x)).scaleb(-2) for x in rng.integers(0, 11, n)]
+    tax = [Decimal(int(x)).scaleb(-2) for x in rng.integers(0, 9, n)]
+    ship = rng.integers(-2922, -2922 + 2526, n).astype(np.int32)       # 1992-01-02 .. 1998-12-01
+    cols = [kds.Column("char1", rf), kds.Column("char1", ls), kds.numeric_column(qty),
+            kds.numeric_column(price), kds.numeric_column(disc), kds.numeric_column(tax),
+            kds.Column("date", ship)]
+    one_minus_d = "(numeric_sub (const numeric 1) (var 5 numeric))"
+    one_plus_t = "(numeric_add (const numeric 1) (var 6 numeric))"
+    disc_price = "(numeric_mul (var 4 numeric) %s)" % one_minus_d
+    spec = ("(gpupreagg (qual (date_le (var 7 date) (const date '1998-09-02')))"
+            " (key (var 1 char1)) (key (var 2 char1))"
+            " (psum (var 3 numeric) 0) (psum (var 4 numeric) 2) (psum %s 4) (psum (numeric_mul %s %s) 6)"
+            " (nrows (isnotnull (var 3 numeric))) (nrows (isnotnull (var 4 numeric)))"
+            " (psum (var 5 numeric) 2) (nrows (isnotnull (var 5 numeric))) (nrows))"
+            % (disc_price, disc_price, one_plus_t))
+    half = n // 2
+    chunks = [kds.build_kds("column", [kds.Column(c.sqltype, c.values[s], None) for c in cols])
+              for s in (slice(0, half), slice(half, n))]
+    agg = GpuPreAgg(spec).begin([(65, 18), (70, 10)])
+    for b in chunks:
+        assert agg.fold(b)[0] == 0
+    got = {(r[0], r[1]): r for r in fetch_rows(agg)}
+    agg.end()
+    cutoff = -486
+    assert len(got) == 6
+    for (f, s), r in got.items():
+        idx = [j for j in range(n) if rf[j] == f and ls[j] == s and ship[j] <= cutoff]
+        assert r[2] == sum(qty[j] for j in idx)
+        assert r[3] == sum(price[j] for j in idx)
+        assert r[4] == sum(price[j] * (1 - disc[j]) for j in idx)
+        assert r[5] == sum(price[j] * (1 - disc[j]) * (1 + tax[j]) for j in idx)
+        assert r[6] == r[7] == r[9] == r[10] == len(idx)
+        assert r[8] == sum(disc[j] for j in idx)
+    # and bit for bit against the oracle's partial rows
+    merged = {}
+    for b in chunks:
+        rc, v, isn = oracle.gpupreagg(spec, b, 11)
+        assert rc == 0
+        for i in range(len(v)):
+            key = (int(v[i, 0].view(np.int64)), int(v[i, 1].view(np.int64)))
+            acc = merged.setdefault(key, [0] * 9)
+            for t in range(2, 11):
+                acc[t - 2] += int(v[i, t].view(np.int64))
+    scales = [0, 2, 4, 6, None, None, 2, None, None]
+    for key, acc in merged.items():
+        r = got[key]
+        for t, (a, sc) in enumerate(zip(acc, scales)):
+            want = a if sc is None else Decimal(a).scaleb(-sc)
+            assert r[t + 2] == want
