@@ -275,6 +275,26 @@ strom_task *strom_submit_gpuhashjoin(strom_hashjoin_table *tbl,
 									 strom_done_cb done, void *arg,
 									 int *p_errcode);
 
+/*
+ * Same, followed by kern_gpuhashjoin_projection_slot (opencl_hashjoin.h:
+ * 691-839): the joined rows are materialised into 'kds_dest', a TUPSLOT
+ * kern_data_store whose head (ncols, colmeta, nrooms) the caller filled;
+ * destination column r takes column src_colidx[r] (0-based) of relation
+ * src_depth[r] (0 = outer chunk, d = d-th inner relation).  On completion
+ * kds_dest holds nitems rows.  Fixed-width by-value columns.
+ */
+strom_task *strom_submit_gpuhashjoin_projection(strom_hashjoin_table *tbl,
+												kern_hashjoin *khashjoin,
+												const kern_data_store *kds,
+												strom_dstore *kds_dev,
+												const kern_row_map *krowmap,
+												kern_data_store *kds_dest,
+												const int32_t *src_depth,
+												const int32_t *src_colidx,
+												uint32_t flags,
+												strom_done_cb done, void *arg,
+												int *p_errcode);
+
 /* block until the request finished; returns its errcode.  Frees the task. */
 int			strom_task_wait(strom_task *task, strom_perfmon *pfm_out);
 /* device address of the kern_gpuscan / kern_hashjoin image of a task that

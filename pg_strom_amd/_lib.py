@@ -150,6 +150,9 @@ PROTOTYPES = {
     "strom_hashjoin_table_download": (c_int, [c_void_p, c_void_p, c_size_t]),
     "strom_submit_gpuhashjoin": (c_void_p, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                             c_uint32, c_void_p, c_void_p, ctypes.POINTER(c_int)]),
+    "strom_submit_gpuhashjoin_projection": (c_void_p, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                                       c_void_p, c_void_p, c_void_p, c_uint32,
+                                                       c_void_p, c_void_p, ctypes.POINTER(c_int)]),
     "strom_task_wait": (c_int, [c_void_p, ctypes.POINTER(strom_perfmon)]),
     "strom_task_devptr": (c_void_p, [c_void_p]),
     "strom_synchronize": (None, []),

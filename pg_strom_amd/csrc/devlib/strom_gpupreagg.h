@@ -573,6 +573,301 @@ gpupreagg_dense_generic(kern_gpupreagg *kgpreagg,
 }
 
 /* ====================================================================== *
+ * register accumulators: at most GPUPREAGG_REG_GROUPS dense ids
+ *
+ * LDS atomics cost ~24 (u32) / ~53 (u64) / ~110 (f64) cycles per wave
+ * instruction on gfx950 (profiles/r01_preagg_atomics.txt), so a
+ * low-cardinality GROUP BY (TPC-H Q1: 6 groups, 9 partial columns; any
+ * aggregate without GROUP BY) is atomic-bound in the LDS path whatever
+ * the replication.  Here every thread keeps one accumulator per
+ * (aggregate, group) in registers and folds a row with predicated selects
+ * (no memory traffic at all); at the end a wave tree-reduces with
+ * shuffles and its lane 0 merges into the work-group's LDS image, which
+ * then leaves through the same slab / merge path as the LDS kernels.
+ * ====================================================================== */
+#ifndef GPUPREAGG_REG_GROUPS
+#define GPUPREAGG_REG_GROUPS	8
+#endif
+#ifndef GPUPREAGG_REG_BLOCK
+#define GPUPREAGG_REG_BLOCK		256
+#endif
+#define GPUPREAGG_REG_TILE_ROWS	(GPUPREAGG_REG_BLOCK * 4 * GPUPREAGG_QUADS)
+
+template <int NG>
+struct gpupreagg_reg_state {
+#define X(aidx,resno,OP,NAME)	cl_ulong v_##aidx[NG];
+	GPUPREAGG_AGG_LIST(X)
+#undef X
+	cl_uint		flags[NG];
+};
+
+template <int NG>
+STROM_DEVICE void
+gpupreagg_reg_row(gpupreagg_reg_state<NG> &S, const gpupreagg_dense_ctl *ctl,
+				  const strom_kparams &KP, const strom_kvars &KV,
+				  cl_int param_error, cl_int *chunk_status)
+{
+	cl_int		errcode = param_error;
+	pg_bool_t	rc = gpupreagg_qual_eval(&errcode, KP, KV);
+	cl_uint		gid = 0;
+	bool		out_of_domain = false;
+
+	if (errcode == StromError_Success && !EVAL(rc))
+		return;
+#define X(kidx,resno,NAME)															\
+	{																				\
+		pg_##NAME##_t kv = gpupreagg_key_##kidx(&errcode, KP, KV);					\
+		cl_long		off64 = (cl_long)kv.value - ctl->key_min[kidx];					\
+		cl_uint		range = ctl->key_range[kidx];									\
+		cl_uint		off = (kv.isnull ? range : (cl_uint)off64);						\
+		if (!kv.isnull && (off64 < 0 || off64 >= (cl_long)range))					\
+			out_of_domain = true;													\
+		gid += off * ctl->key_stride[kidx];											\
+	}
+	GPUPREAGG_KEY_LIST(X)
+#undef X
+#define X(aidx,resno,OP,NAME)														\
+	pg_##NAME##_t av_##aidx = gpupreagg_agg_##aidx(&errcode, KP, KV);
+	GPUPREAGG_AGG_LIST(X)
+#undef X
+	if (errcode != StromError_Success)
+	{
+		STROM_SET_ERROR(chunk_status, errcode);
+		return;
+	}
+	if (out_of_domain || gid >= (cl_uint)NG)
+	{
+		STROM_SET_ERROR(chunk_status, StromError_DataStoreOutOfRange);
+		return;
+	}
+	cl_uint		need = GPUPREAGG_FLAG_SEEN;
+#define X(aidx,resno,OP,NAME)														\
+	{																				\
+		typedef pg_##NAME##_base_t base_t;											\
+		bool		has = !av_##aidx.isnull;										\
+		cl_ulong	x;																\
+		if (GPUPREAGG_OP_##OP == GPUPREAGG_OP_NROWS)								\
+			x = (has ? (cl_ulong)(cl_uint)av_##aidx.value : 0);						\
+		else if (gpupreagg_is_float<base_t>::value)									\
+			x = (GPUPREAGG_OP_##OP == GPUPREAGG_OP_PSUM								\
+				 ? (cl_ulong)__double_as_longlong((cl_double)av_##aidx.value)		\
+				 : gpupreagg_f64_ordered((cl_double)av_##aidx.value));				\
+		else																		\
+			x = (cl_ulong)(cl_long)av_##aidx.value;									\
+		if (GPUPREAGG_OP_##OP == GPUPREAGG_OP_PSUM && !gpupreagg_is_float<base_t>::value &&	\
+			has && gpupreagg_int8_near_overflow((cl_long)x))						\
+			STROM_SET_ERROR(chunk_status, StromError_CpuReCheck);					\
+		if (GPUPREAGG_OP_##OP != GPUPREAGG_OP_NROWS && has)							\
+			need |= (2u << aidx);													\
+		_Pragma("unroll")															\
+		for (int g = 0; g < NG; g++)												\
+		{																			\
+			bool hit = (has && gid == (cl_uint)g);									\
+			cl_ulong cur = S.v_##aidx[g];											\
+			cl_ulong nxt = (GPUPREAGG_OP_##OP == GPUPREAGG_OP_NROWS ? cur + x		\
+							: gpupreagg_merge8<GPUPREAGG_OP_##OP == GPUPREAGG_OP_NROWS	\
+											   ? GPUPREAGG_OP_PSUM : GPUPREAGG_OP_##OP, base_t>(cur, x));	\
+			S.v_##aidx[g] = (hit ? nxt : cur);										\
+		}																			\
+	}
+	GPUPREAGG_AGG_LIST(X)
+#undef X
+#pragma unroll
+	for (int g = 0; g < NG; g++)
+		S.flags[g] |= (gid == (cl_uint)g ? need : 0u);
+}
+
+STROM_DEVICE cl_ulong
+gpupreagg_shfl_xor_u64(cl_ulong v, int mask)
+{
+	cl_uint lo = __shfl_xor((cl_uint)v, mask, STROM_WAVE);
+	cl_uint hi = __shfl_xor((cl_uint)(v >> 32), mask, STROM_WAVE);
+	return ((cl_ulong)hi << 32) | lo;
+}
+
+template <int NG>
+__device__ __forceinline__ void
+gpupreagg_reg_kernel_body(kern_gpupreagg *kgpreagg, const kern_data_store *kds,
+						  const gpupreagg_dense_ctl *ctl, char *slabs, char *lds)
+{
+	const kern_parambuf *kparams = KERN_GPUPREAGG_PARAMBUF(kgpreagg);
+	const kern_coldir *coldir = KERN_DATA_STORE_COLDIR(kds);
+	cl_uint		nitems = kds->nitems;
+	cl_uint		ntiles = (nitems + GPUPREAGG_REG_TILE_ROWS - 1) / GPUPREAGG_REG_TILE_ROWS;
+	cl_uint		G = ctl->groups_per_split;
+	cl_int		chunk_status = StromError_Success;
+	cl_int		param_error = StromError_Success;
+	strom_kparams KP;
+	gpupreagg_lds_layout L;
+	gpupreagg_reg_state<NG> S;
+
+	gpupreagg_load_kparams(KP, kparams, &param_error);
+	gpupreagg_lds_layout_init(L, G, 1);
+	/* LDS image (one replica) is only touched at the very end */
+	for (cl_uint i = threadIdx.x * 16; i < L.total; i += GPUPREAGG_REG_BLOCK * 16)
+		*(uint4 *)(lds + i) = make_uint4(0, 0, 0, 0);
+	__syncthreads();
+#define X(aidx,resno,OP,NAME)															\
+	if (GPUPREAGG_OP_##OP == GPUPREAGG_OP_PMIN || GPUPREAGG_OP_##OP == GPUPREAGG_OP_PMAX)	\
+		for (cl_uint i = threadIdx.x; i < G; i += GPUPREAGG_REG_BLOCK)					\
+			((cl_ulong *)(lds + L.vals_off[aidx]))[i] =									\
+				gpupreagg_identity<GPUPREAGG_OP_##OP, pg_##NAME##_base_t>();
+	GPUPREAGG_AGG_LIST(X)
+#undef X
+	__syncthreads();
+#pragma unroll
+	for (int g = 0; g < NG; g++)
+	{
+		S.flags[g] = 0;
+#define X(aidx,resno,OP,NAME)															\
+		S.v_##aidx[g] = (GPUPREAGG_OP_##OP == GPUPREAGG_OP_NROWS ? 0UL :				\
+						 gpupreagg_identity<GPUPREAGG_OP_##OP == GPUPREAGG_OP_NROWS		\
+											? GPUPREAGG_OP_PSUM : GPUPREAGG_OP_##OP,	\
+											pg_##NAME##_base_t>());
+		GPUPREAGG_AGG_LIST(X)
+#undef X
+	}
+#define X(attno,colidx,NAME)													\
+	const char *col_##attno = (const char *)kds + coldir[colidx].values_off;	\
+	const cl_uint *nul_##attno = (coldir[colidx].nulls_off != 0					\
+		? (const cl_uint *)((const char *)kds + coldir[colidx].nulls_off) : NULL);
+	STROM_KVAR_LIST(X)
+#undef X
+	for (cl_uint tile = blockIdx.x; tile < ntiles; tile += gridDim.x)
+	{
+		cl_uint		tile_base = tile * GPUPREAGG_REG_TILE_ROWS;
+		bool		full_tile = (tile_base + GPUPREAGG_REG_TILE_ROWS <= nitems);
+		gpupreagg_column_tile T;
+
+#pragma unroll
+		for (int k = 0; k < GPUPREAGG_QUADS; k++)
+		{
+			cl_uint	row0 = tile_base + (k * GPUPREAGG_REG_BLOCK + threadIdx.x) * 4;
+#define X(attno,colidx,NAME)													\
+			strom_column_load_quad<pg_##NAME##_base_t>(col_##attno, nul_##attno,	\
+													   row0, nitems,				\
+													   T.v_##attno[k], T.nn_##attno[k]);
+			STROM_KVAR_LIST(X)
+#undef X
+		}
+#pragma unroll
+		for (int k = 0; k < GPUPREAGG_QUADS; k++)
+		{
+			cl_uint	row0 = tile_base + (k * GPUPREAGG_REG_BLOCK + threadIdx.x) * 4;
+#pragma unroll
+			for (int j = 0; j < 4; j++)
+			{
+				if (full_tile || row0 + j < nitems)
+				{
+					strom_kvars	KV;
+#define X(attno,colidx,NAME)													\
+					KV.KVAR_##attno = pg_##NAME##_make(T.v_##attno[k][j],			\
+													   !((T.nn_##attno[k] >> j) & 1));
+					STROM_KVAR_LIST(X)
+#undef X
+					KV.__dummy = 0;
+					gpupreagg_reg_row<NG>(S, ctl, KP, KV, param_error, &chunk_status);
+				}
+			}
+		}
+	}
+	/* wave tree reduction, then lane 0 folds into the LDS image */
+#pragma unroll
+	for (int g = 0; g < NG; g++)
+	{
+		cl_uint	flags = S.flags[g];
+#pragma unroll
+		for (int m = 32; m > 0; m >>= 1)
+			flags |= __shfl_xor(flags, m, STROM_WAVE);
+#define X(aidx,resno,OP,NAME)															\
+		{																				\
+			cl_ulong v = S.v_##aidx[g];													\
+			_Pragma("unroll")															\
+			for (int m = 32; m > 0; m >>= 1)											\
+			{																			\
+				cl_ulong o = gpupreagg_shfl_xor_u64(v, m);								\
+				v = (GPUPREAGG_OP_##OP == GPUPREAGG_OP_NROWS ? v + o					\
+					 : gpupreagg_merge8<GPUPREAGG_OP_##OP == GPUPREAGG_OP_NROWS			\
+										? GPUPREAGG_OP_PSUM : GPUPREAGG_OP_##OP,		\
+										pg_##NAME##_base_t>(v, o));						\
+			}																			\
+			if (strom_lane_id() == 0 && (cl_uint)g < G)									\
+			{																			\
+				char *slot = lds + L.vals_off[aidx];									\
+				if (GPUPREAGG_OP_##OP == GPUPREAGG_OP_NROWS)							\
+					__hip_atomic_fetch_add((cl_uint *)slot + g, (cl_uint)v,				\
+										   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);	\
+				else if (flags & (2u << aidx))											\
+				{																		\
+					if (GPUPREAGG_OP_##OP == GPUPREAGG_OP_PSUM)							\
+					{																	\
+						if (gpupreagg_is_float<pg_##NAME##_base_t>::value)				\
+							__hip_atomic_fetch_add((cl_double *)slot + g,				\
+												   __longlong_as_double((long long)v),	\
+												   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);	\
+						else															\
+							__hip_atomic_fetch_add((cl_long *)slot + g, (cl_long)v,		\
+												   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);	\
+					}																	\
+					else if (gpupreagg_is_float<pg_##NAME##_base_t>::value)				\
+					{																	\
+						if (GPUPREAGG_OP_##OP == GPUPREAGG_OP_PMIN)						\
+							__hip_atomic_fetch_min((cl_ulong *)slot + g, v,				\
+												   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);	\
+						else															\
+							__hip_atomic_fetch_max((cl_ulong *)slot + g, v,				\
+												   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);	\
+					}																	\
+					else																\
+					{																	\
+						if (GPUPREAGG_OP_##OP == GPUPREAGG_OP_PMIN)						\
+							__hip_atomic_fetch_min((cl_long *)slot + g, (cl_long)v,		\
+												   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);	\
+						else															\
+							__hip_atomic_fetch_max((cl_long *)slot + g, (cl_long)v,		\
+												   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);	\
+					}																	\
+				}																		\
+			}																			\
+		}
+		GPUPREAGG_AGG_LIST(X)
+#undef X
+		if (strom_lane_id() == 0 && (cl_uint)g < G && flags != 0)
+		{
+			cl_uint *word = (cl_uint *)(lds + ((g * (cl_uint)sizeof(gpupreagg_flags_t)) & ~3u));
+			cl_uint	 shift = ((g * (cl_uint)sizeof(gpupreagg_flags_t)) & 3u) * 8u;
+			__hip_atomic_fetch_or(word, flags << shift, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+		}
+	}
+	/* same slab format as the LDS kernels (block size differs: plain loops) */
+	__syncthreads();
+	{
+		char *slab = slabs + (size_t)blockIdx.x * ctl->slab_bytes;
+		for (cl_uint i = threadIdx.x * 4; i < L.total; i += GPUPREAGG_REG_BLOCK * 4)
+			*(cl_uint *)(slab + i) = *(const cl_uint *)(lds + i);
+	}
+	gpupreagg_writeback_status(&kgpreagg->status, chunk_status);
+}
+
+extern "C" __global__ void
+__launch_bounds__(GPUPREAGG_REG_BLOCK)
+gpupreagg_reg_column(kern_gpupreagg *kgpreagg, const kern_data_store *kds,
+					 const gpupreagg_dense_ctl *ctl, char *slabs)
+{
+	extern __shared__ __attribute__((aligned(16))) char lds[];
+	gpupreagg_reg_kernel_body<GPUPREAGG_REG_GROUPS>(kgpreagg, kds, ctl, slabs, lds);
+}
+
+extern "C" __global__ void
+__launch_bounds__(GPUPREAGG_REG_BLOCK)
+gpupreagg_reg1_column(kern_gpupreagg *kgpreagg, const kern_data_store *kds,
+					  const gpupreagg_dense_ctl *ctl, char *slabs)
+{
+	extern __shared__ __attribute__((aligned(16))) char lds[];
+	gpupreagg_reg_kernel_body<1>(kgpreagg, kds, ctl, slabs, lds);
+}
+
+/* ====================================================================== *
  * slabs -> resident table, fixed order; skipped when the chunk failed
  * ====================================================================== */
 extern "C" __global__ void

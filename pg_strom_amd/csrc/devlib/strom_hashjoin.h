@@ -653,4 +653,74 @@ gpuhashjoin_main_fast(kern_hashjoin *khashjoin,
 	}
 }
 
+/* ====================================================================== *
+ * projection into a TUPSLOT kern_data_store
+ * (kern_gpuhashjoin_projection_slot, opencl_hashjoin.h:691-839).  One
+ * thread per result record; destination column r takes column
+ * src_colidx[r] of relation src_depth[r] (0 = the outer chunk, d = the d-th
+ * inner relation) -- the mapping the reference bakes into the generated
+ * gpuhashjoin_projection_mapping / _datum (gpuhashjoin.c:1026-1181) arrives
+ * here as two small arrays.  Fixed-width by-value columns only.
+ * ====================================================================== */
+extern "C" __global__ void
+__launch_bounds__(256)
+gpuhashjoin_projection_slot(kern_hashjoin *khashjoin,
+							const kern_multihash *kmhash,
+							const kern_data_store *kds,
+							const kern_data_store *ktoast,
+							kern_data_store *kds_dest,
+							const cl_int *src_depth,
+							const cl_int *src_colidx)
+{
+	kern_resultbuf *kresults = KERN_HASHJOIN_RESULTBUF(khashjoin);
+	cl_uint		nrels = kresults->nrels;
+	cl_uint		nitems = kresults->nitems;
+	cl_uint		ncols = kds_dest->ncols;
+
+	/* overflow: the main kernel already said DataStoreNoSpace, nothing to do */
+	if (kresults->errcode != StromError_Success ||
+		nitems > kresults->nrooms || nitems > kds_dest->nrooms)
+	{
+		if (blockIdx.x == 0 && threadIdx.x == 0 && nitems > kds_dest->nrooms)
+			atomicMax(&kresults->errcode, StromError_DataStoreNoSpace);
+		return;
+	}
+	if (blockIdx.x == 0 && threadIdx.x == 0)
+		kds_dest->nitems = nitems;
+	for (cl_uint i = blockIdx.x * blockDim.x + threadIdx.x;
+		 i < nitems;
+		 i += gridDim.x * blockDim.x)
+	{
+		const cl_int *rbuffer = kresults->results + (size_t)nrels * i;
+		Datum	   *values = KERN_DATA_STORE_VALUES(kds_dest, i);
+		cl_char	   *isnull = KERN_DATA_STORE_ISNULL(kds_dest, i);
+
+		for (cl_uint r = 0; r < ncols; r++)
+		{
+			cl_int		depth = src_depth[r];
+			cl_int		col = src_colidx[r];
+			const void *addr = NULL;
+			cl_int		attlen = 0;
+
+			if (depth == 0)
+			{
+				addr = kern_get_datum(kds, ktoast, col, (cl_uint)(rbuffer[0] - 1));
+				attlen = (col < (cl_int)kds->ncols ? kds->colmeta[col].attlen : 0);
+			}
+			else if (depth > 0 && depth < (cl_int)nrels)
+			{
+				const kern_hashtable *kht = KERN_HASHTABLE(kmhash, depth - 1);
+				const kern_hashentry *ent = (const kern_hashentry *)((const char *)kht + rbuffer[depth]);
+				addr = kern_get_datum_tuple(kht->colmeta, &ent->htup, col);
+				attlen = (col < (cl_int)kht->ncols ? kht->colmeta[col].attlen : 0);
+			}
+			Datum	d = 0;
+			if (addr && attlen > 0 && attlen <= 8)
+				__builtin_memcpy(&d, addr, attlen);
+			values[r] = d;
+			isnull[r] = (addr == NULL || attlen <= 0);
+		}
+	}
+}
+
 #endif	/* STROM_HASHJOIN_DEVICE_H */

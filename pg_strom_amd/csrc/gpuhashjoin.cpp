@@ -247,6 +247,9 @@ namespace {
 	} while (0)
 
 struct hashjoin_request {
+	/* projection (optional): TUPSLOT destination + column mapping */
+	kern_data_store	   *kds_dest = nullptr;
+	std::vector<cl_int>	map_depth, map_colidx;
 	strom_hashjoin_table *tbl;
 	kern_hashjoin	   *khj;
 	const kern_data_store *kds;
@@ -379,6 +382,54 @@ gpuhashjoin_launch(strom_task_impl *task, hashjoin_request req)
 		task->pfm.num_kern_exec++;
 	}
 	task_event(task);									/* ev[2] */
+	char	   *d_dest = nullptr;
+	size_t		dest_head = 0, dest_stride = 0;
+	if (req.kds_dest)
+	{
+		/* kern_gpuhashjoin_projection_slot (gpuhashjoin.c:4585-4588, 4883-4968) */
+		kern_data_store *kd = req.kds_dest;
+		int			e2 = 0;
+		hipFunction_t fn_proj = prog->get_function(dev, "gpuhashjoin_projection_slot", &e2);
+		if (!fn_proj)
+		{
+			task_fail(task, e2);
+			return;
+		}
+		dest_head = KDS_HEAD_LENGTH(kd->ncols);
+		dest_stride = KDS_TUPSLOT_STRIDE(kd->ncols);
+		size_t	dest_len = dest_head + dest_stride * (size_t)kd->nrooms;
+		size_t	map_len = sizeof(cl_int) * kd->ncols;
+		d_dest = (char *)dev->pool.alloc(dest_len);
+		cl_int *d_map = (cl_int *)dev->pool.alloc(2 * map_len);
+		if (!d_dest || !d_map)
+		{
+			if (d_dest) dev->pool.release(d_dest);
+			if (d_map) dev->pool.release(d_map);
+			task_fail(task, StromError_OutOfMemory);
+			return;
+		}
+		task->devbufs.push_back(d_dest);
+		task->devbufs.push_back(d_map);
+		/* small, rare: plain synchronous-staging copies are fine here */
+		REQ_CHECK(hipMemcpyAsync(d_dest, kd, dest_head, hipMemcpyHostToDevice, task->stream),
+				  "send kds_dest head");
+		REQ_CHECK(hipMemcpyAsync(d_map, req.map_depth.data(), map_len, hipMemcpyHostToDevice, task->stream),
+				  "send projection map");
+		REQ_CHECK(hipMemcpyAsync(d_map + kd->ncols, req.map_colidx.data(), map_len,
+								 hipMemcpyHostToDevice, task->stream), "send projection map");
+		void	   *a_khj = d_khj;
+		const void *a_km = tbl->d_kmhash;
+		const void *a_kds = d_kds;
+		const void *a_toast = nullptr;
+		void	   *a_dest = d_dest;
+		const void *a_md = d_map;
+		const void *a_mc = d_map + kd->ncols;
+		void	   *args[] = { &a_khj, &a_km, &a_kds, &a_toast, &a_dest, &a_md, &a_mc };
+		unsigned	pgrid = (unsigned)dev->prop.multiProcessorCount * 8;
+		REQ_CHECK(hipModuleLaunchKernel(fn_proj, pgrid, 1, 1, 256, 1, 1, 0, task->stream, args, nullptr),
+				  "launch gpuhashjoin projection");
+		task->pfm.num_kern_proj++;
+	}
 	char	   *stage_res = (stage ? stage + STROMALIGN(head_len) : nullptr);
 	REQ_CHECK(hipMemcpyAsync(stage_res ? (void *)stage_res : (void *)kres_host,
 							 d_khj + res_offset, offsetof(kern_resultbuf, results),
@@ -388,16 +439,36 @@ gpuhashjoin_launch(strom_task_impl *task, hashjoin_request req)
 	task->pfm.bytes_dma_recv += offsetof(kern_resultbuf, results);
 	task_event(task);									/* ev[3] */
 	bool	results_on_device = (req.flags & STROM_RESULTS_ON_DEVICE) != 0;
-	task->finish = [kres_host, d_khj, res_offset, results_on_device, stage_res](strom_task_impl *t)
+	kern_data_store *kds_dest = req.kds_dest;
+	task->finish = [kres_host, d_khj, res_offset, results_on_device, stage_res,
+					kds_dest, d_dest, dest_head, dest_stride](strom_task_impl *t)
 	{
 		if (stage_res)
 			memcpy(kres_host, stage_res, offsetof(kern_resultbuf, results));
+		if (kres_host->errcode == StromError_Success && kds_dest &&
+			kres_host->nitems > kds_dest->nrooms)
+			kres_host->errcode = StromError_DataStoreNoSpace;
 		if (kres_host->errcode != StromError_Success)
 		{
 			/* DataStoreNoSpace: nitems holds the room a retry needs
 			 * (gpuhashjoin.c:4330-4425); CpuReCheck: no CPU path for joins */
 			t->errcode = kres_host->errcode;
 			return;
+		}
+		if (kds_dest)
+		{
+			size_t	len = dest_stride * (size_t)kres_host->nitems;
+			hipError_t rc = hipSuccess;
+			if (len > 0)
+				rc = hipMemcpyAsync((char *)kds_dest + dest_head, d_dest + dest_head, len,
+									hipMemcpyDeviceToHost, t->stream);
+			if (rc == hipSuccess)
+				rc = hipStreamSynchronize(t->stream);
+			if (rc != hipSuccess)
+				t->errcode = hip_errcode(rc, "recv kds_dest");
+			kds_dest->nitems = kres_host->nitems;
+			t->pfm.num_dma_recv++;
+			t->pfm.bytes_dma_recv += len;
 		}
 		if (results_on_device || kres_host->nitems == 0)
 			return;
@@ -417,6 +488,13 @@ gpuhashjoin_launch(strom_task_impl *task, hashjoin_request req)
 
 }	/* namespace */
 
+static strom_task *
+submit_hashjoin_common(strom_hashjoin_table *tbl, kern_hashjoin *khashjoin,
+					   const kern_data_store *kds, strom_dstore *kds_dev,
+					   const kern_row_map *krowmap,
+					   kern_data_store *kds_dest, const int32_t *src_depth, const int32_t *src_colidx,
+					   uint32_t flags, strom_done_cb done, void *arg, int *p_errcode);
+
 extern "C" strom_task *
 strom_submit_gpuhashjoin(strom_hashjoin_table *tbl,
 						 kern_hashjoin *khashjoin,
@@ -424,6 +502,37 @@ strom_submit_gpuhashjoin(strom_hashjoin_table *tbl,
 						 const kern_row_map *krowmap,
 						 uint32_t flags,
 						 strom_done_cb done, void *arg, int *p_errcode)
+{
+	return submit_hashjoin_common(tbl, khashjoin, kds, kds_dev, krowmap, nullptr, nullptr, nullptr,
+								  flags, done, arg, p_errcode);
+}
+
+extern "C" strom_task *
+strom_submit_gpuhashjoin_projection(strom_hashjoin_table *tbl,
+									kern_hashjoin *khashjoin,
+									const kern_data_store *kds, strom_dstore *kds_dev,
+									const kern_row_map *krowmap,
+									kern_data_store *kds_dest,
+									const int32_t *src_depth, const int32_t *src_colidx,
+									uint32_t flags,
+									strom_done_cb done, void *arg, int *p_errcode)
+{
+	if (!kds_dest || !src_depth || !src_colidx || kds_dest->format != KDS_FORMAT_TUPSLOT)
+	{
+		if (p_errcode)
+			*p_errcode = StromError_BadRequestMessage;
+		return nullptr;
+	}
+	return submit_hashjoin_common(tbl, khashjoin, kds, kds_dev, krowmap, kds_dest, src_depth, src_colidx,
+								  flags, done, arg, p_errcode);
+}
+
+static strom_task *
+submit_hashjoin_common(strom_hashjoin_table *tbl, kern_hashjoin *khashjoin,
+					   const kern_data_store *kds, strom_dstore *kds_dev,
+					   const kern_row_map *krowmap,
+					   kern_data_store *kds_dest, const int32_t *src_depth, const int32_t *src_colidx,
+					   uint32_t flags, strom_done_cb done, void *arg, int *p_errcode)
 {
 	int		dummy;
 	if (!p_errcode)
@@ -450,6 +559,12 @@ strom_submit_gpuhashjoin(strom_hashjoin_table *tbl,
 	req.kds_dev = kds_dev;
 	req.krowmap = (krowmap && krowmap->nvalids >= 0) ? krowmap : nullptr;
 	req.flags = flags;
+	if (kds_dest)
+	{
+		req.kds_dest = kds_dest;
+		req.map_depth.assign(src_depth, src_depth + kds_dest->ncols);
+		req.map_colidx.assign(src_colidx, src_colidx + kds_dest->ncols);
+	}
 	kern_data_store head;
 	if (kds)
 		memcpy(&head, kds, offsetof(kern_data_store, colmeta));

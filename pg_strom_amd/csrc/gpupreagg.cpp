@@ -56,6 +56,7 @@ struct strom_gpupreagg {
 	char			   *d_ctl = nullptr;	/* device copy of ctl */
 	char			   *d_slabs = nullptr;
 	int					block = 1024, quads = 2;
+	int					reg_groups = 0;		/* 1 or 8: register-accumulator kernel, 0: LDS */
 	std::mutex			lock;
 
 	/* mirrors gpupreagg_image_offset / gpupreagg_table_offset of
@@ -171,6 +172,16 @@ setup_geometry(strom_gpupreagg *sess, const strom_preagg_domain *dom)
 	}
 	if (const char *v = getenv("STROM_GPUPREAGG_NREP"))
 		ctl.nrep = std::max(1, atoi(v));
+	/*
+	 * a handful of groups: accumulate in registers (gpupreagg_reg_column),
+	 * LDS atomics are the bottleneck of the replicated-table path
+	 */
+	sess->reg_groups = 0;
+	if (ctl.nsplits == 1 && ctl.ngroups <= 8 && !getenv("STROM_GPUPREAGG_NO_REG"))
+	{
+		sess->reg_groups = (ctl.ngroups == 1 ? 1 : 8);
+		ctl.nrep = 1;
+	}
 	sess->lds_bytes = sess->image_offset(sess->nsections(), ctl.groups_per_split, ctl.nrep);
 	ctl.slab_bytes = STROM_TYPEALIGN(256, sess->image_offset(sess->nsections(), ctl.groups_per_split, 1));
 	sess->table_bytes = sess->table_offset(sess->nsections(), ctl.ngroups);
@@ -181,6 +192,8 @@ setup_geometry(strom_gpupreagg *sess, const strom_preagg_domain *dom)
 		per_cu = std::max(1, atoi(v));
 	size_t	wgs = (size_t)dev->prop.multiProcessorCount * per_cu;
 	wgs = std::max<size_t>(ctl.nsplits, wgs - wgs % ctl.nsplits);
+	if (sess->reg_groups)
+		wgs = (size_t)dev->prop.multiProcessorCount * 4;	/* 256-thread work-groups */
 	ctl.nslabs = (cl_uint)wgs;
 	sess->has_domain = true;
 	return 0;
@@ -247,7 +260,10 @@ gpupreagg_launch(strom_task_impl *task, preagg_request req)
 	task->stream = dev->streams[0];
 
 	bool	use_column = (req.format == KDS_FORMAT_COLUMN && req.krowmap == nullptr);
-	hipFunction_t fn = prog->get_function(dev, use_column ? "gpupreagg_dense_column"
+	bool	use_reg = (use_column && sess->reg_groups != 0);
+	hipFunction_t fn = prog->get_function(dev, use_reg ? (sess->reg_groups == 1 ? "gpupreagg_reg1_column"
+																			  : "gpupreagg_reg_column")
+										  : use_column ? "gpupreagg_dense_column"
 										  : "gpupreagg_dense_generic", &errcode);
 	hipFunction_t fn_merge = fn ? prog->get_function(dev, "gpupreagg_dense_merge", &errcode) : nullptr;
 	if (!fn || !fn_merge)
@@ -324,7 +340,7 @@ gpupreagg_launch(strom_task_impl *task, preagg_request req)
 		void	   *args_col[] = { &a_kg, &a_kds, &a_ctl, &a_slabs };
 		void	   *args_gen[] = { &a_kg, &a_kds, &a_toast, &a_map, &a_ctl, &a_slabs };
 		void	   *args_mrg[] = { &a_kg, &a_ctl, &a_slabs, &a_table };
-		REQ_CHECK(hipModuleLaunchKernel(fn, sess->ctl.nslabs, 1, 1, sess->block, 1, 1,
+		REQ_CHECK(hipModuleLaunchKernel(fn, sess->ctl.nslabs, 1, 1, use_reg ? 256 : sess->block, 1, 1,
 										(unsigned)sess->lds_bytes, task->stream,
 										use_column ? args_col : args_gen, nullptr),
 				  "launch gpupreagg reduction");

@@ -168,6 +168,65 @@ class GpuHashJoin(object):
             res.retried = True
         return res
 
+    def join_chunk_project(self, chunk, dest_columns, nrooms=None):
+        """join + kern_gpuhashjoin_projection_slot: dest_columns is a list of
+        (depth, attno, sqltype) -- depth 0 is the outer chunk, d the d-th inner
+        relation.  Returns (nitems, [(values, isnull)] per destination column)"""
+        from .kds import SQL_TYPES, KDS_HEAD_FIXED
+        nrows = chunk.nitems if isinstance(chunk, runtime.DeviceStore) else KdsHead(chunk).nitems
+        if nrooms is None:
+            nrooms = int(nrows * self.ratio * 1.1) + 1
+        ncols = len(dest_columns)
+        for attempt in range(2):
+            head_len = (KDS_HEAD_FIXED + 8 * ncols + 15) & ~15
+            stride = (9 * ncols + 7) & ~7
+            dest = aligned_buffer(head_len + stride * nrooms, 64)
+            dest[:head_len] = 0
+            u32 = dest[:KDS_HEAD_FIXED].view(np.uint32)
+            u32[2] = len(dest)
+            u32[4] = ncols
+            u32[6] = nrooms
+            dest[36] = 3                                     # KDS_FORMAT_TUPSLOT
+            for i, (_, _, typ) in enumerate(dest_columns):
+                attlen = SQL_TYPES[typ][1]
+                meta = dest[KDS_HEAD_FIXED + 8 * i: KDS_HEAD_FIXED + 8 * i + 8]
+                meta[0] = 1
+                meta[1] = attlen
+                meta[2:4] = np.array([attlen], dtype=np.int16).view(np.uint8)
+                meta[4:6] = np.array([i + 1], dtype=np.int16).view(np.uint8)
+                meta[6:8] = np.array([-1], dtype=np.int16).view(np.uint8)
+            depth = np.array([d for d, _, _ in dest_columns], dtype=np.int32)
+            colidx = np.array([a - 1 for _, a, _ in dest_columns], dtype=np.int32)
+            khj, res_off = self._make_khj(nrooms, True)
+            if isinstance(chunk, runtime.DeviceStore):
+                kds_host, kds_dev = None, chunk.handle
+            else:
+                kds_host, kds_dev = chunk.ctypes.data, None
+            err = ctypes.c_int(0)
+            task = lib.strom_submit_gpuhashjoin_projection(
+                self.table, khj.ctypes.data, kds_host, kds_dev, None, dest.ctypes.data,
+                depth.ctypes.data, colidx.ctypes.data, 0, None, None, ctypes.byref(err))
+            if not task:
+                raise runtime.StromError(err.value, "strom_submit_gpuhashjoin_projection")
+            rc = lib.strom_task_wait(task, None)
+            nitems = int(np.frombuffer(khj[res_off + 8:res_off + 12].tobytes(), dtype=np.uint32)[0])
+            if rc == ERR_NOSPACE and attempt == 0:
+                nrooms = nitems
+                continue
+            if rc != 0:
+                raise runtime.StromError(rc, "GpuHashJoin projection")
+            body = dest[head_len:head_len + stride * nitems].reshape(nitems, stride)
+            values = body[:, :8 * ncols].copy().view(np.uint64).reshape(nitems, ncols)
+            isnull = body[:, 8 * ncols:9 * ncols] != 0
+            out = []
+            for i, (_, _, typ) in enumerate(dest_columns):
+                dt = np.dtype(SQL_TYPES[typ][2])
+                raw = np.ascontiguousarray(values[:, i])
+                v = raw.view(dt) if dt.itemsize == 8 else \
+                    raw.view(np.uint8).reshape(-1, 8)[:, :dt.itemsize].copy().view(dt).reshape(-1)
+                out.append((v, isnull[:, i]))
+            return nitems, out
+
     def end(self):
         if self.table:
             lib.strom_hashjoin_table_release(self.table)

@@ -86,17 +86,17 @@ class GpuScan(object):
                                         flags, None, None, ctypes.byref(err))
         if not task:
             raise runtime.StromError(err.value, "strom_submit_gpuscan")
-        return (task, kgs, res_off, chunk, rowmap_buf)
+        return (task, kgs, res_off, chunk, rowmap_buf, bool(flags & STROM_RESULTS_ON_DEVICE))
 
     def collect(self, pending):
-        task, kgs, res_off, _chunk, _rm = pending
+        task, kgs, res_off, _chunk, _rm, on_device = pending
         pfm = strom_perfmon()
         rc = lib.strom_task_wait(task, ctypes.byref(pfm))
         if rc != 0:
             if rc == -11:
                 raise runtime.StromError(rc, "GpuScan kernel build:\n" + self.program.errmsg())
             raise runtime.StromError(rc, "GpuScan")
-        if len(kgs) - res_off <= 32:     # head only (results stayed on the device)
+        if on_device:                    # head only (results stayed on the device)
             head = np.frombuffer(kgs[res_off:res_off + 20].tobytes(), dtype=np.int32)
             nitems, errcode, results = int(head[2]), int(head[3]), np.zeros(0, dtype=np.int32)
         else:

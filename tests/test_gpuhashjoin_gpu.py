@@ -132,6 +132,30 @@ def test_float_and_int8_keys():
     run_and_compare("(gpuhashjoin (rel (hashkey (var 1 int8) 1 int8)))", outer, [inner], [[1]], expect_mode="hash")
 
 
+def test_projection_into_tupslot():
+    """kern_gpuhashjoin_projection_slot: joined rows materialised as TUPSLOT"""
+    pk, payload, pkn, fk, fkn = fact_dim(50000, 3000, 77, dup=True)
+    amount = np.random.default_rng(7).random(len(fk))
+    inner = kds.build_kds("row", [kds.Column("int4", pk, pkn), kds.Column("int4", payload, payload % 17 == 0)])
+    km = build_multihash([(inner, [1])])
+    for ofmt in ("row", "column"):
+        outer = kds.build_kds(ofmt, [kds.Column("int4", fk, fkn), kds.Column("float8", amount)])
+        rc, n, want = oracle.gpuhashjoin(C3_SPEC, outer, [inner])
+        join = GpuHashJoin(C3_SPEC, row_population_ratio=0.2).begin(km)     # forces one retry
+        nitems, cols = join.join_chunk_project(outer, [(0, 2, "float8"), (1, 2, "int4"), (0, 1, "int4"), (1, 1, "int4")])
+        join.end()
+        assert nitems == n
+        (amt, amt_n), (pay, pay_n), (ofk, ofk_n), (ipk, ipk_n) = cols
+        assert not amt_n.any() and not ofk_n.any() and not ipk_n.any()
+        assert np.array_equal(ofk, ipk)                                   # join keys equal
+        got = sorted(zip(ofk.tolist(), amt.tolist(), [None if x else int(v) for v, x in zip(pay, pay_n)]),
+                     key=lambda t: (t[0], t[1], -1 if t[2] is None else t[2]))
+        exp = sorted(((int(fk[o - 1]), float(amount[o - 1]),
+                       None if payload[r] % 17 == 0 else int(payload[r])) for o, r in want.tolist()),
+                     key=lambda t: (t[0], t[1], -1 if t[2] is None else t[2]))
+        assert got == exp
+
+
 def test_c3_shape_properties_at_1e8():
     """BASELINE configs[2] shape: 1e8 fact x 1e6 dim on int4, 80% hit.
     Properties instead of the tuple-at-a-time oracle: every record's keys are
