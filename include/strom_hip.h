@@ -137,6 +137,18 @@ strom_dstore *strom_dstore_wrap(void *devptr, size_t length, int dindex);
 void	   *strom_dstore_devptr(strom_dstore *ds);
 size_t		strom_dstore_length(strom_dstore *ds);
 void		strom_dstore_release(strom_dstore *ds);
+/* copy the first 'length' bytes of the chunk image back to the host */
+int			strom_dstore_download(strom_dstore *ds, void *host, size_t length);
+/*
+ * Transpose a resident ROW / ROW_FLAT / TUPSLOT chunk (fixed-width columns)
+ * into a new resident KDS_FORMAT_COLUMN chunk on the device -- the step the
+ * reference has no need for because its kernels walk heap tuples
+ * (kern_get_datum_rs, opencl_common.h:886-907).  'type_oids' (ncols
+ * entries, may be NULL) enables the zone maps GpuPreAgg / GpuHashJoin use.
+ * Blocks until the chunk is ready; *p_kern_ns receives the device time.
+ */
+strom_dstore *strom_dstore_to_column(strom_dstore *src, const int32_t *type_oids, int ntypes,
+									 uint64_t *p_kern_ns, int *p_errcode);
 
 /* ------------------------------------------------------------------ *
  * requests

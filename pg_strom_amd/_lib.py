@@ -125,6 +125,9 @@ PROTOTYPES = {
     "strom_dstore_devptr": (c_void_p, [c_void_p]),
     "strom_dstore_length": (c_size_t, [c_void_p]),
     "strom_dstore_release": (None, [c_void_p]),
+    "strom_dstore_download": (c_int, [c_void_p, c_void_p, c_size_t]),
+    "strom_dstore_to_column": (c_void_p, [c_void_p, ctypes.POINTER(ctypes.c_int32), c_int,
+                                          ctypes.POINTER(c_uint64), ctypes.POINTER(c_int)]),
     "strom_submit_gpuscan": (c_void_p, [c_uint64, c_void_p, c_void_p, c_void_p, c_void_p,
                                         c_uint32, c_void_p, c_void_p, ctypes.POINTER(c_int)]),
     "strom_gpupreagg_create": (c_void_p, [c_uint64, ctypes.POINTER(strom_preagg_target), c_int,

@@ -435,11 +435,20 @@ kern_writeback_error_status(cl_int *error_status, cl_int own_errcode)
  * for 8-byte types), so a wave's loads of a 4-byte column are one fully
  * coalesced 1 KiB request.  values_off is 256-B aligned by construction.
  * ---------------------------------------------------------------- */
+__device__ const cl_uint strom_all_ones[2] = { 0xffffffffu, 0xffffffffu };
+/* explicit global address space: a select between two generic pointers
+ * would make the load a flat_load */
+typedef const __attribute__((address_space(1))) cl_uint *strom_global_uint_p;
+
 template <typename BASE> struct strom_quad {
 	typedef BASE vec_t __attribute__((ext_vector_type(4)));
 };
 
-template <typename BASE>
+/* FULL: the caller knows (wave-uniformly) that the whole tile is in range;
+ * the loads then sit in straight-line code and all of a tile's requests
+ * are in flight before the first use -- with the per-lane range check
+ * every load ends in its own branch join and the waits serialise */
+template <typename BASE, bool FULL, bool NONULL = false>
 STROM_DEVICE void
 strom_column_load_quad(const char *values, const cl_uint *notnull,
 					   cl_uint row0, cl_uint nitems,
@@ -447,16 +456,22 @@ strom_column_load_quad(const char *values, const cl_uint *notnull,
 {
 	typedef typename strom_quad<BASE>::vec_t vec_t;
 
-	if (row0 + 4 <= nitems)
+	if (FULL || row0 + 4 <= nitems)
 	{
+		/* the bitmap word is fetched unconditionally (from an all-ones
+		 * word when the column has no NULL): a branch around it would
+		 * put a full vmcnt(0) wait between the value loads */
+		strom_global_uint_p nnword = (notnull ? (strom_global_uint_p)(notnull + (row0 >> 5))
+									  : (strom_global_uint_p)strom_all_ones);
 #if !defined(COLUMN_LOAD_NT) || COLUMN_LOAD_NT
 		/* streamed once: do not keep the lines in L2 / Infinity Cache */
 		vec_t	q = __builtin_nontemporal_load((const vec_t *)(values + (size_t)row0 * sizeof(BASE)));
 #else
 		vec_t	q = *(const vec_t *)(values + (size_t)row0 * sizeof(BASE));
 #endif
+		cl_uint	w = (NONULL ? 0xffffffffu : *nnword);	/* NONULL: no chunk column has a bitmap */
 		v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
-		nnbits = (notnull ? (notnull[row0 >> 5] >> (row0 & 31)) & 0xf : 0xf);
+		nnbits = (w >> (row0 & 31)) & 0xf;
 	}
 	else
 	{

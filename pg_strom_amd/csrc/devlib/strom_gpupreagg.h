@@ -478,6 +478,10 @@ gpupreagg_dense_column(kern_gpupreagg *kgpreagg,
 		? (const cl_uint *)((const char *)kds + coldir[colidx].nulls_off) : NULL);
 	STROM_KVAR_LIST(X)
 #undef X
+	bool		any_nulls = false;		/* wave-uniform: picks the bitmap-free loader */
+#define X(attno,colidx,NAME)	any_nulls = any_nulls || (nul_##attno != NULL);
+	STROM_KVAR_LIST(X)
+#undef X
 
 	for (cl_uint tile = wg_in_split; tile < ntiles; tile += wgs_per_split)
 	{
@@ -485,16 +489,47 @@ gpupreagg_dense_column(kern_gpupreagg *kgpreagg,
 		bool		full_tile = (tile_base + GPUPREAGG_TILE_ROWS <= nitems);
 		gpupreagg_column_tile T;
 
-#pragma unroll
-		for (int k = 0; k < GPUPREAGG_QUADS; k++)
+		if (full_tile && !any_nulls)
 		{
-			cl_uint	row0 = tile_base + (k * GPUPREAGG_BLOCK + threadIdx.x) * 4;
+#pragma unroll
+			for (int k = 0; k < GPUPREAGG_QUADS; k++)
+			{
+				cl_uint	row0 = tile_base + (k * GPUPREAGG_BLOCK + threadIdx.x) * 4;
 #define X(attno,colidx,NAME)													\
-			strom_column_load_quad<pg_##NAME##_base_t>(col_##attno, nul_##attno,	\
-													   row0, nitems,				\
-													   T.v_##attno[k], T.nn_##attno[k]);
-			STROM_KVAR_LIST(X)
+				strom_column_load_quad<pg_##NAME##_base_t, true, true>(col_##attno, nul_##attno,	\
+														   row0, nitems,				\
+														   T.v_##attno[k], T.nn_##attno[k]);
+				STROM_KVAR_LIST(X)
 #undef X
+			}
+		}
+		else if (full_tile)
+		{
+#pragma unroll
+			for (int k = 0; k < GPUPREAGG_QUADS; k++)
+			{
+				cl_uint	row0 = tile_base + (k * GPUPREAGG_BLOCK + threadIdx.x) * 4;
+#define X(attno,colidx,NAME)													\
+				strom_column_load_quad<pg_##NAME##_base_t, true>(col_##attno, nul_##attno,	\
+														   row0, nitems,				\
+														   T.v_##attno[k], T.nn_##attno[k]);
+				STROM_KVAR_LIST(X)
+#undef X
+			}
+		}
+		else
+		{
+#pragma unroll
+			for (int k = 0; k < GPUPREAGG_QUADS; k++)
+			{
+				cl_uint	row0 = tile_base + (k * GPUPREAGG_BLOCK + threadIdx.x) * 4;
+#define X(attno,colidx,NAME)													\
+				strom_column_load_quad<pg_##NAME##_base_t, false>(col_##attno, nul_##attno,	\
+														   row0, nitems,				\
+														   T.v_##attno[k], T.nn_##attno[k]);
+				STROM_KVAR_LIST(X)
+#undef X
+			}
 		}
 #pragma unroll
 		for (int k = 0; k < GPUPREAGG_QUADS; k++)
@@ -733,22 +768,57 @@ gpupreagg_reg_kernel_body(kern_gpupreagg *kgpreagg, const kern_data_store *kds,
 		? (const cl_uint *)((const char *)kds + coldir[colidx].nulls_off) : NULL);
 	STROM_KVAR_LIST(X)
 #undef X
+	bool		any_nulls = false;		/* wave-uniform: picks the bitmap-free loader */
+#define X(attno,colidx,NAME)	any_nulls = any_nulls || (nul_##attno != NULL);
+	STROM_KVAR_LIST(X)
+#undef X
 	for (cl_uint tile = blockIdx.x; tile < ntiles; tile += gridDim.x)
 	{
 		cl_uint		tile_base = tile * GPUPREAGG_REG_TILE_ROWS;
 		bool		full_tile = (tile_base + GPUPREAGG_REG_TILE_ROWS <= nitems);
 		gpupreagg_column_tile T;
 
-#pragma unroll
-		for (int k = 0; k < GPUPREAGG_QUADS; k++)
+		if (full_tile && !any_nulls)
 		{
-			cl_uint	row0 = tile_base + (k * GPUPREAGG_REG_BLOCK + threadIdx.x) * 4;
+#pragma unroll
+			for (int k = 0; k < GPUPREAGG_QUADS; k++)
+			{
+				cl_uint	row0 = tile_base + (k * GPUPREAGG_REG_BLOCK + threadIdx.x) * 4;
 #define X(attno,colidx,NAME)													\
-			strom_column_load_quad<pg_##NAME##_base_t>(col_##attno, nul_##attno,	\
-													   row0, nitems,				\
-													   T.v_##attno[k], T.nn_##attno[k]);
-			STROM_KVAR_LIST(X)
+				strom_column_load_quad<pg_##NAME##_base_t, true, true>(col_##attno, nul_##attno,	\
+														   row0, nitems,				\
+														   T.v_##attno[k], T.nn_##attno[k]);
+				STROM_KVAR_LIST(X)
 #undef X
+			}
+		}
+		else if (full_tile)
+		{
+#pragma unroll
+			for (int k = 0; k < GPUPREAGG_QUADS; k++)
+			{
+				cl_uint	row0 = tile_base + (k * GPUPREAGG_REG_BLOCK + threadIdx.x) * 4;
+#define X(attno,colidx,NAME)													\
+				strom_column_load_quad<pg_##NAME##_base_t, true>(col_##attno, nul_##attno,	\
+														   row0, nitems,				\
+														   T.v_##attno[k], T.nn_##attno[k]);
+				STROM_KVAR_LIST(X)
+#undef X
+			}
+		}
+		else
+		{
+#pragma unroll
+			for (int k = 0; k < GPUPREAGG_QUADS; k++)
+			{
+				cl_uint	row0 = tile_base + (k * GPUPREAGG_REG_BLOCK + threadIdx.x) * 4;
+#define X(attno,colidx,NAME)													\
+				strom_column_load_quad<pg_##NAME##_base_t, false>(col_##attno, nul_##attno,	\
+														   row0, nitems,				\
+														   T.v_##attno[k], T.nn_##attno[k]);
+				STROM_KVAR_LIST(X)
+#undef X
+			}
 		}
 #pragma unroll
 		for (int k = 0; k < GPUPREAGG_QUADS; k++)
@@ -849,13 +919,332 @@ gpupreagg_reg_kernel_body(kern_gpupreagg *kgpreagg, const kern_data_store *kds,
 	gpupreagg_writeback_status(&kgpreagg->status, chunk_status);
 }
 
+/* ====================================================================== *
+ * lane-private LDS accumulators: 2 .. 32 dense ids
+ *
+ * Every thread owns one accumulator per (aggregate, group) in LDS at
+ * [group][thread] -- a wave's lanes always hit 64 consecutive words
+ * whatever their groups are (group stride = block size * width, a
+ * multiple of the bank row), so a fold is a plain conflict-free
+ * ds_read / op / ds_write: 2-8 LDS cycles per wave instruction against
+ * the 24 / 53 / 110 of the u32 / u64 / f64 LDS atomics
+ * (profiles/r01_preagg_atomics.txt).  "Seen" / "has a value" flags are
+ * bit masks in registers.  At the end a wave tree-reduces its 64 entries
+ * per (aggregate, group) with shuffles and lane 0 folds into the
+ * work-group image, which leaves through the same slab / merge path.
+ * ====================================================================== */
+struct gpupreagg_priv_state {
+	cl_uint		poff[GPUPREAGG_NAGGS + 1];
+	cl_uint		has[GPUPREAGG_NAGGS + 1];
+	cl_uint		seen;
+};
+
+STROM_DEVICE void
+gpupreagg_priv_row(char *lds, gpupreagg_priv_state &S, const gpupreagg_dense_ctl *ctl,
+				   const strom_kparams &KP, const strom_kvars &KV, cl_uint G,
+				   cl_int param_error, cl_int *chunk_status)
+{
+	cl_int		errcode = param_error;
+	pg_bool_t	rc = gpupreagg_qual_eval(&errcode, KP, KV);
+	cl_uint		gid = 0;
+	bool		out_of_domain = false;
+
+	if (errcode == StromError_Success && !EVAL(rc))
+		return;
+#define X(kidx,resno,NAME)															\
+	{																				\
+		pg_##NAME##_t kv = gpupreagg_key_##kidx(&errcode, KP, KV);					\
+		cl_long		off64 = (cl_long)kv.value - ctl->key_min[kidx];					\
+		cl_uint		range = ctl->key_range[kidx];									\
+		cl_uint		off = (kv.isnull ? range : (cl_uint)off64);						\
+		if (!kv.isnull && (off64 < 0 || off64 >= (cl_long)range))					\
+			out_of_domain = true;													\
+		gid += off * ctl->key_stride[kidx];											\
+	}
+	GPUPREAGG_KEY_LIST(X)
+#undef X
+#define X(aidx,resno,OP,NAME)														\
+	pg_##NAME##_t av_##aidx = gpupreagg_agg_##aidx(&errcode, KP, KV);
+	GPUPREAGG_AGG_LIST(X)
+#undef X
+	if (errcode != StromError_Success)
+	{
+		STROM_SET_ERROR(chunk_status, errcode);
+		return;
+	}
+	if (out_of_domain || gid >= G)
+	{
+		STROM_SET_ERROR(chunk_status, StromError_DataStoreOutOfRange);
+		return;
+	}
+	cl_uint		bit = 1u << gid;
+	cl_uint		idx = gid * GPUPREAGG_REG_BLOCK + threadIdx.x;
+
+	S.seen |= bit;
+	/* the slots are this thread's own: read them all, fold, write them all
+	 * back -- three LDS reads in flight instead of three round trips */
+#define X(aidx,resno,OP,NAME)														\
+	cl_ulong	cur_##aidx = (GPUPREAGG_OP_##OP == GPUPREAGG_OP_NROWS					\
+		? (cl_ulong)((const cl_uint *)(lds + S.poff[aidx]))[idx]						\
+		: ((const cl_ulong *)(lds + S.poff[aidx]))[idx]);
+	GPUPREAGG_AGG_LIST(X)
+#undef X
+#define X(aidx,resno,OP,NAME)														\
+	if (!av_##aidx.isnull)															\
+	{																				\
+		typedef pg_##NAME##_base_t base_t;											\
+		if (GPUPREAGG_OP_##OP == GPUPREAGG_OP_NROWS)								\
+			cur_##aidx += (cl_uint)av_##aidx.value;									\
+		else																		\
+		{																			\
+			cl_ulong  x;															\
+			if (gpupreagg_is_float<base_t>::value)									\
+				x = (GPUPREAGG_OP_##OP == GPUPREAGG_OP_PSUM							\
+					 ? (cl_ulong)__double_as_longlong((cl_double)av_##aidx.value)	\
+					 : gpupreagg_f64_ordered((cl_double)av_##aidx.value));			\
+			else																	\
+			{																		\
+				x = (cl_ulong)(cl_long)av_##aidx.value;								\
+				if (GPUPREAGG_OP_##OP == GPUPREAGG_OP_PSUM &&						\
+					gpupreagg_int8_near_overflow((cl_long)x))						\
+					STROM_SET_ERROR(chunk_status, StromError_CpuReCheck);			\
+			}																		\
+			cur_##aidx = gpupreagg_merge8<GPUPREAGG_OP_##OP == GPUPREAGG_OP_NROWS	\
+										  ? GPUPREAGG_OP_PSUM : GPUPREAGG_OP_##OP,	\
+										  base_t>(cur_##aidx, x);					\
+			S.has[aidx] |= bit;														\
+		}																			\
+	}
+	GPUPREAGG_AGG_LIST(X)
+#undef X
+#define X(aidx,resno,OP,NAME)														\
+	if (GPUPREAGG_OP_##OP == GPUPREAGG_OP_NROWS)									\
+		((cl_uint *)(lds + S.poff[aidx]))[idx] = (cl_uint)cur_##aidx;				\
+	else																			\
+		((cl_ulong *)(lds + S.poff[aidx]))[idx] = cur_##aidx;
+	GPUPREAGG_AGG_LIST(X)
+#undef X
+}
+
 extern "C" __global__ void
 __launch_bounds__(GPUPREAGG_REG_BLOCK)
-gpupreagg_reg_column(kern_gpupreagg *kgpreagg, const kern_data_store *kds,
-					 const gpupreagg_dense_ctl *ctl, char *slabs)
+gpupreagg_priv_column(kern_gpupreagg *kgpreagg, const kern_data_store *kds,
+					  const gpupreagg_dense_ctl *ctl, char *slabs)
 {
 	extern __shared__ __attribute__((aligned(16))) char lds[];
-	gpupreagg_reg_kernel_body<GPUPREAGG_REG_GROUPS>(kgpreagg, kds, ctl, slabs, lds);
+	const kern_parambuf *kparams = KERN_GPUPREAGG_PARAMBUF(kgpreagg);
+	const kern_coldir *coldir = KERN_DATA_STORE_COLDIR(kds);
+	cl_uint		nitems = kds->nitems;
+	cl_uint		ntiles = (nitems + GPUPREAGG_REG_TILE_ROWS - 1) / GPUPREAGG_REG_TILE_ROWS;
+	cl_uint		G = ctl->groups_per_split;		/* 2 .. 32, one split */
+	cl_int		chunk_status = StromError_Success;
+	cl_int		param_error = StromError_Success;
+	strom_kparams KP;
+	gpupreagg_lds_layout L;
+	gpupreagg_priv_state S;
+
+	gpupreagg_load_kparams(KP, kparams, &param_error);
+	gpupreagg_lds_layout_init(L, G, 1);
+	/* work-group image, touched again only at the very end */
+	for (cl_uint i = threadIdx.x * 16; i < L.total; i += GPUPREAGG_REG_BLOCK * 16)
+		*(uint4 *)(lds + i) = make_uint4(0, 0, 0, 0);
+	__syncthreads();
+	S.seen = 0;
+	{
+		cl_uint	off = L.total;
+#define X(aidx,resno,OP,NAME)															\
+		S.poff[aidx] = off;																\
+		S.has[aidx] = 0;																\
+		off += G * GPUPREAGG_REG_BLOCK * (GPUPREAGG_OP_##OP == GPUPREAGG_OP_NROWS ? 4u : 8u);	\
+		if (GPUPREAGG_OP_##OP == GPUPREAGG_OP_PMIN || GPUPREAGG_OP_##OP == GPUPREAGG_OP_PMAX)	\
+			for (cl_uint i = threadIdx.x; i < G; i += GPUPREAGG_REG_BLOCK)				\
+				((cl_ulong *)(lds + L.vals_off[aidx]))[i] =								\
+					gpupreagg_identity<GPUPREAGG_OP_##OP, pg_##NAME##_base_t>();		\
+		for (cl_uint g = 0; g < G; g++)													\
+		{																				\
+			if (GPUPREAGG_OP_##OP == GPUPREAGG_OP_NROWS)								\
+				((cl_uint *)(lds + S.poff[aidx]))[g * GPUPREAGG_REG_BLOCK + threadIdx.x] = 0;	\
+			else																		\
+				((cl_ulong *)(lds + S.poff[aidx]))[g * GPUPREAGG_REG_BLOCK + threadIdx.x] =	\
+					gpupreagg_identity<GPUPREAGG_OP_##OP == GPUPREAGG_OP_NROWS			\
+									   ? GPUPREAGG_OP_PSUM : GPUPREAGG_OP_##OP,			\
+									   pg_##NAME##_base_t>();							\
+		}
+		GPUPREAGG_AGG_LIST(X)
+#undef X
+	}
+	__syncthreads();
+#define X(attno,colidx,NAME)													\
+	const char *col_##attno = (const char *)kds + coldir[colidx].values_off;	\
+	const cl_uint *nul_##attno = (coldir[colidx].nulls_off != 0					\
+		? (const cl_uint *)((const char *)kds + coldir[colidx].nulls_off) : NULL);
+	STROM_KVAR_LIST(X)
+#undef X
+	bool		any_nulls = false;		/* wave-uniform: picks the bitmap-free loader */
+#define X(attno,colidx,NAME)	any_nulls = any_nulls || (nul_##attno != NULL);
+	STROM_KVAR_LIST(X)
+#undef X
+	for (cl_uint tile = blockIdx.x; tile < ntiles; tile += gridDim.x)
+	{
+		cl_uint		tile_base = tile * GPUPREAGG_REG_TILE_ROWS;
+		bool		full_tile = (tile_base + GPUPREAGG_REG_TILE_ROWS <= nitems);
+		gpupreagg_column_tile T;
+
+		if (full_tile && !any_nulls)
+		{
+#pragma unroll
+			for (int k = 0; k < GPUPREAGG_QUADS; k++)
+			{
+				cl_uint	row0 = tile_base + (k * GPUPREAGG_REG_BLOCK + threadIdx.x) * 4;
+#define X(attno,colidx,NAME)													\
+				strom_column_load_quad<pg_##NAME##_base_t, true, true>(col_##attno, nul_##attno,	\
+														   row0, nitems,				\
+														   T.v_##attno[k], T.nn_##attno[k]);
+				STROM_KVAR_LIST(X)
+#undef X
+			}
+		}
+		else if (full_tile)
+		{
+#pragma unroll
+			for (int k = 0; k < GPUPREAGG_QUADS; k++)
+			{
+				cl_uint	row0 = tile_base + (k * GPUPREAGG_REG_BLOCK + threadIdx.x) * 4;
+#define X(attno,colidx,NAME)													\
+				strom_column_load_quad<pg_##NAME##_base_t, true>(col_##attno, nul_##attno,	\
+														   row0, nitems,				\
+														   T.v_##attno[k], T.nn_##attno[k]);
+				STROM_KVAR_LIST(X)
+#undef X
+			}
+		}
+		else
+		{
+#pragma unroll
+			for (int k = 0; k < GPUPREAGG_QUADS; k++)
+			{
+				cl_uint	row0 = tile_base + (k * GPUPREAGG_REG_BLOCK + threadIdx.x) * 4;
+#define X(attno,colidx,NAME)													\
+				strom_column_load_quad<pg_##NAME##_base_t, false>(col_##attno, nul_##attno,	\
+														   row0, nitems,				\
+														   T.v_##attno[k], T.nn_##attno[k]);
+				STROM_KVAR_LIST(X)
+#undef X
+			}
+		}
+#pragma unroll
+		for (int k = 0; k < GPUPREAGG_QUADS; k++)
+		{
+			cl_uint	row0 = tile_base + (k * GPUPREAGG_REG_BLOCK + threadIdx.x) * 4;
+#pragma unroll
+			for (int j = 0; j < 4; j++)
+			{
+				if (full_tile || row0 + j < nitems)
+				{
+					strom_kvars	KV;
+#define X(attno,colidx,NAME)													\
+					KV.KVAR_##attno = pg_##NAME##_make(T.v_##attno[k][j],			\
+													   !((T.nn_##attno[k] >> j) & 1));
+					STROM_KVAR_LIST(X)
+#undef X
+					KV.__dummy = 0;
+					gpupreagg_priv_row(lds, S, ctl, KP, KV, G, param_error, &chunk_status);
+				}
+			}
+		}
+	}
+	/* wave tree reduction of the lane-private entries, lane 0 folds into
+	 * the work-group image */
+	cl_uint		wave_seen = S.seen;
+#pragma unroll
+	for (int m = 32; m > 0; m >>= 1)
+		wave_seen |= __shfl_xor(wave_seen, m, STROM_WAVE);
+#define X(aidx,resno,OP,NAME)															\
+	{																					\
+		_Pragma("unroll")																\
+		for (int m = 32; m > 0; m >>= 1)												\
+			S.has[aidx] |= __shfl_xor(S.has[aidx], m, STROM_WAVE);						\
+	}
+	GPUPREAGG_AGG_LIST(X)
+#undef X
+	for (cl_uint g = 0; g < G; g++)
+	{
+		if (!((wave_seen >> g) & 1))
+			continue;					/* wave-uniform */
+		cl_uint		idx = g * GPUPREAGG_REG_BLOCK + threadIdx.x;
+		cl_uint		flags = GPUPREAGG_FLAG_SEEN;
+#define X(aidx,resno,OP,NAME)															\
+		{																				\
+			cl_ulong v = (GPUPREAGG_OP_##OP == GPUPREAGG_OP_NROWS						\
+						  ? (cl_ulong)((const cl_uint *)(lds + S.poff[aidx]))[idx]		\
+						  : ((const cl_ulong *)(lds + S.poff[aidx]))[idx]);				\
+			_Pragma("unroll")															\
+			for (int m = 32; m > 0; m >>= 1)											\
+			{																			\
+				cl_ulong o = gpupreagg_shfl_xor_u64(v, m);								\
+				v = (GPUPREAGG_OP_##OP == GPUPREAGG_OP_NROWS ? v + o					\
+					 : gpupreagg_merge8<GPUPREAGG_OP_##OP == GPUPREAGG_OP_NROWS			\
+										? GPUPREAGG_OP_PSUM : GPUPREAGG_OP_##OP,		\
+										pg_##NAME##_base_t>(v, o));						\
+			}																			\
+			bool has = (GPUPREAGG_OP_##OP != GPUPREAGG_OP_NROWS && ((S.has[aidx] >> g) & 1));	\
+			if (has)																	\
+				flags |= (2u << aidx);													\
+			if (strom_lane_id() == 0)													\
+			{																			\
+				char *slot = lds + L.vals_off[aidx];									\
+				if (GPUPREAGG_OP_##OP == GPUPREAGG_OP_NROWS)							\
+					__hip_atomic_fetch_add((cl_uint *)slot + g, (cl_uint)v,				\
+										   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);	\
+				else if (has)															\
+				{																		\
+					if (GPUPREAGG_OP_##OP == GPUPREAGG_OP_PSUM)							\
+					{																	\
+						if (gpupreagg_is_float<pg_##NAME##_base_t>::value)				\
+							__hip_atomic_fetch_add((cl_double *)slot + g,				\
+												   __longlong_as_double((long long)v),	\
+												   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);	\
+						else															\
+							__hip_atomic_fetch_add((cl_long *)slot + g, (cl_long)v,		\
+												   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);	\
+					}																	\
+					else if (gpupreagg_is_float<pg_##NAME##_base_t>::value)				\
+					{																	\
+						if (GPUPREAGG_OP_##OP == GPUPREAGG_OP_PMIN)						\
+							__hip_atomic_fetch_min((cl_ulong *)slot + g, v,				\
+												   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);	\
+						else															\
+							__hip_atomic_fetch_max((cl_ulong *)slot + g, v,				\
+												   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);	\
+					}																	\
+					else																\
+					{																	\
+						if (GPUPREAGG_OP_##OP == GPUPREAGG_OP_PMIN)						\
+							__hip_atomic_fetch_min((cl_long *)slot + g, (cl_long)v,		\
+												   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);	\
+						else															\
+							__hip_atomic_fetch_max((cl_long *)slot + g, (cl_long)v,		\
+												   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);	\
+					}																	\
+				}																		\
+			}																			\
+		}
+		GPUPREAGG_AGG_LIST(X)
+#undef X
+		if (strom_lane_id() == 0)
+		{
+			cl_uint *word = (cl_uint *)(lds + ((g * (cl_uint)sizeof(gpupreagg_flags_t)) & ~3u));
+			cl_uint	 shift = ((g * (cl_uint)sizeof(gpupreagg_flags_t)) & 3u) * 8u;
+			__hip_atomic_fetch_or(word, flags << shift, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+		}
+	}
+	__syncthreads();
+	{
+		char *slab = slabs + (size_t)blockIdx.x * ctl->slab_bytes;
+		for (cl_uint i = threadIdx.x * 4; i < L.total; i += GPUPREAGG_REG_BLOCK * 4)
+			*(cl_uint *)(slab + i) = *(const cl_uint *)(lds + i);
+	}
+	gpupreagg_writeback_status(&kgpreagg->status, chunk_status);
 }
 
 extern "C" __global__ void
@@ -877,60 +1266,112 @@ gpupreagg_dense_merge(const kern_gpupreagg *kgpreagg,
 					  const char *slabs,
 					  char *table)
 {
+	/*
+	 * 256 threads = GL lanes along consecutive groups (coalesced slab
+	 * reads) x WS stripes over the slabs.  A thread folds slabs stripe,
+	 * stripe+WS, ... in that order, the stripes are then combined by a
+	 * fixed-shape tree in LDS: the result depends on the launch geometry
+	 * only, never on timing -- float sums are reproducible.
+	 */
+	__shared__ cl_ulong	red_val[256];
+	__shared__ cl_uint	red_flags[256];
 	cl_uint		N = ctl->ngroups;
 	cl_uint		G = ctl->groups_per_split;
 	cl_uint		nsplits = ctl->nsplits;
 	cl_uint		wgs_per_split = ctl->nslabs / nsplits;
+	size_t		slab_bytes = ctl->slab_bytes;
 	cl_uint	   *t_flags = (cl_uint *)table;
+	cl_uint		GL = 1;
 
 	if (kgpreagg->status != StromError_Success)
 		return;
-	for (cl_uint gid = blockIdx.x * blockDim.x + threadIdx.x;
-		 gid < N;
-		 gid += gridDim.x * blockDim.x)
+	while (GL < N && GL < 64)
+		GL <<= 1;
+	cl_uint		WS = 256 / GL;
+	cl_uint		lane = threadIdx.x % GL;
+	cl_uint		stripe = threadIdx.x / GL;
+
+	for (cl_uint gbase = blockIdx.x * GL; gbase < N; gbase += gridDim.x * GL)
 	{
-		cl_uint		split = gid / G;
-		cl_uint		lgid = gid - split * G;
+		cl_uint		gid = gbase + lane;
+		bool		valid = (gid < N);
+		cl_uint		split = (valid ? gid / G : 0);
+		cl_uint		lgid = (valid ? gid - split * G : 0);
+		const char *slab0 = slabs + (size_t)split * slab_bytes;
+		size_t		slab_step = (size_t)nsplits * slab_bytes;
 		cl_uint		flags = 0;
 
-		for (cl_uint w = 0; w < wgs_per_split; w++)
+		if (valid)
+			for (cl_uint w = stripe; w < wgs_per_split; w += WS)
+				flags |= ((const gpupreagg_flags_t *)(slab0 + w * slab_step))[lgid];
+		red_flags[threadIdx.x] = flags;
+		__syncthreads();
+		for (cl_uint s = WS / 2; s > 0; s >>= 1)
 		{
-			const char *slab = slabs + (size_t)(w * nsplits + split) * ctl->slab_bytes;
-			flags |= ((const gpupreagg_flags_t *)slab)[lgid];
+			if (stripe < s)
+				red_flags[threadIdx.x] |= red_flags[threadIdx.x + s * GL];
+			__syncthreads();
 		}
-		if (flags == 0)
-			continue;
-		cl_uint		had = t_flags[gid];
+		flags = red_flags[lane];
+		__syncthreads();
+		cl_uint		had = (valid && stripe == 0 ? t_flags[gid] : 0);
 #define X(aidx,resno,OP,NAME)																	\
 		{																						\
 			cl_uint		s_vals = gpupreagg_image_offset(1 + aidx, G, 1);						\
 			cl_ulong   *t_vals = (cl_ulong *)(table + gpupreagg_table_offset(1 + aidx, N));	\
-			if (GPUPREAGG_OP_##OP == GPUPREAGG_OP_NROWS)										\
+			cl_ulong	acc = (GPUPREAGG_OP_##OP == GPUPREAGG_OP_NROWS ? 0UL :					\
+							   gpupreagg_identity<GPUPREAGG_OP_##OP == GPUPREAGG_OP_NROWS		\
+												  ? GPUPREAGG_OP_PSUM : GPUPREAGG_OP_##OP,		\
+												  pg_##NAME##_base_t>());						\
+			bool		live = (valid && (GPUPREAGG_OP_##OP == GPUPREAGG_OP_NROWS				\
+										  ? flags != 0 : (flags & (2u << aidx)) != 0));			\
+			if (live)																			\
 			{																					\
-				cl_ulong sum = 0;																\
-				for (cl_uint w = 0; w < wgs_per_split; w++)										\
-					sum += ((const cl_uint *)(slabs + (size_t)(w * nsplits + split) *			\
-											  ctl->slab_bytes + s_vals))[lgid];					\
-				t_vals[gid] += sum;																\
-			}																					\
-			else if (flags & (2u << aidx))														\
-			{																					\
-				cl_ulong acc = gpupreagg_identity<GPUPREAGG_OP_##OP, pg_##NAME##_base_t>();		\
-				for (cl_uint w = 0; w < wgs_per_split; w++)										\
+				for (cl_uint w = stripe; w < wgs_per_split; w += WS)							\
 				{																				\
-					const char *slab = slabs + (size_t)(w * nsplits + split) * ctl->slab_bytes;	\
-					if (((const gpupreagg_flags_t *)slab)[lgid] & (2u << aidx))					\
-						acc = gpupreagg_merge8<GPUPREAGG_OP_##OP, pg_##NAME##_base_t>			\
+					const char *slab = slab0 + w * slab_step;									\
+					if (GPUPREAGG_OP_##OP == GPUPREAGG_OP_NROWS)								\
+						acc += ((const cl_uint *)(slab + s_vals))[lgid];						\
+					else if (((const gpupreagg_flags_t *)slab)[lgid] & (2u << aidx))			\
+						acc = gpupreagg_merge8<GPUPREAGG_OP_##OP == GPUPREAGG_OP_NROWS			\
+											   ? GPUPREAGG_OP_PSUM : GPUPREAGG_OP_##OP,			\
+											   pg_##NAME##_base_t>								\
 							(acc, ((const cl_ulong *)(slab + s_vals))[lgid]);					\
 				}																				\
-				t_vals[gid] = (had & (2u << aidx))												\
-					? gpupreagg_merge8<GPUPREAGG_OP_##OP, pg_##NAME##_base_t>(t_vals[gid], acc)	\
-					: acc;																		\
 			}																					\
+			red_val[threadIdx.x] = acc;															\
+			__syncthreads();																	\
+			for (cl_uint s = WS / 2; s > 0; s >>= 1)											\
+			{																					\
+				if (stripe < s)																	\
+				{																				\
+					cl_ulong o = red_val[threadIdx.x + s * GL];									\
+					red_val[threadIdx.x] = (GPUPREAGG_OP_##OP == GPUPREAGG_OP_NROWS				\
+						? red_val[threadIdx.x] + o												\
+						: gpupreagg_merge8<GPUPREAGG_OP_##OP == GPUPREAGG_OP_NROWS				\
+										   ? GPUPREAGG_OP_PSUM : GPUPREAGG_OP_##OP,				\
+										   pg_##NAME##_base_t>(red_val[threadIdx.x], o));		\
+				}																				\
+				__syncthreads();																\
+			}																					\
+			if (live && stripe == 0)															\
+			{																					\
+				acc = red_val[threadIdx.x];														\
+				if (GPUPREAGG_OP_##OP == GPUPREAGG_OP_NROWS)									\
+					t_vals[gid] += acc;															\
+				else																			\
+					t_vals[gid] = (had & (2u << aidx))											\
+						? gpupreagg_merge8<GPUPREAGG_OP_##OP == GPUPREAGG_OP_NROWS				\
+										   ? GPUPREAGG_OP_PSUM : GPUPREAGG_OP_##OP,				\
+										   pg_##NAME##_base_t>(t_vals[gid], acc)				\
+						: acc;																	\
+			}																					\
+			__syncthreads();																	\
 		}
 		GPUPREAGG_AGG_LIST(X)
 #undef X
-		t_flags[gid] = had | flags;
+		if (valid && stripe == 0 && flags != 0)
+			t_flags[gid] = had | flags;
 	}
 }
 

@@ -221,24 +221,60 @@ gpuscan_qual_column(kern_gpuscan *kgpuscan, const kern_data_store *kds)
 		? (const cl_uint *)((const char *)kds + coldir[colidx].nulls_off) : NULL);
 	STROM_KVAR_LIST(X)
 #undef X
+	bool		any_nulls = false;		/* wave-uniform: picks the bitmap-free loader */
+#define X(attno,colidx,NAME)	any_nulls = any_nulls || (nul_##attno != NULL);
+	STROM_KVAR_LIST(X)
+#undef X
 
 	for (cl_uint tile = blockIdx.x; tile < ntiles; tile += gridDim.x)
 	{
 		cl_uint		tile_base = tile * GPUSCAN_TILE_ROWS;
+		bool		full_tile = (tile_base + GPUSCAN_TILE_ROWS <= nitems);
 		gpuscan_column_tile T;
 		int			st[GPUSCAN_QUADS][4];
 
 		/* issue every load of the tile before the first use */
-#pragma unroll
-		for (int k = 0; k < GPUSCAN_QUADS; k++)
+		if (full_tile && !any_nulls)
 		{
-			cl_uint	row0 = tile_base + (k * GPUSCAN_BLOCK + threadIdx.x) * 4;
+#pragma unroll
+			for (int k = 0; k < GPUSCAN_QUADS; k++)
+			{
+				cl_uint	row0 = tile_base + (k * GPUSCAN_BLOCK + threadIdx.x) * 4;
 #define X(attno,colidx,NAME)													\
-			strom_column_load_quad<pg_##NAME##_base_t>(col_##attno, nul_##attno,	\
-													   row0, nitems,				\
-													   T.v_##attno[k], T.nn_##attno[k]);
-			STROM_KVAR_LIST(X)
+				strom_column_load_quad<pg_##NAME##_base_t, true, true>(col_##attno, nul_##attno,	\
+														   row0, nitems,				\
+														   T.v_##attno[k], T.nn_##attno[k]);
+				STROM_KVAR_LIST(X)
 #undef X
+			}
+		}
+		else if (full_tile)
+		{
+#pragma unroll
+			for (int k = 0; k < GPUSCAN_QUADS; k++)
+			{
+				cl_uint	row0 = tile_base + (k * GPUSCAN_BLOCK + threadIdx.x) * 4;
+#define X(attno,colidx,NAME)													\
+				strom_column_load_quad<pg_##NAME##_base_t, true>(col_##attno, nul_##attno,	\
+														   row0, nitems,				\
+														   T.v_##attno[k], T.nn_##attno[k]);
+				STROM_KVAR_LIST(X)
+#undef X
+			}
+		}
+		else
+		{
+#pragma unroll
+			for (int k = 0; k < GPUSCAN_QUADS; k++)
+			{
+				cl_uint	row0 = tile_base + (k * GPUSCAN_BLOCK + threadIdx.x) * 4;
+#define X(attno,colidx,NAME)													\
+				strom_column_load_quad<pg_##NAME##_base_t, false>(col_##attno, nul_##attno,	\
+														   row0, nitems,				\
+														   T.v_##attno[k], T.nn_##attno[k]);
+				STROM_KVAR_LIST(X)
+#undef X
+			}
 		}
 		if (fill + GPUSCAN_TILE_ROWS > GPUSCAN_STAGE)
 		{

@@ -514,24 +514,60 @@ gpuhashjoin_main_fast(kern_hashjoin *khashjoin,
 		? (const cl_uint *)((const char *)kds + coldir[colidx].nulls_off) : NULL);
 	STROM_KVAR_LIST(X)
 #undef X
+	bool		any_nulls = false;		/* wave-uniform: picks the bitmap-free loader */
+#define X(attno,colidx,NAME)	any_nulls = any_nulls || (nul_##attno != NULL);
+	STROM_KVAR_LIST(X)
+#undef X
 
 	for (cl_uint tile = blockIdx.x; tile < ntiles; tile += gridDim.x)
 	{
 		cl_uint		tile_base = tile * HASHJOIN_TILE_ROWS;
+		bool		full_tile = (tile_base + HASHJOIN_TILE_ROWS <= nitems);
 		hashjoin_column_tile T;
 		cl_uint		match[HASHJOIN_QUADS][4];
 		cl_uint		my_prefix[HASHJOIN_QUADS];
 
-#pragma unroll
-		for (int k = 0; k < HASHJOIN_QUADS; k++)
+		if (full_tile && !any_nulls)
 		{
-			cl_uint	row0 = tile_base + (k * HASHJOIN_BLOCK + threadIdx.x) * 4;
+#pragma unroll
+			for (int k = 0; k < HASHJOIN_QUADS; k++)
+			{
+				cl_uint	row0 = tile_base + (k * HASHJOIN_BLOCK + threadIdx.x) * 4;
 #define X(attno,colidx,NAME)													\
-			strom_column_load_quad<pg_##NAME##_base_t>(col_##attno, nul_##attno,	\
-													   row0, nitems,				\
-													   T.v_##attno[k], T.nn_##attno[k]);
-			STROM_KVAR_LIST(X)
+				strom_column_load_quad<pg_##NAME##_base_t, true, true>(col_##attno, nul_##attno,	\
+														   row0, nitems,				\
+														   T.v_##attno[k], T.nn_##attno[k]);
+				STROM_KVAR_LIST(X)
 #undef X
+			}
+		}
+		else if (full_tile)
+		{
+#pragma unroll
+			for (int k = 0; k < HASHJOIN_QUADS; k++)
+			{
+				cl_uint	row0 = tile_base + (k * HASHJOIN_BLOCK + threadIdx.x) * 4;
+#define X(attno,colidx,NAME)													\
+				strom_column_load_quad<pg_##NAME##_base_t, true>(col_##attno, nul_##attno,	\
+														   row0, nitems,				\
+														   T.v_##attno[k], T.nn_##attno[k]);
+				STROM_KVAR_LIST(X)
+#undef X
+			}
+		}
+		else
+		{
+#pragma unroll
+			for (int k = 0; k < HASHJOIN_QUADS; k++)
+			{
+				cl_uint	row0 = tile_base + (k * HASHJOIN_BLOCK + threadIdx.x) * 4;
+#define X(attno,colidx,NAME)													\
+				strom_column_load_quad<pg_##NAME##_base_t, false>(col_##attno, nul_##attno,	\
+														   row0, nitems,				\
+														   T.v_##attno[k], T.nn_##attno[k]);
+				STROM_KVAR_LIST(X)
+#undef X
+			}
 		}
 		/* every slot read of the tile is issued before the first is used */
 #pragma unroll

@@ -1,0 +1,216 @@
+/*
+ * strom_ingest.h -- ROW / ROW_FLAT / TUPSLOT -> KDS_FORMAT_COLUMN on the device
+ *
+ * The step in front of the hot path: PostgreSQL hands
+ * over heap pages (KDS_FORMAT_ROW, datastore.c:556-710); the streaming
+ * kernels want column arrays.  One thread per row walks its tuple ONCE
+ * (the single pass of kern_get_datum_tuple, opencl_common.h:817-864) and
+ * stores every fixed-width attribute into the destination column at the
+ * row's index -- consecutive lanes write consecutive addresses; the
+ * not-null bitmap words come from one __ballot per column.  Zone-map
+ * min/max of integer-like columns are folded with wave reductions.
+ */
+#ifndef STROM_INGEST_DEVICE_H
+#define STROM_INGEST_DEVICE_H
+
+#define INGEST_MAXCOLS	64
+
+STROM_DEVICE const HeapTupleHeaderData *
+ingest_get_tuple(const kern_data_store *src, cl_uint row)
+{
+	if (src->format == KDS_FORMAT_ROW)
+		return kern_get_tuple_rs(src, row);
+	if (src->format == KDS_FORMAT_ROW_FLAT)
+		return kern_get_tuple_rsflat(src, row);
+	return NULL;
+}
+
+extern "C" __global__ void
+__launch_bounds__(256)
+ingest_to_column(const kern_data_store *src, kern_data_store *dst,
+				 const cl_int *type_oids, cl_uint *col_has_null)
+{
+	/* per work-group zone maps / NULL flags: global atomics on one address
+	 * serialise (a per-wave atomic pair costs more than the transpose) */
+	__shared__ cl_ulong	s_min[INGEST_MAXCOLS];
+	__shared__ cl_ulong	s_max[INGEST_MAXCOLS];
+	__shared__ cl_uint	s_hasnull[INGEST_MAXCOLS];
+	cl_uint		nitems = src->nitems;
+	cl_uint		ncols = src->ncols;
+	kern_coldir *coldir = KERN_DATA_STORE_COLDIR(dst);
+	cl_uint		lane = threadIdx.x & 63;
+
+	for (cl_uint c = threadIdx.x; c < INGEST_MAXCOLS; c += blockDim.x)
+	{
+		s_min[c] = ~0UL;
+		s_max[c] = 0UL;
+		s_hasnull[c] = 0;
+	}
+	__syncthreads();
+
+	for (cl_uint base = (blockIdx.x * blockDim.x) & ~63u;
+		 base < nitems;
+		 base += (gridDim.x * blockDim.x))
+	{
+		cl_uint		row = base + threadIdx.x;		/* blockDim is a multiple of 64 */
+		bool		valid = (row < nitems);
+		const HeapTupleHeaderData *htup = NULL;
+		cl_uint		offset = 0, natts = 0;
+		bool		hasnull = false;
+
+		if (valid && src->format != KDS_FORMAT_TUPSLOT)
+		{
+			htup = ingest_get_tuple(src, row);
+			if (htup)
+			{
+				offset = htup->t_hoff;
+				natts = htup->t_infomask2 & HEAP_NATTS_MASK;
+				hasnull = (htup->t_infomask & HEAP_HASNULL) != 0;
+			}
+		}
+		for (cl_uint c = 0; c < ncols; c++)
+		{
+			kern_colmeta cm = src->colmeta[c];
+			const char *addr = NULL;
+
+			if (valid)
+			{
+				if (src->format == KDS_FORMAT_TUPSLOT)
+				{
+					if (!KERN_DATA_STORE_ISNULL(src, row)[c])
+						addr = (const char *)(KERN_DATA_STORE_VALUES(src, row) + c);
+				}
+				else if (htup && c < natts &&
+						 !(hasnull && !(htup->t_bits[c >> 3] & (1 << (c & 7)))))
+				{
+					if (cm.attlen > 0)
+						offset = STROM_TYPEALIGN(cm.attalign, offset);
+					else if (!strom_varatt_not_pad_byte((const char *)htup + offset))
+						offset = STROM_TYPEALIGN(cm.attalign, offset);
+					addr = (const char *)htup + offset;
+					offset += (cm.attlen > 0 ? (cl_uint)cm.attlen : strom_varsize_any(addr));
+				}
+			}
+			/* value */
+			cl_long		v = 0;
+			if (addr && cm.attlen > 0 && cm.attlen <= 8)
+			{
+				char *out = (char *)dst + coldir[c].values_off + (size_t)cm.attlen * row;
+				switch (cm.attlen)
+				{
+					case 1: { cl_char x = *(const cl_char *)addr; *(cl_char *)out = x; v = x; } break;
+					case 2: { cl_short x = strom_fetch<cl_short>(addr); *(cl_short *)out = x; v = x; } break;
+					case 4: { cl_int x = strom_fetch<cl_int>(addr); *(cl_int *)out = x; v = x; } break;
+					default:{ cl_long x = strom_fetch<cl_long>(addr); *(cl_long *)out = x; v = x; } break;
+				}
+			}
+			else if (valid && cm.attlen > 0 && cm.attlen <= 8)
+			{
+				/* NULL slot holds zero: reads of it are deterministic */
+				char *out = (char *)dst + coldir[c].values_off + (size_t)cm.attlen * row;
+				for (int b = 0; b < cm.attlen; b++)
+					out[b] = 0;
+			}
+			/* not-null bitmap: one ballot -> two 32-bit words per wave */
+			strom_lanemask_t nn = __ballot(addr != NULL);
+			strom_lanemask_t vv = __ballot(valid);
+			if (coldir[c].nulls_off != 0 && vv != 0)
+			{
+				cl_uint *words = (cl_uint *)((char *)dst + coldir[c].nulls_off);
+				cl_uint	 w0 = (base + (threadIdx.x & ~63u)) >> 5;
+				if (lane == 0)
+					words[w0] = (cl_uint)nn;
+				if (lane == 32 && (vv >> 32) != 0)
+					words[w0 + 1] = (cl_uint)(nn >> 32);
+			}
+			if (nn != vv && lane == 0)
+				s_hasnull[c] = 1;
+			/* zone map: order-preserving u64 image of the value (sign bit
+			 * flipped for integers; the usual IEEE trick for floats, NaN
+			 * left out), unsigned min / max over the wave, one atomic pair */
+			cl_int	oid = (type_oids ? type_oids[c] : 0);
+			if (oid != 0 && oid != STROM_NUMERICOID && cm.attlen > 0 && cm.attlen <= 8)
+			{
+				bool		isflt = (oid == STROM_FLOAT4OID || oid == STROM_FLOAT8OID);
+				bool		ok = (addr != NULL);
+				cl_ulong	key;
+
+				if (isflt)
+				{
+					cl_double d = (cm.attlen == 4 ? (cl_double)__int_as_float((cl_int)v)
+								   : __longlong_as_double((long long)v));
+					cl_ulong bits = (cl_ulong)__double_as_longlong(d);
+					ok = ok && !__builtin_isnan(d);
+					key = (bits & 0x8000000000000000UL) ? ~bits : (bits | 0x8000000000000000UL);
+				}
+				else
+					key = (cl_ulong)v ^ 0x8000000000000000UL;
+				cl_ulong mn = (ok ? key : ~0UL);
+				cl_ulong mx = (ok ? key : 0UL);
+#pragma unroll
+				for (int m = 32; m > 0; m >>= 1)
+				{
+					cl_ulong o1 = ((cl_ulong)(cl_uint)__shfl_xor((cl_int)(mn >> 32), m, 64) << 32) |
+						(cl_uint)__shfl_xor((cl_int)mn, m, 64);
+					cl_ulong o2 = ((cl_ulong)(cl_uint)__shfl_xor((cl_int)(mx >> 32), m, 64) << 32) |
+						(cl_uint)__shfl_xor((cl_int)mx, m, 64);
+					mn = (o1 < mn ? o1 : mn);
+					mx = (o2 > mx ? o2 : mx);
+				}
+				if (lane == 0 && mn <= mx)
+				{
+					atomicMin((unsigned long long *)&s_min[c], (unsigned long long)mn);
+					atomicMax((unsigned long long *)&s_max[c], (unsigned long long)mx);
+				}
+			}
+		}
+	}
+	__syncthreads();
+	for (cl_uint c = threadIdx.x; c < ncols; c += blockDim.x)
+	{
+		if (s_hasnull[c])
+			col_has_null[c] = 1;
+		if (s_min[c] <= s_max[c])
+		{
+			atomicMin((unsigned long long *)&coldir[c].minval, (unsigned long long)s_min[c]);
+			atomicMax((unsigned long long *)&coldir[c].maxval, (unsigned long long)s_max[c]);
+		}
+	}
+}
+
+/* after the pass: drop the bitmap of columns that turned out NULL-free and
+ * decode the zone map (the host seeded minval = ~0, maxval = 0) */
+extern "C" __global__ void
+ingest_finish(kern_data_store *dst, const cl_int *type_oids, const cl_uint *col_has_null)
+{
+	kern_coldir *coldir = KERN_DATA_STORE_COLDIR(dst);
+	for (cl_uint c = threadIdx.x; c < dst->ncols; c += blockDim.x)
+	{
+		if (!col_has_null[c])
+			coldir[c].nulls_off = 0;
+		cl_int		oid = (type_oids ? type_oids[c] : 0);
+		bool		isflt = (oid == STROM_FLOAT4OID || oid == STROM_FLOAT8OID);
+		cl_ulong	mn = (cl_ulong)coldir[c].minval;
+		cl_ulong	mx = (cl_ulong)coldir[c].maxval;
+
+		if (oid == 0 || oid == STROM_NUMERICOID || mn > mx)
+		{
+			coldir[c].stat_flags = 0;
+			coldir[c].minval = coldir[c].maxval = 0;
+		}
+		else if (isflt)
+		{
+			coldir[c].stat_flags = KDS_COLSTAT_MINMAX | KDS_COLSTAT_ISFLOAT;
+			coldir[c].minval = (cl_long)((mn & 0x8000000000000000UL) ? (mn & 0x7fffffffffffffffUL) : ~mn);
+			coldir[c].maxval = (cl_long)((mx & 0x8000000000000000UL) ? (mx & 0x7fffffffffffffffUL) : ~mx);
+		}
+		else
+		{
+			coldir[c].stat_flags = KDS_COLSTAT_MINMAX;
+			coldir[c].minval = (cl_long)(mn ^ 0x8000000000000000UL);
+			coldir[c].maxval = (cl_long)(mx ^ 0x8000000000000000UL);
+		}
+	}
+}
+
+#endif	/* STROM_INGEST_DEVICE_H */

@@ -56,7 +56,7 @@ struct strom_gpupreagg {
 	char			   *d_ctl = nullptr;	/* device copy of ctl */
 	char			   *d_slabs = nullptr;
 	int					block = 1024, quads = 2;
-	int					reg_groups = 0;		/* 1 or 8: register-accumulator kernel, 0: LDS */
+	int					reg_groups = 0;		/* 1: register accumulators, 2: lane-private LDS, 0: LDS atomics */
 	std::mutex			lock;
 
 	/* mirrors gpupreagg_image_offset / gpupreagg_table_offset of
@@ -173,16 +173,33 @@ setup_geometry(strom_gpupreagg *sess, const strom_preagg_domain *dom)
 	if (const char *v = getenv("STROM_GPUPREAGG_NREP"))
 		ctl.nrep = std::max(1, atoi(v));
 	/*
-	 * a handful of groups: accumulate in registers (gpupreagg_reg_column),
-	 * LDS atomics are the bottleneck of the replicated-table path
+	 * a handful of groups: no LDS atomics at all.  One group (no GROUP BY):
+	 * register accumulators (gpupreagg_reg1_column); up to 32: lane-private
+	 * LDS accumulators (gpupreagg_priv_column) when [group][thread] arrays
+	 * for a 256-thread work-group fit the budget.
 	 */
 	sess->reg_groups = 0;
-	if (ctl.nsplits == 1 && ctl.ngroups <= 8 && !getenv("STROM_GPUPREAGG_NO_REG"))
+	size_t	priv_bytes = 0;
+	if (ctl.nsplits == 1 && ctl.ngroups <= 32 && !getenv("STROM_GPUPREAGG_NO_REG"))
 	{
-		sess->reg_groups = (ctl.ngroups == 1 ? 1 : 8);
-		ctl.nrep = 1;
+		size_t	priv_budget = 64 * 1024;
+		if (const char *v = getenv("STROM_GPUPREAGG_PRIV_LDS"))
+			priv_budget = (size_t)atol(v);
+		size_t	per_entry = 0;
+		for (int resno : sess->agg_resno)
+			per_entry += (sess->targets[resno].kind == STROM_PREAGG_NROWS ? 4 : 8);
+		priv_bytes = sess->image_offset(sess->nsections(), ctl.ngroups, 1) +
+			(size_t)ctl.ngroups * 256 * per_entry;
+		if (ctl.ngroups == 1)
+			sess->reg_groups = 1;
+		else if (priv_bytes <= priv_budget)
+			sess->reg_groups = 2;
+		if (sess->reg_groups)
+			ctl.nrep = 1;
 	}
 	sess->lds_bytes = sess->image_offset(sess->nsections(), ctl.groups_per_split, ctl.nrep);
+	if (sess->reg_groups == 2)
+		sess->lds_bytes = priv_bytes;
 	ctl.slab_bytes = STROM_TYPEALIGN(256, sess->image_offset(sess->nsections(), ctl.groups_per_split, 1));
 	sess->table_bytes = sess->table_offset(sess->nsections(), ctl.ngroups);
 	/* work-groups: fill the CUs at the occupancy LDS allows */
@@ -192,8 +209,14 @@ setup_geometry(strom_gpupreagg *sess, const strom_preagg_domain *dom)
 		per_cu = std::max(1, atoi(v));
 	size_t	wgs = (size_t)dev->prop.multiProcessorCount * per_cu;
 	wgs = std::max<size_t>(ctl.nsplits, wgs - wgs % ctl.nsplits);
-	if (sess->reg_groups)
-		wgs = (size_t)dev->prop.multiProcessorCount * 4;	/* 256-thread work-groups */
+	if (sess->reg_groups)								/* 256-thread work-groups */
+	{
+		size_t	fit = std::max<size_t>(1, std::min<size_t>(8, (size_t)(160 * 1024) /
+															std::max<size_t>(sess->lds_bytes, 1)));
+		if (const char *v = getenv("STROM_GPUPREAGG_BLOCKS_PER_CU"))
+			fit = std::max(1, atoi(v));
+		wgs = (size_t)dev->prop.multiProcessorCount * fit;
+	}
 	ctl.nslabs = (cl_uint)wgs;
 	sess->has_domain = true;
 	return 0;
@@ -262,7 +285,7 @@ gpupreagg_launch(strom_task_impl *task, preagg_request req)
 	bool	use_column = (req.format == KDS_FORMAT_COLUMN && req.krowmap == nullptr);
 	bool	use_reg = (use_column && sess->reg_groups != 0);
 	hipFunction_t fn = prog->get_function(dev, use_reg ? (sess->reg_groups == 1 ? "gpupreagg_reg1_column"
-																			  : "gpupreagg_reg_column")
+																			  : "gpupreagg_priv_column")
 										  : use_column ? "gpupreagg_dense_column"
 										  : "gpupreagg_dense_generic", &errcode);
 	hipFunction_t fn_merge = fn ? prog->get_function(dev, "gpupreagg_dense_merge", &errcode) : nullptr;
@@ -344,7 +367,17 @@ gpupreagg_launch(strom_task_impl *task, preagg_request req)
 										(unsigned)sess->lds_bytes, task->stream,
 										use_column ? args_col : args_gen, nullptr),
 				  "launch gpupreagg reduction");
-		unsigned mgrid = std::min<unsigned>((sess->ctl.ngroups + 255) / 256,
+		if (task->pfm.enabled)
+		{
+			task_event(task);							/* ev[2]: main kernel done */
+			task->has_ev_proj = true;
+		}
+		/* the merge kernel lays 256 threads out as GL group lanes x stripes
+		 * over the slabs (strom_gpupreagg.h) */
+		unsigned gl = 1;
+		while (gl < sess->ctl.ngroups && gl < 64)
+			gl <<= 1;
+		unsigned mgrid = std::min<unsigned>((sess->ctl.ngroups + gl - 1) / gl,
 											(unsigned)dev->prop.multiProcessorCount * 4);
 		REQ_CHECK(hipModuleLaunchKernel(fn_merge, std::max(1u, mgrid), 1, 1, 256, 1, 1, 0,
 										task->stream, args_mrg, nullptr),

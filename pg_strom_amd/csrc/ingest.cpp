@@ -1,0 +1,182 @@
+/*
+ * ingest.cpp -- ROW / ROW_FLAT / TUPSLOT chunk -> KDS_FORMAT_COLUMN in HBM
+ *
+ * The caller side of the hot path: the reference
+ * ships heap pages to the device for every request
+ * (clserv_dmasend_data_store, datastore.c:837-973) and every kernel walks
+ * tuples.  Here a resident chunk is transposed ONCE by ingest_to_column
+ * (devlib/strom_ingest.h) and the streaming kernels then read exactly the
+ * referenced bytes.  The layout equals what strom_kds_build() produces
+ * for KDS_FORMAT_COLUMN on the host, so both can be compared byte by byte.
+ */
+#include <cstring>
+#include <vector>
+
+#include "runtime.h"
+
+using namespace strom;
+
+namespace {
+
+const char *ingest_source =
+	"#include \"strom_kds.h\"\n"
+	"#include \"strom_common.h\"\n"
+	"#include \"strom_ingest.h\"\n";
+
+}	/* namespace */
+
+extern "C" strom_dstore *
+strom_dstore_to_column(strom_dstore *src, const int32_t *type_oids, int ntypes,
+					   uint64_t *p_kern_ns, int *p_errcode)
+{
+	int		dummy;
+	if (!p_errcode)
+		p_errcode = &dummy;
+	*p_errcode = 0;
+	if (p_kern_ns)
+		*p_kern_ns = 0;
+	if (!src)
+	{
+		*p_errcode = StromError_BadRequestMessage;
+		return nullptr;
+	}
+	Device *dev = get_device(src->dindex);
+	if (!dev)
+	{
+		*p_errcode = StromError_ServerNotReady;
+		return nullptr;
+	}
+	int		ncols = (int)src->head.ncols;
+	cl_uint	nitems = src->head.nitems;
+	int		format = src->head.format;
+	if (ncols < 1 || ncols > 64 || (type_oids && ntypes != ncols) ||
+		!(format == KDS_FORMAT_ROW || format == KDS_FORMAT_ROW_FLAT || format == KDS_FORMAT_TUPSLOT))
+	{
+		*p_errcode = StromError_BadRequestMessage;
+		return nullptr;
+	}
+	/* one reference is kept for the life of the process */
+	static strom_devprog_key key = strom_get_devprog_key(ingest_source, 0);
+	if (strom_lookup_device_program(key, 1) != STROM_DEVPROG_READY)
+	{
+		*p_errcode = StromError_ProgramBuildFailure;
+		return nullptr;
+	}
+	Program *prog = lookup_program(key);
+	int		errcode = 0;
+	(void)hipSetDevice(dev->hip_id);
+	hipFunction_t fn_main = prog->get_function(dev, "ingest_to_column", &errcode);
+	hipFunction_t fn_fin = fn_main ? prog->get_function(dev, "ingest_finish", &errcode) : nullptr;
+	if (!fn_main || !fn_fin)
+	{
+		*p_errcode = errcode;
+		return nullptr;
+	}
+	hipStream_t stream = dev->streams[0];
+	/* source column metadata */
+	size_t	head_len = KDS_HEAD_LENGTH(ncols);
+	std::vector<char> hbuf(KDS_COLUMN_HEAD_LENGTH(ncols), 0);
+	if (hipMemcpy(hbuf.data(), src->devptr, head_len, hipMemcpyDeviceToHost) != hipSuccess)
+	{
+		*p_errcode = StromError_HipInternal;
+		return nullptr;
+	}
+	kern_data_store *head = (kern_data_store *)hbuf.data();
+	kern_coldir *cd = KERN_DATA_STORE_COLDIR(head);
+	size_t	off = KDS_COLUMN_HEAD_LENGTH(ncols);
+	for (int i = 0; i < ncols; i++)
+	{
+		int attlen = head->colmeta[i].attlen;
+		if (!(attlen == 1 || attlen == 2 || attlen == 4 || attlen == 8))
+		{
+			*p_errcode = StromError_DataStoreCorruption;	/* varlena columns: host path */
+			return nullptr;
+		}
+		cd[i].values_off = (cl_uint)off;
+		off += KDS_COLUMN_VALUES_LENGTH(attlen, nitems);
+		cd[i].nulls_off = (cl_uint)off;			/* dropped by ingest_finish if unused */
+		off += KDS_COLUMN_NULLS_LENGTH(nitems);
+		cd[i].extra_off = 0;
+		cd[i].stat_flags = 0;
+		cd[i].minval = (cl_long)~0UL;			/* unsigned-ordered seeds */
+		cd[i].maxval = 0;
+		if (off > 0xffffffffUL)
+		{
+			*p_errcode = StromError_DataStoreOutOfRange;
+			return nullptr;
+		}
+	}
+	head->hostptr = 0;
+	head->length = (cl_uint)off;
+	head->usage = 0;
+	head->nitems = nitems;
+	head->nrooms = nitems;
+	head->nblocks = 0;
+	head->maxblocks = 0;
+	head->format = KDS_FORMAT_COLUMN;
+
+	size_t	aux_len = sizeof(cl_int) * 2 * (size_t)ncols;
+	char   *d_dst = (char *)dev->pool.alloc(off);
+	char   *d_aux = (char *)dev->pool.alloc(aux_len);
+	hipEvent_t ev0 = nullptr, ev1 = nullptr;
+	strom_dstore *result = nullptr;
+	std::vector<cl_int> aux(2 * (size_t)ncols, 0);
+	if (type_oids)
+		memcpy(aux.data(), type_oids, sizeof(cl_int) * ncols);
+	do {
+		if (!d_dst || !d_aux)
+		{
+			*p_errcode = StromError_OutOfMemory;
+			break;
+		}
+		if (hipMemcpyAsync(d_dst, hbuf.data(), hbuf.size(), hipMemcpyHostToDevice, stream) != hipSuccess ||
+			hipMemcpyAsync(d_aux, aux.data(), aux_len, hipMemcpyHostToDevice, stream) != hipSuccess ||
+			hipEventCreate(&ev0) != hipSuccess || hipEventCreate(&ev1) != hipSuccess)
+		{
+			*p_errcode = StromError_HipInternal;
+			break;
+		}
+		const void *a_src = src->devptr;
+		void	   *a_dst = d_dst;
+		const void *a_oids = (type_oids ? d_aux : nullptr);
+		void	   *a_flags = d_aux + sizeof(cl_int) * ncols;
+		void	   *args_main[] = { &a_src, &a_dst, &a_oids, &a_flags };
+		void	   *args_fin[] = { &a_dst, &a_oids, &a_flags };
+		unsigned	nwg = (unsigned)std::min<size_t>(((size_t)nitems + 255) / 256,
+													 (size_t)dev->prop.multiProcessorCount * 8);
+		(void)hipEventRecord(ev0, stream);
+		if (nwg > 0 &&
+			hipModuleLaunchKernel(fn_main, nwg, 1, 1, 256, 1, 1, 0, stream, args_main, nullptr) != hipSuccess)
+		{
+			*p_errcode = StromError_HipInternal;
+			break;
+		}
+		if (hipModuleLaunchKernel(fn_fin, 1, 1, 1, 64, 1, 1, 0, stream, args_fin, nullptr) != hipSuccess)
+		{
+			*p_errcode = StromError_HipInternal;
+			break;
+		}
+		(void)hipEventRecord(ev1, stream);
+		result = new strom_dstore{d_dst, off, src->dindex, true, {}};
+		if (hipMemcpyAsync(&result->head, d_dst, offsetof(kern_data_store, colmeta),
+						   hipMemcpyDeviceToHost, stream) != hipSuccess ||
+			hipStreamSynchronize(stream) != hipSuccess)
+		{
+			delete result;
+			result = nullptr;
+			*p_errcode = StromError_HipInternal;
+			break;
+		}
+		if (p_kern_ns)
+		{
+			float ms = 0;
+			if (hipEventElapsedTime(&ms, ev0, ev1) == hipSuccess)
+				*p_kern_ns = (uint64_t)((double)ms * 1e6);
+		}
+	} while (0);
+	if (ev0) (void)hipEventDestroy(ev0);
+	if (ev1) (void)hipEventDestroy(ev1);
+	if (d_aux) dev->pool.release(d_aux);
+	if (!result && d_dst) dev->pool.release(d_dst);
+	return result;
+}

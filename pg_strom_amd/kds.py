@@ -210,3 +210,51 @@ def numeric_column(strings, isnull=None):
             raise ValueError("numeric %r does not fit the 64-bit device form" % (s,))
         vals[i] = img
     return Column("numeric", vals, isnull)
+
+
+def decode_column_chunk(buf):
+    """KDS_FORMAT_COLUMN image -> list of dicts(values, notnull, stat_flags,
+    minval, maxval) -- raw little-endian integers of attlen bytes"""
+    head = KdsHead(buf)
+    assert head.format == FORMAT_NAMES["column"]
+    coldir_off = stromalign(KDS_HEAD_FIXED + 8 * head.ncols)     # KDS_HEAD_LENGTH
+    cd = np.frombuffer(buf[coldir_off:coldir_off + 32 * head.ncols].tobytes(),
+                       dtype=np.dtype([("values_off", "<u4"), ("nulls_off", "<u4"),
+                                       ("extra_off", "<u4"), ("stat_flags", "<u4"),
+                                       ("minval", "<i8"), ("maxval", "<i8")]))
+    out = []
+    n = head.nitems
+    for c in range(head.ncols):
+        attlen = int(head.colmeta[c]["attlen"])
+        voff = int(cd[c]["values_off"])
+        vals = np.frombuffer(buf[voff:voff + attlen * n].tobytes(), dtype="<i%d" % attlen)
+        notnull = None
+        if cd[c]["nulls_off"]:
+            noff = int(cd[c]["nulls_off"])
+            words = np.frombuffer(buf[noff:noff + 4 * ((n + 31) // 32)].tobytes(), dtype="<u4")
+            bits = np.unpackbits(words.view(np.uint8), bitorder="little")[:n]
+            notnull = bits.astype(bool)
+        out.append(dict(values=vals, notnull=notnull, stat_flags=int(cd[c]["stat_flags"]),
+                        minval=int(cd[c]["minval"]), maxval=int(cd[c]["maxval"])))
+    return out
+
+
+def numeric_from_scaled(values, scale, isnull=None):
+    """vectorised numeric column: integer array 'values' at 10^-scale
+    (value = values * 10**-scale) -> Column('numeric') in the normalised
+    64-bit form (trailing decimal zeros moved into the exponent)"""
+    v = np.asarray(values, dtype=np.int64)
+    sign = (v < 0).astype(np.uint64)
+    mant = np.abs(v).astype(np.uint64)
+    exp = np.full(v.shape, -int(scale), dtype=np.int64)
+    for _ in range(19):
+        strip = (mant != 0) & (mant % np.uint64(10) == 0)
+        if not strip.any():
+            break
+        mant = np.where(strip, mant // np.uint64(10), mant)
+        exp = exp + strip.astype(np.int64)
+    if (mant >= np.uint64(1 << 57)).any() or (exp < -32).any() or (exp > 31).any():
+        raise ValueError("numeric value does not fit the 64-bit device form")
+    img = ((exp & 0x3f).astype(np.uint64) << np.uint64(58)) | (sign << np.uint64(57)) | mant
+    img = np.where(mant == 0, np.uint64(0), img)
+    return Column("numeric", img, isnull)

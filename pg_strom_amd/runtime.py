@@ -160,6 +160,33 @@ class DeviceStore(object):
     def devptr(self):
         return lib.strom_dstore_devptr(self.handle)
 
+    @property
+    def length(self):
+        return lib.strom_dstore_length(self.handle)
+
+    def to_column(self, type_oids=None):
+        """transpose a resident ROW / ROW_FLAT / TUPSLOT chunk on the device
+        (strom_dstore_to_column); returns (DeviceStore, kernel_ns)"""
+        err = ctypes.c_int(0)
+        ns = ctypes.c_uint64(0)
+        oids, n = None, 0
+        if type_oids is not None:
+            n = len(type_oids)
+            oids = (ctypes.c_int32 * n)(*[int(t) for t in type_oids])
+        h = lib.strom_dstore_to_column(self.handle, oids, n, ctypes.byref(ns), ctypes.byref(err))
+        if not h:
+            raise StromError(err.value, "strom_dstore_to_column")
+        return DeviceStore(h, self.nitems), ns.value
+
+    def download(self):
+        """copy the chunk image back to the host (tests, debugging)"""
+        n = self.length
+        out = np.zeros((n + 7) // 8, dtype=np.uint64).view(np.uint8)[:n]
+        rc = lib.strom_dstore_download(self.handle, out.ctypes.data, n)
+        if rc != 0:
+            raise StromError(rc, "strom_dstore_download")
+        return out
+
     def release(self):
         if self.handle:
             lib.strom_dstore_release(self.handle)
