@@ -243,6 +243,24 @@ strom_task *strom_submit_gpupreagg(strom_gpupreagg *sess,
  * bytes needed when dest == NULL; the number of groups (>= 0) otherwise;
  * a negative StromError on failure. */
 long		strom_gpupreagg_fetch(strom_gpupreagg *sess, kern_data_store *dest, size_t destlen);
+/*
+ * Group-slot agreement ("agree on dense group slots").
+ * Zone maps bound every key on its own; the product of the ranges can be far
+ * larger than the combinations that occur.  strom_gpupreagg_census() marks,
+ * one bit per dense id, the ids of the rows of a chunk that pass the qual
+ * (accumulating over calls; a copy is returned in bitmap_out when not NULL,
+ * strom_gpupreagg_dense_groups() ids -> (n+31)/32 words).  The caller may
+ * OR the bitmaps of several ranks.  strom_gpupreagg_compact() then maps the
+ * marked ids (bitmap == NULL: the session's own census) to consecutive table
+ * slots; it must precede the first fold.  A later row whose combination was
+ * not marked fails its chunk with StromError_DataStoreOutOfRange.
+ */
+uint32_t	strom_gpupreagg_dense_groups(strom_gpupreagg *sess);
+int			strom_gpupreagg_census(strom_gpupreagg *sess,
+								   const kern_data_store *kds, strom_dstore *kds_dev,
+								   const kern_row_map *krowmap,
+								   uint32_t *bitmap_out, size_t nwords);
+int			strom_gpupreagg_compact(strom_gpupreagg *sess, const uint32_t *bitmap, size_t nwords);
 void		strom_gpupreagg_reset(strom_gpupreagg *sess);
 void		strom_gpupreagg_release(strom_gpupreagg *sess);
 

@@ -142,6 +142,9 @@ PROTOTYPES = {
     "strom_submit_gpupreagg": (c_void_p, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                           c_void_p, ctypes.POINTER(c_int)]),
     "strom_gpupreagg_fetch": (ctypes.c_long, [c_void_p, c_void_p, c_size_t]),
+    "strom_gpupreagg_dense_groups": (c_uint32, [c_void_p]),
+    "strom_gpupreagg_census": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t]),
+    "strom_gpupreagg_compact": (c_int, [c_void_p, c_void_p, c_size_t]),
     "strom_gpupreagg_reset": (None, [c_void_p]),
     "strom_gpupreagg_release": (None, [c_void_p]),
     "strom_hashjoin_table_create": (c_void_p, [c_uint64, c_void_p, c_size_t, c_int,

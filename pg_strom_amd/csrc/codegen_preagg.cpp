@@ -229,6 +229,18 @@ strom_codegen_gpupreagg(const char *spec, strom_codegen_result *out,
 				 targets.size(), nkeys, naggs);
 		src += tmp;
 		src += key_list + "\n" + agg_list + "\n";
+		{
+			/* wide rows: one quad per thread and tile, two would not leave
+			 * registers for the row body (a -D tunable still wins) */
+			int		row_bytes = 0;
+			for (auto &v : ctx.used_vars)
+			{
+				const devtype_info *dt = devtype_lookup(v.type_oid);
+				row_bytes += (dt && dt->type_length > 0 ? dt->type_length : 8);
+			}
+			if (row_bytes > 24)
+				src += "#ifndef GPUPREAGG_QUADS\n#define GPUPREAGG_QUADS 1\n#endif\n";
+		}
 		src += "#include \"strom_gpupreagg.h\"\n";
 		src += "STROM_DEVICE pg_bool_t\n"
 			"gpupreagg_qual_eval(cl_int *errcode, const strom_kparams &KP, const strom_kvars &KV)\n{\n" +

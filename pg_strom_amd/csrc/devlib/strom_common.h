@@ -448,7 +448,7 @@ template <typename BASE> struct strom_quad {
  * the loads then sit in straight-line code and all of a tile's requests
  * are in flight before the first use -- with the per-lane range check
  * every load ends in its own branch join and the waits serialise */
-template <typename BASE, bool FULL, bool NONULL = false>
+template <typename BASE, bool FULL, bool NONULL = false, bool CACHED = false>
 STROM_DEVICE void
 strom_column_load_quad(const char *values, const cl_uint *notnull,
 					   cl_uint row0, cl_uint nitems,
@@ -463,12 +463,15 @@ strom_column_load_quad(const char *values, const cl_uint *notnull,
 		 * put a full vmcnt(0) wait between the value loads */
 		strom_global_uint_p nnword = (notnull ? (strom_global_uint_p)(notnull + (row0 >> 5))
 									  : (strom_global_uint_p)strom_all_ones);
+		vec_t	q;
 #if !defined(COLUMN_LOAD_NT) || COLUMN_LOAD_NT
-		/* streamed once: do not keep the lines in L2 / Infinity Cache */
-		vec_t	q = __builtin_nontemporal_load((const vec_t *)(values + (size_t)row0 * sizeof(BASE)));
-#else
-		vec_t	q = *(const vec_t *)(values + (size_t)row0 * sizeof(BASE));
+		/* streamed once: do not keep the lines in L2 / Infinity Cache --
+		 * unless a sibling work-group reads the same tile (CACHED) */
+		if (!CACHED)
+			q = __builtin_nontemporal_load((const vec_t *)(values + (size_t)row0 * sizeof(BASE)));
+		else
 #endif
+			q = *(const vec_t *)(values + (size_t)row0 * sizeof(BASE));
 		cl_uint	w = (NONULL ? 0xffffffffu : *nnword);	/* NONULL: no chunk column has a bitmap */
 		v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
 		nnbits = (w >> (row0 & 31)) & 0xf;

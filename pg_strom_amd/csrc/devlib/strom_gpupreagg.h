@@ -87,7 +87,25 @@ struct gpupreagg_dense_ctl {
 	cl_long		key_min[GPUPREAGG_MAXKEYS];
 	cl_uint		key_range[GPUPREAGG_MAXKEYS];	/* max-min+1; NULL slot == key_range */
 	cl_uint		key_stride[GPUPREAGG_MAXKEYS];
+	/* compaction (strom_gpupreagg_compact): dense id -> slot of the ids that
+	 * actually occur, ~0 = absent; 0 = ids are used as they are */
+	cl_ulong	remap;				/* device address of cl_uint[dense_ngroups] */
+	cl_uint		dense_ngroups;		/* product of (key_range + 1) */
+	cl_uint		__pad;
 };
+
+/* dense id -> table slot; false when the combination is not in the table */
+STROM_DEVICE bool
+gpupreagg_remap_gid(const gpupreagg_dense_ctl *ctl, cl_uint &gid)
+{
+	if (ctl->remap != 0)
+	{
+		gid = ((const cl_uint *)ctl->remap)[gid];
+		if (gid == 0xffffffffu)
+			return false;
+	}
+	return true;
+}
 
 /* ---- accumulator encodings ------------------------------------------ *
  * NROWS   : u32 in LDS / slab, i64 in the resident table
@@ -304,6 +322,8 @@ gpupreagg_dense_row(char *lds, const gpupreagg_dense_ctl *ctl, const gpupreagg_l
 	}
 	GPUPREAGG_KEY_LIST(X)
 #undef X
+	if (!out_of_domain && !gpupreagg_remap_gid(ctl, gid))
+		out_of_domain = true;
 	/* partial inputs (evaluated for every surviving row so that arithmetic
 	 * errors are seen before anything is folded) */
 #define X(aidx,resno,OP,NAME)														\
@@ -459,9 +479,24 @@ gpupreagg_dense_column(kern_gpupreagg *kgpreagg,
 	cl_uint		G = ctl->groups_per_split;
 	cl_uint		NREP = ctl->nrep;
 	cl_uint		split = blockIdx.x % nsplits;
-	cl_uint		gid_lo = split * G;
 	cl_uint		wg_in_split = blockIdx.x / nsplits;
 	cl_uint		wgs_per_split = gridDim.x / nsplits;
+	/*
+	 * Several roles read every tile (state > LDS): put the nsplits
+	 * work-groups of one tile stream on the SAME XCD (work-groups are
+	 * dealt round-robin over the 8 XCDs) and read with cacheable loads,
+	 * so that only the first reader goes to HBM and the siblings hit
+	 * that XCD's L2.
+	 */
+	bool		shared_tiles = (nsplits > 1 && gridDim.x % (8 * nsplits) == 0);
+	if (shared_tiles)
+	{
+		cl_uint	xcd = blockIdx.x & 7;
+		cl_uint	slot = blockIdx.x >> 3;
+		split = slot % nsplits;
+		wg_in_split = (slot / nsplits) * 8 + xcd;
+	}
+	cl_uint		gid_lo = split * G;
 	cl_uint		rep = threadIdx.x & (NREP - 1);
 	cl_int		chunk_status = StromError_Success;
 	cl_int		param_error = StromError_Success;
@@ -489,7 +524,21 @@ gpupreagg_dense_column(kern_gpupreagg *kgpreagg,
 		bool		full_tile = (tile_base + GPUPREAGG_TILE_ROWS <= nitems);
 		gpupreagg_column_tile T;
 
-		if (full_tile && !any_nulls)
+		if (full_tile && !any_nulls && shared_tiles)
+		{
+#pragma unroll
+			for (int k = 0; k < GPUPREAGG_QUADS; k++)
+			{
+				cl_uint	row0 = tile_base + (k * GPUPREAGG_BLOCK + threadIdx.x) * 4;
+#define X(attno,colidx,NAME)													\
+				strom_column_load_quad<pg_##NAME##_base_t, true, true, true>(col_##attno, nul_##attno,	\
+														   row0, nitems,				\
+														   T.v_##attno[k], T.nn_##attno[k]);
+				STROM_KVAR_LIST(X)
+#undef X
+			}
+		}
+		else if (full_tile && !any_nulls)
 		{
 #pragma unroll
 			for (int k = 0; k < GPUPREAGG_QUADS; k++)
@@ -553,7 +602,7 @@ gpupreagg_dense_column(kern_gpupreagg *kgpreagg,
 			}
 		}
 	}
-	gpupreagg_store_slab(lds, L, slabs + (size_t)blockIdx.x * ctl->slab_bytes, G, NREP);
+	gpupreagg_store_slab(lds, L, slabs + (size_t)(wg_in_split * nsplits + split) * ctl->slab_bytes, G, NREP);
 	gpupreagg_writeback_status(&kgpreagg->status, chunk_status);
 }
 
@@ -661,6 +710,8 @@ gpupreagg_reg_row(gpupreagg_reg_state<NG> &S, const gpupreagg_dense_ctl *ctl,
 	}
 	GPUPREAGG_KEY_LIST(X)
 #undef X
+	if (!out_of_domain && !gpupreagg_remap_gid(ctl, gid))
+		out_of_domain = true;
 #define X(aidx,resno,OP,NAME)														\
 	pg_##NAME##_t av_##aidx = gpupreagg_agg_##aidx(&errcode, KP, KV);
 	GPUPREAGG_AGG_LIST(X)
@@ -963,6 +1014,8 @@ gpupreagg_priv_row(char *lds, gpupreagg_priv_state &S, const gpupreagg_dense_ctl
 	}
 	GPUPREAGG_KEY_LIST(X)
 #undef X
+	if (!out_of_domain && !gpupreagg_remap_gid(ctl, gid))
+		out_of_domain = true;
 #define X(aidx,resno,OP,NAME)														\
 	pg_##NAME##_t av_##aidx = gpupreagg_agg_##aidx(&errcode, KP, KV);
 	GPUPREAGG_AGG_LIST(X)
@@ -1257,14 +1310,74 @@ gpupreagg_reg1_column(kern_gpupreagg *kgpreagg, const kern_data_store *kds,
 }
 
 /* ====================================================================== *
+ * census: which dense ids occur in this chunk (after the qual)?
+ *
+ * Zone maps bound each key separately; the product of the ranges can be
+ * far larger than the number of combinations present (TPC-H Q1: 19 x 11
+ * dense ids, 4-6 groups).  The host compacts the ids that occur into table
+ * slots (remap), which restores full LDS replication / the lane-private
+ * kernel for such queries, and is the step where the ranks of a multi-GPU
+ * run agree on the slots.  One bit per dense id.
+ * ====================================================================== */
+extern "C" __global__ void
+__launch_bounds__(256)
+gpupreagg_census(const kern_gpupreagg *kgpreagg, const kern_data_store *kds,
+				 const kern_data_store *ktoast, const kern_row_map *krowmap,
+				 const gpupreagg_dense_ctl *ctl, cl_uint *bitmap)
+{
+	const kern_parambuf *kparams = KERN_GPUPREAGG_PARAMBUF(kgpreagg);
+	bool		use_map = (krowmap != NULL && krowmap->nvalids >= 0);
+	size_t		nrows = (use_map ? (size_t)krowmap->nvalids : (size_t)kds->nitems);
+	cl_int		param_error = StromError_Success;
+	strom_kparams KP;
+
+	gpupreagg_load_kparams(KP, kparams, &param_error);
+	for (size_t r = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+		 r < nrows;
+		 r += (size_t)gridDim.x * blockDim.x)
+	{
+		cl_uint		kds_index = (use_map ? (cl_uint)krowmap->rindex[r] : (cl_uint)r);
+		strom_kvars	KV;
+		cl_int		errcode = param_error;
+		cl_uint		gid = 0;
+		bool		out_of_domain = false;
+#define X(attno,colidx,NAME)													\
+		KV.KVAR_##attno = pg_##NAME##_vref(kds, ktoast, &errcode, colidx, kds_index);
+		STROM_KVAR_LIST(X)
+#undef X
+		KV.__dummy = 0;
+		pg_bool_t	rc = gpupreagg_qual_eval(&errcode, KP, KV);
+		if (errcode == StromError_Success && !EVAL(rc))
+			continue;
+#define X(kidx,resno,NAME)															\
+		{																			\
+			pg_##NAME##_t kv = gpupreagg_key_##kidx(&errcode, KP, KV);				\
+			cl_long		off64 = (cl_long)kv.value - ctl->key_min[kidx];				\
+			cl_uint		range = ctl->key_range[kidx];								\
+			cl_uint		off = (kv.isnull ? range : (cl_uint)off64);					\
+			if (!kv.isnull && (off64 < 0 || off64 >= (cl_long)range))				\
+				out_of_domain = true;												\
+			gid += off * ctl->key_stride[kidx];										\
+		}
+		GPUPREAGG_KEY_LIST(X)
+#undef X
+		if (out_of_domain)
+			continue;				/* the fold reports it */
+		cl_uint		bit = 1u << (gid & 31);
+		if (!(bitmap[gid >> 5] & bit))
+			atomicOr(&bitmap[gid >> 5], bit);
+	}
+}
+
+/* ====================================================================== *
  * slabs -> resident table, fixed order; skipped when the chunk failed
  * ====================================================================== */
 extern "C" __global__ void
 __launch_bounds__(256)
-gpupreagg_dense_merge(const kern_gpupreagg *kgpreagg,
-					  const gpupreagg_dense_ctl *ctl,
-					  const char *slabs,
-					  char *table)
+gpupreagg_dense_merge(const kern_gpupreagg *__restrict__ kgpreagg,
+					  const gpupreagg_dense_ctl *__restrict__ ctl,
+					  const char *__restrict__ slabs,
+					  char *__restrict__ table)
 {
 	/*
 	 * 256 threads = GL lanes along consecutive groups (coalesced slab
@@ -1281,13 +1394,15 @@ gpupreagg_dense_merge(const kern_gpupreagg *kgpreagg,
 	cl_uint		wgs_per_split = ctl->nslabs / nsplits;
 	size_t		slab_bytes = ctl->slab_bytes;
 	cl_uint	   *t_flags = (cl_uint *)table;
-	cl_uint		GL = 1;
+	cl_uint		WS = 1;
 
 	if (kgpreagg->status != StromError_Success)
 		return;
-	while (GL < N && GL < 64)
-		GL <<= 1;
-	cl_uint		WS = 256 / GL;
+	/* stripes: about 8 slabs per thread (the loop is latency bound: the
+	 * slabs are small), at least 4 group lanes for some coalescing */
+	while (WS < 64 && WS * 8 < wgs_per_split)
+		WS <<= 1;
+	cl_uint		GL = 256 / WS;
 	cl_uint		lane = threadIdx.x % GL;
 	cl_uint		stripe = threadIdx.x / GL;
 

@@ -3,9 +3,15 @@
  *
  * Role in the reference: opencl_numeric.h.  Same value format
  * (122-162): bits 63..58 signed base-10 exponent, bit 57 sign, bits 56..0
- * mantissa; value = (-1)^sign * mantissa * 10^exponent, kept normalised
- * (no trailing decimal zero in the mantissa while the exponent can still
- * grow; zero is all-zero).  Same contract: whatever does not fit -- an
+ * mantissa; value = (-1)^sign * mantissa * 10^exponent; zero is all-zero.
+ * Chunks carry the normalised form (no trailing decimal zero in the mantissa
+ * while the exponent can still grow).  INSIDE an expression results are
+ * normalised lazily: stripping zeros costs 64-bit divisions, so a result
+ * that fits as it is stays as it is, and whenever an operation would fail on
+ * such operands it normalises them and tries again -- the outcome (value or
+ * CpuReCheck) is exactly that of always-normalised arithmetic, every
+ * consumer (compare, casts, fixed-point partial sums) works on the value.
+ * Same contract: whatever does not fit -- an
  * exponent outside [-32, 31], a mantissa beyond 57 bits, an intermediate
  * product beyond 64 bits -- yields NULL + StromError_CpuReCheck and
  * PostgreSQL's arbitrary-precision numeric finishes the row
@@ -44,15 +50,46 @@ strom_numeric_recheck(cl_int *errcode)
 }
 
 /* 10^n for 0 <= n <= 19, 0 when it does not fit 64 bits */
+__device__ const cl_ulong strom_pow10_table[20] = {
+	1UL, 10UL, 100UL, 1000UL, 10000UL, 100000UL, 1000000UL, 10000000UL, 100000000UL,
+	1000000000UL, 10000000000UL, 100000000000UL, 1000000000000UL, 10000000000000UL,
+	100000000000000UL, 1000000000000000UL, 10000000000000000UL, 100000000000000000UL,
+	1000000000000000000UL, 10000000000000000000UL
+};
+
+/* a table read (a memory instruction, cached) instead of 64-bit multiplies:
+ * integer multiplies are quarter rate on the VALU and this is on every
+ * numeric operation's path */
 STROM_DEVICE cl_ulong
 strom_pow10_u64(int n)
 {
-	cl_ulong m = 1;
 	if (n < 0 || n > 19)
 		return 0;
-	for (int i = 0; i < n; i++)
-		m *= 10;
-	return m;
+	return strom_pow10_table[n];
+}
+
+/* a * b with overflow report; operands below 2^32 (the common case: money
+ * amounts, rates) take one 32x32->64 multiply instead of the 128-bit check */
+STROM_DEVICE bool
+strom_mul_overflow_u64(cl_ulong a, cl_ulong b, cl_ulong *out)
+{
+	if (((a | b) >> 32) == 0)
+	{
+		*out = (cl_ulong)(cl_uint)a * (cl_ulong)(cl_uint)b;
+		return false;
+	}
+	return __builtin_mul_overflow(a, b, out);
+}
+
+/* move trailing decimal zeros of the mantissa into the exponent */
+STROM_DEVICE void
+strom_numeric_strip(cl_ulong &mant, int &expo)
+{
+	while (mant != 0 && mant % 10 == 0 && expo < PG_NUMERIC_EXPONENT_MAX)
+	{
+		mant /= 10;
+		expo++;
+	}
 }
 
 /* normalise and pack; anything out of range goes back to the CPU */
@@ -67,11 +104,15 @@ strom_numeric_pack(cl_int *errcode, int expo, bool sign, cl_ulong mant)
 		v.value = 0;
 		return v;
 	}
-	while (mant % 10 == 0 && expo < PG_NUMERIC_EXPONENT_MAX)
+	/* fits as it is: no normalisation (see the header comment) */
+	if (!(mant & ~PG_NUMERIC_MANTISSA_MASK) &&
+		expo >= PG_NUMERIC_EXPONENT_MIN && expo <= PG_NUMERIC_EXPONENT_MAX)
 	{
-		mant /= 10;
-		expo++;
+		v.isnull = false;
+		v.value = PG_NUMERIC_SET(expo, sign, mant);
+		return v;
 	}
+	strom_numeric_strip(mant, expo);
 	/* an exponent above the field can be traded for mantissa digits */
 	while (expo > PG_NUMERIC_EXPONENT_MAX)
 	{
@@ -85,6 +126,22 @@ strom_numeric_pack(cl_int *errcode, int expo, bool sign, cl_ulong mant)
 	v.isnull = false;
 	v.value = PG_NUMERIC_SET(expo, sign, mant);
 	return v;
+}
+
+/* canonical image (what chunks carry): needed where the datum image itself
+ * is consumed -- hashing, stores */
+STROM_DEVICE pg_numeric_t
+pgfn_numeric_normalize(cl_int *errcode, pg_numeric_t arg)
+{
+	if (!arg.isnull)
+	{
+		int			expo = PG_NUMERIC_EXPONENT(arg.value);
+		cl_ulong	mant = PG_NUMERIC_MANTISSA(arg.value);
+
+		strom_numeric_strip(mant, expo);
+		arg.value = (mant == 0 ? 0UL : PG_NUMERIC_SET(expo, PG_NUMERIC_SIGN(arg.value), mant));
+	}
+	return arg;
 }
 
 STROM_DEVICE pg_numeric_t pgfn_numeric_uplus(cl_int *errcode, pg_numeric_t arg)
@@ -120,30 +177,48 @@ pgfn_numeric_add(cl_int *errcode, pg_numeric_t arg1, pg_numeric_t arg2)
 		return arg2;
 	if (mant2 == 0)
 		return arg1;
-	/* bring both to the smaller exponent */
-	if (expo1 != expo2)
+	/* bring both to the smaller exponent; operands may be un-normalised:
+	 * on failure normalise them and try once more */
+	for (int attempt = 0; ; attempt++)
 	{
-		int			diff = (expo1 > expo2 ? expo1 - expo2 : expo2 - expo1);
-		cl_ulong	mag = strom_pow10_u64(diff);
-		cl_ulong   *big = (expo1 > expo2 ? &mant1 : &mant2);
+		cl_ulong	m1 = mant1, m2 = mant2;
+		int			e = (expo1 < expo2 ? expo1 : expo2);
+		bool		ok = true;
 
-		if (mag == 0 || __builtin_mul_overflow(*big, mag, big))
-			return strom_numeric_recheck(errcode);
-		expo1 = expo2 = (expo1 < expo2 ? expo1 : expo2);
-	}
-	if (sign1 != sign2)
-	{
-		if (mant1 < mant2)
+		if (expo1 != expo2)
 		{
-			sign1 = sign2;
-			mant1 = mant2 - mant1;
+			bool		first_big = (expo1 > expo2);
+			int			diff = (first_big ? expo1 - expo2 : expo2 - expo1);
+			cl_ulong	mag = strom_pow10_u64(diff);
+			cl_ulong	big = (first_big ? m1 : m2);	/* no pointer to a local: that is scratch */
+
+			if (mag == 0 || strom_mul_overflow_u64(big, mag, &big))
+				ok = false;
+			m1 = (first_big ? big : m1);
+			m2 = (first_big ? m2 : big);
 		}
-		else
-			mant1 -= mant2;
+		if (ok)
+		{
+			if (sign1 != sign2)
+			{
+				if (m1 < m2)
+				{
+					sign1 = sign2;
+					m1 = m2 - m1;
+				}
+				else
+					m1 -= m2;
+			}
+			else if (__builtin_add_overflow(m1, m2, &m1))
+				ok = false;
+		}
+		if (ok)
+			return strom_numeric_pack(errcode, e, sign1, m1);
+		if (attempt != 0)
+			return strom_numeric_recheck(errcode);
+		strom_numeric_strip(mant1, expo1);
+		strom_numeric_strip(mant2, expo2);
 	}
-	else if (__builtin_add_overflow(mant1, mant2, &mant1))
-		return strom_numeric_recheck(errcode);
-	return strom_numeric_pack(errcode, expo1, sign1, mant1);
 }
 
 STROM_DEVICE pg_numeric_t
@@ -172,10 +247,17 @@ pgfn_numeric_mul(cl_int *errcode, pg_numeric_t arg1, pg_numeric_t arg2)
 		v.value = 0;
 		return v;
 	}
-	if (__builtin_mul_overflow(mant1, mant2, &prod))
-		return strom_numeric_recheck(errcode);
-	return strom_numeric_pack(errcode,
-							  PG_NUMERIC_EXPONENT(arg1.value) + PG_NUMERIC_EXPONENT(arg2.value),
+	int			expo1 = PG_NUMERIC_EXPONENT(arg1.value), expo2 = PG_NUMERIC_EXPONENT(arg2.value);
+
+	if (strom_mul_overflow_u64(mant1, mant2, &prod))
+	{
+		/* un-normalised operands?  strip them and try once more */
+		strom_numeric_strip(mant1, expo1);
+		strom_numeric_strip(mant2, expo2);
+		if (strom_mul_overflow_u64(mant1, mant2, &prod))
+			return strom_numeric_recheck(errcode);
+	}
+	return strom_numeric_pack(errcode, expo1 + expo2,
 							  PG_NUMERIC_SIGN(arg1.value) != PG_NUMERIC_SIGN(arg2.value), prod);
 }
 
@@ -208,7 +290,7 @@ strom_numeric_cmp(pg_numeric_t arg1, pg_numeric_t arg2)
 		cl_ulong	scaled;
 		int			c;		/* compare(big side, small side) */
 
-		if (mag == 0 || __builtin_mul_overflow(big, mag, &scaled))
+		if (mag == 0 || strom_mul_overflow_u64(big, mag, &scaled))
 			c = 1;			/* does not even fit 64 bits: it is the larger */
 		else
 			c = (scaled < small ? -1 : (scaled > small ? 1 : 0));
@@ -287,7 +369,7 @@ strom_numeric_to_int64(pg_numeric_t arg, cl_long lo, cl_long hi, cl_long *p_valu
 	else if (expo > 0)
 	{
 		cl_ulong mag = strom_pow10_u64(expo);
-		if (mag == 0 || __builtin_mul_overflow(mant, mag, &mant))
+		if (mag == 0 || strom_mul_overflow_u64(mant, mag, &mant))
 			return false;
 	}
 	if (!sign)
@@ -378,13 +460,17 @@ strom_numeric_to_fixed(cl_int *errcode, pg_numeric_t arg, int scale)
 	r.value = 0;
 	if (!r.isnull)
 	{
-		int			shift = PG_NUMERIC_EXPONENT(arg.value) + scale;
+		int			expo = PG_NUMERIC_EXPONENT(arg.value);
 		cl_ulong	mant = PG_NUMERIC_MANTISSA(arg.value);
-		cl_ulong	mag = strom_pow10_u64(shift);
 
 		if (mant == 0)
 			return r;
-		if (shift < 0 || mag == 0 || __builtin_mul_overflow(mant, mag, &mant) ||
+		if (expo + scale < 0)
+			strom_numeric_strip(mant, expo);	/* un-normalised: zeros may cover it */
+		int			shift = expo + scale;
+		cl_ulong	mag = strom_pow10_u64(shift);
+
+		if (shift < 0 || mag == 0 || strom_mul_overflow_u64(mant, mag, &mant) ||
 			mant > 9223372036854775807UL)
 		{
 			/* finer than the accumulator's scale, or too large */

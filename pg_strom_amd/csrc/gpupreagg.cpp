@@ -34,6 +34,9 @@ struct dense_ctl {
 	cl_long		key_min[STROM_PREAGG_MAXKEYS];
 	cl_uint		key_range[STROM_PREAGG_MAXKEYS];
 	cl_uint		key_stride[STROM_PREAGG_MAXKEYS];
+	cl_ulong	remap;				/* device cl_uint[dense_ngroups], 0 = none */
+	cl_uint		dense_ngroups;
+	cl_uint		__pad;
 };
 
 inline size_t align16(size_t v) { return (v + 15) & ~(size_t)15; }
@@ -56,6 +59,11 @@ struct strom_gpupreagg {
 	char			   *d_ctl = nullptr;	/* device copy of ctl */
 	char			   *d_slabs = nullptr;
 	int					block = 1024, quads = 2;
+	/* compaction of the dense ids that occur (census -> compact) */
+	char			   *d_census = nullptr;	/* bitmap over dense ids (device) */
+	char			   *d_remap = nullptr;
+	std::vector<cl_uint> present;			/* table slot -> dense id */
+	size_t				nfolds = 0;
 	int					reg_groups = 0;		/* 1: register accumulators, 2: lane-private LDS, 0: LDS atomics */
 	std::mutex			lock;
 
@@ -115,15 +123,13 @@ type_is_float(int type_oid)
 /*
  * geometry for a domain: how the dense ids are laid over LDS
  */
+int	setup_layout(strom_gpupreagg *sess);
+
 int
 setup_geometry(strom_gpupreagg *sess, const strom_preagg_domain *dom)
 {
-	Device	   *dev = sess->dev;
 	dense_ctl  &ctl = sess->ctl;
-	size_t		lds_budget = std::min<size_t>(dev->prop.sharedMemPerBlock, 160 * 1024) - 4096;
 
-	if (const char *v = getenv("STROM_GPUPREAGG_LDS_BUDGET"))
-		lds_budget = (size_t)atol(v);
 	if (dom->nkeys != (int)sess->key_resno.size() || dom->nkeys > STROM_PREAGG_MAXKEYS)
 		return StromError_BadRequestMessage;
 	memset(&ctl, 0, sizeof(ctl));
@@ -139,6 +145,24 @@ setup_geometry(strom_gpupreagg *sess, const strom_preagg_domain *dom)
 			return StromError_DataStoreOutOfRange;		/* too sparse for dense ids */
 	}
 	ctl.ngroups = (cl_uint)ngroups;
+	ctl.dense_ngroups = (cl_uint)ngroups;
+	ctl.remap = 0;
+	sess->present.clear();
+	return setup_layout(sess);
+}
+
+/*
+ * how ctl.ngroups table slots are laid over LDS
+ */
+int
+setup_layout(strom_gpupreagg *sess)
+{
+	Device	   *dev = sess->dev;
+	dense_ctl  &ctl = sess->ctl;
+	size_t		lds_budget = std::min<size_t>(dev->prop.sharedMemPerBlock, 160 * 1024) - 4096;
+
+	if (const char *v = getenv("STROM_GPUPREAGG_LDS_BUDGET"))
+		lds_budget = (size_t)atol(v);
 	size_t	one = sess->image_offset(sess->nsections(), ctl.ngroups, 1);
 	if (one <= lds_budget)
 	{
@@ -209,6 +233,10 @@ setup_geometry(strom_gpupreagg *sess, const strom_preagg_domain *dom)
 		per_cu = std::max(1, atoi(v));
 	size_t	wgs = (size_t)dev->prop.multiProcessorCount * per_cu;
 	wgs = std::max<size_t>(ctl.nsplits, wgs - wgs % ctl.nsplits);
+	/* several roles per tile: a multiple of 8 XCDs x nsplits lets the kernel
+	 * keep the roles of one tile stream on one XCD (shared L2) */
+	if (ctl.nsplits > 1 && wgs >= 8 * (size_t)ctl.nsplits)
+		wgs -= wgs % (8 * (size_t)ctl.nsplits);
 	if (sess->reg_groups)								/* 256-thread work-groups */
 	{
 		size_t	fit = std::max<size_t>(1, std::min<size_t>(8, (size_t)(160 * 1024) /
@@ -374,11 +402,12 @@ gpupreagg_launch(strom_task_impl *task, preagg_request req)
 		}
 		/* the merge kernel lays 256 threads out as GL group lanes x stripes
 		 * over the slabs (strom_gpupreagg.h) */
-		unsigned gl = 1;
-		while (gl < sess->ctl.ngroups && gl < 64)
-			gl <<= 1;
+		unsigned ws = 1, per_split = sess->ctl.nslabs / sess->ctl.nsplits;
+		while (ws < 64 && ws * 8 < per_split)
+			ws <<= 1;
+		unsigned gl = 256 / ws;
 		unsigned mgrid = std::min<unsigned>((sess->ctl.ngroups + gl - 1) / gl,
-											(unsigned)dev->prop.multiProcessorCount * 4);
+											(unsigned)dev->prop.multiProcessorCount * 8);
 		REQ_CHECK(hipModuleLaunchKernel(fn_merge, std::max(1u, mgrid), 1, 1, 256, 1, 1, 0,
 										task->stream, args_mrg, nullptr),
 				  "launch gpupreagg merge");
@@ -494,6 +523,9 @@ strom_gpupreagg_table_devptr(strom_gpupreagg *sess) { return sess ? sess->table 
 extern "C" uint32_t
 strom_gpupreagg_num_groups(strom_gpupreagg *sess) { return (sess && sess->has_domain) ? sess->ctl.ngroups : 0; }
 
+extern "C" uint32_t
+strom_gpupreagg_dense_groups(strom_gpupreagg *sess) { return (sess && sess->has_domain) ? sess->ctl.dense_ngroups : 0; }
+
 extern "C" int
 strom_gpupreagg_table_layout(strom_gpupreagg *sess, int resno, size_t *p_bits_off, size_t *p_vals_off)
 {
@@ -549,9 +581,171 @@ strom_submit_gpupreagg(strom_gpupreagg *sess,
 		head = kds_dev->head;
 	req.format = head.format;
 	req.nrows = req.krowmap ? (uint32_t)req.krowmap->nvalids : head.nitems;
+	sess->nfolds++;
 	strom_task_impl *task = task_create(sess->dev, done, arg);
 	program_run_or_park(sess->prog, [task, req]() { gpupreagg_launch(task, req); });
 	return task;
+}
+
+/*
+ * census / compact: see gpupreagg_census in strom_gpupreagg.h.  Both are
+ * planning-time calls (blocking); they must precede the first fold.
+ */
+extern "C" int
+strom_gpupreagg_census(strom_gpupreagg *sess,
+					   const kern_data_store *kds, strom_dstore *kds_dev,
+					   const kern_row_map *krowmap,
+					   uint32_t *bitmap_out, size_t nwords)
+{
+	if (!sess || !sess->has_domain || (!kds) == (!kds_dev))
+		return StromError_BadRequestMessage;
+	if (sess->ctl.remap != 0)
+		return StromError_BadRequestMessage;		/* already compacted */
+	Device *dev = sess->dev;
+	if (kds_dev && kds_dev->dindex != dev->dindex)
+		return StromError_BadRequestMessage;
+	size_t	words = ((size_t)sess->ctl.dense_ngroups + 31) / 32;
+	if (bitmap_out && nwords < words)
+		return StromError_DataStoreNoSpace;
+	if (strom_lookup_device_program(sess->key, 1) != STROM_DEVPROG_READY)
+		return StromError_ProgramBuildFailure;
+	std::lock_guard<std::mutex> g(sess->lock);
+	(void)hipSetDevice(dev->hip_id);
+	hipStream_t stream = dev->streams[0];
+	int		errcode = 0;
+	hipFunction_t fn = sess->prog->get_function(dev, "gpupreagg_census", &errcode);
+	if (!fn)
+		return errcode;
+	if (!sess->d_census)
+	{
+		sess->d_census = (char *)dev->pool.alloc(words * sizeof(cl_uint));
+		if (!sess->d_census)
+			return StromError_OutOfMemory;
+		if (hipMemsetAsync(sess->d_census, 0, words * sizeof(cl_uint), stream) != hipSuccess)
+			return StromError_HipInternal;
+	}
+	size_t	kg_len = STROMALIGN(offsetof(kern_gpupreagg, kparams) + sess->kparams.size());
+	std::vector<char> kg(kg_len, 0);
+	memcpy(kg.data() + offsetof(kern_gpupreagg, kparams), sess->kparams.data(), sess->kparams.size());
+	char   *d_kg = (char *)dev->pool.alloc(kg_len);
+	void   *d_chunk = nullptr, *d_map = nullptr;
+	int		rc = 0;
+	do {
+		if (!d_kg || hipMemcpyAsync(d_kg, kg.data(), kg_len, hipMemcpyHostToDevice, stream) != hipSuccess)
+		{
+			rc = StromError_OutOfMemory;
+			break;
+		}
+		const void *a_kds = (kds_dev ? kds_dev->devptr : nullptr);
+		cl_uint	nrows;
+		if (kds)
+		{
+			size_t	len = kds->length;
+			if (kds->format == KDS_FORMAT_ROW)
+				len = KERN_DATA_STORE_ROWBLOCK_OFFSET(kds) + (size_t)BLCKSZ * kds->nblocks;
+			d_chunk = dev->pool.alloc(len);
+			if (!d_chunk || hipMemcpyAsync(d_chunk, kds, len, hipMemcpyHostToDevice, stream) != hipSuccess)
+			{
+				rc = StromError_OutOfMemory;
+				break;
+			}
+			a_kds = d_chunk;
+			nrows = kds->nitems;
+		}
+		else
+			nrows = kds_dev->head.nitems;
+		const void *a_map = nullptr;
+		if (krowmap && krowmap->nvalids >= 0)
+		{
+			size_t	len = offsetof(kern_row_map, rindex) + sizeof(cl_int) * (size_t)krowmap->nvalids;
+			d_map = dev->pool.alloc(len);
+			if (!d_map || hipMemcpyAsync(d_map, krowmap, len, hipMemcpyHostToDevice, stream) != hipSuccess)
+			{
+				rc = StromError_OutOfMemory;
+				break;
+			}
+			a_map = d_map;
+			nrows = (cl_uint)krowmap->nvalids;
+		}
+		const void *a_kg = d_kg;
+		const void *a_toast = nullptr;
+		const void *a_ctl = sess->d_ctl;
+		void	   *a_bitmap = sess->d_census;
+		void	   *args[] = { &a_kg, &a_kds, &a_toast, &a_map, &a_ctl, &a_bitmap };
+		unsigned	grid = (unsigned)std::min<size_t>(((size_t)nrows + 255) / 256,
+													  (size_t)dev->prop.multiProcessorCount * 8);
+		if (grid > 0 &&
+			hipModuleLaunchKernel(fn, grid, 1, 1, 256, 1, 1, 0, stream, args, nullptr) != hipSuccess)
+		{
+			rc = StromError_HipInternal;
+			break;
+		}
+		if (bitmap_out &&
+			hipMemcpyAsync(bitmap_out, sess->d_census, words * sizeof(cl_uint),
+						   hipMemcpyDeviceToHost, stream) != hipSuccess)
+			rc = StromError_HipInternal;
+	} while (0);
+	if (hipStreamSynchronize(stream) != hipSuccess && rc == 0)
+		rc = StromError_HipInternal;
+	if (d_kg) dev->pool.release(d_kg);
+	if (d_chunk) dev->pool.release(d_chunk);
+	if (d_map) dev->pool.release(d_map);
+	return rc;
+}
+
+extern "C" int
+strom_gpupreagg_compact(strom_gpupreagg *sess, const uint32_t *bitmap, size_t nwords)
+{
+	if (!sess || !sess->has_domain || sess->nfolds != 0 || !sess->table_owned || sess->ctl.remap != 0)
+		return StromError_BadRequestMessage;
+	Device *dev = sess->dev;
+	dense_ctl &ctl = sess->ctl;
+	size_t	words = ((size_t)ctl.dense_ngroups + 31) / 32;
+	std::vector<cl_uint> bits(words, 0);
+	std::lock_guard<std::mutex> g(sess->lock);
+
+	(void)hipSetDevice(dev->hip_id);
+	if (bitmap)
+	{
+		if (nwords < words)
+			return StromError_BadRequestMessage;
+		memcpy(bits.data(), bitmap, words * sizeof(cl_uint));
+	}
+	else if (sess->d_census)
+	{
+		if (hipStreamSynchronize(dev->streams[0]) != hipSuccess ||
+			hipMemcpy(bits.data(), sess->d_census, words * sizeof(cl_uint), hipMemcpyDeviceToHost) != hipSuccess)
+			return StromError_HipInternal;
+	}
+	std::vector<cl_uint> remap(ctl.dense_ngroups, 0xffffffffu);
+	sess->present.clear();
+	for (cl_uint d = 0; d < ctl.dense_ngroups; d++)
+		if (bits[d >> 5] & (1u << (d & 31)))
+		{
+			remap[d] = (cl_uint)sess->present.size();
+			sess->present.push_back(d);
+		}
+	if (sess->present.empty())
+	{
+		/* nothing passes the qual: keep one (never used) slot */
+		sess->present.push_back(0);
+	}
+	sess->d_remap = (char *)dev->pool.alloc(remap.size() * sizeof(cl_uint));
+	if (!sess->d_remap)
+		return StromError_OutOfMemory;
+	if (hipMemcpy(sess->d_remap, remap.data(), remap.size() * sizeof(cl_uint), hipMemcpyHostToDevice) != hipSuccess)
+		return StromError_HipInternal;
+	/* new table geometry over the compact slots */
+	if (sess->table) dev->pool.release(sess->table);
+	if (sess->d_ctl) dev->pool.release(sess->d_ctl);
+	if (sess->d_slabs) dev->pool.release(sess->d_slabs);
+	sess->table = sess->d_ctl = sess->d_slabs = nullptr;
+	ctl.ngroups = (cl_uint)sess->present.size();
+	ctl.remap = (cl_ulong)(uintptr_t)sess->d_remap;
+	int rc = setup_layout(sess);
+	if (rc == 0)
+		rc = alloc_session_buffers(sess);
+	return rc;
 }
 
 extern "C" void
@@ -578,6 +772,10 @@ strom_gpupreagg_release(strom_gpupreagg *sess)
 		dev->pool.release(sess->d_ctl);
 	if (sess->d_slabs)
 		dev->pool.release(sess->d_slabs);
+	if (sess->d_census)
+		dev->pool.release(sess->d_census);
+	if (sess->d_remap)
+		dev->pool.release(sess->d_remap);
 	strom_put_devprog_key(sess->key);
 	delete sess;
 }
@@ -697,7 +895,8 @@ strom_gpupreagg_fetch(strom_gpupreagg *sess, kern_data_store *dest, size_t destl
 		for (size_t k = 0; k < sess->key_resno.size(); k++)
 		{
 			int		resno = sess->key_resno[k];
-			cl_uint	off = (g / sess->ctl.key_stride[k]) % (sess->ctl.key_range[k] + 1);
+			cl_uint	dense = (sess->present.empty() ? g : sess->present[g]);
+			cl_uint	off = (dense / sess->ctl.key_stride[k]) % (sess->ctl.key_range[k] + 1);
 			if (off == sess->ctl.key_range[k])
 				isnull[resno] = 1;
 			else
@@ -761,7 +960,8 @@ strom_gpupreagg_fetch(strom_gpupreagg *sess, kern_data_store *dest, size_t destl
 		for (size_t k = 0; k < sess->key_resno.size(); k++)
 		{
 			int		resno = sess->key_resno[k];
-			cl_uint	off = (sp.gid / sess->ctl.key_stride[k]) % (sess->ctl.key_range[k] + 1);
+			cl_uint	dense = (sess->present.empty() ? sp.gid : sess->present[sp.gid]);
+			cl_uint	off = (dense / sess->ctl.key_stride[k]) % (sess->ctl.key_range[k] + 1);
 			if (off != sess->ctl.key_range[k])
 			{
 				cl_long v = sess->ctl.key_min[k] + off;

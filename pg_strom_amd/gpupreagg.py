@@ -121,6 +121,39 @@ class GpuPreAgg(object):
             raise runtime.StromError(err.value, "strom_gpupreagg_create")
         return self
 
+    # group-slot agreement ---------------------------------------------------
+    def census(self, chunk, row_map=None):
+        """mark the dense ids that occur in 'chunk' (after the qual); returns
+        the accumulated bitmap (uint32 words, one bit per dense id)"""
+        if isinstance(chunk, runtime.DeviceStore):
+            kds_host, kds_dev = None, chunk.handle
+        else:
+            kds_host, kds_dev = chunk.ctypes.data, None
+        rm = None
+        if row_map is not None:
+            r = np.ascontiguousarray(row_map, dtype=np.int32)
+            rm = np.concatenate([np.array([len(r)], dtype=np.int32), r])
+        nwords = (lib.strom_gpupreagg_dense_groups(self.session) + 31) // 32
+        bitmap = np.zeros(nwords, dtype=np.uint32)
+        rc = lib.strom_gpupreagg_census(self.session, kds_host, kds_dev,
+                                        rm.ctypes.data if rm is not None else None,
+                                        bitmap.ctypes.data, nwords)
+        if rc != 0:
+            raise runtime.StromError(rc, "strom_gpupreagg_census")
+        return bitmap
+
+    def compact(self, bitmap=None):
+        """map the ids marked in 'bitmap' (default: this session's census) to
+        consecutive table slots; before the first fold"""
+        if bitmap is not None:
+            bitmap = np.ascontiguousarray(bitmap, dtype=np.uint32)
+        rc = lib.strom_gpupreagg_compact(self.session,
+                                         bitmap.ctypes.data if bitmap is not None else None,
+                                         len(bitmap) if bitmap is not None else 0)
+        if rc != 0:
+            raise runtime.StromError(rc, "strom_gpupreagg_compact")
+        return lib.strom_gpupreagg_num_groups(self.session)
+
     # requests -------------------------------------------------------------
     def submit(self, chunk, row_map=None):
         if isinstance(chunk, runtime.DeviceStore):
@@ -195,6 +228,19 @@ class GpuPreAgg(object):
             raise runtime.StromError(rc, "strom_gpupreagg_bind_table")
         self._table_tensor = t
         return t
+
+    def agree_group_slots(self, chunks, group=None, device=None):
+        """multi-GPU planning step: census of the local chunks, union over
+        the ranks, compact -- all ranks end with identical table slots"""
+        from . import parallel
+        bitmap = None
+        for c in chunks:
+            bitmap = self.census(c)
+        if bitmap is None:
+            nwords = (lib.strom_gpupreagg_dense_groups(self.session) + 31) // 32
+            bitmap = np.zeros(nwords, dtype=np.uint32)
+        merged = parallel.allreduce_census(bitmap, group, device)
+        return self.compact(merged)
 
     def allreduce(self, group=None):
         """merge the per-GPU partial tables over RCCL (pg_strom_amd.parallel)"""

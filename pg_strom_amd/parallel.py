@@ -167,3 +167,20 @@ def unpack_rows(layout, domain, tbl):
             else:
                 values[r, t] = vals[gid]
     return values, isnull
+
+
+def allreduce_census(bitmap, group=None, device=None):
+    """union of the ranks' census bitmaps (uint32 words, one bit per dense
+    id): every rank then compacts to the SAME table slots, which is what makes
+    allreduce_table() a plain element-wise collective (SURVEY.md section 8e:
+    "agree on dense group slots").  NCCL/RCCL has no bitwise OR, so the bits
+    travel unpacked as bytes under MAX; the map is small (<= 2^26 bits)."""
+    import torch
+    import torch.distributed as dist
+    bits = np.unpackbits(np.ascontiguousarray(bitmap, dtype=np.uint32).view(np.uint8), bitorder="little")
+    t = torch.from_numpy(bits.copy())
+    if device is not None:
+        t = t.to(device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+    merged = np.packbits(t.cpu().numpy(), bitorder="little").view(np.uint32)
+    return merged

@@ -17,7 +17,7 @@ import time
 
 import numpy as np
 
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 from pg_strom_amd import kds, runtime  # noqa: E402
 from pg_strom_amd.gpuhashjoin import GpuHashJoin, build_multihash  # noqa: E402
 from pg_strom_amd.gpupreagg import GpuPreAgg  # noqa: E402
@@ -175,6 +175,10 @@ def c5():
             % (disc_price, disc_price, one_plus_t))
     ds = runtime.DeviceStore.upload(kds.build_kds("column", cols))
     agg = GpuPreAgg(spec).begin([(65, 18), (70, 10)])
+    t0 = time.time()
+    agg.census(ds)
+    nslots = agg.compact()
+    t_census = time.time() - t0
     ts, tm = [], []
     for _ in range(REPS):
         st, pfm = agg.fold(ds)
@@ -183,7 +187,8 @@ def c5():
         tm.append(pfm["time_kern_proj_ns"])
     pr = agg.fetch()
     emit("C5 Q1 shape (6 groups, 9 partials)", "gpupreagg_*_column+merge", n, med(ts), 38.0 * n,
-         merge_us=round(med(tm) / 1e3, 1), groups=len(pr.column(0)[0]))
+         merge_us=round(med(tm) / 1e3, 1), groups=len(pr.column(0)[0]), table_slots=nslots,
+         census_compact_ms=round(t_census * 1e3, 2))
     agg.end()
     ds.release()
 

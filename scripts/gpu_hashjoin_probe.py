@@ -1,7 +1,7 @@
 """GpuHashJoin C3-shape timing: 1e8 fact x 1e6 dim on int4 (80% hit), resident fact chunk"""
 import os, sys, time
 import numpy as np
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 from pg_strom_amd import kds, runtime
 from pg_strom_amd.gpuhashjoin import GpuHashJoin, build_multihash, STROM_RESULTS_ON_DEVICE
 nf = int(sys.argv[1]) if len(sys.argv) > 1 else 100_000_000

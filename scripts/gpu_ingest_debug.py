@@ -1,6 +1,6 @@
 import sys
 import numpy as np
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 from pg_strom_amd import kds, runtime
 runtime.init()
 for fmt in ("row", "row_flat", "tupslot"):

@@ -5,7 +5,7 @@ import time
 
 import numpy as np
 
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 from pg_strom_amd import kds, runtime  # noqa: E402
 
 runtime.init()

@@ -1,7 +1,7 @@
 """where does per-request time go?  resident 1e8-row chunk, requests back to back"""
 import sys, time, collections
 import numpy as np
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 from pg_strom_amd import kds, runtime
 from pg_strom_amd.gpuscan import GpuScan, STROM_RESULTS_ON_DEVICE
 QUAL = "(and (int4lt (var 1 int4) (param 0 int4)) (float8gt (var 2 float8) (param 1 float8)))"

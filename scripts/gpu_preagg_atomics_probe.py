@@ -1,7 +1,7 @@
 """how does GpuPreAgg kernel time scale with the number of LDS atomics per row?"""
 import sys
 import numpy as np
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 from pg_strom_amd import kds, runtime
 from pg_strom_amd.gpupreagg import GpuPreAgg
 n = 100_000_000

@@ -1,7 +1,7 @@
 """GpuPreAgg C4-shape timing on a resident chunk: GROUP BY g (ngroups) COUNT(*), SUM(x), AVG(y)"""
 import sys, time
 import numpy as np
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 from pg_strom_amd import kds, runtime
 from pg_strom_amd.gpupreagg import GpuPreAgg
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 100_000_000
@@ -10,7 +10,8 @@ rng = np.random.default_rng(3)
 x = rng.integers(-10**6, 10**6, n, dtype=np.int64).astype(np.int32)
 y = rng.random(n) * 100
 spec = "(gpupreagg (key (var 1 int4)) (nrows) (psum (int8 (var 2 int4))) (psum (var 3 float8)))"
-for ngroups in (1, 6, 30, 100, 1000, 5000, 10000, 20000):
+groups = [int(v) for v in sys.argv[2].split(',')] if len(sys.argv) > 2 else [1, 6, 30, 100, 1000, 5000, 10000, 20000]
+for ngroups in groups:
     g = rng.integers(0, ngroups, n, dtype=np.int64).astype(np.int32)
     ds = runtime.DeviceStore.upload(kds.build_kds("column", [kds.Column("int4", g), kds.Column("int4", x), kds.Column("float8", y)]))
     agg = GpuPreAgg(spec).begin([(0, ngroups)])

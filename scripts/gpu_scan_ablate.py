@@ -2,7 +2,7 @@
    0 = shipped kernel, 1 = no result stores, 2 = no reservation atomic"""
 import os, sys
 import numpy as np
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 from pg_strom_amd import kds, runtime
 from pg_strom_amd.gpuscan import GpuScan, STROM_RESULTS_ON_DEVICE
 QUAL = "(and (int4lt (var 1 int4) (param 0 int4)) (float8gt (var 2 float8) (param 1 float8)))"

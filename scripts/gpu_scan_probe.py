@@ -5,7 +5,7 @@ import time
 
 import numpy as np
 
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 import pg_strom_amd as ps
 from pg_strom_amd import kds, runtime
 from pg_strom_amd.gpuscan import GpuScan, STROM_RESULTS_ON_DEVICE

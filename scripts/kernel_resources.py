@@ -7,7 +7,7 @@ import re
 import subprocess
 import sys
 
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 import os  # noqa: E402
 
 from pg_strom_amd import gpuhashjoin, gpupreagg, runtime  # noqa: E402

@@ -111,11 +111,15 @@ def test_reference_regression_suites_on_device(fmt, nchunks):
     assert total >= 200
 
 
-def compare_with_oracle(spec, bufs, domain, ext=(), float_tol=1e-12):
+def compare_with_oracle(spec, bufs, domain, ext=(), float_tol=1e-12, compact=False):
     agg = GpuPreAgg(spec)
     agg.begin(domain, ext_params=ext)
     nt = len(agg.targets)
     try:
+        if compact:
+            for b in bufs:
+                agg.census(b)
+            agg.compact()
         for b in bufs:
             status, _ = agg.fold(b)
             assert status == 0
@@ -294,3 +298,77 @@ def test_c4_shape_full_size_properties():
     assert np.array_equal(pr.column(1)[0][order], cnt)
     assert np.array_equal(pr.column(2)[0][order], sx.astype(np.int64))
     assert np.allclose(pr.column(3)[0][order], sy, rtol=1e-12, atol=0)
+
+
+# ---- group-slot agreement: census + compact ----------
+SPARSE_SPEC = ("(gpupreagg (qual (int4gt (var 3 int4) (const int4 -900000)))"
+               " (key (var 1 int4)) (key (var 2 int2)) (nrows)"
+               " (psum (int8 (var 3 int4))) (psum (var 4 float8)) (pmax (var 3 int4)))")
+
+
+def sparse_table(n, seed):
+    """two keys with wide ranges, a dozen combinations that occur"""
+    rng = np.random.default_rng(seed)
+    combos = [(int(a), int(b)) for a, b in zip(rng.integers(-500, 500, 12), rng.integers(0, 200, 12))]
+    pick = rng.integers(0, len(combos), n)
+    g = np.array([combos[i][0] for i in pick], dtype=np.int32)
+    h = np.array([combos[i][1] for i in pick], dtype=np.int16)
+    gn = rng.random(n) < 0.02
+    x = rng.integers(-10**6, 10**6, n).astype(np.int32)
+    y = rng.random(n)
+    return [kds.Column("int4", g, gn), kds.Column("int2", h), kds.Column("int4", x), kds.Column("float8", y)]
+
+
+@pytest.mark.parametrize("fmt", ["column", "row", "tupslot"])
+def test_compacted_slots_give_the_same_partial_rows(fmt):
+    cols = sparse_table(60000, 77)
+    bufs = [kds.build_kds(fmt, [kds.Column(c.sqltype, c.values[s], None if c.isnull is None else c.isnull[s])
+                                for c in cols]) for s in (slice(0, 25000), slice(25000, 60000))]
+    domain = [(-500, 1000), (0, 200)]
+    compare_with_oracle(SPARSE_SPEC, bufs, domain, compact=True)
+
+
+def test_census_bitmap_is_the_set_of_dense_ids_that_pass_the_qual():
+    cols = sparse_table(40000, 78)
+    buf = kds.build_kds("column", cols)
+    domain = [(-500, 1000), (0, 200)]
+    agg = GpuPreAgg(SPARSE_SPEC).begin(domain)
+    try:
+        bitmap = agg.census(buf)
+        g, h, x = cols[0], cols[1], cols[2]
+        ok = x.values > -900000
+        off_g = np.where(g.isnull != 0, 1000, g.values.astype(np.int64) + 500)
+        dense = (off_g + (h.values.astype(np.int64) - 0) * 1001)[ok]
+        want = np.zeros(len(bitmap) * 32, dtype=bool)
+        want[np.unique(dense)] = True
+        got = np.unpackbits(bitmap.view(np.uint8), bitorder="little").astype(bool)
+        assert np.array_equal(got, want)
+        ngroups = agg.compact()
+        assert ngroups == len(np.unique(dense))
+        # the compacted table is small enough for the lane-private kernel
+        status, _ = agg.fold(buf)
+        assert status == 0
+        pr = agg.fetch()
+        assert len(pr.column(0)[0]) == ngroups
+    finally:
+        agg.end()
+
+
+def test_unmarked_combination_fails_its_chunk_after_compact():
+    cols = sparse_table(20000, 79)
+    first = kds.build_kds("column", cols)
+    agg = GpuPreAgg(SPARSE_SPEC).begin([(-500, 1000), (0, 200)])
+    try:
+        agg.census(first)
+        agg.compact()
+        assert agg.fold(first)[0] == 0
+        other = [kds.Column("int4", np.array([499], dtype=np.int32)), kds.Column("int2", np.array([199], dtype=np.int16)),
+                 kds.Column("int4", np.array([5], dtype=np.int32)), kds.Column("float8", np.array([0.5]))]
+        with pytest.raises(runtime.StromError) as ei:
+            agg.fold(kds.build_kds("column", other))
+        assert ei.value.errcode == 302          # StromError_DataStoreOutOfRange
+        # census / compact are planning-time calls: refused once folding began
+        with pytest.raises(runtime.StromError):
+            agg.compact()
+    finally:
+        agg.end()

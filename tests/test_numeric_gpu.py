@@ -114,7 +114,8 @@ def test_fixed_point_numeric_partials_and_wide_sums():
     assert sum(r[1] for r in rows if r[1] is not None) == sum(big)
 
 
-def test_tpch_q1_shape():
+@pytest.mark.parametrize("compact", [False, True])
+def test_tpch_q1_shape(compact):
     """returnflag, linestatus, sum(qty), sum(price), sum(price*(1-disc)),
     sum(price*(1-disc)*(1+tax)), avg(qty), avg(price), avg(disc), count(*)
     WHERE shipdate <= date '1998-09-02' (SURVEY.md section 8d, C5 columns)"""
@@ -143,6 +144,11 @@ def test_tpch_q1_shape():
     chunks = [kds.build_kds("column", [kds.Column(c.sqltype, c.values[s], None) for c in cols])
               for s in (slice(0, half), slice(half, n))]
     agg = GpuPreAgg(spec).begin([(65, 18), (70, 10)])
+    if compact:
+        # 19 x 11 dense ids, 6 combinations occur: agree on 6 table slots first
+        for b in chunks:
+            agg.census(b)
+        assert agg.compact() == 6
     for b in chunks:
         assert agg.fold(b)[0] == 0
     got = {(r[0], r[1]): r for r in fetch_rows(agg)}

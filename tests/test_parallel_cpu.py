@@ -92,3 +92,36 @@ def test_pack_unpack_round_trip():
     b = np.lexsort((gv[:, 0].view(np.int64), gn[:, 0]))
     assert np.array_equal(isn[a], gn[b])
     assert np.array_equal(np.where(isn[a], 0, v[a]), np.where(gn[b], 0, gv[b]))
+
+
+def _census_worker(rank, world, port, outq):
+    sys.path.insert(0, os.path.dirname(HERE))
+    import torch.distributed as dist
+    from pg_strom_amd import parallel
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    try:
+        nbits = 209                                  # the Q1 domain: 19 x 11 dense ids
+        mine = np.zeros((nbits + 31) // 32, dtype=np.uint32)
+        for d in ((0, 5, 40, 208) if rank == 0 else (5, 77, 100)):
+            mine[d >> 5] |= np.uint32(1 << (d & 31))
+        merged = parallel.allreduce_census(mine)
+        got = np.flatnonzero(np.unpackbits(merged.view(np.uint8), bitorder="little"))
+        outq.put((rank, [int(x) for x in got]))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_ranks_agree_on_group_slots():
+    """census bitmaps are OR-ed over the ranks: both compact to the same slots"""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_census_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(180)
+        assert p.exitcode == 0
+    res = dict(q.get(timeout=5) for _ in range(2))
+    assert res[0] == res[1] == [0, 5, 40, 77, 100, 208]
