@@ -70,6 +70,62 @@ def cpu_baseline(k, c, budget_s=12.0):
     }
 
 
+def cpu_worker(k, c, seconds):
+    """one host core's share of the all-cores baseline (child process: no GPU)"""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_binding as oracle
+    from pg_strom_amd import kds
+    chunk_rows = 325_000
+    a, b = make_columns(chunk_rows, 0x5eed0002)
+    buf = kds.build_kds("row", [kds.Column("int4", a), kds.Column("float8", b)])
+    oracle.gpuscan(C2_QUAL, buf, [k, c])
+    t0 = time.perf_counter()
+    reps = 0
+    while time.perf_counter() - t0 < seconds:
+        oracle.gpuscan(C2_QUAL, buf, [k, c])
+        reps += 1
+    print(json.dumps({"rows": reps * chunk_rows, "seconds": time.perf_counter() - t0}), flush=True)
+
+
+def cpu_baseline_all_cores(k, c, seconds=8.0):
+    """chunk-parallel flavour of the same baseline: one child process per
+    host core, each scanning its own ROW chunk"""
+    import subprocess
+    try:
+        ncores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        ncores = os.cpu_count() or 1
+    ncores = max(1, min(ncores, 64))
+    procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-worker",
+                               "%d,%r,%f" % (int(k), float(c), seconds)],
+                              stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True)
+             for _ in range(ncores)]
+    rate = 0.0
+    for p in procs:
+        out, _ = p.communicate(timeout=seconds * 10 + 120)
+        for line in out.splitlines():
+            if line.startswith("{"):
+                d = json.loads(line)
+                rate += d["rows"] / d["seconds"]
+    return {"value": rate / 1e6, "unit": "Mrows/s", "cores": ncores, "kind": "port",
+            "sample": "%d processes x %.0f s of 325000-row KDS_FORMAT_ROW chunks" % (ncores, seconds)}
+
+
+def cpu_baseline_columnar(k, c, seconds=3.0):
+    """best-effort columnar flavour: vectorised numpy over COLUMN arrays on
+    one core -- shows the GPU/CPU ratio is not a row-format artefact"""
+    n = 10_000_000
+    a, b = make_columns(n, 0x5eed0002)
+    t0 = time.perf_counter()
+    reps = 0
+    while time.perf_counter() - t0 < seconds:
+        sel = np.flatnonzero((a < k) & (b > c)).astype(np.int32)
+        reps += 1
+    dt = time.perf_counter() - t0
+    return {"value": reps * n / dt / 1e6, "unit": "Mrows/s", "cores": 1, "kind": "port",
+            "sample": "%d x %d-row column arrays, numpy (a<k)&(b>c) -> row ids, %.1f s" % (reps, n, dt)}
+
+
 def load_traffic(chunk_rows):
     """per-launch HBM bytes from the committed rocprofv3 --pmc passes, if any"""
     path = os.path.join(ROOT, "profiles", "gpuscan_traffic.json")
@@ -93,7 +149,12 @@ def main():
                     help="requests kept in flight (pg_strom.max_async_chunks)")
     ap.add_argument("--selectivity", type=float, default=0.10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-worker", default=None, help=argparse.SUPPRESS)
     args = ap.parse_args()
+    if args.cpu_worker:
+        kk, cc, secs = args.cpu_worker.split(",")
+        cpu_worker(np.int32(int(kk)), float(cc), float(secs))
+        return
 
     import torch
     import torch.distributed as dist
@@ -237,6 +298,8 @@ def main():
         }
         if ngpus == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(k, c)
+            out["cpu_baseline_all_cores"] = cpu_baseline_all_cores(k, c)
+            out["cpu_baseline_columnar"] = cpu_baseline_columnar(k, c)
         print(json.dumps(out), flush=True)
 
     scan.end()

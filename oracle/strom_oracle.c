@@ -789,6 +789,13 @@ parse_expr(parser *ps)
 		e->attno = atoi(buf);
 		if (!read_atom(ps, buf, sizeof(buf)) || !(e->type_oid = type_by_name(buf)))
 		{ perr(ps, "bad type"); goto fail; }
+		/* (var ATTNO numeric SCALE): the column's typmod scale -- a promise
+		 * the device emitter uses to pick fixed-point code; the value is the
+		 * same, so the checker ignores it */
+		if (head[0] == 'v' && !peek_close(ps))
+		{
+			if (!read_atom(ps, buf, sizeof(buf))) { perr(ps, "scale expected"); goto fail; }
+		}
 	}
 	else if (!strcmp(head, "ivar"))
 	{

@@ -606,6 +606,60 @@ type_atom(const sexpr &n)
 
 static int emit_expr(const sexpr &n, codegen_context &ctx, std::string &out);
 
+/*
+ * fixed-scale numerics (strom_numeric.h, pg_fixed_t): pseudo type ids that
+ * exist only inside the emitter.  STROM_FIXED_BASE + s = int64 at 10^-s.
+ */
+bool	codegen_type_is_fixed(int t) { return t >= STROM_FIXED_BASE && t <= STROM_FIXED_BASE + 18; }
+int		codegen_fixed_scale(int t) { return t - STROM_FIXED_BASE; }
+
+static std::string
+pow10_literal(int k)
+{
+	std::string s = "1";
+	for (int i = 0; i < k; i++)
+		s += "0";
+	return s + "L";
+}
+
+/* fixed<scale> text -> pg_numeric_t text */
+std::string
+codegen_fixed_as_numeric(const std::string &text, int scale)
+{
+	/* a literal carries its kern_parambuf twin: pg_fixed_lit(VALUE, KP.KPARAM_n) */
+	if (text.compare(0, 13, "pg_fixed_lit(") == 0 && text.back() == ')')
+	{
+		size_t comma = text.find(", ");
+		if (comma != std::string::npos)
+			return text.substr(comma + 2, text.size() - comma - 3);
+	}
+	return "pgfn_fixed_to_numeric(errcode, " + text + ", " + std::to_string(scale) + ")";
+}
+
+/* fixed<from> text -> fixed<to> text, to >= from */
+std::string
+codegen_fixed_rescale(const std::string &text, int from, int to)
+{
+	if (to == from)
+		return text;
+	return "pgfn_fixed_scaleup(errcode, " + text + ", " + pow10_literal(to - from) + ")";
+}
+
+/* like emit_expr, but a fixed-scale result is turned into a plain numeric */
+static int
+emit_expr_plain(const sexpr &n, codegen_context &ctx, std::string &out)
+{
+	std::string t;
+	int		type = emit_expr(n, ctx, t);
+	if (codegen_type_is_fixed(type))
+	{
+		out += codegen_fixed_as_numeric(t, codegen_fixed_scale(type));
+		return STROM_NUMERICOID;
+	}
+	out += t;
+	return type;
+}
+
 static void
 emit_bool_chain(const sexpr &n, codegen_context &ctx, std::string &out, const char *fn)
 {
@@ -655,6 +709,35 @@ emit_expr(const sexpr &n, codegen_context &ctx, std::string &out)
 			literal_to_datum(t, n.items[2].atom, &d);
 		ctx.extra_flags |= t->type_flags;
 		snprintf(tmp, sizeof(tmp), "KP.KPARAM_%d", ctx.track_param(d));
+		if (t->type_oid == STROM_NUMERICOID && !d.isnull)
+		{
+			/* plain decimal literal: also usable as a fixed-scale value */
+			const std::string &lit = n.items[2].atom;
+			size_t	i = 0, ndigits = 0, ndec = 0;
+			bool	neg = false, seen_dot = false, ok = !lit.empty();
+			std::string digits;
+			if (i < lit.size() && (lit[i] == '+' || lit[i] == '-'))
+				neg = (lit[i++] == '-');
+			for (; ok && i < lit.size(); i++)
+			{
+				if (lit[i] >= '0' && lit[i] <= '9')
+				{
+					digits += lit[i];
+					ndigits++;
+					if (seen_dot)
+						ndec++;
+				}
+				else if (lit[i] == '.' && !seen_dot)
+					seen_dot = true;
+				else
+					ok = false;
+			}
+			if (ok && ndigits >= 1 && ndigits <= 18 && ndec <= 18)
+			{
+				out += std::string("pg_fixed_lit(") + (neg ? "-" : "") + digits + "L, " + tmp + ")";
+				return STROM_FIXED_BASE + (int)ndec;
+			}
+		}
 		out += tmp;
 		return t->type_oid;
 	}
@@ -678,8 +761,8 @@ emit_expr(const sexpr &n, codegen_context &ctx, std::string &out)
 	}
 	if (head == "var")
 	{
-		if (nargs != 2 || n.items[1].is_list)
-			codegen_error("(var ATTNO TYPE) expected");
+		if ((nargs != 2 && nargs != 3) || n.items[1].is_list)
+			codegen_error("(var ATTNO TYPE [SCALE]) expected");
 		const devtype_info *t = type_atom(n.items[2]);
 		int		attno = atoi(n.items[1].atom.c_str());
 		if (attno < 1)
@@ -688,6 +771,15 @@ emit_expr(const sexpr &n, codegen_context &ctx, std::string &out)
 		ctx.extra_flags |= t->type_flags;
 		snprintf(tmp, sizeof(tmp), "%s.%s_%d", ctx.var_struct.c_str(),
 				 ctx.var_label.c_str(), attno);
+		if (nargs == 3)
+		{
+			/* typmod scale of a numeric column: fixed-point from here on */
+			int		scale = (n.items[3].is_list ? -1 : atoi(n.items[3].atom.c_str()));
+			if (t->type_oid != STROM_NUMERICOID || scale < 0 || scale > 18)
+				codegen_error("(var ATTNO numeric SCALE): scale 0..18 on a numeric column expected");
+			out += std::string("pgfn_numeric_as_fixed(errcode, ") + tmp + ", " + std::to_string(scale) + ")";
+			return STROM_FIXED_BASE + scale;
+		}
 		out += tmp;
 		return t->type_oid;
 	}
@@ -738,8 +830,11 @@ emit_expr(const sexpr &n, codegen_context &ctx, std::string &out)
 			codegen_error("(%s e) expected", head.c_str());
 		std::string arg;
 		int		t = emit_expr(n.items[1], ctx, arg);
-		out += "pgfn_" + std::string(devtype_lookup(t)->dev_name) + "_" + head +
-			"(errcode, " + arg + ")";
+		if (codegen_type_is_fixed(t))
+			out += "pgfn_fixed_" + head + "(errcode, " + arg + ")";
+		else
+			out += "pgfn_" + std::string(devtype_lookup(t)->dev_name) + "_" + head +
+				"(errcode, " + arg + ")";
 		return STROM_BOOLOID;
 	}
 	if (head == "is_true" || head == "is_not_true" || head == "is_false" ||
@@ -758,7 +853,7 @@ emit_expr(const sexpr &n, codegen_context &ctx, std::string &out)
 		if (nargs != 2)
 			codegen_error("(relabel TYPE e) expected");
 		const devtype_info *t = type_atom(n.items[1]);
-		int		at = emit_expr(n.items[2], ctx, out);
+		int		at = emit_expr_plain(n.items[2], ctx, out);
 		if (devtype_lookup(at)->type_length != t->type_length)
 			codegen_error("relabel between types of different width");
 		return at;		/* same binary form */
@@ -776,7 +871,7 @@ emit_expr(const sexpr &n, codegen_context &ctx, std::string &out)
 		{
 			if (nargs < 2)
 				codegen_error("(case_eq arg (when v r) ... (else d)) expected");
-			argtype = emit_expr(n.items[1], ctx, argtext);
+			argtype = emit_expr_plain(n.items[1], ctx, argtext);
 			first = 2;
 		}
 		int			restype = 0;
@@ -793,7 +888,7 @@ emit_expr(const sexpr &n, codegen_context &ctx, std::string &out)
 				if (c.items.size() != 3 || has_else)
 					codegen_error("(when cond result) expected before (else ...)");
 				std::string cond, res;
-				int ct = emit_expr(c.items[1], ctx, cond);
+				int ct = emit_expr_plain(c.items[1], ctx, cond);
 				if (head == "case_eq")
 				{
 					const char *eq = devtype_eqfunc(argtype);
@@ -805,7 +900,7 @@ emit_expr(const sexpr &n, codegen_context &ctx, std::string &out)
 				}
 				else if (ct != STROM_BOOLOID)
 					codegen_error("WHEN condition is not bool");
-				int rt = emit_expr(c.items[2], ctx, res);
+				int rt = emit_expr_plain(c.items[2], ctx, res);
 				if (restype == 0)	restype = rt;
 				else if (restype != rt)
 					codegen_error("CASE branches have different types");
@@ -817,7 +912,7 @@ emit_expr(const sexpr &n, codegen_context &ctx, std::string &out)
 				if (c.items.size() != 2)
 					codegen_error("(else result) expected");
 				std::string res;
-				int rt = emit_expr(c.items[1], ctx, res);
+				int rt = emit_expr_plain(c.items[1], ctx, res);
 				if (restype == 0)	restype = rt;
 				else if (restype != rt)
 					codegen_error("CASE branches have different types");
@@ -850,6 +945,61 @@ emit_expr(const sexpr &n, codegen_context &ctx, std::string &out)
 		argtypes.push_back(emit_expr(n.items[i], ctx, t));
 		argtexts.push_back(t);
 	}
+	/* fixed-scale numerics: scales are resolved here, at code-generation time */
+	bool	any_fixed = false, all_fixed = (nargs > 0);
+	for (int t : argtypes)
+	{
+		any_fixed = any_fixed || codegen_type_is_fixed(t);
+		all_fixed = all_fixed && codegen_type_is_fixed(t);
+	}
+	if (all_fixed)
+	{
+		ctx.extra_flags |= DEVFUNC_NEEDS_NUMERIC;
+		if (nargs == 2 && (head == "numeric_add" || head == "numeric_sub"))
+		{
+			int s1 = codegen_fixed_scale(argtypes[0]), s2 = codegen_fixed_scale(argtypes[1]);
+			int sc = std::max(s1, s2);
+			out += "pgfn_fixed_" + head.substr(8) + "(errcode, " +
+				codegen_fixed_rescale(argtexts[0], s1, sc) + ", " +
+				codegen_fixed_rescale(argtexts[1], s2, sc) + ")";
+			return STROM_FIXED_BASE + sc;
+		}
+		if (nargs == 2 && head == "numeric_mul" &&
+			codegen_fixed_scale(argtypes[0]) + codegen_fixed_scale(argtypes[1]) <= 18)
+		{
+			out += "pgfn_fixed_mul(errcode, " + argtexts[0] + ", " + argtexts[1] + ")";
+			return STROM_FIXED_BASE + codegen_fixed_scale(argtypes[0]) + codegen_fixed_scale(argtypes[1]);
+		}
+		if (nargs == 2 && (head == "numeric_eq" || head == "numeric_ne" || head == "numeric_lt" ||
+						   head == "numeric_le" || head == "numeric_gt" || head == "numeric_ge"))
+		{
+			int s1 = codegen_fixed_scale(argtypes[0]), s2 = codegen_fixed_scale(argtypes[1]);
+			int sc = std::max(s1, s2);
+			out += "pgfn_fixed_" + head.substr(8) + "(errcode, " +
+				codegen_fixed_rescale(argtexts[0], s1, sc) + ", " +
+				codegen_fixed_rescale(argtexts[1], s2, sc) + ")";
+			return STROM_BOOLOID;
+		}
+		if (nargs == 1 && (head == "numeric_uminus" || head == "numeric_abs" || head == "numeric_uplus"))
+		{
+			if (head == "numeric_uplus")
+				out += argtexts[0];
+			else
+				out += "pgfn_fixed_" + head.substr(8) + "(errcode, " + argtexts[0] + ")";
+			return argtypes[0];
+		}
+	}
+	if (any_fixed)
+	{
+		/* mixed with a scale-less value or not a fixed-point operation:
+		 * back to the 64-bit numeric form */
+		for (size_t i = 0; i < argtypes.size(); i++)
+			if (codegen_type_is_fixed(argtypes[i]))
+			{
+				argtexts[i] = codegen_fixed_as_numeric(argtexts[i], codegen_fixed_scale(argtypes[i]));
+				argtypes[i] = STROM_NUMERICOID;
+			}
+	}
 	const devfunc_info *f = devfunc_lookup(head, argtypes);
 	if (!f)
 	{
@@ -868,6 +1018,13 @@ emit_expr(const sexpr &n, codegen_context &ctx, std::string &out)
 
 int
 codegen_expression(const sexpr &n, codegen_context &ctx, std::string &out)
+{
+	return emit_expr_plain(n, ctx, out);
+}
+
+/* may return a fixed-scale pseudo type (codegen_type_is_fixed) */
+int
+codegen_expression_raw(const sexpr &n, codegen_context &ctx, std::string &out)
 {
 	return emit_expr(n, ctx, out);
 }

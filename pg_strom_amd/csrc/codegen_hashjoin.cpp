@@ -40,6 +40,7 @@ struct rel {
 	std::vector<hashkey> keys;
 	std::string	qual_text;		/* empty: none */
 	std::set<std::pair<int,int>> ivars;	/* (attno, type) of this depth used anywhere */
+	std::set<std::pair<int,int>> expr_ivars;	/* ... used by an expression (not only as a key column) */
 };
 
 bool
@@ -126,13 +127,16 @@ strom_codegen_gpuhashjoin(const char *spec, strom_codegen_result *out, int *p_nr
 			codegen_error("1..8 inner relations expected");
 		/* inner columns referenced through (ivar ..), plus every key column */
 		for (auto &iv : ctx.used_ivars)
+		{
 			rels[iv.depth - 1].ivars.insert({iv.attno, iv.type_oid});
+			rels[iv.depth - 1].expr_ivars.insert({iv.attno, iv.type_oid});
+		}
 		for (auto &R : rels)
 			for (auto &k : R.keys)
 				R.ivars.insert({k.inner_attno, k.type_oid});
 
 		int		nrels = (int)rels.size();
-		char	tmp[256];
+		char	tmp[1024];
 		std::string src = "/* generated by strom_codegen_gpuhashjoin */\n";
 		src += codegen_includes(ctx.extra_flags);
 		src += codegen_param_list(ctx);
@@ -195,8 +199,8 @@ strom_codegen_gpuhashjoin(const char *spec, strom_codegen_result *out, int *p_nr
 		/* ---- gpuhashjoin_execute: nested probe loops --------------------- */
 		src += "STROM_DEVICE cl_uint\n"
 			"gpuhashjoin_execute(cl_int *errcode, const strom_kparams &KP, const strom_kvars &KV,\n"
-			"                    const kern_multihash *kmhash, const hashjoin_index *hjidx,\n"
-			"                    cl_uint kds_index, cl_int *rbuffer)\n{\n"
+			"                    const kern_multihash *__restrict__ kmhash, const hashjoin_index *__restrict__ hjidx,\n"
+			"                    cl_uint kds_index, cl_int *__restrict__ rbuffer)\n{\n"
 			"  cl_uint n_matches = 0;\n";
 		std::string indent = "  ";
 		std::string closing;
@@ -225,23 +229,40 @@ strom_codegen_gpuhashjoin(const char *spec, strom_codegen_result *out, int *p_nr
 						 indent.c_str(), d, k, d, k);
 				src += tmp;
 			}
+			/*
+			 * A DIRECT index (one integer-like key, slots[key - min]) chains
+			 * exactly the entries of that key: the key comparison is implied
+			 * and, when the keys are unique too, the entry is not read at all
+			 * -- the probe then costs one 4-byte slot read per outer row.
+			 */
+			bool	direct_ok = (R.keys.size() == 1 && type_is_intlike(R.keys[0].type_oid));
 			snprintf(tmp, sizeof(tmp),
 					 "%scl_uint hash_%d;\n"
-					 "%sfor (cl_uint off_%d = hashjoin_first(hjidx, %d, kimg_%d, %zu, &hash_%d);\n"
+					 "%sconst bool direct_%d = %s;\n"
+					 "%sconst bool single_%d = direct_%d && hjidx->rel[%d].unique != 0;\n"
+					 "%sfor (cl_uint off_%d = hashjoin_first(hjidx, %d, kimg_%d, %zu, &hash_%d), next_%d = 0;\n"
 					 "%s     off_%d != 0;\n"
-					 "%s     off_%d = ((const kern_hashentry *)((const char *)kht_%d + off_%d))->next)\n%s{\n",
+					 "%s     off_%d = next_%d)\n%s{\n",
 					 indent.c_str(), d,
-					 indent.c_str(), d, d - 1, d, R.keys.size(), d,
 					 indent.c_str(), d,
-					 indent.c_str(), d, d, d, indent.c_str());
+					 direct_ok ? ("hjidx->rel[" + std::to_string(d - 1) + "].mode == HASHJOIN_MODE_DIRECT").c_str() : "false",
+					 indent.c_str(), d, d, d - 1,
+					 indent.c_str(), d, d - 1, d, R.keys.size(), d, d,
+					 indent.c_str(), d,
+					 indent.c_str(), d, d, indent.c_str());
 			src += tmp;
 			indent += "  ";
 			snprintf(tmp, sizeof(tmp),
 					 "%sconst kern_hashentry *ent_%d = (const kern_hashentry *)((const char *)kht_%d + off_%d);\n"
-					 "%sif (!hashjoin_candidate(hjidx, %d, ent_%d, hash_%d))\n%s  continue;\n",
-					 indent.c_str(), d, d, d, indent.c_str(), d - 1, d, d, indent.c_str());
+					 "%snext_%d = (single_%d ? 0 : ent_%d->next);\n"
+					 "%sif (!direct_%d && ent_%d->hash != hash_%d)\n%s  continue;\n",
+					 indent.c_str(), d, d, d,
+					 indent.c_str(), d, d, d,
+					 indent.c_str(), d, d, d, indent.c_str());
 			src += tmp;
-			for (auto &iv : R.ivars)
+			/* inner columns an expression refers to are fetched here; columns
+			 * that only serve the key comparison inside its branch */
+			for (auto &iv : R.expr_ivars)
 			{
 				const char *tn = devtype_lookup(iv.second)->dev_name;
 				snprintf(tmp, sizeof(tmp),
@@ -249,8 +270,10 @@ strom_codegen_gpuhashjoin(const char *spec, strom_codegen_result *out, int *p_nr
 						 indent.c_str(), tn, d, iv.first, tn, d, d, iv.first - 1);
 				src += tmp;
 			}
+			snprintf(tmp, sizeof(tmp), "%sbool keys_equal_%d = true;\n%sif (!direct_%d)\n%s{\n",
+					 indent.c_str(), d, indent.c_str(), d, indent.c_str());
+			src += tmp;
 			/* hash clauses: outer key = inner column, by the type's equality function */
-			std::string cond;
 			for (size_t k = 0; k < R.keys.size(); k++)
 			{
 				int		rettype, flags;
@@ -260,10 +283,29 @@ strom_codegen_gpuhashjoin(const char *spec, strom_codegen_result *out, int *p_nr
 				if (eq.empty())
 					codegen_error("no device equality function for hash key");
 				ctx.extra_flags |= flags;
-				snprintf(tmp, sizeof(tmp), "%sEVAL(pgfn_%s(errcode, okey_%d_%zu, IVAR_%d_%d))",
-						 k ? " && " : "", eq.c_str(), d, k, d, R.keys[k].inner_attno);
-				cond += tmp;
+				const char *tn = devtype_lookup(R.keys[k].type_oid)->dev_name;
+				std::string ivname;
+				if (R.expr_ivars.count({R.keys[k].inner_attno, R.keys[k].type_oid}))
+				{
+					snprintf(tmp, sizeof(tmp), "IVAR_%d_%d", d, R.keys[k].inner_attno);
+					ivname = tmp;
+				}
+				else
+				{
+					snprintf(tmp, sizeof(tmp), "ikey_%d_%zu", d, k);
+					ivname = tmp;
+					snprintf(tmp, sizeof(tmp),
+							 "%s  pg_%s_t %s = pg_%s_tupref(kht_%d->colmeta, &ent_%d->htup, %d);\n",
+							 indent.c_str(), tn, ivname.c_str(), tn, d, d, R.keys[k].inner_attno - 1);
+					src += tmp;
+				}
+				snprintf(tmp, sizeof(tmp),
+						 "%s  keys_equal_%d = keys_equal_%d && EVAL(pgfn_%s(errcode, okey_%d_%zu, %s));\n",
+						 indent.c_str(), d, d, eq.c_str(), d, k, ivname.c_str());
+				src += tmp;
 			}
+			src += indent + "}\n";
+			std::string cond = "keys_equal_" + std::to_string(d);
 			if (!R.qual_text.empty())
 				cond += " && EVAL(" + R.qual_text + ")";
 			src += indent + "if (" + cond + ")\n" + indent + "{\n";
@@ -272,10 +314,11 @@ strom_codegen_gpuhashjoin(const char *spec, strom_codegen_result *out, int *p_nr
 		}
 		/* innermost: emit one record */
 		src += indent + "if (rbuffer)\n" + indent + "{\n" +
-			indent + "  rbuffer[0] = (cl_int)(kds_index + 1);\n";
+			indent + "  __builtin_nontemporal_store((cl_int)(kds_index + 1), &rbuffer[0]);\n";
 		for (int d = 1; d <= nrels; d++)
 		{
-			snprintf(tmp, sizeof(tmp), "%s  rbuffer[%d] = (cl_int)off_%d;\n", indent.c_str(), d, d);
+			snprintf(tmp, sizeof(tmp), "%s  __builtin_nontemporal_store((cl_int)off_%d, &rbuffer[%d]);\n",
+					 indent.c_str(), d, d);
 			src += tmp;
 		}
 		snprintf(tmp, sizeof(tmp), "%s  rbuffer += %d;\n%s}\n%sn_matches++;\n",

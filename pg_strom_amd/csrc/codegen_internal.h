@@ -41,6 +41,14 @@ struct codegen_context {
 	void	track_var(int attno, int type_oid);
 };
 
+/* fixed-scale numerics: pseudo type ids inside the emitter (codegen.cpp) */
+#define STROM_FIXED_BASE	0x7F000000
+bool		codegen_type_is_fixed(int type);
+int			codegen_fixed_scale(int type);
+std::string	codegen_fixed_as_numeric(const std::string &text, int scale);
+std::string	codegen_fixed_rescale(const std::string &text, int from, int to);
+int			codegen_expression_raw(const sexpr &n, codegen_context &ctx, std::string &out);
+
 [[noreturn]] void codegen_error(const char *fmt, ...);
 sexpr		sexpr_parse(const char *text);
 const devtype_info *devtype_lookup(int oid);

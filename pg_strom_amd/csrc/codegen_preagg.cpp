@@ -112,7 +112,21 @@ strom_codegen_gpupreagg(const char *spec, strom_codegen_result *out,
 				std::string e;
 				tg.kind = (head == "psum" ? STROM_PREAGG_PSUM :
 						   head == "pmin" ? STROM_PREAGG_PMIN : STROM_PREAGG_PMAX);
-				tg.type_oid = codegen_expression(t.items[1], ctx, e);
+				int		raw_type = codegen_expression_raw(t.items[1], ctx, e);
+				int		fixed_scale = -1;
+				if (codegen_type_is_fixed(raw_type))
+				{
+					/* typmod-scaled numerics stay int64 all the way into the sum */
+					fixed_scale = codegen_fixed_scale(raw_type);
+					int want = (nargs == 2 && !t.items[2].is_list) ? atoi(t.items[2].atom.c_str()) : -1;
+					if (want < fixed_scale || want > 18)
+					{
+						e = codegen_fixed_as_numeric(e, fixed_scale);
+						fixed_scale = -1;
+					}
+					raw_type = STROM_NUMERICOID;
+				}
+				tg.type_oid = raw_type;
 				if (tg.kind == STROM_PREAGG_PSUM &&
 					!(tg.type_oid == STROM_INT8OID || tg.type_oid == STROM_FLOAT8OID ||
 					  tg.type_oid == STROM_FLOAT4OID || tg.type_oid == STROM_NUMERICOID))
@@ -134,7 +148,11 @@ strom_codegen_gpupreagg(const char *spec, strom_codegen_result *out,
 					tg.acc_oid = STROM_INT8OID;
 					char sb[16];
 					snprintf(sb, sizeof(sb), "%d", tg.scale);
-					tg.body = "  return strom_numeric_to_fixed(errcode, " + e + ", " + sb + ");\n";
+					if (fixed_scale >= 0)
+						tg.body = "  return pgfn_fixed_to_int8(errcode, " +
+							codegen_fixed_rescale(e, fixed_scale, tg.scale) + ");\n";
+					else
+						tg.body = "  return strom_numeric_to_fixed(errcode, " + e + ", " + sb + ");\n";
 				}
 				else
 				{

@@ -495,4 +495,16 @@ strom_column_load_quad(const char *values, const cl_uint *notnull,
 	}
 }
 
+/*
+ * one datum of a COLUMN chunk from hoisted column pointers: what the
+ * row-at-a-time kernels use instead of kern_get_datum() when the chunk is
+ * KDS_FORMAT_COLUMN (row maps, several inner relations), so that no chunk
+ * header field is read per row.  Non-temporal: the column streams through
+ * once and must not evict what the kernel probes at random (hash slots).
+ */
+#define STROM_COLUMN_REF(NAME, values, notnull, rowidx)								\
+	pg_##NAME##_make(__builtin_nontemporal_load(&((const pg_##NAME##_base_t *)(values))[rowidx]),	\
+					 (notnull) != NULL &&												\
+					 !((((const cl_uint *)(notnull))[(rowidx) >> 5] >> ((rowidx) & 31)) & 1))
+
 #endif	/* STROM_COMMON_DEVICE_H */

@@ -94,13 +94,34 @@ struct gpupreagg_dense_ctl {
 	cl_uint		__pad;
 };
 
-/* dense id -> table slot; false when the combination is not in the table */
+/*
+ * dense id -> table slot; false when the combination is not in the table.
+ * A small map is staged in LDS by gpupreagg_remap_init(): the lookup sits on
+ * every row's dependent path (keys -> dense id -> slot -> accumulator
+ * address) and an L1/L2 round trip there costs more than the fold.
+ */
+#define GPUPREAGG_REMAP_LDS		1024
+__shared__ cl_uint	gpupreagg_remap_staged[GPUPREAGG_REMAP_LDS];
+
+STROM_DEVICE void
+gpupreagg_remap_init(const gpupreagg_dense_ctl *ctl)
+{
+	if (ctl->remap != 0 && ctl->dense_ngroups <= GPUPREAGG_REMAP_LDS)
+	{
+		for (cl_uint i = threadIdx.x; i < ctl->dense_ngroups; i += blockDim.x)
+			gpupreagg_remap_staged[i] = ((const cl_uint *)ctl->remap)[i];
+	}
+	__syncthreads();
+}
+
 STROM_DEVICE bool
 gpupreagg_remap_gid(const gpupreagg_dense_ctl *ctl, cl_uint &gid)
 {
 	if (ctl->remap != 0)
 	{
-		gid = ((const cl_uint *)ctl->remap)[gid];
+		gid = (ctl->dense_ngroups <= GPUPREAGG_REMAP_LDS
+			   ? gpupreagg_remap_staged[gid]
+			   : ((const cl_uint *)ctl->remap)[gid]);
 		if (gid == 0xffffffffu)
 			return false;
 	}
@@ -504,6 +525,7 @@ gpupreagg_dense_column(kern_gpupreagg *kgpreagg,
 	gpupreagg_lds_layout L;
 
 	gpupreagg_load_kparams(KP, kparams, &param_error);
+	gpupreagg_remap_init(ctl);
 	gpupreagg_lds_layout_init(L, G, NREP);
 	gpupreagg_lds_init(lds, L, G, NREP);
 
@@ -523,6 +545,7 @@ gpupreagg_dense_column(kern_gpupreagg *kgpreagg,
 		cl_uint		tile_base = tile * GPUPREAGG_TILE_ROWS;
 		bool		full_tile = (tile_base + GPUPREAGG_TILE_ROWS <= nitems);
 		gpupreagg_column_tile T;
+
 
 		if (full_tile && !any_nulls && shared_tiles)
 		{
@@ -636,8 +659,19 @@ gpupreagg_dense_generic(kern_gpupreagg *kgpreagg,
 	gpupreagg_lds_layout L;
 
 	gpupreagg_load_kparams(KP, kparams, &param_error);
+	gpupreagg_remap_init(ctl);
 	gpupreagg_lds_layout_init(L, G, NREP);
 	gpupreagg_lds_init(lds, L, G, NREP);
+	/* COLUMN chunk (row map, census): column pointers hoisted, no chunk
+	 * header field is read per row */
+	bool		is_column = (kds->format == KDS_FORMAT_COLUMN);
+	const kern_coldir *coldir_g = KERN_DATA_STORE_COLDIR(kds);
+#define X(attno,colidx,NAME)													\
+	const char *col_##attno = (is_column ? (const char *)kds + coldir_g[colidx].values_off : NULL);	\
+	const cl_uint *nul_##attno = ((is_column && coldir_g[colidx].nulls_off != 0)	\
+		? (const cl_uint *)((const char *)kds + coldir_g[colidx].nulls_off) : NULL);
+	STROM_KVAR_LIST(X)
+#undef X
 	for (size_t r = (size_t)wg_in_split * GPUPREAGG_BLOCK + threadIdx.x;
 		 r < nrows;
 		 r += (size_t)wgs_per_split * GPUPREAGG_BLOCK)
@@ -646,7 +680,9 @@ gpupreagg_dense_generic(kern_gpupreagg *kgpreagg,
 		strom_kvars	KV;
 		cl_int		errcode = param_error;
 #define X(attno,colidx,NAME)													\
-		KV.KVAR_##attno = pg_##NAME##_vref(kds, ktoast, &errcode, colidx, kds_index);
+		KV.KVAR_##attno = (is_column												\
+			? STROM_COLUMN_REF(NAME, col_##attno, nul_##attno, kds_index)			\
+			: pg_##NAME##_vref(kds, ktoast, &errcode, colidx, kds_index));
 		STROM_KVAR_LIST(X)
 #undef X
 		KV.__dummy = 0;
@@ -788,6 +824,7 @@ gpupreagg_reg_kernel_body(kern_gpupreagg *kgpreagg, const kern_data_store *kds,
 	gpupreagg_reg_state<NG> S;
 
 	gpupreagg_load_kparams(KP, kparams, &param_error);
+	gpupreagg_remap_init(ctl);
 	gpupreagg_lds_layout_init(L, G, 1);
 	/* LDS image (one replica) is only touched at the very end */
 	for (cl_uint i = threadIdx.x * 16; i < L.total; i += GPUPREAGG_REG_BLOCK * 16)
@@ -1097,6 +1134,7 @@ gpupreagg_priv_column(kern_gpupreagg *kgpreagg, const kern_data_store *kds,
 	gpupreagg_priv_state S;
 
 	gpupreagg_load_kparams(KP, kparams, &param_error);
+	gpupreagg_remap_init(ctl);
 	gpupreagg_lds_layout_init(L, G, 1);
 	/* work-group image, touched again only at the very end */
 	for (cl_uint i = threadIdx.x * 16; i < L.total; i += GPUPREAGG_REG_BLOCK * 16)
@@ -1332,6 +1370,16 @@ gpupreagg_census(const kern_gpupreagg *kgpreagg, const kern_data_store *kds,
 	strom_kparams KP;
 
 	gpupreagg_load_kparams(KP, kparams, &param_error);
+	/* COLUMN chunk (row map, census): column pointers hoisted, no chunk
+	 * header field is read per row */
+	bool		is_column = (kds->format == KDS_FORMAT_COLUMN);
+	const kern_coldir *coldir_g = KERN_DATA_STORE_COLDIR(kds);
+#define X(attno,colidx,NAME)													\
+	const char *col_##attno = (is_column ? (const char *)kds + coldir_g[colidx].values_off : NULL);	\
+	const cl_uint *nul_##attno = ((is_column && coldir_g[colidx].nulls_off != 0)	\
+		? (const cl_uint *)((const char *)kds + coldir_g[colidx].nulls_off) : NULL);
+	STROM_KVAR_LIST(X)
+#undef X
 	for (size_t r = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
 		 r < nrows;
 		 r += (size_t)gridDim.x * blockDim.x)
@@ -1342,7 +1390,9 @@ gpupreagg_census(const kern_gpupreagg *kgpreagg, const kern_data_store *kds,
 		cl_uint		gid = 0;
 		bool		out_of_domain = false;
 #define X(attno,colidx,NAME)													\
-		KV.KVAR_##attno = pg_##NAME##_vref(kds, ktoast, &errcode, colidx, kds_index);
+		KV.KVAR_##attno = (is_column												\
+			? STROM_COLUMN_REF(NAME, col_##attno, nul_##attno, kds_index)			\
+			: pg_##NAME##_vref(kds, ktoast, &errcode, colidx, kds_index));
 		STROM_KVAR_LIST(X)
 #undef X
 		KV.__dummy = 0;

@@ -330,6 +330,16 @@ gpuscan_qual_generic(kern_gpuscan *kgpuscan,
 
 	gpuscan_load_kparams(KP, kparams, &param_error);
 
+	/* COLUMN chunk behind a row map: column pointers hoisted, no chunk
+	 * header field is read per row */
+	bool		is_column = (kds->format == KDS_FORMAT_COLUMN);
+	const kern_coldir *coldir_g = KERN_DATA_STORE_COLDIR(kds);
+#define X(attno,colidx,NAME)													\
+	const char *col_##attno = (is_column ? (const char *)kds + coldir_g[colidx].values_off : NULL);	\
+	const cl_uint *nul_##attno = ((is_column && coldir_g[colidx].nulls_off != 0)	\
+		? (const cl_uint *)((const char *)kds + coldir_g[colidx].nulls_off) : NULL);
+	STROM_KVAR_LIST(X)
+#undef X
 	for (cl_uint tile = blockIdx.x; tile < ntiles; tile += gridDim.x)
 	{
 		cl_uint		tile_base = tile * GPUSCAN_TILE_ROWS;
@@ -356,8 +366,9 @@ gpuscan_qual_generic(kern_gpuscan *kgpuscan,
 					strom_kvars	KV;
 					cl_int		errcode = param_error;
 #define X(attno,colidx,NAME)													\
-					KV.KVAR_##attno = pg_##NAME##_vref(kds, ktoast, &errcode,		\
-													   colidx, kds_index);
+					KV.KVAR_##attno = (is_column									\
+						? STROM_COLUMN_REF(NAME, col_##attno, nul_##attno, kds_index)	\
+						: pg_##NAME##_vref(kds, ktoast, &errcode, colidx, kds_index));
 					STROM_KVAR_LIST(X)
 #undef X
 					KV.__dummy = 0;

@@ -149,8 +149,8 @@ hashjoin_fast_outer_key(cl_int *errcode, const strom_kparams &KP, const strom_kv
 						cl_long *p_key);
 STROM_DEVICE cl_uint
 gpuhashjoin_execute(cl_int *errcode, const strom_kparams &KP, const strom_kvars &KV,
-					const kern_multihash *kmhash, const hashjoin_index *hjidx,
-					cl_uint kds_index, cl_int *rbuffer);
+					const kern_multihash *__restrict__ kmhash, const hashjoin_index *__restrict__ hjidx,
+					cl_uint kds_index, cl_int *__restrict__ rbuffer);
 
 STROM_DEVICE int
 hashjoin_nkeys_of(int depth)
@@ -360,12 +360,12 @@ hashjoin_block_scan(cl_uint v, cl_uint *lds_wave_totals, cl_uint *p_total)
 
 extern "C" __global__ void
 __launch_bounds__(HASHJOIN_BLOCK)
-gpuhashjoin_main(kern_hashjoin *khashjoin,
-				 const kern_multihash *kmhash,
-				 const hashjoin_index *hjidx,
-				 const kern_data_store *kds,
-				 const kern_data_store *ktoast,
-				 const kern_row_map *krowmap)
+gpuhashjoin_main(kern_hashjoin *__restrict__ khashjoin,
+				 const kern_multihash *__restrict__ kmhash,
+				 const hashjoin_index *__restrict__ hjidx,
+				 const kern_data_store *__restrict__ kds,
+				 const kern_data_store *__restrict__ ktoast,
+				 const kern_row_map *__restrict__ krowmap)
 {
 	__shared__ cl_uint	wave_totals[HASHJOIN_NWAVES];
 	__shared__ cl_uint	tile_base_slot;
@@ -381,6 +381,15 @@ gpuhashjoin_main(kern_hashjoin *khashjoin,
 	strom_kparams KP;
 
 	hashjoin_load_kparams(KP, kparams, &param_error);
+	/* COLUMN chunk: column pointers hoisted, no header reads per row */
+	bool		is_column = (kds->format == KDS_FORMAT_COLUMN);
+	const kern_coldir *coldir = KERN_DATA_STORE_COLDIR(kds);
+#define X(attno,colidx,NAME)													\
+	const char *col_##attno = (is_column ? (const char *)kds + coldir[colidx].values_off : NULL);	\
+	const cl_uint *nul_##attno = ((is_column && coldir[colidx].nulls_off != 0)	\
+		? (const cl_uint *)((const char *)kds + coldir[colidx].nulls_off) : NULL);
+	STROM_KVAR_LIST(X)
+#undef X
 	if (nrels != kmhash->ntables + 1 || nrels != HASHJOIN_NRELS + 1)
 	{
 		/* uniform: every thread leaves (opencl_hashjoin.h:305-309) */
@@ -406,7 +415,9 @@ gpuhashjoin_main(kern_hashjoin *khashjoin,
 				cl_int		errcode = param_error;
 				strom_kvars	KV;
 #define X(attno,colidx,NAME)													\
-				KV.KVAR_##attno = pg_##NAME##_vref(kds, ktoast, &errcode, colidx, kds_index);
+				KV.KVAR_##attno = (is_column											\
+					? STROM_COLUMN_REF(NAME, col_##attno, nul_##attno, kds_index)		\
+					: pg_##NAME##_vref(kds, ktoast, &errcode, colidx, kds_index));
 				STROM_KVAR_LIST(X)
 #undef X
 				KV.__dummy = 0;
@@ -447,7 +458,9 @@ gpuhashjoin_main(kern_hashjoin *khashjoin,
 				cl_int		errcode = param_error;
 				strom_kvars	KV;
 #define X(attno,colidx,NAME)													\
-				KV.KVAR_##attno = pg_##NAME##_vref(kds, ktoast, &errcode, colidx, kds_index);
+				KV.KVAR_##attno = (is_column											\
+					? STROM_COLUMN_REF(NAME, col_##attno, nul_##attno, kds_index)		\
+					: pg_##NAME##_vref(kds, ktoast, &errcode, colidx, kds_index));
 				STROM_KVAR_LIST(X)
 #undef X
 				KV.__dummy = 0;

@@ -483,4 +483,173 @@ strom_numeric_to_fixed(cl_int *errcode, pg_numeric_t arg, int scale)
 	return r;
 }
 
+/* ====================================================================== *
+ * fixed-scale numerics: pg_fixed_t
+ *
+ * When the plan knows a numeric column's typmod scale -- (var N numeric
+ * SCALE) -- the emitter keeps the value as an int64 at 10^-SCALE for the
+ * whole expression: the column datum is converted once (exactly, or the
+ * row is re-checked), add / sub / mul / compare are single checked integer
+ * operations with scales resolved at code-generation time, and a partial
+ * sum needs no conversion at all.  The 64-bit float-decimal form stays the
+ * chunk format and the fallback for anything mixed with scale-less values.
+ * Results are exact; what overflows int64 goes back to the CPU like any
+ * other numeric overflow.
+ * ====================================================================== */
+struct pg_fixed_t {
+	cl_long		value;
+	cl_bool		isnull;
+};
+
+STROM_DEVICE pg_fixed_t
+pg_fixed_make(cl_long value, bool isnull)
+{
+	pg_fixed_t r;
+	r.value = value;
+	r.isnull = isnull;
+	return r;
+}
+
+/* a literal: 'asnumeric' is the same constant as a kern_parambuf entry, used
+ * by the emitter when the literal meets a scale-less operand */
+STROM_DEVICE pg_fixed_t
+pg_fixed_lit(cl_long value, pg_numeric_t asnumeric)
+{
+	return pg_fixed_make(value, false);
+}
+
+STROM_DEVICE pg_fixed_t
+pg_fixed_recheck(cl_int *errcode)
+{
+	STROM_SET_ERROR(errcode, StromError_CpuReCheck);
+	return pg_fixed_make(0, true);
+}
+
+STROM_DEVICE pg_fixed_t
+pgfn_numeric_as_fixed(cl_int *errcode, pg_numeric_t arg, int scale)
+{
+	pg_int8_t v = strom_numeric_to_fixed(errcode, arg, scale);
+	return pg_fixed_make(v.value, v.isnull);
+}
+
+STROM_DEVICE pg_numeric_t
+pgfn_fixed_to_numeric(cl_int *errcode, pg_fixed_t arg, int scale)
+{
+	if (arg.isnull)
+	{
+		pg_numeric_t v;
+		v.isnull = true;
+		v.value = 0;
+		return v;
+	}
+	bool		sign = (arg.value < 0);
+	cl_ulong	mant = (sign ? (cl_ulong)0 - (cl_ulong)arg.value : (cl_ulong)arg.value);
+	return strom_numeric_pack(errcode, -scale, sign, mant);
+}
+
+STROM_DEVICE pg_int8_t
+pgfn_fixed_to_int8(cl_int *errcode, pg_fixed_t arg)
+{
+	pg_int8_t r;
+	r.value = arg.value;
+	r.isnull = arg.isnull;
+	return r;
+}
+
+/* value * factor, factor = 10^k chosen by the emitter */
+STROM_DEVICE pg_fixed_t
+pgfn_fixed_scaleup(cl_int *errcode, pg_fixed_t arg, cl_long factor)
+{
+	if (arg.isnull)
+		return arg;
+	if (__builtin_mul_overflow(arg.value, factor, &arg.value))
+		return pg_fixed_recheck(errcode);
+	return arg;
+}
+
+STROM_DEVICE pg_fixed_t
+pgfn_fixed_add(cl_int *errcode, pg_fixed_t a, pg_fixed_t b)
+{
+	if (a.isnull || b.isnull)
+		return pg_fixed_make(0, true);
+	if (__builtin_add_overflow(a.value, b.value, &a.value))
+		return pg_fixed_recheck(errcode);
+	return a;
+}
+
+STROM_DEVICE pg_fixed_t
+pgfn_fixed_sub(cl_int *errcode, pg_fixed_t a, pg_fixed_t b)
+{
+	if (a.isnull || b.isnull)
+		return pg_fixed_make(0, true);
+	if (__builtin_sub_overflow(a.value, b.value, &a.value))
+		return pg_fixed_recheck(errcode);
+	return a;
+}
+
+STROM_DEVICE pg_fixed_t
+pgfn_fixed_mul(cl_int *errcode, pg_fixed_t a, pg_fixed_t b)
+{
+	if (a.isnull || b.isnull)
+		return pg_fixed_make(0, true);
+	/* both within int32 (amounts x rates): one 32x32->64 multiply */
+	if (a.value == (cl_long)(cl_int)a.value && b.value == (cl_long)(cl_int)b.value)
+		return pg_fixed_make((cl_long)(cl_int)a.value * (cl_long)(cl_int)b.value, false);
+	if (__builtin_mul_overflow(a.value, b.value, &a.value))
+		return pg_fixed_recheck(errcode);
+	return a;
+}
+
+STROM_DEVICE pg_fixed_t
+pgfn_fixed_uminus(cl_int *errcode, pg_fixed_t a)
+{
+	if (!a.isnull)
+	{
+		if (a.value == (-0x7fffffffffffffffL - 1))
+			return pg_fixed_recheck(errcode);
+		a.value = -a.value;
+	}
+	return a;
+}
+
+STROM_DEVICE pg_fixed_t
+pgfn_fixed_abs(cl_int *errcode, pg_fixed_t a)
+{
+	return (!a.isnull && a.value < 0) ? pgfn_fixed_uminus(errcode, a) : a;
+}
+
+STROM_DEVICE pg_bool_t
+pgfn_fixed_isnull(cl_int *errcode, pg_fixed_t a)
+{
+	pg_bool_t r;
+	r.isnull = false;
+	r.value = a.isnull;
+	return r;
+}
+
+STROM_DEVICE pg_bool_t
+pgfn_fixed_isnotnull(cl_int *errcode, pg_fixed_t a)
+{
+	pg_bool_t r;
+	r.isnull = false;
+	r.value = !a.isnull;
+	return r;
+}
+
+#define STROM_FIXED_COMPARE(name,OP)											\
+	STROM_DEVICE pg_bool_t														\
+	pgfn_fixed_##name(cl_int *errcode, pg_fixed_t a, pg_fixed_t b)				\
+	{																			\
+		pg_bool_t r;															\
+		r.isnull = a.isnull | b.isnull;											\
+		r.value = (!r.isnull && (a.value OP b.value));							\
+		return r;																\
+	}
+STROM_FIXED_COMPARE(eq, ==)
+STROM_FIXED_COMPARE(ne, !=)
+STROM_FIXED_COMPARE(lt, <)
+STROM_FIXED_COMPARE(le, <=)
+STROM_FIXED_COMPARE(gt, >)
+STROM_FIXED_COMPARE(ge, >=)
+
 #endif	/* STROM_NUMERIC_DEVICE_H */

@@ -159,7 +159,7 @@ setup_layout(strom_gpupreagg *sess)
 {
 	Device	   *dev = sess->dev;
 	dense_ctl  &ctl = sess->ctl;
-	size_t		lds_budget = std::min<size_t>(dev->prop.sharedMemPerBlock, 160 * 1024) - 4096;
+	size_t		lds_budget = std::min<size_t>(dev->prop.sharedMemPerBlock, 160 * 1024) - 8192;	/* static LDS: remap stage, scan scratch */
 
 	if (const char *v = getenv("STROM_GPUPREAGG_LDS_BUDGET"))
 		lds_budget = (size_t)atol(v);
@@ -227,7 +227,7 @@ setup_layout(strom_gpupreagg *sess)
 	ctl.slab_bytes = STROM_TYPEALIGN(256, sess->image_offset(sess->nsections(), ctl.groups_per_split, 1));
 	sess->table_bytes = sess->table_offset(sess->nsections(), ctl.ngroups);
 	/* work-groups: fill the CUs at the occupancy LDS allows */
-	size_t	per_cu = std::max<size_t>(1, std::min<size_t>((size_t)dev->prop.sharedMemPerBlock / std::max<size_t>(sess->lds_bytes, 1),
+	size_t	per_cu = std::max<size_t>(1, std::min<size_t>((size_t)dev->prop.sharedMemPerBlock / (sess->lds_bytes + 4608),	/* + static LDS */
 														  2048 / sess->block));
 	if (const char *v = getenv("STROM_GPUPREAGG_BLOCKS_PER_CU"))
 		per_cu = std::max(1, atoi(v));
@@ -240,7 +240,7 @@ setup_layout(strom_gpupreagg *sess)
 	if (sess->reg_groups)								/* 256-thread work-groups */
 	{
 		size_t	fit = std::max<size_t>(1, std::min<size_t>(8, (size_t)(160 * 1024) /
-															std::max<size_t>(sess->lds_bytes, 1)));
+															(sess->lds_bytes + 4608)));
 		if (const char *v = getenv("STROM_GPUPREAGG_BLOCKS_PER_CU"))
 			fit = std::max(1, atoi(v));
 		wgs = (size_t)dev->prop.multiProcessorCount * fit;

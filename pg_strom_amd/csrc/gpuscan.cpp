@@ -97,9 +97,18 @@ gpuscan_launch(strom_task_impl *task, Program *prog, gpuscan_request req)
 		task->pinned_blocks.push_back(stage);
 		memcpy(stage, kgs, head_len);
 	}
-	task_event(task);									/* ev[0] */
+	/*
+	 * resident chunk: three streams.  The small copies would otherwise sit
+	 * between two kernels of consecutive requests on the same stream (two
+	 * DMA round trips, ~20 us per 200 us kernel).
+	 */
+	bool		piped = (req.kds_dev != nullptr && stage != nullptr && dev->copy_in && dev->copy_out);
+	hipStream_t	s_in = (piped ? dev->copy_in : task->stream);
+	hipStream_t	s_out = (piped ? dev->copy_out : task->stream);
+
+	task_event(task, s_in);								/* ev[0] */
 	REQ_CHECK(hipMemcpyAsync(d_kgs, stage ? (void *)stage : (void *)kgs, head_len,
-							 hipMemcpyHostToDevice, task->stream),
+							 hipMemcpyHostToDevice, s_in),
 			  "send kern_gpuscan");
 	task->pfm.num_dma_send++;
 	task->pfm.bytes_dma_send += head_len;
@@ -137,13 +146,22 @@ gpuscan_launch(strom_task_impl *task, Program *prog, gpuscan_request req)
 			return;
 		}
 		task->devbufs.push_back(p);
-		REQ_CHECK(hipMemcpyAsync(p, req.krowmap, len, hipMemcpyHostToDevice, task->stream),
+		REQ_CHECK(hipMemcpyAsync(p, req.krowmap, len, hipMemcpyHostToDevice, s_in),
 				  "send kern_row_map");
 		task->pfm.num_dma_send++;
 		task->pfm.bytes_dma_send += len;
 		d_rowmap = p;
 	}
-	task_event(task);									/* ev[1] */
+	if (piped)
+	{
+		hipEvent_t sent = task_event(task, s_in);		/* ev[1]: head is down */
+		REQ_CHECK(hipStreamWaitEvent(task->stream, sent, 0), "wait for the request head");
+		/* the kernel is timed from the moment the main stream gets to it */
+		hipEvent_t begin = task_event(task);			/* ev[2] */
+		(void)begin;
+	}
+	else
+		task_event(task);								/* ev[1] */
 
 	/*
 	 * grid: enough persistent work-groups to fill every CU at the
@@ -181,16 +199,19 @@ gpuscan_launch(strom_task_impl *task, Program *prog, gpuscan_request req)
 				  "launch gpuscan kernel");
 		task->pfm.num_kern_exec++;
 	}
-	task_event(task);									/* ev[2] */
+	hipEvent_t kernel_done = task_event(task);			/* ev[2] (piped: ev[3]) */
+	if (piped)
+		REQ_CHECK(hipStreamWaitEvent(s_out, kernel_done, 0), "wait for the kernel");
 	/* result head first; results[0..nitems) follow once nitems is known */
 	char	   *stage_res = (stage ? stage + STROMALIGN(head_len) : nullptr);
 	REQ_CHECK(hipMemcpyAsync(stage_res ? (void *)stage_res : (void *)kres_host,
 							 d_kgs + res_offset, offsetof(kern_resultbuf, results),
-							 hipMemcpyDeviceToHost, task->stream),
+							 hipMemcpyDeviceToHost, s_out),
 			  "recv kern_resultbuf head");
 	task->pfm.num_dma_recv++;
 	task->pfm.bytes_dma_recv += offsetof(kern_resultbuf, results);
-	task_event(task);									/* ev[3] */
+	task_event(task, s_out);							/* ev[3] (piped: ev[4]) */
+	task->has_ev_prep = piped;		/* tells the completer about the extra event */
 
 	bool	results_on_device = (req.flags & STROM_RESULTS_ON_DEVICE) != 0;
 	task->finish = [kres_host, d_kgs, res_offset, results_on_device, stage_res](strom_task_impl *t)
@@ -203,11 +224,12 @@ gpuscan_launch(strom_task_impl *task, Program *prog, gpuscan_request req)
 			return;
 		size_t	len = sizeof(cl_int) * (size_t)kres_host->nitems;
 		auto	t0 = std::chrono::steady_clock::now();
+		hipStream_t	st = (t->has_ev_prep ? t->dev->copy_out : t->stream);
 		hipError_t rc = hipMemcpyAsync(kres_host->results,
 									   d_kgs + res_offset + offsetof(kern_resultbuf, results),
-									   len, hipMemcpyDeviceToHost, t->stream);
+									   len, hipMemcpyDeviceToHost, st);
 		if (rc == hipSuccess)
-			rc = hipStreamSynchronize(t->stream);
+			rc = hipStreamSynchronize(st);
 		if (rc != hipSuccess)
 			t->errcode = hip_errcode(rc, "recv results[]");
 		t->pfm.num_dma_recv++;

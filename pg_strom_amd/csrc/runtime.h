@@ -78,6 +78,10 @@ struct Device {
 	int					hip_id = 0;
 	hipDeviceProp_t		prop;
 	std::vector<hipStream_t> streams;
+	/* resident-chunk requests: the request head goes down on copy_in and
+	 * the result head comes back on copy_out, so that on streams[0] one
+	 * chunk's kernel follows the previous one's without a DMA in between */
+	hipStream_t			copy_in = nullptr, copy_out = nullptr;
 	std::atomic<unsigned> next_stream{0};
 	BufferPool			pool;
 	PinnedPool			pinned;
@@ -148,7 +152,7 @@ bool		perfmon_enabled();
 strom_task_impl *task_create(Device *dev, strom_done_cb done, void *arg);
 void		task_enqueue(strom_task_impl *task);
 void		task_fail(strom_task_impl *task, int errcode);
-hipEvent_t	task_event(strom_task_impl *task);
+hipEvent_t	task_event(strom_task_impl *task, hipStream_t stream = nullptr);
 int			hip_errcode(hipError_t rc, const char *what);
 /* run 'fn' now if the program is ready, park it if the build is in
  * flight; returns the program state */

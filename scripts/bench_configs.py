@@ -153,7 +153,7 @@ def c4():
         ds.release()
 
 
-def c5():
+def c5(typmod=True):
     rng = np.random.default_rng(0x5eed0005)
     n = N
     rf = rng.choice(np.array([65, 78, 82], dtype=np.int8), n)
@@ -164,15 +164,18 @@ def c5():
             kds.numeric_from_scaled(rng.integers(0, 11, n), 2),
             kds.numeric_from_scaled(rng.integers(0, 9, n), 2),
             kds.Column("date", rng.integers(-2922, -2922 + 2526, n).astype(np.int32))]
-    one_minus_d = "(numeric_sub (const numeric 1) (var 5 numeric))"
-    one_plus_t = "(numeric_add (const numeric 1) (var 6 numeric))"
-    disc_price = "(numeric_mul (var 4 numeric) %s)" % one_minus_d
+    qty, prc, dsc, txx = (("(var 3 numeric 0)", "(var 4 numeric 2)", "(var 5 numeric 2)", "(var 6 numeric 2)")
+                          if typmod else
+                          ("(var 3 numeric)", "(var 4 numeric)", "(var 5 numeric)", "(var 6 numeric)"))
+    one_minus_d = "(numeric_sub (const numeric 1) %s)" % dsc
+    one_plus_t = "(numeric_add (const numeric 1) %s)" % txx
+    disc_price = "(numeric_mul %s %s)" % (prc, one_minus_d)
     spec = ("(gpupreagg (qual (date_le (var 7 date) (const date '1998-09-02')))"
             " (key (var 1 char1)) (key (var 2 char1))"
-            " (psum (var 3 numeric) 0) (psum (var 4 numeric) 2) (psum %s 4) (psum (numeric_mul %s %s) 6)"
-            " (nrows (isnotnull (var 3 numeric))) (nrows (isnotnull (var 4 numeric)))"
-            " (psum (var 5 numeric) 2) (nrows (isnotnull (var 5 numeric))) (nrows))"
-            % (disc_price, disc_price, one_plus_t))
+            " (psum %s 0) (psum %s 2) (psum %s 4) (psum (numeric_mul %s %s) 6)"
+            " (nrows (isnotnull %s)) (nrows (isnotnull %s))"
+            " (psum %s 2) (nrows (isnotnull %s)) (nrows))"
+            % (qty, prc, disc_price, disc_price, one_plus_t, qty, prc, dsc, dsc))
     ds = runtime.DeviceStore.upload(kds.build_kds("column", cols))
     agg = GpuPreAgg(spec).begin([(65, 18), (70, 10)])
     t0 = time.time()
@@ -186,7 +189,8 @@ def c5():
         ts.append(pfm["time_kern_exec_ns"])
         tm.append(pfm["time_kern_proj_ns"])
     pr = agg.fetch()
-    emit("C5 Q1 shape (6 groups, 9 partials)", "gpupreagg_*_column+merge", n, med(ts), 38.0 * n,
+    emit("C5 Q1 shape (6 groups, 9 partials)%s" % (", typmod scales" if typmod else ", scale-less numerics"),
+         "gpupreagg_*_column+merge", n, med(ts), 38.0 * n,
          merge_us=round(med(tm) / 1e3, 1), groups=len(pr.column(0)[0]), table_slots=nslots,
          census_compact_ms=round(t_census * 1e3, 2))
     agg.end()
@@ -197,4 +201,4 @@ if __name__ == "__main__":
     runtime.init()
     which = sys.argv[2].split(",") if len(sys.argv) > 2 else ["c2", "c3", "c4", "c5"]
     for name in which:
-        {"c2": c2, "c3": c3, "c4": c4, "c5": c5}[name]()
+        {"c2": c2, "c3": c3, "c4": c4, "c5": c5, "c5dyn": lambda: c5(False)}[name]()

@@ -114,8 +114,8 @@ def test_fixed_point_numeric_partials_and_wide_sums():
     assert sum(r[1] for r in rows if r[1] is not None) == sum(big)
 
 
-@pytest.mark.parametrize("compact", [False, True])
-def test_tpch_q1_shape(compact):
+@pytest.mark.parametrize("compact,typmod", [(False, False), (True, False), (True, True)])
+def test_tpch_q1_shape(compact, typmod):
     """returnflag, linestatus, sum(qty), sum(price), sum(price*(1-disc)),
     sum(price*(1-disc)*(1+tax)), avg(qty), avg(price), avg(disc), count(*)
     WHERE shipdate <= date '1998-09-02' (SURVEY.md section 8d, C5 columns)"""
@@ -131,15 +131,19 @@ def test_tpch_q1_shape(compact):
     cols = [kds.Column("char1", rf), kds.Column("char1", ls), kds.numeric_column(qty),
             kds.numeric_column(price), kds.numeric_column(disc), kds.numeric_column(tax),
             kds.Column("date", ship)]
-    one_minus_d = "(numeric_sub (const numeric 1) (var 5 numeric))"
-    one_plus_t = "(numeric_add (const numeric 1) (var 6 numeric))"
-    disc_price = "(numeric_mul (var 4 numeric) %s)" % one_minus_d
+    # typmod: the plan passes the columns' numeric(p,s) scale -> fixed-point device code
+    v_qty, v_prc, v_dsc, v_tax = (("(var 3 numeric 0)", "(var 4 numeric 2)", "(var 5 numeric 2)", "(var 6 numeric 2)")
+                                  if typmod else
+                                  ("(var 3 numeric)", "(var 4 numeric)", "(var 5 numeric)", "(var 6 numeric)"))
+    one_minus_d = "(numeric_sub (const numeric 1) %s)" % v_dsc
+    one_plus_t = "(numeric_add (const numeric 1) %s)" % v_tax
+    disc_price = "(numeric_mul %s %s)" % (v_prc, one_minus_d)
     spec = ("(gpupreagg (qual (date_le (var 7 date) (const date '1998-09-02')))"
             " (key (var 1 char1)) (key (var 2 char1))"
-            " (psum (var 3 numeric) 0) (psum (var 4 numeric) 2) (psum %s 4) (psum (numeric_mul %s %s) 6)"
-            " (nrows (isnotnull (var 3 numeric))) (nrows (isnotnull (var 4 numeric)))"
-            " (psum (var 5 numeric) 2) (nrows (isnotnull (var 5 numeric))) (nrows))"
-            % (disc_price, disc_price, one_plus_t))
+            " (psum %s 0) (psum %s 2) (psum %s 4) (psum (numeric_mul %s %s) 6)"
+            " (nrows (isnotnull %s)) (nrows (isnotnull %s))"
+            " (psum %s 2) (nrows (isnotnull %s)) (nrows))"
+            % (v_qty, v_prc, disc_price, disc_price, one_plus_t, v_qty, v_prc, v_dsc, v_dsc))
     half = n // 2
     chunks = [kds.build_kds("column", [kds.Column(c.sqltype, c.values[s], None) for c in cols])
               for s in (slice(0, half), slice(half, n))]
