@@ -325,6 +325,35 @@ strom_task *strom_submit_gpuhashjoin_projection(strom_hashjoin_table *tbl,
 												strom_done_cb done, void *arg,
 												int *p_errcode);
 
+/* ------------------------------------------------------------------ *
+ * chained operators: device-resident row maps
+ *
+ * The reference hands the rows an operator selected to the next one as
+ * pgstrom_bulkslot {pds, nvalids, rindex[]} built on the host from
+ * kern_resultbuf (pg_strom.h:323-329, gpuscan.c:1318-1446).  Here the ids
+ * stay in HBM: strom_rowmap_from_task() waits for a GpuScan submitted with
+ * STROM_RESULTS_ON_DEVICE, turns its results[] into a kern_row_map in place
+ * (one tiny kernel) and takes the buffer over; the *_mapped submit calls
+ * pass it to the next operator on the same resident chunk.  A chunk with
+ * rows to re-check (negative ids) cannot be chained: StromError_CpuReCheck
+ * is returned and the caller takes the host path for that chunk.  The map
+ * must outlive the requests that use it; strom_task_wait() is still due for
+ * the scan task.
+ * ------------------------------------------------------------------ */
+typedef struct strom_rowmap strom_rowmap;
+strom_rowmap *strom_rowmap_from_task(strom_task *gpuscan_task, int *p_errcode);
+uint32_t	strom_rowmap_nvalids(strom_rowmap *map);
+void	   *strom_rowmap_devptr(strom_rowmap *map);
+void		strom_rowmap_release(strom_rowmap *map);
+strom_task *strom_submit_gpuscan_mapped(strom_devprog_key key, kern_gpuscan *kgpuscan,
+										strom_dstore *kds_dev, strom_rowmap *rowmap,
+										uint32_t flags, strom_done_cb done, void *arg, int *p_errcode);
+strom_task *strom_submit_gpuhashjoin_mapped(strom_hashjoin_table *table, kern_hashjoin *khashjoin,
+											strom_dstore *kds_dev, strom_rowmap *rowmap,
+											uint32_t flags, strom_done_cb done, void *arg, int *p_errcode);
+strom_task *strom_submit_gpupreagg_mapped(strom_gpupreagg *sess, strom_dstore *kds_dev, strom_rowmap *rowmap,
+										  strom_done_cb done, void *arg, int *p_errcode);
+
 /* block until the request finished; returns its errcode.  Frees the task. */
 int			strom_task_wait(strom_task *task, strom_perfmon *pfm_out);
 /* device address of the kern_gpuscan / kern_hashjoin image of a task that

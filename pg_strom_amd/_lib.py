@@ -159,6 +159,16 @@ PROTOTYPES = {
     "strom_submit_gpuhashjoin_projection": (c_void_p, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                                        c_void_p, c_void_p, c_void_p, c_uint32,
                                                        c_void_p, c_void_p, ctypes.POINTER(c_int)]),
+    "strom_rowmap_from_task": (c_void_p, [c_void_p, ctypes.POINTER(c_int)]),
+    "strom_rowmap_nvalids": (c_uint32, [c_void_p]),
+    "strom_rowmap_devptr": (c_void_p, [c_void_p]),
+    "strom_rowmap_release": (None, [c_void_p]),
+    "strom_submit_gpuscan_mapped": (c_void_p, [c_uint64, c_void_p, c_void_p, c_void_p, c_uint32,
+                                               c_void_p, c_void_p, ctypes.POINTER(c_int)]),
+    "strom_submit_gpuhashjoin_mapped": (c_void_p, [c_void_p, c_void_p, c_void_p, c_void_p, c_uint32,
+                                                   c_void_p, c_void_p, ctypes.POINTER(c_int)]),
+    "strom_submit_gpupreagg_mapped": (c_void_p, [c_void_p, c_void_p, c_void_p,
+                                                 c_void_p, c_void_p, ctypes.POINTER(c_int)]),
     "strom_task_wait": (c_int, [c_void_p, ctypes.POINTER(strom_perfmon)]),
     "strom_task_devptr": (c_void_p, [c_void_p]),
     "strom_synchronize": (None, []),

@@ -27,24 +27,31 @@ ingest_get_tuple(const kern_data_store *src, cl_uint row)
 
 extern "C" __global__ void
 __launch_bounds__(256)
-ingest_to_column(const kern_data_store *src, kern_data_store *dst,
-				 const cl_int *type_oids, cl_uint *col_has_null)
+ingest_to_column(const kern_data_store *__restrict__ src, kern_data_store *__restrict__ dst,
+				 const cl_int *__restrict__ type_oids, cl_uint *__restrict__ col_has_null)
 {
-	/* per work-group zone maps / NULL flags: global atomics on one address
-	 * serialise (a per-wave atomic pair costs more than the transpose) */
-	__shared__ cl_ulong	s_min[INGEST_MAXCOLS];
-	__shared__ cl_ulong	s_max[INGEST_MAXCOLS];
+	/* per work-group NULL flags (global stores to one address serialise) */
 	__shared__ cl_uint	s_hasnull[INGEST_MAXCOLS];
+	/* column descriptors staged once: read per (row, column) otherwise, each
+	 * a dependent scalar load the compiler may not hoist over the stores */
+	__shared__ kern_colmeta	s_colmeta[INGEST_MAXCOLS];
+	__shared__ cl_uint		s_values_off[INGEST_MAXCOLS];
+	__shared__ cl_uint		s_nulls_off[INGEST_MAXCOLS];
 	cl_uint		nitems = src->nitems;
 	cl_uint		ncols = src->ncols;
-	kern_coldir *coldir = KERN_DATA_STORE_COLDIR(dst);
+	cl_int		format = src->format;
 	cl_uint		lane = threadIdx.x & 63;
 
 	for (cl_uint c = threadIdx.x; c < INGEST_MAXCOLS; c += blockDim.x)
 	{
-		s_min[c] = ~0UL;
-		s_max[c] = 0UL;
 		s_hasnull[c] = 0;
+		if (c < ncols)
+		{
+			const kern_coldir *cd = KERN_DATA_STORE_COLDIR(dst) + c;
+			s_colmeta[c] = src->colmeta[c];
+			s_values_off[c] = cd->values_off;
+			s_nulls_off[c] = cd->nulls_off;
+		}
 	}
 	__syncthreads();
 
@@ -58,7 +65,7 @@ ingest_to_column(const kern_data_store *src, kern_data_store *dst,
 		cl_uint		offset = 0, natts = 0;
 		bool		hasnull = false;
 
-		if (valid && src->format != KDS_FORMAT_TUPSLOT)
+		if (valid && format != KDS_FORMAT_TUPSLOT)
 		{
 			htup = ingest_get_tuple(src, row);
 			if (htup)
@@ -70,12 +77,12 @@ ingest_to_column(const kern_data_store *src, kern_data_store *dst,
 		}
 		for (cl_uint c = 0; c < ncols; c++)
 		{
-			kern_colmeta cm = src->colmeta[c];
+			kern_colmeta cm = s_colmeta[c];
 			const char *addr = NULL;
 
 			if (valid)
 			{
-				if (src->format == KDS_FORMAT_TUPSLOT)
+				if (format == KDS_FORMAT_TUPSLOT)
 				{
 					if (!KERN_DATA_STORE_ISNULL(src, row)[c])
 						addr = (const char *)(KERN_DATA_STORE_VALUES(src, row) + c);
@@ -95,7 +102,7 @@ ingest_to_column(const kern_data_store *src, kern_data_store *dst,
 			cl_long		v = 0;
 			if (addr && cm.attlen > 0 && cm.attlen <= 8)
 			{
-				char *out = (char *)dst + coldir[c].values_off + (size_t)cm.attlen * row;
+				char *out = (char *)dst + s_values_off[c] + (size_t)cm.attlen * row;
 				switch (cm.attlen)
 				{
 					case 1: { cl_char x = *(const cl_char *)addr; *(cl_char *)out = x; v = x; } break;
@@ -107,16 +114,16 @@ ingest_to_column(const kern_data_store *src, kern_data_store *dst,
 			else if (valid && cm.attlen > 0 && cm.attlen <= 8)
 			{
 				/* NULL slot holds zero: reads of it are deterministic */
-				char *out = (char *)dst + coldir[c].values_off + (size_t)cm.attlen * row;
+				char *out = (char *)dst + s_values_off[c] + (size_t)cm.attlen * row;
 				for (int b = 0; b < cm.attlen; b++)
 					out[b] = 0;
 			}
 			/* not-null bitmap: one ballot -> two 32-bit words per wave */
 			strom_lanemask_t nn = __ballot(addr != NULL);
 			strom_lanemask_t vv = __ballot(valid);
-			if (coldir[c].nulls_off != 0 && vv != 0)
+			if (s_nulls_off[c] != 0 && vv != 0)
 			{
-				cl_uint *words = (cl_uint *)((char *)dst + coldir[c].nulls_off);
+				cl_uint *words = (cl_uint *)((char *)dst + s_nulls_off[c]);
 				cl_uint	 w0 = (base + (threadIdx.x & ~63u)) >> 5;
 				if (lane == 0)
 					words[w0] = (cl_uint)nn;
@@ -125,44 +132,6 @@ ingest_to_column(const kern_data_store *src, kern_data_store *dst,
 			}
 			if (nn != vv && lane == 0)
 				s_hasnull[c] = 1;
-			/* zone map: order-preserving u64 image of the value (sign bit
-			 * flipped for integers; the usual IEEE trick for floats, NaN
-			 * left out), unsigned min / max over the wave, one atomic pair */
-			cl_int	oid = (type_oids ? type_oids[c] : 0);
-			if (oid != 0 && oid != STROM_NUMERICOID && cm.attlen > 0 && cm.attlen <= 8)
-			{
-				bool		isflt = (oid == STROM_FLOAT4OID || oid == STROM_FLOAT8OID);
-				bool		ok = (addr != NULL);
-				cl_ulong	key;
-
-				if (isflt)
-				{
-					cl_double d = (cm.attlen == 4 ? (cl_double)__int_as_float((cl_int)v)
-								   : __longlong_as_double((long long)v));
-					cl_ulong bits = (cl_ulong)__double_as_longlong(d);
-					ok = ok && !__builtin_isnan(d);
-					key = (bits & 0x8000000000000000UL) ? ~bits : (bits | 0x8000000000000000UL);
-				}
-				else
-					key = (cl_ulong)v ^ 0x8000000000000000UL;
-				cl_ulong mn = (ok ? key : ~0UL);
-				cl_ulong mx = (ok ? key : 0UL);
-#pragma unroll
-				for (int m = 32; m > 0; m >>= 1)
-				{
-					cl_ulong o1 = ((cl_ulong)(cl_uint)__shfl_xor((cl_int)(mn >> 32), m, 64) << 32) |
-						(cl_uint)__shfl_xor((cl_int)mn, m, 64);
-					cl_ulong o2 = ((cl_ulong)(cl_uint)__shfl_xor((cl_int)(mx >> 32), m, 64) << 32) |
-						(cl_uint)__shfl_xor((cl_int)mx, m, 64);
-					mn = (o1 < mn ? o1 : mn);
-					mx = (o2 > mx ? o2 : mx);
-				}
-				if (lane == 0 && mn <= mx)
-				{
-					atomicMin((unsigned long long *)&s_min[c], (unsigned long long)mn);
-					atomicMax((unsigned long long *)&s_max[c], (unsigned long long)mx);
-				}
-			}
 		}
 	}
 	__syncthreads();
@@ -170,11 +139,93 @@ ingest_to_column(const kern_data_store *src, kern_data_store *dst,
 	{
 		if (s_hasnull[c])
 			col_has_null[c] = 1;
-		if (s_min[c] <= s_max[c])
+	}
+}
+
+/*
+ * zone maps in a pass of their own over the transposed columns (coalesced
+ * 4-12 B/row, mostly still in L2 / Infinity Cache): blockIdx.y = column.  A
+ * thread keeps a running min / max of the order-preserving u64 image of
+ * its rows (sign bit flipped for integers; the usual IEEE trick for floats,
+ * NaN left out); one wave reduction and one atomic pair per work-group at
+ * the end.  Doing this inside the transpose cost a 64-lane reduction per
+ * column and wave.
+ */
+extern "C" __global__ void
+__launch_bounds__(256)
+ingest_minmax(kern_data_store *dst, const cl_int *type_oids)
+{
+	__shared__ cl_ulong	s_min, s_max;
+	kern_coldir *coldir = KERN_DATA_STORE_COLDIR(dst);
+	cl_uint		c = blockIdx.y;
+	cl_uint		nitems = dst->nitems;
+	cl_int		oid = (type_oids ? type_oids[c] : 0);
+	int			attlen = dst->colmeta[c].attlen;
+
+	if (oid == 0 || oid == STROM_NUMERICOID || attlen < 1 || attlen > 8)
+		return;
+	bool		isflt = (oid == STROM_FLOAT4OID || oid == STROM_FLOAT8OID);
+	const char *values = (const char *)dst + coldir[c].values_off;
+	const cl_uint *notnull = (coldir[c].nulls_off != 0
+							  ? (const cl_uint *)((const char *)dst + coldir[c].nulls_off) : NULL);
+	cl_ulong	mn = ~0UL, mx = 0UL;
+
+	if (threadIdx.x == 0)
+	{
+		s_min = ~0UL;
+		s_max = 0UL;
+	}
+	__syncthreads();
+	for (cl_uint row = blockIdx.x * blockDim.x + threadIdx.x;
+		 row < nitems;
+		 row += gridDim.x * blockDim.x)
+	{
+		cl_long		v;
+		switch (attlen)
 		{
-			atomicMin((unsigned long long *)&coldir[c].minval, (unsigned long long)s_min[c]);
-			atomicMax((unsigned long long *)&coldir[c].maxval, (unsigned long long)s_max[c]);
+			case 1: v = ((const cl_char *)values)[row]; break;
+			case 2: v = ((const cl_short *)values)[row]; break;
+			case 4: v = ((const cl_int *)values)[row]; break;
+			default: v = ((const cl_long *)values)[row]; break;
 		}
+		bool		ok = (!notnull || ((notnull[row >> 5] >> (row & 31)) & 1));
+		cl_ulong	key;
+		if (isflt)
+		{
+			cl_double d = (attlen == 4 ? (cl_double)__int_as_float((cl_int)v)
+						   : __longlong_as_double((long long)v));
+			cl_ulong bits = (cl_ulong)__double_as_longlong(d);
+			ok = ok && !__builtin_isnan(d);
+			key = (bits & 0x8000000000000000UL) ? ~bits : (bits | 0x8000000000000000UL);
+		}
+		else
+			key = (cl_ulong)v ^ 0x8000000000000000UL;
+		if (ok)
+		{
+			mn = (key < mn ? key : mn);
+			mx = (key > mx ? key : mx);
+		}
+	}
+#pragma unroll
+	for (int m = 32; m > 0; m >>= 1)
+	{
+		cl_ulong o1 = ((cl_ulong)(cl_uint)__shfl_xor((cl_int)(mn >> 32), m, 64) << 32) |
+			(cl_uint)__shfl_xor((cl_int)mn, m, 64);
+		cl_ulong o2 = ((cl_ulong)(cl_uint)__shfl_xor((cl_int)(mx >> 32), m, 64) << 32) |
+			(cl_uint)__shfl_xor((cl_int)mx, m, 64);
+		mn = (o1 < mn ? o1 : mn);
+		mx = (o2 > mx ? o2 : mx);
+	}
+	if ((threadIdx.x & 63) == 0 && mn <= mx)
+	{
+		atomicMin((unsigned long long *)&s_min, (unsigned long long)mn);
+		atomicMax((unsigned long long *)&s_max, (unsigned long long)mx);
+	}
+	__syncthreads();
+	if (threadIdx.x == 0 && s_min <= s_max)
+	{
+		atomicMin((unsigned long long *)&coldir[c].minval, (unsigned long long)s_min);
+		atomicMax((unsigned long long *)&coldir[c].maxval, (unsigned long long)s_max);
 	}
 }
 

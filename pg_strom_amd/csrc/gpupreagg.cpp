@@ -288,6 +288,7 @@ struct preagg_request {
 	const kern_data_store *kds;
 	strom_dstore	   *kds_dev;
 	const kern_row_map *krowmap;
+	strom_rowmap	   *rowmap_dev;		/* device-resident row map (chained operators) */
 	uint32_t			format;
 	uint32_t			nrows;
 };
@@ -310,7 +311,7 @@ gpupreagg_launch(strom_task_impl *task, preagg_request req)
 	/* chunks fold into one table: keep them in order on one stream */
 	task->stream = dev->streams[0];
 
-	bool	use_column = (req.format == KDS_FORMAT_COLUMN && req.krowmap == nullptr);
+	bool	use_column = (req.format == KDS_FORMAT_COLUMN && req.krowmap == nullptr && req.rowmap_dev == nullptr);
 	bool	use_reg = (use_column && sess->reg_groups != 0);
 	hipFunction_t fn = prog->get_function(dev, use_reg ? (sess->reg_groups == 1 ? "gpupreagg_reg1_column"
 																			  : "gpupreagg_priv_column")
@@ -364,8 +365,8 @@ gpupreagg_launch(strom_task_impl *task, preagg_request req)
 		task->pfm.bytes_dma_send += kds_len;
 		d_kds = p;
 	}
-	const void *d_rowmap = nullptr;
-	if (req.krowmap)
+	const void *d_rowmap = (req.rowmap_dev ? req.rowmap_dev->devptr : nullptr);
+	if (!req.rowmap_dev && req.krowmap)
 	{
 		size_t	len = offsetof(kern_row_map, rindex) + sizeof(cl_int) * (size_t)req.krowmap->nvalids;
 		void   *p = dev->pool.alloc(len);
@@ -543,11 +544,11 @@ strom_gpupreagg_table_layout(strom_gpupreagg *sess, int resno, size_t *p_bits_of
 	return 0;
 }
 
-extern "C" strom_task *
-strom_submit_gpupreagg(strom_gpupreagg *sess,
-					   const kern_data_store *kds, strom_dstore *kds_dev,
-					   const kern_row_map *krowmap,
-					   strom_done_cb done, void *arg, int *p_errcode)
+static strom_task *
+submit_gpupreagg_common(strom_gpupreagg *sess,
+						const kern_data_store *kds, strom_dstore *kds_dev,
+						const kern_row_map *krowmap, strom_rowmap *rowmap_dev,
+						strom_done_cb done, void *arg, int *p_errcode)
 {
 	int		dummy;
 	if (!p_errcode)
@@ -558,7 +559,8 @@ strom_submit_gpupreagg(strom_gpupreagg *sess,
 		*p_errcode = StromError_BadRequestMessage;
 		return nullptr;
 	}
-	if (kds_dev && kds_dev->dindex != sess->dev->dindex)
+	if ((kds_dev && kds_dev->dindex != sess->dev->dindex) ||
+		(rowmap_dev && (!kds_dev || krowmap || rowmap_dev->dindex != kds_dev->dindex)))
 	{
 		*p_errcode = StromError_BadRequestMessage;
 		return nullptr;
@@ -574,17 +576,41 @@ strom_submit_gpupreagg(strom_gpupreagg *sess,
 	req.kds = kds;
 	req.kds_dev = kds_dev;
 	req.krowmap = (krowmap && krowmap->nvalids >= 0) ? krowmap : nullptr;
+	req.rowmap_dev = rowmap_dev;
 	kern_data_store head;
 	if (kds)
 		memcpy(&head, kds, offsetof(kern_data_store, colmeta));
 	else
 		head = kds_dev->head;
 	req.format = head.format;
-	req.nrows = req.krowmap ? (uint32_t)req.krowmap->nvalids : head.nitems;
+	req.nrows = (rowmap_dev ? rowmap_dev->nvalids
+				 : req.krowmap ? (uint32_t)req.krowmap->nvalids : head.nitems);
 	sess->nfolds++;
 	strom_task_impl *task = task_create(sess->dev, done, arg);
 	program_run_or_park(sess->prog, [task, req]() { gpupreagg_launch(task, req); });
 	return task;
+}
+
+extern "C" strom_task *
+strom_submit_gpupreagg(strom_gpupreagg *sess,
+					   const kern_data_store *kds, strom_dstore *kds_dev,
+					   const kern_row_map *krowmap,
+					   strom_done_cb done, void *arg, int *p_errcode)
+{
+	return submit_gpupreagg_common(sess, kds, kds_dev, krowmap, nullptr, done, arg, p_errcode);
+}
+
+extern "C" strom_task *
+strom_submit_gpupreagg_mapped(strom_gpupreagg *sess, strom_dstore *kds_dev, strom_rowmap *rowmap,
+							  strom_done_cb done, void *arg, int *p_errcode)
+{
+	if (!rowmap)
+	{
+		if (p_errcode)
+			*p_errcode = StromError_BadRequestMessage;
+		return nullptr;
+	}
+	return submit_gpupreagg_common(sess, nullptr, kds_dev, nullptr, rowmap, done, arg, p_errcode);
 }
 
 /*

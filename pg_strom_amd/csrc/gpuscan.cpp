@@ -27,6 +27,7 @@ struct gpuscan_request {
 	const kern_data_store *kds;			/* host chunk or NULL */
 	strom_dstore	   *kds_dev;
 	const kern_row_map *krowmap;
+	strom_rowmap	   *rowmap_dev;		/* device-resident row map (chained operators) */
 	uint32_t			flags;
 	uint32_t			nrows;			/* rows the kernel walks */
 	uint32_t			format;
@@ -72,7 +73,7 @@ gpuscan_launch(strom_task_impl *task, Program *prog, gpuscan_request req)
 	else
 		task->stream = dev->streams[1 + dev->next_stream++ % (dev->streams.size() - 1)];
 
-	bool		use_column = (req.format == KDS_FORMAT_COLUMN && req.krowmap == nullptr);
+	bool		use_column = (req.format == KDS_FORMAT_COLUMN && req.krowmap == nullptr && req.rowmap_dev == nullptr);
 	hipFunction_t fn = prog->get_function(dev, use_column ? "gpuscan_qual_column"
 										  : "gpuscan_qual_generic", &errcode);
 	if (!fn)
@@ -135,8 +136,8 @@ gpuscan_launch(strom_task_impl *task, Program *prog, gpuscan_request req)
 		task->pfm.bytes_dma_send += kds_len;
 		d_kds = p;
 	}
-	const void *d_rowmap = nullptr;
-	if (req.krowmap && req.krowmap->nvalids >= 0)
+	const void *d_rowmap = (req.rowmap_dev ? req.rowmap_dev->devptr : nullptr);
+	if (!req.rowmap_dev && req.krowmap && req.krowmap->nvalids >= 0)
 	{
 		size_t	len = offsetof(kern_row_map, rindex) + sizeof(cl_int) * (size_t)req.krowmap->nvalids;
 		void   *p = dev->pool.alloc(len);
@@ -214,12 +215,15 @@ gpuscan_launch(strom_task_impl *task, Program *prog, gpuscan_request req)
 	task->has_ev_prep = piped;		/* tells the completer about the extra event */
 
 	bool	results_on_device = (req.flags & STROM_RESULTS_ON_DEVICE) != 0;
+	task->res_offset = res_offset;
+	task->res_is_scan = true;
 	task->finish = [kres_host, d_kgs, res_offset, results_on_device, stage_res](strom_task_impl *t)
 	{
 		if (stage_res)
 			memcpy(kres_host, stage_res, offsetof(kern_resultbuf, results));
 		if (StromErrorIsSignificant(kres_host->errcode))
 			t->errcode = kres_host->errcode;
+		t->res_nitems = kres_host->nitems;
 		if (results_on_device || kres_host->nitems == 0)
 			return;
 		size_t	len = sizeof(cl_int) * (size_t)kres_host->nitems;
@@ -242,22 +246,24 @@ gpuscan_launch(strom_task_impl *task, Program *prog, gpuscan_request req)
 
 }	/* namespace */
 
-extern "C" strom_task *
-strom_submit_gpuscan(strom_devprog_key key,
-					 kern_gpuscan *kgpuscan,
-					 const kern_data_store *kds,
-					 strom_dstore *kds_dev,
-					 const kern_row_map *krowmap,
-					 uint32_t flags,
-					 strom_done_cb done, void *arg,
-					 int *p_errcode)
+static strom_task *
+submit_gpuscan_common(strom_devprog_key key,
+					  kern_gpuscan *kgpuscan,
+					  const kern_data_store *kds,
+					  strom_dstore *kds_dev,
+					  const kern_row_map *krowmap,
+					  strom_rowmap *rowmap_dev,
+					  uint32_t flags,
+					  strom_done_cb done, void *arg,
+					  int *p_errcode)
 {
 	int		dummy;
 	if (!p_errcode)
 		p_errcode = &dummy;
 	*p_errcode = 0;
 	Program *prog = lookup_program(key);
-	if (!prog || !kgpuscan || (!kds) == (!kds_dev))
+	if (!prog || !kgpuscan || (!kds) == (!kds_dev) ||
+		(rowmap_dev && (!kds_dev || krowmap || rowmap_dev->dindex != kds_dev->dindex)))
 	{
 		*p_errcode = StromError_BadRequestMessage;
 		return nullptr;
@@ -275,6 +281,7 @@ strom_submit_gpuscan(strom_devprog_key key,
 	req.kds = kds;
 	req.kds_dev = kds_dev;
 	req.krowmap = (krowmap && krowmap->nvalids >= 0) ? krowmap : nullptr;
+	req.rowmap_dev = rowmap_dev;
 	req.flags = flags;
 	/*
 	 * the kernel needs nitems / format to size its grid; a resident chunk
@@ -286,7 +293,8 @@ strom_submit_gpuscan(strom_devprog_key key,
 	else
 		head = kds_dev->head;
 	req.format = head.format;
-	req.nrows = req.krowmap ? (uint32_t)req.krowmap->nvalids : head.nitems;
+	req.nrows = (rowmap_dev ? rowmap_dev->nvalids
+				 : req.krowmap ? (uint32_t)req.krowmap->nvalids : head.nitems);
 	kern_resultbuf *kres = KERN_GPUSCAN_RESULTBUF(kgpuscan);
 	if (kres->nrels != 1 || kres->nrooms < req.nrows)
 	{
@@ -300,4 +308,147 @@ strom_submit_gpuscan(strom_devprog_key key,
 	strom_task_impl *task = task_create(dev, done, arg);
 	program_run_or_park(prog, [task, prog, req]() { gpuscan_launch(task, prog, req); });
 	return task;
+}
+
+extern "C" strom_task *
+strom_submit_gpuscan(strom_devprog_key key,
+					 kern_gpuscan *kgpuscan,
+					 const kern_data_store *kds,
+					 strom_dstore *kds_dev,
+					 const kern_row_map *krowmap,
+					 uint32_t flags,
+					 strom_done_cb done, void *arg,
+					 int *p_errcode)
+{
+	return submit_gpuscan_common(key, kgpuscan, kds, kds_dev, krowmap, nullptr, flags, done, arg, p_errcode);
+}
+
+extern "C" strom_task *
+strom_submit_gpuscan_mapped(strom_devprog_key key,
+							kern_gpuscan *kgpuscan,
+							strom_dstore *kds_dev,
+							strom_rowmap *rowmap,
+							uint32_t flags,
+							strom_done_cb done, void *arg,
+							int *p_errcode)
+{
+	if (!rowmap)
+	{
+		if (p_errcode)
+			*p_errcode = StromError_BadRequestMessage;
+		return nullptr;
+	}
+	return submit_gpuscan_common(key, kgpuscan, nullptr, kds_dev, nullptr, rowmap, flags, done, arg, p_errcode);
+}
+
+/* ------------------------------------------------------------------ *
+ * device-resident row maps: the hand-over between chained operators
+ * ------------------------------------------------------------------ */
+namespace {
+const char *rowmap_source =
+	"#include \"strom_kds.h\"\n"
+	"#include \"strom_common.h\"\n"
+	"#include \"strom_rowmap.h\"\n";
+}
+
+extern "C" strom_rowmap *
+strom_rowmap_from_task(strom_task *handle, int *p_errcode)
+{
+	int		dummy;
+	if (!p_errcode)
+		p_errcode = &dummy;
+	*p_errcode = 0;
+	strom_task_impl *task = static_cast<strom_task_impl *>(handle);
+	if (!task)
+	{
+		*p_errcode = StromError_BadRequestMessage;
+		return nullptr;
+	}
+	{
+		/* the request may still be parked behind its program build */
+		std::unique_lock<std::mutex> g(task->lock);
+		task->cond.wait(g, [&]{ return task->completed; });
+	}
+	if (!task->res_is_scan || !task->keep_main)
+	{
+		*p_errcode = (task->errcode ? task->errcode
+					  : StromError_BadRequestMessage);	/* not a GpuScan with STROM_RESULTS_ON_DEVICE */
+		return nullptr;
+	}
+	if (task->errcode != 0 || !task->main_devptr)
+	{
+		*p_errcode = (task->errcode ? task->errcode : StromError_BadRequestMessage);
+		return nullptr;
+	}
+	Device *dev = task->dev;
+	static strom_devprog_key key = strom_get_devprog_key(rowmap_source, 0);
+	if (strom_lookup_device_program(key, 1) != STROM_DEVPROG_READY)
+	{
+		*p_errcode = StromError_ProgramBuildFailure;
+		return nullptr;
+	}
+	int		errcode = 0;
+	(void)hipSetDevice(dev->hip_id);
+	hipFunction_t fn = lookup_program(key)->get_function(dev, "rowmap_from_results", &errcode);
+	if (!fn)
+	{
+		*p_errcode = errcode;
+		return nullptr;
+	}
+	hipStream_t stream = dev->streams[0];
+	cl_int	   *d_status = (cl_int *)dev->pool.alloc(sizeof(cl_int));
+	cl_int		h_status = 0;
+	if (!d_status)
+	{
+		*p_errcode = StromError_OutOfMemory;
+		return nullptr;
+	}
+	void	   *a_kres = (char *)task->main_devptr + task->res_offset;
+	cl_uint		a_nitems = task->res_nitems;
+	void	   *a_status = d_status;
+	void	   *args[] = { &a_kres, &a_nitems, &a_status };
+	unsigned	grid = (unsigned)std::max<size_t>(1, std::min<size_t>(((size_t)a_nitems + 255) / 256,
+																	  (size_t)dev->prop.multiProcessorCount * 8));
+	bool		ok = (hipMemsetAsync(d_status, 0, sizeof(cl_int), stream) == hipSuccess &&
+					  hipModuleLaunchKernel(fn, grid, 1, 1, 256, 1, 1, 0, stream, args, nullptr) == hipSuccess &&
+					  hipMemcpyAsync(&h_status, d_status, sizeof(cl_int), hipMemcpyDeviceToHost, stream) == hipSuccess &&
+					  hipStreamSynchronize(stream) == hipSuccess);
+	dev->pool.release(d_status);
+	if (!ok)
+	{
+		*p_errcode = StromError_HipInternal;
+		return nullptr;
+	}
+	if (h_status != 0)
+	{
+		/* rows to re-check on the CPU: the ids were partly rewritten, the
+		 * buffer is of no further use -- the caller redoes this chunk on the
+		 * host path */
+		*p_errcode = h_status;
+		return nullptr;
+	}
+	strom_rowmap *map = new strom_rowmap();
+	map->buffer = task->main_devptr;
+	map->devptr = (char *)a_kres + offsetof(kern_resultbuf, results) - sizeof(cl_int);
+	map->nvalids = a_nitems;
+	map->dindex = dev->dindex;
+	task->main_devptr = nullptr;		/* ownership moved; strom_task_wait still frees the task */
+	return map;
+}
+
+extern "C" uint32_t
+strom_rowmap_nvalids(strom_rowmap *map) { return map ? map->nvalids : 0; }
+
+extern "C" void *
+strom_rowmap_devptr(strom_rowmap *map) { return map ? map->devptr : nullptr; }
+
+extern "C" void
+strom_rowmap_release(strom_rowmap *map)
+{
+	if (!map)
+		return;
+	Device *dev = get_device(map->dindex);
+	if (dev && map->buffer)
+		dev->pool.release(map->buffer);
+	delete map;
 }

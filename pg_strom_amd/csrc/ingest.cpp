@@ -67,7 +67,8 @@ strom_dstore_to_column(strom_dstore *src, const int32_t *type_oids, int ntypes,
 	(void)hipSetDevice(dev->hip_id);
 	hipFunction_t fn_main = prog->get_function(dev, "ingest_to_column", &errcode);
 	hipFunction_t fn_fin = fn_main ? prog->get_function(dev, "ingest_finish", &errcode) : nullptr;
-	if (!fn_main || !fn_fin)
+	hipFunction_t fn_mm = fn_fin ? prog->get_function(dev, "ingest_minmax", &errcode) : nullptr;
+	if (!fn_main || !fn_fin || !fn_mm)
 	{
 		*p_errcode = errcode;
 		return nullptr;
@@ -147,6 +148,17 @@ strom_dstore_to_column(strom_dstore *src, const int32_t *type_oids, int ntypes,
 		(void)hipEventRecord(ev0, stream);
 		if (nwg > 0 &&
 			hipModuleLaunchKernel(fn_main, nwg, 1, 1, 256, 1, 1, 0, stream, args_main, nullptr) != hipSuccess)
+		{
+			*p_errcode = StromError_HipInternal;
+			break;
+		}
+		/* zone maps from the transposed columns, one grid row per column */
+		void	   *args_mm[] = { &a_dst, &a_oids };
+		unsigned	mmgrid = (unsigned)std::min<size_t>(((size_t)nitems + 255) / 256,
+														(size_t)dev->prop.multiProcessorCount * 4);
+		if (type_oids && mmgrid > 0 &&
+			hipModuleLaunchKernel(fn_mm, mmgrid, (unsigned)ncols, 1, 256, 1, 1, 0, stream,
+								  args_mm, nullptr) != hipSuccess)
 		{
 			*p_errcode = StromError_HipInternal;
 			break;

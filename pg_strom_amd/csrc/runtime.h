@@ -109,6 +109,14 @@ struct strom_dstore {
 	kern_data_store head;		/* host snapshot of the fixed head (no colmeta) */
 };
 
+/* device-resident kern_row_map (a finished GpuScan's results, in place) */
+struct strom_rowmap {
+	void	   *buffer;			/* pool allocation that holds the map */
+	void	   *devptr;			/* the kern_row_map inside it */
+	uint32_t	nvalids;
+	int			dindex;
+};
+
 struct strom_task {
 	/* the public handle is the impl itself */
 };
@@ -132,6 +140,11 @@ struct strom_task_impl : public strom_task {
 	std::vector<char *> pinned_blocks;
 	void	   *main_devptr = nullptr;	/* kern_gpuscan / kern_hashjoin image */
 	bool		keep_main = false;		/* released by strom_task_wait */
+	/* GpuScan with STROM_RESULTS_ON_DEVICE: where the kern_resultbuf sits in
+	 * main_devptr and how many rows it holds (strom_rowmap_from_task) */
+	size_t		res_offset = 0;
+	uint32_t	res_nitems = 0;
+	bool		res_is_scan = false;
 	/* operator-specific second half, runs on the completer thread after the
 	 * first event fired; may issue further copies on 'stream' and must
 	 * leave the stream idle when it returns */

@@ -128,6 +128,18 @@ class GpuHashJoin(object):
             nrows = KdsHead(chunk).nitems
             kds_host, kds_dev = chunk.ctypes.data, None
         rm = None
+        if isinstance(row_map, runtime.DeviceRowMap):
+            nrows = row_map.nvalids
+            if nrooms is None:
+                nrooms = int(nrows * self.ratio * 1.1) + 1
+            khj, res_off = self._make_khj(nrooms, not (flags & STROM_RESULTS_ON_DEVICE))
+            err = ctypes.c_int(0)
+            task = lib.strom_submit_gpuhashjoin_mapped(self.table, khj.ctypes.data, kds_dev,
+                                                       row_map.handle, flags, None, None,
+                                                       ctypes.byref(err))
+            if not task:
+                raise runtime.StromError(err.value, "strom_submit_gpuhashjoin_mapped")
+            return (task, khj, res_off, chunk, row_map, flags)
         if row_map is not None:
             r = np.ascontiguousarray(row_map, dtype=np.int32)
             rm = np.concatenate([np.array([len(r)], dtype=np.int32), r])

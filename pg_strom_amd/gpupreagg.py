@@ -161,6 +161,13 @@ class GpuPreAgg(object):
         else:
             kds_host, kds_dev = chunk.ctypes.data, None
         rm = None
+        if isinstance(row_map, runtime.DeviceRowMap):
+            err = ctypes.c_int(0)
+            task = lib.strom_submit_gpupreagg_mapped(self.session, kds_dev, row_map.handle,
+                                                     None, None, ctypes.byref(err))
+            if not task:
+                raise runtime.StromError(err.value, "strom_submit_gpupreagg_mapped")
+            return (task, chunk, row_map)
         if row_map is not None:
             r = np.ascontiguousarray(row_map, dtype=np.int32)
             rm = np.concatenate([np.array([len(r)], dtype=np.int32), r])

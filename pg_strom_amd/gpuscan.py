@@ -74,6 +74,16 @@ class GpuScan(object):
             kds_host, kds_dev = chunk.ctypes.data, None
         rowmap_buf = None
         nrooms = nrows
+        if isinstance(row_map, runtime.DeviceRowMap):
+            nrooms = row_map.nvalids
+            kgs, res_off = make_kern_gpuscan(self.parambuf, max(nrooms, 1),
+                                             host_results=not (flags & STROM_RESULTS_ON_DEVICE))
+            err = ctypes.c_int(0)
+            task = lib.strom_submit_gpuscan_mapped(self.program.key, kgs.ctypes.data, kds_dev,
+                                                   row_map.handle, flags, None, None, ctypes.byref(err))
+            if not task:
+                raise runtime.StromError(err.value, "strom_submit_gpuscan_mapped")
+            return (task, kgs, res_off, chunk, row_map, bool(flags & STROM_RESULTS_ON_DEVICE))
         if row_map is not None:
             rm = np.ascontiguousarray(row_map, dtype=np.int32)
             rowmap_buf = np.concatenate([np.array([len(rm)], dtype=np.int32), rm])
@@ -105,6 +115,19 @@ class GpuScan(object):
 
     def scan_chunk(self, chunk, **kw):
         return self.collect(self.submit(chunk, **kw))
+
+    def scan_to_rowmap(self, chunk, row_map=None):
+        """scan a resident chunk and keep the selected row ids in HBM as a
+        kern_row_map for the next operator (strom_rowmap_from_task).
+        Returns (DeviceRowMap, GpuScanResult); raises StromError(2) when the
+        chunk has rows to re-check -- the caller then takes the host path."""
+        pending = self.submit(chunk, row_map=row_map, flags=STROM_RESULTS_ON_DEVICE)
+        err = ctypes.c_int(0)
+        handle = lib.strom_rowmap_from_task(pending[0], ctypes.byref(err))
+        res = self.collect(pending)              # the scan task is still waited for
+        if not handle:
+            raise runtime.StromError(err.value, "strom_rowmap_from_task")
+        return runtime.DeviceRowMap(handle), res
 
     def scan_chunks(self, chunks, **kw):
         """keeps up to max_async_chunks requests in flight, yields in order"""

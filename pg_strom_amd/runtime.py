@@ -193,5 +193,24 @@ class DeviceStore(object):
             self.handle = None
 
 
+class DeviceRowMap(object):
+    """row ids selected by a GpuScan, left in HBM as a kern_row_map
+    (strom_rowmap): the hand-over between chained operators"""
+
+    def __init__(self, handle):
+        if not handle:
+            raise StromError(106, "strom_rowmap")
+        self.handle = handle
+
+    @property
+    def nvalids(self):
+        return lib.strom_rowmap_nvalids(self.handle)
+
+    def release(self):
+        if self.handle:
+            lib.strom_rowmap_release(self.handle)
+            self.handle = None
+
+
 def perfmon_dict(pfm):
     return {name: getattr(pfm, name) for name, _ in strom_perfmon._fields_}

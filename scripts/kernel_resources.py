@@ -10,6 +10,15 @@ import sys
 sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 import os  # noqa: E402
 
+import importlib.util  # noqa: E402
+
+_spec = importlib.util.spec_from_file_location(
+    "_strom_build", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                                 "pg_strom_amd", "build.py"))
+_build = importlib.util.module_from_spec(_spec)
+_spec.loader.exec_module(_build)
+_build.build_library(verbose=False)          # the device library is embedded in the .so
+
 from pg_strom_amd import gpuhashjoin, gpupreagg, runtime  # noqa: E402
 
 

@@ -1,0 +1,126 @@
+"""
+Chained operators over a device-resident row map (SURVEY.md section 8 f2;
+needs an MI355X: -m gpu).  GpuScan leaves the ids of the rows it selected in
+HBM (strom_rowmap_from_task), GpuPreAgg / GpuHashJoin / a second GpuScan then
+run over exactly those rows of the same resident chunk.  The bar: identical
+to feeding the oracle the same row ids through a host kern_row_map, and to
+the single operator with the scan's qual pulled in.
+"""
+import numpy as np
+import pytest
+
+import oracle_binding as oracle
+from pg_strom_amd import kds, runtime
+from pg_strom_amd.gpuhashjoin import GpuHashJoin, build_multihash
+from pg_strom_amd.gpupreagg import GpuPreAgg
+from pg_strom_amd.gpuscan import GpuScan
+
+pytestmark = pytest.mark.gpu
+
+QUAL = "(and (int4lt (var 2 int4) (param 0 int4)) (float8gt (var 3 float8) (param 1 float8)))"
+
+
+def table(n, seed):
+    rng = np.random.default_rng(seed)
+    g = rng.integers(0, 40, n).astype(np.int32)
+    a = rng.integers(0, 2**31, n, dtype=np.int64).astype(np.int32)
+    b = rng.random(n)
+    return [kds.Column("int4", g, rng.random(n) < 0.01), kds.Column("int4", a), kds.Column("float8", b)]
+
+
+def test_scan_then_preagg_over_the_device_row_map():
+    runtime.init()
+    cols = table(300007, 21)
+    buf = kds.build_kds("column", cols)
+    ext = [np.int32(2**30), 0.5]
+    ds = runtime.DeviceStore.upload(buf)
+    scan = GpuScan(QUAL).begin(ext_params=ext)
+    spec = "(gpupreagg (key (var 1 int4)) (nrows) (psum (int8 (var 2 int4))) (psum (var 3 float8)) (pmax (var 2 int4)))"
+    agg = GpuPreAgg(spec).begin([(0, 40)])
+    try:
+        rowmap, res = scan.scan_to_rowmap(ds)
+        assert rowmap.nvalids == res.nitems
+        st, _ = agg.fold(ds, row_map=rowmap)
+        assert st == 0
+        pr = agg.fetch()
+        rowmap.release()
+    finally:
+        agg.end()
+        scan.end()
+        ds.release()
+    # oracle: the scan's rows as a host row map into the oracle's preagg
+    rc, ids = oracle.gpuscan(QUAL, buf, ext)
+    assert rc == 0 and len(ids) == res.nitems
+    rows = np.sort(np.asarray(ids, dtype=np.int64) - 1).astype(np.int32)
+    rc, v, isn = oracle.gpupreagg(spec, buf, 5, row_map=rows)
+    assert rc == 0
+    want = {(None if isn[i, 0] else int(v[i, 0].view(np.int64))): v[i] for i in range(len(v))}
+    keys, knull = pr.column(0)
+    assert len(keys) == len(want)
+    for i in range(len(keys)):
+        k = None if knull[i] else int(keys[i])
+        w = want[k]
+        assert int(pr.column(1)[0][i]) == int(w[1].view(np.int64))
+        assert int(pr.column(2)[0][i]) == int(w[2].view(np.int64))
+        assert abs(float(pr.column(3)[0][i]) - float(w[3].view(np.float64))) <= 1e-12 * abs(float(w[3].view(np.float64)))
+        assert int(pr.column(4)[0][i]) == int(w[4].view(np.int64))
+
+
+def test_scan_then_join_over_the_device_row_map():
+    runtime.init()
+    n, nd = 200003, 5000
+    rng = np.random.default_rng(22)
+    fk = rng.integers(0, int(nd * 1.3), n).astype(np.int32)
+    a = rng.integers(0, 2**31, n, dtype=np.int64).astype(np.int32)
+    b = rng.random(n)
+    buf = kds.build_kds("column", [kds.Column("int4", fk), kds.Column("int4", a), kds.Column("float8", b)])
+    inner = kds.build_kds("row_flat", [kds.Column("int4", rng.permutation(nd).astype(np.int32)),
+                                       kds.Column("int4", np.arange(nd, dtype=np.int32))])
+    km = build_multihash([(inner, [1])])
+    ext = [np.int32(2**30), 0.25]
+    ds = runtime.DeviceStore.upload(buf)
+    scan = GpuScan(QUAL).begin(ext_params=ext)
+    join = GpuHashJoin("(gpuhashjoin (rel (hashkey (var 1 int4) 1 int4)))").begin(km)
+    try:
+        rowmap, res = scan.scan_to_rowmap(ds)
+        out = join.join_chunk(ds, row_map=rowmap)
+        rowmap.release()
+    finally:
+        join.end()
+        scan.end()
+        ds.release()
+    sel = (a < ext[0]) & (b > ext[1])
+    assert res.nitems == int(sel.sum())
+    want_outer = np.sort(np.flatnonzero(sel & (fk < nd)))
+    assert out.errcode == 0 and out.nitems == len(want_outer)
+    assert np.array_equal(np.sort(out.records[:, 0].astype(np.int64) - 1), want_outer)
+
+
+def test_scan_over_a_device_row_map_and_recheck_fallback():
+    runtime.init()
+    cols = table(100003, 23)
+    buf = kds.build_kds("column", cols)
+    ds = runtime.DeviceStore.upload(buf)
+    first = GpuScan("(int4lt (var 2 int4) (param 0 int4))").begin(ext_params=[np.int32(2**30)])
+    second = GpuScan("(float8gt (var 3 float8) (param 0 float8))").begin(ext_params=[0.5])
+    try:
+        rowmap, r1 = first.scan_to_rowmap(ds)
+        r2 = second.scan_chunk(ds, row_map=rowmap)
+        rowmap.release()
+    finally:
+        first.end()
+        second.end()
+    a, b = cols[1].values, cols[2].values
+    first_rows = np.flatnonzero(a < 2**30)
+    assert r1.nitems == len(first_rows)
+    # with a row map the reported id is the position in the map (+1): count is what can be compared
+    assert r2.nitems == int(np.count_nonzero(b[first_rows] > 0.5))
+    # a chunk with rows to re-check cannot be chained
+    over = GpuScan("(int4gt (int4pl (var 2 int4) (const int4 2147483000)) (const int4 0))").begin()
+    try:
+        with pytest.raises(runtime.StromError) as ei:
+            over.scan_to_rowmap(ds)
+        assert ei.value.errcode == 2            # StromError_CpuReCheck
+    finally:
+        over.end()
+        ds.release()
