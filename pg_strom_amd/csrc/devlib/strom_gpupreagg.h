@@ -345,6 +345,13 @@ gpupreagg_dense_row(char *lds, const gpupreagg_dense_ctl *ctl, const gpupreagg_l
 #undef X
 	if (!out_of_domain && !gpupreagg_remap_gid(ctl, gid))
 		out_of_domain = true;
+	/*
+	 * a row of another role's slice of the slot range: that role evaluates
+	 * (and error-checks) its partial inputs -- leaving here halves the
+	 * per-row work of a split table, which is bound by instruction issue
+	 */
+	if (errcode == StromError_Success && !out_of_domain && gid - gid_lo >= G)
+		return;
 	/* partial inputs (evaluated for every surviving row so that arithmetic
 	 * errors are seen before anything is folded) */
 #define X(aidx,resno,OP,NAME)														\
