@@ -37,8 +37,20 @@ STROM_SET_ERROR(cl_int *p_error, cl_int errcode)
 		if (!StromErrorIsSignificant(oldcode))
 			*p_error = errcode;
 	}
-	else if (errcode > oldcode)
+	else if (!StromErrorIsSignificant(oldcode) && errcode > oldcode)
 		*p_error = errcode;
+}
+
+/* the common case in arithmetic, without a branch: raise CpuReCheck when
+ * 'cond' holds (a select; per-row "if"s cost a taken skip-branch each in
+ * the usual no-error case) */
+STROM_DEVICE void
+STROM_SET_RECHECK_IF(cl_int *p_error, bool cond)
+{
+	cl_int	oldcode = *p_error;
+
+	*p_error = ((cond & (oldcode >= 0) & (oldcode < StromError_CpuReCheck))
+				? StromError_CpuReCheck : oldcode);
 }
 
 /* ---------------------------------------------------------------- *

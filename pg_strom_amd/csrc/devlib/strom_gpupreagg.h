@@ -215,49 +215,57 @@ gpupreagg_table_offset(int sec, cl_uint N)
 	return off + vals * (size_t)(sec - 1);
 }
 
-/* fold one row's partial value into the LDS accumulator at 'slot';
- * returns the flag bit to raise (0 when the input was NULL) */
+/*
+ * fold one row's partial value into the LDS accumulator at 'slot'; returns
+ * the flag bit to raise (0 when the input was NULL).  No branch: a NULL input
+ * folds the operation's identity (0, -0.0 which leaves even the sign of a
+ * zero sum alone, the min/max sentinels), so the atomic is issued for every
+ * row that reaches this point -- a per-row "if" costs an exec-mask save and a
+ * taken skip-branch in the common case, the extra lanes of an atomic nothing.
+ */
 template <int OP, int AIDX, typename PGT>
 STROM_DEVICE cl_uint
 gpupreagg_lds_accum(char *lds, cl_uint vals_off, cl_uint slot, PGT v)
 {
+	typedef decltype(v.value) base_t;
+	bool	has = !v.isnull;
+
 	if (OP == GPUPREAGG_OP_NROWS)
 	{
-		if (!v.isnull && v.value != 0)
-			__hip_atomic_fetch_add((cl_uint *)(lds + vals_off) + slot, (cl_uint)v.value,
-								   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+		__hip_atomic_fetch_add((cl_uint *)(lds + vals_off) + slot, has ? (cl_uint)v.value : 0u,
+							   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 		return 0;
 	}
-	if (v.isnull)
-		return 0;
-	typedef decltype(v.value) base_t;
 	if (gpupreagg_is_float<base_t>::value)
 	{
 		if (OP == GPUPREAGG_OP_PSUM)
-			__hip_atomic_fetch_add((cl_double *)(lds + vals_off) + slot, (cl_double)v.value,
+			__hip_atomic_fetch_add((cl_double *)(lds + vals_off) + slot,
+								   has ? (cl_double)v.value : -0.0,
 								   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 		else if (OP == GPUPREAGG_OP_PMIN)
 			__hip_atomic_fetch_min((cl_ulong *)(lds + vals_off) + slot,
-								   gpupreagg_f64_ordered((cl_double)v.value),
+								   has ? gpupreagg_f64_ordered((cl_double)v.value) : 0xffffffffffffffffUL,
 								   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 		else
 			__hip_atomic_fetch_max((cl_ulong *)(lds + vals_off) + slot,
-								   gpupreagg_f64_ordered((cl_double)v.value),
+								   has ? gpupreagg_f64_ordered((cl_double)v.value) : 0UL,
 								   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 	}
 	else
 	{
 		if (OP == GPUPREAGG_OP_PSUM)
-			__hip_atomic_fetch_add((cl_long *)(lds + vals_off) + slot, (cl_long)v.value,
+			__hip_atomic_fetch_add((cl_long *)(lds + vals_off) + slot, has ? (cl_long)v.value : 0L,
 								   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 		else if (OP == GPUPREAGG_OP_PMIN)
-			__hip_atomic_fetch_min((cl_long *)(lds + vals_off) + slot, (cl_long)v.value,
+			__hip_atomic_fetch_min((cl_long *)(lds + vals_off) + slot,
+								   has ? (cl_long)v.value : 0x7fffffffffffffffL,
 								   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 		else
-			__hip_atomic_fetch_max((cl_long *)(lds + vals_off) + slot, (cl_long)v.value,
+			__hip_atomic_fetch_max((cl_long *)(lds + vals_off) + slot,
+								   has ? (cl_long)v.value : (-0x7fffffffffffffffL - 1),
 								   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 	}
-	return 2u << AIDX;
+	return has ? (2u << AIDX) : 0u;
 }
 
 /* identity element of an 8-byte accumulator */
@@ -296,7 +304,7 @@ gpupreagg_merge8(cl_ulong a, cl_ulong b)
 STROM_DEVICE bool
 gpupreagg_int8_near_overflow(cl_long v)
 {
-	return v >= (1L << 62) || v <= -(1L << 62);
+	return (v >= (1L << 62)) | (v <= -(1L << 62));
 }
 
 /* LDS section offsets, computed once per kernel */
@@ -377,9 +385,9 @@ gpupreagg_dense_row(char *lds, const gpupreagg_dense_ctl *ctl, const gpupreagg_l
 
 #define X(aidx,resno,OP,NAME)														\
 	if (GPUPREAGG_OP_##OP == GPUPREAGG_OP_PSUM &&									\
-		!gpupreagg_is_float<pg_##NAME##_base_t>::value &&							\
-		!av_##aidx.isnull && gpupreagg_int8_near_overflow((cl_long)av_##aidx.value))	\
-		STROM_SET_ERROR(chunk_status, StromError_CpuReCheck);						\
+		!gpupreagg_is_float<pg_##NAME##_base_t>::value)								\
+		STROM_SET_RECHECK_IF(chunk_status, !av_##aidx.isnull &						\
+							 gpupreagg_int8_near_overflow((cl_long)av_##aidx.value));	\
 	need |= gpupreagg_lds_accum<GPUPREAGG_OP_##OP, aidx>(lds, L.vals_off[aidx], slot, av_##aidx);
 	GPUPREAGG_AGG_LIST(X)
 #undef X

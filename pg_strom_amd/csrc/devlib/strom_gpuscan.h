@@ -114,8 +114,13 @@ gpuscan_stage_flush(gpuscan_stage &stage, kern_resultbuf *kresults, cl_uint fill
 	cl_uint		base = stage.flush_base;
 	cl_int	   *dest = kresults->results + base;
 #if !defined(GPUSCAN_ABLATE) || GPUSCAN_ABLATE != 1
+#if defined(GPUSCAN_STORE_NT) && GPUSCAN_STORE_NT
+	for (cl_uint i = threadIdx.x; i < fill; i += GPUSCAN_BLOCK)
+		__builtin_nontemporal_store(stage.entries[i], &dest[i]);
+#else
 	for (cl_uint i = threadIdx.x; i < fill; i += GPUSCAN_BLOCK)
 		dest[i] = stage.entries[i];
+#endif
 #else
 	/* diagnostic build (wrong results): no result stores */
 	if (fill == 0xffffffffu)

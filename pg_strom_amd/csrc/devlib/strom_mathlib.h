@@ -39,14 +39,12 @@
 	pgfn_##name(cl_int *errcode, pg_##x_type##_t arg1, pg_##y_type##_t arg2)	\
 	{																		\
 		STROM_STRICT2(pg_##r_type##_t)										\
-		if (!result.isnull)													\
-		{																	\
-			pg_##r_type##_base_t a = arg1.value, b = arg2.value, c;			\
-			if (__builtin_add_overflow(a, b, &c))							\
-				STROM_RECHECK();											\
-			else															\
-				result.value = c;											\
-		}																	\
+		/* branch-free: overflow and NULL-ness are selects */				\
+		pg_##r_type##_base_t a = arg1.value, b = arg2.value, c;				\
+		bool	ovf = __builtin_add_overflow(a, b, &c) & !result.isnull;		\
+		STROM_SET_RECHECK_IF(errcode, ovf);									\
+		result.value = ((result.isnull | ovf) ? (pg_##r_type##_base_t)0 : c);	\
+		result.isnull |= ovf;												\
 		return result;														\
 	}
 #define STROM_INT_SUBFUNC(name,r_type,x_type,y_type)						\
@@ -54,14 +52,12 @@
 	pgfn_##name(cl_int *errcode, pg_##x_type##_t arg1, pg_##y_type##_t arg2)	\
 	{																		\
 		STROM_STRICT2(pg_##r_type##_t)										\
-		if (!result.isnull)													\
-		{																	\
-			pg_##r_type##_base_t a = arg1.value, b = arg2.value, c;			\
-			if (__builtin_sub_overflow(a, b, &c))							\
-				STROM_RECHECK();											\
-			else															\
-				result.value = c;											\
-		}																	\
+		/* branch-free: overflow and NULL-ness are selects */				\
+		pg_##r_type##_base_t a = arg1.value, b = arg2.value, c;				\
+		bool	ovf = __builtin_sub_overflow(a, b, &c) & !result.isnull;		\
+		STROM_SET_RECHECK_IF(errcode, ovf);									\
+		result.value = ((result.isnull | ovf) ? (pg_##r_type##_base_t)0 : c);	\
+		result.isnull |= ovf;												\
 		return result;														\
 	}
 #define STROM_INT_MULFUNC(name,r_type,x_type,y_type)						\
@@ -69,14 +65,12 @@
 	pgfn_##name(cl_int *errcode, pg_##x_type##_t arg1, pg_##y_type##_t arg2)	\
 	{																		\
 		STROM_STRICT2(pg_##r_type##_t)										\
-		if (!result.isnull)													\
-		{																	\
-			pg_##r_type##_base_t a = arg1.value, b = arg2.value, c;			\
-			if (__builtin_mul_overflow(a, b, &c))							\
-				STROM_RECHECK();											\
-			else															\
-				result.value = c;											\
-		}																	\
+		/* branch-free: overflow and NULL-ness are selects */				\
+		pg_##r_type##_base_t a = arg1.value, b = arg2.value, c;				\
+		bool	ovf = __builtin_mul_overflow(a, b, &c) & !result.isnull;		\
+		STROM_SET_RECHECK_IF(errcode, ovf);									\
+		result.value = ((result.isnull | ovf) ? (pg_##r_type##_base_t)0 : c);	\
+		result.isnull |= ovf;												\
 		return result;														\
 	}
 /* x / 0 and MIN / -1 both go back to the CPU */

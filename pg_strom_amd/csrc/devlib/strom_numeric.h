@@ -529,8 +529,27 @@ pg_fixed_recheck(cl_int *errcode)
 STROM_DEVICE pg_fixed_t
 pgfn_numeric_as_fixed(cl_int *errcode, pg_numeric_t arg, int scale)
 {
-	pg_int8_t v = strom_numeric_to_fixed(errcode, arg, scale);
-	return pg_fixed_make(v.value, v.isnull);
+	/*
+	 * column datum -> int64 at 10^-scale.  The usual datum (mantissa below
+	 * 2^32, 0 <= exponent + scale <= 9) takes straight-line code: 10^shift
+	 * from three selects and two 32-bit multiplies, one 32x32->64 multiply.
+	 * Everything else goes through the general conversion.
+	 */
+	int			expo = PG_NUMERIC_EXPONENT(arg.value);
+	cl_ulong	mant = PG_NUMERIC_MANTISSA(arg.value);
+	cl_uint		shift = (cl_uint)(expo + scale);
+	bool		fast = ((mant >> 32) == 0) & (shift <= 9u);
+
+	if (fast)
+	{
+		cl_uint		p = ((shift & 1) ? 10u : 1u) * ((shift & 2) ? 100u : 1u) * ((shift & 4) ? 10000u : 1u);
+		cl_ulong	v = (cl_ulong)(cl_uint)mant * (cl_ulong)p;
+
+		v = ((shift & 8) ? v * 100000000UL : v);		/* < 2^32 * 10^9 < 2^62 */
+		return pg_fixed_make(PG_NUMERIC_SIGN(arg.value) ? -(cl_long)v : (cl_long)v, arg.isnull);
+	}
+	pg_int8_t r = strom_numeric_to_fixed(errcode, arg, scale);
+	return pg_fixed_make(r.value, r.isnull);
 }
 
 STROM_DEVICE pg_numeric_t
@@ -557,48 +576,56 @@ pgfn_fixed_to_int8(cl_int *errcode, pg_fixed_t arg)
 	return r;
 }
 
+/*
+ * The checked operations below are written without branches: NULL-ness and
+ * overflow are selects, the error code is raised by STROM_SET_RECHECK_IF.
+ */
 /* value * factor, factor = 10^k chosen by the emitter */
 STROM_DEVICE pg_fixed_t
 pgfn_fixed_scaleup(cl_int *errcode, pg_fixed_t arg, cl_long factor)
 {
-	if (arg.isnull)
-		return arg;
-	if (__builtin_mul_overflow(arg.value, factor, &arg.value))
-		return pg_fixed_recheck(errcode);
-	return arg;
+	cl_long		v;
+	bool		ovf = __builtin_mul_overflow(arg.value, factor, &v) & !arg.isnull;
+
+	STROM_SET_RECHECK_IF(errcode, ovf);
+	return pg_fixed_make(ovf ? 0 : v, arg.isnull | ovf);
 }
 
 STROM_DEVICE pg_fixed_t
 pgfn_fixed_add(cl_int *errcode, pg_fixed_t a, pg_fixed_t b)
 {
-	if (a.isnull || b.isnull)
-		return pg_fixed_make(0, true);
-	if (__builtin_add_overflow(a.value, b.value, &a.value))
-		return pg_fixed_recheck(errcode);
-	return a;
+	cl_long		v;
+	bool		isnull = a.isnull | b.isnull;
+	bool		ovf = __builtin_add_overflow(a.value, b.value, &v) & !isnull;
+
+	STROM_SET_RECHECK_IF(errcode, ovf);
+	return pg_fixed_make((isnull | ovf) ? 0 : v, isnull | ovf);
 }
 
 STROM_DEVICE pg_fixed_t
 pgfn_fixed_sub(cl_int *errcode, pg_fixed_t a, pg_fixed_t b)
 {
-	if (a.isnull || b.isnull)
-		return pg_fixed_make(0, true);
-	if (__builtin_sub_overflow(a.value, b.value, &a.value))
-		return pg_fixed_recheck(errcode);
-	return a;
+	cl_long		v;
+	bool		isnull = a.isnull | b.isnull;
+	bool		ovf = __builtin_sub_overflow(a.value, b.value, &v) & !isnull;
+
+	STROM_SET_RECHECK_IF(errcode, ovf);
+	return pg_fixed_make((isnull | ovf) ? 0 : v, isnull | ovf);
 }
 
 STROM_DEVICE pg_fixed_t
 pgfn_fixed_mul(cl_int *errcode, pg_fixed_t a, pg_fixed_t b)
 {
-	if (a.isnull || b.isnull)
-		return pg_fixed_make(0, true);
+	bool		isnull = a.isnull | b.isnull;
+
 	/* both within int32 (amounts x rates): one 32x32->64 multiply */
-	if (a.value == (cl_long)(cl_int)a.value && b.value == (cl_long)(cl_int)b.value)
-		return pg_fixed_make((cl_long)(cl_int)a.value * (cl_long)(cl_int)b.value, false);
-	if (__builtin_mul_overflow(a.value, b.value, &a.value))
-		return pg_fixed_recheck(errcode);
-	return a;
+	if ((a.value == (cl_long)(cl_int)a.value) & (b.value == (cl_long)(cl_int)b.value))
+		return pg_fixed_make(isnull ? 0 : (cl_long)(cl_int)a.value * (cl_long)(cl_int)b.value, isnull);
+	cl_long		v;
+	bool		ovf = __builtin_mul_overflow(a.value, b.value, &v) & !isnull;
+
+	STROM_SET_RECHECK_IF(errcode, ovf);
+	return pg_fixed_make((isnull | ovf) ? 0 : v, isnull | ovf);
 }
 
 STROM_DEVICE pg_fixed_t

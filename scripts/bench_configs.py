@@ -102,6 +102,33 @@ def c2():
     ds.release()
 
 
+def c2host():
+    """the boundary hands over HOST chunks: upload + scan per request (PCIe-inclusive)"""
+    rng = np.random.default_rng(0x5eed0002)
+    n = 25_000_000
+    a = rng.integers(0, 2**31, n, dtype=np.int64).astype(np.int32)
+    b = rng.random(n)
+    qual = "(and (int4lt (var 1 int4) (param 0 int4)) (float8gt (var 2 float8) (param 1 float8)))"
+    for fmt in ("column", "row"):
+        rows = n if fmt == "column" else 10_000_000
+        buf = kds.build_kds(fmt, [kds.Column("int4", a[:rows]), kds.Column("float8", b[:rows])])
+        runtime.lib.strom_pin_host_range(buf.ctypes.data, len(buf))
+        scan = GpuScan(qual).begin(ext_params=[np.int32(2**31 * 0.5), 0.8])
+        scan.scan_chunk(buf)
+        t0 = time.perf_counter()
+        reps = 6
+        sel = 0
+        for res in scan.scan_chunks([buf] * reps):
+            sel = res.nitems
+        dt = (time.perf_counter() - t0) / reps
+        scan.end()
+        runtime.lib.strom_unpin_host_range(buf.ctypes.data)
+        print(json.dumps(dict(config="C2 host chunk, %s format (PCIe-inclusive)" % fmt.upper(), rows=rows,
+                              chunk_bytes=len(buf), wall_us_per_chunk=round(dt * 1e6, 1),
+                              mrows_s=round(rows / dt / 1e6), upload_gbs=round(len(buf) / dt / 1e9, 1),
+                              selected=sel)), flush=True)
+
+
 def c3():
     nd = 1_000_000
     rng = np.random.default_rng(0x5eed0003)
@@ -201,4 +228,4 @@ if __name__ == "__main__":
     runtime.init()
     which = sys.argv[2].split(",") if len(sys.argv) > 2 else ["c2", "c3", "c4", "c5"]
     for name in which:
-        {"c2": c2, "c3": c3, "c4": c4, "c5": c5, "c5dyn": lambda: c5(False)}[name]()
+        {"c2": c2, "c2host": c2host, "c3": c3, "c4": c4, "c5": c5, "c5dyn": lambda: c5(False)}[name]()
