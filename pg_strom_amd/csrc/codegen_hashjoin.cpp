@@ -197,7 +197,10 @@ strom_codegen_gpuhashjoin(const char *spec, strom_codegen_result *out, int *p_nr
 				"                        cl_long *p_key)\n{\n  return false;\n}\n";
 
 		/* ---- gpuhashjoin_execute: nested probe loops --------------------- */
-		src += "STROM_DEVICE cl_uint\n"
+		/* ALL_SINGLE: every relation has a DIRECT index with unique keys (the
+		 * kernel checks once per launch); the mode tests then fold away and
+		 * no hash entry is read at all */
+		src += "template <bool ALL_SINGLE>\nSTROM_DEVICE cl_uint\n"
 			"gpuhashjoin_execute(cl_int *errcode, const strom_kparams &KP, const strom_kvars &KV,\n"
 			"                    const kern_multihash *__restrict__ kmhash, const hashjoin_index *__restrict__ hjidx,\n"
 			"                    cl_uint kds_index, cl_int *__restrict__ rbuffer)\n{\n"
@@ -239,13 +242,13 @@ strom_codegen_gpuhashjoin(const char *spec, strom_codegen_result *out, int *p_nr
 			snprintf(tmp, sizeof(tmp),
 					 "%scl_uint hash_%d;\n"
 					 "%sconst bool direct_%d = %s;\n"
-					 "%sconst bool single_%d = direct_%d && hjidx->rel[%d].unique != 0;\n"
+					 "%sconst bool single_%d = ALL_SINGLE || (direct_%d && hjidx->rel[%d].unique != 0);\n"
 					 "%sfor (cl_uint off_%d = hashjoin_first(hjidx, %d, kimg_%d, %zu, &hash_%d), next_%d = 0;\n"
 					 "%s     off_%d != 0;\n"
 					 "%s     off_%d = next_%d)\n%s{\n",
 					 indent.c_str(), d,
 					 indent.c_str(), d,
-					 direct_ok ? ("hjidx->rel[" + std::to_string(d - 1) + "].mode == HASHJOIN_MODE_DIRECT").c_str() : "false",
+					 direct_ok ? ("(ALL_SINGLE || hjidx->rel[" + std::to_string(d - 1) + "].mode == HASHJOIN_MODE_DIRECT)").c_str() : "false",
 					 indent.c_str(), d, d, d - 1,
 					 indent.c_str(), d, d - 1, d, R.keys.size(), d, d,
 					 indent.c_str(), d,

@@ -114,7 +114,10 @@ gpuscan_stage_flush(gpuscan_stage &stage, kern_resultbuf *kresults, cl_uint fill
 	cl_uint		base = stage.flush_base;
 	cl_int	   *dest = kresults->results + base;
 #if !defined(GPUSCAN_ABLATE) || GPUSCAN_ABLATE != 1
-#if defined(GPUSCAN_STORE_NT) && GPUSCAN_STORE_NT
+#if !defined(GPUSCAN_STORE_NT) || GPUSCAN_STORE_NT
+	/* results are written once and read elsewhere: non-temporal stores keep
+	 * them out of the L2 write-allocate path of the read stream (+5 % at 10 %
+	 * selectivity, +8 % at 49 %: profiles/r01_gpuscan_tune_v2.txt) */
 	for (cl_uint i = threadIdx.x; i < fill; i += GPUSCAN_BLOCK)
 		__builtin_nontemporal_store(stage.entries[i], &dest[i]);
 #else

@@ -147,6 +147,7 @@ hashjoin_inner_key_images(int depth, const kern_hashtable *kht, const kern_hashe
 STROM_DEVICE bool
 hashjoin_fast_outer_key(cl_int *errcode, const strom_kparams &KP, const strom_kvars &KV,
 						cl_long *p_key);
+template <bool ALL_SINGLE>
 STROM_DEVICE cl_uint
 gpuhashjoin_execute(cl_int *errcode, const strom_kparams &KP, const strom_kvars &KV,
 					const kern_multihash *__restrict__ kmhash, const hashjoin_index *__restrict__ hjidx,
@@ -356,19 +357,26 @@ hashjoin_block_scan(cl_uint v, cl_uint *lds_wave_totals, cl_uint *p_total)
 /* ====================================================================== *
  * general probe: any format, row map, duplicates, several relations
  * ====================================================================== */
-#define HASHJOIN_GENERIC_ROWS	8
+/* tile geometry of the general probe (see gpuhashjoin_main_body) */
+#ifndef HASHJOIN_GENERIC_ROWS
+#define HASHJOIN_GENERIC_ROWS	64		/* rows per thread and tile */
+#endif
+#define HASHJOIN_SLICE_ROWS		16		/* rows per thread and emit slice */
+#define HASHJOIN_NSLICES		(HASHJOIN_GENERIC_ROWS / HASHJOIN_SLICE_ROWS)
+#define HASHJOIN_EMIT_STAGE_BYTES	32768
+static_assert(HASHJOIN_GENERIC_ROWS <= 64 && HASHJOIN_GENERIC_ROWS % HASHJOIN_SLICE_ROWS == 0,
+			  "a tile is at most 64 rows per thread (emit bit mask), in whole slices");
 
-extern "C" __global__ void
-__launch_bounds__(HASHJOIN_BLOCK)
-gpuhashjoin_main(kern_hashjoin *__restrict__ khashjoin,
+template <bool IS_COLUMN, bool ALL_SINGLE>
+__device__ __forceinline__ void
+gpuhashjoin_main_body(kern_hashjoin *__restrict__ khashjoin,
 				 const kern_multihash *__restrict__ kmhash,
 				 const hashjoin_index *__restrict__ hjidx,
 				 const kern_data_store *__restrict__ kds,
 				 const kern_data_store *__restrict__ ktoast,
-				 const kern_row_map *__restrict__ krowmap)
+				 const kern_row_map *__restrict__ krowmap,
+				 cl_uint *wave_totals, cl_uint &tile_base_slot, cl_int *emit_stage)
 {
-	__shared__ cl_uint	wave_totals[HASHJOIN_NWAVES];
-	__shared__ cl_uint	tile_base_slot;
 	const kern_parambuf *kparams = KERN_HASHJOIN_PARAMBUF(khashjoin);
 	kern_resultbuf *kresults = KERN_HASHJOIN_RESULTBUF(khashjoin);
 	bool		use_map = (krowmap != NULL && krowmap->nvalids >= 0);
@@ -382,7 +390,7 @@ gpuhashjoin_main(kern_hashjoin *__restrict__ khashjoin,
 
 	hashjoin_load_kparams(KP, kparams, &param_error);
 	/* COLUMN chunk: column pointers hoisted, no header reads per row */
-	bool		is_column = (kds->format == KDS_FORMAT_COLUMN);
+	const bool	is_column = IS_COLUMN;	/* compile-time: the other accessor is not even compiled in */
 	const kern_coldir *coldir = KERN_DATA_STORE_COLDIR(kds);
 #define X(attno,colidx,NAME)													\
 	const char *col_##attno = (is_column ? (const char *)kds + coldir[colidx].values_off : NULL);	\
@@ -397,43 +405,76 @@ gpuhashjoin_main(kern_hashjoin *__restrict__ khashjoin,
 			atomicMax(&kresults->errcode, StromError_DataStoreCorruption);
 		return;
 	}
+	/*
+	 * A tile is HASHJOIN_GENERIC_ROWS rows per thread in slices of
+	 * HASHJOIN_SLICE_ROWS.  Counting covers the whole tile and ends in ONE
+	 * reservation on kresults->nitems: a returning atomic on one address is
+	 * served at ~27 M/s chip-wide (48.8 k of them -- 2048-row tiles -- cost
+	 * 1.8 ms per 1e8 rows before any probe).  Emission goes slice by slice
+	 * through an LDS stage and leaves with coalesced stores: with large
+	 * tiles a thread's own output range is hundreds of bytes from its
+	 * neighbour's, and writing it directly costs more than the atomics did
+	 * (profiles/r01_hashjoin_ablation.txt).
+	 */
+	cl_uint		stage_cap = (HASHJOIN_EMIT_STAGE_BYTES / (cl_uint)sizeof(cl_int)) / nrels;	/* records */
+
 	/* chunk_error is per thread: the tile loop must not end divergently */
 	for (cl_uint tile = blockIdx.x; tile < ntiles; tile += gridDim.x)
 	{
-		cl_uint		counts[HASHJOIN_GENERIC_ROWS];
-		cl_uint		mine = 0;
+		cl_ulong	emit_mask = 0;		/* bit j: row j of this thread has matches to emit */
+		cl_uint		cnt[HASHJOIN_NSLICES];
+		cl_uint		off[HASHJOIN_NSLICES];
+		cl_uint		tot[HASHJOIN_NSLICES];
+		cl_uint		total = 0;
 
 		/* pass 1: count */
 #pragma unroll
-		for (int j = 0; j < HASHJOIN_GENERIC_ROWS; j++)
+		for (int s = 0; s < HASHJOIN_NSLICES; s++)
 		{
-			cl_uint	r = tile * tile_rows + j * HASHJOIN_BLOCK + threadIdx.x;
-			counts[j] = 0;
-			if (r < nrows)
+			cnt[s] = 0;
+#pragma unroll 1
+			for (int jj = 0; jj < HASHJOIN_SLICE_ROWS; jj++)
 			{
-				cl_uint		kds_index = (use_map ? (cl_uint)krowmap->rindex[r] : r);
-				cl_int		errcode = param_error;
-				strom_kvars	KV;
-#define X(attno,colidx,NAME)													\
-				KV.KVAR_##attno = (is_column											\
-					? STROM_COLUMN_REF(NAME, col_##attno, nul_##attno, kds_index)		\
-					: pg_##NAME##_vref(kds, ktoast, &errcode, colidx, kds_index));
-				STROM_KVAR_LIST(X)
-#undef X
-				KV.__dummy = 0;
-				counts[j] = gpuhashjoin_execute(&errcode, KP, KV, kmhash, hjidx, kds_index, NULL);
-				if (errcode != StromError_Success)
+				int		j = s * HASHJOIN_SLICE_ROWS + jj;
+				cl_uint	r = tile * tile_rows + j * HASHJOIN_BLOCK + threadIdx.x;
+				if (r < nrows)
 				{
-					/* the reference cannot re-check a join row on the CPU
-					 * (gpuhashjoin.c:2948-2952): surface it as the chunk status */
-					STROM_SET_ERROR(&chunk_error, errcode);
-					counts[j] = 0;
+					cl_uint		kds_index = (use_map ? (cl_uint)krowmap->rindex[r] : r);
+					cl_int		errcode = param_error;
+					cl_uint		n;
+					strom_kvars	KV;
+#define X(attno,colidx,NAME)													\
+					KV.KVAR_##attno = (is_column										\
+						? STROM_COLUMN_REF(NAME, col_##attno, nul_##attno, kds_index)	\
+						: pg_##NAME##_vref(kds, ktoast, &errcode, colidx, kds_index));
+					STROM_KVAR_LIST(X)
+#undef X
+					KV.__dummy = 0;
+#if defined(HASHJOIN_ABLATE) && HASHJOIN_ABLATE == 2
+					n = 1;				/* diagnostic build (wrong results): no probe */
+#else
+					n = gpuhashjoin_execute<ALL_SINGLE>(&errcode, KP, KV, kmhash, hjidx, kds_index, NULL);
+#endif
+					if (errcode != StromError_Success)
+					{
+						/* the reference cannot re-check a join row on the CPU
+						 * (gpuhashjoin.c:2948-2952): surface it as the chunk status */
+						STROM_SET_ERROR(&chunk_error, errcode);
+						n = 0;
+					}
+					if (n > 0)
+						emit_mask |= (1UL << j);
+					cnt[s] += n;
 				}
 			}
-			mine += counts[j];
 		}
-		cl_uint		total;
-		cl_uint		offset = hashjoin_block_scan(mine, wave_totals, &total);
+		/* per slice: this thread's offset inside the slice, the slice total */
+#pragma unroll
+		for (int s = 0; s < HASHJOIN_NSLICES; s++)
+		{
+			off[s] = hashjoin_block_scan(cnt[s], wave_totals, &tot[s]);
+			total += tot[s];
+		}
 		if (threadIdx.x == 0)
 			tile_base_slot = (total > 0 ? atomicAdd(&kresults->nitems, total) : 0);
 		__syncthreads();
@@ -446,28 +487,50 @@ gpuhashjoin_main(kern_hashjoin *__restrict__ khashjoin,
 				atomicMax(&kresults->errcode, StromError_DataStoreNoSpace);
 			continue;
 		}
-		/* pass 2: emit */
-		cl_uint		pos = base + offset;
+#if defined(HASHJOIN_ABLATE) && HASHJOIN_ABLATE >= 1
+		continue;					/* diagnostic build (wrong results): count only */
+#endif
+		/* pass 2: emit (the probe is repeated; what it finds is what was counted) */
 #pragma unroll
-		for (int j = 0; j < HASHJOIN_GENERIC_ROWS; j++)
+		for (int s = 0; s < HASHJOIN_NSLICES; s++)
 		{
-			if (counts[j] > 0)
+			bool		staged = (tot[s] <= stage_cap);		/* uniform */
+			cl_int	   *out = (staged ? emit_stage + (size_t)nrels * off[s]
+								   : kresults->results + (size_t)nrels * (base + off[s]));
+			if (tot[s] == 0)
+				continue;
+#pragma unroll 1
+			for (int jj = 0; jj < HASHJOIN_SLICE_ROWS; jj++)
 			{
-				cl_uint		r = tile * tile_rows + j * HASHJOIN_BLOCK + threadIdx.x;
-				cl_uint		kds_index = (use_map ? (cl_uint)krowmap->rindex[r] : r);
-				cl_int		errcode = param_error;
-				strom_kvars	KV;
+				int		j = s * HASHJOIN_SLICE_ROWS + jj;
+				if ((emit_mask >> j) & 1)
+				{
+					cl_uint		r = tile * tile_rows + j * HASHJOIN_BLOCK + threadIdx.x;
+					cl_uint		kds_index = (use_map ? (cl_uint)krowmap->rindex[r] : r);
+					cl_int		errcode = param_error;
+					strom_kvars	KV;
 #define X(attno,colidx,NAME)													\
-				KV.KVAR_##attno = (is_column											\
-					? STROM_COLUMN_REF(NAME, col_##attno, nul_##attno, kds_index)		\
-					: pg_##NAME##_vref(kds, ktoast, &errcode, colidx, kds_index));
-				STROM_KVAR_LIST(X)
+					KV.KVAR_##attno = (is_column										\
+						? STROM_COLUMN_REF(NAME, col_##attno, nul_##attno, kds_index)	\
+						: pg_##NAME##_vref(kds, ktoast, &errcode, colidx, kds_index));
+					STROM_KVAR_LIST(X)
 #undef X
-				KV.__dummy = 0;
-				gpuhashjoin_execute(&errcode, KP, KV, kmhash, hjidx, kds_index,
-									kresults->results + (size_t)nrels * pos);
-				pos += counts[j];
+					KV.__dummy = 0;
+					out += (size_t)nrels *
+						gpuhashjoin_execute<ALL_SINGLE>(&errcode, KP, KV, kmhash, hjidx, kds_index, out);
+				}
 			}
+			if (staged)
+			{
+				/* stage -> results[], coalesced */
+				__syncthreads();
+				cl_int	   *dest = kresults->results + (size_t)nrels * base;
+				cl_uint		nwords = nrels * tot[s];
+				for (cl_uint i = threadIdx.x; i < nwords; i += HASHJOIN_BLOCK)
+					__builtin_nontemporal_store(emit_stage[i], &dest[i]);
+				__syncthreads();
+			}
+			base += tot[s];
 		}
 	}
 	/* significant errors and CpuReCheck alike end up in kresults->errcode */
@@ -475,6 +538,44 @@ gpuhashjoin_main(kern_hashjoin *__restrict__ khashjoin,
 		cl_int worst = strom_wave_max_i32(chunk_error);
 		if (strom_lane_id() == 0 && worst != StromError_Success)
 			atomicMax(&kresults->errcode, worst);
+	}
+}
+
+extern "C" __global__ void
+__launch_bounds__(HASHJOIN_BLOCK)
+gpuhashjoin_main(kern_hashjoin *__restrict__ khashjoin,
+				 const kern_multihash *__restrict__ kmhash,
+				 const hashjoin_index *__restrict__ hjidx,
+				 const kern_data_store *__restrict__ kds,
+				 const kern_data_store *__restrict__ ktoast,
+				 const kern_row_map *__restrict__ krowmap)
+{
+	__shared__ cl_uint	wave_totals[HASHJOIN_NWAVES];
+	__shared__ cl_uint	tile_base_slot;
+	__shared__ cl_int	emit_stage[HASHJOIN_EMIT_STAGE_BYTES / sizeof(cl_int)];
+
+	/*
+	 * Uniform decisions made once per launch, not per datum / per probe: the
+	 * chunk format, and whether every relation is a DIRECT index with unique
+	 * keys.  Left as run-time values inside the row loop they cost 4.4 ms
+	 * per 1e8 rows against 0.95 ms (profiles/r01_hashjoin_ablation.txt): the
+	 * hash-entry loads behind them are issued whether they are needed or not.
+	 */
+	bool	all_single = true;
+	for (cl_uint d = 0; d < hjidx->nrels; d++)
+		all_single = all_single && (hjidx->rel[d].mode == HASHJOIN_MODE_DIRECT && hjidx->rel[d].unique != 0);
+	if (kds->format == KDS_FORMAT_COLUMN)
+	{
+		if (all_single)
+			gpuhashjoin_main_body<true, true>(khashjoin, kmhash, hjidx, kds, ktoast, krowmap, wave_totals, tile_base_slot, emit_stage);
+		else
+			gpuhashjoin_main_body<true, false>(khashjoin, kmhash, hjidx, kds, ktoast, krowmap, wave_totals, tile_base_slot, emit_stage);
+	}
+	else
+	{
+		/* row formats are bound by the tuple walk: one instantiation (every
+		 * copy of the generated probe costs JIT time at query start) */
+		gpuhashjoin_main_body<false, false>(khashjoin, kmhash, hjidx, kds, ktoast, krowmap, wave_totals, tile_base_slot, emit_stage);
 	}
 }
 
@@ -627,7 +728,13 @@ gpuhashjoin_main_fast(kern_hashjoin *khashjoin,
 				{
 					cl_long *dest = (cl_long *)(kresults->results + 2 * (size_t)base);
 					for (cl_uint i = threadIdx.x; i < fill; i += HASHJOIN_BLOCK)
-						__builtin_memcpy(&dest[i], stage.entries[i], 8);
+						{
+							/* non-temporal: 640 MB of result pairs must not evict
+							 * the slot array the probes hit in L2 */
+							cl_long	pair;
+							__builtin_memcpy(&pair, stage.entries[i], 8);
+							__builtin_nontemporal_store(pair, &dest[i]);
+						}
 				}
 				else
 					STROM_SET_ERROR(&chunk_error, StromError_DataStoreNoSpace);
@@ -690,7 +797,13 @@ gpuhashjoin_main_fast(kern_hashjoin *khashjoin,
 		{
 			cl_long *dest = (cl_long *)(kresults->results + 2 * (size_t)base);
 			for (cl_uint i = threadIdx.x; i < fill; i += HASHJOIN_BLOCK)
-				__builtin_memcpy(&dest[i], stage.entries[i], 8);
+				{
+							/* non-temporal: 640 MB of result pairs must not evict
+							 * the slot array the probes hit in L2 */
+							cl_long	pair;
+							__builtin_memcpy(&pair, stage.entries[i], 8);
+							__builtin_nontemporal_store(pair, &dest[i]);
+						}
 		}
 		else
 			STROM_SET_ERROR(&chunk_error, StromError_DataStoreNoSpace);

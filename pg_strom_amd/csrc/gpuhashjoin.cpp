@@ -361,7 +361,10 @@ gpuhashjoin_launch(strom_task_impl *task, hashjoin_request req)
 	task_event(task);									/* ev[1] */
 	{
 		int		block = 256;
-		size_t	tile_rows = fast ? (size_t)block * 4 * 2 : (size_t)block * 8;
+		int		generic_rows = 64;								/* HASHJOIN_GENERIC_ROWS */
+		if (const char *v = getenv("STROM_HASHJOIN_GENERIC_ROWS"))
+			generic_rows = std::max(1, atoi(v));
+		size_t	tile_rows = fast ? (size_t)block * 4 * 2 : (size_t)block * generic_rows;
 		size_t	ntiles = (req.nrows + tile_rows - 1) / tile_rows;
 		int		per_cu = 0;
 		if (hipModuleOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, block, 0) != hipSuccess || per_cu < 1)

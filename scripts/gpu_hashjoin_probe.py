@@ -5,7 +5,7 @@ sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(_
 from pg_strom_amd import kds, runtime
 from pg_strom_amd.gpuhashjoin import GpuHashJoin, build_multihash, STROM_RESULTS_ON_DEVICE
 nf = int(sys.argv[1]) if len(sys.argv) > 1 else 100_000_000
-nd = 1_000_000
+nd = int(sys.argv[2]) if len(sys.argv) > 2 else 1_000_000
 runtime.init()
 rng = np.random.default_rng(3)
 pk = rng.permutation(nd).astype(np.int32)
@@ -24,7 +24,7 @@ for label, env in (("direct+fast", {}), ("direct generic", {"STROM_HASHJOIN_NO_F
     ts = []
     for it in range(8):
         res = join.join_chunk(ds, flags=STROM_RESULTS_ON_DEVICE)
-        assert res.errcode == 0 and res.nitems == nmatch, (res.errcode, res.nitems, nmatch)
+        assert os.environ.get('STROM_HASHJOIN_ABLATE') or (res.errcode == 0 and res.nitems == nmatch), (res.errcode, res.nitems, nmatch)
         ts.append(res.perfmon["time_kern_exec_ns"])
     t = float(np.median(ts[2:])) * 1e-9
     byts = 4.0 * nf + 8.0 * nmatch

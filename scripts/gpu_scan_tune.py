@@ -13,17 +13,18 @@ buf = kds.build_kds("column", [kds.Column("int4", a), kds.Column("float8", b)])
 ds = runtime.DeviceStore.upload(buf)
 del buf
 configs = []
-for block, quads, stage, nt in [(256,2,8192,1),(256,2,8192,0),(256,4,8192,1),(256,4,16384,1),(512,2,8192,1),
-                                (512,2,16384,1),(512,4,16384,1),(1024,2,16384,1),(1024,2,32768,1),(256,1,4096,1),
-                                (256,1,8192,1),(128,4,8192,1),(256,2,4096,1),(256,2,2048,1)]:
+for block, quads, stage, nt in [(256,1,8192,1),(256,2,8192,1),(256,2,16384,1),(256,4,16384,1),(512,1,8192,1),
+                                (512,2,16384,1),(128,2,8192,1),(256,1,4096,1)]:
     for percu in ("", ):
-        configs.append((block, quads, stage, nt, percu))
+        for snt in (0, 1):
+            configs.append((block, quads, stage, nt, percu, snt))
 sels = ((0.02, 0.5), (0.5, 0.8), (0.7, 0.3))
-for block, quads, stage, nt, percu in configs:
+for block, quads, stage, nt, percu, snt in configs:
     os.environ["STROM_GPUSCAN_BLOCK"] = str(block)
     os.environ["STROM_GPUSCAN_QUADS"] = str(quads)
     os.environ["STROM_GPUSCAN_STAGE"] = str(stage)
     os.environ["STROM_COLUMN_LOAD_NT"] = str(nt)
+    os.environ["STROM_GPUSCAN_STORE_NT"] = str(snt)
     if percu: os.environ["STROM_GPUSCAN_BLOCKS_PER_CU"] = percu
     else: os.environ.pop("STROM_GPUSCAN_BLOCKS_PER_CU", None)
     scan = GpuScan(QUAL).begin(ext_params=[np.int32(0), 0.0])
@@ -41,5 +42,5 @@ for block, quads, stage, nt, percu in configs:
         t = float(np.median(ts[2:])) * 1e-9
         byts = 12.0 * n + 4.0 * res.nitems
         out.append("sel=%.2f %.1fus %.0fGB/s" % (res.nitems / n, t * 1e6, byts / t / 1e9))
-    print("block=%d quads=%d stage=%d nt=%d percu=%s | %s" % (block, quads, stage, nt, percu or "auto", " | ".join(out)), flush=True)
+    print("block=%d quads=%d stage=%d nt=%d store_nt=%d percu=%s | %s" % (block, quads, stage, nt, snt, percu or "auto", " | ".join(out)), flush=True)
     scan.end()
