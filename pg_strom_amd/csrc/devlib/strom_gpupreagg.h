@@ -647,16 +647,16 @@ gpupreagg_dense_column(kern_gpupreagg *kgpreagg,
 /* ====================================================================== *
  * dense-id reduction, any format / row map (one datum at a time)
  * ====================================================================== */
-extern "C" __global__ void
-__launch_bounds__(GPUPREAGG_BLOCK)
-gpupreagg_dense_generic(kern_gpupreagg *kgpreagg,
+template <bool IS_COLUMN>
+__device__ __forceinline__ void
+gpupreagg_dense_generic_body(kern_gpupreagg *kgpreagg,
 						const kern_data_store *kds,
 						const kern_data_store *ktoast,
 						const kern_row_map *krowmap,
 						const gpupreagg_dense_ctl *ctl,
-						char *slabs)
+						char *slabs,
+	char *lds)
 {
-	extern __shared__ __attribute__((aligned(16))) char lds[];
 	const kern_parambuf *kparams = KERN_GPUPREAGG_PARAMBUF(kgpreagg);
 	bool		use_map = (krowmap != NULL && krowmap->nvalids >= 0);
 	cl_uint		nrows = (use_map ? (cl_uint)krowmap->nvalids : kds->nitems);
@@ -679,7 +679,7 @@ gpupreagg_dense_generic(kern_gpupreagg *kgpreagg,
 	gpupreagg_lds_init(lds, L, G, NREP);
 	/* COLUMN chunk (row map, census): column pointers hoisted, no chunk
 	 * header field is read per row */
-	bool		is_column = (kds->format == KDS_FORMAT_COLUMN);
+	const bool	is_column = IS_COLUMN;		/* fixed per launch */
 	const kern_coldir *coldir_g = KERN_DATA_STORE_COLDIR(kds);
 #define X(attno,colidx,NAME)													\
 	const char *col_##attno = (is_column ? (const char *)kds + coldir_g[colidx].values_off : NULL);	\
@@ -705,6 +705,23 @@ gpupreagg_dense_generic(kern_gpupreagg *kgpreagg,
 	}
 	gpupreagg_store_slab(lds, L, slabs + (size_t)blockIdx.x * ctl->slab_bytes, G, NREP);
 	gpupreagg_writeback_status(&kgpreagg->status, chunk_status);
+}
+
+extern "C" __global__ void
+__launch_bounds__(GPUPREAGG_BLOCK)
+gpupreagg_dense_generic(kern_gpupreagg *kgpreagg,
+						const kern_data_store *kds,
+						const kern_data_store *ktoast,
+						const kern_row_map *krowmap,
+						const gpupreagg_dense_ctl *ctl,
+						char *slabs)
+{
+	extern __shared__ __attribute__((aligned(16))) char lds[];
+	/* the chunk format is decided once per launch, not once per datum */
+	if (kds->format == KDS_FORMAT_COLUMN)
+		gpupreagg_dense_generic_body<true>(kgpreagg, kds, ktoast, krowmap, ctl, slabs, lds);
+	else
+		gpupreagg_dense_generic_body<false>(kgpreagg, kds, ktoast, krowmap, ctl, slabs, lds);
 }
 
 /* ====================================================================== *
@@ -1372,9 +1389,9 @@ gpupreagg_reg1_column(kern_gpupreagg *kgpreagg, const kern_data_store *kds,
  * kernel for such queries, and is the step where the ranks of a multi-GPU
  * run agree on the slots.  One bit per dense id.
  * ====================================================================== */
-extern "C" __global__ void
-__launch_bounds__(256)
-gpupreagg_census(const kern_gpupreagg *kgpreagg, const kern_data_store *kds,
+template <bool IS_COLUMN>
+__device__ __forceinline__ void
+gpupreagg_census_body(const kern_gpupreagg *kgpreagg, const kern_data_store *kds,
 				 const kern_data_store *ktoast, const kern_row_map *krowmap,
 				 const gpupreagg_dense_ctl *ctl, cl_uint *bitmap)
 {
@@ -1387,7 +1404,7 @@ gpupreagg_census(const kern_gpupreagg *kgpreagg, const kern_data_store *kds,
 	gpupreagg_load_kparams(KP, kparams, &param_error);
 	/* COLUMN chunk (row map, census): column pointers hoisted, no chunk
 	 * header field is read per row */
-	bool		is_column = (kds->format == KDS_FORMAT_COLUMN);
+	const bool	is_column = IS_COLUMN;		/* fixed per launch */
 	const kern_coldir *coldir_g = KERN_DATA_STORE_COLDIR(kds);
 #define X(attno,colidx,NAME)													\
 	const char *col_##attno = (is_column ? (const char *)kds + coldir_g[colidx].values_off : NULL);	\
@@ -1432,6 +1449,19 @@ gpupreagg_census(const kern_gpupreagg *kgpreagg, const kern_data_store *kds,
 		if (!(bitmap[gid >> 5] & bit))
 			atomicOr(&bitmap[gid >> 5], bit);
 	}
+}
+
+extern "C" __global__ void
+__launch_bounds__(256)
+gpupreagg_census(const kern_gpupreagg *kgpreagg, const kern_data_store *kds,
+				 const kern_data_store *ktoast, const kern_row_map *krowmap,
+				 const gpupreagg_dense_ctl *ctl, cl_uint *bitmap)
+{
+	/* the chunk format is decided once per launch, not once per datum */
+	if (kds->format == KDS_FORMAT_COLUMN)
+		gpupreagg_census_body<true>(kgpreagg, kds, ktoast, krowmap, ctl, bitmap);
+	else
+		gpupreagg_census_body<false>(kgpreagg, kds, ktoast, krowmap, ctl, bitmap);
 }
 
 /* ====================================================================== *

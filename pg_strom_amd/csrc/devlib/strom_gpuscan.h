@@ -318,14 +318,14 @@ gpuscan_qual_column(kern_gpuscan *kgpuscan, const kern_data_store *kds)
 /* ====================================================================== *
  * any format, optional row map: one datum at a time
  * ====================================================================== */
-extern "C" __global__ void
-__launch_bounds__(GPUSCAN_BLOCK)
-gpuscan_qual_generic(kern_gpuscan *kgpuscan,
+template <bool IS_COLUMN>
+__device__ __forceinline__ void
+gpuscan_qual_generic_body(kern_gpuscan *kgpuscan,
 					 const kern_data_store *kds,
 					 const kern_data_store *ktoast,
-					 const kern_row_map *krowmap)
+					 const kern_row_map *krowmap,
+					 gpuscan_stage &stage)
 {
-	__shared__ gpuscan_stage stage;
 	const kern_parambuf *kparams = KERN_GPUSCAN_PARAMBUF(kgpuscan);
 	kern_resultbuf *kresults = KERN_GPUSCAN_RESULTBUF(kgpuscan);
 	bool		use_map = (krowmap != NULL && krowmap->nvalids >= 0);
@@ -340,7 +340,7 @@ gpuscan_qual_generic(kern_gpuscan *kgpuscan,
 
 	/* COLUMN chunk behind a row map: column pointers hoisted, no chunk
 	 * header field is read per row */
-	bool		is_column = (kds->format == KDS_FORMAT_COLUMN);
+	const bool	is_column = IS_COLUMN;		/* fixed per launch: the other accessor is not compiled in */
 	const kern_coldir *coldir_g = KERN_DATA_STORE_COLDIR(kds);
 #define X(attno,colidx,NAME)													\
 	const char *col_##attno = (is_column ? (const char *)kds + coldir_g[colidx].values_off : NULL);	\
@@ -409,6 +409,22 @@ gpuscan_qual_generic(kern_gpuscan *kgpuscan,
 	}
 	gpuscan_stage_flush(stage, kresults, fill);
 	kern_writeback_error_status(&kresults->errcode, chunk_error);
+}
+
+extern "C" __global__ void
+__launch_bounds__(GPUSCAN_BLOCK)
+gpuscan_qual_generic(kern_gpuscan *kgpuscan,
+					 const kern_data_store *kds,
+					 const kern_data_store *ktoast,
+					 const kern_row_map *krowmap)
+{
+	__shared__ gpuscan_stage stage;
+
+	/* the chunk format is decided once per launch, not once per datum */
+	if (kds->format == KDS_FORMAT_COLUMN)
+		gpuscan_qual_generic_body<true>(kgpuscan, kds, ktoast, krowmap, stage);
+	else
+		gpuscan_qual_generic_body<false>(kgpuscan, kds, ktoast, krowmap, stage);
 }
 
 #endif	/* STROM_GPUSCAN_DEVICE_H */

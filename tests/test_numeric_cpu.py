@@ -107,3 +107,33 @@ def test_fixed_point_partial_sums():
     # a value finer than the accumulator's scale sends the chunk back
     rc, v, isn = oracle.gpupreagg("(gpupreagg (psum (var 2 numeric) 1))", buf, 1)
     assert rc == 2
+
+
+def test_typmod_scale_is_a_codegen_hint_only():
+    """(var N numeric SCALE): the device emitter switches to fixed-point code
+    (pg_fixed_t), the oracle ignores the hint -- same partial rows either way"""
+    from pg_strom_amd.gpupreagg import codegen_gpupreagg
+    rng = np.random.default_rng(10)
+    price = [Decimal(int(rng.integers(90000, 10494950))).scaleb(-2) for _ in range(2000)]
+    disc = [Decimal(int(rng.integers(0, 11))).scaleb(-2) for _ in range(2000)]
+    buf = kds.build_kds("column", [kds.numeric_column(price), kds.numeric_column(disc)])
+    plain = ("(gpupreagg (nrows) (psum (numeric_mul (var 1 numeric) "
+             "(numeric_sub (const numeric 1) (var 2 numeric))) 4))")
+    typed = plain.replace("(var 1 numeric)", "(var 1 numeric 2)").replace("(var 2 numeric)", "(var 2 numeric 2)")
+    rc1, v1, n1 = oracle.gpupreagg(plain, buf, 2)
+    rc2, v2, n2 = oracle.gpupreagg(typed, buf, 2)
+    assert rc1 == rc2 == 0 and np.array_equal(v1, v2) and np.array_equal(n1, n2)
+    assert Decimal(int(v1[0, 1].view(np.int64))).scaleb(-4) == sum(p * (1 - d) for p, d in zip(price, disc))
+
+    def source_of(spec):
+        cg = codegen_gpupreagg(spec)
+        return (cg[0] if isinstance(cg, tuple) else cg).source
+    src = source_of(typed)
+    assert "pgfn_fixed_mul(" in src and "pgfn_numeric_as_fixed(" in src and "pgfn_numeric_mul(" not in src
+    # a scale-less operand anywhere pulls the expression back to the 64-bit numeric form
+    mixed = source_of(plain.replace("(var 1 numeric)", "(var 1 numeric 2)"))
+    assert "pgfn_numeric_mul(" in mixed and "pgfn_fixed_to_numeric(" in mixed
+    # the literal meets a scale-less value as its kern_parambuf twin, not through a conversion
+    assert "pg_fixed_lit(" not in source_of(plain)
+    with pytest.raises(ValueError):
+        codegen_gpupreagg("(gpupreagg (psum (var 1 int4 2)))")
