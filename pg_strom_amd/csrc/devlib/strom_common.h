@@ -519,4 +519,35 @@ strom_column_load_quad(const char *values, const cl_uint *notnull,
 					 (notnull) != NULL &&												\
 					 !((((const cl_uint *)(notnull))[(rowidx) >> 5] >> ((rowidx) & 31)) & 1))
 
+/*
+ * row formats in the row-at-a-time kernels: locate the heap tuple ONCE per
+ * row (row item -> page -> line pointer is a chain of dependent loads) and
+ * take every referenced attribute from it; the per-datum accessor repeats
+ * the chain for each attribute
+ */
+STROM_DEVICE const HeapTupleHeaderData *
+strom_locate_tuple(const kern_data_store *kds, cl_int format, cl_uint rowidx)
+{
+	if (format == KDS_FORMAT_ROW)
+		return kern_get_tuple_rs(kds, rowidx);
+	if (format == KDS_FORMAT_ROW_FLAT)
+		return kern_get_tuple_rsflat(kds, rowidx);
+	return NULL;
+}
+
+template <typename PGT, typename BASE>
+STROM_DEVICE PGT
+strom_tuple_ref(const kern_data_store *kds, const HeapTupleHeaderData *htup, cl_uint colidx)
+{
+	const char *addr = ((htup && colidx < kds->ncols)
+						? kern_get_datum_tuple(kds->colmeta, htup, colidx) : NULL);
+	PGT		r;
+
+	r.isnull = (addr == NULL);
+	r.value = (addr ? strom_fetch<BASE>(addr) : (BASE)0);
+	return r;
+}
+#define STROM_TUPLE_REF(NAME, kds, htup, colidx)	\
+	strom_tuple_ref<pg_##NAME##_t, pg_##NAME##_base_t>(kds, htup, colidx)
+
 #endif	/* STROM_COMMON_DEVICE_H */

@@ -680,6 +680,8 @@ gpupreagg_dense_generic_body(kern_gpupreagg *kgpreagg,
 	/* COLUMN chunk (row map, census): column pointers hoisted, no chunk
 	 * header field is read per row */
 	const bool	is_column = IS_COLUMN;		/* fixed per launch */
+	const cl_int chunk_format = kds->format;
+	const bool	row_family = (chunk_format == KDS_FORMAT_ROW || chunk_format == KDS_FORMAT_ROW_FLAT);
 	const kern_coldir *coldir_g = KERN_DATA_STORE_COLDIR(kds);
 #define X(attno,colidx,NAME)													\
 	const char *col_##attno = (is_column ? (const char *)kds + coldir_g[colidx].values_off : NULL);	\
@@ -694,9 +696,13 @@ gpupreagg_dense_generic_body(kern_gpupreagg *kgpreagg,
 		cl_uint		kds_index = (use_map ? (cl_uint)krowmap->rindex[r] : (cl_uint)r);
 		strom_kvars	KV;
 		cl_int		errcode = param_error;
+		const HeapTupleHeaderData *htup = NULL;
+		if (!is_column && row_family)
+			htup = strom_locate_tuple(kds, chunk_format, kds_index);
 #define X(attno,colidx,NAME)													\
-		KV.KVAR_##attno = (is_column												\
-			? STROM_COLUMN_REF(NAME, col_##attno, nul_##attno, kds_index)			\
+		KV.KVAR_##attno = (is_column											\
+			? STROM_COLUMN_REF(NAME, col_##attno, nul_##attno, kds_index)		\
+			: row_family ? STROM_TUPLE_REF(NAME, kds, htup, colidx)				\
 			: pg_##NAME##_vref(kds, ktoast, &errcode, colidx, kds_index));
 		STROM_KVAR_LIST(X)
 #undef X
@@ -1405,6 +1411,8 @@ gpupreagg_census_body(const kern_gpupreagg *kgpreagg, const kern_data_store *kds
 	/* COLUMN chunk (row map, census): column pointers hoisted, no chunk
 	 * header field is read per row */
 	const bool	is_column = IS_COLUMN;		/* fixed per launch */
+	const cl_int chunk_format = kds->format;
+	const bool	row_family = (chunk_format == KDS_FORMAT_ROW || chunk_format == KDS_FORMAT_ROW_FLAT);
 	const kern_coldir *coldir_g = KERN_DATA_STORE_COLDIR(kds);
 #define X(attno,colidx,NAME)													\
 	const char *col_##attno = (is_column ? (const char *)kds + coldir_g[colidx].values_off : NULL);	\
@@ -1421,9 +1429,13 @@ gpupreagg_census_body(const kern_gpupreagg *kgpreagg, const kern_data_store *kds
 		cl_int		errcode = param_error;
 		cl_uint		gid = 0;
 		bool		out_of_domain = false;
+		const HeapTupleHeaderData *htup = NULL;
+		if (!is_column && row_family)
+			htup = strom_locate_tuple(kds, chunk_format, kds_index);
 #define X(attno,colidx,NAME)													\
-		KV.KVAR_##attno = (is_column												\
-			? STROM_COLUMN_REF(NAME, col_##attno, nul_##attno, kds_index)			\
+		KV.KVAR_##attno = (is_column											\
+			? STROM_COLUMN_REF(NAME, col_##attno, nul_##attno, kds_index)		\
+			: row_family ? STROM_TUPLE_REF(NAME, kds, htup, colidx)				\
 			: pg_##NAME##_vref(kds, ktoast, &errcode, colidx, kds_index));
 		STROM_KVAR_LIST(X)
 #undef X

@@ -391,6 +391,8 @@ gpuhashjoin_main_body(kern_hashjoin *__restrict__ khashjoin,
 	hashjoin_load_kparams(KP, kparams, &param_error);
 	/* COLUMN chunk: column pointers hoisted, no header reads per row */
 	const bool	is_column = IS_COLUMN;	/* compile-time: the other accessor is not even compiled in */
+	const cl_int chunk_format = kds->format;
+	const bool	row_family = (chunk_format == KDS_FORMAT_ROW || chunk_format == KDS_FORMAT_ROW_FLAT);
 	const kern_coldir *coldir = KERN_DATA_STORE_COLDIR(kds);
 #define X(attno,colidx,NAME)													\
 	const char *col_##attno = (is_column ? (const char *)kds + coldir[colidx].values_off : NULL);	\
@@ -443,9 +445,13 @@ gpuhashjoin_main_body(kern_hashjoin *__restrict__ khashjoin,
 					cl_int		errcode = param_error;
 					cl_uint		n;
 					strom_kvars	KV;
+					const HeapTupleHeaderData *htup = NULL;
+					if (!is_column && row_family)
+						htup = strom_locate_tuple(kds, chunk_format, kds_index);
 #define X(attno,colidx,NAME)													\
-					KV.KVAR_##attno = (is_column										\
-						? STROM_COLUMN_REF(NAME, col_##attno, nul_##attno, kds_index)	\
+					KV.KVAR_##attno = (is_column											\
+						? STROM_COLUMN_REF(NAME, col_##attno, nul_##attno, kds_index)		\
+						: row_family ? STROM_TUPLE_REF(NAME, kds, htup, colidx)				\
 						: pg_##NAME##_vref(kds, ktoast, &errcode, colidx, kds_index));
 					STROM_KVAR_LIST(X)
 #undef X
@@ -509,9 +515,13 @@ gpuhashjoin_main_body(kern_hashjoin *__restrict__ khashjoin,
 					cl_uint		kds_index = (use_map ? (cl_uint)krowmap->rindex[r] : r);
 					cl_int		errcode = param_error;
 					strom_kvars	KV;
+					const HeapTupleHeaderData *htup = NULL;
+					if (!is_column && row_family)
+						htup = strom_locate_tuple(kds, chunk_format, kds_index);
 #define X(attno,colidx,NAME)													\
-					KV.KVAR_##attno = (is_column										\
-						? STROM_COLUMN_REF(NAME, col_##attno, nul_##attno, kds_index)	\
+					KV.KVAR_##attno = (is_column											\
+						? STROM_COLUMN_REF(NAME, col_##attno, nul_##attno, kds_index)		\
+						: row_family ? STROM_TUPLE_REF(NAME, kds, htup, colidx)				\
 						: pg_##NAME##_vref(kds, ktoast, &errcode, colidx, kds_index));
 					STROM_KVAR_LIST(X)
 #undef X
