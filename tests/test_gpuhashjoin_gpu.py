@@ -183,3 +183,25 @@ def test_c3_shape_properties_at_1e8():
     assert np.array_equal(fk[orow], pk[irow])
     srt = np.sort(orow)
     assert np.all(np.diff(srt) > 0)
+
+
+@pytest.mark.parametrize("nfact", [1, 255, 4096, 16383, 16384, 16385, 40001])
+@pytest.mark.parametrize("fanout", [1, 40])
+def test_general_kernel_tile_and_slice_boundaries(nfact, fanout):
+    """the general kernel counts per 16k-row tile and emits per 4096-row slice
+    through a 32 KB LDS stage; a slice whose matches do not fit the stage
+    (fan-out 40) takes the direct path.  A row map forces the general kernel."""
+    rng = np.random.default_rng(1000 + nfact + fanout)
+    ndim_keys = 300
+    pk = np.repeat(np.arange(ndim_keys, dtype=np.int32), fanout)
+    rng.shuffle(pk)
+    inner = kds.build_kds("row_flat", [kds.Column("int4", pk),
+                                       kds.Column("int4", np.arange(len(pk), dtype=np.int32))])
+    fk = rng.integers(0, int(ndim_keys * 1.3), nfact).astype(np.int32)
+    fkn = rng.random(nfact) < 0.01
+    outer = kds.build_kds("column", [kds.Column("int4", fk, fkn), kds.Column("float8", np.zeros(nfact))])
+    row_map = np.arange(nfact, dtype=np.int32)[::-1].copy()       # every row, reversed
+    res, info = run_and_compare(C3_SPEC, outer, [inner], [[1]], row_map=row_map, ratio=float(fanout))
+    assert info[0]["unique"] == (fanout == 1)
+    want = int(np.count_nonzero((fk < ndim_keys) & ~fkn)) * fanout
+    assert res.nitems == want
