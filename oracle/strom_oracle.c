@@ -294,6 +294,66 @@ num_pow10(int n)
 	return m;
 }
 
+/*
+ * PostgreSQL's varlena numeric as it sits in a heap tuple -> 64-bit form
+ * (opencl_numeric.h:166-307 does this per row on the device; layout:
+ * utils/adt/numeric.c of PostgreSQL 9.4).  Returns 0 when the value cannot
+ * be carried (NaN, compressed / external datum, mantissa beyond 57 bits).
+ */
+int
+oracle_numeric_from_varlena(const void *addr, uint64_t *out)
+{
+	const unsigned char *p = (const unsigned char *)addr;
+	uint32_t	len, n_header, ndigits, i;
+	int			sign, weight;
+	uint64_t	mant = 0;
+
+	if (p[0] == 0x01)
+		return 0;
+	if (p[0] & 0x01)
+	{
+		len = (p[0] >> 1) & 0x7f;
+		if (len < 3) return 0;
+		len -= 1;
+		p += 1;
+	}
+	else
+	{
+		uint32_t w = (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24);
+		if ((w & 3) != 0 || (w >> 2) < 6) return 0;
+		len = (w >> 2) - 4;
+		p += 4;
+	}
+	n_header = (uint32_t)p[0] | ((uint32_t)p[1] << 8);
+	if ((n_header & 0xC000) == 0xC000)
+		return 0;							/* NaN */
+	if ((n_header & 0xC000) == 0x8000)
+	{
+		sign = (n_header & 0x2000) != 0;
+		weight = (int)(n_header & 0x3F);
+		if (n_header & 0x40) weight |= ~0x3F;
+		p += 2;
+		ndigits = (len - 2) / 2;
+	}
+	else
+	{
+		if (len < 4) return 0;
+		sign = (n_header & 0xC000) == 0x4000;
+		weight = (int)(int16_t)((uint32_t)p[2] | ((uint32_t)p[3] << 8));
+		p += 4;
+		ndigits = (len - 4) / 2;
+	}
+	for (i = 0; i < ndigits; i++)
+	{
+		uint32_t d = (uint32_t)p[2 * i] | ((uint32_t)p[2 * i + 1] << 8);
+		if (d > 9999 || mant > (UINT64_MAX - 9999) / 10000)
+			return 0;
+		mant = mant * 10000 + d;
+	}
+	/* num_pack strips trailing decimal zeros before it checks the 57 bits */
+	return num_pack((weight - (int)ndigits + 1) * 4, sign, mant, out);
+}
+
 int
 oracle_numeric_from_text(const char *lit, uint64_t *out)
 {
@@ -1364,11 +1424,23 @@ eval_node(const oracle_expr *e, const eval_ctx *cx, int32_t *errcode)
 				return make_null(e->type_oid);
 			return load_datum(e->type_oid, &cx->ext_values[e->attno]);
 		case N_VAR:
-			return load_datum(e->type_oid, oracle_get_datum(cx->kds, e->attno - 1, cx->rowidx));
 		case N_IVAR:
-			return load_datum(e->type_oid,
-							  oracle_get_datum(cx->inner_kds[e->depth - 1], e->attno - 1,
-											   cx->inner_row[e->depth - 1]));
+			{
+				const kern_data_store *k = (e->kind == N_VAR ? cx->kds : cx->inner_kds[e->depth - 1]);
+				uint32_t	row = (e->kind == N_VAR ? cx->rowidx : cx->inner_row[e->depth - 1]);
+				const void *addr = oracle_get_datum(k, e->attno - 1, row);
+
+				/* a numeric inside a heap tuple is PostgreSQL's varlena form */
+				if (addr && e->type_oid == STROM_NUMERICOID &&
+					(uint32_t)(e->attno - 1) < k->ncols && k->colmeta[e->attno - 1].attlen < 0)
+				{
+					uint64_t	image;
+					if (!oracle_numeric_from_varlena(addr, &image))
+						return recheck(e->type_oid, errcode);
+					return load_datum(e->type_oid, &image);
+				}
+				return load_datum(e->type_oid, addr);
+			}
 		case N_RELABEL:
 			return eval_node(e->args[0], cx, errcode);
 		case N_FUNC:

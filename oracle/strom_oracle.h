@@ -107,6 +107,8 @@ int32_t		oracle_eval_rows(const char *expr,
 							 uint64_t *out_values, uint8_t *out_isnull, int32_t *out_errcode,
 							 int32_t *p_type_oid, char *errbuf, size_t errlen);
 int			oracle_numeric_from_text(const char *lit, uint64_t *out);
+/* PostgreSQL's varlena numeric (heap tuple datum) -> 64-bit form; 0 = not representable */
+int			oracle_numeric_from_varlena(const void *addr, uint64_t *out);
 
 /* sizes / offsets of the wire structs, for the layout tests */
 typedef struct {

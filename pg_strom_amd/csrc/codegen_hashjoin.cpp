@@ -171,11 +171,14 @@ strom_codegen_gpuhashjoin(const char *spec, strom_codegen_result *out, int *p_nr
 			{
 				const hashkey &hk = rels[d - 1].keys[k];
 				const char *tn = devtype_lookup(hk.type_oid)->dev_name;
+				/* numeric: the index hashes the datum image, which must be the
+				 * canonical one (a varlena numeric decodes un-normalised) */
 				snprintf(tmp, sizeof(tmp),
-						 "      { pg_%s_t v = pg_%s_tupref(kht->colmeta, &ent->htup, %d);\n"
+						 "      { pg_%s_t v = %spg_%s_tupref(errcode, kht->colmeta, &ent->htup, %d));\n"
 						 "        if (v.isnull) return false;\n"
 						 "        images[%zu] = hashjoin_key_image(v.value); }\n",
-						 tn, tn, hk.inner_attno - 1, k);
+						 tn, hk.type_oid == STROM_NUMERICOID ? "pgfn_numeric_normalize(errcode, " : "(",
+						 tn, hk.inner_attno - 1, k);
 				src += tmp;
 			}
 			src += "      return true;\n";
@@ -269,7 +272,7 @@ strom_codegen_gpuhashjoin(const char *spec, strom_codegen_result *out, int *p_nr
 			{
 				const char *tn = devtype_lookup(iv.second)->dev_name;
 				snprintf(tmp, sizeof(tmp),
-						 "%spg_%s_t IVAR_%d_%d = pg_%s_tupref(kht_%d->colmeta, &ent_%d->htup, %d);\n",
+						 "%spg_%s_t IVAR_%d_%d = pg_%s_tupref(errcode, kht_%d->colmeta, &ent_%d->htup, %d);\n",
 						 indent.c_str(), tn, d, iv.first, tn, d, d, iv.first - 1);
 				src += tmp;
 			}
@@ -298,7 +301,7 @@ strom_codegen_gpuhashjoin(const char *spec, strom_codegen_result *out, int *p_nr
 					snprintf(tmp, sizeof(tmp), "ikey_%d_%zu", d, k);
 					ivname = tmp;
 					snprintf(tmp, sizeof(tmp),
-							 "%s  pg_%s_t %s = pg_%s_tupref(kht_%d->colmeta, &ent_%d->htup, %d);\n",
+							 "%s  pg_%s_t %s = pg_%s_tupref(errcode, kht_%d->colmeta, &ent_%d->htup, %d);\n",
 							 indent.c_str(), tn, ivname.c_str(), tn, d, d, R.keys[k].inner_attno - 1);
 					src += tmp;
 				}

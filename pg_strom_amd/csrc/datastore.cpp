@@ -66,6 +66,79 @@ is_null(const strom_column_input &c, uint32_t row)
 	return c.isnull != nullptr && c.isnull[row] != 0;
 }
 
+/*
+ * NUMERIC as PostgreSQL stores it in a heap tuple (utils/adt/numeric.c of
+ * 9.4; decoded on the device by strom_numeric_from_varlena): a varlena with
+ * a 1-byte header (these values are short), then the "short" layout
+ *   uint16 n_header = 0x8000 | sign 0x2000 | dscale << 7 | weight & 0x7F
+ * or, when weight / dscale do not fit, the "long" one
+ *   uint16 n_sign_dscale (0x4000 = negative) ; int16 n_weight
+ * and base-10000 digits, most significant first.  Input is the 64-bit
+ * device image (6-bit exponent, sign, 57-bit mantissa).
+ */
+inline bool
+is_varlena_numeric(const strom_column_input &c)
+{
+	return c.attlen == -1 && c.type_oid == STROM_NUMERICOID;
+}
+
+size_t
+numeric_image_to_varlena(uint64_t image, unsigned char *out)
+{
+	int			expo = (int)((int64_t)image >> 58);
+	bool		sign = (image & (1UL << 57)) != 0;
+	unsigned __int128 mant = image & ((1UL << 57) - 1);
+	std::vector<uint16_t> digits;			/* least significant first */
+	int			weight = 0, dscale = 0;
+
+	if (mant != 0)
+	{
+		int		e4 = (expo >= 0 ? expo / 4 : -((-expo + 3) / 4));	/* floor(expo / 4) */
+		int		r = expo - 4 * e4;									/* 0..3 */
+		for (int i = 0; i < r; i++)
+			mant *= 10;
+		while (mant != 0)
+		{
+			digits.push_back((uint16_t)(mant % 10000));
+			mant /= 10000;
+		}
+		size_t	strip = 0;
+		while (strip < digits.size() && digits[strip] == 0)
+			strip++;						/* PostgreSQL strips trailing zero digits */
+		digits.erase(digits.begin(), digits.begin() + strip);
+		e4 += (int)strip;
+		weight = (int)digits.size() - 1 + e4;
+		dscale = (expo < 0 ? -expo : 0);
+	}
+	else
+		sign = false;
+	bool		is_short = (weight >= -64 && weight <= 63 && dscale <= 63);
+	size_t		body = (is_short ? 2 : 4) + 2 * digits.size();
+	size_t		total = 1 + body;
+	unsigned char *p = out;
+
+	*p++ = (unsigned char)((total << 1) | 0x01);				/* 1-byte varlena header */
+	if (is_short)
+	{
+		uint16_t h = (uint16_t)(0x8000 | (sign ? 0x2000 : 0) | (dscale << 7) |
+								(weight < 0 ? 0x0040 : 0) | (weight & 0x003F));
+		memcpy(p, &h, 2); p += 2;
+	}
+	else
+	{
+		uint16_t h = (uint16_t)((sign ? 0x4000 : 0) | (dscale & 0x3FFF));
+		int16_t	 w = (int16_t)weight;
+		memcpy(p, &h, 2); p += 2;
+		memcpy(p, &w, 2); p += 2;
+	}
+	for (size_t i = digits.size(); i-- > 0; )
+	{
+		memcpy(p, &digits[i], 2);
+		p += 2;
+	}
+	return total;
+}
+
 /* size of the heap tuple for 'row': header, optional bitmap, aligned data */
 size_t
 heap_tuple_size(int ncols, const strom_column_input *cols, uint32_t row, size_t *p_hoff)
@@ -83,6 +156,13 @@ heap_tuple_size(int ncols, const strom_column_input *cols, uint32_t row, size_t 
 	{
 		if (is_null(cols[i], row))
 			continue;
+		if (is_varlena_numeric(cols[i]))
+		{
+			/* short varlena header: no alignment padding */
+			unsigned char tmp[64];
+			off += numeric_image_to_varlena(((const uint64_t *)cols[i].values)[row], tmp);
+			continue;
+		}
 		off = STROM_TYPEALIGN(cols[i].attalign, off);
 		off += cols[i].attlen;
 	}
@@ -110,17 +190,27 @@ heap_tuple_form(char *dest, int ncols, const strom_column_input *cols, uint32_t 
 								   | 0x0100 /* XMIN_COMMITTED */);
 	htup->t_hoff = (cl_uchar)hoff;
 	size_t	off = hoff;
+	bool	hasvarwidth = false;
 	for (int i = 0; i < ncols; i++)
 	{
 		if (is_null(cols[i], row))
 			continue;
 		if (hasnull)
 			htup->t_bits[i >> 3] |= (cl_uchar)(1 << (i & 7));
+		if (is_varlena_numeric(cols[i]))
+		{
+			off += numeric_image_to_varlena(((const uint64_t *)cols[i].values)[row],
+											(unsigned char *)dest + off);
+			hasvarwidth = true;
+			continue;
+		}
 		off = STROM_TYPEALIGN(cols[i].attalign, off);
 		memcpy(dest + off, (const char *)cols[i].values + (size_t)cols[i].attlen * row,
 			   cols[i].attlen);
 		off += cols[i].attlen;
 	}
+	if (hasvarwidth)
+		htup->t_infomask |= 0x0002;				/* HEAP_HASVARWIDTH */
 }
 
 /* ---- ROW: how many pages do nrows rows need ------------------------- */
@@ -148,14 +238,23 @@ row_count_pages(int ncols, const strom_column_input *cols, uint32_t nrows)
 }
 
 bool
-cols_valid(int ncols, const strom_column_input *cols)
+cols_valid(int ncols, const strom_column_input *cols, int format = 0)
 {
 	if (ncols < 1 || !cols)
 		return false;
 	for (int i = 0; i < ncols; i++)
 	{
 		int l = cols[i].attlen;
-		if (!(l == 1 || l == 2 || l == 4 || l == 8) || !cols[i].values)
+		if (!cols[i].values)
+			return false;
+		if (is_varlena_numeric(cols[i]))
+		{
+			/* heap tuples only: COLUMN / TUPSLOT carry the 8-byte form */
+			if (format != KDS_FORMAT_ROW && format != KDS_FORMAT_ROW_FLAT)
+				return false;
+			continue;
+		}
+		if (!(l == 1 || l == 2 || l == 4 || l == 8))
 			return false;
 	}
 	return true;
@@ -247,7 +346,7 @@ column_minmax(const strom_column_input &c, uint32_t nrows, kern_coldir *cd)
 extern "C" size_t
 strom_kds_required_length(int format, int ncols, const strom_column_input *cols, uint32_t nrows)
 {
-	if (!cols_valid(ncols, cols))
+	if (!cols_valid(ncols, cols, format))
 		return 0;
 	switch (format)
 	{
@@ -435,7 +534,23 @@ host_get_datum_tuple(const kern_colmeta *colmeta, const HeapTupleHeaderData *htu
 			continue;
 		}
 		if (colmeta[i].attlen <= 0)
-			return nullptr;			/* fixed-width only on this path */
+		{
+			/* varlena: padding only in front of a 4-byte header */
+			const unsigned char *p = (const unsigned char *)htup + off;
+			if (p[0] == 0)
+			{
+				off = STROM_TYPEALIGN(colmeta[i].attalign, off);
+				p = (const unsigned char *)htup + off;
+			}
+			if (i == colidx)
+				return (const char *)p;
+			if (p[0] == 0x01)
+				return nullptr;				/* external TOAST pointer: not on this path */
+			off += ((p[0] & 0x01) ? (size_t)((p[0] >> 1) & 0x7f)
+					: (size_t)((((uint32_t)p[0]) | ((uint32_t)p[1] << 8) |
+								((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24)) >> 2));
+			continue;
+		}
 		off = STROM_TYPEALIGN(colmeta[i].attalign, off);
 		if (i == colidx)
 			return (const char *)htup + off;
@@ -497,7 +612,16 @@ strom_kds_fetch(const kern_data_store *kds, uint32_t rowidx, uint32_t colidx, ui
 	if (!p)
 		return 1;
 	*value = 0;
-	memcpy(value, p, kds->colmeta[colidx].attlen);
+	int		attlen = kds->colmeta[colidx].attlen;
+	if (attlen > 0)
+		memcpy(value, p, attlen);
+	else
+	{
+		/* varlena: the first bytes of the datum (header included), at most 8 */
+		const unsigned char *v = (const unsigned char *)p;
+		size_t	len = ((v[0] & 0x01) ? (size_t)((v[0] >> 1) & 0x7f) : 4);
+		memcpy(value, p, len < 8 ? len : 8);
+	}
 	return 0;
 }
 

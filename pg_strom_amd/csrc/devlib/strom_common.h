@@ -260,7 +260,12 @@ STROM_DEVICE BASE strom_fetch(const void *addr)
 	return v;
 }
 
-#define STROM_DECLARE_VARREF(NAME)											\
+/*
+ * FROM_ADDR(errcode, addr, attlen) turns a located datum into the SQL value;
+ * fixed-width types copy attlen bytes, NUMERIC also decodes PostgreSQL's
+ * varlena form (strom_numeric.h).
+ */
+#define STROM_DECLARE_VARREF_EX(NAME, FROM_ADDR)							\
 	STROM_DEVICE pg_##NAME##_t												\
 	pg_##NAME##_vref(const kern_data_store *kds,							\
 					 const kern_data_store *ktoast,							\
@@ -274,10 +279,8 @@ STROM_DEVICE BASE strom_fetch(const void *addr)
 			result.value = 0;												\
 		}																	\
 		else																\
-		{																	\
-			result.isnull = false;											\
-			result.value = strom_fetch<pg_##NAME##_base_t>(addr);			\
-		}																	\
+			result = FROM_ADDR(errcode, (const char *)addr,					\
+							   kds->colmeta[colidx].attlen);				\
 		return result;														\
 	}																		\
 	STROM_DEVICE pg_##NAME##_t												\
@@ -299,15 +302,22 @@ STROM_DEVICE BASE strom_fetch(const void *addr)
 		}																	\
 		return result;														\
 	}																		\
-	/* attribute of a bare heap tuple (inner tuple of a hash entry) */		\
+	/* attribute of a bare heap tuple (row formats; inner tuple of a hash	\
+	 * entry) */															\
 	STROM_DEVICE pg_##NAME##_t												\
-	pg_##NAME##_tupref(const kern_colmeta *colmeta,							\
+	pg_##NAME##_tupref(cl_int *errcode, const kern_colmeta *colmeta,		\
 					   const HeapTupleHeaderData *htup, cl_uint colidx)		\
 	{																		\
 		pg_##NAME##_t	result;												\
 		const void	   *addr = kern_get_datum_tuple(colmeta, htup, colidx);	\
-		result.isnull = (addr == NULL);										\
-		result.value = (addr ? strom_fetch<pg_##NAME##_base_t>(addr) : 0);	\
+		if (!addr)															\
+		{																	\
+			result.isnull = true;											\
+			result.value = 0;												\
+		}																	\
+		else																\
+			result = FROM_ADDR(errcode, (const char *)addr,					\
+							   colmeta[colidx].attlen);						\
 		return result;														\
 	}																		\
 	STROM_DEVICE pg_##NAME##_t												\
@@ -328,6 +338,17 @@ STROM_DEVICE BASE strom_fetch(const void *addr)
 	{																		\
 		pg_bool_t r; r.isnull = false; r.value = !arg.isnull; return r;		\
 	}
+
+#define STROM_DECLARE_VARREF(NAME)											\
+	STROM_DEVICE pg_##NAME##_t												\
+	pg_##NAME##_from_addr(cl_int *errcode, const char *addr, cl_short attlen)	\
+	{																		\
+		pg_##NAME##_t	result;												\
+		result.isnull = false;												\
+		result.value = strom_fetch<pg_##NAME##_base_t>(addr);				\
+		return result;														\
+	}																		\
+	STROM_DECLARE_VARREF_EX(NAME, pg_##NAME##_from_addr)
 
 STROM_DECLARE_VARREF(bool)
 STROM_DECLARE_VARREF(int2)
@@ -535,19 +556,10 @@ strom_locate_tuple(const kern_data_store *kds, cl_int format, cl_uint rowidx)
 	return NULL;
 }
 
-template <typename PGT, typename BASE>
-STROM_DEVICE PGT
-strom_tuple_ref(const kern_data_store *kds, const HeapTupleHeaderData *htup, cl_uint colidx)
-{
-	const char *addr = ((htup && colidx < kds->ncols)
-						? kern_get_datum_tuple(kds->colmeta, htup, colidx) : NULL);
-	PGT		r;
-
-	r.isnull = (addr == NULL);
-	r.value = (addr ? strom_fetch<BASE>(addr) : (BASE)0);
-	return r;
-}
-#define STROM_TUPLE_REF(NAME, kds, htup, colidx)	\
-	strom_tuple_ref<pg_##NAME##_t, pg_##NAME##_base_t>(kds, htup, colidx)
+/* needs a 'cl_int errcode' in scope, like the pg_<T>_vref() calls it replaces */
+#define STROM_TUPLE_REF(NAME, kds, htup, colidx)									\
+	(((htup) != NULL && (cl_uint)(colidx) < (kds)->ncols)							\
+	 ? pg_##NAME##_tupref(&errcode, (kds)->colmeta, htup, colidx)					\
+	 : pg_##NAME##_make(0, true))
 
 #endif	/* STROM_COMMON_DEVICE_H */

@@ -32,6 +32,7 @@ ingest_to_column(const kern_data_store *__restrict__ src, kern_data_store *__res
 {
 	/* per work-group NULL flags (global stores to one address serialise) */
 	__shared__ cl_uint	s_hasnull[INGEST_MAXCOLS];
+	__shared__ cl_uint	s_failed;
 	/* column descriptors staged once: read per (row, column) otherwise, each
 	 * a dependent scalar load the compiler may not hoist over the stores */
 	__shared__ kern_colmeta	s_colmeta[INGEST_MAXCOLS];
@@ -42,6 +43,8 @@ ingest_to_column(const kern_data_store *__restrict__ src, kern_data_store *__res
 	cl_int		format = src->format;
 	cl_uint		lane = threadIdx.x & 63;
 
+	if (threadIdx.x == 0)
+		s_failed = 0;
 	for (cl_uint c = threadIdx.x; c < INGEST_MAXCOLS; c += blockDim.x)
 	{
 		s_hasnull[c] = 0;
@@ -98,6 +101,26 @@ ingest_to_column(const kern_data_store *__restrict__ src, kern_data_store *__res
 					offset += (cm.attlen > 0 ? (cl_uint)cm.attlen : strom_varsize_any(addr));
 				}
 			}
+			/* a varlena NUMERIC becomes the 8-byte device form (canonical
+			 * image); one that does not fit fails the whole conversion */
+			if (cm.attlen < 0 && type_oids != NULL && type_oids[c] == STROM_NUMERICOID)
+			{
+				if (valid)
+				{
+					cl_ulong   *out = (cl_ulong *)((char *)dst + s_values_off[c]) + row;
+					cl_ulong	image = 0;
+					if (addr)
+					{
+						cl_int		e = StromError_Success;
+						pg_numeric_t nv = pgfn_numeric_normalize(&e, strom_numeric_from_varlena(&e, addr));
+						if (nv.isnull)
+							s_failed = 1;
+						else
+							image = nv.value;
+					}
+					*out = image;
+				}
+			}
 			/* value */
 			cl_long		v = 0;
 			if (addr && cm.attlen > 0 && cm.attlen <= 8)
@@ -140,6 +163,8 @@ ingest_to_column(const kern_data_store *__restrict__ src, kern_data_store *__res
 		if (s_hasnull[c])
 			col_has_null[c] = 1;
 	}
+	if (threadIdx.x == 0 && s_failed)
+		col_has_null[ncols] = 1;			/* slot after the flags: conversion failed */
 }
 
 /*

@@ -17,9 +17,10 @@
  * PostgreSQL's arbitrary-precision numeric finishes the row
  * (casts 399-779, add/sub/mul 816-1027, compare 1035-1234).
  *
- * Not here yet: decoding PostgreSQL's varlena numeric from heap tuples
- * (166-307; chunks carry the 8-byte form, the reference's
- * "internal_format", datastore.c:355-363) and float -> numeric casts.
+ * Chunks carry either the 8-byte form (COLUMN, TUPSLOT, hash-join images:
+ * the reference's "internal_format", datastore.c:355-363) or, inside heap
+ * tuples, PostgreSQL's varlena numeric, decoded per row by
+ * strom_numeric_from_varlena (166-307).  Not here: float -> numeric casts.
  */
 #ifndef STROM_NUMERIC_DEVICE_H
 #define STROM_NUMERIC_DEVICE_H
@@ -37,7 +38,6 @@
 	 ((mant) & PG_NUMERIC_MANTISSA_MASK))
 
 STROM_DECLARE_SIMPLE_TYPE(numeric, cl_ulong)
-STROM_DECLARE_VARREF(numeric)
 
 STROM_DEVICE pg_numeric_t
 strom_numeric_recheck(cl_int *errcode)
@@ -128,6 +128,94 @@ strom_numeric_pack(cl_int *errcode, int expo, bool sign, cl_ulong mant)
 	v.value = PG_NUMERIC_SET(expo, sign, mant);
 	return v;
 }
+
+/*
+ * PostgreSQL's on-disk numeric (what a heap page holds; the reference decodes
+ * it per row, opencl_numeric.h:166-307): a varlena whose payload is either
+ *   short:  uint16 n_header                    ((n_header & 0xC000) == 0x8000)
+ *           sign 0x2000, dscale (0x1F80 >> 7), weight sign 0x0040, weight 0x003F
+ *   long :  uint16 n_sign_dscale (sign 0xC000: 0 +, 0x4000 -, 0xC000 NaN),
+ *           int16 n_weight
+ * followed by base-10000 digits, most significant first:
+ *   value = sum digit[i] * 10000^(weight - i).
+ * Compressed / external varlenas, NaN and values beyond the 64-bit form go
+ * back to the CPU.
+ */
+STROM_DEVICE pg_numeric_t
+strom_numeric_from_varlena(cl_int *errcode, const char *addr)
+{
+	const cl_uchar *p = (const cl_uchar *)addr;
+	cl_uint		len;
+
+	if (p[0] == 0x01)
+		return strom_numeric_recheck(errcode);			/* external TOAST pointer */
+	if (p[0] & 0x01)
+	{
+		len = (p[0] >> 1) & 0x7f;						/* 1-byte header, total size */
+		if (len < 1 + 2)
+			return strom_numeric_recheck(errcode);
+		len -= 1;
+		p += 1;
+	}
+	else
+	{
+		cl_uint	w = (cl_uint)p[0] | ((cl_uint)p[1] << 8) | ((cl_uint)p[2] << 16) | ((cl_uint)p[3] << 24);
+		if ((w & 0x03) != 0 || (w >> 2) < 4 + 2)
+			return strom_numeric_recheck(errcode);		/* compressed, or not a numeric */
+		len = (w >> 2) - 4;
+		p += 4;
+	}
+	cl_uint		n_header = (cl_uint)p[0] | ((cl_uint)p[1] << 8);
+	bool		sign;
+	int			weight;
+	cl_uint		ndigits;
+
+	if ((n_header & 0xC000) == 0xC000)
+		return strom_numeric_recheck(errcode);			/* NaN */
+	if ((n_header & 0xC000) == 0x8000)
+	{
+		sign = (n_header & 0x2000) != 0;
+		weight = (int)(n_header & 0x003F);
+		if (n_header & 0x0040)
+			weight |= ~0x003F;
+		p += 2;
+		ndigits = (len - 2) / 2;
+	}
+	else
+	{
+		if (len < 4)
+			return strom_numeric_recheck(errcode);
+		sign = (n_header & 0xC000) == 0x4000;
+		weight = (int)(cl_short)((cl_uint)p[2] | ((cl_uint)p[3] << 8));
+		p += 4;
+		ndigits = (len - 4) / 2;
+	}
+	cl_ulong	mant = 0;
+	for (cl_uint i = 0; i < ndigits; i++)
+	{
+		cl_uint	d = (cl_uint)p[2 * i] | ((cl_uint)p[2 * i + 1] << 8);
+		if (d > 9999 || mant > (0xffffffffffffffffUL - 9999UL) / 10000UL)
+			return strom_numeric_recheck(errcode);
+		mant = mant * 10000UL + d;
+	}
+	return strom_numeric_pack(errcode, (weight - (int)ndigits + 1) * 4, sign, mant);
+}
+
+/* a located numeric datum: the 8-byte device form (attlen 8, what COLUMN /
+ * TUPSLOT chunks and hash-join images carry) or the heap's varlena form */
+STROM_DEVICE pg_numeric_t
+pg_numeric_from_addr(cl_int *errcode, const char *addr, cl_short attlen)
+{
+	if (attlen > 0)
+	{
+		pg_numeric_t v;
+		v.isnull = false;
+		v.value = strom_fetch<cl_ulong>(addr);
+		return v;
+	}
+	return strom_numeric_from_varlena(errcode, addr);
+}
+STROM_DECLARE_VARREF_EX(numeric, pg_numeric_from_addr)
 
 /* canonical image (what chunks carry): needed where the datum image itself
  * is consumed -- hashing, stores */

@@ -21,6 +21,8 @@ namespace {
 const char *ingest_source =
 	"#include \"strom_kds.h\"\n"
 	"#include \"strom_common.h\"\n"
+	"#include \"strom_mathlib.h\"\n"
+	"#include \"strom_numeric.h\"\n"
 	"#include \"strom_ingest.h\"\n";
 
 }	/* namespace */
@@ -88,9 +90,18 @@ strom_dstore_to_column(strom_dstore *src, const int32_t *type_oids, int ntypes,
 	for (int i = 0; i < ncols; i++)
 	{
 		int attlen = head->colmeta[i].attlen;
+		if (attlen == -1 && type_oids && type_oids[i] == STROM_NUMERICOID)
+		{
+			/* PostgreSQL's varlena numeric -> the 8-byte by-value device form
+			 * (what the reference does to colmeta, datastore.c:355-363) */
+			attlen = 8;
+			head->colmeta[i].attlen = 8;
+			head->colmeta[i].attalign = 8;
+			head->colmeta[i].attbyval = 1;
+		}
 		if (!(attlen == 1 || attlen == 2 || attlen == 4 || attlen == 8))
 		{
-			*p_errcode = StromError_DataStoreCorruption;	/* varlena columns: host path */
+			*p_errcode = StromError_DataStoreCorruption;	/* other varlena columns: host path */
 			return nullptr;
 		}
 		cd[i].values_off = (cl_uint)off;
@@ -116,12 +127,12 @@ strom_dstore_to_column(strom_dstore *src, const int32_t *type_oids, int ntypes,
 	head->maxblocks = 0;
 	head->format = KDS_FORMAT_COLUMN;
 
-	size_t	aux_len = sizeof(cl_int) * 2 * (size_t)ncols;
+	size_t	aux_len = sizeof(cl_int) * (2 * (size_t)ncols + 1);	/* type oids, NULL flags, failure flag */
 	char   *d_dst = (char *)dev->pool.alloc(off);
 	char   *d_aux = (char *)dev->pool.alloc(aux_len);
 	hipEvent_t ev0 = nullptr, ev1 = nullptr;
 	strom_dstore *result = nullptr;
-	std::vector<cl_int> aux(2 * (size_t)ncols, 0);
+	std::vector<cl_int> aux(2 * (size_t)ncols + 1, 0);
 	if (type_oids)
 		memcpy(aux.data(), type_oids, sizeof(cl_int) * ncols);
 	do {
@@ -170,13 +181,25 @@ strom_dstore_to_column(strom_dstore *src, const int32_t *type_oids, int ntypes,
 		}
 		(void)hipEventRecord(ev1, stream);
 		result = new strom_dstore{d_dst, off, src->dindex, true, {}};
+		cl_int	failed = 0;
 		if (hipMemcpyAsync(&result->head, d_dst, offsetof(kern_data_store, colmeta),
+						   hipMemcpyDeviceToHost, stream) != hipSuccess ||
+			hipMemcpyAsync(&failed, d_aux + sizeof(cl_int) * 2 * (size_t)ncols, sizeof(cl_int),
 						   hipMemcpyDeviceToHost, stream) != hipSuccess ||
 			hipStreamSynchronize(stream) != hipSuccess)
 		{
 			delete result;
 			result = nullptr;
 			*p_errcode = StromError_HipInternal;
+			break;
+		}
+		if (failed)
+		{
+			/* a numeric beyond the 64-bit device form: this chunk stays in
+			 * its row format (the kernels re-check such rows one by one) */
+			delete result;
+			result = nullptr;
+			*p_errcode = StromError_CpuReCheck;
 			break;
 		}
 		if (p_kern_ns)

@@ -35,6 +35,9 @@ SQL_TYPES = {
     "time": (1083, 8, np.int64),
     "timestamp": (1114, 8, np.int64),
     "numeric": (1700, 8, np.uint64),   # 64-bit device form
+    # the same values laid out as PostgreSQL's varlena numeric inside heap
+    # tuples (ROW / ROW_FLAT only); 'values' are the 64-bit images
+    "numeric_varlena": (1700, -1, np.uint64),
     "char1": (1042, 1, np.int8),
 }
 
@@ -75,8 +78,8 @@ def _column_inputs(columns):
     for i, c in enumerate(columns):
         arr[i].type_oid = c.type_oid
         arr[i].attlen = c.attlen
-        arr[i].attalign = c.attlen
-        arr[i].attbyval = 1
+        arr[i].attalign = c.attlen if c.attlen > 0 else 4
+        arr[i].attbyval = 1 if c.attlen > 0 else 0
         arr[i].values = c.values.ctypes.data
         arr[i].isnull = c.isnull.ctypes.data if c.isnull is not None else None
     return arr

@@ -26,8 +26,8 @@ def main():
     kind, spec = sys.argv[1], sys.argv[2]
     if kind == "ingest":
         class _S(object):
-            source = ('#include "strom_kds.h"\n#include "strom_common.h"\n'
-                      '#include "strom_ingest.h"\n')
+            source = ('#include "strom_kds.h"\n#include "strom_common.h"\n#include "strom_mathlib.h"\n'
+                      '#include "strom_numeric.h"\n#include "strom_ingest.h"\n')
             extra_flags = 0
         cg = _S()
     elif kind == "gpuscan":

@@ -185,3 +185,14 @@ def layout():
     out = oracle_layout()
     load().oracle_get_layout(ctypes.byref(out))
     return {n: getattr(out, n) for n, _ in oracle_layout._fields_}
+
+
+def numeric_from_varlena(raw):
+    """PostgreSQL varlena numeric bytes -> 64-bit image, or None when it
+    cannot be carried (oracle_numeric_from_varlena)"""
+    lib = load()
+    lib.oracle_numeric_from_varlena.restype = ctypes.c_int
+    lib.oracle_numeric_from_varlena.argtypes = [ctypes.c_char_p, ctypes.POINTER(ctypes.c_uint64)]
+    out = ctypes.c_uint64(0)
+    ok = lib.oracle_numeric_from_varlena(bytes(raw) + b"\0" * 8, ctypes.byref(out))
+    return int(out.value) if ok else None

@@ -137,3 +137,85 @@ def test_typmod_scale_is_a_codegen_hint_only():
     assert "pg_fixed_lit(" not in source_of(plain)
     with pytest.raises(ValueError):
         codegen_gpupreagg("(gpupreagg (psum (var 1 int4 2)))")
+
+
+def pg_numeric_varlena(d):
+    """Decimal -> the bytes PostgreSQL 9.4 stores in a heap tuple for a
+    numeric (utils/adt/numeric.c: base-10000 digits, short header when weight
+    and dscale fit, 1-byte varlena header for these sizes).  Written from the
+    format description, independently of the builder under test."""
+    import struct
+    sign, digs, exp = d.as_tuple()
+    dscale = max(0, -exp)
+    if not any(digs):
+        groups, weight, sign = [], 0, 0
+    else:
+        s = "".join(map(str, digs))
+        if exp >= 0:
+            intpart, frac = s + "0" * exp, ""
+        else:
+            s = s.rjust(-exp + 1, "0")
+            intpart, frac = s[:exp], s[exp:]
+        intpart = intpart.lstrip("0")
+        pad = (-len(intpart)) % 4
+        intpart = "0" * pad + intpart
+        frac = frac + "0" * ((-len(frac)) % 4)
+        groups = [int(intpart[i:i + 4]) for i in range(0, len(intpart), 4)]
+        weight = len(groups) - 1
+        groups += [int(frac[i:i + 4]) for i in range(0, len(frac), 4)]
+        while groups and groups[0] == 0:          # leading zero digits
+            groups.pop(0)
+            weight -= 1
+        while groups and groups[-1] == 0:         # trailing zero digits
+            groups.pop()
+    if -64 <= weight <= 63 and dscale <= 63:
+        body = struct.pack("<H", 0x8000 | (0x2000 if sign else 0) | (dscale << 7) |
+                           (0x0040 if weight < 0 else 0) | (weight & 0x3F))
+    else:
+        body = struct.pack("<Hh", (0x4000 if sign else 0) | dscale, weight)
+    body += b"".join(struct.pack("<H", g) for g in groups)
+    total = 1 + len(body)
+    assert total <= 126
+    return bytes([(total << 1) | 1]) + body
+
+
+def test_varlena_numeric_decode_and_heap_layout():
+    """a21: PostgreSQL's on-disk numeric -> the 64-bit form (oracle side) and the
+    host builder's heap tuples carry exactly those bytes"""
+    cases = [Decimal(x) for x in ("0", "1", "-1", "0.5", "12.5", "-12.50", "0.0001", "10000", "9999.9999",
+                                  "123456789.123456", "1E+20", "-1E-14", "100000000", "0.00000001",
+                                  "99999999999999999", "-0.100", "5000", "1E+30", "1E-32")]
+    for d in cases:
+        raw = pg_numeric_varlena(d)
+        assert oracle.numeric_from_varlena(raw) == kds.numeric_encode(d), d
+    # long header (dscale beyond the short format's 6 bits is not reachable with 57-bit
+    # mantissas, a weight beyond 63 is not either): decode a hand-made long datum
+    import struct
+    body = struct.pack("<Hh", 0x4000 | 2, 1) + struct.pack("<HHH", 12, 3456, 7800)   # -123456.78
+    raw = bytes([((1 + len(body)) << 1) | 1]) + body
+    assert oracle.numeric_from_varlena(raw) == kds.numeric_encode(Decimal("-123456.78"))
+    # 4-byte varlena header, NaN, too many digits
+    raw4 = struct.pack("<I", (4 + 4) << 2) + struct.pack("<HH", 0x8000, 7)
+    assert oracle.numeric_from_varlena(raw4) == kds.numeric_encode(Decimal(7))
+    assert oracle.numeric_from_varlena(bytes([(3 << 1) | 1]) + struct.pack("<H", 0xC000)) is None
+    big = pg_numeric_varlena(Decimal("123456789012345678901234"))
+    assert oracle.numeric_from_varlena(big) is None
+    # the builder lays the same bytes into heap tuples: a scan through the oracle sees the values
+    rng = np.random.default_rng(3)
+    vals = [Decimal(int(rng.integers(-10**9, 10**9))).scaleb(-int(rng.integers(0, 7))) for _ in range(3000)]
+    imgs = np.array([kds.numeric_encode(v) for v in vals], dtype=np.uint64)
+    isnull = rng.random(3000) < 0.05
+    a = np.arange(3000, dtype=np.int32)
+    for fmt in ("row", "row_flat"):
+        buf = kds.build_kds(fmt, [kds.Column("int4", a), kds.Column("numeric_varlena", imgs, isnull),
+                                  kds.Column("int4", a * 2)])
+        rc, res = oracle.gpuscan("(and (numeric_gt (var 2 numeric) (const numeric 12.5))"
+                                 " (int4eq (var 3 int4) (int4mul (var 1 int4) (const int4 2))))", buf)
+        assert rc == 0
+        want = [i + 1 for i in range(3000) if not isnull[i] and vals[i] > Decimal("12.5")]
+        assert sorted(res) == want
+        rc, v, isn = oracle.gpupreagg("(gpupreagg (nrows) (psum (var 2 numeric) 6))", buf, 2)
+        assert rc == 0
+        assert Decimal(int(v[0, 1].view(np.int64))).scaleb(-6) == sum(x for x, n in zip(vals, isnull) if not n)
+    with pytest.raises(ValueError):
+        kds.build_kds("column", [kds.Column("numeric_varlena", imgs)])      # heap tuples only
