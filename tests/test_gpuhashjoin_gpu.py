@@ -205,3 +205,25 @@ def test_general_kernel_tile_and_slice_boundaries(nfact, fanout):
     assert info[0]["unique"] == (fanout == 1)
     want = int(np.count_nonzero((fk < ndim_keys) & ~fkn)) * fanout
     assert res.nitems == want
+
+
+@pytest.mark.parametrize("ofmt", ["row", "row_flat"])
+def test_numeric_key_from_varlena_outer(ofmt):
+    """outer key: PostgreSQL's varlena numeric inside heap tuples (decoded and
+    normalised per row); inner key: the 8-byte form -- the index hashes images"""
+    from decimal import Decimal
+    rng = np.random.default_rng(77)
+    nd, nf = 500, 20011
+    dim_vals = [Decimal(int(x)).scaleb(-2) for x in rng.permutation(5000)[:nd]]
+    dim_img = np.array([kds.numeric_encode(v) for v in dim_vals], dtype=np.uint64)
+    inner = kds.build_kds("row", [kds.Column("numeric", dim_img), kds.Column("int4", np.arange(nd, dtype=np.int32))])
+    # the same values written with trailing zeros / other scales on the outer side
+    pick = rng.integers(0, 5000, nf)
+    fact_img = np.array([kds.numeric_encode(Decimal(int(x)).scaleb(-2)) for x in pick], dtype=np.uint64)
+    fn = rng.random(nf) < 0.02
+    outer = kds.build_kds(ofmt, [kds.Column("numeric_varlena", fact_img, fn),
+                                 kds.Column("int4", np.arange(nf, dtype=np.int32))])
+    spec = "(gpuhashjoin (rel (hashkey (var 1 numeric) 1 numeric)))"
+    res, info = run_and_compare(spec, outer, [inner], [[1]])
+    present = set(int(round(float(v) * 100)) for v in dim_vals)
+    assert res.nitems == sum(1 for x, isn in zip(pick, fn) if not isn and int(x) in present)
