@@ -261,6 +261,27 @@ int			strom_gpupreagg_census(strom_gpupreagg *sess,
 								   const kern_row_map *krowmap,
 								   uint32_t *bitmap_out, size_t nwords);
 int			strom_gpupreagg_compact(strom_gpupreagg *sess, const uint32_t *bitmap, size_t nwords);
+/*
+ * hashed GROUP BY: keys of ANY device type (float4/float8/numeric as well)
+ * and any spread.  The reference sorts row indexes by gpupreagg_keycomp and
+ * reduces runs of equal keys (opencl_gpupreagg.h:620-856, bitonic steps
+ * driven from gpupreagg.c:3955-4120); here the groups live in an
+ * open-addressing table in HBM keyed by the keys' canonical 64-bit images
+ * (-0 = +0, one NaN, stripped numerics), grown by the library as the group
+ * count needs.  A session made by this call takes the same
+ * strom_submit_gpupreagg*() / strom_gpupreagg_fetch() / _reset() / _release()
+ * calls; the dense-table calls (table_length, bind_table, table_devptr,
+ * table_layout, census, compact) answer BadRequest / 0 for it, and
+ * strom_gpupreagg_num_groups() returns the groups seen so far.  Sessions of
+ * several ranks are merged by concatenating their partial rows: the final
+ * aggregate adds them up (pg_strom--1.0.sql:247-401).
+ * ngroups_hint sizes the first table (0 = default).
+ */
+strom_gpupreagg *strom_gpupreagg_create_hashed(strom_devprog_key key,
+											   const strom_preagg_target *targets, int ntargets,
+											   const kern_parambuf *kparams,
+											   uint32_t ngroups_hint,
+											   int dindex, int *p_errcode);
 void		strom_gpupreagg_reset(strom_gpupreagg *sess);
 void		strom_gpupreagg_release(strom_gpupreagg *sess);
 

@@ -1788,7 +1788,25 @@ oracle_gpupreagg(const char *spec_text,
 			oracle_value v = oracle_expr_eval(sp.targets[key_of[k]].exprs[0], kds, row,
 											  ext_values, ext_isnull, n_ext, &errcode);
 			kn[k] = (uint8_t)v.isnull;
-			kv[k] = v.isnull ? 0 : (type_is_float(v.type_oid) ? (int64_t)v.v.u : v.v.i);
+			/* group identity is the key's CANONICAL image (what the type's own
+			 * comparator calls equal, gpupreagg_keycomp opencl_gpupreagg.h:236):
+			 * float keys as float8 with -0 = +0 and one NaN, numerics stripped */
+			if (v.isnull)
+				kv[k] = 0;
+			else if (type_is_float(v.type_oid))
+			{
+				double d = float_of(v);
+				if (isnan(d)) kv[k] = 0x7ff8000000000000LL;
+				else { if (d == 0.0) d = 0.0; memcpy(&kv[k], &d, 8); }
+			}
+			else if (v.type_oid == STROM_NUMERICOID)
+			{
+				uint64_t c = v.v.u;
+				(void)num_pack(NUM_EXPO(c), NUM_SIGN(c), NUM_MANT(c), &c);
+				kv[k] = (int64_t)c;
+			}
+			else
+				kv[k] = v.v.i;
 		}
 		for (a = 0; a < naggs; a++)
 		{
@@ -1939,7 +1957,7 @@ oracle_gpupreagg(const char *spec_text,
 				{
 					size_t o = (size_t)g * sp.ntargets + key_of[k];
 					out_isnull[o] = groups[g].keynull[k];
-					out_values[o] = (uint64_t)groups[g].keyval[k];
+					out_values[o] = (uint64_t)groups[g].keyval[k];	/* float keys: float8 image, like float partials */
 				}
 				for (a = 0; a < naggs; a++)
 				{

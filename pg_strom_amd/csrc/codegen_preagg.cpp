@@ -86,6 +86,9 @@ strom_codegen_gpupreagg(const char *spec, strom_codegen_result *out,
 				std::string e;
 				tg.kind = STROM_PREAGG_KEY;
 				tg.type_oid = codegen_expression(t.items[1], ctx, e);
+				/* a numeric key groups by its canonical image (hashed GROUP BY) */
+				if (tg.type_oid == STROM_NUMERICOID)
+					e = "pgfn_numeric_normalize(errcode, " + e + ")";
 				tg.body = "  return " + e + ";\n";
 			}
 			else if (head == "nrows")

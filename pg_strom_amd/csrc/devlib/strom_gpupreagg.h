@@ -1386,6 +1386,389 @@ gpupreagg_reg1_column(kern_gpupreagg *kgpreagg, const kern_data_store *kds,
 }
 
 /* ====================================================================== *
+ * hashed GROUP BY: any key type, any key range
+ *
+ * The dense-id kernels need integer-like keys whose ranges multiply to at
+ * most 2^26 ids.  Everything else -- float8 / numeric keys, sparse int8
+ * keys -- goes through an open-addressing table in HBM keyed by the keys'
+ * canonical 64-bit images (the reference sorts row indexes by
+ * gpupreagg_keycomp instead, opencl_gpupreagg.h:620-856):
+ *
+ *   head                       gpupreagg_hash_head
+ *   state[C]      u32          0 empty, 1 being claimed, 2 ready
+ *   knull[C]      u32          bit k: key k is NULL
+ *   keys[C*NKEYS] u64          key images, slot-major
+ *   flags[C]      u32          bit 0 seen, bit 1+a aggregate a has a value
+ *   vals_a[C]     8 bytes      per aggregate (NROWS widened to i64)
+ *
+ * A chunk is folded in two launches: gpupreagg_hash_check evaluates every
+ * row for errors only; gpupreagg_hash_fold runs if the chunk is clean, so a
+ * CpuReCheck still sends the WHOLE chunk back untouched (gpupreagg.c:2746-2750).
+ * Accumulation is by global atomics: this path is for generality, the
+ * dense kernels are the fast one.
+ * ====================================================================== */
+struct gpupreagg_hash_head {
+	cl_uint		capacity;			/* power of two */
+	cl_uint		nkeys;
+	cl_uint		ngroups;			/* slots claimed so far */
+	cl_uint		overflow;			/* set when a probe found no free slot */
+	cl_ulong	off_state, off_knull, off_keys, off_flags;
+	cl_ulong	off_vals[GPUPREAGG_NAGGS + 1];
+};
+
+STROM_DEVICE cl_ulong strom_key_image(cl_char v)	{ return (cl_ulong)(cl_long)v; }
+STROM_DEVICE cl_ulong strom_key_image(cl_short v)	{ return (cl_ulong)(cl_long)v; }
+STROM_DEVICE cl_ulong strom_key_image(cl_int v)		{ return (cl_ulong)(cl_long)v; }
+STROM_DEVICE cl_ulong strom_key_image(cl_long v)	{ return (cl_ulong)v; }
+STROM_DEVICE cl_ulong strom_key_image(cl_ulong v)	{ return v; }	/* numeric: canonical image */
+STROM_DEVICE cl_ulong strom_key_image(cl_double v)
+{
+	if (__builtin_isnan(v))
+		return 0x7ff8000000000000UL;		/* all NaNs are one group, as in PostgreSQL */
+	if (v == 0.0)
+		v = 0.0;							/* -0 = +0 */
+	return (cl_ulong)__double_as_longlong(v);
+}
+STROM_DEVICE cl_ulong strom_key_image(cl_float v)	{ return strom_key_image((cl_double)v); }
+
+STROM_DEVICE cl_uint
+gpupreagg_hash_of(const cl_ulong *kimg, cl_uint knull)
+{
+	cl_ulong	h = 0x9e3779b97f4a7c15UL;
+	for (int k = 0; k < GPUPREAGG_NKEYS; k++)
+	{
+		h = (h ^ kimg[k]) * 0xff51afd7ed558ccdUL;
+		h ^= h >> 33;
+	}
+	h = (h ^ knull) * 0xc4ceb9fe1a85ec53UL;
+	h ^= h >> 29;
+	return (cl_uint)h;
+}
+
+/*
+ * find the slot of a key, or claim an empty one.  One loop, no inner wait:
+ * a lane that meets a slot somebody is still filling (state 1) just goes
+ * round again, so the claimer -- possibly a lane of the SAME wave, whose
+ * divergent block runs before or after ours but within this iteration --
+ * always gets to publish.  Returns the slot, or ~0u when the table is full.
+ */
+template <bool MATCH>
+STROM_DEVICE cl_uint
+gpupreagg_hash_slot(gpupreagg_hash_head *head, cl_uint *h_state, cl_uint *h_knull, cl_ulong *h_keys,
+					const cl_ulong *kimg, cl_uint knull)
+{
+	cl_uint		mask = head->capacity - 1;
+	cl_uint		slot = gpupreagg_hash_of(kimg, knull) & mask;
+	cl_uint		probes = 0;
+	cl_uint		result = ~0u;
+	bool		done = false;
+
+	for (cl_uint turns = 0; !done && turns < (1u << 28); turns++)
+	{
+		cl_uint	st = __hip_atomic_load(&h_state[slot], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+
+		if (st == 0)
+		{
+			cl_uint	expect = 0;
+			if (__hip_atomic_compare_exchange_strong(&h_state[slot], &expect, 1u,
+													 __ATOMIC_ACQUIRE, __ATOMIC_ACQUIRE,
+													 __HIP_MEMORY_SCOPE_AGENT))
+			{
+				for (int k = 0; k < GPUPREAGG_NKEYS; k++)
+					h_keys[(size_t)slot * GPUPREAGG_NKEYS + k] = kimg[k];
+				h_knull[slot] = knull;
+				__hip_atomic_store(&h_state[slot], 2u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+				atomicAdd(&head->ngroups, 1u);
+				result = slot;
+				done = true;
+			}
+			/* lost the race: look at the same slot again next turn */
+		}
+		else if (st == 2)
+		{
+			bool	same = (MATCH && h_knull[slot] == knull);
+			if (MATCH)
+			{
+				for (int k = 0; k < GPUPREAGG_NKEYS; k++)
+					same = same && (h_keys[(size_t)slot * GPUPREAGG_NKEYS + k] == kimg[k]);
+			}
+			if (same)
+			{
+				result = slot;
+				done = true;
+			}
+			else if (++probes > mask)
+				done = true;			/* every slot taken by other keys */
+			else
+				slot = (slot + 1) & mask;
+		}
+		else
+			__builtin_amdgcn_s_sleep(1);	/* being filled: next turn */
+	}
+	return result;
+}
+
+template <bool IS_COLUMN, bool FOLD>
+__device__ __forceinline__ void
+gpupreagg_hash_body(kern_gpupreagg *kgpreagg,
+					const kern_data_store *kds,
+					const kern_data_store *ktoast,
+					const kern_row_map *krowmap,
+					char *htab, cl_uint row_lo, cl_uint row_hi)
+{
+	const kern_parambuf *kparams = KERN_GPUPREAGG_PARAMBUF(kgpreagg);
+	gpupreagg_hash_head *head = (gpupreagg_hash_head *)htab;
+	bool		use_map = (krowmap != NULL && krowmap->nvalids >= 0);
+	cl_uint		nrows = (use_map ? (cl_uint)krowmap->nvalids : kds->nitems);
+	cl_uint	   *h_state = (cl_uint *)(htab + head->off_state);
+	cl_uint	   *h_knull = (cl_uint *)(htab + head->off_knull);
+	cl_ulong   *h_keys = (cl_ulong *)(htab + head->off_keys);
+	cl_uint	   *h_flags = (cl_uint *)(htab + head->off_flags);
+	cl_int		chunk_status = StromError_Success;
+	cl_int		param_error = StromError_Success;
+	strom_kparams KP;
+
+	if (FOLD && kgpreagg->status != StromError_Success)
+		return;							/* the check pass found a reason to send the chunk back */
+	gpupreagg_load_kparams(KP, kparams, &param_error);
+	const bool	is_column = IS_COLUMN;
+	const cl_int chunk_format = kds->format;
+	const bool	row_family = (chunk_format == KDS_FORMAT_ROW || chunk_format == KDS_FORMAT_ROW_FLAT);
+	const kern_coldir *coldir_g = KERN_DATA_STORE_COLDIR(kds);
+#define X(attno,colidx,NAME)													\
+	const char *col_##attno = (is_column ? (const char *)kds + coldir_g[colidx].values_off : NULL);	\
+	const cl_uint *nul_##attno = ((is_column && coldir_g[colidx].nulls_off != 0)	\
+		? (const cl_uint *)((const char *)kds + coldir_g[colidx].nulls_off) : NULL);
+	STROM_KVAR_LIST(X)
+#undef X
+	if (row_hi < nrows)
+		nrows = row_hi;					/* this launch folds rows [row_lo, row_hi) */
+	for (size_t r = (size_t)row_lo + (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+		 r < nrows;
+		 r += (size_t)gridDim.x * blockDim.x)
+	{
+		cl_uint		kds_index = (use_map ? (cl_uint)krowmap->rindex[r] : (cl_uint)r);
+		strom_kvars	KV;
+		cl_int		errcode = param_error;
+		const HeapTupleHeaderData *htup = NULL;
+		if (!is_column && row_family)
+			htup = strom_locate_tuple(kds, chunk_format, kds_index);
+#define X(attno,colidx,NAME)													\
+		KV.KVAR_##attno = (is_column											\
+			? STROM_COLUMN_REF(NAME, col_##attno, nul_##attno, kds_index)		\
+			: row_family ? STROM_TUPLE_REF(NAME, kds, htup, colidx)				\
+			: pg_##NAME##_vref(kds, ktoast, &errcode, colidx, kds_index));
+		STROM_KVAR_LIST(X)
+#undef X
+		KV.__dummy = 0;
+		cl_ulong	kimg[GPUPREAGG_NKEYS + 1];
+		cl_uint		knull = 0;
+		pg_bool_t	rc = gpupreagg_qual_eval(&errcode, KP, KV);
+		if (errcode == StromError_Success && !EVAL(rc))
+			continue;
+#define X(kidx,resno,NAME)															\
+		{																			\
+			pg_##NAME##_t kv = gpupreagg_key_##kidx(&errcode, KP, KV);				\
+			kimg[kidx] = (kv.isnull ? 0UL : strom_key_image(kv.value));				\
+			knull |= (kv.isnull ? (1u << kidx) : 0u);								\
+		}
+		GPUPREAGG_KEY_LIST(X)
+#undef X
+#define X(aidx,resno,OP,NAME)														\
+		pg_##NAME##_t av_##aidx = gpupreagg_agg_##aidx(&errcode, KP, KV);
+		GPUPREAGG_AGG_LIST(X)
+#undef X
+		if (errcode != StromError_Success)
+		{
+			STROM_SET_ERROR(&chunk_status, errcode);
+			continue;
+		}
+#define X(aidx,resno,OP,NAME)														\
+		if (GPUPREAGG_OP_##OP == GPUPREAGG_OP_PSUM &&								\
+			!gpupreagg_is_float<pg_##NAME##_base_t>::value)							\
+			STROM_SET_RECHECK_IF(&chunk_status, !av_##aidx.isnull &					\
+								 gpupreagg_int8_near_overflow((cl_long)av_##aidx.value));
+		GPUPREAGG_AGG_LIST(X)
+#undef X
+		if (!FOLD)
+			continue;
+		/* find or claim the group's slot */
+		cl_uint		slot = gpupreagg_hash_slot<true>(head, h_state, h_knull, h_keys, kimg, knull);
+		if (slot == ~0u)
+		{
+			head->overflow = 1;
+			continue;
+		}
+		cl_uint		need = GPUPREAGG_FLAG_SEEN;
+#define X(aidx,resno,OP,NAME)														\
+		{																			\
+			typedef pg_##NAME##_base_t base_t;										\
+			cl_ulong   *vals = (cl_ulong *)(htab + head->off_vals[aidx]);			\
+			bool		has = !av_##aidx.isnull;									\
+			if (GPUPREAGG_OP_##OP == GPUPREAGG_OP_NROWS)							\
+			{																		\
+				if (has && av_##aidx.value != 0)									\
+					atomicAdd((unsigned long long *)&vals[slot],					\
+							  (unsigned long long)(cl_uint)av_##aidx.value);		\
+			}																		\
+			else if (has)															\
+			{																		\
+				need |= (2u << aidx);												\
+				if (gpupreagg_is_float<base_t>::value)								\
+				{																	\
+					if (GPUPREAGG_OP_##OP == GPUPREAGG_OP_PSUM)						\
+						atomicAdd((cl_double *)&vals[slot], (cl_double)av_##aidx.value);	\
+					else if (GPUPREAGG_OP_##OP == GPUPREAGG_OP_PMIN)				\
+						atomicMin((unsigned long long *)&vals[slot],				\
+								  (unsigned long long)gpupreagg_f64_ordered((cl_double)av_##aidx.value));	\
+					else															\
+						atomicMax((unsigned long long *)&vals[slot],				\
+								  (unsigned long long)gpupreagg_f64_ordered((cl_double)av_##aidx.value));	\
+				}																	\
+				else if (GPUPREAGG_OP_##OP == GPUPREAGG_OP_PSUM)					\
+					atomicAdd((unsigned long long *)&vals[slot],					\
+							  (unsigned long long)(cl_long)av_##aidx.value);		\
+				else if (GPUPREAGG_OP_##OP == GPUPREAGG_OP_PMIN)					\
+					atomicMin((long long *)&vals[slot], (long long)av_##aidx.value);	\
+				else																\
+					atomicMax((long long *)&vals[slot], (long long)av_##aidx.value);	\
+			}																		\
+		}
+		GPUPREAGG_AGG_LIST(X)
+#undef X
+		if ((h_flags[slot] & need) != need)
+			atomicOr(&h_flags[slot], need);
+	}
+	gpupreagg_writeback_status(&kgpreagg->status, chunk_status);
+}
+
+extern "C" __global__ void
+__launch_bounds__(256)
+gpupreagg_hash_check(kern_gpupreagg *kgpreagg, const kern_data_store *kds,
+					 const kern_data_store *ktoast, const kern_row_map *krowmap, char *htab,
+					 cl_uint row_lo, cl_uint row_hi)
+{
+	if (kds->format == KDS_FORMAT_COLUMN)
+		gpupreagg_hash_body<true, false>(kgpreagg, kds, ktoast, krowmap, htab, row_lo, row_hi);
+	else
+		gpupreagg_hash_body<false, false>(kgpreagg, kds, ktoast, krowmap, htab, row_lo, row_hi);
+}
+
+extern "C" __global__ void
+__launch_bounds__(256)
+gpupreagg_hash_fold(kern_gpupreagg *kgpreagg, const kern_data_store *kds,
+					const kern_data_store *ktoast, const kern_row_map *krowmap, char *htab,
+					cl_uint row_lo, cl_uint row_hi)
+{
+	if (kds->format == KDS_FORMAT_COLUMN)
+		gpupreagg_hash_body<true, true>(kgpreagg, kds, ktoast, krowmap, htab, row_lo, row_hi);
+	else
+		gpupreagg_hash_body<false, true>(kgpreagg, kds, ktoast, krowmap, htab, row_lo, row_hi);
+}
+
+/* min / max accumulators start from their identities (sums from the zeroed table) */
+extern "C" __global__ void
+__launch_bounds__(256)
+gpupreagg_hash_init(char *htab)
+{
+	gpupreagg_hash_head *head = (gpupreagg_hash_head *)htab;
+	cl_uint		C = head->capacity;
+#define X(aidx,resno,OP,NAME)															\
+	if (GPUPREAGG_OP_##OP == GPUPREAGG_OP_PMIN || GPUPREAGG_OP_##OP == GPUPREAGG_OP_PMAX)	\
+	{																					\
+		cl_ulong   *vals = (cl_ulong *)(htab + head->off_vals[aidx]);					\
+		for (cl_uint i = blockIdx.x * blockDim.x + threadIdx.x; i < C; i += gridDim.x * blockDim.x)	\
+			vals[i] = gpupreagg_identity<GPUPREAGG_OP_##OP, pg_##NAME##_base_t>();		\
+	}
+	GPUPREAGG_AGG_LIST(X)
+#undef X
+}
+
+/*
+ * the groups, packed for the host: records of
+ * { knull u32, flags u32, keys[NKEYS] u64, vals[NAGGS] u64 } in out[], their
+ * number in *counter (the order is arbitrary: partial rows are a set)
+ */
+extern "C" __global__ void
+__launch_bounds__(256)
+gpupreagg_hash_export(const char *htab, char *out, cl_uint *counter)
+{
+	const gpupreagg_hash_head *head = (const gpupreagg_hash_head *)htab;
+	const cl_uint  *h_state = (const cl_uint *)(htab + head->off_state);
+	const cl_uint  *h_knull = (const cl_uint *)(htab + head->off_knull);
+	const cl_ulong *h_keys = (const cl_ulong *)(htab + head->off_keys);
+	const cl_uint  *h_flags = (const cl_uint *)(htab + head->off_flags);
+	const size_t	reclen = 8 + 8 * (GPUPREAGG_NKEYS + GPUPREAGG_NAGGS);
+	cl_uint		C = head->capacity;
+
+	for (cl_uint base = blockIdx.x * blockDim.x; base < C; base += gridDim.x * blockDim.x)
+	{
+		cl_uint		i = base + threadIdx.x;
+		bool		ready = (i < C && h_state[i] == 2);
+		cl_ulong	mask = __ballot(ready);
+		cl_uint		first = 0;
+		/* one reservation per wave */
+		if (mask == 0)
+			continue;
+		if (strom_lane_id() == 0)
+			first = atomicAdd(counter, (cl_uint)__popcll(mask));
+		first = __shfl(first, 0, STROM_WAVE);
+		if (!ready)
+			continue;
+		cl_uint		idx = first + (cl_uint)__popcll(mask & ((1UL << strom_lane_id()) - 1));
+		char	   *rec = out + reclen * idx;
+		((cl_uint *)rec)[0] = h_knull[i];
+		((cl_uint *)rec)[1] = h_flags[i];
+		cl_ulong   *body = (cl_ulong *)(rec + 8);
+		for (int k = 0; k < GPUPREAGG_NKEYS; k++)
+			body[k] = h_keys[(size_t)i * GPUPREAGG_NKEYS + k];
+#define X(aidx,resno,OP,NAME)															\
+		body[GPUPREAGG_NKEYS + aidx] = ((const cl_ulong *)(htab + head->off_vals[aidx]))[i];
+		GPUPREAGG_AGG_LIST(X)
+#undef X
+	}
+}
+
+/* growth: every group of the old table moves to a (zeroed, initialised) larger one */
+extern "C" __global__ void
+__launch_bounds__(256)
+gpupreagg_hash_rehash(const char *otab, char *ntab)
+{
+	const gpupreagg_hash_head *ohead = (const gpupreagg_hash_head *)otab;
+	gpupreagg_hash_head *nhead = (gpupreagg_hash_head *)ntab;
+	const cl_uint  *o_state = (const cl_uint *)(otab + ohead->off_state);
+	const cl_uint  *o_knull = (const cl_uint *)(otab + ohead->off_knull);
+	const cl_ulong *o_keys = (const cl_ulong *)(otab + ohead->off_keys);
+	const cl_uint  *o_flags = (const cl_uint *)(otab + ohead->off_flags);
+	cl_uint	   *n_state = (cl_uint *)(ntab + nhead->off_state);
+	cl_uint	   *n_knull = (cl_uint *)(ntab + nhead->off_knull);
+	cl_ulong   *n_keys = (cl_ulong *)(ntab + nhead->off_keys);
+	cl_uint	   *n_flags = (cl_uint *)(ntab + nhead->off_flags);
+	cl_uint		C = ohead->capacity;
+
+	for (cl_uint i = blockIdx.x * blockDim.x + threadIdx.x; i < C; i += gridDim.x * blockDim.x)
+	{
+		if (o_state[i] != 2)
+			continue;
+		cl_ulong	kimg[GPUPREAGG_NKEYS + 1];
+		for (int k = 0; k < GPUPREAGG_NKEYS; k++)
+			kimg[k] = o_keys[(size_t)i * GPUPREAGG_NKEYS + k];
+		cl_uint		slot = gpupreagg_hash_slot<false>(nhead, n_state, n_knull, n_keys, kimg, o_knull[i]);
+		if (slot == ~0u)
+		{
+			nhead->overflow = 1;
+			continue;
+		}
+		n_flags[slot] = o_flags[i];
+#define X(aidx,resno,OP,NAME)															\
+		((cl_ulong *)(ntab + nhead->off_vals[aidx]))[slot] =							\
+			((const cl_ulong *)(otab + ohead->off_vals[aidx]))[i];
+		GPUPREAGG_AGG_LIST(X)
+#undef X
+	}
+}
+
+/* ====================================================================== *
  * census: which dense ids occur in this chunk (after the qual)?
  *
  * Zone maps bound each key separately; the product of the ranges can be

@@ -90,14 +90,24 @@ gpuscan_row_status(pg_bool_t rc, cl_int errcode, cl_int *chunk_error)
 }
 
 /* ---- LDS stage shared by both kernels ---------------------------------- */
-struct gpuscan_stage {
-	cl_int		entries[GPUSCAN_STAGE];
+template <int NENTRIES>
+struct gpuscan_stage_t {
+	cl_int		entries[NENTRIES];
 	cl_uint		wave_total[GPUSCAN_QUADS][GPUSCAN_NWAVES];
 	cl_uint		flush_base;
 };
+typedef gpuscan_stage_t<GPUSCAN_STAGE> gpuscan_stage;
+/* the row-at-a-time kernel's stage: measured, a shallow stage (2048 entries,
+ * twice the resident waves) is SLOWER than the deep one (630 vs 390 us per
+ * 1e7 rows) -- more flushes mean more reservations on the one result cursor */
+#ifndef GPUSCAN_GENERIC_STAGE
+#define GPUSCAN_GENERIC_STAGE	GPUSCAN_STAGE
+#endif
+typedef gpuscan_stage_t<GPUSCAN_GENERIC_STAGE> gpuscan_generic_stage;
 
+template <typename STAGE>
 STROM_DEVICE void
-gpuscan_stage_flush(gpuscan_stage &stage, kern_resultbuf *kresults, cl_uint fill)
+gpuscan_stage_flush(STAGE &stage, kern_resultbuf *kresults, cl_uint fill)
 {
 	/* caller guarantees a barrier since the last write into the stage */
 	if (fill == 0)
@@ -138,8 +148,9 @@ gpuscan_stage_flush(gpuscan_stage &stage, kern_resultbuf *kresults, cl_uint fill
  * order: (k, wave, lane, j).  Returns the number of entries appended; the
  * value is identical in every thread.
  */
+template <typename STAGE>
 STROM_DEVICE cl_uint
-gpuscan_stage_append(gpuscan_stage &stage, cl_uint fill,
+gpuscan_stage_append(STAGE &stage, cl_uint fill,
 					 cl_uint tile_base, const int (&st)[GPUSCAN_QUADS][4])
 {
 	cl_uint		lane = threadIdx.x & (STROM_WAVE - 1);
@@ -324,7 +335,7 @@ gpuscan_qual_generic_body(kern_gpuscan *kgpuscan,
 					 const kern_data_store *kds,
 					 const kern_data_store *ktoast,
 					 const kern_row_map *krowmap,
-					 gpuscan_stage &stage)
+					 gpuscan_generic_stage &stage)
 {
 	const kern_parambuf *kparams = KERN_GPUSCAN_PARAMBUF(kgpuscan);
 	kern_resultbuf *kresults = KERN_GPUSCAN_RESULTBUF(kgpuscan);
@@ -355,7 +366,7 @@ gpuscan_qual_generic_body(kern_gpuscan *kgpuscan,
 		cl_uint		tile_base = tile * GPUSCAN_TILE_ROWS;
 		int			st[GPUSCAN_QUADS][4];
 
-		if (fill + GPUSCAN_TILE_ROWS > GPUSCAN_STAGE)
+		if (fill + GPUSCAN_TILE_ROWS > GPUSCAN_GENERIC_STAGE)
 		{
 			gpuscan_stage_flush(stage, kresults, fill);
 			fill = 0;
@@ -424,7 +435,7 @@ gpuscan_qual_generic(kern_gpuscan *kgpuscan,
 					 const kern_data_store *ktoast,
 					 const kern_row_map *krowmap)
 {
-	__shared__ gpuscan_stage stage;
+	__shared__ gpuscan_generic_stage stage;
 
 	/* the chunk format is decided once per launch, not once per datum */
 	if (kds->format == KDS_FORMAT_COLUMN)

@@ -64,6 +64,12 @@ struct strom_gpupreagg {
 	char			   *d_remap = nullptr;
 	std::vector<cl_uint> present;			/* table slot -> dense id */
 	size_t				nfolds = 0;
+	/* hashed GROUP BY (strom_gpupreagg_create_hashed) */
+	bool				hashed = false;
+	char			   *htab = nullptr;
+	size_t				htab_bytes = 0;
+	cl_uint				hash_capacity = 0;
+	cl_ulong			groups_upper = 0;	/* groups known at the last read-back + rows folded since */
 	int					reg_groups = 0;		/* 1: register accumulators, 2: lane-private LDS, 0: LDS atomics */
 	std::mutex			lock;
 
@@ -431,17 +437,319 @@ gpupreagg_launch(strom_task_impl *task, preagg_request req)
 	task_enqueue(task);
 }
 
+
+/* ------------------------------------------------------------------ *
+ * hashed GROUP BY (gpupreagg_hash_* of strom_gpupreagg.h)
+ * ------------------------------------------------------------------ */
+
+/* host image of struct gpupreagg_hash_head: 16 + 8 * (4 + naggs + 1) bytes */
+struct hash_layout {
+	std::vector<char> head;
+	size_t		total;
+};
+
+hash_layout
+hash_table_layout(const strom_gpupreagg *sess, cl_uint capacity)
+{
+	hash_layout	L;
+	size_t		nkeys = sess->key_resno.size(), naggs = sess->agg_resno.size();
+	size_t		head_len = STROM_TYPEALIGN(256, 16 + 8 * (4 + naggs + 1));
+	size_t		off = head_len;
+	std::vector<cl_ulong> offs;
+
+	auto section = [&](size_t bytes) { offs.push_back(off); off += STROM_TYPEALIGN(256, bytes); };
+	section(4 * (size_t)capacity);					/* state */
+	section(4 * (size_t)capacity);					/* knull */
+	section(8 * (size_t)capacity * std::max<size_t>(nkeys, 1));	/* keys */
+	section(4 * (size_t)capacity);					/* flags */
+	for (size_t a = 0; a < naggs; a++)
+		section(8 * (size_t)capacity);
+	offs.push_back(off);
+	L.total = off;
+	L.head.assign(head_len, 0);
+	cl_uint	words[4] = { capacity, (cl_uint)nkeys, 0, 0 };
+	memcpy(L.head.data(), words, sizeof(words));
+	memcpy(L.head.data() + 16, offs.data(), 8 * offs.size());
+	return L;
+}
+
+/* a zeroed, initialised table of 'capacity' slots on the session's stream */
+int
+hash_table_new(strom_gpupreagg *sess, cl_uint capacity, char **p_tab, size_t *p_bytes, char *reuse)
+{
+	Device	   *dev = sess->dev;
+	hipStream_t	stream = dev->streams[0];
+	hash_layout	L = hash_table_layout(sess, capacity);
+	int			errcode = 0;
+	hipFunction_t fn_init = sess->prog->get_function(dev, "gpupreagg_hash_init", &errcode);
+	if (!fn_init)
+		return errcode;
+	char   *tab = (reuse ? reuse : (char *)dev->pool.alloc(L.total));
+	if (!tab)
+		return StromError_OutOfMemory;
+	/* the head is tiny: a synchronous copy from pageable memory is fine and keeps
+	 * the source alive */
+	if (hipMemsetAsync(tab, 0, L.total, stream) != hipSuccess ||
+		hipStreamSynchronize(stream) != hipSuccess ||
+		hipMemcpy(tab, L.head.data(), L.head.size(), hipMemcpyHostToDevice) != hipSuccess)
+	{
+		if (!reuse) dev->pool.release(tab);
+		return StromError_HipInternal;
+	}
+	void   *a_tab = tab;
+	void   *args[] = { &a_tab };
+	unsigned grid = std::max(1u, std::min<unsigned>((capacity + 255) / 256,
+													(unsigned)dev->prop.multiProcessorCount * 8));
+	if (hipModuleLaunchKernel(fn_init, grid, 1, 1, 256, 1, 1, 0, stream, args, nullptr) != hipSuccess)
+	{
+		if (!reuse) dev->pool.release(tab);
+		return StromError_HipInternal;
+	}
+	*p_tab = tab;
+	*p_bytes = L.total;
+	return 0;
+}
+
+/* groups claimed so far (drains the session's stream) */
+int
+hash_table_ngroups(strom_gpupreagg *sess, cl_uint *p_ngroups, cl_uint *p_overflow)
+{
+	cl_uint	words[4];
+	if (hipStreamSynchronize(sess->dev->streams[0]) != hipSuccess ||
+		hipMemcpy(words, sess->htab, sizeof(words), hipMemcpyDeviceToHost) != hipSuccess)
+		return StromError_HipInternal;
+	*p_ngroups = words[2];
+	if (p_overflow)
+		*p_overflow = words[3];
+	return 0;
+}
+
+/*
+ * room for the next rows.  A fold of n rows can claim at most n new slots,
+ * so with groups_upper + n <= 3/4 capacity a probe always ends at a free
+ * slot.  Returns how many rows may be folded now (>= 1), growing the table
+ * (x4 at least, old groups re-inserted by gpupreagg_hash_rehash) when less
+ * than min(want, 2^20) would fit.
+ */
+int
+hash_table_reserve(strom_gpupreagg *sess, cl_ulong want, cl_ulong *p_rows)
+{
+	Device	   *dev = sess->dev;
+	cl_ulong	floor_rows = std::min<cl_ulong>(want, 1UL << 20);
+	auto avail = [&]() -> cl_ulong {
+		cl_ulong limit = (cl_ulong)sess->hash_capacity / 4 * 3;
+		return limit > sess->groups_upper ? limit - sess->groups_upper : 0;
+	};
+
+	if (avail() < floor_rows)
+	{
+		cl_uint	ngroups = 0;
+		int		rc = hash_table_ngroups(sess, &ngroups, nullptr);
+		if (rc)
+			return rc;
+		sess->groups_upper = ngroups;
+		if (avail() < floor_rows)
+		{
+			cl_ulong	need = ((cl_ulong)ngroups + floor_rows) * 2;
+			cl_ulong	capacity = (cl_ulong)sess->hash_capacity * 4;
+			while (capacity < need)
+				capacity <<= 1;
+			if (capacity > (1UL << 31))
+				return StromError_DataStoreNoSpace;
+			char	   *ntab = nullptr;
+			size_t		nbytes = 0;
+			rc = hash_table_new(sess, (cl_uint)capacity, &ntab, &nbytes, nullptr);
+			if (rc)
+				return rc;
+			if (ngroups > 0)
+			{
+				int		errcode = 0;
+				hipFunction_t fn = sess->prog->get_function(dev, "gpupreagg_hash_rehash", &errcode);
+				const void *a_old = sess->htab;
+				void	   *a_new = ntab;
+				void	   *args[] = { &a_old, &a_new };
+				unsigned	grid = std::min<unsigned>((sess->hash_capacity + 255) / 256,
+													  (unsigned)dev->prop.multiProcessorCount * 8);
+				if (!fn ||
+					hipModuleLaunchKernel(fn, grid, 1, 1, 256, 1, 1, 0, dev->streams[0], args, nullptr) != hipSuccess ||
+					hipStreamSynchronize(dev->streams[0]) != hipSuccess)
+				{
+					dev->pool.release(ntab);
+					return fn ? StromError_HipInternal : errcode;
+				}
+			}
+			dev->pool.release(sess->htab);
+			sess->htab = ntab;
+			sess->htab_bytes = nbytes;
+			sess->hash_capacity = (cl_uint)capacity;
+		}
+	}
+	*p_rows = std::min<cl_ulong>(want, avail());
+	return 0;
+}
+
+void
+gpupreagg_launch_hashed(strom_task_impl *task, preagg_request req)
+{
+	strom_gpupreagg *sess = req.sess;
+	Device	   *dev = task->dev;
+	Program	   *prog = sess->prog;
+	int			errcode = 0;
+	std::lock_guard<std::mutex> g(sess->lock);
+
+	(void)hipSetDevice(dev->hip_id);
+	if (prog->state != STROM_DEVPROG_READY)
+	{
+		task_fail(task, StromError_ProgramBuildFailure);
+		return;
+	}
+	task->pfm.time_kern_build = (cl_ulong)prog->build_usec;
+	task->stream = dev->streams[0];
+	hipFunction_t fn_check = prog->get_function(dev, "gpupreagg_hash_check", &errcode);
+	hipFunction_t fn_fold = fn_check ? prog->get_function(dev, "gpupreagg_hash_fold", &errcode) : nullptr;
+	if (!fn_check || !fn_fold)
+	{
+		task_fail(task, errcode);
+		return;
+	}
+	if (!sess->htab)
+	{
+		int rc = hash_table_new(sess, sess->hash_capacity, &sess->htab, &sess->htab_bytes, nullptr);
+		if (rc)
+		{
+			task_fail(task, rc);
+			return;
+		}
+	}
+	size_t	kg_len = STROMALIGN(offsetof(kern_gpupreagg, kparams) + sess->kparams.size());
+	char   *stage = dev->pinned.alloc();
+	char   *d_kg = (char *)dev->pool.alloc(kg_len);
+	if (!stage || !d_kg || kg_len + 64 > PinnedPool::BLOCK)
+	{
+		if (stage) dev->pinned.release(stage);
+		if (d_kg) dev->pool.release(d_kg);
+		task_fail(task, StromError_OutOfMemory);
+		return;
+	}
+	task->pinned_blocks.push_back(stage);
+	task->main_devptr = d_kg;
+	memset(stage, 0, kg_len);
+	memcpy(stage + offsetof(kern_gpupreagg, kparams), sess->kparams.data(), sess->kparams.size());
+
+	task_event(task);									/* ev[0] */
+	REQ_CHECK(hipMemcpyAsync(d_kg, stage, kg_len, hipMemcpyHostToDevice, task->stream),
+			  "send kern_gpupreagg");
+	task->pfm.num_dma_send++;
+	task->pfm.bytes_dma_send += kg_len;
+	const void *d_kds;
+	if (req.kds_dev)
+		d_kds = req.kds_dev->devptr;
+	else
+	{
+		size_t	kds_len = req.kds->length;
+		if (req.kds->format == KDS_FORMAT_ROW)
+			kds_len = KERN_DATA_STORE_ROWBLOCK_OFFSET(req.kds) + (size_t)BLCKSZ * req.kds->nblocks;
+		void   *p = dev->pool.alloc(kds_len);
+		if (!p)
+		{
+			task_fail(task, StromError_OutOfMemory);
+			return;
+		}
+		task->devbufs.push_back(p);
+		REQ_CHECK(hipMemcpyAsync(p, req.kds, kds_len, hipMemcpyHostToDevice, task->stream),
+				  "send kern_data_store");
+		task->pfm.num_dma_send++;
+		task->pfm.bytes_dma_send += kds_len;
+		d_kds = p;
+	}
+	const void *d_rowmap = (req.rowmap_dev ? req.rowmap_dev->devptr : nullptr);
+	if (!req.rowmap_dev && req.krowmap)
+	{
+		size_t	len = offsetof(kern_row_map, rindex) + sizeof(cl_int) * (size_t)req.krowmap->nvalids;
+		void   *p = dev->pool.alloc(len);
+		if (!p)
+		{
+			task_fail(task, StromError_OutOfMemory);
+			return;
+		}
+		task->devbufs.push_back(p);
+		REQ_CHECK(hipMemcpyAsync(p, req.krowmap, len, hipMemcpyHostToDevice, task->stream),
+				  "send kern_row_map");
+		d_rowmap = p;
+	}
+	task_event(task);									/* ev[1] */
+	{
+		void	   *a_kg = d_kg;
+		const void *a_kds = d_kds;
+		const void *a_toast = nullptr;
+		const void *a_map = d_rowmap;
+		cl_uint		nrows = req.nrows;
+		unsigned	maxgrid = (unsigned)dev->prop.multiProcessorCount * 8;
+		/* pass 1: errors only -- a chunk with a CpuReCheck row is not folded at all */
+		{
+			void	   *a_tab = sess->htab;
+			cl_uint		lo = 0, hi = nrows;
+			void	   *args[] = { &a_kg, &a_kds, &a_toast, &a_map, &a_tab, &lo, &hi };
+			unsigned	grid = std::max(1u, std::min<unsigned>((nrows + 255) / 256, maxgrid));
+			REQ_CHECK(hipModuleLaunchKernel(fn_check, grid, 1, 1, 256, 1, 1, 0, task->stream, args, nullptr),
+					  "launch gpupreagg hash check");
+			task->pfm.num_kern_exec++;
+		}
+		/* pass 2: fold, as many rows at a time as the table has guaranteed room for */
+		for (cl_uint lo = 0; lo < nrows; )
+		{
+			cl_ulong	rows = 0;
+			int			rc = hash_table_reserve(sess, nrows - lo, &rows);
+			if (rc != 0 || rows == 0)
+			{
+				task_fail(task, rc ? rc : StromError_DataStoreNoSpace);
+				return;
+			}
+			void	   *a_tab = sess->htab;
+			cl_uint		hi = lo + (cl_uint)rows;
+			void	   *args[] = { &a_kg, &a_kds, &a_toast, &a_map, &a_tab, &lo, &hi };
+			unsigned	grid = std::max(1u, std::min<unsigned>(((cl_uint)rows + 255) / 256, maxgrid));
+			REQ_CHECK(hipModuleLaunchKernel(fn_fold, grid, 1, 1, 256, 1, 1, 0, task->stream, args, nullptr),
+					  "launch gpupreagg hash fold");
+			task->pfm.num_kern_exec++;
+			sess->groups_upper += rows;
+			lo = hi;
+		}
+	}
+	task_event(task);									/* ev[2] */
+	char   *stage_status = stage + kg_len;
+	REQ_CHECK(hipMemcpyAsync(stage_status, d_kg + offsetof(kern_gpupreagg, status), sizeof(cl_int),
+							 hipMemcpyDeviceToHost, task->stream),
+			  "recv status");
+	REQ_CHECK(hipMemcpyAsync(stage_status + 16, sess->htab, 16, hipMemcpyDeviceToHost, task->stream),
+			  "recv table head");
+	task->pfm.num_dma_recv += 2;
+	task->pfm.bytes_dma_recv += sizeof(cl_int) + 16;
+	task_event(task);									/* ev[3] */
+	task->finish = [stage_status](strom_task_impl *t)
+	{
+		cl_int	status;
+		cl_uint	words[4];
+		memcpy(&status, stage_status, sizeof(status));
+		memcpy(words, stage_status + 16, sizeof(words));
+		if (status == StromError_Success && words[3] != 0)
+			status = StromError_DataStoreNoSpace;	/* cannot happen: room is reserved before a fold */
+		t->errcode = status;
+	};
+	task_enqueue(task);
+}
+
 }	/* namespace */
 
 /* ================================================================== *
  * C ABI
  * ================================================================== */
-extern "C" strom_gpupreagg *
-strom_gpupreagg_create(strom_devprog_key key,
-					   const strom_preagg_target *targets, int ntargets,
-					   const kern_parambuf *kparams,
-					   const strom_preagg_domain *domain,
-					   int dindex, int *p_errcode)
+static strom_gpupreagg *
+gpupreagg_session_new(strom_devprog_key key,
+					  const strom_preagg_target *targets, int ntargets,
+					  const kern_parambuf *kparams,
+					  const strom_preagg_domain *domain, bool hashed,
+					  int dindex, int *p_errcode)
 {
 	int		dummy;
 	if (!p_errcode)
@@ -463,7 +771,7 @@ strom_gpupreagg_create(strom_devprog_key key,
 	{
 		if (targets[i].kind == STROM_PREAGG_KEY)
 		{
-			if (type_is_float(targets[i].type_oid) || targets[i].type_oid == STROM_NUMERICOID)
+			if (!hashed && (type_is_float(targets[i].type_oid) || targets[i].type_oid == STROM_NUMERICOID))
 			{
 				/* dense ids need integer-like keys */
 				*p_errcode = StromError_DataStoreOutOfRange;
@@ -481,6 +789,13 @@ strom_gpupreagg_create(strom_devprog_key key,
 	if (const char *v = getenv("STROM_GPUPREAGG_QUADS"))
 		sess->quads = atoi(v);
 	strom_retain_devprog_key(key);
+	sess->hashed = hashed;
+	if (hashed && (sess->key_resno.size() > 31 || sess->agg_resno.size() > 30))
+	{
+		*p_errcode = StromError_BadRequestMessage;
+		strom_gpupreagg_release(sess);
+		return nullptr;
+	}
 	if (domain)
 	{
 		int rc = setup_geometry(sess, domain);
@@ -493,6 +808,35 @@ strom_gpupreagg_create(strom_devprog_key key,
 			return nullptr;
 		}
 	}
+	return sess;
+}
+
+extern "C" strom_gpupreagg *
+strom_gpupreagg_create(strom_devprog_key key,
+					   const strom_preagg_target *targets, int ntargets,
+					   const kern_parambuf *kparams,
+					   const strom_preagg_domain *domain,
+					   int dindex, int *p_errcode)
+{
+	return gpupreagg_session_new(key, targets, ntargets, kparams, domain, false, dindex, p_errcode);
+}
+
+extern "C" strom_gpupreagg *
+strom_gpupreagg_create_hashed(strom_devprog_key key,
+							  const strom_preagg_target *targets, int ntargets,
+							  const kern_parambuf *kparams,
+							  uint32_t ngroups_hint,
+							  int dindex, int *p_errcode)
+{
+	strom_gpupreagg *sess = gpupreagg_session_new(key, targets, ntargets, kparams, nullptr, true,
+												  dindex, p_errcode);
+	if (!sess)
+		return nullptr;
+	/* the table itself is made by the first fold (the program may still be building) */
+	cl_ulong	capacity = 1UL << 16;
+	while (capacity < (cl_ulong)ngroups_hint * 2 && capacity < (1UL << 31))
+		capacity <<= 1;
+	sess->hash_capacity = (cl_uint)capacity;
 	return sess;
 }
 
@@ -522,7 +866,19 @@ extern "C" void *
 strom_gpupreagg_table_devptr(strom_gpupreagg *sess) { return sess ? sess->table : nullptr; }
 
 extern "C" uint32_t
-strom_gpupreagg_num_groups(strom_gpupreagg *sess) { return (sess && sess->has_domain) ? sess->ctl.ngroups : 0; }
+strom_gpupreagg_num_groups(strom_gpupreagg *sess)
+{
+	if (sess && sess->hashed)
+	{
+		cl_uint	ngroups = 0;
+		std::lock_guard<std::mutex> g(sess->lock);
+		(void)hipSetDevice(sess->dev->hip_id);
+		if (!sess->htab || hash_table_ngroups(sess, &ngroups, nullptr) != 0)
+			return 0;
+		return ngroups;
+	}
+	return (sess && sess->has_domain) ? sess->ctl.ngroups : 0;
+}
 
 extern "C" uint32_t
 strom_gpupreagg_dense_groups(strom_gpupreagg *sess) { return (sess && sess->has_domain) ? sess->ctl.dense_ngroups : 0; }
@@ -565,7 +921,7 @@ submit_gpupreagg_common(strom_gpupreagg *sess,
 		*p_errcode = StromError_BadRequestMessage;
 		return nullptr;
 	}
-	if (!sess->has_domain)
+	if (!sess->hashed && !sess->has_domain)
 	{
 		/* first chunk fixes the dense domain (see strom_hip.h) */
 		*p_errcode = StromError_DataStoreOutOfRange;
@@ -587,7 +943,10 @@ submit_gpupreagg_common(strom_gpupreagg *sess,
 				 : req.krowmap ? (uint32_t)req.krowmap->nvalids : head.nitems);
 	sess->nfolds++;
 	strom_task_impl *task = task_create(sess->dev, done, arg);
-	program_run_or_park(sess->prog, [task, req]() { gpupreagg_launch(task, req); });
+	if (sess->hashed)
+		program_run_or_park(sess->prog, [task, req]() { gpupreagg_launch_hashed(task, req); });
+	else
+		program_run_or_park(sess->prog, [task, req]() { gpupreagg_launch(task, req); });
 	return task;
 }
 
@@ -777,6 +1136,15 @@ strom_gpupreagg_compact(strom_gpupreagg *sess, const uint32_t *bitmap, size_t nw
 extern "C" void
 strom_gpupreagg_reset(strom_gpupreagg *sess)
 {
+	if (sess && sess->hashed)
+	{
+		std::lock_guard<std::mutex> g(sess->lock);
+		(void)hipSetDevice(sess->dev->hip_id);
+		if (sess->htab)
+			(void)hash_table_new(sess, sess->hash_capacity, &sess->htab, &sess->htab_bytes, sess->htab);
+		sess->groups_upper = 0;
+		return;
+	}
 	if (!sess || !sess->table)
 		return;
 	(void)hipSetDevice(sess->dev->hip_id);
@@ -802,6 +1170,8 @@ strom_gpupreagg_release(strom_gpupreagg *sess)
 		dev->pool.release(sess->d_census);
 	if (sess->d_remap)
 		dev->pool.release(sess->d_remap);
+	if (sess->htab)
+		dev->pool.release(sess->htab);
 	strom_put_devprog_key(sess->key);
 	delete sess;
 }
@@ -841,6 +1211,202 @@ struct numeric_spill {
 
 }	/* namespace */
 
+namespace {
+
+void
+fetch_init_head(strom_gpupreagg *sess, kern_data_store *dest, size_t need, size_t nrooms)
+{
+	int		ncols = (int)sess->targets.size();
+	memset(dest, 0, KDS_HEAD_LENGTH(ncols));
+	dest->hostptr = (hostptr_t)(uintptr_t)&dest->hostptr;
+	dest->length = (cl_uint)need;
+	dest->ncols = ncols;
+	dest->nrooms = (cl_uint)nrooms;
+	dest->format = KDS_FORMAT_TUPSLOT;
+	dest->tdtypeid = 2249;
+	dest->tdtypmod = -1;
+	for (int i = 0; i < ncols; i++)
+	{
+		const strom_preagg_target &t = sess->targets[i];
+		int len = (t.kind == STROM_PREAGG_NROWS ? 8 : type_length(t.type_oid));
+		dest->colmeta[i].attbyval = 1;
+		dest->colmeta[i].attalign = (cl_char)len;
+		dest->colmeta[i].attlen = (cl_short)len;
+		dest->colmeta[i].attnum = (cl_short)(i + 1);
+		dest->colmeta[i].attcacheoff = -1;
+	}
+}
+
+/* a float accumulator image -> the column's datum */
+cl_ulong
+float_image_to_datum(const strom_preagg_target &t, cl_ulong raw, bool ordered)
+{
+	if (ordered)		/* order-preserving key -> IEEE bits */
+		raw = (raw & 0x8000000000000000UL) ? (raw & 0x7fffffffffffffffUL) : ~raw;
+	if (t.type_oid == STROM_FLOAT4OID)
+	{
+		double d; float f;
+		memcpy(&d, &raw, 8);
+		f = (float)d;
+		raw = 0;
+		memcpy(&raw, &f, 4);
+	}
+	return raw;
+}
+
+/*
+ * hashed sessions: gpupreagg_hash_export packs the groups on the device,
+ * only ngroups records cross PCIe
+ */
+long
+gpupreagg_fetch_hashed(strom_gpupreagg *sess, kern_data_store *dest, size_t destlen)
+{
+	Device *dev = sess->dev;
+	int		ncols = (int)sess->targets.size();
+	size_t	nkeys = sess->key_resno.size(), naggs = sess->agg_resno.size();
+	size_t	reclen = 8 + 8 * (nkeys + naggs);
+	cl_uint	ngroups = 0, overflow = 0;
+	std::vector<char> recs;
+	std::lock_guard<std::mutex> g(sess->lock);
+
+	(void)hipSetDevice(dev->hip_id);
+	if (sess->htab)
+	{
+		int rc = hash_table_ngroups(sess, &ngroups, &overflow);
+		if (rc)
+			return -rc;
+		if (overflow)
+			return -StromError_DataStoreNoSpace;
+	}
+	if (ngroups > 0)
+	{
+		int		errcode = 0;
+		hipFunction_t fn = sess->prog->get_function(dev, "gpupreagg_hash_export", &errcode);
+		if (!fn)
+			return -errcode;
+		char   *d_out = (char *)dev->pool.alloc(reclen * ngroups + 16);
+		if (!d_out)
+			return -StromError_OutOfMemory;
+		char   *d_counter = d_out + reclen * ngroups;
+		const void *a_tab = sess->htab;
+		void	   *a_out = d_out, *a_cnt = d_counter;
+		void	   *args[] = { &a_tab, &a_out, &a_cnt };
+		unsigned	grid = std::min<unsigned>((sess->hash_capacity + 255) / 256,
+											  (unsigned)dev->prop.multiProcessorCount * 8);
+		cl_uint		count = 0;
+		recs.resize(reclen * ngroups);
+		bool ok = (hipMemsetAsync(d_counter, 0, 16, dev->streams[0]) == hipSuccess &&
+				   hipModuleLaunchKernel(fn, grid, 1, 1, 256, 1, 1, 0, dev->streams[0], args, nullptr) == hipSuccess &&
+				   hipStreamSynchronize(dev->streams[0]) == hipSuccess &&
+				   hipMemcpy(&count, d_counter, sizeof(count), hipMemcpyDeviceToHost) == hipSuccess &&
+				   count == ngroups &&
+				   hipMemcpy(recs.data(), d_out, recs.size(), hipMemcpyDeviceToHost) == hipSuccess);
+		dev->pool.release(d_out);
+		if (!ok)
+			return -StromError_HipInternal;
+	}
+	/* numeric sums too wide for the 64-bit form leave as two partial rows */
+	const cl_long P17 = 100000000000000000L;
+	struct spill { cl_uint rec; int resno; cl_ulong image; };
+	std::vector<spill> spills;
+	for (cl_uint r = 0; r < ngroups; r++)
+	{
+		const char *rec = recs.data() + reclen * r;
+		cl_uint		flags = ((const cl_uint *)rec)[1];
+		const cl_ulong *vals = (const cl_ulong *)(rec + 8) + nkeys;
+		for (size_t a = 0; a < naggs; a++)
+		{
+			const strom_preagg_target &t = sess->targets[sess->agg_resno[a]];
+			cl_ulong	img;
+			if (t.type_oid != STROM_NUMERICOID || t.kind == STROM_PREAGG_NROWS || !(flags & (2u << a)))
+				continue;
+			cl_long v = (cl_long)vals[a];
+			if (!fixed_to_numeric(v, t.scale, &img))
+			{
+				if (!fixed_to_numeric((v / P17) * P17, t.scale, &img))
+					return -StromError_DataStoreOutOfRange;
+				spills.push_back(spill{r, sess->agg_resno[a], img});
+			}
+		}
+	}
+	size_t	nrows_out = (size_t)ngroups + spills.size();
+	size_t	need = STROMALIGN(KDS_HEAD_LENGTH(ncols) + KDS_TUPSLOT_STRIDE(ncols) * nrows_out);
+	if (!dest)
+		return (long)need;
+	if (destlen < need)
+		return -StromError_DataStoreNoSpace;
+	fetch_init_head(sess, dest, need, nrows_out);
+	auto put_keys = [&](const char *rec, Datum *values, cl_char *isnull)
+	{
+		cl_uint		knull = ((const cl_uint *)rec)[0];
+		const cl_ulong *kimg = (const cl_ulong *)(rec + 8);
+		for (size_t k = 0; k < nkeys; k++)
+		{
+			int		resno = sess->key_resno[k];
+			const strom_preagg_target &t = sess->targets[resno];
+			if (knull & (1u << k))
+			{
+				isnull[resno] = 1;
+				continue;
+			}
+			isnull[resno] = 0;
+			cl_ulong raw = kimg[k];
+			if (type_is_float(t.type_oid))
+				raw = float_image_to_datum(t, raw, false);
+			values[resno] = 0;
+			memcpy(&values[resno], &raw, type_length(t.type_oid));
+		}
+	};
+	cl_uint	row = 0;
+	for (cl_uint r = 0; r < ngroups; r++, row++)
+	{
+		const char *rec = recs.data() + reclen * r;
+		cl_uint		flags = ((const cl_uint *)rec)[1];
+		const cl_ulong *vals = (const cl_ulong *)(rec + 8) + nkeys;
+		Datum	   *values = KERN_DATA_STORE_VALUES(dest, row);
+		cl_char	   *isnull = KERN_DATA_STORE_ISNULL(dest, row);
+		memset(values, 0, KDS_TUPSLOT_STRIDE(ncols));
+		put_keys(rec, values, isnull);
+		for (size_t a = 0; a < naggs; a++)
+		{
+			int		resno = sess->agg_resno[a];
+			const strom_preagg_target &t = sess->targets[resno];
+			cl_ulong raw = vals[a];
+			if (t.kind == STROM_PREAGG_NROWS)
+				values[resno] = raw;
+			else if (!(flags & (2u << a)))
+				isnull[resno] = 1;
+			else if (t.type_oid == STROM_NUMERICOID)
+			{
+				cl_long v = (cl_long)raw;
+				if (!fixed_to_numeric(v, t.scale, &raw))
+					(void)fixed_to_numeric(v - (v / P17) * P17, t.scale, &raw);	/* high part: spill row */
+				values[resno] = raw;
+			}
+			else if (type_is_float(t.type_oid))
+				values[resno] = float_image_to_datum(t, raw, t.kind != STROM_PREAGG_PSUM);
+			else
+				memcpy(&values[resno], &raw, type_length(t.type_oid));
+		}
+	}
+	for (const spill &sp : spills)
+	{
+		Datum	   *values = KERN_DATA_STORE_VALUES(dest, row);
+		cl_char	   *isnull = KERN_DATA_STORE_ISNULL(dest, row);
+		memset(values, 0, KDS_TUPSLOT_STRIDE(ncols));
+		for (int i = 0; i < ncols; i++)
+			isnull[i] = (sess->targets[i].kind != STROM_PREAGG_NROWS);	/* nrows = 0 */
+		put_keys(recs.data() + reclen * sp.rec, values, isnull);
+		isnull[sp.resno] = 0;
+		values[sp.resno] = sp.image;
+		row++;
+	}
+	dest->nitems = row;
+	return (long)row;
+}
+
+}	/* namespace */
+
 /*
  * partial rows out: TUPSLOT, one row per group seen so far (plus, for a
  * numeric sum too wide for the 64-bit numeric form, one extra partial row
@@ -850,6 +1416,8 @@ struct numeric_spill {
 extern "C" long
 strom_gpupreagg_fetch(strom_gpupreagg *sess, kern_data_store *dest, size_t destlen)
 {
+	if (sess && sess->hashed)
+		return gpupreagg_fetch_hashed(sess, dest, destlen);
 	if (!sess || !sess->has_domain)
 		return -StromError_BadRequestMessage;
 	Device *dev = sess->dev;

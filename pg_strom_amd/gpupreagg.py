@@ -121,6 +121,24 @@ class GpuPreAgg(object):
             raise runtime.StromError(err.value, "strom_gpupreagg_create")
         return self
 
+    def begin_hashed(self, ext_params=(), ext_isnull=None, ngroups_hint=0, dindex=0):
+        """GROUP BY over keys of any type / spread: groups live in a hash table in
+        HBM (strom_gpupreagg_create_hashed); same submit / fetch calls afterwards"""
+        runtime.init()
+        self.program = runtime.DevProgram(self.codegen.source, self.codegen.extra_flags)
+        self.parambuf = self.codegen.parambuf(ext_params, ext_isnull)
+        err = ctypes.c_int(0)
+        pb = ctypes.create_string_buffer(self.parambuf, len(self.parambuf))
+        self.session = lib.strom_gpupreagg_create_hashed(self.program.key, self.codegen._targets_c,
+                                                         len(self.targets), pb, int(ngroups_hint),
+                                                         dindex, ctypes.byref(err))
+        if not self.session:
+            raise runtime.StromError(err.value, "strom_gpupreagg_create_hashed")
+        return self
+
+    def num_groups(self):
+        return lib.strom_gpupreagg_num_groups(self.session)
+
     # group-slot agreement ---------------------------------------------------
     def census(self, chunk, row_map=None):
         """mark the dense ids that occur in 'chunk' (after the qual); returns

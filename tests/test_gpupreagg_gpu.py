@@ -111,9 +111,12 @@ def test_reference_regression_suites_on_device(fmt, nchunks):
     assert total >= 200
 
 
-def compare_with_oracle(spec, bufs, domain, ext=(), float_tol=1e-12, compact=False):
+def compare_with_oracle(spec, bufs, domain, ext=(), float_tol=1e-12, compact=False, hashed=False):
     agg = GpuPreAgg(spec)
-    agg.begin(domain, ext_params=ext)
+    if hashed:
+        agg.begin_hashed(ext_params=ext)
+    else:
+        agg.begin(domain, ext_params=ext)
     nt = len(agg.targets)
     try:
         if compact:
@@ -372,3 +375,170 @@ def test_unmarked_combination_fails_its_chunk_after_compact():
             agg.compact()
     finally:
         agg.end()
+
+
+# ---------------------------------------------------------------------------
+# hashed GROUP BY (strom_gpupreagg_create_hashed): keys of any type and spread
+# ---------------------------------------------------------------------------
+def any_key_table(n, seed, nulls=0.03):
+    rng = np.random.default_rng(seed)
+    f = rng.integers(-4, 5, n).astype(np.float64) / 4            # float8 key incl. -0.0 / +0.0
+    f[rng.random(n) < 0.05] = -0.0
+    f[rng.random(n) < 0.03] = np.nan                              # NaN is ONE group
+    big = (rng.integers(0, 7, n).astype(np.int64) - 3) * (2**40 + 12345)   # int8 key, sparse
+    num = kds.numeric_from_scaled(rng.integers(-3, 4, n) * 250, 3, rng.random(n) < nulls)   # numeric key
+    x = rng.integers(-10**6, 10**6, n).astype(np.int32)
+    y = rng.random(n) * 100
+    z = rng.integers(-2, 3, n).astype(np.float32) * 0.5           # float4 key
+    return [kds.Column("float8", f, rng.random(n) < nulls), kds.Column("int8", big, rng.random(n) < nulls),
+            num, kds.Column("int4", x, rng.random(n) < nulls), kds.Column("float8", y, rng.random(n) < nulls),
+            kds.Column("float4", z)]
+
+
+SPEC_ANY_KEYS = ("(gpupreagg (key (var 1 float8)) (key (var 2 int8)) (nrows) (nrows (isnotnull (var 4 int4)))"
+                 " (psum (int8 (var 4 int4))) (pmin (var 4 int4)) (pmax (var 4 int4))"
+                 " (psum (var 5 float8)) (pmin (var 5 float8)) (pmax (var 5 float8)))")
+
+
+@pytest.mark.parametrize("fmt", ["column", "row", "tupslot"])
+def test_hashed_float_and_sparse_int8_keys(fmt):
+    cols = any_key_table(40000, 31)
+    bufs = [kds.build_kds(fmt, [kds.Column(c.sqltype, c.values[i::2], None if c.isnull is None else c.isnull[i::2])
+                                for c in cols]) for i in range(2)]
+    compare_with_oracle(SPEC_ANY_KEYS, bufs, None, hashed=True)
+
+
+def test_hashed_numeric_and_float4_keys_with_a_qual():
+    cols = any_key_table(30000, 37)
+    buf = kds.build_kds("column", cols)
+    spec = ("(gpupreagg (qual (int4gt (var 4 int4) (param 0 int4)))"
+            " (key (var 3 numeric)) (key (var 6 float4)) (nrows) (psum (int8 (var 4 int4))) (pmax (var 5 float8)))")
+    compare_with_oracle(spec, [buf], None, ext=[np.int32(-250000)], hashed=True)
+
+
+def test_hashed_numeric_key_groups_by_value_not_by_image():
+    """1.50 and 1.5 are one group: numeric keys are stripped before hashing"""
+    n = 6000
+    rng = np.random.default_rng(41)
+    k = rng.integers(1, 6, n)
+    # the same values in two images: mantissa*10 with exponent-1 (unnormalised)
+    norm = kds.numeric_from_scaled(k * 5, 1).values
+    mant = norm & np.uint64((1 << 57) - 1)
+    expo = (norm.view(np.int64) >> 58)
+    loose = (((expo - 1) & 0x3f).astype(np.uint64) << np.uint64(58)) | (mant * np.uint64(10))
+    img = np.where(rng.random(n) < 0.5, norm, loose)
+    buf = kds.build_kds("column", [kds.Column("numeric", img), kds.Column("int4", np.ones(n, dtype=np.int32))])
+    agg = GpuPreAgg("(gpupreagg (key (var 1 numeric)) (nrows))").begin_hashed()
+    assert agg.fold(buf)[0] == 0
+    pr = agg.fetch()
+    agg.end()
+    assert len(pr) == 5
+    keys, _ = pr.column(0)
+    cnt, _ = pr.column(1)
+    want = {int(v): int((k == kk).sum()) for kk, v in zip(range(1, 6), kds.numeric_from_scaled(np.arange(1, 6) * 5, 1).values)}
+    assert {int(a): int(b) for a, b in zip(keys, cnt)} == want
+
+
+def test_hashed_table_grows_with_the_group_count():
+    """300k distinct int8 keys through a table that starts at 65536 slots; three
+    chunks, the same keys again in the last one"""
+    rng = np.random.default_rng(43)
+    nkeys = 300000
+    universe = rng.permutation(np.arange(nkeys, dtype=np.int64) * 1000003 - 7 * 10**10)
+    chunks = [universe[:120000], universe[120000:], universe[::3]]
+    agg = GpuPreAgg("(gpupreagg (key (var 1 int8)) (nrows) (psum (int8 (var 2 int4))) (pmax (var 2 int4)))").begin_hashed()
+    vals = []
+    for c in chunks:
+        v = rng.integers(-1000, 1000, len(c)).astype(np.int32)
+        vals.append(v)
+        assert agg.fold(kds.build_kds("column", [kds.Column("int8", c), kds.Column("int4", v)]))[0] == 0
+    assert agg.num_groups() == nkeys
+    pr = agg.fetch()
+    agg.end()
+    assert len(pr) == nkeys
+    allk = np.concatenate(chunks)
+    allv = np.concatenate(vals).astype(np.int64)
+    uk, inv = np.unique(allk, return_inverse=True)
+    want_cnt = np.bincount(inv)
+    want_sum = np.bincount(inv, weights=allv).astype(np.int64)
+    want_max = np.full(len(uk), -2**31, dtype=np.int64)
+    np.maximum.at(want_max, inv, allv)
+    k, _ = pr.column(0)
+    order = np.argsort(k)
+    assert np.array_equal(k[order], uk)
+    assert np.array_equal(pr.column(1)[0][order], want_cnt)
+    assert np.array_equal(pr.column(2)[0][order], want_sum)
+    assert np.array_equal(pr.column(3)[0][order].astype(np.int64), want_max)
+
+
+def test_hashed_recheck_chunk_is_not_folded_and_reset():
+    x = np.array([1, 2**31 - 1, 3] * 100, dtype=np.int32)
+    k = np.arange(300, dtype=np.float64) % 7
+    bad = kds.build_kds("column", [kds.Column("int4", x), kds.Column("float8", k)])
+    good = kds.build_kds("column", [kds.Column("int4", np.arange(70, dtype=np.int32)),
+                                    kds.Column("float8", np.arange(70, dtype=np.float64) % 7)])
+    spec = "(gpupreagg (key (var 2 float8)) (nrows) (psum (int8 (int4pl (var 1 int4) (const int4 1)))))"
+    agg = GpuPreAgg(spec).begin_hashed()
+    assert agg.fold(good)[0] == 0
+    assert agg.fold(bad)[0] == 2            # CpuReCheck: contributes nothing, claims no slot
+    assert agg.fold(good)[0] == 0
+    pr = agg.fetch()
+    assert len(pr) == 7 and agg.num_groups() == 7
+    assert int(pr.column(1)[0].sum()) == 140 and int(pr.column(2)[0].sum()) == 2 * sum(range(1, 71))
+    agg.reset()
+    assert agg.num_groups() == 0 and len(agg.fetch()) == 0
+    assert agg.fold(good)[0] == 0
+    pr = agg.fetch()
+    agg.end()
+    assert len(pr) == 7 and int(pr.column(1)[0].sum()) == 70
+
+
+def test_hashed_row_map_inputs_host_and_device():
+    from pg_strom_amd.gpuscan import GpuScan
+    cols = any_key_table(30000, 47)
+    spec = "(gpupreagg (key (var 1 float8)) (nrows) (psum (int8 (var 4 int4))))"
+    # host row map over a ROW chunk
+    buf = kds.build_kds("row", cols)
+    rmap = np.random.default_rng(2).permutation(30000)[:9000].astype(np.int32)
+    agg = GpuPreAgg(spec).begin_hashed()
+    assert agg.fold(buf, row_map=rmap)[0] == 0
+    got_v, got_n = partial_rows_as_raw8(agg.fetch())
+    agg.end()
+    rc, v, n = oracle.gpupreagg(spec, buf, 3, row_map=rmap)
+    assert rc == 0
+    order_g = np.lexsort((got_v[:, 0], got_n[:, 0]))
+    order_o = np.lexsort((v[:, 0], n[:, 0]))
+    assert np.array_equal(got_v[order_g], v[order_o]) and np.array_equal(got_n[order_g], n[order_o])
+    # device row map: GpuScan -> GpuPreAgg without leaving HBM
+    colbuf = kds.build_kds("column", cols)
+    store = runtime.DeviceStore.upload(colbuf)
+    qual = "(int4gt (var 4 int4) (const int4 0))"
+    scan = GpuScan(qual).begin()
+    rowmap, _ = scan.scan_to_rowmap(store)
+    agg = GpuPreAgg(spec).begin_hashed()
+    assert agg.fold(store, row_map=rowmap)[0] == 0
+    got_v, got_n = partial_rows_as_raw8(agg.fetch())
+    agg.end()
+    scan.end()
+    rowmap.release()
+    store.release()
+    rc, sel = oracle.gpuscan(qual, colbuf, [])
+    rc, v, n = oracle.gpupreagg(spec, colbuf, 3, row_map=(np.sort(sel) - 1).astype(np.int32))   # results[] are 1-based
+    assert rc == 0
+    order_g = np.lexsort((got_v[:, 0], got_n[:, 0]))
+    order_o = np.lexsort((v[:, 0], n[:, 0]))
+    assert np.array_equal(got_v[order_g], v[order_o]) and np.array_equal(got_n[order_g], n[order_o])
+
+
+def test_hashed_session_refuses_the_dense_table_calls():
+    agg = GpuPreAgg("(gpupreagg (key (var 1 float8)) (nrows))").begin_hashed()
+    from pg_strom_amd._lib import lib
+    assert lib.strom_gpupreagg_table_length(agg.session) == 0
+    assert lib.strom_gpupreagg_dense_groups(agg.session) == 0
+    with pytest.raises(runtime.StromError):
+        agg.compact()
+    assert len(agg.fetch()) == 0            # nothing folded yet
+    agg.end()
+    # and the dense path still refuses what only the hashed one can group
+    with pytest.raises(runtime.StromError):
+        GpuPreAgg("(gpupreagg (key (var 1 float8)) (nrows))").begin([(0, 10)])
