@@ -1392,29 +1392,51 @@ gpupreagg_reg1_column(kern_gpupreagg *kgpreagg, const kern_data_store *kds,
  * most 2^26 ids.  Everything else -- float8 / numeric keys, sparse int8
  * keys -- goes through an open-addressing table in HBM keyed by the keys'
  * canonical 64-bit images (the reference sorts row indexes by
- * gpupreagg_keycomp instead, opencl_gpupreagg.h:620-856):
+ * gpupreagg_keycomp instead, opencl_gpupreagg.h:620-856).  One slot is one
+ * record, so a probe touches one cache line:
  *
- *   head                       gpupreagg_hash_head
- *   state[C]      u32          0 empty, 1 being claimed, 2 ready
- *   knull[C]      u32          bit k: key k is NULL
- *   keys[C*NKEYS] u64          key images, slot-major
- *   flags[C]      u32          bit 0 seen, bit 1+a aggregate a has a value
- *   vals_a[C]     8 bytes      per aggregate (NROWS widened to i64)
+ *   +0   state  u32     0 empty, 1 being claimed, 2 ready
+ *   +4   knull  u32     bit k: key k is NULL
+ *   +8   flags  u32     bit 0 seen, bit 1+a aggregate a has a value
+ *   +16  keys[NKEYS]    u64 images
+ *        vals[NAGGS]    8 bytes each (NROWS widened to i64, float min/max as
+ *                       order-preserving keys, like the dense table)
+ *
+ * records start GPUPREAGG_HASH_HEAD bytes into the table, after the head.
  *
  * A chunk is folded in two launches: gpupreagg_hash_check evaluates every
  * row for errors only; gpupreagg_hash_fold runs if the chunk is clean, so a
  * CpuReCheck still sends the WHOLE chunk back untouched (gpupreagg.c:2746-2750).
- * Accumulation is by global atomics: this path is for generality, the
- * dense kernels are the fast one.
+ * The fold keeps a small table of the same shape in LDS in front of the
+ * global one: rows of keys that found room there cost LDS atomics only and
+ * reach HBM once per work-group, the others go to the global table row by
+ * row.
  * ====================================================================== */
+#define GPUPREAGG_HASH_HEAD		256
+#define GPUPREAGG_HASH_RECLEN	(16 + 8 * (GPUPREAGG_NKEYS + GPUPREAGG_NAGGS))
+#define GPUPREAGG_HASH_STRIDE	(GPUPREAGG_HASH_RECLEN <= 32 ? 32 :					\
+								 GPUPREAGG_HASH_RECLEN <= 64 ? 64 :					\
+								 ((GPUPREAGG_HASH_RECLEN + 127) / 128 * 128))
+#define GPUPREAGG_HASH_LDS_PROBES	8
+
 struct gpupreagg_hash_head {
 	cl_uint		capacity;			/* power of two */
 	cl_uint		nkeys;
 	cl_uint		ngroups;			/* slots claimed so far */
 	cl_uint		overflow;			/* set when a probe found no free slot */
-	cl_ulong	off_state, off_knull, off_keys, off_flags;
-	cl_ulong	off_vals[GPUPREAGG_NAGGS + 1];
+	cl_uint		stride;				/* GPUPREAGG_HASH_STRIDE, checked by the host */
+	cl_uint		naggs;
 };
+
+STROM_DEVICE char *gpupreagg_hash_rec(char *htab, cl_uint slot)
+{ return htab + GPUPREAGG_HASH_HEAD + (size_t)slot * GPUPREAGG_HASH_STRIDE; }
+STROM_DEVICE const char *gpupreagg_hash_rec(const char *htab, cl_uint slot)
+{ return htab + GPUPREAGG_HASH_HEAD + (size_t)slot * GPUPREAGG_HASH_STRIDE; }
+#define HASH_REC_STATE(rec)		((cl_uint *)(rec))
+#define HASH_REC_KNULL(rec)		((cl_uint *)((rec) + 4))
+#define HASH_REC_FLAGS(rec)		((cl_uint *)((rec) + 8))
+#define HASH_REC_KEYS(rec)		((cl_ulong *)((rec) + 16))
+#define HASH_REC_VALS(rec)		((cl_ulong *)((rec) + 16) + GPUPREAGG_NKEYS)
 
 STROM_DEVICE cl_ulong strom_key_image(cl_char v)	{ return (cl_ulong)(cl_long)v; }
 STROM_DEVICE cl_ulong strom_key_image(cl_short v)	{ return (cl_ulong)(cl_long)v; }
@@ -1450,34 +1472,46 @@ gpupreagg_hash_of(const cl_ulong *kimg, cl_uint knull)
  * a lane that meets a slot somebody is still filling (state 1) just goes
  * round again, so the claimer -- possibly a lane of the SAME wave, whose
  * divergent block runs before or after ours but within this iteration --
- * always gets to publish.  Returns the slot, or ~0u when the table is full.
+ * always gets to publish.  Returns the slot, GPUPREAGG_HASH_FULL, or -- for a
+ * key that is not in the table while claim_limit groups are -- _DEFER: the
+ * host then grows the table and folds the deferred rows again.
  */
+#define GPUPREAGG_HASH_FULL		(~0u)
+#define GPUPREAGG_HASH_DEFER	(~1u)		/* a new group, but claim_limit groups exist: not now */
+
 template <bool MATCH>
 STROM_DEVICE cl_uint
-gpupreagg_hash_slot(gpupreagg_hash_head *head, cl_uint *h_state, cl_uint *h_knull, cl_ulong *h_keys,
-					const cl_ulong *kimg, cl_uint knull)
+gpupreagg_hash_slot(char *htab, cl_uint hash, const cl_ulong *kimg, cl_uint knull, cl_uint claim_limit)
 {
+	gpupreagg_hash_head *head = (gpupreagg_hash_head *)htab;
 	cl_uint		mask = head->capacity - 1;
-	cl_uint		slot = gpupreagg_hash_of(kimg, knull) & mask;
+	cl_uint		slot = hash & mask;
 	cl_uint		probes = 0;
 	cl_uint		result = ~0u;
 	bool		done = false;
 
 	for (cl_uint turns = 0; !done && turns < (1u << 28); turns++)
 	{
-		cl_uint	st = __hip_atomic_load(&h_state[slot], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+		char   *rec = gpupreagg_hash_rec(htab, slot);
+		cl_uint	st = __hip_atomic_load(HASH_REC_STATE(rec), __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
 
-		if (st == 0)
+		if (st == 0 && claim_limit != ~0u &&
+			__hip_atomic_load(&head->ngroups, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= claim_limit)
+		{
+			result = GPUPREAGG_HASH_DEFER;
+			done = true;
+		}
+		else if (st == 0)
 		{
 			cl_uint	expect = 0;
-			if (__hip_atomic_compare_exchange_strong(&h_state[slot], &expect, 1u,
+			if (__hip_atomic_compare_exchange_strong(HASH_REC_STATE(rec), &expect, 1u,
 													 __ATOMIC_ACQUIRE, __ATOMIC_ACQUIRE,
 													 __HIP_MEMORY_SCOPE_AGENT))
 			{
 				for (int k = 0; k < GPUPREAGG_NKEYS; k++)
-					h_keys[(size_t)slot * GPUPREAGG_NKEYS + k] = kimg[k];
-				h_knull[slot] = knull;
-				__hip_atomic_store(&h_state[slot], 2u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+					HASH_REC_KEYS(rec)[k] = kimg[k];
+				*HASH_REC_KNULL(rec) = knull;
+				__hip_atomic_store(HASH_REC_STATE(rec), 2u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
 				atomicAdd(&head->ngroups, 1u);
 				result = slot;
 				done = true;
@@ -1486,11 +1520,11 @@ gpupreagg_hash_slot(gpupreagg_hash_head *head, cl_uint *h_state, cl_uint *h_knul
 		}
 		else if (st == 2)
 		{
-			bool	same = (MATCH && h_knull[slot] == knull);
+			bool	same = (MATCH && *HASH_REC_KNULL(rec) == knull);
 			if (MATCH)
 			{
 				for (int k = 0; k < GPUPREAGG_NKEYS; k++)
-					same = same && (h_keys[(size_t)slot * GPUPREAGG_NKEYS + k] == kimg[k]);
+					same = same && (HASH_REC_KEYS(rec)[k] == kimg[k]);
 			}
 			if (same)
 			{
@@ -1508,29 +1542,123 @@ gpupreagg_hash_slot(gpupreagg_hash_head *head, cl_uint *h_state, cl_uint *h_knul
 	return result;
 }
 
+/* the same search in the work-group's LDS table, a few probes only */
+struct gpupreagg_hash_lds {
+	cl_uint	   *state;
+	cl_uint	   *knull;
+	cl_ulong   *keys;				/* [slots * NKEYS] */
+	cl_uint		mask;
+	cl_uint		shift;				/* 32 - log2(slots) */
+};
+
+STROM_DEVICE cl_uint
+gpupreagg_hash_lds_slot(const gpupreagg_hash_lds &T, cl_uint hash, const cl_ulong *kimg, cl_uint knull)
+{
+	cl_uint		slot = (hash * 0x9e3779b1u) >> T.shift;
+	cl_uint		probes = 0;
+	cl_uint		result = ~0u;
+	bool		done = false;
+
+	for (cl_uint turns = 0; !done && turns < (1u << 24); turns++)
+	{
+		cl_uint	st = __hip_atomic_load(&T.state[slot], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+
+		if (st == 0)
+		{
+			cl_uint	expect = 0;
+			if (__hip_atomic_compare_exchange_strong(&T.state[slot], &expect, 1u,
+													 __ATOMIC_ACQUIRE, __ATOMIC_ACQUIRE,
+													 __HIP_MEMORY_SCOPE_WORKGROUP))
+			{
+				for (int k = 0; k < GPUPREAGG_NKEYS; k++)
+					T.keys[slot * GPUPREAGG_NKEYS + k] = kimg[k];
+				T.knull[slot] = knull;
+				__hip_atomic_store(&T.state[slot], 2u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+				result = slot;
+				done = true;
+			}
+		}
+		else if (st == 2)
+		{
+			bool	same = (T.knull[slot] == knull);
+			for (int k = 0; k < GPUPREAGG_NKEYS; k++)
+				same = same && (T.keys[slot * GPUPREAGG_NKEYS + k] == kimg[k]);
+			if (same)
+			{
+				result = slot;
+				done = true;
+			}
+			else if (++probes >= GPUPREAGG_HASH_LDS_PROBES)
+				done = true;			/* no room nearby: this row goes to the global table */
+			else
+				slot = (slot + 1) & T.mask;
+		}
+	}
+	return result;
+}
+
+/* merge one 8-byte value (in its stored form) into a global accumulator */
+template <int OP, typename BASE>
+STROM_DEVICE void
+gpupreagg_hash_merge8(cl_ulong *addr, cl_ulong x)
+{
+	if (OP == GPUPREAGG_OP_NROWS || (OP == GPUPREAGG_OP_PSUM && !gpupreagg_is_float<BASE>::value))
+		__hip_atomic_fetch_add(addr, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+	else if (OP == GPUPREAGG_OP_PSUM)
+		__hip_atomic_fetch_add((cl_double *)addr, __longlong_as_double((long long)x),
+							   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+	else if (gpupreagg_is_float<BASE>::value)
+	{
+		if (OP == GPUPREAGG_OP_PMIN)
+			__hip_atomic_fetch_min(addr, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		else
+			__hip_atomic_fetch_max(addr, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+	}
+	else
+	{
+		if (OP == GPUPREAGG_OP_PMIN)
+			__hip_atomic_fetch_min((cl_long *)addr, (cl_long)x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		else
+			__hip_atomic_fetch_max((cl_long *)addr, (cl_long)x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+	}
+}
+
 template <bool IS_COLUMN, bool FOLD>
 __device__ __forceinline__ void
 gpupreagg_hash_body(kern_gpupreagg *kgpreagg,
 					const kern_data_store *kds,
 					const kern_data_store *ktoast,
 					const kern_row_map *krowmap,
-					char *htab, cl_uint row_lo, cl_uint row_hi)
+					char *htab, cl_uint claim_limit, kern_row_map *deferred,
+					cl_uint lds_slots, char *lds)
 {
 	const kern_parambuf *kparams = KERN_GPUPREAGG_PARAMBUF(kgpreagg);
 	gpupreagg_hash_head *head = (gpupreagg_hash_head *)htab;
 	bool		use_map = (krowmap != NULL && krowmap->nvalids >= 0);
 	cl_uint		nrows = (use_map ? (cl_uint)krowmap->nvalids : kds->nitems);
-	cl_uint	   *h_state = (cl_uint *)(htab + head->off_state);
-	cl_uint	   *h_knull = (cl_uint *)(htab + head->off_knull);
-	cl_ulong   *h_keys = (cl_ulong *)(htab + head->off_keys);
-	cl_uint	   *h_flags = (cl_uint *)(htab + head->off_flags);
 	cl_int		chunk_status = StromError_Success;
 	cl_int		param_error = StromError_Success;
 	strom_kparams KP;
+	gpupreagg_lds_layout L;
+	gpupreagg_hash_lds T;
 
 	if (FOLD && kgpreagg->status != StromError_Success)
 		return;							/* the check pass found a reason to send the chunk back */
 	gpupreagg_load_kparams(KP, kparams, &param_error);
+	if (FOLD)
+	{
+		/* LDS: the dense kernels' image for lds_slots slots, then the hash part */
+		gpupreagg_lds_layout_init(L, lds_slots, 1);
+		T.state = (cl_uint *)(lds + L.total);
+		T.knull = T.state + lds_slots;
+		T.keys = (cl_ulong *)(T.knull + lds_slots);
+		T.mask = lds_slots - 1;
+		T.shift = 32 - (31 - __clz((int)lds_slots));
+		gpupreagg_lds_init(lds, L, lds_slots, 1);
+		for (cl_uint i = threadIdx.x; i < lds_slots; i += blockDim.x)
+			T.state[i] = 0;
+		__syncthreads();
+	}
 	const bool	is_column = IS_COLUMN;
 	const cl_int chunk_format = kds->format;
 	const bool	row_family = (chunk_format == KDS_FORMAT_ROW || chunk_format == KDS_FORMAT_ROW_FLAT);
@@ -1541,9 +1669,7 @@ gpupreagg_hash_body(kern_gpupreagg *kgpreagg,
 		? (const cl_uint *)((const char *)kds + coldir_g[colidx].nulls_off) : NULL);
 	STROM_KVAR_LIST(X)
 #undef X
-	if (row_hi < nrows)
-		nrows = row_hi;					/* this launch folds rows [row_lo, row_hi) */
-	for (size_t r = (size_t)row_lo + (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+	for (size_t r = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
 		 r < nrows;
 		 r += (size_t)gridDim.x * blockDim.x)
 	{
@@ -1592,52 +1718,102 @@ gpupreagg_hash_body(kern_gpupreagg *kgpreagg,
 #undef X
 		if (!FOLD)
 			continue;
-		/* find or claim the group's slot */
-		cl_uint		slot = gpupreagg_hash_slot<true>(head, h_state, h_knull, h_keys, kimg, knull);
-		if (slot == ~0u)
+		cl_uint		hash = gpupreagg_hash_of(kimg, knull);
+		cl_uint		lslot = gpupreagg_hash_lds_slot(T, hash, kimg, knull);
+		cl_uint		need = GPUPREAGG_FLAG_SEEN;
+		if (lslot != ~0u)
+		{
+			/* the work-group's own table: LDS atomics, as in gpupreagg_dense_row */
+#define X(aidx,resno,OP,NAME)														\
+			need |= gpupreagg_lds_accum<GPUPREAGG_OP_##OP, aidx>(lds, L.vals_off[aidx], lslot, av_##aidx);
+			GPUPREAGG_AGG_LIST(X)
+#undef X
+			gpupreagg_flags_t *flags = (gpupreagg_flags_t *)lds;
+			if ((flags[lslot] & need) != need)
+			{
+				cl_uint *word = (cl_uint *)(lds + ((lslot * (cl_uint)sizeof(gpupreagg_flags_t)) & ~3u));
+				cl_uint	 shift = ((lslot * (cl_uint)sizeof(gpupreagg_flags_t)) & 3u) * 8u;
+				__hip_atomic_fetch_or(word, need << shift, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+			}
+			continue;
+		}
+		/* no room in LDS: straight to the global table */
+		cl_uint		slot = gpupreagg_hash_slot<true>(htab, hash, kimg, knull, claim_limit);
+		if (slot == GPUPREAGG_HASH_DEFER)
+		{
+			/* a new group and the table is at its fill limit: the host grows it
+			 * and sends this row again */
+			cl_uint	idx = atomicAdd((cl_uint *)&deferred->nvalids, 1u);
+			deferred->rindex[idx] = (cl_int)kds_index;
+			continue;
+		}
+		if (slot == GPUPREAGG_HASH_FULL)
 		{
 			head->overflow = 1;
 			continue;
 		}
-		cl_uint		need = GPUPREAGG_FLAG_SEEN;
+		char	   *rec = gpupreagg_hash_rec(htab, slot);
 #define X(aidx,resno,OP,NAME)														\
 		{																			\
 			typedef pg_##NAME##_base_t base_t;										\
-			cl_ulong   *vals = (cl_ulong *)(htab + head->off_vals[aidx]);			\
 			bool		has = !av_##aidx.isnull;									\
+			cl_ulong	x;															\
 			if (GPUPREAGG_OP_##OP == GPUPREAGG_OP_NROWS)							\
-			{																		\
-				if (has && av_##aidx.value != 0)									\
-					atomicAdd((unsigned long long *)&vals[slot],					\
-							  (unsigned long long)(cl_uint)av_##aidx.value);		\
-			}																		\
-			else if (has)															\
-			{																		\
+				x = (has ? (cl_ulong)(cl_uint)av_##aidx.value : 0);					\
+			else if (gpupreagg_is_float<base_t>::value)								\
+				x = (GPUPREAGG_OP_##OP == GPUPREAGG_OP_PSUM							\
+					 ? (cl_ulong)__double_as_longlong((cl_double)av_##aidx.value)	\
+					 : gpupreagg_f64_ordered((cl_double)av_##aidx.value));			\
+			else																	\
+				x = (cl_ulong)(cl_long)av_##aidx.value;								\
+			if (GPUPREAGG_OP_##OP != GPUPREAGG_OP_NROWS && has)						\
 				need |= (2u << aidx);												\
-				if (gpupreagg_is_float<base_t>::value)								\
-				{																	\
-					if (GPUPREAGG_OP_##OP == GPUPREAGG_OP_PSUM)						\
-						atomicAdd((cl_double *)&vals[slot], (cl_double)av_##aidx.value);	\
-					else if (GPUPREAGG_OP_##OP == GPUPREAGG_OP_PMIN)				\
-						atomicMin((unsigned long long *)&vals[slot],				\
-								  (unsigned long long)gpupreagg_f64_ordered((cl_double)av_##aidx.value));	\
-					else															\
-						atomicMax((unsigned long long *)&vals[slot],				\
-								  (unsigned long long)gpupreagg_f64_ordered((cl_double)av_##aidx.value));	\
-				}																	\
-				else if (GPUPREAGG_OP_##OP == GPUPREAGG_OP_PSUM)					\
-					atomicAdd((unsigned long long *)&vals[slot],					\
-							  (unsigned long long)(cl_long)av_##aidx.value);		\
-				else if (GPUPREAGG_OP_##OP == GPUPREAGG_OP_PMIN)					\
-					atomicMin((long long *)&vals[slot], (long long)av_##aidx.value);	\
-				else																\
-					atomicMax((long long *)&vals[slot], (long long)av_##aidx.value);	\
-			}																		\
+			if (has && !(GPUPREAGG_OP_##OP == GPUPREAGG_OP_NROWS && x == 0))		\
+				gpupreagg_hash_merge8<GPUPREAGG_OP_##OP, base_t>(HASH_REC_VALS(rec) + aidx, x);	\
 		}
 		GPUPREAGG_AGG_LIST(X)
 #undef X
-		if ((h_flags[slot] & need) != need)
-			atomicOr(&h_flags[slot], need);
+		if ((*HASH_REC_FLAGS(rec) & need) != need)
+			atomicOr(HASH_REC_FLAGS(rec), need);
+	}
+	if (FOLD)
+	{
+		/* the work-group's groups reach the global table once */
+		const gpupreagg_flags_t *lflags = (const gpupreagg_flags_t *)lds;
+		__syncthreads();
+		for (cl_uint s = threadIdx.x; s < lds_slots; s += blockDim.x)
+		{
+			if (T.state[s] != 2)
+				continue;
+			cl_ulong	kimg[GPUPREAGG_NKEYS + 1];
+			cl_uint		knull = T.knull[s];
+			for (int k = 0; k < GPUPREAGG_NKEYS; k++)
+				kimg[k] = T.keys[s * GPUPREAGG_NKEYS + k];
+			/* (no limit here: these rows are folded already; the host keeps
+			 * gridDim.x * lds_slots slots of headroom for this) */
+			cl_uint		slot = gpupreagg_hash_slot<true>(htab, gpupreagg_hash_of(kimg, knull), kimg, knull, ~0u);
+			if (slot == GPUPREAGG_HASH_FULL)
+			{
+				head->overflow = 1;
+				continue;
+			}
+			char	   *rec = gpupreagg_hash_rec(htab, slot);
+			cl_uint		lf = lflags[s];
+#define X(aidx,resno,OP,NAME)														\
+			if (GPUPREAGG_OP_##OP == GPUPREAGG_OP_NROWS)							\
+			{																		\
+				cl_uint c = ((const cl_uint *)(lds + L.vals_off[aidx]))[s];			\
+				if (c != 0)															\
+					gpupreagg_hash_merge8<GPUPREAGG_OP_NROWS, cl_long>(HASH_REC_VALS(rec) + aidx, (cl_ulong)c);	\
+			}																		\
+			else if (lf & (2u << aidx))												\
+				gpupreagg_hash_merge8<GPUPREAGG_OP_##OP, pg_##NAME##_base_t>		\
+					(HASH_REC_VALS(rec) + aidx, ((const cl_ulong *)(lds + L.vals_off[aidx]))[s]);
+			GPUPREAGG_AGG_LIST(X)
+#undef X
+			if ((*HASH_REC_FLAGS(rec) & lf) != lf)
+				atomicOr(HASH_REC_FLAGS(rec), lf);
+		}
 	}
 	gpupreagg_writeback_status(&kgpreagg->status, chunk_status);
 }
@@ -1646,24 +1822,25 @@ extern "C" __global__ void
 __launch_bounds__(256)
 gpupreagg_hash_check(kern_gpupreagg *kgpreagg, const kern_data_store *kds,
 					 const kern_data_store *ktoast, const kern_row_map *krowmap, char *htab,
-					 cl_uint row_lo, cl_uint row_hi)
+					 cl_uint claim_limit, kern_row_map *deferred, cl_uint lds_slots)
 {
 	if (kds->format == KDS_FORMAT_COLUMN)
-		gpupreagg_hash_body<true, false>(kgpreagg, kds, ktoast, krowmap, htab, row_lo, row_hi);
+		gpupreagg_hash_body<true, false>(kgpreagg, kds, ktoast, krowmap, htab, 0, NULL, 0, NULL);
 	else
-		gpupreagg_hash_body<false, false>(kgpreagg, kds, ktoast, krowmap, htab, row_lo, row_hi);
+		gpupreagg_hash_body<false, false>(kgpreagg, kds, ktoast, krowmap, htab, 0, NULL, 0, NULL);
 }
 
 extern "C" __global__ void
-__launch_bounds__(256)
+__launch_bounds__(GPUPREAGG_BLOCK)
 gpupreagg_hash_fold(kern_gpupreagg *kgpreagg, const kern_data_store *kds,
 					const kern_data_store *ktoast, const kern_row_map *krowmap, char *htab,
-					cl_uint row_lo, cl_uint row_hi)
+					cl_uint claim_limit, kern_row_map *deferred, cl_uint lds_slots)
 {
+	extern __shared__ __attribute__((aligned(16))) char lds[];
 	if (kds->format == KDS_FORMAT_COLUMN)
-		gpupreagg_hash_body<true, true>(kgpreagg, kds, ktoast, krowmap, htab, row_lo, row_hi);
+		gpupreagg_hash_body<true, true>(kgpreagg, kds, ktoast, krowmap, htab, claim_limit, deferred, lds_slots, lds);
 	else
-		gpupreagg_hash_body<false, true>(kgpreagg, kds, ktoast, krowmap, htab, row_lo, row_hi);
+		gpupreagg_hash_body<false, true>(kgpreagg, kds, ktoast, krowmap, htab, claim_limit, deferred, lds_slots, lds);
 }
 
 /* min / max accumulators start from their identities (sums from the zeroed table) */
@@ -1673,15 +1850,21 @@ gpupreagg_hash_init(char *htab)
 {
 	gpupreagg_hash_head *head = (gpupreagg_hash_head *)htab;
 	cl_uint		C = head->capacity;
+	for (cl_uint i = blockIdx.x * blockDim.x + threadIdx.x; i < C; i += gridDim.x * blockDim.x)
+	{
+		cl_ulong   *vals = HASH_REC_VALS(gpupreagg_hash_rec(htab, i));
 #define X(aidx,resno,OP,NAME)															\
-	if (GPUPREAGG_OP_##OP == GPUPREAGG_OP_PMIN || GPUPREAGG_OP_##OP == GPUPREAGG_OP_PMAX)	\
-	{																					\
-		cl_ulong   *vals = (cl_ulong *)(htab + head->off_vals[aidx]);					\
-		for (cl_uint i = blockIdx.x * blockDim.x + threadIdx.x; i < C; i += gridDim.x * blockDim.x)	\
-			vals[i] = gpupreagg_identity<GPUPREAGG_OP_##OP, pg_##NAME##_base_t>();		\
-	}
-	GPUPREAGG_AGG_LIST(X)
+		if (GPUPREAGG_OP_##OP == GPUPREAGG_OP_PMIN || GPUPREAGG_OP_##OP == GPUPREAGG_OP_PMAX)	\
+			vals[aidx] = gpupreagg_identity<GPUPREAGG_OP_##OP, pg_##NAME##_base_t>();
+		GPUPREAGG_AGG_LIST(X)
 #undef X
+		(void)vals;
+	}
+	if (blockIdx.x == 0 && threadIdx.x == 0)
+	{
+		head->stride = GPUPREAGG_HASH_STRIDE;
+		head->naggs = GPUPREAGG_NAGGS;
+	}
 }
 
 /*
@@ -1694,17 +1877,14 @@ __launch_bounds__(256)
 gpupreagg_hash_export(const char *htab, char *out, cl_uint *counter)
 {
 	const gpupreagg_hash_head *head = (const gpupreagg_hash_head *)htab;
-	const cl_uint  *h_state = (const cl_uint *)(htab + head->off_state);
-	const cl_uint  *h_knull = (const cl_uint *)(htab + head->off_knull);
-	const cl_ulong *h_keys = (const cl_ulong *)(htab + head->off_keys);
-	const cl_uint  *h_flags = (const cl_uint *)(htab + head->off_flags);
 	const size_t	reclen = 8 + 8 * (GPUPREAGG_NKEYS + GPUPREAGG_NAGGS);
 	cl_uint		C = head->capacity;
 
 	for (cl_uint base = blockIdx.x * blockDim.x; base < C; base += gridDim.x * blockDim.x)
 	{
 		cl_uint		i = base + threadIdx.x;
-		bool		ready = (i < C && h_state[i] == 2);
+		const char *src = gpupreagg_hash_rec(htab, i < C ? i : 0);
+		bool		ready = (i < C && *HASH_REC_STATE(src) == 2);
 		cl_ulong	mask = __ballot(ready);
 		cl_uint		first = 0;
 		/* one reservation per wave */
@@ -1717,15 +1897,11 @@ gpupreagg_hash_export(const char *htab, char *out, cl_uint *counter)
 			continue;
 		cl_uint		idx = first + (cl_uint)__popcll(mask & ((1UL << strom_lane_id()) - 1));
 		char	   *rec = out + reclen * idx;
-		((cl_uint *)rec)[0] = h_knull[i];
-		((cl_uint *)rec)[1] = h_flags[i];
+		((cl_uint *)rec)[0] = *HASH_REC_KNULL(src);
+		((cl_uint *)rec)[1] = *HASH_REC_FLAGS(src);
 		cl_ulong   *body = (cl_ulong *)(rec + 8);
-		for (int k = 0; k < GPUPREAGG_NKEYS; k++)
-			body[k] = h_keys[(size_t)i * GPUPREAGG_NKEYS + k];
-#define X(aidx,resno,OP,NAME)															\
-		body[GPUPREAGG_NKEYS + aidx] = ((const cl_ulong *)(htab + head->off_vals[aidx]))[i];
-		GPUPREAGG_AGG_LIST(X)
-#undef X
+		for (int k = 0; k < GPUPREAGG_NKEYS + GPUPREAGG_NAGGS; k++)
+			body[k] = HASH_REC_KEYS(src)[k];
 	}
 }
 
@@ -1736,35 +1912,27 @@ gpupreagg_hash_rehash(const char *otab, char *ntab)
 {
 	const gpupreagg_hash_head *ohead = (const gpupreagg_hash_head *)otab;
 	gpupreagg_hash_head *nhead = (gpupreagg_hash_head *)ntab;
-	const cl_uint  *o_state = (const cl_uint *)(otab + ohead->off_state);
-	const cl_uint  *o_knull = (const cl_uint *)(otab + ohead->off_knull);
-	const cl_ulong *o_keys = (const cl_ulong *)(otab + ohead->off_keys);
-	const cl_uint  *o_flags = (const cl_uint *)(otab + ohead->off_flags);
-	cl_uint	   *n_state = (cl_uint *)(ntab + nhead->off_state);
-	cl_uint	   *n_knull = (cl_uint *)(ntab + nhead->off_knull);
-	cl_ulong   *n_keys = (cl_ulong *)(ntab + nhead->off_keys);
-	cl_uint	   *n_flags = (cl_uint *)(ntab + nhead->off_flags);
 	cl_uint		C = ohead->capacity;
 
 	for (cl_uint i = blockIdx.x * blockDim.x + threadIdx.x; i < C; i += gridDim.x * blockDim.x)
 	{
-		if (o_state[i] != 2)
+		const char *src = gpupreagg_hash_rec(otab, i);
+		if (*HASH_REC_STATE(src) != 2)
 			continue;
 		cl_ulong	kimg[GPUPREAGG_NKEYS + 1];
+		cl_uint		knull = *HASH_REC_KNULL(src);
 		for (int k = 0; k < GPUPREAGG_NKEYS; k++)
-			kimg[k] = o_keys[(size_t)i * GPUPREAGG_NKEYS + k];
-		cl_uint		slot = gpupreagg_hash_slot<false>(nhead, n_state, n_knull, n_keys, kimg, o_knull[i]);
-		if (slot == ~0u)
+			kimg[k] = HASH_REC_KEYS(src)[k];
+		cl_uint		slot = gpupreagg_hash_slot<false>(ntab, gpupreagg_hash_of(kimg, knull), kimg, knull, ~0u);
+		if (slot == GPUPREAGG_HASH_FULL)
 		{
 			nhead->overflow = 1;
 			continue;
 		}
-		n_flags[slot] = o_flags[i];
-#define X(aidx,resno,OP,NAME)															\
-		((cl_ulong *)(ntab + nhead->off_vals[aidx]))[slot] =							\
-			((const cl_ulong *)(otab + ohead->off_vals[aidx]))[i];
-		GPUPREAGG_AGG_LIST(X)
-#undef X
+		char	   *dst = gpupreagg_hash_rec(ntab, slot);
+		*HASH_REC_FLAGS(dst) = *HASH_REC_FLAGS(src);
+		for (int a = 0; a < GPUPREAGG_NAGGS; a++)
+			HASH_REC_VALS(dst)[a] = HASH_REC_VALS(src)[a];
 	}
 }
 

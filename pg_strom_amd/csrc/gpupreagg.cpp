@@ -442,35 +442,47 @@ gpupreagg_launch(strom_task_impl *task, preagg_request req)
  * hashed GROUP BY (gpupreagg_hash_* of strom_gpupreagg.h)
  * ------------------------------------------------------------------ */
 
-/* host image of struct gpupreagg_hash_head: 16 + 8 * (4 + naggs + 1) bytes */
+/* host image of the table: head (GPUPREAGG_HASH_HEAD bytes), then one record
+ * per slot { state, knull, flags, pad, keys[nkeys], vals[naggs] } */
 struct hash_layout {
 	std::vector<char> head;
+	size_t		stride;
 	size_t		total;
 };
+
+const size_t HASH_HEAD_LEN = 256;
 
 hash_layout
 hash_table_layout(const strom_gpupreagg *sess, cl_uint capacity)
 {
 	hash_layout	L;
 	size_t		nkeys = sess->key_resno.size(), naggs = sess->agg_resno.size();
-	size_t		head_len = STROM_TYPEALIGN(256, 16 + 8 * (4 + naggs + 1));
-	size_t		off = head_len;
-	std::vector<cl_ulong> offs;
+	size_t		reclen = 16 + 8 * (nkeys + naggs);
 
-	auto section = [&](size_t bytes) { offs.push_back(off); off += STROM_TYPEALIGN(256, bytes); };
-	section(4 * (size_t)capacity);					/* state */
-	section(4 * (size_t)capacity);					/* knull */
-	section(8 * (size_t)capacity * std::max<size_t>(nkeys, 1));	/* keys */
-	section(4 * (size_t)capacity);					/* flags */
-	for (size_t a = 0; a < naggs; a++)
-		section(8 * (size_t)capacity);
-	offs.push_back(off);
-	L.total = off;
-	L.head.assign(head_len, 0);
-	cl_uint	words[4] = { capacity, (cl_uint)nkeys, 0, 0 };
+	L.stride = (reclen <= 32 ? 32 : reclen <= 64 ? 64 : (reclen + 127) / 128 * 128);
+	L.total = HASH_HEAD_LEN + L.stride * (size_t)capacity;
+	L.head.assign(HASH_HEAD_LEN, 0);
+	cl_uint	words[6] = { capacity, (cl_uint)nkeys, 0, 0, (cl_uint)L.stride, (cl_uint)naggs };
 	memcpy(L.head.data(), words, sizeof(words));
-	memcpy(L.head.data() + 16, offs.data(), 8 * offs.size());
 	return L;
+}
+
+/* slots of the work-group's LDS table in front of the global one, and its bytes */
+cl_uint
+hash_lds_slots(const strom_gpupreagg *sess, size_t *p_bytes)
+{
+	size_t		nkeys = sess->key_resno.size();
+	cl_uint		slots = 4096;
+	size_t		bytes;
+	for (;;)
+	{
+		bytes = sess->image_offset(sess->nsections(), slots, 1) + (size_t)slots * (8 + 8 * nkeys);
+		if (bytes <= 64 * 1024 || slots == 64)
+			break;
+		slots >>= 1;
+	}
+	*p_bytes = bytes;
+	return slots;
 }
 
 /* a zeroed, initialised table of 'capacity' slots on the session's stream */
@@ -525,66 +537,52 @@ hash_table_ngroups(strom_gpupreagg *sess, cl_uint *p_ngroups, cl_uint *p_overflo
 }
 
 /*
- * room for the next rows.  A fold of n rows can claim at most n new slots,
- * so with groups_upper + n <= 3/4 capacity a probe always ends at a free
- * slot.  Returns how many rows may be folded now (>= 1), growing the table
- * (x4 at least, old groups re-inserted by gpupreagg_hash_rehash) when less
- * than min(want, 2^20) would fit.
+ * a table of at least min_capacity slots, the groups of the current one
+ * re-inserted by gpupreagg_hash_rehash (drains the stream)
  */
 int
-hash_table_reserve(strom_gpupreagg *sess, cl_ulong want, cl_ulong *p_rows)
+hash_table_grow(strom_gpupreagg *sess, cl_ulong min_capacity)
 {
 	Device	   *dev = sess->dev;
-	cl_ulong	floor_rows = std::min<cl_ulong>(want, 1UL << 20);
-	auto avail = [&]() -> cl_ulong {
-		cl_ulong limit = (cl_ulong)sess->hash_capacity / 4 * 3;
-		return limit > sess->groups_upper ? limit - sess->groups_upper : 0;
-	};
+	cl_ulong	capacity = sess->hash_capacity;
+	cl_uint		ngroups = 0;
+	int			rc = hash_table_ngroups(sess, &ngroups, nullptr);
 
-	if (avail() < floor_rows)
+	if (rc)
+		return rc;
+	while (capacity < min_capacity)
+		capacity <<= 1;
+	if (capacity > (1UL << 31))
+		return StromError_DataStoreNoSpace;
+	if (capacity == sess->hash_capacity)
+		return 0;
+	char	   *ntab = nullptr;
+	size_t		nbytes = 0;
+	rc = hash_table_new(sess, (cl_uint)capacity, &ntab, &nbytes, nullptr);
+	if (rc)
+		return rc;
+	if (ngroups > 0)
 	{
-		cl_uint	ngroups = 0;
-		int		rc = hash_table_ngroups(sess, &ngroups, nullptr);
-		if (rc)
-			return rc;
-		sess->groups_upper = ngroups;
-		if (avail() < floor_rows)
+		int		errcode = 0;
+		hipFunction_t fn = sess->prog->get_function(dev, "gpupreagg_hash_rehash", &errcode);
+		const void *a_old = sess->htab;
+		void	   *a_new = ntab;
+		void	   *args[] = { &a_old, &a_new };
+		unsigned	grid = std::min<unsigned>((sess->hash_capacity + 255) / 256,
+											  (unsigned)dev->prop.multiProcessorCount * 8);
+		if (!fn ||
+			hipModuleLaunchKernel(fn, grid, 1, 1, 256, 1, 1, 0, dev->streams[0], args, nullptr) != hipSuccess ||
+			hipStreamSynchronize(dev->streams[0]) != hipSuccess)
 		{
-			cl_ulong	need = ((cl_ulong)ngroups + floor_rows) * 2;
-			cl_ulong	capacity = (cl_ulong)sess->hash_capacity * 4;
-			while (capacity < need)
-				capacity <<= 1;
-			if (capacity > (1UL << 31))
-				return StromError_DataStoreNoSpace;
-			char	   *ntab = nullptr;
-			size_t		nbytes = 0;
-			rc = hash_table_new(sess, (cl_uint)capacity, &ntab, &nbytes, nullptr);
-			if (rc)
-				return rc;
-			if (ngroups > 0)
-			{
-				int		errcode = 0;
-				hipFunction_t fn = sess->prog->get_function(dev, "gpupreagg_hash_rehash", &errcode);
-				const void *a_old = sess->htab;
-				void	   *a_new = ntab;
-				void	   *args[] = { &a_old, &a_new };
-				unsigned	grid = std::min<unsigned>((sess->hash_capacity + 255) / 256,
-													  (unsigned)dev->prop.multiProcessorCount * 8);
-				if (!fn ||
-					hipModuleLaunchKernel(fn, grid, 1, 1, 256, 1, 1, 0, dev->streams[0], args, nullptr) != hipSuccess ||
-					hipStreamSynchronize(dev->streams[0]) != hipSuccess)
-				{
-					dev->pool.release(ntab);
-					return fn ? StromError_HipInternal : errcode;
-				}
-			}
-			dev->pool.release(sess->htab);
-			sess->htab = ntab;
-			sess->htab_bytes = nbytes;
-			sess->hash_capacity = (cl_uint)capacity;
+			dev->pool.release(ntab);
+			return fn ? StromError_HipInternal : errcode;
 		}
 	}
-	*p_rows = std::min<cl_ulong>(want, avail());
+	dev->pool.release(sess->htab);
+	sess->htab = ntab;
+	sess->htab_bytes = nbytes;
+	sess->hash_capacity = (cl_uint)capacity;
+	sess->groups_upper = ngroups;
 	return 0;
 }
 
@@ -612,8 +610,23 @@ gpupreagg_launch_hashed(strom_task_impl *task, preagg_request req)
 		task_fail(task, errcode);
 		return;
 	}
+	/*
+	 * geometry: two work-groups per CU (64 KB of LDS each).  Slots can be
+	 * claimed past the fill limit by threads that raced through the limit test
+	 * (one each at most) and by the work-groups' final LDS flushes: that much
+	 * headroom, and an eighth of the table on top, always stays free.
+	 */
+	size_t		lds_bytes = 0;
+	cl_uint		lds_slots = hash_lds_slots(sess, &lds_bytes);
+	unsigned	block = (unsigned)sess->block;
+	unsigned	fold_grid = (unsigned)dev->prop.multiProcessorCount * 2;
+	cl_ulong	headroom = (cl_ulong)fold_grid * block + (cl_ulong)fold_grid * lds_slots;
 	if (!sess->htab)
 	{
+		cl_ulong	capacity = sess->hash_capacity;
+		while (capacity < 4 * headroom)
+			capacity <<= 1;
+		sess->hash_capacity = (cl_uint)capacity;
 		int rc = hash_table_new(sess, sess->hash_capacity, &sess->htab, &sess->htab_bytes, nullptr);
 		if (rc)
 		{
@@ -685,35 +698,89 @@ gpupreagg_launch_hashed(strom_task_impl *task, preagg_request req)
 		const void *a_map = d_rowmap;
 		cl_uint		nrows = req.nrows;
 		unsigned	maxgrid = (unsigned)dev->prop.multiProcessorCount * 8;
+		cl_uint		no_limit = ~0u;
+		void	   *a_nodefer = nullptr;
 		/* pass 1: errors only -- a chunk with a CpuReCheck row is not folded at all */
 		{
 			void	   *a_tab = sess->htab;
-			cl_uint		lo = 0, hi = nrows;
-			void	   *args[] = { &a_kg, &a_kds, &a_toast, &a_map, &a_tab, &lo, &hi };
+			void	   *args[] = { &a_kg, &a_kds, &a_toast, &a_map, &a_tab, &no_limit, &a_nodefer, &lds_slots };
 			unsigned	grid = std::max(1u, std::min<unsigned>((nrows + 255) / 256, maxgrid));
 			REQ_CHECK(hipModuleLaunchKernel(fn_check, grid, 1, 1, 256, 1, 1, 0, task->stream, args, nullptr),
 					  "launch gpupreagg hash check");
 			task->pfm.num_kern_exec++;
 		}
-		/* pass 2: fold, as many rows at a time as the table has guaranteed room for */
-		for (cl_uint lo = 0; lo < nrows; )
+		/*
+		 * pass 2: fold.  While even nrows new groups fit under the fill limit
+		 * nothing can be deferred and the task stays asynchronous; otherwise
+		 * rows that need a new group beyond the limit come back as a row map,
+		 * the table grows, and they are folded again.
+		 */
+		cl_uint		todo = nrows;
+		void	   *d_defer[2] = { nullptr, nullptr };
+		int			turn = 0;
+		while (todo > 0)
 		{
-			cl_ulong	rows = 0;
-			int			rc = hash_table_reserve(sess, nrows - lo, &rows);
-			if (rc != 0 || rows == 0)
+			cl_ulong	fill_limit = (cl_ulong)sess->hash_capacity / 8 * 7 - headroom;
+			if (sess->groups_upper + todo > fill_limit)
 			{
-				task_fail(task, rc ? rc : StromError_DataStoreNoSpace);
-				return;
+				/* the bound is stale or the table is small: look */
+				cl_uint	ngroups = 0;
+				int		rc = hash_table_ngroups(sess, &ngroups, nullptr);
+				if (rc == 0)
+				{
+					sess->groups_upper = ngroups;
+					if (turn > 0 || (cl_ulong)ngroups * 2 > fill_limit)
+						rc = hash_table_grow(sess, (cl_ulong)sess->hash_capacity * 4);	/* geometric: the deferred
+																						 * rows say little about
+																						 * the groups among them */
+				}
+				if (rc)
+				{
+					task_fail(task, rc);
+					return;
+				}
+				fill_limit = (cl_ulong)sess->hash_capacity / 8 * 7 - headroom;
 			}
+			bool		may_defer = (sess->groups_upper + todo > fill_limit);
+			cl_uint		claim_limit = (may_defer ? (cl_uint)fill_limit : no_limit);
 			void	   *a_tab = sess->htab;
-			cl_uint		hi = lo + (cl_uint)rows;
-			void	   *args[] = { &a_kg, &a_kds, &a_toast, &a_map, &a_tab, &lo, &hi };
-			unsigned	grid = std::max(1u, std::min<unsigned>(((cl_uint)rows + 255) / 256, maxgrid));
-			REQ_CHECK(hipModuleLaunchKernel(fn_fold, grid, 1, 1, 256, 1, 1, 0, task->stream, args, nullptr),
+			void	   *a_defer = nullptr;
+			if (may_defer)
+			{
+				size_t	len = offsetof(kern_row_map, rindex) + sizeof(cl_int) * (size_t)todo;
+				if (!d_defer[turn & 1])
+				{
+					d_defer[turn & 1] = dev->pool.alloc(len);
+					if (!d_defer[turn & 1])
+					{
+						task_fail(task, StromError_OutOfMemory);
+						return;
+					}
+					task->devbufs.push_back(d_defer[turn & 1]);
+				}
+				a_defer = d_defer[turn & 1];
+				REQ_CHECK(hipMemsetAsync(a_defer, 0, offsetof(kern_row_map, rindex), task->stream),
+						  "reset deferred rows");
+			}
+			void	   *args[] = { &a_kg, &a_kds, &a_toast, &a_map, &a_tab, &claim_limit, &a_defer, &lds_slots };
+			unsigned	grid = std::max(1u, std::min<unsigned>((todo + block - 1) / block, fold_grid));
+			REQ_CHECK(hipModuleLaunchKernel(fn_fold, grid, 1, 1, block, 1, 1, (unsigned)lds_bytes,
+											task->stream, args, nullptr),
 					  "launch gpupreagg hash fold");
 			task->pfm.num_kern_exec++;
-			sess->groups_upper += rows;
-			lo = hi;
+			if (!may_defer)
+			{
+				sess->groups_upper += todo;
+				break;
+			}
+			cl_int		ndeferred = 0;
+			REQ_CHECK(hipMemcpyAsync(&ndeferred, a_defer, sizeof(cl_int), hipMemcpyDeviceToHost, task->stream),
+					  "recv deferred rows");
+			REQ_CHECK(hipStreamSynchronize(task->stream), "fold");
+			sess->groups_upper = std::min<cl_ulong>(sess->groups_upper + todo, sess->hash_capacity);
+			todo = (cl_uint)ndeferred;
+			a_map = a_defer;			/* the deferred rows are the next launch's row map */
+			turn++;
 		}
 	}
 	task_event(task);									/* ev[2] */

@@ -440,12 +440,13 @@ def test_hashed_numeric_key_groups_by_value_not_by_image():
 
 
 def test_hashed_table_grows_with_the_group_count():
-    """300k distinct int8 keys through a table that starts at 65536 slots; three
-    chunks, the same keys again in the last one"""
+    """4M distinct int8 keys: more than the first table's fill limit, so rows of
+    new groups are deferred, the table grows (device re-insert) and they are
+    folded again; three chunks, the same keys again in the last one"""
     rng = np.random.default_rng(43)
-    nkeys = 300000
+    nkeys = 4000000
     universe = rng.permutation(np.arange(nkeys, dtype=np.int64) * 1000003 - 7 * 10**10)
-    chunks = [universe[:120000], universe[120000:], universe[::3]]
+    chunks = [universe[:1500000], universe[1500000:], universe[::3]]
     agg = GpuPreAgg("(gpupreagg (key (var 1 int8)) (nrows) (psum (int8 (var 2 int4))) (pmax (var 2 int4)))").begin_hashed()
     vals = []
     for c in chunks:
