@@ -1630,7 +1630,7 @@ gpupreagg_hash_body(kern_gpupreagg *kgpreagg,
 					const kern_data_store *ktoast,
 					const kern_row_map *krowmap,
 					char *htab, cl_uint claim_limit, kern_row_map *deferred,
-					cl_uint lds_slots, char *lds)
+					cl_uint lds_slots, cl_uint nroles, char *lds)
 {
 	const kern_parambuf *kparams = KERN_GPUPREAGG_PARAMBUF(kgpreagg);
 	gpupreagg_hash_head *head = (gpupreagg_hash_head *)htab;
@@ -1669,10 +1669,25 @@ gpupreagg_hash_body(kern_gpupreagg *kgpreagg,
 		? (const cl_uint *)((const char *)kds + coldir_g[colidx].nulls_off) : NULL);
 	STROM_KVAR_LIST(X)
 #undef X
-	for (size_t r = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-		 r < nrows;
-		 r += (size_t)gridDim.x * blockDim.x)
+	/*
+	 * who folds what.  More groups than one LDS table holds: the work-groups
+	 * take ROLES, role j folds the keys whose hash says j and skips the others
+	 * right after hashing, so each role's groups fit its LDS table again (the
+	 * dense kernels split their id range the same way).  Work-group i runs on
+	 * XCD i % 8: the tiles are dealt to the XCDs, and inside an XCD all roles
+	 * walk the same tiles, so the repeated reads meet in that XCD's L2.
+	 * gridDim.x is a multiple of 8 * nroles (nroles a power of two).
+	 */
+	cl_uint		xcd = blockIdx.x & 7;
+	cl_uint		local = blockIdx.x >> 3;
+	cl_uint		role = local & (nroles - 1);
+	cl_uint		member = local / nroles;
+	cl_uint		nmembers = (gridDim.x >> 3) / nroles;
+	for (size_t tile = xcd + 8 * (size_t)member; tile * blockDim.x < nrows; tile += 8 * (size_t)nmembers)
 	{
+		size_t		r = tile * blockDim.x + threadIdx.x;
+		if (r >= nrows)
+			continue;
 		cl_uint		kds_index = (use_map ? (cl_uint)krowmap->rindex[r] : (cl_uint)r);
 		strom_kvars	KV;
 		cl_int		errcode = param_error;
@@ -1700,6 +1715,10 @@ gpupreagg_hash_body(kern_gpupreagg *kgpreagg,
 		}
 		GPUPREAGG_KEY_LIST(X)
 #undef X
+		/* another role's key (the check pass has seen this row's errors) */
+		cl_uint		hash = gpupreagg_hash_of(kimg, knull);
+		if (FOLD && errcode == StromError_Success && ((hash >> 7) & (nroles - 1)) != role)
+			continue;
 #define X(aidx,resno,OP,NAME)														\
 		pg_##NAME##_t av_##aidx = gpupreagg_agg_##aidx(&errcode, KP, KV);
 		GPUPREAGG_AGG_LIST(X)
@@ -1718,7 +1737,6 @@ gpupreagg_hash_body(kern_gpupreagg *kgpreagg,
 #undef X
 		if (!FOLD)
 			continue;
-		cl_uint		hash = gpupreagg_hash_of(kimg, knull);
 		cl_uint		lslot = gpupreagg_hash_lds_slot(T, hash, kimg, knull);
 		cl_uint		need = GPUPREAGG_FLAG_SEEN;
 		if (lslot != ~0u)
@@ -1822,25 +1840,27 @@ extern "C" __global__ void
 __launch_bounds__(256)
 gpupreagg_hash_check(kern_gpupreagg *kgpreagg, const kern_data_store *kds,
 					 const kern_data_store *ktoast, const kern_row_map *krowmap, char *htab,
-					 cl_uint claim_limit, kern_row_map *deferred, cl_uint lds_slots)
+					 cl_uint claim_limit, kern_row_map *deferred, cl_uint lds_slots, cl_uint nroles)
 {
 	if (kds->format == KDS_FORMAT_COLUMN)
-		gpupreagg_hash_body<true, false>(kgpreagg, kds, ktoast, krowmap, htab, 0, NULL, 0, NULL);
+		gpupreagg_hash_body<true, false>(kgpreagg, kds, ktoast, krowmap, htab, 0, NULL, 0, 1, NULL);
 	else
-		gpupreagg_hash_body<false, false>(kgpreagg, kds, ktoast, krowmap, htab, 0, NULL, 0, NULL);
+		gpupreagg_hash_body<false, false>(kgpreagg, kds, ktoast, krowmap, htab, 0, NULL, 0, 1, NULL);
 }
 
 extern "C" __global__ void
 __launch_bounds__(GPUPREAGG_BLOCK)
 gpupreagg_hash_fold(kern_gpupreagg *kgpreagg, const kern_data_store *kds,
 					const kern_data_store *ktoast, const kern_row_map *krowmap, char *htab,
-					cl_uint claim_limit, kern_row_map *deferred, cl_uint lds_slots)
+					cl_uint claim_limit, kern_row_map *deferred, cl_uint lds_slots, cl_uint nroles)
 {
 	extern __shared__ __attribute__((aligned(16))) char lds[];
 	if (kds->format == KDS_FORMAT_COLUMN)
-		gpupreagg_hash_body<true, true>(kgpreagg, kds, ktoast, krowmap, htab, claim_limit, deferred, lds_slots, lds);
+		gpupreagg_hash_body<true, true>(kgpreagg, kds, ktoast, krowmap, htab, claim_limit, deferred,
+										lds_slots, nroles, lds);
 	else
-		gpupreagg_hash_body<false, true>(kgpreagg, kds, ktoast, krowmap, htab, claim_limit, deferred, lds_slots, lds);
+		gpupreagg_hash_body<false, true>(kgpreagg, kds, ktoast, krowmap, htab, claim_limit, deferred,
+										 lds_slots, nroles, lds);
 }
 
 /* min / max accumulators start from their identities (sums from the zeroed table) */

@@ -25,10 +25,12 @@ ingest_get_tuple(const kern_data_store *src, cl_uint row)
 	return NULL;
 }
 
-extern "C" __global__ void
-__launch_bounds__(256)
-ingest_to_column(const kern_data_store *__restrict__ src, kern_data_store *__restrict__ dst,
-				 const cl_int *__restrict__ type_oids, cl_uint *__restrict__ col_has_null)
+/* VARNUM: some column is a varlena NUMERIC to decode (fixed per launch, so the
+ * common all-fixed-width chunk does not carry the decoder) */
+template <bool VARNUM>
+__device__ __forceinline__ void
+ingest_to_column_body(const kern_data_store *__restrict__ src, kern_data_store *__restrict__ dst,
+					  const cl_int *__restrict__ type_oids, cl_uint *__restrict__ col_has_null)
 {
 	/* per work-group NULL flags (global stores to one address serialise) */
 	__shared__ cl_uint	s_hasnull[INGEST_MAXCOLS];
@@ -103,7 +105,7 @@ ingest_to_column(const kern_data_store *__restrict__ src, kern_data_store *__res
 			}
 			/* a varlena NUMERIC becomes the 8-byte device form (canonical
 			 * image); one that does not fit fails the whole conversion */
-			if (cm.attlen < 0 && type_oids != NULL && type_oids[c] == STROM_NUMERICOID)
+			if (VARNUM && cm.attlen < 0 && type_oids != NULL && type_oids[c] == STROM_NUMERICOID)
 			{
 				if (valid)
 				{
@@ -165,6 +167,22 @@ ingest_to_column(const kern_data_store *__restrict__ src, kern_data_store *__res
 	}
 	if (threadIdx.x == 0 && s_failed)
 		col_has_null[ncols] = 1;			/* slot after the flags: conversion failed */
+}
+
+extern "C" __global__ void
+__launch_bounds__(256)
+ingest_to_column(const kern_data_store *__restrict__ src, kern_data_store *__restrict__ dst,
+				 const cl_int *__restrict__ type_oids, cl_uint *__restrict__ col_has_null)
+{
+	ingest_to_column_body<false>(src, dst, type_oids, col_has_null);
+}
+
+extern "C" __global__ void
+__launch_bounds__(256)
+ingest_to_column_varnum(const kern_data_store *__restrict__ src, kern_data_store *__restrict__ dst,
+						const cl_int *__restrict__ type_oids, cl_uint *__restrict__ col_has_null)
+{
+	ingest_to_column_body<true>(src, dst, type_oids, col_has_null);
 }
 
 /*

@@ -12,6 +12,7 @@
  * the job clserv_compute_workgroup_size + the sort-size heuristics
  * (gpupreagg.c:4105-4141) do in the reference.
  */
+#include <atomic>
 #include <cstring>
 #include <cstdio>
 #include <algorithm>
@@ -70,6 +71,7 @@ struct strom_gpupreagg {
 	size_t				htab_bytes = 0;
 	cl_uint				hash_capacity = 0;
 	cl_ulong			groups_upper = 0;	/* groups known at the last read-back + rows folded since */
+	std::atomic<cl_uint> groups_known{0};	/* groups at the last read-back (or the caller's hint) */
 	int					reg_groups = 0;		/* 1: register accumulators, 2: lane-private LDS, 0: LDS atomics */
 	std::mutex			lock;
 
@@ -531,6 +533,7 @@ hash_table_ngroups(strom_gpupreagg *sess, cl_uint *p_ngroups, cl_uint *p_overflo
 		hipMemcpy(words, sess->htab, sizeof(words), hipMemcpyDeviceToHost) != hipSuccess)
 		return StromError_HipInternal;
 	*p_ngroups = words[2];
+	sess->groups_known = std::max<cl_uint>(sess->groups_known, words[2]);
 	if (p_overflow)
 		*p_overflow = words[3];
 	return 0;
@@ -703,8 +706,11 @@ gpupreagg_launch_hashed(strom_task_impl *task, preagg_request req)
 		/* pass 1: errors only -- a chunk with a CpuReCheck row is not folded at all */
 		{
 			void	   *a_tab = sess->htab;
-			void	   *args[] = { &a_kg, &a_kds, &a_toast, &a_map, &a_tab, &no_limit, &a_nodefer, &lds_slots };
-			unsigned	grid = std::max(1u, std::min<unsigned>((nrows + 255) / 256, maxgrid));
+			cl_uint		one_role = 1;
+			void	   *args[] = { &a_kg, &a_kds, &a_toast, &a_map, &a_tab, &no_limit, &a_nodefer, &lds_slots,
+								   &one_role };
+			/* (the kernels deal tiles to 8 XCDs: grids are multiples of 8) */
+			unsigned	grid = std::max(8u, std::min<unsigned>((nrows + 255) / 256 + 7, maxgrid) & ~7u);
 			REQ_CHECK(hipModuleLaunchKernel(fn_check, grid, 1, 1, 256, 1, 1, 0, task->stream, args, nullptr),
 					  "launch gpupreagg hash check");
 			task->pfm.num_kern_exec++;
@@ -762,8 +768,31 @@ gpupreagg_launch_hashed(strom_task_impl *task, preagg_request req)
 				REQ_CHECK(hipMemsetAsync(a_defer, 0, offsetof(kern_row_map, rindex), task->stream),
 						  "reset deferred rows");
 			}
-			void	   *args[] = { &a_kg, &a_kds, &a_toast, &a_map, &a_tab, &claim_limit, &a_defer, &lds_slots };
-			unsigned	grid = std::max(1u, std::min<unsigned>((todo + block - 1) / block, fold_grid));
+			/*
+			 * roles: as many as it takes for a role's share of the groups seen so
+			 * far to sit in its LDS table at ~60 % fill; beyond 64 roles (each row
+			 * is hashed once per role) the global table is the better place
+			 */
+			cl_uint		nroles = 1;
+			cl_ulong	per_role = (cl_ulong)lds_slots * 6 / 10;
+			cl_ulong	known = sess->groups_known;
+			if (known > per_role && known <= per_role * 64 * 3 / 2)
+			{
+				while (nroles < 64 && (cl_ulong)nroles * per_role < known)
+					nroles <<= 1;
+			}
+			if (const char *v = getenv("STROM_GPUPREAGG_HASH_ROLES"))
+			{
+				/* 1, 2, 4 ... 64; anything else would break the tile walk */
+				int want = atoi(v);
+				if (want >= 1 && want <= 64 && (want & (want - 1)) == 0)
+					nroles = (cl_uint)want;
+			}
+			void	   *args[] = { &a_kg, &a_kds, &a_toast, &a_map, &a_tab, &claim_limit, &a_defer, &lds_slots,
+								   &nroles };
+			unsigned	unit = 8 * nroles;
+			unsigned	grid = std::min<unsigned>(((todo + block - 1) / block + unit - 1) / unit * unit, fold_grid);
+			grid = std::max(unit, grid / unit * unit);
 			REQ_CHECK(hipModuleLaunchKernel(fn_fold, grid, 1, 1, block, 1, 1, (unsigned)lds_bytes,
 											task->stream, args, nullptr),
 					  "launch gpupreagg hash fold");
@@ -793,14 +822,15 @@ gpupreagg_launch_hashed(strom_task_impl *task, preagg_request req)
 	task->pfm.num_dma_recv += 2;
 	task->pfm.bytes_dma_recv += sizeof(cl_int) + 16;
 	task_event(task);									/* ev[3] */
-	task->finish = [stage_status](strom_task_impl *t)
+	task->finish = [stage_status, sess](strom_task_impl *t)
 	{
 		cl_int	status;
 		cl_uint	words[4];
 		memcpy(&status, stage_status, sizeof(status));
 		memcpy(words, stage_status + 16, sizeof(words));
 		if (status == StromError_Success && words[3] != 0)
-			status = StromError_DataStoreNoSpace;	/* cannot happen: room is reserved before a fold */
+			status = StromError_DataStoreNoSpace;	/* cannot happen: headroom is kept for every claim */
+		sess->groups_known = std::max<cl_uint>(sess->groups_known, words[2]);
 		t->errcode = status;
 	};
 	task_enqueue(task);
@@ -904,6 +934,7 @@ strom_gpupreagg_create_hashed(strom_devprog_key key,
 	while (capacity < (cl_ulong)ngroups_hint * 2 && capacity < (1UL << 31))
 		capacity <<= 1;
 	sess->hash_capacity = (cl_uint)capacity;
+	sess->groups_known = ngroups_hint;
 	return sess;
 }
 
@@ -1210,6 +1241,7 @@ strom_gpupreagg_reset(strom_gpupreagg *sess)
 		if (sess->htab)
 			(void)hash_table_new(sess, sess->hash_capacity, &sess->htab, &sess->htab_bytes, sess->htab);
 		sess->groups_upper = 0;
+		sess->groups_known = 0;
 		return;
 	}
 	if (!sess || !sess->table)

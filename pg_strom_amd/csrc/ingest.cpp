@@ -67,7 +67,12 @@ strom_dstore_to_column(strom_dstore *src, const int32_t *type_oids, int ntypes,
 	Program *prog = lookup_program(key);
 	int		errcode = 0;
 	(void)hipSetDevice(dev->hip_id);
-	hipFunction_t fn_main = prog->get_function(dev, "ingest_to_column", &errcode);
+	/* the decoder for varlena NUMERIC columns rides only when one is there */
+	bool	varnum = false;
+	for (int i = 0; type_oids && i < ncols; i++)
+		varnum = varnum || (type_oids[i] == STROM_NUMERICOID);
+	hipFunction_t fn_main = prog->get_function(dev, varnum ? "ingest_to_column_varnum" : "ingest_to_column",
+											   &errcode);
 	hipFunction_t fn_fin = fn_main ? prog->get_function(dev, "ingest_finish", &errcode) : nullptr;
 	hipFunction_t fn_mm = fn_fin ? prog->get_function(dev, "ingest_minmax", &errcode) : nullptr;
 	if (!fn_main || !fn_fin || !fn_mm)

@@ -74,3 +74,31 @@ def test_recheck_makes_the_chunk_recheck():
     buf = kds.build_kds("column", [kds.Column("int4", x)])
     rc, v, n = oracle.gpupreagg("(gpupreagg (psum (int8 (int4pl (var 1 int4) (const int4 1)))))", buf, 1)
     assert rc == 2 and len(v) == 0
+
+
+def test_group_identity_is_the_keys_canonical_image():
+    """float keys: -0 = +0, every NaN is one group; numeric keys: 1.50 = 1.5
+    (what the types' comparators call equal, gpupreagg_keycomp
+    opencl_gpupreagg.h:236) -- the hashed GROUP BY on the device uses the same images"""
+    f = np.array([0.0, -0.0, np.nan, np.float64(np.nan) * -1, 1.5, 1.5, 0.0], dtype=np.float64)
+    f4 = np.array([0.0, -0.0, 2.5, 2.5, np.nan, np.nan, -0.0], dtype=np.float32)
+    norm = kds.numeric_from_scaled(np.array([15, 15, 20, 20, 15, 0, 0]), 1).values
+    mant = norm & np.uint64((1 << 57) - 1)
+    expo = norm.view(np.int64) >> 58
+    loose = np.where(mant != 0, (((expo - 1) & 0x3f).astype(np.uint64) << np.uint64(58)) | (mant * np.uint64(10)), norm)
+    img = np.where(np.arange(7) % 2 == 0, norm, loose)
+    buf = kds.build_kds("column", [kds.Column("float8", f), kds.Column("float4", f4), kds.Column("numeric", img)])
+    rc, v, n = oracle.gpupreagg("(gpupreagg (key (var 1 float8)) (nrows))", buf, 2)
+    assert rc == 0
+    got = {int(a): int(b) for a, b in zip(v[:, 0].view(np.int64), v[:, 1])}
+    nan_img = np.array([0x7ff8000000000000], dtype=np.uint64).view(np.int64)[0]
+    assert got == {0: 3, int(nan_img): 2, int(np.array([1.5]).view(np.int64)[0]): 2}
+    rc, v, n = oracle.gpupreagg("(gpupreagg (key (var 2 float4)) (nrows))", buf, 2)
+    assert rc == 0                     # float4 keys leave as float8 images, like float partials
+    got = {int(a): int(b) for a, b in zip(v[:, 0].view(np.int64), v[:, 1])}
+    assert got == {0: 3, int(np.array([2.5]).view(np.int64)[0]): 2, int(nan_img): 2}
+    rc, v, n = oracle.gpupreagg("(gpupreagg (key (var 3 numeric)) (nrows))", buf, 2)
+    assert rc == 0
+    got = {int(a): int(b) for a, b in zip(v[:, 0], v[:, 1])}
+    canon = kds.numeric_from_scaled(np.array([15, 20, 0]), 1).values
+    assert got == {int(canon[0]): 3, int(canon[1]): 2, int(canon[2]): 2}
