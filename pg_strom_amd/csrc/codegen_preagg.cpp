@@ -245,6 +245,46 @@ strom_codegen_gpupreagg(const char *spec, strom_codegen_result *out,
 		src += codegen_includes(ctx.extra_flags);
 		src += codegen_param_list(ctx);
 		src += codegen_var_list(ctx, "STROM_KVAR_LIST");
+		{
+			/*
+			 * the columns the qual and the keys read, and the rest: the hashed
+			 * fold with roles (strom_gpupreagg.h) decides from the former
+			 * whether a row is its own and loads the latter only then
+			 */
+			codegen_context kctx;
+			kctx.var_label = "KVAR";
+			kctx.var_struct = "KV";
+			for (size_t i = 1; i < tree.items.size(); i++)
+			{
+				const sexpr &t = tree.items[i];
+				if (t.is_list && t.items.size() == 2 && !t.items[0].is_list &&
+					(t.items[0].atom == "qual" || t.items[0].atom == "key"))
+				{
+					std::string e;
+					codegen_expression(t.items[1], kctx, e);
+				}
+			}
+			codegen_context rctx;
+			for (auto &v : ctx.used_vars)
+			{
+				bool grouping = false;
+				for (auto &k : kctx.used_vars)
+					grouping = grouping || (k.attno == v.attno);
+				if (!grouping)
+					rctx.used_vars.push_back(v);
+			}
+			codegen_context gctx;
+			for (auto &v : ctx.used_vars)
+			{
+				bool rest = false;
+				for (auto &r : rctx.used_vars)
+					rest = rest || (r.attno == v.attno);
+				if (!rest)
+					gctx.used_vars.push_back(v);
+			}
+			src += codegen_var_list(gctx, "STROM_KVAR_LIST_GROUPING");
+			src += codegen_var_list(rctx, "STROM_KVAR_LIST_REST");
+		}
 		snprintf(tmp, sizeof(tmp),
 				 "#define GPUPREAGG_NTARGETS %zu\n#define GPUPREAGG_NKEYS %d\n#define GPUPREAGG_NAGGS %d\n",
 				 targets.size(), nkeys, naggs);

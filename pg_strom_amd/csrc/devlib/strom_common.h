@@ -540,6 +540,13 @@ strom_column_load_quad(const char *values, const cl_uint *notnull,
 					 (notnull) != NULL &&												\
 					 !((((const cl_uint *)(notnull))[(rowidx) >> 5] >> ((rowidx) & 31)) & 1))
 
+/* the same through the caches: for rows that several work-groups of an XCD
+ * read one after the other (hash roles of the hashed GROUP BY) */
+#define STROM_COLUMN_REF_CACHED(NAME, values, notnull, rowidx)						\
+	pg_##NAME##_make(((const pg_##NAME##_base_t *)(values))[rowidx],					\
+					 (notnull) != NULL &&												\
+					 !((((const cl_uint *)(notnull))[(rowidx) >> 5] >> ((rowidx) & 31)) & 1))
+
 /*
  * row formats in the row-at-a-time kernels: locate the heap tuple ONCE per
  * row (row item -> page -> line pointer is a chain of dependent loads) and

@@ -1417,7 +1417,13 @@ gpupreagg_reg1_column(kern_gpupreagg *kgpreagg, const kern_data_store *kds,
 #define GPUPREAGG_HASH_STRIDE	(GPUPREAGG_HASH_RECLEN <= 32 ? 32 :					\
 								 GPUPREAGG_HASH_RECLEN <= 64 ? 64 :					\
 								 ((GPUPREAGG_HASH_RECLEN + 127) / 128 * 128))
-#define GPUPREAGG_HASH_LDS_PROBES	8
+#ifndef GPUPREAGG_HASH_UNROLL
+#define GPUPREAGG_HASH_UNROLL	2		/* 4 needs 66 VGPRs: the second work-group of a CU no longer fits */
+#endif
+#ifndef GPUPREAGG_HASH_LDS_PROBES
+#define GPUPREAGG_HASH_LDS_PROBES	64	/* a key that finds no room in LDS sends ALL its rows to one
+										 * global record: same-address atomics, to be avoided */
+#endif
 
 struct gpupreagg_hash_head {
 	cl_uint		capacity;			/* power of two */
@@ -1453,18 +1459,22 @@ STROM_DEVICE cl_ulong strom_key_image(cl_double v)
 }
 STROM_DEVICE cl_ulong strom_key_image(cl_float v)	{ return strom_key_image((cl_double)v); }
 
+/* 32-bit multiplies only: a 64-bit product is four quarter-rate VALU operations
+ * on gfx950, and with hash roles every row is hashed once per role */
 STROM_DEVICE cl_uint
 gpupreagg_hash_of(const cl_ulong *kimg, cl_uint knull)
 {
-	cl_ulong	h = 0x9e3779b97f4a7c15UL;
+	cl_uint		h = 0x9e3779b9u ^ knull;
 	for (int k = 0; k < GPUPREAGG_NKEYS; k++)
 	{
-		h = (h ^ kimg[k]) * 0xff51afd7ed558ccdUL;
-		h ^= h >> 33;
+		h = (h ^ (cl_uint)kimg[k]) * 0x85ebca6bu;
+		h ^= h >> 15;
+		h = (h ^ (cl_uint)(kimg[k] >> 32)) * 0xc2b2ae35u;
+		h ^= h >> 13;
 	}
-	h = (h ^ knull) * 0xc4ceb9fe1a85ec53UL;
-	h ^= h >> 29;
-	return (cl_uint)h;
+	h *= 0x27d4eb2fu;
+	h ^= h >> 16;
+	return h;
 }
 
 /*
@@ -1623,7 +1633,7 @@ gpupreagg_hash_merge8(cl_ulong *addr, cl_ulong x)
 	}
 }
 
-template <bool IS_COLUMN, bool FOLD>
+template <bool IS_COLUMN, bool FOLD, bool ROLES>
 __device__ __forceinline__ void
 gpupreagg_hash_body(kern_gpupreagg *kgpreagg,
 					const kern_data_store *kds,
@@ -1683,25 +1693,58 @@ gpupreagg_hash_body(kern_gpupreagg *kgpreagg,
 	cl_uint		role = local & (nroles - 1);
 	cl_uint		member = local / nroles;
 	cl_uint		nmembers = (gridDim.x >> 3) / nroles;
-	for (size_t tile = xcd + 8 * (size_t)member; tile * blockDim.x < nrows; tile += 8 * (size_t)nmembers)
+	/*
+	 * a tile is GPUPREAGG_HASH_UNROLL x blockDim rows: a thread first loads
+	 * its rows of the tile, then folds them one by one.  With one row per turn
+	 * the loop is bound by the latency of that one load (0.36 ms per 1e8 rows
+	 * and role, whatever the caches did).
+	 */
+	for (size_t tile = xcd + 8 * (size_t)member;
+		 tile * GPUPREAGG_HASH_UNROLL * blockDim.x < nrows;
+		 tile += 8 * (size_t)nmembers)
 	{
-		size_t		r = tile * blockDim.x + threadIdx.x;
-		if (r >= nrows)
-			continue;
-		cl_uint		kds_index = (use_map ? (cl_uint)krowmap->rindex[r] : (cl_uint)r);
-		strom_kvars	KV;
-		cl_int		errcode = param_error;
-		const HeapTupleHeaderData *htup = NULL;
-		if (!is_column && row_family)
-			htup = strom_locate_tuple(kds, chunk_format, kds_index);
+		strom_kvars	KVs[GPUPREAGG_HASH_UNROLL];
+		cl_int		errs[GPUPREAGG_HASH_UNROLL];
+		cl_uint		kidx[GPUPREAGG_HASH_UNROLL];
+		bool		live[GPUPREAGG_HASH_UNROLL];
+#pragma unroll
+		for (int j = 0; j < GPUPREAGG_HASH_UNROLL; j++)
+		{
+			size_t		r = (tile * GPUPREAGG_HASH_UNROLL + j) * blockDim.x + threadIdx.x;
+			live[j] = (r < nrows);
+			if (!live[j])
+				r = 0;					/* nrows > 0 here: a harmless row, ignored below */
+			cl_uint		kds_index = (use_map ? (cl_uint)krowmap->rindex[r] : (cl_uint)r);
+			cl_int		errcode = param_error;
+			const HeapTupleHeaderData *htup = NULL;
+			if (!is_column && row_family)
+				htup = strom_locate_tuple(kds, chunk_format, kds_index);
+			/* with roles (COLUMN chunks only): the columns the qual and the keys
+			 * read now, the others once the row turns out to be this role's */
 #define X(attno,colidx,NAME)													\
-		KV.KVAR_##attno = (is_column											\
-			? STROM_COLUMN_REF(NAME, col_##attno, nul_##attno, kds_index)		\
-			: row_family ? STROM_TUPLE_REF(NAME, kds, htup, colidx)				\
-			: pg_##NAME##_vref(kds, ktoast, &errcode, colidx, kds_index));
-		STROM_KVAR_LIST(X)
+			KVs[j].KVAR_##attno = (is_column									\
+				? (ROLES ? STROM_COLUMN_REF_CACHED(NAME, col_##attno, nul_##attno, kds_index)	\
+						 : STROM_COLUMN_REF(NAME, col_##attno, nul_##attno, kds_index))	\
+				: row_family ? STROM_TUPLE_REF(NAME, kds, htup, colidx)			\
+				: pg_##NAME##_vref(kds, ktoast, &errcode, colidx, kds_index));
+			STROM_KVAR_LIST_GROUPING(X)
+			if (!ROLES)
+			{
+				STROM_KVAR_LIST_REST(X)
+			}
 #undef X
-		KV.__dummy = 0;
+			KVs[j].__dummy = 0;
+			errs[j] = errcode;
+			kidx[j] = kds_index;
+		}
+#pragma unroll
+		for (int j = 0; j < GPUPREAGG_HASH_UNROLL; j++)
+		{
+		if (!live[j])
+			continue;
+		strom_kvars &KV = KVs[j];
+		cl_int		errcode = errs[j];
+		cl_uint		kds_index = kidx[j];
 		cl_ulong	kimg[GPUPREAGG_NKEYS + 1];
 		cl_uint		knull = 0;
 		pg_bool_t	rc = gpupreagg_qual_eval(&errcode, KP, KV);
@@ -1719,6 +1762,13 @@ gpupreagg_hash_body(kern_gpupreagg *kgpreagg,
 		cl_uint		hash = gpupreagg_hash_of(kimg, knull);
 		if (FOLD && errcode == StromError_Success && ((hash >> 7) & (nroles - 1)) != role)
 			continue;
+		if (ROLES)
+		{
+#define X(attno,colidx,NAME)													\
+			KV.KVAR_##attno = STROM_COLUMN_REF(NAME, col_##attno, nul_##attno, kds_index);
+			STROM_KVAR_LIST_REST(X)
+#undef X
+		}
 #define X(aidx,resno,OP,NAME)														\
 		pg_##NAME##_t av_##aidx = gpupreagg_agg_##aidx(&errcode, KP, KV);
 		GPUPREAGG_AGG_LIST(X)
@@ -1793,6 +1843,7 @@ gpupreagg_hash_body(kern_gpupreagg *kgpreagg,
 #undef X
 		if ((*HASH_REC_FLAGS(rec) & need) != need)
 			atomicOr(HASH_REC_FLAGS(rec), need);
+		}	/* rows of the tile */
 	}
 	if (FOLD)
 	{
@@ -1843,9 +1894,9 @@ gpupreagg_hash_check(kern_gpupreagg *kgpreagg, const kern_data_store *kds,
 					 cl_uint claim_limit, kern_row_map *deferred, cl_uint lds_slots, cl_uint nroles)
 {
 	if (kds->format == KDS_FORMAT_COLUMN)
-		gpupreagg_hash_body<true, false>(kgpreagg, kds, ktoast, krowmap, htab, 0, NULL, 0, 1, NULL);
+		gpupreagg_hash_body<true, false, false>(kgpreagg, kds, ktoast, krowmap, htab, 0, NULL, 0, 1, NULL);
 	else
-		gpupreagg_hash_body<false, false>(kgpreagg, kds, ktoast, krowmap, htab, 0, NULL, 0, 1, NULL);
+		gpupreagg_hash_body<false, false, false>(kgpreagg, kds, ktoast, krowmap, htab, 0, NULL, 0, 1, NULL);
 }
 
 extern "C" __global__ void
@@ -1855,12 +1906,17 @@ gpupreagg_hash_fold(kern_gpupreagg *kgpreagg, const kern_data_store *kds,
 					cl_uint claim_limit, kern_row_map *deferred, cl_uint lds_slots, cl_uint nroles)
 {
 	extern __shared__ __attribute__((aligned(16))) char lds[];
-	if (kds->format == KDS_FORMAT_COLUMN)
-		gpupreagg_hash_body<true, true>(kgpreagg, kds, ktoast, krowmap, htab, claim_limit, deferred,
-										lds_slots, nroles, lds);
+	/* (decided once per launch; with roles a row is read by several
+	 * work-groups of the XCD, so its lines should stay in L2) */
+	if (kds->format != KDS_FORMAT_COLUMN)
+		gpupreagg_hash_body<false, true, false>(kgpreagg, kds, ktoast, krowmap, htab, claim_limit, deferred,
+												lds_slots, nroles, lds);
+	else if (nroles > 1)
+		gpupreagg_hash_body<true, true, true>(kgpreagg, kds, ktoast, krowmap, htab, claim_limit, deferred,
+											  lds_slots, nroles, lds);
 	else
-		gpupreagg_hash_body<false, true>(kgpreagg, kds, ktoast, krowmap, htab, claim_limit, deferred,
-										 lds_slots, nroles, lds);
+		gpupreagg_hash_body<true, true, false>(kgpreagg, kds, ktoast, krowmap, htab, claim_limit, deferred,
+											   lds_slots, nroles, lds);
 }
 
 /* min / max accumulators start from their identities (sums from the zeroed table) */

@@ -770,15 +770,19 @@ gpupreagg_launch_hashed(strom_task_impl *task, preagg_request req)
 			}
 			/*
 			 * roles: as many as it takes for a role's share of the groups seen so
-			 * far to sit in its LDS table at ~60 % fill; beyond 64 roles (each row
-			 * is hashed once per role) the global table is the better place
+			 * far to half-fill its LDS table.  Every role hashes every row: a role
+			 * pass costs ~0.4 ms per 1e8 rows, the global table 27-42 ms, so up to
+			 * 32 roles pay (measured: 1000 groups 11.5 -> 2.2 ms with 2 roles,
+			 * 1e4 groups 26.7 -> 14.7 ms with 32; 64 roles 25 ms: no gain)
 			 */
 			cl_uint		nroles = 1;
-			cl_ulong	per_role = (cl_ulong)lds_slots * 6 / 10;
+			cl_ulong	per_role = (cl_ulong)lds_slots / 2;
 			cl_ulong	known = sess->groups_known;
-			if (known > per_role && known <= per_role * 64 * 3 / 2)
+			if (const char *v = getenv("STROM_GPUPREAGG_HASH_FILL"))
+				per_role = std::max<cl_ulong>(1, (cl_ulong)lds_slots * (cl_ulong)atoi(v) / 100);
+			if (known > per_role && known <= per_role * 32)
 			{
-				while (nroles < 64 && (cl_ulong)nroles * per_role < known)
+				while (nroles < 32 && (cl_ulong)nroles * per_role < known)
 					nroles <<= 1;
 			}
 			if (const char *v = getenv("STROM_GPUPREAGG_HASH_ROLES"))

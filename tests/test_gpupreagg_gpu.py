@@ -543,3 +543,37 @@ def test_hashed_session_refuses_the_dense_table_calls():
     # and the dense path still refuses what only the hashed one can group
     with pytest.raises(runtime.StromError):
         GpuPreAgg("(gpupreagg (key (var 1 float8)) (nrows))").begin([(0, 10)])
+
+
+@pytest.mark.parametrize("hint", [0, 5000])
+def test_hashed_roles_split_the_groups_over_lds_tables(hint):
+    """5000 float8 keys: with the hint (or, without it, from the second chunk on,
+    when the group count is known) the work-groups take hash roles so that a
+    role's groups fit its LDS table; the result must not depend on it"""
+    rng = np.random.default_rng(53)
+    n = 400000
+    key = rng.integers(0, 5000, n).astype(np.float64) * 0.25 - 300.0
+    x = rng.integers(-1000, 1000, n).astype(np.int32)
+    isn = rng.random(n) < 0.02
+    agg = GpuPreAgg("(gpupreagg (key (var 1 float8)) (nrows) (psum (int8 (var 2 int4))) (pmin (var 2 int4)))")
+    agg.begin_hashed(ngroups_hint=hint)
+    for i in range(2):
+        sl = slice(i * n // 2, (i + 1) * n // 2)
+        buf = kds.build_kds("column", [kds.Column("float8", key[sl]), kds.Column("int4", x[sl], isn[sl])])
+        assert agg.fold(buf)[0] == 0
+    pr = agg.fetch()
+    agg.end()
+    uk, inv = np.unique(key, return_inverse=True)
+    assert len(pr) == len(uk)
+    k, _ = pr.column(0)
+    order = np.argsort(k)
+    assert np.array_equal(k[order], uk)
+    assert np.array_equal(pr.column(1)[0][order], np.bincount(inv))
+    xs = np.where(isn, 0, x).astype(np.int64)
+    assert np.array_equal(pr.column(2)[0][order], np.bincount(inv, weights=xs).astype(np.int64))
+    want_min = np.full(len(uk), 2**31 - 1, dtype=np.int64)
+    np.minimum.at(want_min, inv[~isn], x[~isn].astype(np.int64))
+    got_min, got_null = pr.column(3)
+    has = want_min != 2**31 - 1
+    assert np.array_equal(got_null[order], ~has)
+    assert np.array_equal(got_min[order][has].astype(np.int64), want_min[has])
