@@ -1420,10 +1420,15 @@ gpupreagg_reg1_column(kern_gpupreagg *kgpreagg, const kern_data_store *kds,
 #ifndef GPUPREAGG_HASH_UNROLL
 #define GPUPREAGG_HASH_UNROLL	2		/* 4 needs 66 VGPRs: the second work-group of a CU no longer fits */
 #endif
+/* queued row numbers per wave (roles): a power of two, >= 64 * (UNROLL + 1) */
+#define GPUPREAGG_HASH_QUEUE	256
 #ifndef GPUPREAGG_HASH_LDS_PROBES
 #define GPUPREAGG_HASH_LDS_PROBES	64	/* a key that finds no room in LDS sends ALL its rows to one
 										 * global record: same-address atomics, to be avoided */
 #endif
+
+static_assert(GPUPREAGG_HASH_QUEUE >= 64 * (GPUPREAGG_HASH_UNROLL + 1) &&
+			  (GPUPREAGG_HASH_QUEUE & (GPUPREAGG_HASH_QUEUE - 1)) == 0, "role queue too small for the tile");
 
 struct gpupreagg_hash_head {
 	cl_uint		capacity;			/* power of two */
@@ -1680,76 +1685,16 @@ gpupreagg_hash_body(kern_gpupreagg *kgpreagg,
 	STROM_KVAR_LIST(X)
 #undef X
 	/*
-	 * who folds what.  More groups than one LDS table holds: the work-groups
-	 * take ROLES, role j folds the keys whose hash says j and skips the others
-	 * right after hashing, so each role's groups fit its LDS table again (the
-	 * dense kernels split their id range the same way).  Work-group i runs on
-	 * XCD i % 8: the tiles are dealt to the XCDs, and inside an XCD all roles
-	 * walk the same tiles, so the repeated reads meet in that XCD's L2.
-	 * gridDim.x is a multiple of 8 * nroles (nroles a power of two).
+	 * one row, its columns loaded: qual, keys, partial inputs, then into the
+	 * work-group's LDS table or, without room there, the global one
 	 */
-	cl_uint		xcd = blockIdx.x & 7;
-	cl_uint		local = blockIdx.x >> 3;
-	cl_uint		role = local & (nroles - 1);
-	cl_uint		member = local / nroles;
-	cl_uint		nmembers = (gridDim.x >> 3) / nroles;
-	/*
-	 * a tile is GPUPREAGG_HASH_UNROLL x blockDim rows: a thread first loads
-	 * its rows of the tile, then folds them one by one.  With one row per turn
-	 * the loop is bound by the latency of that one load (0.36 ms per 1e8 rows
-	 * and role, whatever the caches did).
-	 */
-	for (size_t tile = xcd + 8 * (size_t)member;
-		 tile * GPUPREAGG_HASH_UNROLL * blockDim.x < nrows;
-		 tile += 8 * (size_t)nmembers)
+	auto fold_loaded = [&](const strom_kvars &KV, cl_int errcode, cl_uint kds_index)
 	{
-		strom_kvars	KVs[GPUPREAGG_HASH_UNROLL];
-		cl_int		errs[GPUPREAGG_HASH_UNROLL];
-		cl_uint		kidx[GPUPREAGG_HASH_UNROLL];
-		bool		live[GPUPREAGG_HASH_UNROLL];
-#pragma unroll
-		for (int j = 0; j < GPUPREAGG_HASH_UNROLL; j++)
-		{
-			size_t		r = (tile * GPUPREAGG_HASH_UNROLL + j) * blockDim.x + threadIdx.x;
-			live[j] = (r < nrows);
-			if (!live[j])
-				r = 0;					/* nrows > 0 here: a harmless row, ignored below */
-			cl_uint		kds_index = (use_map ? (cl_uint)krowmap->rindex[r] : (cl_uint)r);
-			cl_int		errcode = param_error;
-			const HeapTupleHeaderData *htup = NULL;
-			if (!is_column && row_family)
-				htup = strom_locate_tuple(kds, chunk_format, kds_index);
-			/* with roles (COLUMN chunks only): the columns the qual and the keys
-			 * read now, the others once the row turns out to be this role's */
-#define X(attno,colidx,NAME)													\
-			KVs[j].KVAR_##attno = (is_column									\
-				? (ROLES ? STROM_COLUMN_REF_CACHED(NAME, col_##attno, nul_##attno, kds_index)	\
-						 : STROM_COLUMN_REF(NAME, col_##attno, nul_##attno, kds_index))	\
-				: row_family ? STROM_TUPLE_REF(NAME, kds, htup, colidx)			\
-				: pg_##NAME##_vref(kds, ktoast, &errcode, colidx, kds_index));
-			STROM_KVAR_LIST_GROUPING(X)
-			if (!ROLES)
-			{
-				STROM_KVAR_LIST_REST(X)
-			}
-#undef X
-			KVs[j].__dummy = 0;
-			errs[j] = errcode;
-			kidx[j] = kds_index;
-		}
-#pragma unroll
-		for (int j = 0; j < GPUPREAGG_HASH_UNROLL; j++)
-		{
-		if (!live[j])
-			continue;
-		strom_kvars &KV = KVs[j];
-		cl_int		errcode = errs[j];
-		cl_uint		kds_index = kidx[j];
 		cl_ulong	kimg[GPUPREAGG_NKEYS + 1];
 		cl_uint		knull = 0;
 		pg_bool_t	rc = gpupreagg_qual_eval(&errcode, KP, KV);
 		if (errcode == StromError_Success && !EVAL(rc))
-			continue;
+			return;
 #define X(kidx,resno,NAME)															\
 		{																			\
 			pg_##NAME##_t kv = gpupreagg_key_##kidx(&errcode, KP, KV);				\
@@ -1758,17 +1703,6 @@ gpupreagg_hash_body(kern_gpupreagg *kgpreagg,
 		}
 		GPUPREAGG_KEY_LIST(X)
 #undef X
-		/* another role's key (the check pass has seen this row's errors) */
-		cl_uint		hash = gpupreagg_hash_of(kimg, knull);
-		if (FOLD && errcode == StromError_Success && ((hash >> 7) & (nroles - 1)) != role)
-			continue;
-		if (ROLES)
-		{
-#define X(attno,colidx,NAME)													\
-			KV.KVAR_##attno = STROM_COLUMN_REF(NAME, col_##attno, nul_##attno, kds_index);
-			STROM_KVAR_LIST_REST(X)
-#undef X
-		}
 #define X(aidx,resno,OP,NAME)														\
 		pg_##NAME##_t av_##aidx = gpupreagg_agg_##aidx(&errcode, KP, KV);
 		GPUPREAGG_AGG_LIST(X)
@@ -1776,7 +1710,7 @@ gpupreagg_hash_body(kern_gpupreagg *kgpreagg,
 		if (errcode != StromError_Success)
 		{
 			STROM_SET_ERROR(&chunk_status, errcode);
-			continue;
+			return;
 		}
 #define X(aidx,resno,OP,NAME)														\
 		if (GPUPREAGG_OP_##OP == GPUPREAGG_OP_PSUM &&								\
@@ -1786,7 +1720,8 @@ gpupreagg_hash_body(kern_gpupreagg *kgpreagg,
 		GPUPREAGG_AGG_LIST(X)
 #undef X
 		if (!FOLD)
-			continue;
+			return;
+		cl_uint		hash = gpupreagg_hash_of(kimg, knull);
 		cl_uint		lslot = gpupreagg_hash_lds_slot(T, hash, kimg, knull);
 		cl_uint		need = GPUPREAGG_FLAG_SEEN;
 		if (lslot != ~0u)
@@ -1803,7 +1738,7 @@ gpupreagg_hash_body(kern_gpupreagg *kgpreagg,
 				cl_uint	 shift = ((lslot * (cl_uint)sizeof(gpupreagg_flags_t)) & 3u) * 8u;
 				__hip_atomic_fetch_or(word, need << shift, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 			}
-			continue;
+			return;
 		}
 		/* no room in LDS: straight to the global table */
 		cl_uint		slot = gpupreagg_hash_slot<true>(htab, hash, kimg, knull, claim_limit);
@@ -1813,12 +1748,12 @@ gpupreagg_hash_body(kern_gpupreagg *kgpreagg,
 			 * and sends this row again */
 			cl_uint	idx = atomicAdd((cl_uint *)&deferred->nvalids, 1u);
 			deferred->rindex[idx] = (cl_int)kds_index;
-			continue;
+			return;
 		}
 		if (slot == GPUPREAGG_HASH_FULL)
 		{
 			head->overflow = 1;
-			continue;
+			return;
 		}
 		char	   *rec = gpupreagg_hash_rec(htab, slot);
 #define X(aidx,resno,OP,NAME)														\
@@ -1843,8 +1778,141 @@ gpupreagg_hash_body(kern_gpupreagg *kgpreagg,
 #undef X
 		if ((*HASH_REC_FLAGS(rec) & need) != need)
 			atomicOr(HASH_REC_FLAGS(rec), need);
-		}	/* rows of the tile */
+	};
+
+	/*
+	 * who folds what.  More groups than one LDS table holds: the work-groups
+	 * take ROLES (COLUMN chunks), role j folds the keys whose hash says j, so
+	 * each role's groups fit its LDS table again (the dense kernels split
+	 * their id range the same way).  Work-group i runs on XCD i % 8: the tiles
+	 * are dealt to the XCDs, and inside an XCD all roles walk the same tiles,
+	 * so the repeated reads meet in that XCD's L2.  gridDim.x is a multiple of
+	 * 8 * nroles (nroles a power of two; 1 without ROLES).
+	 */
+	cl_uint		xcd = blockIdx.x & 7;
+	cl_uint		local = blockIdx.x >> 3;
+	cl_uint		role = local & (nroles - 1);
+	cl_uint		member = local / nroles;
+	cl_uint		nmembers = (gridDim.x >> 3) / nroles;
+	/*
+	 * with roles a wave SCANS its tile -- the columns the qual and the keys
+	 * read, hash, whose row is it -- and only queues its own rows' numbers in
+	 * LDS; whenever 64 are queued the whole wave folds them.  Folding straight
+	 * from the scan cost a full pass per role (0.3 ms per 1e8 rows, whatever
+	 * was loaded): the wave waited for the few lanes that had a row of its
+	 * role to get through their LDS atomics.
+	 */
+	cl_uint	   *queue = NULL;
+	cl_uint		qhead = 0, qtail = 0;		/* wave-uniform */
+	if (ROLES)
+		queue = (cl_uint *)(T.keys + (size_t)lds_slots * GPUPREAGG_NKEYS)
+			+ (threadIdx.x / STROM_WAVE) * GPUPREAGG_HASH_QUEUE;
+	auto drain = [&](cl_uint nready)
+	{
+		/* the first nready (<= 64) queued rows, one per lane */
+		bool		active = (strom_lane_id() < nready);
+		cl_uint		kds_index = queue[(qhead + (active ? strom_lane_id() : 0)) & (GPUPREAGG_HASH_QUEUE - 1)];
+		strom_kvars	KV;
+#define X(attno,colidx,NAME)													\
+		KV.KVAR_##attno = STROM_COLUMN_REF_CACHED(NAME, col_##attno, nul_##attno, kds_index);
+		STROM_KVAR_LIST_GROUPING(X)
+#undef X
+#define X(attno,colidx,NAME)													\
+		KV.KVAR_##attno = STROM_COLUMN_REF(NAME, col_##attno, nul_##attno, kds_index);
+		STROM_KVAR_LIST_REST(X)
+#undef X
+		KV.__dummy = 0;
+		if (active)
+			fold_loaded(KV, param_error, kds_index);
+		qhead += nready;
+	};
+	/*
+	 * a tile is GPUPREAGG_HASH_UNROLL x blockDim rows: a thread first loads
+	 * its rows of the tile, then works on them one by one (with one row per
+	 * turn the loop is bound by the latency of that one load)
+	 */
+	for (size_t tile = xcd + 8 * (size_t)member;
+		 tile * GPUPREAGG_HASH_UNROLL * blockDim.x < nrows;
+		 tile += 8 * (size_t)nmembers)
+	{
+		strom_kvars	KVs[GPUPREAGG_HASH_UNROLL];
+		cl_int		errs[GPUPREAGG_HASH_UNROLL];
+		cl_uint		kidx[GPUPREAGG_HASH_UNROLL];
+		bool		live[GPUPREAGG_HASH_UNROLL];
+#pragma unroll
+		for (int j = 0; j < GPUPREAGG_HASH_UNROLL; j++)
+		{
+			size_t		r = (tile * GPUPREAGG_HASH_UNROLL + j) * blockDim.x + threadIdx.x;
+			live[j] = (r < nrows);
+			if (!live[j])
+				r = 0;					/* nrows > 0 here: a harmless row, ignored below */
+			cl_uint		kds_index = (use_map ? (cl_uint)krowmap->rindex[r] : (cl_uint)r);
+			cl_int		errcode = param_error;
+			const HeapTupleHeaderData *htup = NULL;
+			if (!is_column && row_family)
+				htup = strom_locate_tuple(kds, chunk_format, kds_index);
+#define X(attno,colidx,NAME)													\
+			KVs[j].KVAR_##attno = (is_column									\
+				? (ROLES ? STROM_COLUMN_REF_CACHED(NAME, col_##attno, nul_##attno, kds_index)	\
+						 : STROM_COLUMN_REF(NAME, col_##attno, nul_##attno, kds_index))	\
+				: row_family ? STROM_TUPLE_REF(NAME, kds, htup, colidx)			\
+				: pg_##NAME##_vref(kds, ktoast, &errcode, colidx, kds_index));
+			STROM_KVAR_LIST_GROUPING(X)
+			if (!ROLES)
+			{
+				STROM_KVAR_LIST_REST(X)
+			}
+#undef X
+			KVs[j].__dummy = 0;
+			errs[j] = errcode;
+			kidx[j] = kds_index;
+		}
+#pragma unroll
+		for (int j = 0; j < GPUPREAGG_HASH_UNROLL; j++)
+		{
+			if (!ROLES)
+			{
+				if (live[j])
+					fold_loaded(KVs[j], errs[j], kidx[j]);
+				continue;
+			}
+			/* scan: is this row the role's?  (every lane stays for the ballot) */
+			bool		own = false;
+			if (live[j])
+			{
+				cl_int		errcode = errs[j];
+				pg_bool_t	rc = gpupreagg_qual_eval(&errcode, KP, KVs[j]);
+				if (!(errcode == StromError_Success && !EVAL(rc)))
+				{
+					cl_ulong	kimg[GPUPREAGG_NKEYS + 1];
+					cl_uint		knull = 0;
+#define X(kidx,resno,NAME)															\
+					{																\
+						pg_##NAME##_t kv = gpupreagg_key_##kidx(&errcode, KP, KVs[j]);	\
+						kimg[kidx] = (kv.isnull ? 0UL : strom_key_image(kv.value));	\
+						knull |= (kv.isnull ? (1u << kidx) : 0u);					\
+					}
+					GPUPREAGG_KEY_LIST(X)
+#undef X
+					own = (errcode != StromError_Success ||
+						   ((gpupreagg_hash_of(kimg, knull) >> 7) & (nroles - 1)) == role);
+				}
+			}
+			cl_ulong	mask = __ballot(own);
+			if (own)
+				queue[(qtail + (cl_uint)__popcll(mask & ((1UL << strom_lane_id()) - 1)))
+					  & (GPUPREAGG_HASH_QUEUE - 1)] = kidx[j];
+			qtail += (cl_uint)__popcll(mask);
+			__builtin_amdgcn_wave_barrier();
+		}
+		if (ROLES)
+		{
+			while (qtail - qhead >= STROM_WAVE)
+				drain(STROM_WAVE);
+		}
 	}
+	if (ROLES && qtail != qhead)
+		drain(qtail - qhead);
 	if (FOLD)
 	{
 		/* the work-group's groups reach the global table once */

@@ -476,9 +476,11 @@ hash_lds_slots(const strom_gpupreagg *sess, size_t *p_bytes)
 	size_t		nkeys = sess->key_resno.size();
 	cl_uint		slots = 4096;
 	size_t		bytes;
+	/* after the table: 256 queued row numbers per wave (GPUPREAGG_HASH_QUEUE, used with roles) */
+	size_t		queue = ((size_t)sess->block / 64) * 256 * sizeof(cl_uint);
 	for (;;)
 	{
-		bytes = sess->image_offset(sess->nsections(), slots, 1) + (size_t)slots * (8 + 8 * nkeys);
+		bytes = sess->image_offset(sess->nsections(), slots, 1) + (size_t)slots * (8 + 8 * nkeys) + queue;
 		if (bytes <= 64 * 1024 || slots == 64)
 			break;
 		slots >>= 1;
@@ -770,26 +772,27 @@ gpupreagg_launch_hashed(strom_task_impl *task, preagg_request req)
 			}
 			/*
 			 * roles: as many as it takes for a role's share of the groups seen so
-			 * far to half-fill its LDS table.  Every role hashes every row: a role
-			 * pass costs ~0.4 ms per 1e8 rows, the global table 27-42 ms, so up to
-			 * 32 roles pay (measured: 1000 groups 11.5 -> 2.2 ms with 2 roles,
-			 * 1e4 groups 26.7 -> 14.7 ms with 32; 64 roles 25 ms: no gain)
+			 * far to fill 5/8 of its LDS table (64 probes find room at that fill).
+			 * Every role scans every row's key columns: ~0.2 ms per 1e8 rows and
+			 * role against 23-47 ms through the global table, so up to 64 roles
+			 * pay (measured, 1e8 rows: 1000 groups 11.5 -> 1.6 ms with 2 roles, 1e4
+			 * groups 26.7 -> 5.1 ms with 16, 3e4 groups 13.2 ms with 64)
 			 */
 			cl_uint		nroles = 1;
-			cl_ulong	per_role = (cl_ulong)lds_slots / 2;
+			cl_ulong	per_role = (cl_ulong)lds_slots * 5 / 8;
 			cl_ulong	known = sess->groups_known;
 			if (const char *v = getenv("STROM_GPUPREAGG_HASH_FILL"))
 				per_role = std::max<cl_ulong>(1, (cl_ulong)lds_slots * (cl_ulong)atoi(v) / 100);
-			if (known > per_role && known <= per_role * 32)
+			if (req.format == KDS_FORMAT_COLUMN && known > per_role && known <= per_role * 64)
 			{
-				while (nroles < 32 && (cl_ulong)nroles * per_role < known)
+				while (nroles < 64 && (cl_ulong)nroles * per_role < known)
 					nroles <<= 1;
 			}
 			if (const char *v = getenv("STROM_GPUPREAGG_HASH_ROLES"))
 			{
 				/* 1, 2, 4 ... 64; anything else would break the tile walk */
 				int want = atoi(v);
-				if (want >= 1 && want <= 64 && (want & (want - 1)) == 0)
+				if (req.format == KDS_FORMAT_COLUMN && want >= 1 && want <= 64 && (want & (want - 1)) == 0)
 					nroles = (cl_uint)want;
 			}
 			void	   *args[] = { &a_kg, &a_kds, &a_toast, &a_map, &a_tab, &claim_limit, &a_defer, &lds_slots,
