@@ -346,6 +346,25 @@ strom_task *strom_submit_gpuhashjoin_projection(strom_hashjoin_table *tbl,
 												strom_done_cb done, void *arg,
 												int *p_errcode);
 
+/*
+ * Joined rows for the NEXT operator, without leaving HBM (SURVEY.md section
+ * 8 f2; the reference hands a projected TUPSLOT store to the next node
+ * through the host, gpuhashjoin.c:2686-2689, 4883-4968): after a
+ * strom_submit_gpuhashjoin*() with STROM_RESULTS_ON_DEVICE over the resident
+ * chunk 'outer', and BEFORE strom_task_wait() on it, this call waits for the
+ * join and materialises its result records as a KDS_FORMAT_COLUMN chunk
+ * (zone maps and not-null bitmaps included) that GpuScan / GpuPreAgg /
+ * another GpuHashJoin take as a strom_dstore.  Column r takes column
+ * src_colidx[r] (0-based) of relation src_depth[r]; type_oids[r] gives its
+ * width, which must equal the source's (StromError_DataStoreCorruption
+ * otherwise).  Fixed-width by-value columns.  A join that ended with
+ * StromError_DataStoreNoSpace is reported as such: resize, join again.
+ */
+strom_dstore *strom_hashjoin_project_column(strom_task *join_task, strom_hashjoin_table *tbl,
+											strom_dstore *outer, int ncols,
+											const int32_t *src_depth, const int32_t *src_colidx,
+											const int32_t *type_oids, int *p_errcode);
+
 /* ------------------------------------------------------------------ *
  * chained operators: device-resident row maps
  *

@@ -895,4 +895,97 @@ gpuhashjoin_projection_slot(kern_hashjoin *khashjoin,
 	}
 }
 
+/* ====================================================================== *
+ * projection into a COLUMN chunk that stays in HBM
+ *
+ * What the next operator of a device-resident chain reads (SURVEY.md
+ * section 8 f2): the reference materialises joined rows as TUPSLOT and ships
+ * them to the host for the next node (gpuhashjoin.c:4883-4968, bulk-slot
+ * hand-over gpuhashjoin.c:2686-2689); here they become column arrays, so
+ * that GpuPreAgg / GpuScan run their streaming kernels on them.  One
+ * thread per result record, same mapping arrays as the TUPSLOT kernel;
+ * values are stored at the record's index (consecutive lanes, consecutive
+ * addresses), the not-null words come from one ballot per column.  The
+ * destination's column widths must equal the sources'.
+ * ====================================================================== */
+extern "C" __global__ void
+__launch_bounds__(256)
+gpuhashjoin_projection_column(kern_hashjoin *khashjoin,
+							  const kern_multihash *kmhash,
+							  const kern_data_store *kds,
+							  const kern_data_store *ktoast,
+							  kern_data_store *dst,
+							  const cl_int *src_depth,
+							  const cl_int *src_colidx,
+							  cl_uint *col_has_null)		/* [ncols] flags, then one failure flag */
+{
+	kern_resultbuf *kresults = KERN_HASHJOIN_RESULTBUF(khashjoin);
+	cl_uint		nrels = kresults->nrels;
+	cl_uint		nitems = dst->nitems;				/* set by the host from the finished join */
+	cl_uint		ncols = dst->ncols;
+	const kern_coldir *coldir = KERN_DATA_STORE_COLDIR(dst);
+	cl_uint		lane = threadIdx.x & 63;
+
+	for (cl_uint base = blockIdx.x * blockDim.x; base < nitems; base += gridDim.x * blockDim.x)
+	{
+		cl_uint		i = base + threadIdx.x;				/* blockDim is a multiple of 64 */
+		bool		valid = (i < nitems);
+		const cl_int *rbuffer = kresults->results + (size_t)nrels * (valid ? i : 0);
+
+		for (cl_uint r = 0; r < ncols; r++)
+		{
+			cl_int		depth = src_depth[r];
+			cl_int		col = src_colidx[r];
+			cl_int		dstlen = dst->colmeta[r].attlen;
+			const void *addr = NULL;
+			cl_int		attlen = 0;
+
+			if (valid && depth == 0)
+			{
+				addr = kern_get_datum(kds, ktoast, col, (cl_uint)(rbuffer[0] - 1));
+				attlen = (col < (cl_int)kds->ncols ? kds->colmeta[col].attlen : 0);
+			}
+			else if (valid && depth > 0 && depth < (cl_int)nrels)
+			{
+				const kern_hashtable *kht = KERN_HASHTABLE(kmhash, depth - 1);
+				const kern_hashentry *ent = (const kern_hashentry *)((const char *)kht + rbuffer[depth]);
+				addr = kern_get_datum_tuple(kht->colmeta, &ent->htup, col);
+				attlen = (col < (cl_int)kht->ncols ? kht->colmeta[col].attlen : 0);
+			}
+			if (valid && attlen != dstlen)
+			{
+				col_has_null[ncols] = 1;			/* the mapping does not fit the destination */
+				addr = NULL;
+			}
+			if (valid)
+			{
+				char   *out = (char *)dst + coldir[r].values_off + (size_t)dstlen * i;
+				cl_ulong d = 0;
+				if (addr)
+					__builtin_memcpy(&d, addr, dstlen);
+				switch (dstlen)
+				{
+					case 1: *(cl_char *)out = (cl_char)d; break;
+					case 2: *(cl_short *)out = (cl_short)d; break;
+					case 4: *(cl_int *)out = (cl_int)d; break;
+					default: *(cl_long *)out = (cl_long)d; break;
+				}
+			}
+			strom_lanemask_t nn = __ballot(addr != NULL);
+			strom_lanemask_t vv = __ballot(valid);
+			if (vv != 0)
+			{
+				cl_uint *words = (cl_uint *)((char *)dst + coldir[r].nulls_off);
+				cl_uint	 w0 = (base + (threadIdx.x & ~63u)) >> 5;
+				if (lane == 0)
+					words[w0] = (cl_uint)nn;
+				if (lane == 32 && (vv >> 32) != 0)
+					words[w0 + 1] = (cl_uint)(nn >> 32);
+				if (nn != vv && lane == 0)
+					col_has_null[r] = 1;
+			}
+		}
+	}
+}
+
 #endif	/* STROM_HASHJOIN_DEVICE_H */

@@ -444,6 +444,8 @@ gpuhashjoin_launch(strom_task_impl *task, hashjoin_request req)
 	task_event(task);									/* ev[3] */
 	bool	results_on_device = (req.flags & STROM_RESULTS_ON_DEVICE) != 0;
 	kern_data_store *kds_dest = req.kds_dest;
+	task->res_offset = res_offset;
+	task->res_is_join = true;
 	task->finish = [kres_host, d_khj, res_offset, results_on_device, stage_res,
 					kds_dest, d_dest, dest_head, dest_stride](strom_task_impl *t)
 	{
@@ -474,6 +476,7 @@ gpuhashjoin_launch(strom_task_impl *task, hashjoin_request req)
 			t->pfm.num_dma_recv++;
 			t->pfm.bytes_dma_recv += len;
 		}
+		t->res_nitems = kres_host->nitems;
 		if (results_on_device || kres_host->nitems == 0)
 			return;
 		size_t	len = sizeof(cl_int) * (size_t)kres_host->nitems * kres_host->nrels;
@@ -597,4 +600,179 @@ strom_submit_gpuhashjoin_mapped(strom_hashjoin_table *tbl, kern_hashjoin *khashj
 	}
 	return submit_hashjoin_common(tbl, khashjoin, nullptr, kds_dev, nullptr, rowmap,
 								  nullptr, nullptr, nullptr, flags, done, arg, p_errcode);
+}
+
+
+/*
+ * joined rows -> a COLUMN chunk resident in HBM (gpuhashjoin_projection_column
+ * in strom_hashjoin.h); zone maps and NULL bookkeeping by the ingest
+ * program's kernels, so the result is what strom_dstore_to_column() or a
+ * host-built COLUMN chunk would be
+ */
+extern "C" strom_dstore *
+strom_hashjoin_project_column(strom_task *handle, strom_hashjoin_table *tbl, strom_dstore *outer,
+							  int ncols, const int32_t *src_depth, const int32_t *src_colidx,
+							  const int32_t *type_oids, int *p_errcode)
+{
+	int		dummy;
+	if (!p_errcode)
+		p_errcode = &dummy;
+	*p_errcode = 0;
+	strom_task_impl *task = static_cast<strom_task_impl *>(handle);
+	if (!task || !tbl || !outer || ncols < 1 || ncols > 64 || !src_depth || !src_colidx || !type_oids)
+	{
+		*p_errcode = StromError_BadRequestMessage;
+		return nullptr;
+	}
+	{
+		std::unique_lock<std::mutex> g(task->lock);
+		task->cond.wait(g, [&]{ return task->completed; });
+	}
+	if (!task->res_is_join || !task->keep_main || task->errcode != 0 || !task->main_devptr ||
+		outer->dindex != tbl->dev->dindex)
+	{
+		/* not a finished GpuHashJoin with STROM_RESULTS_ON_DEVICE */
+		*p_errcode = (task->errcode ? task->errcode : StromError_BadRequestMessage);
+		return nullptr;
+	}
+	Device *dev = tbl->dev;
+	static const char *ingest_source =
+		"#include \"strom_kds.h\"\n#include \"strom_common.h\"\n#include \"strom_mathlib.h\"\n"
+		"#include \"strom_numeric.h\"\n#include \"strom_ingest.h\"\n";
+	static strom_devprog_key ingest_key = strom_get_devprog_key(ingest_source, 0);
+	if (strom_lookup_device_program(ingest_key, 1) != STROM_DEVPROG_READY)
+	{
+		*p_errcode = StromError_ProgramBuildFailure;
+		return nullptr;
+	}
+	int		errcode = 0;
+	(void)hipSetDevice(dev->hip_id);
+	Program *iprog = lookup_program(ingest_key);
+	hipFunction_t fn_proj = tbl->prog->get_function(dev, "gpuhashjoin_projection_column", &errcode);
+	hipFunction_t fn_mm = fn_proj ? iprog->get_function(dev, "ingest_minmax", &errcode) : nullptr;
+	hipFunction_t fn_fin = fn_mm ? iprog->get_function(dev, "ingest_finish", &errcode) : nullptr;
+	if (!fn_proj || !fn_mm || !fn_fin)
+	{
+		*p_errcode = errcode;
+		return nullptr;
+	}
+	/* destination head: COLUMN, widths from the type oids */
+	cl_uint	nitems = task->res_nitems;
+	std::vector<char> hbuf(KDS_COLUMN_HEAD_LENGTH(ncols), 0);
+	kern_data_store *head = (kern_data_store *)hbuf.data();
+	head->ncols = ncols;						/* (the column directory sits behind ncols colmeta) */
+	kern_coldir *cd = KERN_DATA_STORE_COLDIR(head);
+	size_t	off = KDS_COLUMN_HEAD_LENGTH(ncols);
+	if ((char *)(cd + ncols) > hbuf.data() + hbuf.size())
+	{
+		*p_errcode = StromError_DataStoreCorruption;
+		return nullptr;
+	}
+	for (int i = 0; i < ncols; i++)
+	{
+		int		attlen;
+		switch (type_oids[i])
+		{
+			case STROM_BOOLOID: case STROM_BPCHAROID:	attlen = 1; break;
+			case STROM_INT2OID:							attlen = 2; break;
+			case STROM_INT4OID: case STROM_FLOAT4OID: case STROM_DATEOID:	attlen = 4; break;
+			default:									attlen = 8; break;
+		}
+		head->colmeta[i].attbyval = 1;
+		head->colmeta[i].attalign = (cl_char)attlen;
+		head->colmeta[i].attlen = (cl_short)attlen;
+		head->colmeta[i].attnum = (cl_short)(i + 1);
+		head->colmeta[i].attcacheoff = -1;
+		cd[i].values_off = (cl_uint)off;
+		off += KDS_COLUMN_VALUES_LENGTH(attlen, nitems);
+		cd[i].nulls_off = (cl_uint)off;			/* dropped by ingest_finish if unused */
+		off += KDS_COLUMN_NULLS_LENGTH(nitems);
+		cd[i].minval = (cl_long)~0UL;			/* unsigned-ordered seeds */
+		cd[i].maxval = 0;
+		if (off > 0xffffffffUL)
+		{
+			*p_errcode = StromError_DataStoreOutOfRange;
+			return nullptr;
+		}
+	}
+	head->length = (cl_uint)off;
+	head->nitems = nitems;
+	head->nrooms = nitems;
+	head->format = KDS_FORMAT_COLUMN;
+	head->tdtypeid = 2249;
+	head->tdtypmod = -1;
+
+	size_t	aux_ints = 4 * (size_t)ncols + 1;		/* depth map, column map, type oids, NULL flags, failure */
+	char   *d_dst = (char *)dev->pool.alloc(off);
+	cl_int *d_aux = (cl_int *)dev->pool.alloc(sizeof(cl_int) * aux_ints);
+	std::vector<cl_int> aux(aux_ints, 0);
+	memcpy(aux.data(), src_depth, sizeof(cl_int) * ncols);
+	memcpy(aux.data() + ncols, src_colidx, sizeof(cl_int) * ncols);
+	memcpy(aux.data() + 2 * ncols, type_oids, sizeof(cl_int) * ncols);
+	hipStream_t stream = dev->streams[0];
+	strom_dstore *result = nullptr;
+	do {
+		if (!d_dst || !d_aux)
+		{
+			*p_errcode = StromError_OutOfMemory;
+			break;
+		}
+		if (hipMemcpyAsync(d_dst, hbuf.data(), hbuf.size(), hipMemcpyHostToDevice, stream) != hipSuccess ||
+			hipMemcpyAsync(d_aux, aux.data(), sizeof(cl_int) * aux_ints, hipMemcpyHostToDevice, stream) != hipSuccess)
+		{
+			*p_errcode = StromError_HipInternal;
+			break;
+		}
+		void	   *a_khj = task->main_devptr;
+		const void *a_km = tbl->d_kmhash;
+		const void *a_kds = outer->devptr;
+		const void *a_toast = nullptr;
+		void	   *a_dst = d_dst;
+		const void *a_md = d_aux;
+		const void *a_mc = d_aux + ncols;
+		const void *a_oids = d_aux + 2 * ncols;
+		void	   *a_flags = d_aux + 3 * ncols;
+		void	   *args[] = { &a_khj, &a_km, &a_kds, &a_toast, &a_dst, &a_md, &a_mc, &a_flags };
+		void	   *args_mm[] = { &a_dst, &a_oids };
+		void	   *args_fin[] = { &a_dst, &a_oids, &a_flags };
+		unsigned	grid = (unsigned)std::min<size_t>(((size_t)nitems + 255) / 256,
+													  (size_t)dev->prop.multiProcessorCount * 8);
+		if (grid > 0 &&
+			(hipModuleLaunchKernel(fn_proj, grid, 1, 1, 256, 1, 1, 0, stream, args, nullptr) != hipSuccess ||
+			 hipModuleLaunchKernel(fn_mm, std::min(grid, (unsigned)dev->prop.multiProcessorCount * 4),
+								   (unsigned)ncols, 1, 256, 1, 1, 0, stream, args_mm, nullptr) != hipSuccess))
+		{
+			*p_errcode = StromError_HipInternal;
+			break;
+		}
+		if (hipModuleLaunchKernel(fn_fin, 1, 1, 1, 64, 1, 1, 0, stream, args_fin, nullptr) != hipSuccess)
+		{
+			*p_errcode = StromError_HipInternal;
+			break;
+		}
+		cl_int	failed = 0;
+		result = new strom_dstore{d_dst, off, outer->dindex, true, {}};
+		if (hipMemcpyAsync(&result->head, d_dst, offsetof(kern_data_store, colmeta),
+						   hipMemcpyDeviceToHost, stream) != hipSuccess ||
+			hipMemcpyAsync(&failed, d_aux + 4 * (size_t)ncols, sizeof(cl_int),
+						   hipMemcpyDeviceToHost, stream) != hipSuccess ||
+			hipStreamSynchronize(stream) != hipSuccess)
+		{
+			delete result;
+			result = nullptr;
+			*p_errcode = StromError_HipInternal;
+			break;
+		}
+		if (failed)
+		{
+			/* a mapped source column is not as wide as its destination type */
+			delete result;
+			result = nullptr;
+			*p_errcode = StromError_DataStoreCorruption;
+			break;
+		}
+	} while (0);
+	if (d_aux) dev->pool.release(d_aux);
+	if (!result && d_dst) dev->pool.release(d_dst);
+	return result;
 }

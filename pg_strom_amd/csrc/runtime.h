@@ -145,6 +145,7 @@ struct strom_task_impl : public strom_task {
 	size_t		res_offset = 0;
 	uint32_t	res_nitems = 0;
 	bool		res_is_scan = false;
+	bool		res_is_join = false;		/* GpuHashJoin likewise (strom_hashjoin_project_column) */
 	/* operator-specific second half, runs on the completer thread after the
 	 * first event fired; may issue further copies on 'stream' and must
 	 * leave the stream idle when it returns */

@@ -239,6 +239,30 @@ class GpuHashJoin(object):
                 out.append((v, isnull[:, i]))
             return nitems, out
 
+    def join_to_column(self, chunk, dest_columns, row_map=None, nrooms=None):
+        """join a RESIDENT chunk and leave the joined rows in HBM as a COLUMN chunk
+        for the next operator (strom_hashjoin_project_column): dest_columns as in
+        join_chunk_project.  Returns (DeviceStore, nitems); the result pairs never
+        cross PCIe."""
+        from .kds import SQL_TYPES
+        ncols = len(dest_columns)
+        depth = np.array([d for d, _, _ in dest_columns], dtype=np.int32)
+        colidx = np.array([a - 1 for _, a, _ in dest_columns], dtype=np.int32)
+        oids = np.array([SQL_TYPES[t][0] for _, _, t in dest_columns], dtype=np.int32)
+        for attempt in range(2):
+            pending = self.submit(chunk, nrooms=nrooms, row_map=row_map, flags=STROM_RESULTS_ON_DEVICE)
+            err = ctypes.c_int(0)
+            handle = lib.strom_hashjoin_project_column(pending[0], self.table, chunk.handle, ncols,
+                                                       depth.ctypes.data, colidx.ctypes.data,
+                                                       oids.ctypes.data, ctypes.byref(err))
+            res = self.collect(pending)
+            if not handle and err.value == ERR_NOSPACE and attempt == 0:
+                nrooms = res.nitems                          # resize and retry (gpuhashjoin.c:4330-4425)
+                continue
+            if not handle:
+                raise runtime.StromError(err.value, "strom_hashjoin_project_column")
+            return runtime.DeviceStore(handle, res.nitems), res.nitems
+
     def end(self):
         if self.table:
             lib.strom_hashjoin_table_release(self.table)

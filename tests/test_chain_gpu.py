@@ -124,3 +124,84 @@ def test_scan_over_a_device_row_map_and_recheck_fallback():
     finally:
         over.end()
         ds.release()
+
+
+def test_scan_join_preagg_chain_stays_in_hbm():
+    """GpuScan -> GpuHashJoin -> GpuPreAgg without a host round trip: the scan
+    leaves a row map, the join leaves its joined rows as a COLUMN chunk
+    (strom_hashjoin_project_column), GpuPreAgg runs its streaming kernels on it"""
+    runtime.init()
+    n, nd = 300007, 4000
+    rng = np.random.default_rng(61)
+    fk = rng.integers(0, int(nd * 1.25), n).astype(np.int32)
+    a = rng.integers(0, 2**31, n, dtype=np.int64).astype(np.int32)
+    an = rng.random(n) < 0.03
+    b = rng.random(n)
+    fact = kds.build_kds("column", [kds.Column("int4", fk), kds.Column("int4", a, an), kds.Column("float8", b)])
+    dkey = rng.permutation(nd).astype(np.int32)
+    dgrp = (dkey % 37).astype(np.int32)
+    dval = rng.random(nd) * 10
+    dvaln = rng.random(nd) < 0.05
+    inner = kds.build_kds("row_flat", [kds.Column("int4", dkey), kds.Column("int4", dgrp),
+                                       kds.Column("float8", dval, dvaln)])
+    km = build_multihash([(inner, [1])])
+    ext = [np.int32(2**30), 0.25]
+    ds = runtime.DeviceStore.upload(fact)
+    scan = GpuScan(QUAL).begin(ext_params=ext)
+    join = GpuHashJoin("(gpuhashjoin (rel (hashkey (var 1 int4) 1 int4)))").begin(km)
+    spec = ("(gpupreagg (key (var 1 int4)) (nrows) (nrows (isnotnull (var 2 int4))) (psum (int8 (var 2 int4)))"
+            " (psum (var 3 float8)) (pmax (var 4 float8)))")
+    agg = GpuPreAgg(spec)
+    try:
+        rowmap, _ = scan.scan_to_rowmap(ds)
+        # a deliberately small first result buffer: the resize-and-retry path
+        joined, nitems = join.join_to_column(ds, [(1, 2, "int4"), (0, 2, "int4"), (0, 3, "float8"), (1, 3, "float8")],
+                                             row_map=rowmap, nrooms=1000)
+        rowmap.release()
+        image = joined.download()
+        agg.begin([(0, 37)])
+        assert agg.fold(joined)[0] == 0
+        pr = agg.fetch()
+    finally:
+        agg.end()
+        join.end()
+        scan.end()
+        ds.release()
+    # the joined rows, as a set
+    an_eff = an.copy()
+    sel = np.flatnonzero((~an) & (a < ext[0]) & (b > ext[1]) & (fk < nd))
+    pos = np.empty(nd, dtype=np.int64)
+    pos[dkey] = np.arange(nd)
+    di = pos[fk[sel]]
+    assert nitems == len(sel)
+    cols = kds.decode_column_chunk(image)
+    assert len(cols) == 4 and all(len(c["values"]) == nitems for c in cols)
+    got = np.stack([cols[0]["values"].astype(np.int64), cols[1]["values"].astype(np.int64),
+                    cols[2]["values"].view(np.int64), cols[3]["values"].view(np.int64)], axis=1)
+    dval_img = np.where(dvaln, 0.0, dval)
+    want = np.stack([dgrp[di].astype(np.int64), a[sel].astype(np.int64), b[sel].view(np.int64),
+                     dval_img[di].view(np.int64)], axis=1)
+    order_g = np.lexsort(got.T[::-1])
+    order_w = np.lexsort(want.T[::-1])
+    assert np.array_equal(got[order_g], want[order_w])
+    assert cols[0]["notnull"] is None and cols[1]["notnull"] is None      # no NULL survives the qual / comes from dgrp
+    nn = cols[3]["notnull"]
+    assert nn is not None and int((~nn).sum()) == int(dvaln[di].sum())
+    assert cols[0]["stat_flags"] & 1 and cols[0]["minval"] == int(dgrp[di].min()) and cols[0]["maxval"] == int(dgrp[di].max())
+    # and the aggregate over them
+    g = dgrp[di]
+    keys, _ = pr.column(0)
+    order = np.argsort(keys)
+    ug, inv = np.unique(g, return_inverse=True)
+    assert np.array_equal(keys[order], ug)
+    assert np.array_equal(pr.column(1)[0][order], np.bincount(inv))
+    assert np.array_equal(pr.column(2)[0][order], np.bincount(inv))
+    assert np.array_equal(pr.column(3)[0][order], np.bincount(inv, weights=a[sel].astype(np.float64)).astype(np.int64))
+    wb = np.bincount(inv, weights=b[sel])
+    assert np.allclose(pr.column(4)[0][order], wb, rtol=1e-12)
+    wmax = np.full(len(ug), -np.inf)
+    ok = ~dvaln[di]
+    np.maximum.at(wmax, inv[ok], dval[di][ok])
+    gmax, gnull = pr.column(5)
+    assert np.array_equal(gnull[order], np.isinf(wmax))
+    assert np.array_equal(gmax[order][~np.isinf(wmax)], wmax[~np.isinf(wmax)])
