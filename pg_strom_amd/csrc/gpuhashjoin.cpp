@@ -737,8 +737,11 @@ strom_hashjoin_project_column(strom_task *handle, strom_hashjoin_table *tbl, str
 		void	   *args_fin[] = { &a_dst, &a_oids, &a_flags };
 		unsigned	grid = (unsigned)std::min<size_t>(((size_t)nitems + 255) / 256,
 													  (size_t)dev->prop.multiProcessorCount * 8);
+		/* (the projection takes 4 records per thread and turn: HASHJOIN_PROJ_ROWS) */
+		unsigned	pgrid = (unsigned)std::min<size_t>(((size_t)nitems + 1023) / 1024,
+													   (size_t)dev->prop.multiProcessorCount * 8);
 		if (grid > 0 &&
-			(hipModuleLaunchKernel(fn_proj, grid, 1, 1, 256, 1, 1, 0, stream, args, nullptr) != hipSuccess ||
+			(hipModuleLaunchKernel(fn_proj, pgrid, 1, 1, 256, 1, 1, 0, stream, args, nullptr) != hipSuccess ||
 			 hipModuleLaunchKernel(fn_mm, std::min(grid, (unsigned)dev->prop.multiProcessorCount * 4),
 								   (unsigned)ncols, 1, 256, 1, 1, 0, stream, args_mm, nullptr) != hipSuccess))
 		{
