@@ -275,7 +275,11 @@ int			strom_gpupreagg_compact(strom_gpupreagg *sess, const uint32_t *bitmap, siz
  * strom_gpupreagg_num_groups() returns the groups seen so far.  Sessions of
  * several ranks are merged by concatenating their partial rows: the final
  * aggregate adds them up (pg_strom--1.0.sql:247-401).
- * ngroups_hint sizes the first table (0 = default).
+ * ngroups_hint sizes the first table (0 = default) and picks the number of
+ * hash roles of the first fold.  The hashed kernels are a device program of
+ * their own, derived from 'key' by the library (its source behind
+ * "#define GPUPREAGG_HASHED 1"); it builds in the background and the first
+ * fold waits for it.  A caller may also pass the key of that derived program.
  */
 strom_gpupreagg *strom_gpupreagg_create_hashed(strom_devprog_key key,
 											   const strom_preagg_target *targets, int ntargets,

@@ -496,6 +496,13 @@ gpupreagg_load_kparams(strom_kparams &KP, const kern_parambuf *kparams, cl_int *
 	KP.__dummy = 0;
 }
 
+/*
+ * A program is built either with the dense-id kernels or, for a session made
+ * by strom_gpupreagg_create_hashed (which derives it from the caller's program
+ * by defining GPUPREAGG_HASHED), with the hashed GROUP BY kernels: a query uses
+ * one of the two, and hiprtc time is paid per kernel.
+ */
+#ifndef GPUPREAGG_HASHED
 /* ====================================================================== *
  * dense-id reduction, COLUMN format
  * ====================================================================== */
@@ -1385,6 +1392,9 @@ gpupreagg_reg1_column(kern_gpupreagg *kgpreagg, const kern_data_store *kds,
 	gpupreagg_reg_kernel_body<1>(kgpreagg, kds, ctl, slabs, lds);
 }
 
+#endif	/* !GPUPREAGG_HASHED */
+
+#ifdef GPUPREAGG_HASHED
 /* ====================================================================== *
  * hashed GROUP BY: any key type, any key range
  *
@@ -2080,6 +2090,9 @@ gpupreagg_hash_rehash(const char *otab, char *ntab)
 	}
 }
 
+#endif	/* GPUPREAGG_HASHED */
+
+#ifndef GPUPREAGG_HASHED
 /* ====================================================================== *
  * census: which dense ids occur in this chunk (after the qual)?
  *
@@ -2291,5 +2304,7 @@ gpupreagg_dense_merge(const kern_gpupreagg *__restrict__ kgpreagg,
 			t_flags[gid] = had | flags;
 	}
 }
+
+#endif	/* !GPUPREAGG_HASHED */
 
 #endif	/* STROM_GPUPREAGG_DEVICE_H */

@@ -932,8 +932,24 @@ strom_gpupreagg_create_hashed(strom_devprog_key key,
 							  uint32_t ngroups_hint,
 							  int dindex, int *p_errcode)
 {
-	strom_gpupreagg *sess = gpupreagg_session_new(key, targets, ntargets, kparams, nullptr, true,
+	/* the hashed kernels are a program of their own, derived from the caller's
+	 * (strom_gpupreagg.h builds one family or the other); it builds in the
+	 * background, the first fold parks behind it */
+	Program *base = lookup_program(key);
+	if (!base)
+	{
+		if (p_errcode)
+			*p_errcode = StromError_BadRequestMessage;
+		return nullptr;
+	}
+	const char *hashed_define = "#define GPUPREAGG_HASHED 1\n";
+	std::string	hsource = base->source;
+	if (hsource.compare(0, strlen(hashed_define), hashed_define) != 0)
+		hsource = hashed_define + hsource;	/* (a caller may also hand over the derived program itself) */
+	strom_devprog_key hkey = strom_get_devprog_key(hsource.c_str(), base->extra_flags);
+	strom_gpupreagg *sess = gpupreagg_session_new(hkey, targets, ntargets, kparams, nullptr, true,
 												  dindex, p_errcode);
+	strom_put_devprog_key(hkey);			/* the session holds its own reference */
 	if (!sess)
 		return nullptr;
 	/* the table itself is made by the first fold (the program may still be building) */

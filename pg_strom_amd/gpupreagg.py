@@ -125,7 +125,10 @@ class GpuPreAgg(object):
         """GROUP BY over keys of any type / spread: groups live in a hash table in
         HBM (strom_gpupreagg_create_hashed); same submit / fetch calls afterwards"""
         runtime.init()
-        self.program = runtime.DevProgram(self.codegen.source, self.codegen.extra_flags)
+        # the hashed kernels are a program of their own (strom_gpupreagg.h builds either
+        # family); asking for it directly spares the build of the dense one
+        self.program = runtime.DevProgram("#define GPUPREAGG_HASHED 1\n" + self.codegen.source,
+                                          self.codegen.extra_flags)
         self.parambuf = self.codegen.parambuf(ext_params, ext_isnull)
         err = ctypes.c_int(0)
         pb = ctypes.create_string_buffer(self.parambuf, len(self.parambuf))
