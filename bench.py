@@ -126,6 +126,79 @@ def cpu_baseline_columnar(k, c, seconds=3.0):
             "sample": "%d x %d-row column arrays, numpy (a<k)&(b>c) -> row ids, %.1f s" % (reps, n, dt)}
 
 
+def other_operator_rates(nrows):
+    """N=1 only, after the timed region: the other two operators of BASELINE.json's metric
+    ("scan+hashjoin+groupby") on a resident chunk of the same size, kernel time from the
+    runtime's events, plus the three chained on the device.  Reported next to the headline,
+    never part of `value`."""
+    from pg_strom_amd import kds, runtime
+    from pg_strom_amd.gpuhashjoin import GpuHashJoin, build_multihash
+    from pg_strom_amd.gpupreagg import GpuPreAgg
+    from pg_strom_amd.gpuscan import GpuScan
+    nd, ngroups = 1_000_000, 10_000
+    rng = np.random.default_rng(0x5eed0003)
+    fk = rng.integers(0, int(nd * 1.25), nrows, dtype=np.int64).astype(np.int32)
+    a = rng.integers(0, 2**31, nrows, dtype=np.int64).astype(np.int32)
+    b = rng.random(nrows)
+    fact = runtime.DeviceStore.upload(kds.build_kds("column", [kds.Column("int4", fk), kds.Column("int4", a),
+                                                               kds.Column("float8", b)]), 0)
+    dkey = rng.permutation(nd).astype(np.int32)
+    dgrp = (dkey % ngroups).astype(np.int32)
+    km = build_multihash([(kds.build_kds("row_flat", [kds.Column("int4", dkey), kds.Column("int4", dgrp)]), [1])])
+    out = {"rows": nrows}
+    join = GpuHashJoin("(gpuhashjoin (rel (hashkey (var 1 int4) 1 int4)))", row_population_ratio=0.8).begin(km)
+    ts = []
+    for _ in range(5):
+        r = join.join_chunk(fact, flags=1)                      # results stay on the device
+        ts.append(r.perfmon["time_kern_exec_ns"])
+    t = float(np.median(ts[1:])) * 1e-9
+    out["gpuhashjoin_c3"] = {"workload": "%d fact x %d dim on int4 key, 80%% match" % (nrows, nd),
+                             "kernel_us": t * 1e6, "mrows_s": nrows / t / 1e6,
+                             "achieved_gbs": (4.0 * nrows + 8.0 * r.nitems) / t / 1e9}
+    # C4: GROUP BY int4 (1e4 groups) count / sum / avg partials
+    g = (fk % ngroups).astype(np.int32)
+    c4 = runtime.DeviceStore.upload(kds.build_kds("column", [kds.Column("int4", g), kds.Column("int4", a),
+                                                             kds.Column("float8", b)]), 0)
+    agg = GpuPreAgg("(gpupreagg (key (var 1 int4)) (nrows) (psum (int8 (var 2 int4))) (psum (var 3 float8)))")
+    agg.begin([(0, ngroups)])
+    ts = []
+    for _ in range(5):
+        st, pfm = agg.fold(c4)
+        ts.append(pfm["time_kern_exec_ns"])
+    t = float(np.median(ts[1:])) * 1e-9
+    out["gpupreagg_c4"] = {"workload": "GROUP BY int4 (%d groups) count, sum(int4), sum(float8) over %d rows" % (ngroups, nrows),
+                           "kernel_us": t * 1e6, "mrows_s": nrows / t / 1e6, "achieved_gbs": 16.0 * nrows / t / 1e9}
+    agg.end()
+    c4.release()
+    # scan -> join -> group by, nothing leaves HBM in between
+    ext = [np.int32(2**30), 0.0]
+    scan = GpuScan("(and (int4lt (var 2 int4) (param 0 int4)) (float8gt (var 3 float8) (param 1 float8)))").begin(ext_params=ext)
+    agg = GpuPreAgg("(gpupreagg (key (var 1 int4)) (nrows) (psum (int8 (var 2 int4))) (psum (var 3 float8)))")
+    agg.begin([(0, ngroups)])
+    walls = []
+    for _ in range(4):
+        agg.reset()
+        t0 = time.perf_counter()
+        rowmap, res = scan.scan_to_rowmap(fact)
+        joined, nitems = join.join_to_column(fact, [(1, 2, "int4"), (0, 2, "int4"), (0, 3, "float8")],
+                                             row_map=rowmap, nrooms=int(res.nitems * 0.82) + 1000)
+        agg.fold(joined)
+        pr = agg.fetch()
+        walls.append(time.perf_counter() - t0)
+        rowmap.release()
+        joined.release()
+    t = float(np.median(walls[1:]))
+    out["scan_join_groupby_chain"] = {"workload": "WHERE keeps 50%%, join 80%% match, GROUP BY dim column (%d groups), "
+                                                  "device-resident hand-overs" % ngroups,
+                                      "wall_ms": t * 1e3, "mrows_s": nrows / t / 1e6,
+                                      "joined_rows": int(nitems), "groups": len(pr)}
+    agg.end()
+    scan.end()
+    join.end()
+    fact.release()
+    return out
+
+
 def load_traffic(chunk_rows):
     """per-launch HBM bytes from the committed rocprofv3 --pmc passes, if any"""
     path = os.path.join(ROOT, "profiles", "gpuscan_traffic.json")
@@ -149,6 +222,8 @@ def main():
                     help="requests kept in flight (pg_strom.max_async_chunks)")
     ap.add_argument("--selectivity", type=float, default=0.10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip the GpuHashJoin / GpuPreAgg / chain figures reported next to the headline")
     ap.add_argument("--cpu-worker", default=None, help=argparse.SUPPRESS)
     args = ap.parse_args()
     if args.cpu_worker:
@@ -300,6 +375,11 @@ def main():
             out["cpu_baseline"] = cpu_baseline(k, c)
             out["cpu_baseline_all_cores"] = cpu_baseline_all_cores(k, c)
             out["cpu_baseline_columnar"] = cpu_baseline_columnar(k, c)
+        if ngpus == 1 and not args.no_extras and not args.no_cpu_baseline:
+            try:
+                out["other_operators"] = other_operator_rates(min(nrows, 100_000_000))
+            except Exception as e:                  # never at the expense of the headline line
+                out["other_operators"] = {"error": "%s: %s" % (type(e).__name__, e)}
         print(json.dumps(out), flush=True)
 
     scan.end()
