@@ -192,6 +192,24 @@ def other_operator_rates(nrows):
                                                   "device-resident hand-overs" % ngroups,
                                       "wall_ms": t * 1e3, "mrows_s": nrows / t / 1e6,
                                       "joined_rows": int(nitems), "groups": len(pr)}
+    # the same query planned the reference's way: the WHERE pulled up into the join
+    # (gpuhashjoin.c:2047-2050) -- no scan pass, the one-pass join kernel
+    join2 = GpuHashJoin("(gpuhashjoin (rel (hashkey (var 1 int4) 1 int4) (qual (and (int4lt (var 2 int4) (param 0 int4))"
+                        " (float8gt (var 3 float8) (param 1 float8))))))", row_population_ratio=0.45).begin(km, ext_params=ext)
+    walls = []
+    for _ in range(4):
+        agg.reset()
+        t0 = time.perf_counter()
+        joined, nitems2 = join2.join_to_column(fact, [(1, 2, "int4"), (0, 2, "int4"), (0, 3, "float8")])
+        agg.fold(joined)
+        pr = agg.fetch()
+        walls.append(time.perf_counter() - t0)
+        joined.release()
+    t = float(np.median(walls[1:]))
+    out["join_with_pulled_up_qual_groupby"] = {"workload": "same query, WHERE inside the join program",
+                                               "wall_ms": t * 1e3, "mrows_s": nrows / t / 1e6,
+                                               "joined_rows": int(nitems2), "groups": len(pr)}
+    join2.end()
     agg.end()
     scan.end()
     join.end()

@@ -144,9 +144,13 @@ strom_codegen_gpuhashjoin(const char *spec, strom_codegen_result *out, int *p_nr
 		snprintf(tmp, sizeof(tmp), "#define HASHJOIN_NRELS %d\n", nrels);
 		src += tmp;
 		/* fast path: one relation, one integer-like key, nothing else to test */
-		bool	fast = (nrels == 1 && rels[0].keys.size() == 1 && rels[0].qual_text.empty() &&
+		/* (a qual that reads outer columns only -- a scan's WHERE pulled up into
+		 * the join -- rides along: HASHJOIN_FAST_OUTER_QUAL) */
+		bool	fast = (nrels == 1 && rels[0].keys.size() == 1 &&
 						type_is_intlike(rels[0].keys[0].type_oid) && ctx.used_ivars.empty());
-		snprintf(tmp, sizeof(tmp), "#define HASHJOIN_FAST_ELIGIBLE %d\n", fast ? 1 : 0);
+		bool	fast_qual = (fast && !rels[0].qual_text.empty());
+		snprintf(tmp, sizeof(tmp), "#define HASHJOIN_FAST_ELIGIBLE %d\n#define HASHJOIN_FAST_OUTER_QUAL %d\n",
+				 fast ? 1 : 0, fast_qual ? 1 : 0);
 		src += tmp;
 		for (int d = 1; d <= nrels; d++)
 		{
@@ -198,6 +202,10 @@ strom_codegen_gpuhashjoin(const char *spec, strom_codegen_result *out, int *p_nr
 			src += "STROM_DEVICE bool\n"
 				"hashjoin_fast_outer_key(cl_int *errcode, const strom_kparams &KP, const strom_kvars &KV,\n"
 				"                        cl_long *p_key)\n{\n  return false;\n}\n";
+		if (fast_qual)
+			src += "STROM_DEVICE bool\n"
+				"hashjoin_fast_outer_qual(cl_int *errcode, const strom_kparams &KP, const strom_kvars &KV)\n"
+				"{\n  pg_bool_t q = " + rels[0].qual_text + ";\n  return EVAL(q);\n}\n";
 
 		/* ---- gpuhashjoin_execute: nested probe loops --------------------- */
 		/* ALL_SINGLE: every relation has a DIRECT index with unique keys (the

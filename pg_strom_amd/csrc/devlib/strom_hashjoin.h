@@ -147,6 +147,10 @@ hashjoin_inner_key_images(int depth, const kern_hashtable *kht, const kern_hashe
 STROM_DEVICE bool
 hashjoin_fast_outer_key(cl_int *errcode, const strom_kparams &KP, const strom_kvars &KV,
 						cl_long *p_key);
+#if HASHJOIN_FAST_OUTER_QUAL
+STROM_DEVICE bool
+hashjoin_fast_outer_qual(cl_int *errcode, const strom_kparams &KP, const strom_kvars &KV);
+#endif
 template <bool ALL_SINGLE>
 STROM_DEVICE cl_uint
 gpuhashjoin_execute(cl_int *errcode, const strom_kparams &KP, const strom_kvars &KV,
@@ -725,6 +729,38 @@ gpuhashjoin_main_fast(kern_hashjoin *khashjoin,
 				}
 			}
 		}
+#if HASHJOIN_FAST_OUTER_QUAL
+		/* a qual over outer columns only (a scan's WHERE pulled up into the
+		 * join, gpuhashjoin.c:2047-2050): evaluated, like in the general kernel,
+		 * for rows that found their entry -- in a loop of its own so that the
+		 * slot reads above stay back to back */
+#pragma unroll
+		for (int k = 0; k < HASHJOIN_QUADS; k++)
+		{
+#pragma unroll
+			for (int j = 0; j < 4; j++)
+			{
+				if (match[k][j] != 0)
+				{
+					strom_kvars	KV;
+					cl_int		errcode = param_error;
+#define X(attno,colidx,NAME)													\
+					KV.KVAR_##attno = pg_##NAME##_make(T.v_##attno[k][j],			\
+													   !((T.nn_##attno[k] >> j) & 1));
+					STROM_KVAR_LIST(X)
+#undef X
+					KV.__dummy = 0;
+					if (!hashjoin_fast_outer_qual(&errcode, KP, KV))
+						match[k][j] = 0;
+					if (errcode != StromError_Success)
+					{
+						STROM_SET_ERROR(&chunk_error, errcode);
+						match[k][j] = 0;
+					}
+				}
+			}
+		}
+#endif
 		if (fill + HASHJOIN_TILE_ROWS > HASHJOIN_STAGE)
 		{
 			/* flush: one reservation, contiguous store */

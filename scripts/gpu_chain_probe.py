@@ -48,6 +48,22 @@ for it in range(4):
           " | total %.2f ms = %.0f Mrows/s of fact rows" % (
               it, (t1 - t0) * 1e3, res.nitems, (t2 - t1) * 1e3, nitems, (t3 - t2) * 1e3,
               pfm["time_kern_exec_ns"] * 1e-3, len(pr), (t3 - t0) * 1e3, n / (t3 - t0) / 1e6), flush=True)
+# the same query with the WHERE pulled up into the join (the reference's plan shape,
+# gpuhashjoin.c:2047-2050): no scan pass, no row map, the one-pass join kernel
+join2 = GpuHashJoin("(gpuhashjoin (rel (hashkey (var 1 int4) 1 int4) (qual " + qual + ")))",
+                    row_population_ratio=0.45).begin(km, ext_params=ext)
+for it in range(4):
+    agg.reset()
+    t0 = time.perf_counter()
+    joined, nitems = join2.join_to_column(ds, [(1, 2, "int4"), (0, 2, "int4"), (0, 3, "float8")])
+    t1 = time.perf_counter()
+    st, pfm = agg.fold(joined)
+    pr = agg.fetch()
+    t2 = time.perf_counter()
+    joined.release()
+    print("pulled-up pass %d: join+project %.2f ms (%d rows) | preagg+fetch %.2f ms | total %.2f ms = %.0f Mrows/s of fact rows" % (
+        it, (t1 - t0) * 1e3, nitems, (t2 - t1) * 1e3, (t2 - t0) * 1e3, n / (t2 - t0) / 1e6), flush=True)
+join2.end()
 m = (a < ext[0]) & (b > ext[1]) & (fk < nd)
 pos = np.empty(nd, dtype=np.int64); pos[dkey] = np.arange(nd)
 g = dgrp[pos[fk[m]]]

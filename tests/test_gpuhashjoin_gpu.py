@@ -227,3 +227,52 @@ def test_numeric_key_from_varlena_outer(ofmt):
     res, info = run_and_compare(spec, outer, [inner], [[1]])
     present = set(int(round(float(v) * 100)) for v in dim_vals)
     assert res.nitems == sum(1 for x, isn in zip(pick, fn) if not isn and int(x) in present)
+
+
+@pytest.mark.parametrize("ofmt", ["column", "row"])
+@pytest.mark.parametrize("dup", [False, True])
+def test_outer_only_qual_pulled_up_into_the_join(ofmt, dup):
+    """a scan's WHERE pulled up into the join (gpuhashjoin.c:2047-2050): with a
+    COLUMN outer chunk and unique keys this runs in the one-pass kernel, which
+    evaluates the qual for rows that found their entry, like the general kernel
+    (other formats / duplicate keys); NULL quals reject"""
+    pk, payload, pkn, fk, fkn = fact_dim(50021, 3000, 19, dup=dup)
+    rng = np.random.default_rng(23)
+    a = rng.integers(0, 2**31, len(fk), dtype=np.int64).astype(np.int32)
+    an = rng.random(len(fk)) < 0.03
+    b = rng.random(len(fk))
+    inner = kds.build_kds("row", [kds.Column("int4", pk, pkn), kds.Column("int4", payload)])
+    outer = kds.build_kds(ofmt, [kds.Column("int4", fk, fkn), kds.Column("int4", a, an), kds.Column("float8", b)])
+    spec = ("(gpuhashjoin (rel (hashkey (var 1 int4) 1 int4)"
+            " (qual (and (int4lt (var 2 int4) (param 0 int4)) (float8gt (var 3 float8) (param 1 float8))))))")
+    res, info = run_and_compare(spec, outer, [inner], [[1]], ext=[np.int32(2**30), 0.25],
+                                expect_mode="direct", ratio=2.0 if dup else 1.0)
+    assert 0 < res.nitems < len(fk) // 2
+
+
+def test_pulled_up_qual_errors_only_count_for_rows_that_match():
+    """int4 overflow in the qual: CpuReCheck if a MATCHING row hits it, nothing if
+    only rows without a partner do (the qual is not evaluated for those)"""
+    pk = np.arange(100, dtype=np.int32)
+    inner = kds.build_kds("row", [kds.Column("int4", pk), kds.Column("int4", pk)])
+    spec = ("(gpuhashjoin (rel (hashkey (var 1 int4) 1 int4)"
+            " (qual (int4gt (int4pl (var 2 int4) (const int4 1)) (const int4 0)))))")
+    km = build_multihash([(inner, [1])])
+    for bad_matches, want_rc in ((False, 0), (True, 2)):
+        fk = np.array([5, 500, 7, 9] * 50, dtype=np.int32)
+        a = np.ones(len(fk), dtype=np.int32)
+        a[1 if not bad_matches else 0] = 2**31 - 1         # row 1 has no partner (fk = 500), row 0 has
+        outer = kds.build_kds("column", [kds.Column("int4", fk), kds.Column("int4", a)])
+        rc_o, n_o, _ = oracle.gpuhashjoin(spec, outer, [inner], [])
+        assert rc_o == want_rc
+        join = GpuHashJoin(spec).begin(km)
+        try:
+            if want_rc == 0:
+                res = join.join_chunk(outer)
+                assert res.errcode == 0 and res.nitems == n_o == 150
+            else:
+                with pytest.raises(runtime.StromError) as ei:
+                    join.join_chunk(outer)
+                assert ei.value.errcode == 2
+        finally:
+            join.end()
