@@ -9,6 +9,7 @@
  * plus the probe index built from it (strom_hashjoin.h).
  */
 #include <cstring>
+#include <map>
 #include <cstdio>
 #include <algorithm>
 
@@ -53,6 +54,10 @@ struct strom_hashjoin_table {
 	index_head			head;
 	int					ntables = 0;
 	std::atomic<int>	refcnt{1};
+	/* inner columns by slot for the COLUMN projection (DIRECT index, unique
+	 * keys): (0-based column, attlen) -> {values, isnull}, built on first use */
+	std::mutex			dim_lock;
+	std::map<std::pair<int, int>, std::pair<char *, char *>> dimcols;
 };
 
 extern "C" strom_hashjoin_table *
@@ -205,6 +210,11 @@ strom_hashjoin_table_release(strom_hashjoin_table *tbl)
 		(void)hipStreamSynchronize(st);
 	dev->pool.release(tbl->d_kmhash);
 	dev->pool.release(tbl->d_index);
+	for (auto &kv : tbl->dimcols)
+	{
+		dev->pool.release(kv.second.first);
+		dev->pool.release(kv.second.second);
+	}
 	strom_put_devprog_key(tbl->key);
 	delete tbl;
 }
@@ -702,9 +712,65 @@ strom_hashjoin_project_column(strom_task *handle, strom_hashjoin_table *tbl, str
 	head->tdtypeid = 2249;
 	head->tdtypmod = -1;
 
+	/*
+	 * inner columns of a DIRECT, unique-key, single-relation table come from
+	 * slot-indexed arrays (hashjoin_build_dimcol_kernel) instead of the entries
+	 */
+	std::vector<cl_ulong> dimptr(2 * (size_t)ncols, 0);
+	bool	use_dim = (tbl->ntables == 1 && tbl->head.rel[0].mode == 1 && tbl->head.rel[0].unique &&
+					   outer->head.format == KDS_FORMAT_COLUMN &&
+					   strstr(tbl->prog->source.c_str(), "#define HASHJOIN_FAST_ELIGIBLE 1") != nullptr &&
+					   !getenv("STROM_HASHJOIN_NO_DIMCOLS"));
+	for (int i = 0; use_dim && i < ncols; i++)
+	{
+		if (src_depth[i] != 1)
+			continue;
+		int		attlen = head->colmeta[i].attlen;
+		std::lock_guard<std::mutex> g(tbl->dim_lock);
+		auto	it = tbl->dimcols.find({src_colidx[i], attlen});
+		if (it == tbl->dimcols.end())
+		{
+			cl_uint	nslots = tbl->head.rel[0].nslots;
+			hipFunction_t fn_dim = tbl->prog->get_function(dev, "hashjoin_build_dimcol_kernel", &errcode);
+			char   *d_vals = (char *)dev->pool.alloc((size_t)attlen * nslots + 16);
+			char   *d_null = (char *)dev->pool.alloc((size_t)nslots + 16);
+			cl_uint	failed = 1;
+			if (fn_dim && d_vals && d_null)
+			{
+				const void *a_km = tbl->d_kmhash;
+				const void *a_idx = tbl->d_index;
+				cl_int		a_col = src_colidx[i], a_len = attlen;
+				void	   *a_vals = d_vals, *a_null = d_null;
+				void	   *a_failed = d_null + nslots;		/* 4-byte flag behind the array (offset kept aligned below) */
+				a_failed = d_null + (((size_t)nslots + 3) & ~(size_t)3);
+				void	   *args[] = { &a_km, &a_idx, &a_col, &a_len, &a_vals, &a_null, &a_failed };
+				unsigned	grid = std::max(1u, std::min<unsigned>((nslots + 255) / 256,
+																   (unsigned)dev->prop.multiProcessorCount * 8));
+				if (hipMemsetAsync(a_failed, 0, sizeof(cl_uint), dev->streams[0]) == hipSuccess &&
+					hipModuleLaunchKernel(fn_dim, grid, 1, 1, 256, 1, 1, 0, dev->streams[0], args, nullptr) == hipSuccess &&
+					hipMemcpyAsync(&failed, a_failed, sizeof(cl_uint), hipMemcpyDeviceToHost, dev->streams[0]) == hipSuccess &&
+					hipStreamSynchronize(dev->streams[0]) == hipSuccess)
+					;
+				else
+					failed = 1;
+			}
+			if (failed)
+			{
+				/* no such column / another width: the entry path reports it */
+				if (d_vals) dev->pool.release(d_vals);
+				if (d_null) dev->pool.release(d_null);
+				continue;
+			}
+			it = tbl->dimcols.insert({{src_colidx[i], attlen}, {d_vals, d_null}}).first;
+		}
+		dimptr[2 * i] = (cl_ulong)(uintptr_t)it->second.first;
+		dimptr[2 * i + 1] = (cl_ulong)(uintptr_t)it->second.second;
+	}
+
 	size_t	aux_ints = 4 * (size_t)ncols + 1;		/* depth map, column map, type oids, NULL flags, failure */
 	char   *d_dst = (char *)dev->pool.alloc(off);
 	cl_int *d_aux = (cl_int *)dev->pool.alloc(sizeof(cl_int) * aux_ints);
+	cl_ulong *d_dimptr = (cl_ulong *)dev->pool.alloc(sizeof(cl_ulong) * dimptr.size());
 	std::vector<cl_int> aux(aux_ints, 0);
 	memcpy(aux.data(), src_depth, sizeof(cl_int) * ncols);
 	memcpy(aux.data() + ncols, src_colidx, sizeof(cl_int) * ncols);
@@ -712,12 +778,14 @@ strom_hashjoin_project_column(strom_task *handle, strom_hashjoin_table *tbl, str
 	hipStream_t stream = dev->streams[0];
 	strom_dstore *result = nullptr;
 	do {
-		if (!d_dst || !d_aux)
+		if (!d_dst || !d_aux || !d_dimptr)
 		{
 			*p_errcode = StromError_OutOfMemory;
 			break;
 		}
 		if (hipMemcpyAsync(d_dst, hbuf.data(), hbuf.size(), hipMemcpyHostToDevice, stream) != hipSuccess ||
+			hipMemcpyAsync(d_dimptr, dimptr.data(), sizeof(cl_ulong) * dimptr.size(),
+						   hipMemcpyHostToDevice, stream) != hipSuccess ||
 			hipMemcpyAsync(d_aux, aux.data(), sizeof(cl_int) * aux_ints, hipMemcpyHostToDevice, stream) != hipSuccess)
 		{
 			*p_errcode = StromError_HipInternal;
@@ -732,7 +800,9 @@ strom_hashjoin_project_column(strom_task *handle, strom_hashjoin_table *tbl, str
 		const void *a_mc = d_aux + ncols;
 		const void *a_oids = d_aux + 2 * ncols;
 		void	   *a_flags = d_aux + 3 * ncols;
-		void	   *args[] = { &a_khj, &a_km, &a_kds, &a_toast, &a_dst, &a_md, &a_mc, &a_flags };
+		const void *a_hjidx = tbl->d_index;
+		const void *a_dimptr = d_dimptr;
+		void	   *args[] = { &a_khj, &a_km, &a_kds, &a_toast, &a_dst, &a_md, &a_mc, &a_flags, &a_hjidx, &a_dimptr };
 		void	   *args_mm[] = { &a_dst, &a_oids };
 		void	   *args_fin[] = { &a_dst, &a_oids, &a_flags };
 		unsigned	grid = (unsigned)std::min<size_t>(((size_t)nitems + 255) / 256,
@@ -776,6 +846,7 @@ strom_hashjoin_project_column(strom_task *handle, strom_hashjoin_table *tbl, str
 		}
 	} while (0);
 	if (d_aux) dev->pool.release(d_aux);
+	if (d_dimptr) dev->pool.release(d_dimptr);
 	if (!result && d_dst) dev->pool.release(d_dst);
 	return result;
 }
