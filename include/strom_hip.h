@@ -361,7 +361,11 @@ strom_task *strom_submit_gpuhashjoin_projection(strom_hashjoin_table *tbl,
  * another GpuHashJoin take as a strom_dstore.  Column r takes column
  * src_colidx[r] (0-based) of relation src_depth[r]; type_oids[r] gives its
  * width, which must equal the source's (StromError_DataStoreCorruption
- * otherwise).  Fixed-width by-value columns.  A join that ended with
+ * otherwise); a NEGATIVE oid means "that type, no zone map needed" and
+ * spares the min/max pass over the column.  Fixed-width by-value columns.
+ * Inner columns of a single-relation table with a DIRECT index and unique
+ * keys are served from slot-indexed arrays the table builds on first use.
+ * A join that ended with
  * StromError_DataStoreNoSpace is reported as such: resize, join again.
  */
 strom_dstore *strom_hashjoin_project_column(strom_task *join_task, strom_hashjoin_table *tbl,

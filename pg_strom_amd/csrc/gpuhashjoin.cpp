@@ -681,7 +681,7 @@ strom_hashjoin_project_column(strom_task *handle, strom_hashjoin_table *tbl, str
 	for (int i = 0; i < ncols; i++)
 	{
 		int		attlen;
-		switch (type_oids[i])
+		switch (type_oids[i] < 0 ? -type_oids[i] : type_oids[i])
 		{
 			case STROM_BOOLOID: case STROM_BPCHAROID:	attlen = 1; break;
 			case STROM_INT2OID:							attlen = 2; break;
@@ -774,7 +774,13 @@ strom_hashjoin_project_column(strom_task *handle, strom_hashjoin_table *tbl, str
 	std::vector<cl_int> aux(aux_ints, 0);
 	memcpy(aux.data(), src_depth, sizeof(cl_int) * ncols);
 	memcpy(aux.data() + ncols, src_colidx, sizeof(cl_int) * ncols);
-	memcpy(aux.data() + 2 * ncols, type_oids, sizeof(cl_int) * ncols);
+	/* a negative oid: that type, but no zone map wanted (ingest_minmax skips oid 0) */
+	bool	any_zone_map = false;
+	for (int i = 0; i < ncols; i++)
+	{
+		aux[2 * ncols + i] = (type_oids[i] > 0 ? type_oids[i] : 0);
+		any_zone_map = any_zone_map || (type_oids[i] > 0);
+	}
 	hipStream_t stream = dev->streams[0];
 	strom_dstore *result = nullptr;
 	do {
@@ -812,8 +818,9 @@ strom_hashjoin_project_column(strom_task *handle, strom_hashjoin_table *tbl, str
 													   (size_t)dev->prop.multiProcessorCount * 8);
 		if (grid > 0 &&
 			(hipModuleLaunchKernel(fn_proj, pgrid, 1, 1, 256, 1, 1, 0, stream, args, nullptr) != hipSuccess ||
-			 hipModuleLaunchKernel(fn_mm, std::min(grid, (unsigned)dev->prop.multiProcessorCount * 4),
-								   (unsigned)ncols, 1, 256, 1, 1, 0, stream, args_mm, nullptr) != hipSuccess))
+			 (any_zone_map &&
+			  hipModuleLaunchKernel(fn_mm, std::min(grid, (unsigned)dev->prop.multiProcessorCount * 4),
+									(unsigned)ncols, 1, 256, 1, 1, 0, stream, args_mm, nullptr) != hipSuccess)))
 		{
 			*p_errcode = StromError_HipInternal;
 			break;

@@ -239,16 +239,18 @@ class GpuHashJoin(object):
                 out.append((v, isnull[:, i]))
             return nitems, out
 
-    def join_to_column(self, chunk, dest_columns, row_map=None, nrooms=None):
+    def join_to_column(self, chunk, dest_columns, row_map=None, nrooms=None, zone_maps=True):
         """join a RESIDENT chunk and leave the joined rows in HBM as a COLUMN chunk
         for the next operator (strom_hashjoin_project_column): dest_columns as in
         join_chunk_project.  Returns (DeviceStore, nitems); the result pairs never
-        cross PCIe."""
+        cross PCIe.  zone_maps=False when the consumer brings its own key domain."""
         from .kds import SQL_TYPES
         ncols = len(dest_columns)
         depth = np.array([d for d, _, _ in dest_columns], dtype=np.int32)
         colidx = np.array([a - 1 for _, a, _ in dest_columns], dtype=np.int32)
         oids = np.array([SQL_TYPES[t][0] for _, _, t in dest_columns], dtype=np.int32)
+        if not zone_maps:
+            oids = -oids                                     # widths only: no min/max pass
         for attempt in range(2):
             pending = self.submit(chunk, nrooms=nrooms, row_map=row_map, flags=STROM_RESULTS_ON_DEVICE)
             err = ctypes.c_int(0)

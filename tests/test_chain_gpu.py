@@ -205,3 +205,53 @@ def test_scan_join_preagg_chain_stays_in_hbm():
     gmax, gnull = pr.column(5)
     assert np.array_equal(gnull[order], np.isinf(wmax))
     assert np.array_equal(gmax[order][~np.isinf(wmax)], wmax[~np.isinf(wmax)])
+
+
+def test_join_to_column_without_zone_maps_and_with_the_general_kernel():
+    """same joined rows whether the inner column comes from the slot-indexed array
+    (DIRECT index, unique keys) or from the entries (duplicate keys: general
+    kernel, no such array), with or without the min/max pass"""
+    runtime.init()
+    n, nd = 100003, 3000
+    rng = np.random.default_rng(71)
+    fk = rng.integers(0, int(nd * 1.2), n).astype(np.int32)
+    a = rng.integers(-1000, 1000, n).astype(np.int32)
+    fact = kds.build_kds("column", [kds.Column("int4", fk, rng.random(n) < 0.02), kds.Column("int4", a)])
+    fkn = kds.decode_column_chunk(fact)[0]["notnull"]
+    for dup in (False, True):
+        dkey = rng.permutation(nd).astype(np.int32)
+        if dup:
+            dkey[:500] = dkey[500:1000]
+        dpay = rng.integers(0, 10**6, nd).astype(np.int32)
+        dpn = rng.random(nd) < 0.1
+        inner = kds.build_kds("row", [kds.Column("int4", dkey), kds.Column("int4", dpay, dpn)])
+        km = build_multihash([(inner, [1])])
+        ds = runtime.DeviceStore.upload(fact)
+        join = GpuHashJoin("(gpuhashjoin (rel (hashkey (var 1 int4) 1 int4)))", row_population_ratio=1.3).begin(km)
+        try:
+            assert join.table_info(1)["unique"] == (not dup)
+            for zm in (True, False):
+                joined, nitems = join.join_to_column(ds, [(0, 2, "int4"), (1, 2, "int4"), (1, 1, "int4")], zone_maps=zm)
+                cols = kds.decode_column_chunk(joined.download())
+                joined.release()
+                # expected pairs: every (outer row, inner row) with equal keys
+                order = np.argsort(dkey, kind="stable")
+                sk = dkey[order]
+                lo = np.searchsorted(sk, fk, "left")
+                hi = np.searchsorted(sk, fk, "right")
+                cnt = np.where(fkn, hi - lo, 0)
+                assert nitems == int(cnt.sum())
+                orow = np.repeat(np.arange(n), cnt)
+                irow = (order[np.concatenate([np.arange(l, h) for l, h, c in zip(lo, hi, cnt) if c > 0])]
+                        if nitems else np.zeros(0, dtype=np.int64))
+                want = np.stack([a[orow].astype(np.int64), np.where(dpn[irow], 0, dpay[irow]).astype(np.int64),
+                                 dkey[irow].astype(np.int64), dpn[irow].astype(np.int64)], axis=1)
+                nn = cols[1]["notnull"]
+                got = np.stack([cols[0]["values"].astype(np.int64), cols[1]["values"].astype(np.int64),
+                                cols[2]["values"].astype(np.int64),
+                                (~nn).astype(np.int64) if nn is not None else np.zeros(nitems, dtype=np.int64)], axis=1)
+                assert np.array_equal(got[np.lexsort(got.T[::-1])], want[np.lexsort(want.T[::-1])])
+                assert bool(cols[2]["stat_flags"] & 1) == zm
+        finally:
+            join.end()
+            ds.release()
