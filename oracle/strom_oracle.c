@@ -280,7 +280,7 @@ num_pack(int expo, int sign, uint64_t mant, uint64_t *out)
 		mant *= 10; expo--;
 	}
 	if (expo < -32 || mant >= (1ULL << 57)) return 0;
-	*out = ((uint64_t)((int64_t)expo << 58)) | ((uint64_t)(sign != 0) << 57) | mant;
+	*out = (((uint64_t)(int64_t)expo) << 58) | ((uint64_t)(sign != 0) << 57) | mant;
 	return 1;
 }
 
@@ -387,7 +387,7 @@ oracle_numeric_from_text(const char *lit, uint64_t *out)
 	while (mant % 10 == 0) { mant /= 10; expo++; }
 	while (expo > 31 && mant < ((unsigned __int128)1 << 57) / 10) { mant *= 10; expo--; }
 	if (mant >= ((unsigned __int128)1 << 57) || expo < -32 || expo > 31) return 0;
-	*out = ((uint64_t)((int64_t)expo << 58)) | ((uint64_t)neg << 57) | (uint64_t)mant;
+	*out = (((uint64_t)(int64_t)expo) << 58) | ((uint64_t)neg << 57) | (uint64_t)mant;
 	return 1;
 }
 

@@ -451,7 +451,7 @@ numeric_literal_to_kernel(const std::string &lit, uint64_t *out)
 	}
 	if (mant >= ((unsigned __int128)1 << 57) || expo < -32 || expo > 31)
 		return false;
-	*out = ((uint64_t)((int64_t)expo << 58)) | (neg ? (1ULL << 57) : 0) |
+	*out = (((uint64_t)(int64_t)expo) << 58) | (neg ? (1ULL << 57) : 0) |
 		((uint64_t)mant & ((1ULL << 57) - 1));
 	return true;
 }

@@ -33,7 +33,7 @@
 #define PG_NUMERIC_SIGN(num)		(((num) & PG_NUMERIC_SIGN_MASK) != 0)
 #define PG_NUMERIC_MANTISSA(num)	((num) & PG_NUMERIC_MANTISSA_MASK)
 #define PG_NUMERIC_SET(expo,sign,mant)							\
-	((cl_ulong)((cl_long)(expo) << 58) |						\
+	((((cl_ulong)(cl_long)(expo)) << 58) |						\
 	 ((sign) ? PG_NUMERIC_SIGN_MASK : 0UL) |					\
 	 ((mant) & PG_NUMERIC_MANTISSA_MASK))
 

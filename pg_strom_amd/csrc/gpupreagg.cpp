@@ -1321,7 +1321,7 @@ fixed_to_numeric(cl_long v, int scale, cl_ulong *out)
 	}
 	if (mant >= (1UL << 57) || expo < -32 || expo > 31)
 		return false;
-	*out = ((cl_ulong)((cl_long)expo << 58)) | (sign ? (1UL << 57) : 0) | mant;
+	*out = (((cl_ulong)(cl_long)expo) << 58) | (sign ? (1UL << 57) : 0) | mant;
 	return true;
 }
 
