@@ -210,6 +210,21 @@ def other_operator_rates(nrows):
     out["join_with_pulled_up_qual_groupby"] = {"workload": "same query, WHERE inside the join program",
                                                "wall_ms": t * 1e3, "mrows_s": nrows / t / 1e6,
                                                "joined_rows": int(nitems2), "groups": len(pr)}
+    # and with the projection fused into the aggregate (strom_submit_gpupreagg_joined)
+    walls = []
+    for _ in range(4):
+        agg.reset()
+        t0 = time.perf_counter()
+        jp = join2.submit(fact, flags=1)
+        ap = agg.submit_joined(join2, jp, fact, [(1, 2, "int4"), (0, 2, "int4"), (0, 3, "float8")])
+        agg.collect(ap)
+        jr = join2.collect(jp)
+        pr = agg.fetch()
+        walls.append(time.perf_counter() - t0)
+    t = float(np.median(walls[1:]))
+    out["join_groupby_fused"] = {"workload": "same query, the aggregate reads the join's result pairs",
+                                 "wall_ms": t * 1e3, "mrows_s": nrows / t / 1e6,
+                                 "joined_rows": int(jr.nitems), "groups": len(pr)}
     join2.end()
     agg.end()
     scan.end()

@@ -373,6 +373,25 @@ strom_dstore *strom_hashjoin_project_column(strom_task *join_task, strom_hashjoi
 											const int32_t *src_depth, const int32_t *src_colidx,
 											const int32_t *type_oids, int *p_errcode);
 
+/*
+ * GpuPreAgg straight over a join's result pairs -- the projection fused into
+ * its consumer.  Row i of the virtual joined
+ * relation is result pair i of 'join_task' (a GpuHashJoin submitted with
+ * STROM_RESULTS_ON_DEVICE over the resident COLUMN chunk 'outer', finished
+ * without error, and not yet given to strom_task_wait -- wait for THIS task
+ * first); its column r is column src_colidx[r] of relation src_depth[r], of
+ * type type_oids[r]; the session's program reads it as (var r+1 ...).
+ * Needs one inner relation with a DIRECT index and unique keys, joined on a
+ * plain outer column: inner columns then come from slot-indexed arrays the
+ * table builds on first use.  Anything else answers BadRequest and the
+ * caller goes through strom_hashjoin_project_column().
+ */
+strom_task *strom_submit_gpupreagg_joined(strom_gpupreagg *sess, strom_task *join_task,
+										  strom_hashjoin_table *tbl, strom_dstore *outer,
+										  int ncols, const int32_t *src_depth, const int32_t *src_colidx,
+										  const int32_t *type_oids,
+										  strom_done_cb done, void *arg, int *p_errcode);
+
 /* ------------------------------------------------------------------ *
  * chained operators: device-resident row maps
  *

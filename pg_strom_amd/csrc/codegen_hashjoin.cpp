@@ -34,6 +34,7 @@ struct hashkey {
 	std::string	outer_text;
 	int			inner_attno;
 	int			type_oid;
+	int			outer_attno = 0;	/* > 0: the outer side is that plain column */
 };
 
 struct rel {
@@ -93,6 +94,9 @@ strom_codegen_gpuhashjoin(const char *spec, strom_codegen_result *out, int *p_nr
 					if (ot != t->type_oid)
 						codegen_error("hashkey: outer expression is %s but inner column is %s "
 									  "(cast the outer side)", devtype_lookup(ot)->sql_name, t->sql_name);
+					if (it.items[1].is_list && it.items[1].items.size() >= 3 && !it.items[1].items[0].is_list &&
+						it.items[1].items[0].atom == "var" && !it.items[1].items[1].is_list)
+						k.outer_attno = atoi(it.items[1].items[1].atom.c_str());
 					k.inner_attno = atoi(it.items[2].atom.c_str());
 					if (k.inner_attno < 1)
 						codegen_error("inner attribute numbers start at 1");
@@ -151,6 +155,11 @@ strom_codegen_gpuhashjoin(const char *spec, strom_codegen_result *out, int *p_nr
 		bool	fast_qual = (fast && !rels[0].qual_text.empty());
 		snprintf(tmp, sizeof(tmp), "#define HASHJOIN_FAST_ELIGIBLE %d\n#define HASHJOIN_FAST_OUTER_QUAL %d\n",
 				 fast ? 1 : 0, fast_qual ? 1 : 0);
+		src += tmp;
+		/* the outer key is a plain column: a consumer can find a joined row's slot
+		 * from the outer chunk alone (strom_submit_gpupreagg_joined) */
+		snprintf(tmp, sizeof(tmp), "#define HASHJOIN_FAST_OUTER_KEY_ATTNO %d\n",
+				 fast ? rels[0].keys[0].outer_attno : 0);
 		src += tmp;
 		for (int d = 1; d <= nrels; d++)
 		{

@@ -738,6 +738,110 @@ gpupreagg_dense_generic(kern_gpupreagg *kgpreagg,
 }
 
 /* ====================================================================== *
+ * dense-id reduction straight over a GpuHashJoin's result pairs
+ *
+ * The consumer the join's projection was made for, without the projection
+ * ("fuse into consumer"): row i of the virtual
+ * joined relation is result pair i = {outer row + 1, inner entry}; its
+ * column n is column jmap->c[n].col of the outer COLUMN chunk (depth 0) or
+ * of the inner relation (depth 1), the latter read from the slot-indexed
+ * dimension arrays of a DIRECT, unique-key table
+ * (hashjoin_build_dimcol_kernel) at slot = outer key - key_min.  The
+ * program's (var N ...) are the virtual relation's columns.
+ * ====================================================================== */
+struct gpupreagg_joined_map {
+	cl_uint		ncols;
+	cl_int		key_col;			/* outer column (0-based) that is the join key */
+	cl_int		key_attlen;
+	cl_uint		nslots;
+	cl_long		key_min;
+	struct {
+		cl_int		depth;
+		cl_int		col;
+		cl_ulong	dimvalues;		/* depth 1: device arrays by slot */
+		cl_ulong	dimisnull;
+	} c[64];
+};
+
+extern "C" __global__ void
+__launch_bounds__(GPUPREAGG_BLOCK)
+gpupreagg_dense_joined(kern_gpupreagg *kgpreagg,
+					   const kern_resultbuf *kresults,
+					   const kern_data_store *kds,
+					   const gpupreagg_joined_map *jmap,
+					   const gpupreagg_dense_ctl *ctl,
+					   char *slabs)
+{
+	extern __shared__ __attribute__((aligned(16))) char lds[];
+	const kern_parambuf *kparams = KERN_GPUPREAGG_PARAMBUF(kgpreagg);
+	const kern_coldir *coldir = KERN_DATA_STORE_COLDIR(kds);
+	cl_uint		nrows = kresults->nitems;
+	cl_uint		nrels = kresults->nrels;
+	cl_uint		nsplits = ctl->nsplits;
+	cl_uint		G = ctl->groups_per_split;
+	cl_uint		NREP = ctl->nrep;
+	cl_uint		split = blockIdx.x % nsplits;
+	cl_uint		gid_lo = split * G;
+	cl_uint		wg_in_split = blockIdx.x / nsplits;
+	cl_uint		wgs_per_split = gridDim.x / nsplits;
+	cl_uint		rep = threadIdx.x & (NREP - 1);
+	cl_int		chunk_status = StromError_Success;
+	cl_int		param_error = StromError_Success;
+	strom_kparams KP;
+	gpupreagg_lds_layout L;
+
+	gpupreagg_load_kparams(KP, kparams, &param_error);
+	gpupreagg_remap_init(ctl);
+	gpupreagg_lds_layout_init(L, G, NREP);
+	gpupreagg_lds_init(lds, L, G, NREP);
+	/* per virtual column: where it comes from (uniform, hoisted) */
+#define X(attno,colidx,NAME)													\
+	const bool	inner_##attno = (jmap->c[colidx].depth != 0);					\
+	const char *val_##attno = (inner_##attno ? (const char *)jmap->c[colidx].dimvalues	\
+							   : (const char *)kds + coldir[jmap->c[colidx].col].values_off);	\
+	const char *nul_##attno = (inner_##attno ? (const char *)jmap->c[colidx].dimisnull	\
+							   : (coldir[jmap->c[colidx].col].nulls_off != 0		\
+								  ? (const char *)kds + coldir[jmap->c[colidx].col].nulls_off : NULL));
+	STROM_KVAR_LIST(X)
+#undef X
+	const char *keyvals = (const char *)kds + coldir[jmap->key_col].values_off;
+	cl_int		key_attlen = jmap->key_attlen;
+	cl_long		key_min = jmap->key_min;
+	cl_uint		nslots = jmap->nslots;
+
+	for (size_t r = (size_t)wg_in_split * GPUPREAGG_BLOCK + threadIdx.x;
+		 r < nrows;
+		 r += (size_t)wgs_per_split * GPUPREAGG_BLOCK)
+	{
+		cl_uint		outer_row = (cl_uint)(kresults->results[(size_t)nrels * r] - 1);
+		cl_long		key = (key_attlen == 4 ? (cl_long)((const cl_int *)keyvals)[outer_row]
+						   : key_attlen == 2 ? (cl_long)((const cl_short *)keyvals)[outer_row]
+						   : key_attlen == 1 ? (cl_long)((const cl_char *)keyvals)[outer_row]
+						   : ((const cl_long *)keyvals)[outer_row]);
+		cl_ulong	slot = (cl_ulong)(key - key_min);
+		strom_kvars	KV;
+		cl_int		errcode = param_error;
+		if (slot >= nslots)
+		{
+			/* not a row this table can have matched */
+			STROM_SET_ERROR(&chunk_status, StromError_DataStoreCorruption);
+			continue;
+		}
+#define X(attno,colidx,NAME)													\
+		KV.KVAR_##attno = (inner_##attno										\
+			? pg_##NAME##_make(((const pg_##NAME##_base_t *)val_##attno)[slot],	\
+							   ((const cl_uchar *)nul_##attno)[slot] != 0)		\
+			: STROM_COLUMN_REF(NAME, val_##attno, nul_##attno, outer_row));
+		STROM_KVAR_LIST(X)
+#undef X
+		KV.__dummy = 0;
+		gpupreagg_dense_row(lds, ctl, L, KP, KV, gid_lo, G, NREP, rep, errcode, &chunk_status);
+	}
+	gpupreagg_store_slab(lds, L, slabs + (size_t)blockIdx.x * ctl->slab_bytes, G, NREP);
+	gpupreagg_writeback_status(&kgpreagg->status, chunk_status);
+}
+
+/* ====================================================================== *
  * register accumulators: at most GPUPREAGG_REG_GROUPS dense ids
  *
  * LDS atomics cost ~24 (u32) / ~53 (u64) / ~110 (f64) cycles per wave

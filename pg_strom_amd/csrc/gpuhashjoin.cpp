@@ -614,6 +614,75 @@ strom_submit_gpuhashjoin_mapped(strom_hashjoin_table *tbl, kern_hashjoin *khashj
 
 
 /*
+ * inner column 'col' (0-based, attlen bytes wide) of a single-relation table
+ * with a DIRECT index and unique keys, as arrays by slot; built on first use
+ * (hashjoin_build_dimcol_kernel) and kept with the table
+ */
+int
+strom::hashjoin_table_dimcol(strom_hashjoin_table *tbl, int col, int attlen, void **p_values, void **p_isnull)
+{
+	Device *dev = tbl->dev;
+	if (tbl->ntables != 1 || tbl->head.rel[0].mode != 1 || !tbl->head.rel[0].unique ||
+		!(attlen == 1 || attlen == 2 || attlen == 4 || attlen == 8))
+		return StromError_BadRequestMessage;
+	std::lock_guard<std::mutex> g(tbl->dim_lock);
+	auto	it = tbl->dimcols.find({col, attlen});
+	if (it == tbl->dimcols.end())
+	{
+		int		errcode = 0;
+		cl_uint	nslots = tbl->head.rel[0].nslots;
+		(void)hipSetDevice(dev->hip_id);
+		hipFunction_t fn_dim = tbl->prog->get_function(dev, "hashjoin_build_dimcol_kernel", &errcode);
+		char   *d_vals = (char *)dev->pool.alloc((size_t)attlen * nslots + 16);
+		char   *d_null = (char *)dev->pool.alloc((size_t)nslots + 16);
+		cl_uint	failed = 1;
+		if (fn_dim && d_vals && d_null)
+		{
+			const void *a_km = tbl->d_kmhash;
+			const void *a_idx = tbl->d_index;
+			cl_int		a_col = col, a_len = attlen;
+			void	   *a_vals = d_vals, *a_null = d_null;
+			void	   *a_failed = d_null + (((size_t)nslots + 3) & ~(size_t)3);	/* flag behind the array */
+			void	   *args[] = { &a_km, &a_idx, &a_col, &a_len, &a_vals, &a_null, &a_failed };
+			unsigned	grid = std::max(1u, std::min<unsigned>((nslots + 255) / 256,
+															   (unsigned)dev->prop.multiProcessorCount * 8));
+			if (!(hipMemsetAsync(a_failed, 0, sizeof(cl_uint), dev->streams[0]) == hipSuccess &&
+				  hipModuleLaunchKernel(fn_dim, grid, 1, 1, 256, 1, 1, 0, dev->streams[0], args, nullptr) == hipSuccess &&
+				  hipMemcpyAsync(&failed, a_failed, sizeof(cl_uint), hipMemcpyDeviceToHost, dev->streams[0]) == hipSuccess &&
+				  hipStreamSynchronize(dev->streams[0]) == hipSuccess))
+				failed = 1;
+		}
+		if (failed)
+		{
+			if (d_vals) dev->pool.release(d_vals);
+			if (d_null) dev->pool.release(d_null);
+			return StromError_DataStoreCorruption;
+		}
+		it = tbl->dimcols.insert({{col, attlen}, {d_vals, d_null}}).first;
+	}
+	*p_values = it->second.first;
+	*p_isnull = it->second.second;
+	return 0;
+}
+
+/* key_min / slot count of that table, and which outer column its program joins on
+ * (0: the key is an expression) */
+int
+strom::hashjoin_table_direct_info(strom_hashjoin_table *tbl, cl_long *p_key_min, cl_uint *p_nslots,
+								  int *p_outer_key_attno, int *p_dindex)
+{
+	if (!tbl || tbl->ntables != 1 || tbl->head.rel[0].mode != 1 || !tbl->head.rel[0].unique ||
+		!strstr(tbl->prog->source.c_str(), "#define HASHJOIN_FAST_ELIGIBLE 1"))
+		return StromError_BadRequestMessage;
+	const char *p = strstr(tbl->prog->source.c_str(), "#define HASHJOIN_FAST_OUTER_KEY_ATTNO ");
+	*p_outer_key_attno = (p ? atoi(p + strlen("#define HASHJOIN_FAST_OUTER_KEY_ATTNO ")) : 0);
+	*p_key_min = tbl->head.rel[0].key_min;
+	*p_nslots = tbl->head.rel[0].nslots;
+	*p_dindex = tbl->dev->dindex;
+	return 0;
+}
+
+/*
  * joined rows -> a COLUMN chunk resident in HBM (gpuhashjoin_projection_column
  * in strom_hashjoin.h); zone maps and NULL bookkeeping by the ingest
  * program's kernels, so the result is what strom_dstore_to_column() or a
@@ -723,48 +792,14 @@ strom_hashjoin_project_column(strom_task *handle, strom_hashjoin_table *tbl, str
 					   !getenv("STROM_HASHJOIN_NO_DIMCOLS"));
 	for (int i = 0; use_dim && i < ncols; i++)
 	{
-		if (src_depth[i] != 1)
-			continue;
-		int		attlen = head->colmeta[i].attlen;
-		std::lock_guard<std::mutex> g(tbl->dim_lock);
-		auto	it = tbl->dimcols.find({src_colidx[i], attlen});
-		if (it == tbl->dimcols.end())
+		void   *vals = nullptr, *nulls = nullptr;
+		if (src_depth[i] == 1 &&
+			hashjoin_table_dimcol(tbl, src_colidx[i], head->colmeta[i].attlen, &vals, &nulls) == 0)
 		{
-			cl_uint	nslots = tbl->head.rel[0].nslots;
-			hipFunction_t fn_dim = tbl->prog->get_function(dev, "hashjoin_build_dimcol_kernel", &errcode);
-			char   *d_vals = (char *)dev->pool.alloc((size_t)attlen * nslots + 16);
-			char   *d_null = (char *)dev->pool.alloc((size_t)nslots + 16);
-			cl_uint	failed = 1;
-			if (fn_dim && d_vals && d_null)
-			{
-				const void *a_km = tbl->d_kmhash;
-				const void *a_idx = tbl->d_index;
-				cl_int		a_col = src_colidx[i], a_len = attlen;
-				void	   *a_vals = d_vals, *a_null = d_null;
-				void	   *a_failed = d_null + nslots;		/* 4-byte flag behind the array (offset kept aligned below) */
-				a_failed = d_null + (((size_t)nslots + 3) & ~(size_t)3);
-				void	   *args[] = { &a_km, &a_idx, &a_col, &a_len, &a_vals, &a_null, &a_failed };
-				unsigned	grid = std::max(1u, std::min<unsigned>((nslots + 255) / 256,
-																   (unsigned)dev->prop.multiProcessorCount * 8));
-				if (hipMemsetAsync(a_failed, 0, sizeof(cl_uint), dev->streams[0]) == hipSuccess &&
-					hipModuleLaunchKernel(fn_dim, grid, 1, 1, 256, 1, 1, 0, dev->streams[0], args, nullptr) == hipSuccess &&
-					hipMemcpyAsync(&failed, a_failed, sizeof(cl_uint), hipMemcpyDeviceToHost, dev->streams[0]) == hipSuccess &&
-					hipStreamSynchronize(dev->streams[0]) == hipSuccess)
-					;
-				else
-					failed = 1;
-			}
-			if (failed)
-			{
-				/* no such column / another width: the entry path reports it */
-				if (d_vals) dev->pool.release(d_vals);
-				if (d_null) dev->pool.release(d_null);
-				continue;
-			}
-			it = tbl->dimcols.insert({{src_colidx[i], attlen}, {d_vals, d_null}}).first;
+			dimptr[2 * i] = (cl_ulong)(uintptr_t)vals;
+			dimptr[2 * i + 1] = (cl_ulong)(uintptr_t)nulls;
 		}
-		dimptr[2 * i] = (cl_ulong)(uintptr_t)it->second.first;
-		dimptr[2 * i + 1] = (cl_ulong)(uintptr_t)it->second.second;
+		/* (no such column / another width: the entry path reports it) */
 	}
 
 	size_t	aux_ints = 4 * (size_t)ncols + 1;		/* depth map, column map, type oids, NULL flags, failure */

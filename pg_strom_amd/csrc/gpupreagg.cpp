@@ -14,6 +14,7 @@
  */
 #include <atomic>
 #include <cstring>
+#include <memory>
 #include <cstdio>
 #include <algorithm>
 
@@ -299,6 +300,9 @@ struct preagg_request {
 	strom_rowmap	   *rowmap_dev;		/* device-resident row map (chained operators) */
 	uint32_t			format;
 	uint32_t			nrows;
+	/* rows = a finished GpuHashJoin's result pairs (strom_submit_gpupreagg_joined) */
+	const void		   *joined_results = nullptr;	/* device kern_resultbuf */
+	std::shared_ptr<std::vector<char>> joined_map;	/* host image of gpupreagg_joined_map */
 };
 
 void
@@ -319,9 +323,12 @@ gpupreagg_launch(strom_task_impl *task, preagg_request req)
 	/* chunks fold into one table: keep them in order on one stream */
 	task->stream = dev->streams[0];
 
-	bool	use_column = (req.format == KDS_FORMAT_COLUMN && req.krowmap == nullptr && req.rowmap_dev == nullptr);
+	bool	use_joined = (req.joined_results != nullptr);
+	bool	use_column = (!use_joined && req.format == KDS_FORMAT_COLUMN &&
+						  req.krowmap == nullptr && req.rowmap_dev == nullptr);
 	bool	use_reg = (use_column && sess->reg_groups != 0);
-	hipFunction_t fn = prog->get_function(dev, use_reg ? (sess->reg_groups == 1 ? "gpupreagg_reg1_column"
+	hipFunction_t fn = prog->get_function(dev, use_joined ? "gpupreagg_dense_joined"
+										  : use_reg ? (sess->reg_groups == 1 ? "gpupreagg_reg1_column"
 																			  : "gpupreagg_priv_column")
 										  : use_column ? "gpupreagg_dense_column"
 										  : "gpupreagg_dense_generic", &errcode);
@@ -388,6 +395,20 @@ gpupreagg_launch(strom_task_impl *task, preagg_request req)
 				  "send kern_row_map");
 		d_rowmap = p;
 	}
+	void   *d_jmap = nullptr;
+	if (use_joined)
+	{
+		d_jmap = dev->pool.alloc(req.joined_map->size());
+		if (!d_jmap)
+		{
+			task_fail(task, StromError_OutOfMemory);
+			return;
+		}
+		task->devbufs.push_back(d_jmap);
+		/* small and pageable: a synchronous copy keeps the source alive */
+		REQ_CHECK(hipMemcpy(d_jmap, req.joined_map->data(), req.joined_map->size(), hipMemcpyHostToDevice),
+				  "send joined map");
+	}
 	task_event(task);									/* ev[1] */
 	{
 		void	   *a_kg = d_kg;
@@ -397,12 +418,15 @@ gpupreagg_launch(strom_task_impl *task, preagg_request req)
 		void	   *a_ctl = sess->d_ctl;
 		void	   *a_slabs = sess->d_slabs;
 		void	   *a_table = sess->table;
+		const void *a_res = req.joined_results;
+		const void *a_jmap = d_jmap;
 		void	   *args_col[] = { &a_kg, &a_kds, &a_ctl, &a_slabs };
 		void	   *args_gen[] = { &a_kg, &a_kds, &a_toast, &a_map, &a_ctl, &a_slabs };
+		void	   *args_join[] = { &a_kg, &a_res, &a_kds, &a_jmap, &a_ctl, &a_slabs };
 		void	   *args_mrg[] = { &a_kg, &a_ctl, &a_slabs, &a_table };
 		REQ_CHECK(hipModuleLaunchKernel(fn, sess->ctl.nslabs, 1, 1, use_reg ? 256 : sess->block, 1, 1,
 										(unsigned)sess->lds_bytes, task->stream,
-										use_column ? args_col : args_gen, nullptr),
+										use_joined ? args_join : use_column ? args_col : args_gen, nullptr),
 				  "launch gpupreagg reduction");
 		if (task->pfm.enabled)
 		{
@@ -1091,6 +1115,141 @@ strom_submit_gpupreagg_mapped(strom_gpupreagg *sess, strom_dstore *kds_dev, stro
 		return nullptr;
 	}
 	return submit_gpupreagg_common(sess, nullptr, kds_dev, nullptr, rowmap, done, arg, p_errcode);
+}
+
+/* host image of struct gpupreagg_joined_map (strom_gpupreagg.h) */
+namespace {
+struct joined_map_image {
+	cl_uint		ncols;
+	cl_int		key_col;
+	cl_int		key_attlen;
+	cl_uint		nslots;
+	cl_long		key_min;
+	struct {
+		cl_int		depth;
+		cl_int		col;
+		cl_ulong	dimvalues;
+		cl_ulong	dimisnull;
+	} c[64];
+};
+}
+
+/*
+ * fold the rows a finished GpuHashJoin produced, straight from its result
+ * pairs (gpupreagg_dense_joined): see strom_hip.h
+ */
+extern "C" strom_task *
+strom_submit_gpupreagg_joined(strom_gpupreagg *sess, strom_task *join_handle,
+							  strom_hashjoin_table *tbl, strom_dstore *outer,
+							  int ncols, const int32_t *src_depth, const int32_t *src_colidx,
+							  const int32_t *type_oids,
+							  strom_done_cb done, void *arg, int *p_errcode)
+{
+	int		dummy;
+	if (!p_errcode)
+		p_errcode = &dummy;
+	*p_errcode = 0;
+	strom_task_impl *jtask = static_cast<strom_task_impl *>(join_handle);
+	if (!sess || sess->hashed || !sess->has_domain || !jtask || !tbl || !outer ||
+		ncols < 1 || ncols > 64 || !src_depth || !src_colidx || !type_oids)
+	{
+		*p_errcode = StromError_BadRequestMessage;
+		return nullptr;
+	}
+	{
+		std::unique_lock<std::mutex> g(jtask->lock);
+		jtask->cond.wait(g, [&]{ return jtask->completed; });
+	}
+	cl_long	key_min = 0;
+	cl_uint	nslots = 0;
+	int		key_attno = 0, tbl_dindex = -1;
+	if (!jtask->res_is_join || !jtask->keep_main || jtask->errcode != 0 || !jtask->main_devptr ||
+		hashjoin_table_direct_info(tbl, &key_min, &nslots, &key_attno, &tbl_dindex) != 0 ||
+		key_attno < 1 || outer->head.format != KDS_FORMAT_COLUMN ||
+		outer->dindex != sess->dev->dindex || tbl_dindex != sess->dev->dindex)
+	{
+		/* needs: a finished join with STROM_RESULTS_ON_DEVICE, one inner relation
+		 * with a DIRECT index and unique keys, joined on a plain outer column,
+		 * over a resident COLUMN chunk */
+		*p_errcode = (jtask->errcode ? jtask->errcode : StromError_BadRequestMessage);
+		return nullptr;
+	}
+	(void)hipSetDevice(sess->dev->hip_id);
+	/* the outer chunk's column widths */
+	int		outer_ncols = (int)outer->head.ncols;
+	std::vector<char> ohead(KDS_HEAD_LENGTH(outer_ncols));
+	if (key_attno > outer_ncols ||
+		hipMemcpy(ohead.data(), outer->devptr, ohead.size(), hipMemcpyDeviceToHost) != hipSuccess)
+	{
+		*p_errcode = StromError_BadRequestMessage;
+		return nullptr;
+	}
+	const kern_data_store *oh = (const kern_data_store *)ohead.data();
+	auto	img = std::make_shared<std::vector<char>>(sizeof(joined_map_image), 0);
+	joined_map_image *jm = (joined_map_image *)img->data();
+	jm->ncols = ncols;
+	jm->key_col = key_attno - 1;
+	jm->key_attlen = oh->colmeta[key_attno - 1].attlen;
+	jm->nslots = nslots;
+	jm->key_min = key_min;
+	for (int i = 0; i < ncols; i++)
+	{
+		int		attlen;
+		switch (type_oids[i] < 0 ? -type_oids[i] : type_oids[i])
+		{
+			case STROM_BOOLOID: case STROM_BPCHAROID:	attlen = 1; break;
+			case STROM_INT2OID:							attlen = 2; break;
+			case STROM_INT4OID: case STROM_FLOAT4OID: case STROM_DATEOID:	attlen = 4; break;
+			default:									attlen = 8; break;
+		}
+		jm->c[i].depth = src_depth[i];
+		jm->c[i].col = src_colidx[i];
+		if (src_depth[i] == 0)
+		{
+			if (src_colidx[i] < 0 || src_colidx[i] >= outer_ncols ||
+				oh->colmeta[src_colidx[i]].attlen != attlen)
+			{
+				*p_errcode = StromError_DataStoreCorruption;
+				return nullptr;
+			}
+		}
+		else if (src_depth[i] == 1)
+		{
+			void   *vals = nullptr, *nulls = nullptr;
+			int		rc = hashjoin_table_dimcol(tbl, src_colidx[i], attlen, &vals, &nulls);
+			if (rc != 0)
+			{
+				*p_errcode = rc;
+				return nullptr;
+			}
+			jm->c[i].dimvalues = (cl_ulong)(uintptr_t)vals;
+			jm->c[i].dimisnull = (cl_ulong)(uintptr_t)nulls;
+		}
+		else
+		{
+			*p_errcode = StromError_BadRequestMessage;
+			return nullptr;
+		}
+	}
+	if (!(jm->key_attlen == 1 || jm->key_attlen == 2 || jm->key_attlen == 4 || jm->key_attlen == 8))
+	{
+		*p_errcode = StromError_DataStoreCorruption;
+		return nullptr;
+	}
+	preagg_request req;
+	req.sess = sess;
+	req.kds = nullptr;
+	req.kds_dev = outer;
+	req.krowmap = nullptr;
+	req.rowmap_dev = nullptr;
+	req.format = KDS_FORMAT_COLUMN;
+	req.nrows = jtask->res_nitems;
+	req.joined_results = (const char *)jtask->main_devptr + jtask->res_offset;
+	req.joined_map = img;
+	sess->nfolds++;
+	strom_task_impl *task = task_create(sess->dev, done, arg);
+	program_run_or_park(sess->prog, [task, req]() { gpupreagg_launch(task, req); });
+	return task;
 }
 
 /*

@@ -160,6 +160,10 @@ struct strom_task_impl : public strom_task {
 
 /* runtime.cpp */
 Device	   *get_device(int dindex);
+/* gpuhashjoin.cpp, for consumers of join results (gpupreagg.cpp) */
+int			hashjoin_table_dimcol(strom_hashjoin_table *tbl, int col, int attlen, void **p_values, void **p_isnull);
+int			hashjoin_table_direct_info(strom_hashjoin_table *tbl, cl_long *p_key_min, cl_uint *p_nslots,
+									   int *p_outer_key_attno, int *p_dindex);
 int			num_devices();
 Program	   *lookup_program(strom_devprog_key key);
 bool		perfmon_enabled();

@@ -200,6 +200,23 @@ class GpuPreAgg(object):
             raise runtime.StromError(err.value, "strom_submit_gpupreagg")
         return (task, chunk, rm)
 
+    def submit_joined(self, join, join_pending, chunk, columns):
+        """fold the rows of a join straight from its result pairs
+        (strom_submit_gpupreagg_joined): join_pending = join.submit(chunk, flags=
+        STROM_RESULTS_ON_DEVICE) not yet collected; columns as in join_to_column.
+        Collect this request BEFORE the join's."""
+        from .kds import SQL_TYPES
+        depth = np.array([d for d, _, _ in columns], dtype=np.int32)
+        colidx = np.array([a - 1 for _, a, _ in columns], dtype=np.int32)
+        oids = np.array([SQL_TYPES[t][0] for _, _, t in columns], dtype=np.int32)
+        err = ctypes.c_int(0)
+        task = lib.strom_submit_gpupreagg_joined(self.session, join_pending[0], join.table, chunk.handle,
+                                                 len(columns), depth.ctypes.data, colidx.ctypes.data,
+                                                 oids.ctypes.data, None, None, ctypes.byref(err))
+        if not task:
+            raise runtime.StromError(err.value, "strom_submit_gpupreagg_joined")
+        return (task, chunk, (depth, colidx, oids))
+
     def collect(self, pending):
         """returns (status, perfmon): status 0 folded, 2 CpuReCheck (not folded)"""
         pfm = strom_perfmon()

@@ -63,6 +63,21 @@ for it in range(4):
     joined.release()
     print("pulled-up pass %d: join+project %.2f ms (%d rows) | preagg+fetch %.2f ms | total %.2f ms = %.0f Mrows/s of fact rows" % (
         it, (t1 - t0) * 1e3, nitems, (t2 - t1) * 1e3, (t2 - t0) * 1e3, n / (t2 - t0) / 1e6), flush=True)
+# and with the projection fused into the aggregate: GpuPreAgg reads the result pairs
+from pg_strom_amd.gpuhashjoin import STROM_RESULTS_ON_DEVICE
+for it in range(4):
+    agg.reset()
+    t0 = time.perf_counter()
+    jp = join2.submit(ds, flags=STROM_RESULTS_ON_DEVICE)
+    ap = agg.submit_joined(join2, jp, ds, [(1, 2, "int4"), (0, 2, "int4"), (0, 3, "float8")])
+    st, pfm = agg.collect(ap)
+    jr = join2.collect(jp)
+    pr = agg.fetch()
+    t1 = time.perf_counter()
+    assert st == 0
+    print("fused pass %d: join %.0f us + aggregate over %d pairs %.0f us (kernel times) | total wall %.2f ms = %.0f Mrows/s of fact rows" % (
+        it, jr.perfmon["time_kern_exec_ns"] * 1e-3, jr.nitems, pfm["time_kern_exec_ns"] * 1e-3,
+        (t1 - t0) * 1e3, n / (t1 - t0) / 1e6), flush=True)
 join2.end()
 m = (a < ext[0]) & (b > ext[1]) & (fk < nd)
 pos = np.empty(nd, dtype=np.int64); pos[dkey] = np.arange(nd)

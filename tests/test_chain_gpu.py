@@ -255,3 +255,65 @@ def test_join_to_column_without_zone_maps_and_with_the_general_kernel():
         finally:
             join.end()
             ds.release()
+
+
+def test_preagg_straight_over_the_join_result_pairs():
+    """strom_submit_gpupreagg_joined: the projection fused into its consumer -- the
+    aggregate reads (outer row, slot) pairs, outer columns from the COLUMN chunk and
+    inner columns from the table's slot-indexed arrays; same partial rows as numpy
+    over the joined rows, with a pulled-up qual and NULL keys / inputs"""
+    from pg_strom_amd.gpuhashjoin import STROM_RESULTS_ON_DEVICE
+    runtime.init()
+    n, nd = 250007, 5000
+    rng = np.random.default_rng(83)
+    fk = rng.integers(0, int(nd * 1.25), n).astype(np.int32)
+    fkn = rng.random(n) < 0.02
+    a = rng.integers(0, 2**31, n, dtype=np.int64).astype(np.int32)
+    an = rng.random(n) < 0.03
+    b = rng.random(n)
+    fact = kds.build_kds("column", [kds.Column("int4", fk, fkn), kds.Column("int4", a, an), kds.Column("float8", b)])
+    dkey = rng.permutation(nd).astype(np.int32)
+    dgrp = (dkey % 53).astype(np.int32)
+    dgn = rng.random(nd) < 0.04                          # NULL group keys: their own group
+    dval = rng.random(nd) * 10
+    dvn = rng.random(nd) < 0.05
+    inner = kds.build_kds("row_flat", [kds.Column("int4", dkey), kds.Column("int4", dgrp, dgn),
+                                       kds.Column("float8", dval, dvn)])
+    km = build_multihash([(inner, [1])])
+    ext = [np.int32(2**30), 0.25]
+    ds = runtime.DeviceStore.upload(fact)
+    join = GpuHashJoin("(gpuhashjoin (rel (hashkey (var 1 int4) 1 int4) (qual " + QUAL + ")))").begin(km, ext_params=ext)
+    spec = ("(gpupreagg (key (var 1 int4)) (nrows) (psum (int8 (var 2 int4))) (psum (var 3 float8)) (pmax (var 4 float8)))")
+    columns = [(1, 2, "int4"), (0, 2, "int4"), (0, 3, "float8"), (1, 3, "float8")]
+    agg = GpuPreAgg(spec)
+    try:
+        agg.begin([(0, 53)])
+        jp = join.submit(ds, flags=STROM_RESULTS_ON_DEVICE)
+        ap = agg.submit_joined(join, jp, ds, columns)
+        assert agg.collect(ap)[0] == 0
+        jr = join.collect(jp)
+        pr = agg.fetch()
+    finally:
+        agg.end()
+        join.end()
+        ds.release()
+    sel = np.flatnonzero((~fkn) & (~an) & (a < ext[0]) & (b > ext[1]) & (fk < nd))
+    pos = np.empty(nd, dtype=np.int64)
+    pos[dkey] = np.arange(nd)
+    di = pos[fk[sel]]
+    assert jr.nitems == len(sel)
+    g = np.where(dgn[di], 1000, dgrp[di])                # 1000 stands for the NULL key
+    ug, inv = np.unique(g, return_inverse=True)
+    keys, knull = pr.column(0)
+    gk = np.where(knull, 1000, keys)
+    order = np.argsort(gk)
+    assert np.array_equal(gk[order], ug)
+    assert np.array_equal(pr.column(1)[0][order], np.bincount(inv))
+    assert np.array_equal(pr.column(2)[0][order], np.bincount(inv, weights=a[sel].astype(np.float64)).astype(np.int64))
+    assert np.allclose(pr.column(3)[0][order], np.bincount(inv, weights=b[sel]), rtol=1e-12)
+    wmax = np.full(len(ug), -np.inf)
+    ok = ~dvn[di]
+    np.maximum.at(wmax, inv[ok], dval[di][ok])
+    gmax, gnull = pr.column(4)
+    assert np.array_equal(gnull[order], np.isinf(wmax))
+    assert np.array_equal(gmax[order][~np.isinf(wmax)], wmax[~np.isinf(wmax)])
