@@ -832,9 +832,34 @@ gpupreagg_dense_joined(kern_gpupreagg *kgpreagg,
 			? pg_##NAME##_make(((const pg_##NAME##_base_t *)val_##attno)[slot],	\
 							   ((const cl_uchar *)nul_##attno)[slot] != 0)		\
 			: STROM_COLUMN_REF(NAME, val_##attno, nul_##attno, outer_row));
-		STROM_KVAR_LIST(X)
-#undef X
+		STROM_KVAR_LIST_GROUPING(X)
 		KV.__dummy = 0;
+		if (nsplits > 1)
+		{
+			/* several id-range roles read every pair: whose row this is follows
+			 * from the columns the keys read -- gather the others only for the
+			 * role's own rows (gpupreagg_dense_row decides again, with errors) */
+			cl_int		e2 = errcode;
+			cl_uint		gid = 0;
+			bool		out_of_domain = false;
+#define Y(kidx,resno,NAME)														\
+			{																	\
+				pg_##NAME##_t kv = gpupreagg_key_##kidx(&e2, KP, KV);			\
+				cl_long		off64 = (cl_long)kv.value - ctl->key_min[kidx];		\
+				cl_uint		range = ctl->key_range[kidx];						\
+				cl_uint		off = (kv.isnull ? range : (cl_uint)off64);			\
+				if (!kv.isnull && (off64 < 0 || off64 >= (cl_long)range))		\
+					out_of_domain = true;										\
+				gid += off * ctl->key_stride[kidx];								\
+			}
+			GPUPREAGG_KEY_LIST(Y)
+#undef Y
+			if (e2 == StromError_Success && !out_of_domain &&
+				gpupreagg_remap_gid(ctl, gid) && gid - gid_lo >= G)
+				continue;
+		}
+		STROM_KVAR_LIST_REST(X)
+#undef X
 		gpupreagg_dense_row(lds, ctl, L, KP, KV, gid_lo, G, NREP, rep, errcode, &chunk_status);
 	}
 	gpupreagg_store_slab(lds, L, slabs + (size_t)blockIdx.x * ctl->slab_bytes, G, NREP);

@@ -257,14 +257,16 @@ def test_join_to_column_without_zone_maps_and_with_the_general_kernel():
             ds.release()
 
 
-def test_preagg_straight_over_the_join_result_pairs():
+@pytest.mark.parametrize("ngroups", [53, 9000])
+def test_preagg_straight_over_the_join_result_pairs(ngroups):
     """strom_submit_gpupreagg_joined: the projection fused into its consumer -- the
     aggregate reads (outer row, slot) pairs, outer columns from the COLUMN chunk and
     inner columns from the table's slot-indexed arrays; same partial rows as numpy
-    over the joined rows, with a pulled-up qual and NULL keys / inputs"""
+    over the joined rows, with a pulled-up qual and NULL keys / inputs; 9000 groups
+    do not fit one LDS image, so id-range roles split them"""
     from pg_strom_amd.gpuhashjoin import STROM_RESULTS_ON_DEVICE
     runtime.init()
-    n, nd = 250007, 5000
+    n, nd = 250007, 20000
     rng = np.random.default_rng(83)
     fk = rng.integers(0, int(nd * 1.25), n).astype(np.int32)
     fkn = rng.random(n) < 0.02
@@ -273,7 +275,7 @@ def test_preagg_straight_over_the_join_result_pairs():
     b = rng.random(n)
     fact = kds.build_kds("column", [kds.Column("int4", fk, fkn), kds.Column("int4", a, an), kds.Column("float8", b)])
     dkey = rng.permutation(nd).astype(np.int32)
-    dgrp = (dkey % 53).astype(np.int32)
+    dgrp = (dkey % ngroups).astype(np.int32)
     dgn = rng.random(nd) < 0.04                          # NULL group keys: their own group
     dval = rng.random(nd) * 10
     dvn = rng.random(nd) < 0.05
@@ -287,7 +289,7 @@ def test_preagg_straight_over_the_join_result_pairs():
     columns = [(1, 2, "int4"), (0, 2, "int4"), (0, 3, "float8"), (1, 3, "float8")]
     agg = GpuPreAgg(spec)
     try:
-        agg.begin([(0, 53)])
+        agg.begin([(0, ngroups)])
         jp = join.submit(ds, flags=STROM_RESULTS_ON_DEVICE)
         ap = agg.submit_joined(join, jp, ds, columns)
         assert agg.collect(ap)[0] == 0
@@ -302,10 +304,10 @@ def test_preagg_straight_over_the_join_result_pairs():
     pos[dkey] = np.arange(nd)
     di = pos[fk[sel]]
     assert jr.nitems == len(sel)
-    g = np.where(dgn[di], 1000, dgrp[di])                # 1000 stands for the NULL key
+    g = np.where(dgn[di], 10**6, dgrp[di])               # 10**6 stands for the NULL key
     ug, inv = np.unique(g, return_inverse=True)
     keys, knull = pr.column(0)
-    gk = np.where(knull, 1000, keys)
+    gk = np.where(knull, 10**6, keys)
     order = np.argsort(gk)
     assert np.array_equal(gk[order], ug)
     assert np.array_equal(pr.column(1)[0][order], np.bincount(inv))
