@@ -4,7 +4,7 @@ import numpy as np
 sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 from pg_strom_amd import kds, runtime
 from pg_strom_amd.gpupreagg import GpuPreAgg
-n = int(sys.argv[1]) if len(sys.argv) > 1 else 100_000_000
+n = int(float(sys.argv[1])) if len(sys.argv) > 1 else 100_000_000
 runtime.init()
 rng = np.random.default_rng(3)
 x = rng.integers(-10**6, 10**6, n, dtype=np.int64).astype(np.int32)
