@@ -510,10 +510,18 @@ extern "C" __global__ void
 __launch_bounds__(GPUPREAGG_BLOCK)
 gpupreagg_dense_column(kern_gpupreagg *kgpreagg,
 					   const kern_data_store *kds,
-					   const gpupreagg_dense_ctl *ctl,
+					   const gpupreagg_dense_ctl *ctl_in_memory,
 					   char *slabs)
 {
 	extern __shared__ __attribute__((aligned(16))) char lds[];
+	/*
+	 * the control block by value: read through the pointer, its fields
+	 * (key_min / key_range / key_stride / remap) were scalar loads in EVERY row
+	 * body, and the s_waitcnt lgkmcnt(0) behind each of them also waited for
+	 * the previous row's LDS atomics -- lgkmcnt counts both
+	 */
+	const gpupreagg_dense_ctl ctl_by_value = *ctl_in_memory;
+	const gpupreagg_dense_ctl *ctl = &ctl_by_value;
 	const kern_parambuf *kparams = KERN_GPUPREAGG_PARAMBUF(kgpreagg);
 	const kern_coldir *coldir = KERN_DATA_STORE_COLDIR(kds);
 	cl_uint		nitems = kds->nitems;
@@ -726,10 +734,13 @@ gpupreagg_dense_generic(kern_gpupreagg *kgpreagg,
 						const kern_data_store *kds,
 						const kern_data_store *ktoast,
 						const kern_row_map *krowmap,
-						const gpupreagg_dense_ctl *ctl,
+						const gpupreagg_dense_ctl *ctl_in_memory,
 						char *slabs)
 {
 	extern __shared__ __attribute__((aligned(16))) char lds[];
+	/* the control block by value (see gpupreagg_dense_column) */
+	const gpupreagg_dense_ctl ctl_by_value = *ctl_in_memory;
+	const gpupreagg_dense_ctl *ctl = &ctl_by_value;
 	/* the chunk format is decided once per launch, not once per datum */
 	if (kds->format == KDS_FORMAT_COLUMN)
 		gpupreagg_dense_generic_body<true>(kgpreagg, kds, ktoast, krowmap, ctl, slabs, lds);
@@ -769,10 +780,14 @@ gpupreagg_dense_joined(kern_gpupreagg *kgpreagg,
 					   const kern_resultbuf *kresults,
 					   const kern_data_store *kds,
 					   const gpupreagg_joined_map *jmap,
-					   const gpupreagg_dense_ctl *ctl,
+					   const gpupreagg_dense_ctl *ctl_in_memory,
 					   char *slabs)
 {
 	extern __shared__ __attribute__((aligned(16))) char lds[];
+	/* the control block by value (see gpupreagg_dense_column) */
+	const gpupreagg_dense_ctl ctl_by_value = *ctl_in_memory;
+	const gpupreagg_dense_ctl *ctl = &ctl_by_value;
+
 	const kern_parambuf *kparams = KERN_GPUPREAGG_PARAMBUF(kgpreagg);
 	const kern_coldir *coldir = KERN_DATA_STORE_COLDIR(kds);
 	cl_uint		nrows = kresults->nitems;
@@ -1293,9 +1308,13 @@ gpupreagg_priv_row(char *lds, gpupreagg_priv_state &S, const gpupreagg_dense_ctl
 extern "C" __global__ void
 __launch_bounds__(GPUPREAGG_REG_BLOCK)
 gpupreagg_priv_column(kern_gpupreagg *kgpreagg, const kern_data_store *kds,
-					  const gpupreagg_dense_ctl *ctl, char *slabs)
+					  const gpupreagg_dense_ctl *ctl_in_memory, char *slabs)
 {
 	extern __shared__ __attribute__((aligned(16))) char lds[];
+	/* the control block by value (see gpupreagg_dense_column) */
+	const gpupreagg_dense_ctl ctl_by_value = *ctl_in_memory;
+	const gpupreagg_dense_ctl *ctl = &ctl_by_value;
+
 	const kern_parambuf *kparams = KERN_GPUPREAGG_PARAMBUF(kgpreagg);
 	const kern_coldir *coldir = KERN_DATA_STORE_COLDIR(kds);
 	cl_uint		nitems = kds->nitems;
@@ -1515,9 +1534,12 @@ gpupreagg_priv_column(kern_gpupreagg *kgpreagg, const kern_data_store *kds,
 extern "C" __global__ void
 __launch_bounds__(GPUPREAGG_REG_BLOCK)
 gpupreagg_reg1_column(kern_gpupreagg *kgpreagg, const kern_data_store *kds,
-					  const gpupreagg_dense_ctl *ctl, char *slabs)
+					  const gpupreagg_dense_ctl *ctl_in_memory, char *slabs)
 {
 	extern __shared__ __attribute__((aligned(16))) char lds[];
+	/* the control block by value (see gpupreagg_dense_column) */
+	const gpupreagg_dense_ctl ctl_by_value = *ctl_in_memory;
+	const gpupreagg_dense_ctl *ctl = &ctl_by_value;
 	gpupreagg_reg_kernel_body<1>(kgpreagg, kds, ctl, slabs, lds);
 }
 
