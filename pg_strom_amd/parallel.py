@@ -184,3 +184,65 @@ def allreduce_census(bitmap, group=None, device=None):
     dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
     merged = np.packbits(t.cpu().numpy(), bitorder="little").view(np.uint32)
     return merged
+
+
+# ---------------------------------------------------------------------------
+# hashed GROUP BY sessions (strom_gpupreagg_create_hashed): no common table
+# layout across ranks -- every rank's table has its own slots -- so the merge
+# is what the reference's Agg node does with partial rows of several chunks:
+# gather them and combine rows of equal keys (pg_strom--1.0.sql:247-401).
+# ---------------------------------------------------------------------------
+def merge_partial_rows(targets, parts):
+    """parts: [(values uint64 [n, ntargets], isnull bool [n, ntargets])] with floats as
+    float8 images (the oracle's / partial_rows_as_raw8's convention).  Returns the
+    combined (values, isnull), one row per distinct key (NULL keys are one group)."""
+    nt = len(targets)
+    values = np.concatenate([np.asarray(v, dtype=np.uint64).reshape(-1, nt) for v, _ in parts])
+    isnull = np.concatenate([np.asarray(n, dtype=bool).reshape(-1, nt) for _, n in parts])
+    keys = [t for t, (kind, _) in enumerate(targets) if kind == KIND_KEY]
+    if len(values) == 0:
+        return values, isnull
+    if keys:
+        ident = np.stack([np.where(isnull[:, t], np.uint64(0), values[:, t]) for t in keys] +
+                         [isnull[:, t].astype(np.uint64) for t in keys], axis=1)
+        _, first, inv = np.unique(ident, axis=0, return_index=True, return_inverse=True)
+        inv = inv.reshape(-1)
+    else:
+        first, inv = np.zeros(1, dtype=np.int64), np.zeros(len(values), dtype=np.int64)
+    ng = len(first)
+    out_v = np.zeros((ng, nt), dtype=np.uint64)
+    out_n = np.ones((ng, nt), dtype=bool)
+    for t, (kind, oid) in enumerate(targets):
+        col, nul = values[:, t], isnull[:, t]
+        if kind == KIND_KEY:
+            out_v[:, t], out_n[:, t] = col[first], nul[first]
+            continue
+        isflt = oid in FLOAT_OIDS
+        x = col.view(np.float64) if isflt else col.view(np.int64)
+        ok = ~nul
+        has = np.zeros(ng, dtype=bool)
+        np.logical_or.at(has, inv[ok], True)
+        if kind in (KIND_NROWS, KIND_PSUM):
+            acc = np.zeros(ng, dtype=x.dtype)
+            np.add.at(acc, inv[ok], x[ok])
+            if kind == KIND_NROWS:
+                has[:] = True
+        elif kind == KIND_PMIN:
+            acc = np.full(ng, np.inf if isflt else np.iinfo(np.int64).max, dtype=x.dtype)
+            np.minimum.at(acc, inv[ok], x[ok])
+        else:
+            acc = np.full(ng, -np.inf if isflt else np.iinfo(np.int64).min, dtype=x.dtype)
+            np.maximum.at(acc, inv[ok], x[ok])
+        out_v[:, t] = np.where(has, acc.view(np.uint64), np.uint64(0))
+        out_n[:, t] = ~has
+    return out_v, out_n
+
+
+def gather_partial_rows(targets, values, isnull, group=None):
+    """all ranks' partial rows, combined by key on every rank (the payload is the
+    groups, not the rows: an object all-gather is enough)"""
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    parts = [None] * world
+    dist.all_gather_object(parts, (np.ascontiguousarray(values), np.ascontiguousarray(isnull)), group=group)
+    return merge_partial_rows(targets, parts)

@@ -125,3 +125,72 @@ def test_two_ranks_agree_on_group_slots():
         assert p.exitcode == 0
     res = dict(q.get(timeout=5) for _ in range(2))
     assert res[0] == res[1] == [0, 5, 40, 77, 100, 208]
+
+
+HASHED_SPEC = ("(gpupreagg (key (var 1 float8)) (key (var 2 int8)) (nrows) (psum (int8 (var 3 int4)))"
+               " (psum (var 4 float8)) (pmin (var 4 float8)) (pmax (var 3 int4)))")
+
+
+def _hashed_table(n, seed):
+    from pg_strom_amd import kds
+    rng = np.random.default_rng(seed)
+    f = rng.integers(-3, 4, n).astype(np.float64) / 2
+    f[rng.random(n) < 0.04] = np.nan
+    big = (rng.integers(0, 5, n).astype(np.int64) - 2) * (2**41 + 7)
+    x = rng.integers(-10**6, 10**6, n).astype(np.int32)
+    y = rng.random(n) * 100
+    return [kds.Column("float8", f, rng.random(n) < 0.03), kds.Column("int8", big, rng.random(n) < 0.03),
+            kds.Column("int4", x, rng.random(n) < 0.05), kds.Column("float8", y, rng.random(n) < 0.05)]
+
+
+def _hashed_worker(rank, world, port, outq):
+    sys.path.insert(0, os.path.dirname(HERE))
+    sys.path.insert(0, HERE)
+    import torch.distributed as dist
+    import oracle_binding as oracle
+    from pg_strom_amd import kds, parallel
+    from pg_strom_amd.gpupreagg import codegen_gpupreagg
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    try:
+        cols = _hashed_table(20000, 97)
+        n = len(cols[0].values)
+        lo, hi = rank * n // world, (rank + 1) * n // world
+        part = [kds.Column(c.sqltype, c.values[lo:hi], c.isnull[lo:hi]) for c in cols]
+        rc, v, isn = oracle.gpupreagg(HASHED_SPEC, kds.build_kds("column", part), 7)
+        assert rc == 0
+        targets = codegen_gpupreagg(HASHED_SPEC).targets
+        gv, gn = parallel.gather_partial_rows(targets, v, isn)
+        if rank == 0:
+            rc, wv, wn = oracle.gpupreagg(HASHED_SPEC, kds.build_kds("column", cols), 7)
+            def order(v_, n_):
+                return np.lexsort((v_[:, 1], n_[:, 1], v_[:, 0], n_[:, 0]))
+            og, ow = order(gv, gn), order(wv, wn)
+            gv, gn, wv, wn = gv[og], gn[og], wv[ow], wn[ow]
+            ok = gv.shape == wv.shape and np.array_equal(gn, wn)
+            for t, (kind, oid) in enumerate(targets):
+                if not ok:
+                    break
+                live = ~wn[:, t]
+                if oid in (700, 701) and kind == 3:
+                    ok &= np.allclose(gv[:, t].view(np.float64)[live], wv[:, t].view(np.float64)[live], rtol=1e-12, atol=0)
+                else:
+                    ok &= np.array_equal(gv[:, t][live], wv[:, t][live])
+            outq.put(bool(ok))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_merge_of_hashed_group_by_partial_rows():
+    """hashed GROUP BY sessions have no common table layout: ranks gather their partial
+    rows and combine equal keys (float keys incl. NaN / NULL, sparse int8 keys)"""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    outq = ctx.Queue()
+    port = 29500 + (os.getpid() % 2000) + 7
+    procs = [ctx.Process(target=_hashed_worker, args=(r, 2, port, outq)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(180)
+    assert all(p.exitcode == 0 for p in procs)
+    assert outq.get(timeout=5) is True
