@@ -378,8 +378,9 @@ strom_dstore *strom_hashjoin_project_column(strom_task *join_task, strom_hashjoi
  * its consumer.  Row i of the virtual joined
  * relation is result pair i of 'join_task' (a GpuHashJoin submitted with
  * STROM_RESULTS_ON_DEVICE over the resident COLUMN chunk 'outer', finished
- * without error, and not yet given to strom_task_wait -- wait for THIS task
- * first); its column r is column src_colidx[r] of relation src_depth[r], of
+ * without error, and not yet given to strom_task_wait; its device results
+ * pass to the new task, so the two can then be waited for in any order);
+ * its column r is column src_colidx[r] of relation src_depth[r], of
  * type type_oids[r]; the session's program reads it as (var r+1 ...).
  * Needs one inner relation with a DIRECT index and unique keys, joined on a
  * plain outer column: inner columns then come from slot-indexed arrays the

@@ -302,6 +302,7 @@ struct preagg_request {
 	uint32_t			nrows;
 	/* rows = a finished GpuHashJoin's result pairs (strom_submit_gpupreagg_joined) */
 	const void		   *joined_results = nullptr;	/* device kern_resultbuf */
+	void			   *joined_buffer = nullptr;	/* the join's device image, owned by this request now */
 	std::shared_ptr<std::vector<char>> joined_map;	/* host image of gpupreagg_joined_map */
 };
 
@@ -314,6 +315,8 @@ gpupreagg_launch(strom_task_impl *task, preagg_request req)
 	int			errcode = 0;
 
 	(void)hipSetDevice(dev->hip_id);
+	if (req.joined_buffer)
+		task->devbufs.push_back(req.joined_buffer);		/* released with this task, whatever happens */
 	if (prog->state != STROM_DEVPROG_READY)
 	{
 		task_fail(task, StromError_ProgramBuildFailure);
@@ -1246,6 +1249,11 @@ strom_submit_gpupreagg_joined(strom_gpupreagg *sess, strom_task *join_handle,
 	req.nrows = jtask->res_nitems;
 	req.joined_results = (const char *)jtask->main_devptr + jtask->res_offset;
 	req.joined_map = img;
+	/* the result pairs now belong to this request: the join task can be waited
+	 * for and released in any order */
+	req.joined_buffer = jtask->main_devptr;
+	jtask->main_devptr = nullptr;
+	jtask->keep_main = false;
 	sess->nfolds++;
 	strom_task_impl *task = task_create(sess->dev, done, arg);
 	program_run_or_park(sess->prog, [task, req]() { gpupreagg_launch(task, req); });

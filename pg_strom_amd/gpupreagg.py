@@ -204,7 +204,7 @@ class GpuPreAgg(object):
         """fold the rows of a join straight from its result pairs
         (strom_submit_gpupreagg_joined): join_pending = join.submit(chunk, flags=
         STROM_RESULTS_ON_DEVICE) not yet collected; columns as in join_to_column.
-        Collect this request BEFORE the join's."""
+        The join's device results pass to this request."""
         from .kds import SQL_TYPES
         depth = np.array([d for d, _, _ in columns], dtype=np.int32)
         colidx = np.array([a - 1 for _, a, _ in columns], dtype=np.int32)

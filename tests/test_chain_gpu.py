@@ -292,8 +292,13 @@ def test_preagg_straight_over_the_join_result_pairs(ngroups):
         agg.begin([(0, ngroups)])
         jp = join.submit(ds, flags=STROM_RESULTS_ON_DEVICE)
         ap = agg.submit_joined(join, jp, ds, columns)
-        assert agg.collect(ap)[0] == 0
-        jr = join.collect(jp)
+        if ngroups == 53:
+            assert agg.collect(ap)[0] == 0
+            jr = join.collect(jp)
+        else:
+            # the join's device results belong to the aggregate's request now: any order
+            jr = join.collect(jp)
+            assert agg.collect(ap)[0] == 0
         pr = agg.fetch()
     finally:
         agg.end()
