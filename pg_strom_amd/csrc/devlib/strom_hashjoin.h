@@ -654,6 +654,9 @@ gpuhashjoin_main_fast(kern_hashjoin *khashjoin,
 		hashjoin_column_tile T;
 		cl_uint		match[HASHJOIN_QUADS][4];
 		cl_uint		my_prefix[HASHJOIN_QUADS];
+#if HASHJOIN_FAST_OUTER_QUAL
+		cl_int		qual_error[HASHJOIN_QUADS][4];
+#endif
 
 		if (full_tile && !any_nulls)
 		{
@@ -715,6 +718,22 @@ gpuhashjoin_main_fast(kern_hashjoin *khashjoin,
 #undef X
 				KV.__dummy = 0;
 				match[k][j] = 0;
+#if HASHJOIN_FAST_OUTER_QUAL
+				/*
+				 * a qual over outer columns only (a scan's WHERE pulled up into
+				 * the join, gpuhashjoin.c:2047-2050).  The general kernel
+				 * evaluates it for rows that found their entry, so its errors
+				 * count for those rows only; here it is evaluated FIRST, on
+				 * the registers the tile already holds, and a row it rejects
+				 * without an error is not probed at all -- the kernel is bound
+				 * by the L2 request rate of the slot reads.  An error is kept
+				 * and raised below if the row turns out to have a partner.
+				 */
+				cl_int		qerr = StromError_Success;
+				bool		qpass = hashjoin_fast_outer_qual(&qerr, KP, KV);
+				qual_error[k][j] = qerr;
+				if (qpass || qerr != StromError_Success)
+#endif
 				if (row0 + j < nitems &&
 					hashjoin_fast_outer_key(&errcode, KP, KV, &key))
 				{
@@ -730,33 +749,16 @@ gpuhashjoin_main_fast(kern_hashjoin *khashjoin,
 			}
 		}
 #if HASHJOIN_FAST_OUTER_QUAL
-		/* a qual over outer columns only (a scan's WHERE pulled up into the
-		 * join, gpuhashjoin.c:2047-2050): evaluated, like in the general kernel,
-		 * for rows that found their entry -- in a loop of its own so that the
-		 * slot reads above stay back to back */
 #pragma unroll
 		for (int k = 0; k < HASHJOIN_QUADS; k++)
 		{
 #pragma unroll
 			for (int j = 0; j < 4; j++)
 			{
-				if (match[k][j] != 0)
+				if (match[k][j] != 0 && qual_error[k][j] != StromError_Success)
 				{
-					strom_kvars	KV;
-					cl_int		errcode = param_error;
-#define X(attno,colidx,NAME)													\
-					KV.KVAR_##attno = pg_##NAME##_make(T.v_##attno[k][j],			\
-													   !((T.nn_##attno[k] >> j) & 1));
-					STROM_KVAR_LIST(X)
-#undef X
-					KV.__dummy = 0;
-					if (!hashjoin_fast_outer_qual(&errcode, KP, KV))
-						match[k][j] = 0;
-					if (errcode != StromError_Success)
-					{
-						STROM_SET_ERROR(&chunk_error, errcode);
-						match[k][j] = 0;
-					}
+					STROM_SET_ERROR(&chunk_error, qual_error[k][j]);
+					match[k][j] = 0;
 				}
 			}
 		}
