@@ -393,6 +393,21 @@ strom_task *strom_submit_gpupreagg_joined(strom_gpupreagg *sess, strom_task *joi
 										  const int32_t *type_oids,
 										  strom_done_cb done, void *arg, int *p_errcode);
 
+/*
+ * ... and without any join request: the join becomes a LOOKUP inside the
+ * aggregate's own pass over the resident COLUMN chunk 'outer'
+ * (gpupreagg_dense_lookup): a row's slot is outer key - key_min, a row
+ * without a partner is dropped, virtual columns as above, a WHERE over
+ * outer columns is the aggregate program's (qual ...).  Same requirements on
+ * the table (one relation, DIRECT index, unique keys, key = a plain outer
+ * column of int4 / int8 / date width); anything else answers BadRequest.
+ */
+strom_task *strom_submit_gpupreagg_lookup(strom_gpupreagg *sess,
+										  strom_hashjoin_table *tbl, strom_dstore *outer,
+										  int ncols, const int32_t *src_depth, const int32_t *src_colidx,
+										  const int32_t *type_oids,
+										  strom_done_cb done, void *arg, int *p_errcode);
+
 /* ------------------------------------------------------------------ *
  * chained operators: device-resident row maps
  *

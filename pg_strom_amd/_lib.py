@@ -137,6 +137,8 @@ PROTOTYPES = {
                                                  c_void_p, ctypes.POINTER(c_int)]),
     "strom_submit_gpupreagg_joined": (c_void_p, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p,
                                                  c_void_p, c_void_p, c_void_p, ctypes.POINTER(c_int)]),
+    "strom_submit_gpupreagg_lookup": (c_void_p, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p,
+                                                 c_void_p, c_void_p, c_void_p, ctypes.POINTER(c_int)]),
     "strom_gpupreagg_create_hashed": (c_void_p, [c_uint64, ctypes.POINTER(strom_preagg_target), c_int,
                                                  c_void_p, c_uint32, c_int, ctypes.POINTER(c_int)]),
     "strom_gpupreagg_table_length": (c_size_t, [c_void_p]),

@@ -772,6 +772,12 @@ struct gpupreagg_joined_map {
 		cl_ulong	dimvalues;		/* depth 1: device arrays by slot */
 		cl_ulong	dimisnull;
 	} c[64];
+	/* gpupreagg_dense_lookup: packed slot records (hashjoin_build_dimrec_kernel); an inner
+	 * column i then has c[i].dimvalues = byte offset of its value in the record and
+	 * c[i].dimisnull = its bit in the record's flags word */
+	cl_ulong	recs;
+	cl_uint		reclen;
+	cl_uint		__pad;
 };
 
 extern "C" __global__ void
@@ -879,6 +885,193 @@ gpupreagg_dense_joined(kern_gpupreagg *kgpreagg,
 	}
 	gpupreagg_store_slab(lds, L, slabs + (size_t)blockIdx.x * ctl->slab_bytes, G, NREP);
 	gpupreagg_writeback_status(&kgpreagg->status, chunk_status);
+}
+
+/* ====================================================================== *
+ * join lookup + dense-id reduction in ONE pass over the outer chunk
+ *
+ * The whole query shape "fact JOIN dim GROUP BY ..." for a dimension with a
+ * DIRECT index and unique keys: the outer COLUMN chunk streams through the
+ * tile loader exactly as in gpupreagg_dense_column, a row's slot is
+ * outer key - key_min, a row without a partner (NULL key, key outside the
+ * table, empty slot) is dropped, and a virtual column of depth 1 comes from
+ * the table's slot-indexed arrays (a few MB, L2-resident).  No result pairs
+ * are written or read at all.  The program's (var N ...) and its qual see
+ * the same virtual relation as gpupreagg_dense_joined; int4 / int8 keys.
+ * ====================================================================== */
+template <typename KEY_T>
+__device__ __forceinline__ void
+gpupreagg_dense_lookup_body(kern_gpupreagg *kgpreagg,
+							const kern_data_store *kds,
+							const gpupreagg_joined_map *jmap,
+							const gpupreagg_dense_ctl *ctl,
+							char *slabs, char *lds)
+{
+	const kern_parambuf *kparams = KERN_GPUPREAGG_PARAMBUF(kgpreagg);
+	const kern_coldir *coldir = KERN_DATA_STORE_COLDIR(kds);
+	cl_uint		nitems = kds->nitems;
+	cl_uint		ntiles = (nitems + GPUPREAGG_TILE_ROWS - 1) / GPUPREAGG_TILE_ROWS;
+	cl_uint		nsplits = ctl->nsplits;
+	cl_uint		G = ctl->groups_per_split;
+	cl_uint		NREP = ctl->nrep;
+	cl_uint		split = blockIdx.x % nsplits;
+	cl_uint		wg_in_split = blockIdx.x / nsplits;
+	cl_uint		wgs_per_split = gridDim.x / nsplits;
+	cl_uint		gid_lo = split * G;
+	cl_uint		rep = threadIdx.x & (NREP - 1);
+	cl_int		chunk_status = StromError_Success;
+	cl_int		param_error = StromError_Success;
+	strom_kparams KP;
+	gpupreagg_lds_layout L;
+
+	gpupreagg_load_kparams(KP, kparams, &param_error);
+	gpupreagg_remap_init(ctl);
+	gpupreagg_lds_layout_init(L, G, NREP);
+	gpupreagg_lds_init(lds, L, G, NREP);
+#define X(attno,colidx,NAME)													\
+	const bool	inner_##attno = (jmap->c[colidx].depth != 0);					\
+	const cl_uint recoff_##attno = (cl_uint)jmap->c[colidx].dimvalues;			\
+	const cl_uint recbit_##attno = (cl_uint)jmap->c[colidx].dimisnull;			\
+	const char *val_##attno = (inner_##attno ? NULL								\
+							   : (const char *)kds + coldir[jmap->c[colidx].col].values_off);	\
+	const char *nul_##attno = (inner_##attno ? NULL								\
+							   : (coldir[jmap->c[colidx].col].nulls_off != 0		\
+								  ? (const char *)kds + coldir[jmap->c[colidx].col].nulls_off : NULL));
+	STROM_KVAR_LIST(X)
+#undef X
+	const char *keyvals = (const char *)kds + coldir[jmap->key_col].values_off;
+	const cl_uint *keynulls = (coldir[jmap->key_col].nulls_off != 0
+							   ? (const cl_uint *)((const char *)kds + coldir[jmap->key_col].nulls_off) : NULL);
+	const char *recs = (const char *)jmap->recs;
+	cl_uint		reclen = jmap->reclen;
+	cl_long		key_min = jmap->key_min;
+	cl_uint		nslots = jmap->nslots;
+
+	for (cl_uint tile = wg_in_split; tile < ntiles; tile += wgs_per_split)
+	{
+		cl_uint		tile_base = tile * GPUPREAGG_TILE_ROWS;
+		bool		full_tile = (tile_base + GPUPREAGG_TILE_ROWS <= nitems);
+		gpupreagg_column_tile T;
+		KEY_T		keyq[GPUPREAGG_QUADS][4];
+		cl_uint		keynn[GPUPREAGG_QUADS];
+
+#pragma unroll
+		for (int k = 0; k < GPUPREAGG_QUADS; k++)
+		{
+			cl_uint	row0 = tile_base + (k * GPUPREAGG_BLOCK + threadIdx.x) * 4;
+			if (full_tile)
+			{
+				strom_column_load_quad<KEY_T, true>(keyvals, keynulls, row0, nitems, keyq[k], keynn[k]);
+#define X(attno,colidx,NAME)													\
+				if (!inner_##attno)												\
+					strom_column_load_quad<pg_##NAME##_base_t, true>(val_##attno, (const cl_uint *)nul_##attno,	\
+															   row0, nitems, T.v_##attno[k], T.nn_##attno[k]);
+				STROM_KVAR_LIST(X)
+#undef X
+			}
+			else
+			{
+				strom_column_load_quad<KEY_T, false>(keyvals, keynulls, row0, nitems, keyq[k], keynn[k]);
+#define X(attno,colidx,NAME)													\
+				if (!inner_##attno)												\
+					strom_column_load_quad<pg_##NAME##_base_t, false>(val_##attno, (const cl_uint *)nul_##attno,	\
+															   row0, nitems, T.v_##attno[k], T.nn_##attno[k]);
+				STROM_KVAR_LIST(X)
+#undef X
+			}
+		}
+		/*
+		 * every lookup of the tile is issued before the first is used (a
+		 * row-by-row "is there a partner? then fetch its columns" is a chain
+		 * of dependent loads per row: 1.5 ms per 1e8 rows that way).  Rows
+		 * without a partner look at slot 0, harmlessly.
+		 */
+		cl_uint		slot[GPUPREAGG_QUADS][4];
+		cl_uint		gone[GPUPREAGG_QUADS];			/* bit j: no partner */
+#pragma unroll
+		for (int k = 0; k < GPUPREAGG_QUADS; k++)
+		{
+			cl_uint	row0 = tile_base + (k * GPUPREAGG_BLOCK + threadIdx.x) * 4;
+			gone[k] = 0;
+#pragma unroll
+			for (int j = 0; j < 4; j++)
+			{
+				cl_ulong	s64 = (cl_ulong)((cl_long)keyq[k][j] - key_min);
+				bool		live = ((full_tile || row0 + j < nitems) && ((keynn[k] >> j) & 1) && s64 < nslots);
+				slot[k][j] = (live ? (cl_uint)s64 : 0u);
+				gone[k] |= (live ? 0u : (1u << j));
+			}
+		}
+#pragma unroll
+		for (int k = 0; k < GPUPREAGG_QUADS; k++)
+		{
+			cl_uint	flags[4];
+			cl_uint	ab = 0;
+#pragma unroll
+			for (int j = 0; j < 4; j++)
+			{
+				flags[j] = *(const cl_uint *)(recs + (size_t)reclen * slot[k][j]);
+				ab |= ((flags[j] & 1u) ? 0u : (1u << j));
+			}
+			gone[k] |= ab;
+			/* the wanted columns sit in the same record: its line is in L1 by now */
+#define X(attno,colidx,NAME)													\
+			if (inner_##attno)													\
+			{																	\
+				cl_uint nn = 0;													\
+				_Pragma("unroll")												\
+				for (int j = 0; j < 4; j++)										\
+				{																\
+					T.v_##attno[k][j] = *(const pg_##NAME##_base_t *)			\
+						(recs + (size_t)reclen * slot[k][j] + recoff_##attno);	\
+					nn |= (((flags[j] >> recbit_##attno) & 1u) ? 0u : (1u << j));	\
+				}																\
+				T.nn_##attno[k] = nn;											\
+			}
+			STROM_KVAR_LIST(X)
+#undef X
+		}
+#pragma unroll
+		for (int k = 0; k < GPUPREAGG_QUADS; k++)
+		{
+#pragma unroll
+			for (int j = 0; j < 4; j++)
+			{
+				if (!((gone[k] >> j) & 1))
+				{
+					strom_kvars	KV;
+#define X(attno,colidx,NAME)													\
+					KV.KVAR_##attno = pg_##NAME##_make(T.v_##attno[k][j],			\
+													   !((T.nn_##attno[k] >> j) & 1));
+					STROM_KVAR_LIST(X)
+#undef X
+					KV.__dummy = 0;
+					gpupreagg_dense_row(lds, ctl, L, KP, KV, gid_lo, G, NREP, rep,
+										param_error, &chunk_status);
+				}
+			}
+		}
+	}
+	gpupreagg_store_slab(lds, L, slabs + (size_t)blockIdx.x * ctl->slab_bytes, G, NREP);
+	gpupreagg_writeback_status(&kgpreagg->status, chunk_status);
+}
+
+extern "C" __global__ void
+__launch_bounds__(GPUPREAGG_BLOCK)
+gpupreagg_dense_lookup(kern_gpupreagg *kgpreagg,
+					   const kern_data_store *kds,
+					   const gpupreagg_joined_map *jmap,
+					   const gpupreagg_dense_ctl *ctl_in_memory,
+					   char *slabs)
+{
+	extern __shared__ __attribute__((aligned(16))) char lds[];
+	/* the control block by value (see gpupreagg_dense_column) */
+	const gpupreagg_dense_ctl ctl_by_value = *ctl_in_memory;
+	const gpupreagg_dense_ctl *ctl = &ctl_by_value;
+	if (jmap->key_attlen == 8)
+		gpupreagg_dense_lookup_body<cl_long>(kgpreagg, kds, jmap, ctl, slabs, lds);
+	else
+		gpupreagg_dense_lookup_body<cl_int>(kgpreagg, kds, jmap, ctl, slabs, lds);
 }
 
 /* ====================================================================== *

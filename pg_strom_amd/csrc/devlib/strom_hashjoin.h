@@ -950,6 +950,13 @@ hashjoin_build_dimcol_kernel(const kern_multihash *kmhash, const hashjoin_index 
 	const hashjoin_index_rel *ir = &hjidx->rel[0];
 	const cl_uint *slots = (const cl_uint *)((const char *)hjidx + ir->slots_off);
 
+	if (col == -1)
+	{
+		/* not a column: which slots hold no inner row at all */
+		for (cl_uint s = blockIdx.x * blockDim.x + threadIdx.x; s < ir->nslots; s += gridDim.x * blockDim.x)
+			isnull[s] = (slots[s] == 0);
+		return;
+	}
 	if (col < 0 || col >= (cl_int)kht->ncols || kht->colmeta[col].attlen != attlen)
 	{
 		if (blockIdx.x == 0 && threadIdx.x == 0)
@@ -974,6 +981,75 @@ hashjoin_build_dimcol_kernel(const kern_multihash *kmhash, const hashjoin_index 
 			default: *(cl_long *)out = (addr ? strom_fetch<cl_long>(addr) : 0); break;
 		}
 		isnull[s] = (addr == NULL);
+	}
+}
+
+/* ====================================================================== *
+ * the same by slot, but PACKED: one record per slot holding a flags word
+ * (bit 0: an inner row is there; bit 1+i: its i-th wanted column is NULL)
+ * and the wanted columns' values, for the join-as-a-lookup aggregate
+ * (gpupreagg_dense_lookup): with separate arrays every row costs one L2
+ * request per array, and that kernel is bound by the L2 request rate.
+ * ====================================================================== */
+struct hashjoin_dimrec_spec {
+	cl_uint		ncols;
+	cl_uint		reclen;
+	struct {
+		cl_int		col;			/* inner column, 0-based */
+		cl_int		attlen;
+		cl_uint		offset;			/* of the value inside the record */
+		cl_uint		__pad;
+	} c[16];
+};
+
+extern "C" __global__ void
+__launch_bounds__(256)
+hashjoin_build_dimrec_kernel(const kern_multihash *kmhash, const hashjoin_index *hjidx,
+							 const hashjoin_dimrec_spec *spec, char *recs, cl_uint *p_failed)
+{
+	const kern_hashtable *kht = KERN_HASHTABLE(kmhash, 0);
+	const hashjoin_index_rel *ir = &hjidx->rel[0];
+	const cl_uint *slots = (const cl_uint *)((const char *)hjidx + ir->slots_off);
+	cl_uint		ncols = spec->ncols;
+	cl_uint		reclen = spec->reclen;
+
+	for (cl_uint i = 0; i < ncols; i++)
+	{
+		cl_int	col = spec->c[i].col;
+		if (col < 0 || col >= (cl_int)kht->ncols || kht->colmeta[col].attlen != spec->c[i].attlen)
+		{
+			if (blockIdx.x == 0 && threadIdx.x == 0)
+				*p_failed = 1;
+			return;
+		}
+	}
+	for (cl_uint s = blockIdx.x * blockDim.x + threadIdx.x; s < ir->nslots; s += gridDim.x * blockDim.x)
+	{
+		char	   *rec = recs + (size_t)reclen * s;
+		cl_uint		off = slots[s];
+		cl_uint		flags = (off != 0 ? 1u : 0u);
+
+		for (cl_uint i = 0; i < ncols; i++)
+		{
+			const char *addr = NULL;
+			cl_int		attlen = spec->c[i].attlen;
+			char	   *out = rec + spec->c[i].offset;
+			if (off != 0)
+			{
+				const kern_hashentry *ent = (const kern_hashentry *)((const char *)kht + off);
+				addr = kern_get_datum_tuple(kht->colmeta, &ent->htup, spec->c[i].col);
+			}
+			switch (attlen)
+			{
+				case 1: *(cl_char *)out = (addr ? *(const cl_char *)addr : 0); break;
+				case 2: *(cl_short *)out = (addr ? strom_fetch<cl_short>(addr) : 0); break;
+				case 4: *(cl_int *)out = (addr ? strom_fetch<cl_int>(addr) : 0); break;
+				default: *(cl_long *)out = (addr ? strom_fetch<cl_long>(addr) : 0); break;
+			}
+			if (addr == NULL)
+				flags |= (2u << i);
+		}
+		*(cl_uint *)rec = flags;
 	}
 }
 

@@ -58,6 +58,9 @@ struct strom_hashjoin_table {
 	 * keys): (0-based column, attlen) -> {values, isnull}, built on first use */
 	std::mutex			dim_lock;
 	std::map<std::pair<int, int>, std::pair<char *, char *>> dimcols;
+	/* the same PACKED, one record per slot, per set of (column, attlen)
+	 * (hashjoin_build_dimrec_kernel): key = the set as text */
+	std::map<std::string, std::pair<char *, unsigned>> dimrecs;
 };
 
 extern "C" strom_hashjoin_table *
@@ -215,6 +218,8 @@ strom_hashjoin_table_release(strom_hashjoin_table *tbl)
 		dev->pool.release(kv.second.first);
 		dev->pool.release(kv.second.second);
 	}
+	for (auto &kv : tbl->dimrecs)
+		dev->pool.release(kv.second.first);
 	strom_put_devprog_key(tbl->key);
 	delete tbl;
 }
@@ -662,6 +667,82 @@ strom::hashjoin_table_dimcol(strom_hashjoin_table *tbl, int col, int attlen, voi
 	}
 	*p_values = it->second.first;
 	*p_isnull = it->second.second;
+	return 0;
+}
+
+/*
+ * packed slot records of the inner columns cols[] (0-based, attlens[] wide):
+ * a u32 flags word (bit 0: row present, bit 1+i: column i NULL) followed by
+ * the values at offsets[] (out); record length in *p_reclen.  Built on first
+ * use per column set and kept with the table.
+ */
+int
+strom::hashjoin_table_dimrecs(strom_hashjoin_table *tbl, int n, const int *cols, const int *attlens,
+							  unsigned *offsets, void **p_recs, unsigned *p_reclen)
+{
+	struct spec_image {
+		cl_uint		ncols, reclen;
+		struct { cl_int col, attlen; cl_uint offset, pad; } c[16];
+	} spec;
+	Device *dev = tbl->dev;
+
+	if (tbl->ntables != 1 || tbl->head.rel[0].mode != 1 || !tbl->head.rel[0].unique || n < 0 || n > 16)
+		return StromError_BadRequestMessage;
+	memset(&spec, 0, sizeof(spec));
+	unsigned	off = 4;
+	std::string	key;
+	for (int i = 0; i < n; i++)
+	{
+		if (!(attlens[i] == 1 || attlens[i] == 2 || attlens[i] == 4 || attlens[i] == 8))
+			return StromError_BadRequestMessage;
+		off = (off + attlens[i] - 1) & ~(unsigned)(attlens[i] - 1);
+		spec.c[i].col = cols[i];
+		spec.c[i].attlen = attlens[i];
+		spec.c[i].offset = offsets[i] = off;
+		off += attlens[i];
+		key += std::to_string(cols[i]) + ":" + std::to_string(attlens[i]) + ",";
+	}
+	unsigned	reclen = (off <= 8 ? 8 : off <= 16 ? 16 : off <= 32 ? 32 : (off + 63) & ~63u);
+	spec.ncols = n;
+	spec.reclen = reclen;
+	std::lock_guard<std::mutex> g(tbl->dim_lock);
+	auto	it = tbl->dimrecs.find(key);
+	if (it == tbl->dimrecs.end())
+	{
+		int		errcode = 0;
+		cl_uint	nslots = tbl->head.rel[0].nslots;
+		(void)hipSetDevice(dev->hip_id);
+		hipFunction_t fn = tbl->prog->get_function(dev, "hashjoin_build_dimrec_kernel", &errcode);
+		char   *d_recs = (char *)dev->pool.alloc((size_t)reclen * nslots + 64);
+		char   *d_spec = (char *)dev->pool.alloc(sizeof(spec) + 16);
+		cl_uint	failed = 1;
+		if (fn && d_recs && d_spec)
+		{
+			const void *a_km = tbl->d_kmhash;
+			const void *a_idx = tbl->d_index;
+			const void *a_spec = d_spec;
+			void	   *a_recs = d_recs;
+			void	   *a_failed = d_spec + sizeof(spec);
+			void	   *args[] = { &a_km, &a_idx, &a_spec, &a_recs, &a_failed };
+			unsigned	grid = std::max(1u, std::min<unsigned>((nslots + 255) / 256,
+															   (unsigned)dev->prop.multiProcessorCount * 8));
+			if (!(hipMemcpy(d_spec, &spec, sizeof(spec), hipMemcpyHostToDevice) == hipSuccess &&
+				  hipMemsetAsync(a_failed, 0, sizeof(cl_uint), dev->streams[0]) == hipSuccess &&
+				  hipModuleLaunchKernel(fn, grid, 1, 1, 256, 1, 1, 0, dev->streams[0], args, nullptr) == hipSuccess &&
+				  hipMemcpyAsync(&failed, a_failed, sizeof(cl_uint), hipMemcpyDeviceToHost, dev->streams[0]) == hipSuccess &&
+				  hipStreamSynchronize(dev->streams[0]) == hipSuccess))
+				failed = 1;
+		}
+		if (d_spec) dev->pool.release(d_spec);
+		if (failed)
+		{
+			if (d_recs) dev->pool.release(d_recs);
+			return StromError_DataStoreCorruption;
+		}
+		it = tbl->dimrecs.insert({key, {d_recs, reclen}}).first;
+	}
+	*p_recs = it->second.first;
+	*p_reclen = it->second.second;
 	return 0;
 }
 

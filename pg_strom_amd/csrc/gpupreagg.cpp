@@ -303,6 +303,7 @@ struct preagg_request {
 	/* rows = a finished GpuHashJoin's result pairs (strom_submit_gpupreagg_joined) */
 	const void		   *joined_results = nullptr;	/* device kern_resultbuf */
 	void			   *joined_buffer = nullptr;	/* the join's device image, owned by this request now */
+	bool				lookup = false;				/* no result pairs: the join is a lookup in the aggregate's pass */
 	std::shared_ptr<std::vector<char>> joined_map;	/* host image of gpupreagg_joined_map */
 };
 
@@ -326,11 +327,13 @@ gpupreagg_launch(strom_task_impl *task, preagg_request req)
 	/* chunks fold into one table: keep them in order on one stream */
 	task->stream = dev->streams[0];
 
+	bool	use_lookup = req.lookup;
 	bool	use_joined = (req.joined_results != nullptr);
-	bool	use_column = (!use_joined && req.format == KDS_FORMAT_COLUMN &&
+	bool	use_column = (!use_joined && !use_lookup && req.format == KDS_FORMAT_COLUMN &&
 						  req.krowmap == nullptr && req.rowmap_dev == nullptr);
 	bool	use_reg = (use_column && sess->reg_groups != 0);
-	hipFunction_t fn = prog->get_function(dev, use_joined ? "gpupreagg_dense_joined"
+	hipFunction_t fn = prog->get_function(dev, use_lookup ? "gpupreagg_dense_lookup"
+										  : use_joined ? "gpupreagg_dense_joined"
 										  : use_reg ? (sess->reg_groups == 1 ? "gpupreagg_reg1_column"
 																			  : "gpupreagg_priv_column")
 										  : use_column ? "gpupreagg_dense_column"
@@ -399,7 +402,7 @@ gpupreagg_launch(strom_task_impl *task, preagg_request req)
 		d_rowmap = p;
 	}
 	void   *d_jmap = nullptr;
-	if (use_joined)
+	if (use_joined || use_lookup)
 	{
 		d_jmap = dev->pool.alloc(req.joined_map->size());
 		if (!d_jmap)
@@ -426,10 +429,12 @@ gpupreagg_launch(strom_task_impl *task, preagg_request req)
 		void	   *args_col[] = { &a_kg, &a_kds, &a_ctl, &a_slabs };
 		void	   *args_gen[] = { &a_kg, &a_kds, &a_toast, &a_map, &a_ctl, &a_slabs };
 		void	   *args_join[] = { &a_kg, &a_res, &a_kds, &a_jmap, &a_ctl, &a_slabs };
+		void	   *args_look[] = { &a_kg, &a_kds, &a_jmap, &a_ctl, &a_slabs };
 		void	   *args_mrg[] = { &a_kg, &a_ctl, &a_slabs, &a_table };
 		REQ_CHECK(hipModuleLaunchKernel(fn, sess->ctl.nslabs, 1, 1, use_reg ? 256 : sess->block, 1, 1,
 										(unsigned)sess->lds_bytes, task->stream,
-										use_joined ? args_join : use_column ? args_col : args_gen, nullptr),
+										use_lookup ? args_look : use_joined ? args_join
+										: use_column ? args_col : args_gen, nullptr),
 				  "launch gpupreagg reduction");
 		if (task->pfm.enabled)
 		{
@@ -1134,6 +1139,9 @@ struct joined_map_image {
 		cl_ulong	dimvalues;
 		cl_ulong	dimisnull;
 	} c[64];
+	cl_ulong	recs;
+	cl_uint		reclen;
+	cl_uint		pad;
 };
 }
 
@@ -1141,24 +1149,25 @@ struct joined_map_image {
  * fold the rows a finished GpuHashJoin produced, straight from its result
  * pairs (gpupreagg_dense_joined): see strom_hip.h
  */
-extern "C" strom_task *
-strom_submit_gpupreagg_joined(strom_gpupreagg *sess, strom_task *join_handle,
-							  strom_hashjoin_table *tbl, strom_dstore *outer,
-							  int ncols, const int32_t *src_depth, const int32_t *src_colidx,
-							  const int32_t *type_oids,
-							  strom_done_cb done, void *arg, int *p_errcode)
+static strom_task *
+submit_gpupreagg_over_join(strom_gpupreagg *sess, strom_task *join_handle, bool lookup,
+						   strom_hashjoin_table *tbl, strom_dstore *outer,
+						   int ncols, const int32_t *src_depth, const int32_t *src_colidx,
+						   const int32_t *type_oids,
+						   strom_done_cb done, void *arg, int *p_errcode)
 {
 	int		dummy;
 	if (!p_errcode)
 		p_errcode = &dummy;
 	*p_errcode = 0;
 	strom_task_impl *jtask = static_cast<strom_task_impl *>(join_handle);
-	if (!sess || sess->hashed || !sess->has_domain || !jtask || !tbl || !outer ||
+	if (!sess || sess->hashed || !sess->has_domain || (!lookup && !jtask) || !tbl || !outer ||
 		ncols < 1 || ncols > 64 || !src_depth || !src_colidx || !type_oids)
 	{
 		*p_errcode = StromError_BadRequestMessage;
 		return nullptr;
 	}
+	if (jtask)
 	{
 		std::unique_lock<std::mutex> g(jtask->lock);
 		jtask->cond.wait(g, [&]{ return jtask->completed; });
@@ -1166,7 +1175,7 @@ strom_submit_gpupreagg_joined(strom_gpupreagg *sess, strom_task *join_handle,
 	cl_long	key_min = 0;
 	cl_uint	nslots = 0;
 	int		key_attno = 0, tbl_dindex = -1;
-	if (!jtask->res_is_join || !jtask->keep_main || jtask->errcode != 0 || !jtask->main_devptr ||
+	if ((jtask && (!jtask->res_is_join || !jtask->keep_main || jtask->errcode != 0 || !jtask->main_devptr)) ||
 		hashjoin_table_direct_info(tbl, &key_min, &nslots, &key_attno, &tbl_dindex) != 0 ||
 		key_attno < 1 || outer->head.format != KDS_FORMAT_COLUMN ||
 		outer->dindex != sess->dev->dindex || tbl_dindex != sess->dev->dindex)
@@ -1174,7 +1183,7 @@ strom_submit_gpupreagg_joined(strom_gpupreagg *sess, strom_task *join_handle,
 		/* needs: a finished join with STROM_RESULTS_ON_DEVICE, one inner relation
 		 * with a DIRECT index and unique keys, joined on a plain outer column,
 		 * over a resident COLUMN chunk */
-		*p_errcode = (jtask->errcode ? jtask->errcode : StromError_BadRequestMessage);
+		*p_errcode = ((jtask && jtask->errcode) ? jtask->errcode : StromError_BadRequestMessage);
 		return nullptr;
 	}
 	(void)hipSetDevice(sess->dev->hip_id);
@@ -1216,6 +1225,8 @@ strom_submit_gpupreagg_joined(strom_gpupreagg *sess, strom_task *join_handle,
 				return nullptr;
 			}
 		}
+		else if (src_depth[i] == 1 && lookup)
+			;						/* packed slot records, below */
 		else if (src_depth[i] == 1)
 		{
 			void   *vals = nullptr, *nulls = nullptr;
@@ -1234,10 +1245,46 @@ strom_submit_gpupreagg_joined(strom_gpupreagg *sess, strom_task *join_handle,
 			return nullptr;
 		}
 	}
-	if (!(jm->key_attlen == 1 || jm->key_attlen == 2 || jm->key_attlen == 4 || jm->key_attlen == 8))
+	if (!(jm->key_attlen == 1 || jm->key_attlen == 2 || jm->key_attlen == 4 || jm->key_attlen == 8) ||
+		(lookup && !(jm->key_attlen == 4 || jm->key_attlen == 8)))
 	{
-		*p_errcode = StromError_DataStoreCorruption;
+		*p_errcode = (lookup ? StromError_BadRequestMessage : StromError_DataStoreCorruption);
 		return nullptr;
+	}
+	if (lookup)
+	{
+		/* one packed record per slot: presence, NULL bits and the wanted inner columns */
+		int		cols[16], lens[16], which[16], n = 0;
+		unsigned offs[16], reclen = 0;
+		void   *recs = nullptr;
+		for (int i = 0; i < ncols; i++)
+		{
+			if (src_depth[i] != 1)
+				continue;
+			if (n == 16)
+			{
+				*p_errcode = StromError_BadRequestMessage;
+				return nullptr;
+			}
+			int		oid = (type_oids[i] < 0 ? -type_oids[i] : type_oids[i]);
+			cols[n] = src_colidx[i];
+			lens[n] = ((oid == STROM_BOOLOID || oid == STROM_BPCHAROID) ? 1 : oid == STROM_INT2OID ? 2
+					   : (oid == STROM_INT4OID || oid == STROM_FLOAT4OID || oid == STROM_DATEOID) ? 4 : 8);
+			which[n++] = i;
+		}
+		int		rc = hashjoin_table_dimrecs(tbl, n, cols, lens, offs, &recs, &reclen);
+		if (rc != 0)
+		{
+			*p_errcode = rc;
+			return nullptr;
+		}
+		for (int k = 0; k < n; k++)
+		{
+			jm->c[which[k]].dimvalues = offs[k];		/* byte offset in the record */
+			jm->c[which[k]].dimisnull = 1 + k;			/* bit in the flags word */
+		}
+		jm->recs = (cl_ulong)(uintptr_t)recs;
+		jm->reclen = reclen;
 	}
 	preagg_request req;
 	req.sess = sess;
@@ -1246,18 +1293,50 @@ strom_submit_gpupreagg_joined(strom_gpupreagg *sess, strom_task *join_handle,
 	req.krowmap = nullptr;
 	req.rowmap_dev = nullptr;
 	req.format = KDS_FORMAT_COLUMN;
-	req.nrows = jtask->res_nitems;
-	req.joined_results = (const char *)jtask->main_devptr + jtask->res_offset;
 	req.joined_map = img;
-	/* the result pairs now belong to this request: the join task can be waited
-	 * for and released in any order */
-	req.joined_buffer = jtask->main_devptr;
-	jtask->main_devptr = nullptr;
-	jtask->keep_main = false;
+	req.lookup = lookup;
+	if (lookup)
+		req.nrows = outer->head.nitems;
+	else
+	{
+		req.nrows = jtask->res_nitems;
+		req.joined_results = (const char *)jtask->main_devptr + jtask->res_offset;
+		/* the result pairs now belong to this request: the join task can be
+		 * waited for and released in any order */
+		req.joined_buffer = jtask->main_devptr;
+		jtask->main_devptr = nullptr;
+		jtask->keep_main = false;
+	}
 	sess->nfolds++;
 	strom_task_impl *task = task_create(sess->dev, done, arg);
 	program_run_or_park(sess->prog, [task, req]() { gpupreagg_launch(task, req); });
 	return task;
+}
+
+extern "C" strom_task *
+strom_submit_gpupreagg_joined(strom_gpupreagg *sess, strom_task *join_handle,
+							  strom_hashjoin_table *tbl, strom_dstore *outer,
+							  int ncols, const int32_t *src_depth, const int32_t *src_colidx,
+							  const int32_t *type_oids,
+							  strom_done_cb done, void *arg, int *p_errcode)
+{
+	return submit_gpupreagg_over_join(sess, join_handle, false, tbl, outer, ncols, src_depth, src_colidx,
+									  type_oids, done, arg, p_errcode);
+}
+
+/*
+ * the join as a lookup inside the aggregate's own pass over the outer chunk
+ * (gpupreagg_dense_lookup): no join request at all
+ */
+extern "C" strom_task *
+strom_submit_gpupreagg_lookup(strom_gpupreagg *sess,
+							  strom_hashjoin_table *tbl, strom_dstore *outer,
+							  int ncols, const int32_t *src_depth, const int32_t *src_colidx,
+							  const int32_t *type_oids,
+							  strom_done_cb done, void *arg, int *p_errcode)
+{
+	return submit_gpupreagg_over_join(sess, nullptr, true, tbl, outer, ncols, src_depth, src_colidx,
+									  type_oids, done, arg, p_errcode);
 }
 
 /*

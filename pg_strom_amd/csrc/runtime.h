@@ -162,6 +162,8 @@ struct strom_task_impl : public strom_task {
 Device	   *get_device(int dindex);
 /* gpuhashjoin.cpp, for consumers of join results (gpupreagg.cpp) */
 int			hashjoin_table_dimcol(strom_hashjoin_table *tbl, int col, int attlen, void **p_values, void **p_isnull);
+int			hashjoin_table_dimrecs(strom_hashjoin_table *tbl, int n, const int *cols, const int *attlens,
+								   unsigned *offsets, void **p_recs, unsigned *p_reclen);
 int			hashjoin_table_direct_info(strom_hashjoin_table *tbl, cl_long *p_key_min, cl_uint *p_nslots,
 									   int *p_outer_key_attno, int *p_dindex);
 int			num_devices();

@@ -217,6 +217,22 @@ class GpuPreAgg(object):
             raise runtime.StromError(err.value, "strom_submit_gpupreagg_joined")
         return (task, chunk, (depth, colidx, oids))
 
+    def submit_lookup(self, join, chunk, columns):
+        """fact JOIN dim GROUP BY in one pass (strom_submit_gpupreagg_lookup): the join
+        is a lookup in the aggregate's own pass over the resident COLUMN chunk; 'join' only
+        lends its hash table.  columns as in join_to_column."""
+        from .kds import SQL_TYPES
+        depth = np.array([d for d, _, _ in columns], dtype=np.int32)
+        colidx = np.array([a - 1 for _, a, _ in columns], dtype=np.int32)
+        oids = np.array([SQL_TYPES[t][0] for _, _, t in columns], dtype=np.int32)
+        err = ctypes.c_int(0)
+        task = lib.strom_submit_gpupreagg_lookup(self.session, join.table, chunk.handle,
+                                                 len(columns), depth.ctypes.data, colidx.ctypes.data,
+                                                 oids.ctypes.data, None, None, ctypes.byref(err))
+        if not task:
+            raise runtime.StromError(err.value, "strom_submit_gpupreagg_lookup")
+        return (task, chunk, (depth, colidx, oids))
+
     def collect(self, pending):
         """returns (status, perfmon): status 0 folded, 2 CpuReCheck (not folded)"""
         pfm = strom_perfmon()

@@ -78,6 +78,24 @@ for it in range(4):
     print("fused pass %d: join %.0f us + aggregate over %d pairs %.0f us (kernel times) | total wall %.2f ms = %.0f Mrows/s of fact rows" % (
         it, jr.perfmon["time_kern_exec_ns"] * 1e-3, jr.nitems, pfm["time_kern_exec_ns"] * 1e-3,
         (t1 - t0) * 1e3, n / (t1 - t0) / 1e6), flush=True)
+# and with the join as a lookup inside the aggregate's own pass (no join request at all)
+agg3 = GpuPreAgg("(gpupreagg (qual " + qual + ") (key (var 1 int4)) (nrows) (psum (int8 (var 2 int4))) (psum (var 3 float8)))")
+agg3.begin([(0, ngroups)], ext_params=ext)
+agg3.program.wait()
+for it in range(4):
+    agg3.reset()
+    t0 = time.perf_counter()
+    st, pfm = agg3.collect(agg3.submit_lookup(join2, ds, [(1, 2, "int4"), (0, 2, "int4"), (0, 3, "float8")]))
+    pr3 = agg3.fetch()
+    t1 = time.perf_counter()
+    assert st == 0
+    print("lookup pass %d: one kernel over the fact chunk %.0f us (+ merge) | total wall %.2f ms = %.0f Mrows/s of fact rows, %d groups" % (
+        it, pfm["time_kern_exec_ns"] * 1e-3, (t1 - t0) * 1e3, n / (t1 - t0) / 1e6, len(pr3)), flush=True)
+order3 = np.argsort(pr3.column(0)[0])
+same = (np.array_equal(pr3.column(1)[0][order3], pr.column(1)[0][np.argsort(pr.column(0)[0])]) and
+        np.array_equal(pr3.column(2)[0][order3], pr.column(2)[0][np.argsort(pr.column(0)[0])]))
+print("lookup_equals_fused=%s" % same)
+agg3.end()
 join2.end()
 m = (a < ext[0]) & (b > ext[1]) & (fk < nd)
 pos = np.empty(nd, dtype=np.int64); pos[dkey] = np.arange(nd)

@@ -324,3 +324,66 @@ def test_preagg_straight_over_the_join_result_pairs(ngroups):
     gmax, gnull = pr.column(4)
     assert np.array_equal(gnull[order], np.isinf(wmax))
     assert np.array_equal(gmax[order][~np.isinf(wmax)], wmax[~np.isinf(wmax)])
+
+
+@pytest.mark.parametrize("ngroups", [53, 9000])
+def test_join_as_a_lookup_inside_the_aggregate(ngroups):
+    """strom_submit_gpupreagg_lookup: fact JOIN dim WHERE ... GROUP BY in ONE pass over
+    the fact chunk -- no join request, no result pairs; rows without a partner (NULL key,
+    key outside the table, empty slot) are dropped, the WHERE is the aggregate's qual"""
+    runtime.init()
+    n, nd = 250007, 20000
+    rng = np.random.default_rng(89)
+    span = int(nd * 1.3)
+    fk = rng.integers(-50, span + 50, n).astype(np.int32)      # also keys below / above the table
+    fkn = rng.random(n) < 0.02
+    a = rng.integers(0, 2**31, n, dtype=np.int64).astype(np.int32)
+    an = rng.random(n) < 0.03
+    b = rng.random(n)
+    fact = kds.build_kds("column", [kds.Column("int4", fk, fkn), kds.Column("int4", a, an), kds.Column("float8", b)])
+    dkey = rng.permutation(span)[:nd].astype(np.int32)         # holes in the key range
+    dgrp = (dkey % ngroups).astype(np.int32)
+    dgn = rng.random(nd) < 0.04
+    dval = rng.random(nd) * 10
+    dvn = rng.random(nd) < 0.05
+    inner = kds.build_kds("row_flat", [kds.Column("int4", dkey), kds.Column("int4", dgrp, dgn),
+                                       kds.Column("float8", dval, dvn)])
+    km = build_multihash([(inner, [1])])
+    ext = [np.int32(2**30), 0.25]
+    ds = runtime.DeviceStore.upload(fact)
+    join = GpuHashJoin("(gpuhashjoin (rel (hashkey (var 1 int4) 1 int4)))").begin(km)
+    spec = ("(gpupreagg (qual " + QUAL + ") (key (var 1 int4)) (nrows) (psum (int8 (var 2 int4)))"
+            " (psum (var 3 float8)) (pmax (var 4 float8)))")
+    agg = GpuPreAgg(spec)
+    try:
+        assert join.table_info(1)["mode"] == "direct" and join.table_info(1)["unique"]
+        agg.begin([(0, ngroups)], ext_params=ext)
+        for _ in range(2):                                      # two chunks into the same table
+            assert agg.collect(agg.submit_lookup(join, ds, [(1, 2, "int4"), (0, 2, "int4"), (0, 3, "float8"),
+                                                            (1, 3, "float8")]))[0] == 0
+        pr = agg.fetch()
+    finally:
+        agg.end()
+        join.end()
+        ds.release()
+    pos = np.full(span + 100, -1, dtype=np.int64)
+    pos[dkey] = np.arange(nd)
+    inrange = (~fkn) & (fk >= 0) & (fk < span)
+    di_all = np.where(inrange, pos[np.clip(fk, 0, span - 1)], -1)
+    sel = np.flatnonzero((di_all >= 0) & (~an) & (a < ext[0]) & (b > ext[1]))
+    di = di_all[sel]
+    g = np.where(dgn[di], 10**6, dgrp[di])
+    ug, inv = np.unique(g, return_inverse=True)
+    keys, knull = pr.column(1 - 1)
+    gk = np.where(knull, 10**6, keys)
+    order = np.argsort(gk)
+    assert np.array_equal(gk[order], ug)
+    assert np.array_equal(pr.column(1)[0][order], 2 * np.bincount(inv))
+    assert np.array_equal(pr.column(2)[0][order], 2 * np.bincount(inv, weights=a[sel].astype(np.float64)).astype(np.int64))
+    assert np.allclose(pr.column(3)[0][order], 2 * np.bincount(inv, weights=b[sel]), rtol=1e-12)
+    wmax = np.full(len(ug), -np.inf)
+    ok = ~dvn[di]
+    np.maximum.at(wmax, inv[ok], dval[di][ok])
+    gmax, gnull = pr.column(4)
+    assert np.array_equal(gnull[order], np.isinf(wmax))
+    assert np.array_equal(gmax[order][~np.isinf(wmax)], wmax[~np.isinf(wmax)])
