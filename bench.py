@@ -225,6 +225,25 @@ def other_operator_rates(nrows):
     out["join_groupby_fused"] = {"workload": "same query, the aggregate reads the join's result pairs",
                                  "wall_ms": t * 1e3, "mrows_s": nrows / t / 1e6,
                                  "joined_rows": int(jr.nitems), "groups": len(pr)}
+    # and with no join request at all: the join is a lookup inside the aggregate's own pass
+    # over the fact chunk (strom_submit_gpupreagg_lookup), the WHERE is the aggregate's qual
+    agg3 = GpuPreAgg("(gpupreagg (qual (and (int4lt (var 2 int4) (param 0 int4)) (float8gt (var 3 float8) (param 1 float8))))"
+                     " (key (var 1 int4)) (nrows) (psum (int8 (var 2 int4))) (psum (var 3 float8)))")
+    agg3.begin([(0, ngroups)], ext_params=ext)
+    walls, kerns = [], []
+    for _ in range(5):
+        agg3.reset()
+        t0 = time.perf_counter()
+        st, pfm = agg3.collect(agg3.submit_lookup(join2, fact, [(1, 2, "int4"), (0, 2, "int4"), (0, 3, "float8")]))
+        pr3 = agg3.fetch()
+        walls.append(time.perf_counter() - t0)
+        kerns.append(pfm["time_kern_exec_ns"])
+    t = float(np.median(walls[1:]))
+    out["join_as_lookup_groupby"] = {"workload": "same query, one pass over the fact chunk: the join is a lookup "
+                                                 "inside the aggregate kernel",
+                                     "wall_ms": t * 1e3, "kernel_us": float(np.median(kerns[1:])) * 1e-3,
+                                     "mrows_s": nrows / t / 1e6, "groups": len(pr3)}
+    agg3.end()
     join2.end()
     agg.end()
     scan.end()

@@ -251,9 +251,9 @@ strom_codegen_gpupreagg(const char *spec, strom_codegen_result *out,
 			 * fold with roles (strom_gpupreagg.h) decides from the former
 			 * whether a row is its own and loads the latter only then
 			 */
-			codegen_context kctx;
-			kctx.var_label = "KVAR";
-			kctx.var_struct = "KV";
+			codegen_context kctx, qctx;
+			kctx.var_label = qctx.var_label = "KVAR";
+			kctx.var_struct = qctx.var_struct = "KV";
 			for (size_t i = 1; i < tree.items.size(); i++)
 			{
 				const sexpr &t = tree.items[i];
@@ -262,7 +262,20 @@ strom_codegen_gpupreagg(const char *spec, strom_codegen_result *out,
 				{
 					std::string e;
 					codegen_expression(t.items[1], kctx, e);
+					if (t.items[0].atom == "qual")
+						codegen_expression(t.items[1], qctx, e);
 				}
+			}
+			{
+				/* which columns the qual reads (bit attno-1): the join-as-a-lookup kernel
+				 * evaluates a qual over outer columns before it probes the table */
+				unsigned long long qmask = 0;
+				for (auto &v : qctx.used_vars)
+					if (v.attno >= 1 && v.attno <= 64)
+						qmask |= (1ULL << (v.attno - 1));
+				char qb[64];
+				snprintf(qb, sizeof(qb), "#define GPUPREAGG_QUAL_VARMASK 0x%llxUL\n", qmask);
+				src += qb;
 			}
 			codegen_context rctx;
 			for (auto &v : ctx.used_vars)

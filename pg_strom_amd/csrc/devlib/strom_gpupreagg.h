@@ -944,6 +944,14 @@ gpupreagg_dense_lookup_body(kern_gpupreagg *kgpreagg,
 							   ? (const cl_uint *)((const char *)kds + coldir[jmap->key_col].nulls_off) : NULL);
 	const char *recs = (const char *)jmap->recs;
 	cl_uint		reclen = jmap->reclen;
+	/* a qual that reads outer columns only is evaluated BEFORE the probe: a row it
+	 * rejects (without an error) costs no L2 request; gpupreagg_dense_row evaluates
+	 * it again for the rows that do have a partner, errors included */
+	cl_ulong	inner_mask = 0;
+#define X(attno,colidx,NAME)	inner_mask |= (inner_##attno ? (1UL << colidx) : 0UL);
+	STROM_KVAR_LIST(X)
+#undef X
+	const bool	qual_first = ((GPUPREAGG_QUAL_VARMASK & inner_mask) == 0 && GPUPREAGG_QUAL_VARMASK != 0);
 	cl_long		key_min = jmap->key_min;
 	cl_uint		nslots = jmap->nslots;
 
@@ -998,6 +1006,20 @@ gpupreagg_dense_lookup_body(kern_gpupreagg *kgpreagg,
 			{
 				cl_ulong	s64 = (cl_ulong)((cl_long)keyq[k][j] - key_min);
 				bool		live = ((full_tile || row0 + j < nitems) && ((keynn[k] >> j) & 1) && s64 < nslots);
+				if (qual_first && live)
+				{
+					strom_kvars	KV;
+					cl_int		qerr = param_error;
+#define X(attno,colidx,NAME)													\
+					KV.KVAR_##attno = (inner_##attno								\
+						? pg_##NAME##_make((pg_##NAME##_base_t)0, true)			\
+						: pg_##NAME##_make(T.v_##attno[k][j], !((T.nn_##attno[k] >> j) & 1)));
+					STROM_KVAR_LIST(X)
+#undef X
+					KV.__dummy = 0;
+					pg_bool_t	rc = gpupreagg_qual_eval(&qerr, KP, KV);
+					live = !(qerr == StromError_Success && !EVAL(rc));
+				}
 				slot[k][j] = (live ? (cl_uint)s64 : 0u);
 				gone[k] |= (live ? 0u : (1u << j));
 			}
@@ -1006,15 +1028,28 @@ gpupreagg_dense_lookup_body(kern_gpupreagg *kgpreagg,
 		for (int k = 0; k < GPUPREAGG_QUADS; k++)
 		{
 			cl_uint	flags[4];
+			cl_uint	word1[4];				/* 8-byte records: bytes 4..7, fetched with the flags */
 			cl_uint	ab = 0;
 #pragma unroll
 			for (int j = 0; j < 4; j++)
 			{
-				flags[j] = *(const cl_uint *)(recs + (size_t)reclen * slot[k][j]);
+				const char *rec = recs + (size_t)reclen * slot[k][j];
+				if (reclen == 8)
+				{
+					/* the whole record in ONE load: a second load of the same
+					 * line is a second L2 request */
+					cl_ulong w = *(const cl_ulong *)rec;
+					flags[j] = (cl_uint)w;
+					word1[j] = (cl_uint)(w >> 32);
+				}
+				else
+				{
+					flags[j] = *(const cl_uint *)rec;
+					word1[j] = 0;
+				}
 				ab |= ((flags[j] & 1u) ? 0u : (1u << j));
 			}
 			gone[k] |= ab;
-			/* the wanted columns sit in the same record: its line is in L1 by now */
 #define X(attno,colidx,NAME)													\
 			if (inner_##attno)													\
 			{																	\
@@ -1022,8 +1057,16 @@ gpupreagg_dense_lookup_body(kern_gpupreagg *kgpreagg,
 				_Pragma("unroll")												\
 				for (int j = 0; j < 4; j++)										\
 				{																\
-					T.v_##attno[k][j] = *(const pg_##NAME##_base_t *)			\
-						(recs + (size_t)reclen * slot[k][j] + recoff_##attno);	\
+					pg_##NAME##_base_t val;										\
+					if (reclen == 8 && sizeof(val) <= 4)						\
+					{															\
+						cl_uint bits = word1[j] >> ((recoff_##attno - 4u) * 8u);	\
+						__builtin_memcpy(&val, &bits, sizeof(val) <= 4 ? sizeof(val) : 4);	\
+					}															\
+					else														\
+						val = *(const pg_##NAME##_base_t *)						\
+							(recs + (size_t)reclen * slot[k][j] + recoff_##attno);	\
+					T.v_##attno[k][j] = val;									\
 					nn |= (((flags[j] >> recbit_##attno) & 1u) ? 0u : (1u << j));	\
 				}																\
 				T.nn_##attno[k] = nn;											\
