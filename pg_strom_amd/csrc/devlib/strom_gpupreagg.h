@@ -1028,25 +1028,32 @@ gpupreagg_dense_lookup_body(kern_gpupreagg *kgpreagg,
 		for (int k = 0; k < GPUPREAGG_QUADS; k++)
 		{
 			cl_uint	flags[4];
-			cl_uint	word1[4];				/* 8-byte records: bytes 4..7, fetched with the flags */
+			cl_uint	words[4][4];			/* records of 8 / 16 bytes: the whole record, fetched in ONE load */
 			cl_uint	ab = 0;
 #pragma unroll
 			for (int j = 0; j < 4; j++)
 			{
 				const char *rec = recs + (size_t)reclen * slot[k][j];
+				/* a second load of the same line is a second L2 request, and this
+				 * kernel is bound by the L2 request rate */
 				if (reclen == 8)
 				{
-					/* the whole record in ONE load: a second load of the same
-					 * line is a second L2 request */
 					cl_ulong w = *(const cl_ulong *)rec;
-					flags[j] = (cl_uint)w;
-					word1[j] = (cl_uint)(w >> 32);
+					words[j][0] = (cl_uint)w;
+					words[j][1] = (cl_uint)(w >> 32);
+					words[j][2] = words[j][3] = 0;
+				}
+				else if (reclen == 16)
+				{
+					uint4 q = *(const uint4 *)rec;
+					words[j][0] = q.x; words[j][1] = q.y; words[j][2] = q.z; words[j][3] = q.w;
 				}
 				else
 				{
-					flags[j] = *(const cl_uint *)rec;
-					word1[j] = 0;
+					words[j][0] = *(const cl_uint *)rec;
+					words[j][1] = words[j][2] = words[j][3] = 0;
 				}
+				flags[j] = words[j][0];
 				ab |= ((flags[j] & 1u) ? 0u : (1u << j));
 			}
 			gone[k] |= ab;
@@ -1058,10 +1065,14 @@ gpupreagg_dense_lookup_body(kern_gpupreagg *kgpreagg,
 				for (int j = 0; j < 4; j++)										\
 				{																\
 					pg_##NAME##_base_t val;										\
-					if (reclen == 8 && sizeof(val) <= 4)						\
+					if (reclen <= 16)											\
 					{															\
-						cl_uint bits = word1[j] >> ((recoff_##attno - 4u) * 8u);	\
-						__builtin_memcpy(&val, &bits, sizeof(val) <= 4 ? sizeof(val) : 4);	\
+						/* (offsets are uniform: the selects are scalar) */		\
+						cl_uint	wi = recoff_##attno >> 2;						\
+						cl_uint	lo = (wi == 1 ? words[j][1] : wi == 2 ? words[j][2] : words[j][3]);	\
+						cl_uint	hi = (wi == 2 ? words[j][3] : 0u);				\
+						cl_ulong bits = (((cl_ulong)hi << 32) | lo) >> ((recoff_##attno & 3u) * 8u);	\
+						__builtin_memcpy(&val, &bits, sizeof(val));				\
 					}															\
 					else														\
 						val = *(const pg_##NAME##_base_t *)						\
