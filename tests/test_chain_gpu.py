@@ -326,8 +326,8 @@ def test_preagg_straight_over_the_join_result_pairs(ngroups):
     assert np.array_equal(gmax[order][~np.isinf(wmax)], wmax[~np.isinf(wmax)])
 
 
-@pytest.mark.parametrize("ngroups", [53, 9000])
-def test_join_as_a_lookup_inside_the_aggregate(ngroups):
+@pytest.mark.parametrize("ngroups,keytype", [(53, "int4"), (9000, "int4"), (53, "int8")])
+def test_join_as_a_lookup_inside_the_aggregate(ngroups, keytype):
     """strom_submit_gpupreagg_lookup: fact JOIN dim WHERE ... GROUP BY in ONE pass over
     the fact chunk -- no join request, no result pairs; rows without a partner (NULL key,
     key outside the table, empty slot) are dropped, the WHERE is the aggregate's qual"""
@@ -340,18 +340,20 @@ def test_join_as_a_lookup_inside_the_aggregate(ngroups):
     a = rng.integers(0, 2**31, n, dtype=np.int64).astype(np.int32)
     an = rng.random(n) < 0.03
     b = rng.random(n)
-    fact = kds.build_kds("column", [kds.Column("int4", fk, fkn), kds.Column("int4", a, an), kds.Column("float8", b)])
+    kdt = np.int32 if keytype == "int4" else np.int64
+    fact = kds.build_kds("column", [kds.Column(keytype, fk.astype(kdt), fkn), kds.Column("int4", a, an),
+                                    kds.Column("float8", b)])
     dkey = rng.permutation(span)[:nd].astype(np.int32)         # holes in the key range
     dgrp = (dkey % ngroups).astype(np.int32)
     dgn = rng.random(nd) < 0.04
     dval = rng.random(nd) * 10
     dvn = rng.random(nd) < 0.05
-    inner = kds.build_kds("row_flat", [kds.Column("int4", dkey), kds.Column("int4", dgrp, dgn),
+    inner = kds.build_kds("row_flat", [kds.Column(keytype, dkey.astype(kdt)), kds.Column("int4", dgrp, dgn),
                                        kds.Column("float8", dval, dvn)])
     km = build_multihash([(inner, [1])])
     ext = [np.int32(2**30), 0.25]
     ds = runtime.DeviceStore.upload(fact)
-    join = GpuHashJoin("(gpuhashjoin (rel (hashkey (var 1 int4) 1 int4)))").begin(km)
+    join = GpuHashJoin("(gpuhashjoin (rel (hashkey (var 1 %s) 1 %s)))" % (keytype, keytype)).begin(km)
     spec = ("(gpupreagg (qual " + QUAL + ") (key (var 1 int4)) (nrows) (psum (int8 (var 2 int4)))"
             " (psum (var 3 float8)) (pmax (var 4 float8)))")
     agg = GpuPreAgg(spec)
