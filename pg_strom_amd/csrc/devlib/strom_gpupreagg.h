@@ -816,15 +816,21 @@ gpupreagg_dense_joined(kern_gpupreagg *kgpreagg,
 	gpupreagg_lds_layout_init(L, G, NREP);
 	gpupreagg_lds_init(lds, L, G, NREP);
 	/* per virtual column: where it comes from (uniform, hoisted) */
+	/* inner columns come from the table's packed slot records (one record, one
+	 * L2 request per pair: hashjoin_build_dimrec_kernel), see gpupreagg_dense_lookup */
 #define X(attno,colidx,NAME)													\
 	const bool	inner_##attno = (jmap->c[colidx].depth != 0);					\
-	const char *val_##attno = (inner_##attno ? (const char *)jmap->c[colidx].dimvalues	\
+	const cl_uint recoff_##attno = (cl_uint)jmap->c[colidx].dimvalues;			\
+	const cl_uint recbit_##attno = (cl_uint)jmap->c[colidx].dimisnull;			\
+	const char *val_##attno = (inner_##attno ? NULL								\
 							   : (const char *)kds + coldir[jmap->c[colidx].col].values_off);	\
-	const char *nul_##attno = (inner_##attno ? (const char *)jmap->c[colidx].dimisnull	\
+	const char *nul_##attno = (inner_##attno ? NULL								\
 							   : (coldir[jmap->c[colidx].col].nulls_off != 0		\
 								  ? (const char *)kds + coldir[jmap->c[colidx].col].nulls_off : NULL));
 	STROM_KVAR_LIST(X)
 #undef X
+	const char *recs = (const char *)jmap->recs;
+	cl_uint		reclen = jmap->reclen;
 	const char *keyvals = (const char *)kds + coldir[jmap->key_col].values_off;
 	cl_int		key_attlen = jmap->key_attlen;
 	cl_long		key_min = jmap->key_min;
@@ -848,11 +854,44 @@ gpupreagg_dense_joined(kern_gpupreagg *kgpreagg,
 			STROM_SET_ERROR(&chunk_status, StromError_DataStoreCorruption);
 			continue;
 		}
+		/* the pair's inner record, whole (8 / 16 bytes in one load) */
+		cl_uint		words[4];
+		{
+			const char *rec = recs + (size_t)reclen * slot;
+			if (reclen == 8)
+			{
+				cl_ulong w = *(const cl_ulong *)rec;
+				words[0] = (cl_uint)w; words[1] = (cl_uint)(w >> 32); words[2] = words[3] = 0;
+			}
+			else if (reclen == 16)
+			{
+				uint4 q = *(const uint4 *)rec;
+				words[0] = q.x; words[1] = q.y; words[2] = q.z; words[3] = q.w;
+			}
+			else
+			{
+				words[0] = *(const cl_uint *)rec;
+				words[1] = words[2] = words[3] = 0;
+			}
+		}
 #define X(attno,colidx,NAME)													\
-		KV.KVAR_##attno = (inner_##attno										\
-			? pg_##NAME##_make(((const pg_##NAME##_base_t *)val_##attno)[slot],	\
-							   ((const cl_uchar *)nul_##attno)[slot] != 0)		\
-			: STROM_COLUMN_REF(NAME, val_##attno, nul_##attno, outer_row));
+		if (inner_##attno)														\
+		{																		\
+			pg_##NAME##_base_t val;												\
+			if (reclen <= 16)													\
+			{																	\
+				cl_uint	wi = recoff_##attno >> 2;								\
+				cl_uint	lo = (wi == 1 ? words[1] : wi == 2 ? words[2] : words[3]);	\
+				cl_uint	hi = (wi == 2 ? words[3] : 0u);							\
+				cl_ulong bits = (((cl_ulong)hi << 32) | lo) >> ((recoff_##attno & 3u) * 8u);	\
+				__builtin_memcpy(&val, &bits, sizeof(val));						\
+			}																	\
+			else																\
+				val = *(const pg_##NAME##_base_t *)(recs + (size_t)reclen * slot + recoff_##attno);	\
+			KV.KVAR_##attno = pg_##NAME##_make(val, ((words[0] >> recbit_##attno) & 1u) != 0);	\
+		}																		\
+		else																	\
+			KV.KVAR_##attno = STROM_COLUMN_REF(NAME, val_##attno, nul_##attno, outer_row);
 		STROM_KVAR_LIST_GROUPING(X)
 		KV.__dummy = 0;
 		if (nsplits > 1)

@@ -1225,20 +1225,8 @@ submit_gpupreagg_over_join(strom_gpupreagg *sess, strom_task *join_handle, bool 
 				return nullptr;
 			}
 		}
-		else if (src_depth[i] == 1 && lookup)
-			;						/* packed slot records, below */
 		else if (src_depth[i] == 1)
-		{
-			void   *vals = nullptr, *nulls = nullptr;
-			int		rc = hashjoin_table_dimcol(tbl, src_colidx[i], attlen, &vals, &nulls);
-			if (rc != 0)
-			{
-				*p_errcode = rc;
-				return nullptr;
-			}
-			jm->c[i].dimvalues = (cl_ulong)(uintptr_t)vals;
-			jm->c[i].dimisnull = (cl_ulong)(uintptr_t)nulls;
-		}
+			;						/* packed slot records, below */
 		else
 		{
 			*p_errcode = StromError_BadRequestMessage;
@@ -1251,7 +1239,6 @@ submit_gpupreagg_over_join(strom_gpupreagg *sess, strom_task *join_handle, bool 
 		*p_errcode = (lookup ? StromError_BadRequestMessage : StromError_DataStoreCorruption);
 		return nullptr;
 	}
-	if (lookup)
 	{
 		/* one packed record per slot: presence, NULL bits and the wanted inner columns */
 		int		cols[16], lens[16], which[16], n = 0;
