@@ -1,26 +1,41 @@
 #!/usr/bin/env python3
 """
-bench.py -- headline measurement of the GpuScan path (BASELINE.json configs[1]).
+bench.py -- headline measurement of the per-chunk path (BASELINE.json metric:
+"Mrows/sec scan+hashjoin+groupby on 1e9-row synth; achieved HBM GB/s vs peak").
 
-A "step" is one pass of GpuScan over the rank's resident table: 1e8 rows of
-(a int4, b float8) in KDS_FORMAT_COLUMN chunks, WHERE a < k AND b > c, every
-chunk submitted through the C ABI (strom_submit_gpuscan) with the results left
-in HBM.  Inputs are resident in HBM before the timed region starts.  With N
-GPUs the table is N x 1e8 rows sharded by row range, one process per GPU,
-no data-path collective (weak scaling).
+Headline (`value`, `roofline`, the timed region): GpuScan over the rank's
+resident table -- 1e9 rows per GPU of (a int4, b float8) in ten 1e8-row
+KDS_FORMAT_COLUMN chunks (a chunk's `length` is 32-bit as in the reference, so
+1e9 rows are 10 chunks), WHERE a < k AND b > c, every chunk submitted through
+the C ABI (strom_submit_gpuscan) with results[] left in HBM.  A "step" is one
+pass over all chunks; inputs are resident before the timed region starts.
+With N GPUs the table is N x 1e9 rows sharded by row range, one process per
+GPU, no data-path collective (weak scaling).
 
-Output: ONE JSON line on rank 0 (see the driver contract), with
-  roofline     algorithmic bytes per launch / mean kernel time per launch,
-               kernel time from HIP events recorded on the launch stream by
-               the runtime (strom_perfmon.time_kern_exec_ns)
-  cpu_baseline the CPU oracle (oracle/, a port: tuple-at-a-time over ROW
-               format heap pages, expression tree interpreted per row, the
-               shape of PostgreSQL's SeqScan+ExecQual) timed on a bounded
-               sample of the same workload on this host, rank 0, N=1 only
+`--gpus N` with N > 1 and no WORLD_SIZE in the environment starts the N ranks
+itself (fresh child processes, before this process touches the GPU) and relays
+rank 0's JSON line; under torch.distributed.run it is one of the ranks.
+
+Next to the headline, in the same JSON line:
+  roofline      algorithmic bytes per launch / mean kernel time per launch (HIP
+                events on the launch stream, strom_perfmon.time_kern_exec_ns),
+                against the nominal 8 TB/s and against the box's own
+                streaming-read rate (strom_membw_probe)
+  cpu_baseline  the CPU oracle (oracle/, a port: tuple-at-a-time over ROW
+                format heap pages, expression tree interpreted per row -- the
+                shape of PostgreSQL's SeqScan + ExecQual), bounded sample
+  operators     (N=1) GpuHashJoin C3, GpuPreAgg C4 at 1e9 rows / 1e4 groups,
+                scan+join+group-by in one pass: each with its own roofline
+                block and CPU baselines (1 core and all cores)
+  gpupreagg_sharded  (every N) a second barrier-bracketed region: every rank
+                folds its row range into its resident table and the tables are
+                merged by strom_gpupreagg_allreduce (RCCL over xGMI); merge
+                time reported separately, merged result checked
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -30,226 +45,384 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 C2_QUAL = "(and (int4lt (var 1 int4) (param 0 int4)) (float8gt (var 2 float8) (param 1 float8)))"
+C3_JOIN = "(gpuhashjoin (rel (hashkey (var 1 int4) 1 int4)))"
+C4_AGG = "(gpupreagg (key (var 1 int4)) (nrows) (psum (int8 (var 2 int4))) (psum (var 3 float8)))"
+CHAIN_QUAL = "(and (int4lt (var 2 int4) (param 0 int4)) (float8gt (var 3 float8) (param 1 float8)))"
+CHAIN_AGG = "(gpupreagg (qual " + CHAIN_QUAL + ") " + C4_AGG[len("(gpupreagg "):]
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+CPU_CHUNK_ROWS = 325_000       # the reference's 15 MB ROW chunk
 
 
-def make_columns(nrows, seed):
+# --------------------------------------------------------------------------- #
+# synthetic inputs
+# --------------------------------------------------------------------------- #
+def c2_columns(nrows, seed):
     rng = np.random.default_rng(seed)
-    a = rng.integers(0, 2**31, nrows, dtype=np.int64).astype(np.int32)
+    a = rng.integers(0, 2**31, nrows, dtype=np.int32)
     b = rng.random(nrows)
     return a, b
 
 
-def cpu_baseline(k, c, budget_s=12.0):
-    """time the CPU oracle on ROW-format chunks of the same distribution"""
-    sys.path.insert(0, os.path.join(ROOT, "tests"))
-    import oracle_binding as oracle
-    from pg_strom_amd import kds
-    oracle.build_oracle()
-    chunk_rows = 325_000            # the reference's 15MB ROW chunk (SURVEY.md Appendix A)
-    a, b = make_columns(chunk_rows, 0x5eed0002)
-    buf = kds.build_kds("row", [kds.Column("int4", a), kds.Column("float8", b)])
-    t0 = time.perf_counter()
-    oracle.gpuscan(C2_QUAL, buf, [k, c])
-    t1 = time.perf_counter() - t0
-    reps = int(max(1, min(400, budget_s / max(t1, 1e-6))))
-    t0 = time.perf_counter()
-    sel = 0
-    for _ in range(reps):
-        _, res = oracle.gpuscan(C2_QUAL, buf, [k, c])
-        sel += len(res)
-    dt = time.perf_counter() - t0
-    rows = reps * chunk_rows
-    return {
-        "value": rows / dt / 1e6,
-        "unit": "Mrows/s",
-        "cores": 1,
-        "kind": "port",
-        "sample": "%d x %d-row KDS_FORMAT_ROW chunks (heap pages, 185 rows/page), "
-                  "tuple-at-a-time deform + interpreted qual, %.1f s" % (reps, chunk_rows, dt),
-    }
+def c3_columns(nrows, seed, nd=1_000_000):
+    rng = np.random.default_rng(seed)
+    fk = rng.integers(0, int(nd * 1.25), nrows, dtype=np.int32)      # 80 % of the keys have a partner
+    a = rng.integers(0, 2**31, nrows, dtype=np.int32)
+    b = rng.random(nrows)
+    return fk, a, b
 
 
-def cpu_worker(k, c, seconds):
-    """one host core's share of the all-cores baseline (child process: no GPU)"""
-    sys.path.insert(0, os.path.join(ROOT, "tests"))
-    import oracle_binding as oracle
-    from pg_strom_amd import kds
-    chunk_rows = 325_000
-    a, b = make_columns(chunk_rows, 0x5eed0002)
-    buf = kds.build_kds("row", [kds.Column("int4", a), kds.Column("float8", b)])
-    oracle.gpuscan(C2_QUAL, buf, [k, c])
-    t0 = time.perf_counter()
-    reps = 0
-    while time.perf_counter() - t0 < seconds:
-        oracle.gpuscan(C2_QUAL, buf, [k, c])
-        reps += 1
-    print(json.dumps({"rows": reps * chunk_rows, "seconds": time.perf_counter() - t0}), flush=True)
+def c3_dimension(nd=1_000_000, ngroups=10_000):
+    dkey = np.random.default_rng(0x5eed0013).permutation(nd).astype(np.int32)
+    return dkey, (dkey % ngroups).astype(np.int32)
 
 
-def cpu_baseline_all_cores(k, c, seconds=8.0):
-    """chunk-parallel flavour of the same baseline: one child process per
-    host core, each scanning its own ROW chunk"""
-    import subprocess
+def c4_columns(nrows, seed, ngroups=10_000):
+    rng = np.random.default_rng(seed)
+    g = rng.integers(0, ngroups, nrows, dtype=np.int32)
+    x = rng.integers(-10**6, 10**6, nrows, dtype=np.int32)
+    y = rng.random(nrows) * 100.0
+    return g, x, y
+
+
+def host_cores():
     try:
-        ncores = len(os.sched_getaffinity(0))
+        return max(1, min(len(os.sched_getaffinity(0)), 64))
     except AttributeError:
-        ncores = os.cpu_count() or 1
-    ncores = max(1, min(ncores, 64))
+        return max(1, min(os.cpu_count() or 1, 64))
+
+
+# --------------------------------------------------------------------------- #
+# CPU baselines: the oracle timed on this host (a reported baseline, never the
+# thing shipped).  kind: scan | join | agg | chain.
+# --------------------------------------------------------------------------- #
+class CpuCase(object):
+    """one PG-shaped unit of CPU work over a KDS_FORMAT_ROW chunk; run() returns
+    the outer rows it processed"""
+
+    def __init__(self, kind, k, c):
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import oracle_binding as oracle
+        from pg_strom_amd import kds
+        self.oracle, self.kind, self.ext = oracle, kind, [k, c]
+        oracle.load()
+        n = CPU_CHUNK_ROWS
+        if kind == "scan":
+            a, b = c2_columns(n, 0x5eed0002)
+            self.buf = kds.build_kds("row", [kds.Column("int4", a), kds.Column("float8", b)])
+        elif kind == "agg":
+            g, x, y = c4_columns(n, 0x5eed0004)
+            self.buf = kds.build_kds("row", [kds.Column("int4", g), kds.Column("int4", x), kds.Column("float8", y)])
+        else:
+            # the hash table is built inside every oracle call (PostgreSQL builds it once
+            # per query): a larger outer sample per call, and the build-only time of an
+            # empty outer chunk is subtracted
+            n = 4 * CPU_CHUNK_ROWS
+            fk, a, b = c3_columns(n, 0x5eed0003)
+            self.buf = kds.build_kds("row", [kds.Column("int4", fk), kds.Column("int4", a), kds.Column("float8", b)])
+            dkey, dgrp = c3_dimension()
+            self.dim = kds.build_kds("row_flat", [kds.Column("int4", dkey), kds.Column("int4", dgrp)])
+            self.empty = kds.build_kds("row", [kds.Column("int4", fk[:0]), kds.Column("int4", a[:0]),
+                                               kds.Column("float8", b[:0])])
+            t0 = time.perf_counter()
+            oracle.gpuhashjoin(C3_JOIN, self.empty, [self.dim], nrooms=16)
+            self.build_s = time.perf_counter() - t0
+            self.dgrp = dgrp
+            self.cols = (fk, a, b)
+        self.rows = n
+
+    def run(self):
+        """returns the seconds of oracle work for self.rows outer rows"""
+        o = self.oracle
+        t0 = time.perf_counter()
+        if self.kind == "scan":
+            o.gpuscan(C2_QUAL, self.buf, self.ext)
+            return time.perf_counter() - t0
+        if self.kind == "agg":
+            o.gpupreagg(C4_AGG, self.buf, 4)
+            return time.perf_counter() - t0
+        if self.kind == "join":
+            o.gpuhashjoin(C3_JOIN, self.buf, [self.dim], nrooms=self.rows)
+            return max(1e-9, time.perf_counter() - t0 - self.build_s)
+        # chain: WHERE (scan) -> join over the selected rows -> group by the dimension column;
+        # the numpy gather that stands for PostgreSQL's projection of the joined rows is not timed
+        from pg_strom_amd import kds
+        rc, sel = o.gpuscan(CHAIN_QUAL, self.buf, self.ext)
+        rc, nitems, recs = o.gpuhashjoin(C3_JOIN, self.buf, [self.dim], row_map=np.sort(sel - 1).astype(np.int32),
+                                         nrooms=self.rows)
+        t_ops = time.perf_counter() - t0 - self.build_s
+        orow, irow = recs[:, 0] - 1, recs[:, 1]
+        joined = kds.build_kds("row", [kds.Column("int4", self.dgrp[irow]), kds.Column("int4", self.cols[1][orow]),
+                                       kds.Column("float8", self.cols[2][orow])])
+        t0 = time.perf_counter()
+        o.gpupreagg(C4_AGG, joined, 4)
+        return max(1e-9, t_ops + time.perf_counter() - t0)
+
+
+CPU_SAMPLE_TEXT = {
+    "scan": "%d-row KDS_FORMAT_ROW chunks (heap pages), tuple-at-a-time deform + interpreted qual",
+    "join": "%d-row KDS_FORMAT_ROW outer chunks probing a 1e6-row chained hash table of heap tuples "
+            "(table build time excluded)",
+    "agg": "%d-row KDS_FORMAT_ROW chunks, tuple-at-a-time deform + hash aggregate (1e4 groups)",
+    "chain": "%d-row KDS_FORMAT_ROW outer chunks: seqscan qual -> hash join (1e6-row dim) -> hash aggregate "
+             "(oracle calls only; the projection of joined rows is not timed)",
+}
+
+
+def cpu_baseline(kind, k, c, budget_s):
+    case = CpuCase(kind, k, c)
+    case.run()
+    rows, secs, reps = 0, 0.0, 0
+    while secs < budget_s:
+        secs += case.run()
+        rows += case.rows
+        reps += 1
+    return {"value": rows / secs / 1e6, "unit": "Mrows/s", "cores": 1, "kind": "port",
+            "sample": "%d x " % reps + CPU_SAMPLE_TEXT[kind] % case.rows + ", %.1f s" % secs}
+
+
+def cpu_worker(kind, k, c, seconds):
+    """one host core's share of the all-cores baseline (child process: no GPU)"""
+    case = CpuCase(kind, k, c)
+    case.run()
+    rows, secs = 0, 0.0
+    while secs < seconds:
+        secs += case.run()
+        rows += case.rows
+    print(json.dumps({"rows": rows, "seconds": secs}), flush=True)
+
+
+def cpu_baseline_all_cores(kind, k, c, seconds):
+    """chunk-parallel flavour: one child process per host core"""
+    ncores = host_cores()
     procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-worker",
-                               "%d,%r,%f" % (int(k), float(c), seconds)],
+                               "%s,%d,%r,%f" % (kind, int(k), float(c), seconds)],
                               stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True)
              for _ in range(ncores)]
     rate = 0.0
     for p in procs:
-        out, _ = p.communicate(timeout=seconds * 10 + 120)
+        out, _ = p.communicate(timeout=seconds * 20 + 300)
         for line in out.splitlines():
             if line.startswith("{"):
                 d = json.loads(line)
                 rate += d["rows"] / d["seconds"]
     return {"value": rate / 1e6, "unit": "Mrows/s", "cores": ncores, "kind": "port",
-            "sample": "%d processes x %.0f s of 325000-row KDS_FORMAT_ROW chunks" % (ncores, seconds)}
+            "sample": "%d processes x %.0f s of " % (ncores, seconds) + CPU_SAMPLE_TEXT[kind] % CPU_CHUNK_ROWS}
 
 
 def cpu_baseline_columnar(k, c, seconds=3.0):
     """best-effort columnar flavour: vectorised numpy over COLUMN arrays on
     one core -- shows the GPU/CPU ratio is not a row-format artefact"""
     n = 10_000_000
-    a, b = make_columns(n, 0x5eed0002)
+    a, b = c2_columns(n, 0x5eed0002)
     t0 = time.perf_counter()
     reps = 0
     while time.perf_counter() - t0 < seconds:
-        sel = np.flatnonzero((a < k) & (b > c)).astype(np.int32)
+        np.flatnonzero((a < k) & (b > c)).astype(np.int32)
         reps += 1
     dt = time.perf_counter() - t0
     return {"value": reps * n / dt / 1e6, "unit": "Mrows/s", "cores": 1, "kind": "port",
             "sample": "%d x %d-row column arrays, numpy (a<k)&(b>c) -> row ids, %.1f s" % (reps, n, dt)}
 
 
-def other_operator_rates(nrows):
-    """N=1 only, after the timed region: the other two operators of BASELINE.json's metric
-    ("scan+hashjoin+groupby") on a resident chunk of the same size, kernel time from the
-    runtime's events, plus the three chained on the device.  Reported next to the headline,
-    never part of `value`."""
+def roofline_block(kernel, bytes_per_launch, kern_ns, measured_peak, traffic=None):
+    mean_ns = float(np.mean(kern_ns))
+    achieved = bytes_per_launch / (mean_ns * 1e-9) / 1e9
+    blk = {"bound": "hbm", "kernel": kernel, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+           "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "bytes_per_launch": bytes_per_launch,
+           "launch_us": mean_ns * 1e-3, "launches_timed": len(kern_ns)}
+    if measured_peak:
+        blk["measured_peak"] = measured_peak
+        blk["frac_of_measured_peak"] = achieved / measured_peak
+    return blk
+
+
+# --------------------------------------------------------------------------- #
+# the other operators of the metric, N=1, outside the headline's timed region
+# --------------------------------------------------------------------------- #
+def operator_figures(args, k, c, measured_peak, with_cpu):
     from pg_strom_amd import kds, runtime
     from pg_strom_amd.gpuhashjoin import GpuHashJoin, build_multihash
     from pg_strom_amd.gpupreagg import GpuPreAgg
-    from pg_strom_amd.gpuscan import GpuScan
+    out = {}
     nd, ngroups = 1_000_000, 10_000
-    rng = np.random.default_rng(0x5eed0003)
-    fk = rng.integers(0, int(nd * 1.25), nrows, dtype=np.int64).astype(np.int32)
-    a = rng.integers(0, 2**31, nrows, dtype=np.int64).astype(np.int32)
-    b = rng.random(nrows)
+    chunk_rows = min(args.chunk_rows, 100_000_000)
+
+    def cpu_blocks(kind):
+        if not with_cpu:
+            return {}
+        return {"cpu_baseline": cpu_baseline(kind, k, c, args.cpu_seconds),
+                "cpu_baseline_all_cores": cpu_baseline_all_cores(kind, k, c, args.cpu_seconds)}
+
+    # ---- C3: 1e8 fact x 1e6 dim on an int4 key -------------------------------
+    fk, a, b = c3_columns(chunk_rows, 0x5eed0003)
     fact = runtime.DeviceStore.upload(kds.build_kds("column", [kds.Column("int4", fk), kds.Column("int4", a),
                                                                kds.Column("float8", b)]), 0)
-    dkey = rng.permutation(nd).astype(np.int32)
-    dgrp = (dkey % ngroups).astype(np.int32)
+    dkey, dgrp = c3_dimension(nd, ngroups)
     km = build_multihash([(kds.build_kds("row_flat", [kds.Column("int4", dkey), kds.Column("int4", dgrp)]), [1])])
-    out = {"rows": nrows}
-    join = GpuHashJoin("(gpuhashjoin (rel (hashkey (var 1 int4) 1 int4)))", row_population_ratio=0.8).begin(km)
-    ts = []
-    for _ in range(5):
-        r = join.join_chunk(fact, flags=1)                      # results stay on the device
+    join = GpuHashJoin(C3_JOIN, row_population_ratio=0.8).begin(km)
+    nmatch = int(np.count_nonzero(fk < nd))
+    ts, walls = [], []
+    for _ in range(6):
+        t0 = time.perf_counter()
+        r = join.join_chunk(fact, flags=1)                      # result pairs stay on the device
+        walls.append(time.perf_counter() - t0)
+        assert r.nitems == nmatch, "GpuHashJoin: %d pairs, expected %d" % (r.nitems, nmatch)
         ts.append(r.perfmon["time_kern_exec_ns"])
-    t = float(np.median(ts[1:])) * 1e-9
-    out["gpuhashjoin_c3"] = {"workload": "%d fact x %d dim on int4 key, 80%% match" % (nrows, nd),
-                             "kernel_us": t * 1e6, "mrows_s": nrows / t / 1e6,
-                             "achieved_gbs": (4.0 * nrows + 8.0 * r.nitems) / t / 1e9}
-    # C4: GROUP BY int4 (1e4 groups) count / sum / avg partials
-    g = (fk % ngroups).astype(np.int32)
-    c4 = runtime.DeviceStore.upload(kds.build_kds("column", [kds.Column("int4", g), kds.Column("int4", a),
-                                                             kds.Column("float8", b)]), 0)
-    agg = GpuPreAgg("(gpupreagg (key (var 1 int4)) (nrows) (psum (int8 (var 2 int4))) (psum (var 3 float8)))")
-    agg.begin([(0, ngroups)])
-    ts = []
-    for _ in range(5):
-        st, pfm = agg.fold(c4)
-        ts.append(pfm["time_kern_exec_ns"])
-    t = float(np.median(ts[1:])) * 1e-9
-    out["gpupreagg_c4"] = {"workload": "GROUP BY int4 (%d groups) count, sum(int4), sum(float8) over %d rows" % (ngroups, nrows),
-                           "kernel_us": t * 1e6, "mrows_s": nrows / t / 1e6, "achieved_gbs": 16.0 * nrows / t / 1e9}
-    agg.end()
-    c4.release()
-    # scan -> join -> group by, nothing leaves HBM in between
+    info = join.table_info()
+    out["gpuhashjoin_c3"] = dict(
+        workload="GpuHashJoin: %d fact x %d dim on int4 key, 80%% match (BASELINE configs[2]), index %s"
+                 % (chunk_rows, nd, info["mode"]),
+        value=chunk_rows / float(np.median(walls[1:])) / 1e6, unit="Mrows/s", results="device-resident",
+        roofline=roofline_block("gpuhashjoin_main_fast", 4.0 * chunk_rows + 8.0 * nmatch, ts[1:], measured_peak),
+        **cpu_blocks("join"))
+
+    # ---- scan + join + group-by, one pass (the metric's shape) ----------------
     ext = [np.int32(2**30), 0.0]
-    scan = GpuScan("(and (int4lt (var 2 int4) (param 0 int4)) (float8gt (var 3 float8) (param 1 float8)))").begin(ext_params=ext)
-    agg = GpuPreAgg("(gpupreagg (key (var 1 int4)) (nrows) (psum (int8 (var 2 int4))) (psum (var 3 float8)))")
-    agg.begin([(0, ngroups)])
-    walls = []
-    for _ in range(4):
-        agg.reset()
-        t0 = time.perf_counter()
-        rowmap, res = scan.scan_to_rowmap(fact)
-        joined, nitems = join.join_to_column(fact, [(1, 2, "int4"), (0, 2, "int4"), (0, 3, "float8")],
-                                             row_map=rowmap, nrooms=int(res.nitems * 0.82) + 1000)
-        agg.fold(joined)
-        pr = agg.fetch()
-        walls.append(time.perf_counter() - t0)
-        rowmap.release()
-        joined.release()
-    t = float(np.median(walls[1:]))
-    out["scan_join_groupby_chain"] = {"workload": "WHERE keeps 50%%, join 80%% match, GROUP BY dim column (%d groups), "
-                                                  "device-resident hand-overs" % ngroups,
-                                      "wall_ms": t * 1e3, "mrows_s": nrows / t / 1e6,
-                                      "joined_rows": int(nitems), "groups": len(pr)}
-    # the same query planned the reference's way: the WHERE pulled up into the join
-    # (gpuhashjoin.c:2047-2050) -- no scan pass, the one-pass join kernel
-    join2 = GpuHashJoin("(gpuhashjoin (rel (hashkey (var 1 int4) 1 int4) (qual (and (int4lt (var 2 int4) (param 0 int4))"
-                        " (float8gt (var 3 float8) (param 1 float8))))))", row_population_ratio=0.45).begin(km, ext_params=ext)
-    walls = []
-    for _ in range(4):
-        agg.reset()
-        t0 = time.perf_counter()
-        joined, nitems2 = join2.join_to_column(fact, [(1, 2, "int4"), (0, 2, "int4"), (0, 3, "float8")],
-                                               zone_maps=False)     # the aggregate brings its key domain
-        agg.fold(joined)
-        pr = agg.fetch()
-        walls.append(time.perf_counter() - t0)
-        joined.release()
-    t = float(np.median(walls[1:]))
-    out["join_with_pulled_up_qual_groupby"] = {"workload": "same query, WHERE inside the join program",
-                                               "wall_ms": t * 1e3, "mrows_s": nrows / t / 1e6,
-                                               "joined_rows": int(nitems2), "groups": len(pr)}
-    # and with the projection fused into the aggregate (strom_submit_gpupreagg_joined)
-    walls = []
-    for _ in range(4):
-        agg.reset()
-        t0 = time.perf_counter()
-        jp = join2.submit(fact, flags=1)
-        ap = agg.submit_joined(join2, jp, fact, [(1, 2, "int4"), (0, 2, "int4"), (0, 3, "float8")])
-        agg.collect(ap)
-        jr = join2.collect(jp)
-        pr = agg.fetch()
-        walls.append(time.perf_counter() - t0)
-    t = float(np.median(walls[1:]))
-    out["join_groupby_fused"] = {"workload": "same query, the aggregate reads the join's result pairs",
-                                 "wall_ms": t * 1e3, "mrows_s": nrows / t / 1e6,
-                                 "joined_rows": int(jr.nitems), "groups": len(pr)}
-    # and with no join request at all: the join is a lookup inside the aggregate's own pass
-    # over the fact chunk (strom_submit_gpupreagg_lookup), the WHERE is the aggregate's qual
-    agg3 = GpuPreAgg("(gpupreagg (qual (and (int4lt (var 2 int4) (param 0 int4)) (float8gt (var 3 float8) (param 1 float8))))"
-                     " (key (var 1 int4)) (nrows) (psum (int8 (var 2 int4))) (psum (var 3 float8)))")
-    agg3.begin([(0, ngroups)], ext_params=ext)
+    sel = (a < ext[0]) & (b > ext[1]) & (fk < nd)
+    grp = dgrp[np.argsort(dkey)]                                # dimension row of key v
+    g_sel = grp[fk[sel]]
+    cnt_ref = np.bincount(g_sel, minlength=ngroups)
+    sum_ref = np.bincount(g_sel, weights=a[sel].astype(np.float64), minlength=ngroups).astype(np.int64)
+    agg = GpuPreAgg(CHAIN_AGG).begin([(0, ngroups)], ext_params=ext)
+    cols = [(1, 2, "int4"), (0, 2, "int4"), (0, 3, "float8")]
     walls, kerns = [], []
-    for _ in range(5):
-        agg3.reset()
+    for _ in range(6):
+        agg.reset()
         t0 = time.perf_counter()
-        st, pfm = agg3.collect(agg3.submit_lookup(join2, fact, [(1, 2, "int4"), (0, 2, "int4"), (0, 3, "float8")]))
-        pr3 = agg3.fetch()
+        st, pfm = agg.collect(agg.submit_lookup(join, fact, cols))
         walls.append(time.perf_counter() - t0)
         kerns.append(pfm["time_kern_exec_ns"])
-    t = float(np.median(walls[1:]))
-    out["join_as_lookup_groupby"] = {"workload": "same query, one pass over the fact chunk: the join is a lookup "
-                                                 "inside the aggregate kernel",
-                                     "wall_ms": t * 1e3, "kernel_us": float(np.median(kerns[1:])) * 1e-3,
-                                     "mrows_s": nrows / t / 1e6, "groups": len(pr3)}
-    agg3.end()
-    join2.end()
+        assert st == 0
+    pr = agg.fetch()
+    order = np.argsort(pr.column(0)[0])
+    assert np.array_equal(pr.column(1)[0][order], cnt_ref[cnt_ref > 0]), "chain: group counts differ"
+    assert np.array_equal(pr.column(2)[0][order], sum_ref[cnt_ref > 0]), "chain: integer sums differ"
+    out["scan_join_groupby"] = dict(
+        workload="scan+hashjoin+groupby in one pass over a resident %d-row fact chunk: WHERE a<k AND b>c (50%%), "
+                 "join 1e6-row dim (80%% match), GROUP BY dim column (%d groups) COUNT/SUM/AVG; the join is a "
+                 "lookup inside the aggregate kernel (strom_submit_gpupreagg_lookup)" % (chunk_rows, ngroups),
+        value=chunk_rows / float(np.median(walls[1:])) / 1e6, unit="Mrows/s", groups=len(pr),
+        checked="counts and integer sums equal numpy's",
+        roofline=roofline_block("gpupreagg_dense_lookup(+merge)", 16.0 * chunk_rows, kerns[1:], measured_peak),
+        **cpu_blocks("chain"))
     agg.end()
-    scan.end()
     join.end()
     fact.release()
+    del fk, a, b
+
+    # ---- C4: GROUP BY int4 (1e4 groups) over args.rows rows in chunks ----------
+    chunks, cnt_ref, sx_ref = [], np.zeros(ngroups, dtype=np.int64), np.zeros(ngroups, dtype=np.int64)
+    nrows = args.rows
+    off = ci = 0
+    while off < nrows:
+        n = min(chunk_rows, nrows - off)
+        g, x, y = c4_columns(n, 0x5eed0004 + ci, ngroups)
+        cnt_ref += np.bincount(g, minlength=ngroups)
+        sx_ref += np.bincount(g, weights=x.astype(np.float64), minlength=ngroups).astype(np.int64)
+        chunks.append(runtime.DeviceStore.upload(
+            kds.build_kds("column", [kds.Column("int4", g), kds.Column("int4", x), kds.Column("float8", y)])))
+        del g, x, y
+        off += n
+        ci += 1
+    agg = GpuPreAgg(C4_AGG).begin([(0, ngroups)])
+    kerns, walls = [], []
+    for it in range(4):
+        agg.reset()
+        t0 = time.perf_counter()
+        pend = [agg.submit(ds) for ds in chunks]
+        for p in pend:
+            st, pfm = agg.collect(p)
+            assert st == 0
+            if it > 0:
+                kerns.append(pfm["time_kern_exec_ns"])
+        walls.append(time.perf_counter() - t0)
+    pr = agg.fetch()
+    order = np.argsort(pr.column(0)[0])
+    assert np.array_equal(pr.column(1)[0][order], cnt_ref), "C4: group counts differ"
+    assert np.array_equal(pr.column(2)[0][order], sx_ref), "C4: integer sums differ"
+    out["gpupreagg_c4"] = dict(
+        workload="GpuPreAgg: GROUP BY int4 (%d groups) COUNT/SUM(int4)/AVG(float8) over %d rows in %d resident "
+                 "COLUMN chunks (BASELINE configs[3], one GPU's share)" % (ngroups, nrows, len(chunks)),
+        value=nrows / float(np.median(walls[1:])) / 1e6, unit="Mrows/s",
+        checked="counts and integer sums equal numpy's",
+        roofline=roofline_block("gpupreagg_dense_column(+merge)", 16.0 * nrows / len(chunks), kerns, measured_peak),
+        **cpu_blocks("agg"))
+    agg.end()
+    for ds in chunks:
+        ds.release()
     return out
+
+
+# --------------------------------------------------------------------------- #
+# every N: row-range sharded GpuPreAgg with the RCCL merge inside the C library
+# --------------------------------------------------------------------------- #
+def sharded_gpupreagg(args, rank, world, local_rank, barrier, dist, torch):
+    from pg_strom_amd import kds, runtime, parallel
+    from pg_strom_amd.gpupreagg import GpuPreAgg
+    ngroups = 10_000
+    nrows = args.agg_rows
+    chunk_rows = min(args.chunk_rows, 100_000_000)
+    chunks, cnt_ref, sx_ref = [], np.zeros(ngroups, dtype=np.int64), np.zeros(ngroups, dtype=np.int64)
+    off = ci = 0
+    while off < nrows:
+        n = min(chunk_rows, nrows - off)
+        g, x, y = c4_columns(n, 0x5eed0400 + 1000 * rank + ci, ngroups)
+        cnt_ref += np.bincount(g, minlength=ngroups)
+        sx_ref += np.bincount(g, weights=x.astype(np.float64), minlength=ngroups).astype(np.int64)
+        chunks.append(runtime.DeviceStore.upload(
+            kds.build_kds("column", [kds.Column("int4", g), kds.Column("int4", x), kds.Column("float8", y)])))
+        del g, x, y
+        off += n
+        ci += 1
+    comm = parallel.RcclComm(rank, world, dindex=0)
+    agg = GpuPreAgg(C4_AGG).begin([(0, ngroups)])
+    agg.program.wait()
+    merge_s = []
+
+    def one_step(record):
+        agg.reset()
+        pend = [agg.submit(ds) for ds in chunks]
+        for p in pend:
+            st, _ = agg.collect(p)
+            assert st == 0
+        t0 = time.perf_counter()
+        agg.allreduce_rccl(comm)
+        if record:
+            merge_s.append(time.perf_counter() - t0)
+
+    steps = max(2, min(args.steps, 10))
+    one_step(False)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        one_step(True)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    tot_cnt, tot_sx = cnt_ref, sx_ref
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        tc, ts = torch.from_numpy(cnt_ref).cuda(), torch.from_numpy(sx_ref).cuda()
+        dist.all_reduce(tc)
+        dist.all_reduce(ts)
+        tot_cnt, tot_sx = tc.cpu().numpy(), ts.cpu().numpy()
+    # every rank now holds the whole table: integers exact
+    pr = agg.fetch()
+    order = np.argsort(pr.column(0)[0])
+    assert np.array_equal(pr.column(1)[0][order], tot_cnt), "merged group counts differ"
+    assert np.array_equal(pr.column(2)[0][order], tot_sx), "merged integer sums differ"
+    agg.end()
+    comm.destroy()
+    for ds in chunks:
+        ds.release()
+    per_step = elapsed / steps
+    return {"workload": "GpuPreAgg C4 sharded by row range: %d rows per GPU x %d GPUs, GROUP BY int4 (%d groups), "
+                        "per-GPU tables merged by strom_gpupreagg_allreduce (RCCL, %d ranks)"
+                        % (nrows, world, ngroups, world),
+            "value": world * nrows / per_step / 1e6, "unit": "Mrows/s", "n_gpus": world, "steps": steps,
+            "ms_per_step": per_step * 1e3, "merge_ms": float(np.mean(merge_s)) * 1e3, "scaling": "weak",
+            "checked": "merged counts and integer sums equal numpy's over all ranks' rows"}
 
 
 def load_traffic(chunk_rows):
@@ -264,24 +437,58 @@ def load_traffic(chunk_rows):
     return None
 
 
+def spawn_ranks(args):
+    """`--gpus N` outside torch.distributed.run: start the N ranks here.  This
+    process has not touched the GPU (counting devices does not initialise it)
+    and never will; every rank is a fresh child."""
+    import torch
+    have = torch.cuda.device_count()
+    if have < args.gpus:
+        print("bench.py: --gpus %d asked for, %d GPU(s) visible" % (args.gpus, have), file=sys.stderr)
+        sys.exit(2)
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus),
+                   LOCAL_WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
+    out, _ = procs[0].communicate()
+    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    sys.stdout.write(out)
+    sys.stdout.flush()
+    sys.exit(0 if all(rc == 0 for rc in rcs) else 1)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--rows", type=int, default=100_000_000, help="rows per GPU")
+    ap.add_argument("--rows", type=int, default=1_000_000_000, help="rows per GPU (north star: 1e9)")
     ap.add_argument("--chunk-rows", type=int, default=100_000_000)
+    ap.add_argument("--agg-rows", type=int, default=200_000_000,
+                    help="rows per GPU of the sharded GpuPreAgg region (second timed region)")
     ap.add_argument("--window", type=int, default=2,
                     help="requests kept in flight (pg_strom.max_async_chunks)")
     ap.add_argument("--selectivity", type=float, default=0.10)
+    ap.add_argument("--cpu-seconds", type=float, default=5.0, help="budget of each CPU baseline leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the GpuHashJoin / GpuPreAgg / chain figures reported next to the headline")
+    ap.add_argument("--no-sharded", action="store_true", help="skip the sharded GpuPreAgg + RCCL merge region")
     ap.add_argument("--cpu-worker", default=None, help=argparse.SUPPRESS)
     args = ap.parse_args()
     if args.cpu_worker:
-        kk, cc, secs = args.cpu_worker.split(",")
-        cpu_worker(np.int32(int(kk)), float(cc), float(secs))
+        kind, kk, cc, secs = args.cpu_worker.split(",")
+        cpu_worker(kind, np.int32(int(kk)), float(cc), float(secs))
+        return
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        spawn_ranks(args)
         return
 
     import torch
@@ -290,6 +497,9 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != max(1, args.gpus):
+        print("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world), file=sys.stderr)
+        sys.exit(2)
     if not torch.cuda.is_available():
         print("bench.py needs a GPU (the product has no CPU path)", file=sys.stderr)
         sys.exit(2)
@@ -299,13 +509,12 @@ def main():
     ngpus = world
 
     from pg_strom_amd import kds, runtime
-    from pg_strom_amd._lib import lib, strom_perfmon
+    from pg_strom_amd._lib import lib
     from pg_strom_amd.gpuscan import GpuScan, STROM_RESULTS_ON_DEVICE
     import ctypes
 
     runtime.init([local_rank])
-    # selectivity s = s1 * s2 with s1 = sqrt-ish split: a<k passes 50%, b>c the rest
-    s1 = 0.5
+    s1 = 0.5                                    # a<k passes 50 %, b>c the rest
     s2 = args.selectivity / s1
     k = np.int32(int(2**31 * s1))
     c = float(1.0 - s2)
@@ -313,12 +522,10 @@ def main():
     # resident table: row range [rank*rows, (rank+1)*rows) in COLUMN chunks
     nrows = args.rows
     chunks = []
-    nsel_expect = 0
-    off = 0
-    ci = 0
+    nsel_expect = off = ci = 0
     while off < nrows:
         n = min(args.chunk_rows, nrows - off)
-        a, b = make_columns(n, 0x5eed0002 + 1000 * rank + ci)
+        a, b = c2_columns(n, 0x5eed0002 + 1000 * rank + ci)
         nsel_expect += int(np.count_nonzero((a < k) & (b > c)))
         buf = kds.build_kds("column", [kds.Column("int4", a), kds.Column("float8", b)])
         chunks.append(runtime.DeviceStore.upload(buf, 0))
@@ -376,15 +583,31 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    # the box's own streaming-read rate: the "measured peak" denominator
+    measured_peak = None
+    gbs = ctypes.c_double(0.0)
+    if lib.strom_membw_probe(0, 1_200_000_000, 10, ctypes.byref(gbs)) == 0 and gbs.value > 0:
+        measured_peak = gbs.value
+
+    scan.end()
+    for ds in chunks:
+        ds.release()
+    nchunks = len(chunks)
+    del chunks
+
+    sharded = None
+    if not args.no_sharded:
+        sharded = sharded_gpupreagg(args, rank, world, local_rank, barrier, dist, torch)
+
     if rank == 0:
         per_step = elapsed / args.steps
         value = ngpus * nrows / per_step / 1e6
         # dominant kernel: gpuscan_qual_column, one launch per chunk
-        launches = len(kern_ns)
-        mean_ns = float(np.mean(kern_ns))
-        rows_per_launch = nrows / len(chunks)
+        rows_per_launch = nrows / nchunks
         alg_bytes = 12.0 * rows_per_launch + 4.0 * float(np.mean(nitems_seen))
-        achieved = alg_bytes / (mean_ns * 1e-9) / 1e9
+        roof = roofline_block("gpuscan_qual_column", alg_bytes, kern_ns, measured_peak,
+                              traffic=load_traffic(args.chunk_rows))
+        roof["traffic_source"] = "profiles/gpuscan_traffic.json (committed rocprofv3 --pmc passes of this command)"
         out = {
             "metric": "GpuScan Mrows/s (WHERE a<k AND b>c over int4,float8 COLUMN chunks), "
                       "achieved HBM GB/s vs peak",
@@ -400,45 +623,37 @@ def main():
             "dtype": "int32+f64",
             "data": "synthetic",
             "config": {
-                "workload": "GpuScan: %d-row int4+float8 kern_data_store per GPU, "
-                            "WHERE a<k AND b>c (BASELINE configs[1])" % nrows,
+                "workload": "GpuScan over a %d-row int4+float8 table per GPU in %d KDS_FORMAT_COLUMN chunks, "
+                            "WHERE a<k AND b>c (BASELINE metric's 1e9-row synth; configs[1] x %d chunks)"
+                            % (nrows, nchunks, nchunks),
                 "rows_per_gpu": nrows,
                 "chunk_rows": args.chunk_rows,
-                "chunks_per_gpu": len(chunks),
+                "chunks_per_gpu": nchunks,
                 "requests_in_flight": args.window,
                 "selectivity": nsel_expect / nrows,
                 "format": "KDS_FORMAT_COLUMN",
+                "results": "device-resident",
                 "parallelism": "row-range x%d" % ngpus,
             },
-            "roofline": {
-                "bound": "hbm",
-                "kernel": "gpuscan_qual_column",
-                "achieved": achieved,
-                "peak": HBM_PEAK_GBS,
-                "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS,
-                "traffic": load_traffic(args.chunk_rows),
-                "bytes_per_launch": alg_bytes,
-                "launch_us": mean_ns * 1e-3,
-                "launches_timed": launches,
-            },
+            "roofline": roof,
             "whole_job_gbs": 12.0 * ngpus * nrows / per_step / 1e9,
         }
-        if ngpus == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(k, c)
-            out["cpu_baseline_all_cores"] = cpu_baseline_all_cores(k, c)
+        with_cpu = (ngpus == 1 and not args.no_cpu_baseline)
+        if with_cpu:
+            out["cpu_baseline"] = cpu_baseline("scan", k, c, 2 * args.cpu_seconds)
+            out["cpu_baseline_all_cores"] = cpu_baseline_all_cores("scan", k, c, args.cpu_seconds)
             out["cpu_baseline_columnar"] = cpu_baseline_columnar(k, c)
-        if ngpus == 1 and not args.no_extras and not args.no_cpu_baseline:
+        if sharded is not None:
+            out["gpupreagg_sharded"] = sharded
+        if ngpus == 1 and not args.no_extras:
             try:
-                out["other_operators"] = other_operator_rates(min(nrows, 100_000_000))
+                out["operators"] = operator_figures(args, k, c, measured_peak, with_cpu)
             except Exception as e:                  # never at the expense of the headline line
-                out["other_operators"] = {"error": "%s: %s" % (type(e).__name__, e)}
+                out["operators"] = {"error": "%s: %s" % (type(e).__name__, e)}
         print(json.dumps(out), flush=True)
 
-    scan.end()
-    for ds in chunks:
-        ds.release()
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
 
 

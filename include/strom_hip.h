@@ -153,6 +153,19 @@ strom_dstore *strom_dstore_to_column(strom_dstore *src, const int32_t *type_oids
 /* ------------------------------------------------------------------ *
  * requests
  * ------------------------------------------------------------------ */
+/*
+ * Completion protocol (pgstrom_message, pg_strom.h:238-248; mqueue.c:140-183,
+ * 533-554).  'done', when not NULL, is invoked exactly once per accepted
+ * request, always on a runtime thread (never on the submitter's stack, also
+ * when the request fails before any device work), after errcode, perfmon and
+ * the host result image (kern_resultbuf / kds_dest) are final -- the
+ * reference's clserv_respond_*() + pgstrom_reply_message().  The returned
+ * handle is the message reference the backend keeps: it stays valid until
+ * strom_task_wait() / strom_task_release() (pgstrom_put_message()), with or
+ * without a callback, so results left in HBM can be chained after the
+ * callback fired.  strom_task_wait() may be called from inside done().
+ * A submit call that returns NULL (with *p_errcode set) never calls done.
+ */
 typedef void (*strom_done_cb)(void *arg, int errcode, const strom_perfmon *pfm);
 typedef struct strom_task strom_task;
 
@@ -169,8 +182,8 @@ typedef struct strom_task strom_task;
  *      into the same host memory before done() runs.
  * Exactly one of kds (host chunk, uploaded for this request) or kds_dev
  * (resident chunk) is non-NULL.  Returns NULL and sets *p_errcode when the
- * request cannot be queued.  'done' may be NULL; the task must then be
- * collected with strom_task_wait().
+ * request cannot be queued.  'done' may be NULL; either way the handle is
+ * given back with strom_task_wait() / strom_task_release().
  */
 strom_task *strom_submit_gpuscan(strom_devprog_key key,
 								 kern_gpuscan *kgpuscan,
@@ -401,6 +414,10 @@ strom_task *strom_submit_gpupreagg_joined(strom_gpupreagg *sess, strom_task *joi
  * outer columns is the aggregate program's (qual ...).  Same requirements on
  * the table (one relation, DIRECT index, unique keys, key = a plain outer
  * column of int4 / int8 / date width); anything else answers BadRequest.
+ * The JOIN program's own qual and parameters are NOT evaluated on this path
+ * (only the aggregate program runs): a table whose program carries a
+ * pulled-up outer qual or a join qual is refused with BadRequest -- put the
+ * WHERE into the aggregate program, or go through _joined / the plain join.
  */
 strom_task *strom_submit_gpupreagg_lookup(strom_gpupreagg *sess,
 										  strom_hashjoin_table *tbl, strom_dstore *outer,
@@ -437,8 +454,50 @@ strom_task *strom_submit_gpuhashjoin_mapped(strom_hashjoin_table *table, kern_ha
 strom_task *strom_submit_gpupreagg_mapped(strom_gpupreagg *sess, strom_dstore *kds_dev, strom_rowmap *rowmap,
 										  strom_done_cb done, void *arg, int *p_errcode);
 
+/* ------------------------------------------------------------------ *
+ * multi-GPU: merge of the per-GPU GpuPreAgg tables over RCCL (xGMI)
+ *
+ * The reference has no collective (SURVEY.md section 2.3 / section 5
+ * "Distributed communication backend: none"): one backend's Agg node adds up
+ * the partial rows of every chunk (gpupreagg.c:4430-4773, pg_strom--1.0.sql:
+ * 247-401).  With one process per GPU that addition happens between the
+ * GPUs: sessions created with the SAME program, targets and key domain have
+ * tables of identical layout, and strom_gpupreagg_allreduce() adds them up in
+ * place -- SUM on int64 (nrows, integer and numeric psum: exact), SUM on
+ * double (float psum: tolerance = summation order), MIN / MAX for pmin /
+ * pmax, OR for the has-value flags -- one collective per table section,
+ * grouped into one RCCL launch.  Afterwards every rank's
+ * strom_gpupreagg_fetch() returns the partial rows of the WHOLE table.
+ * 'comm' is an ncclComm_t (from the host's own RCCL, or from
+ * strom_rccl_comm_init_rank below); 'stream' a hipStream_t or NULL = the
+ * session's own stream.  Both calls return when the merge is done.
+ * strom_gpupreagg_census_allreduce() is the planning-time twin: the union of
+ * the ranks' census bitmaps, to be followed by strom_gpupreagg_compact(sess,
+ * NULL, 0) on every rank.
+ * RCCL is loaded on first use (librccl.so.1); no RCCL type crosses the ABI.
+ * ------------------------------------------------------------------ */
+int			strom_gpupreagg_allreduce(strom_gpupreagg *sess, void *comm, void *stream);
+int			strom_gpupreagg_census_allreduce(strom_gpupreagg *sess, void *comm, void *stream);
+/* communicator bootstrap for a host without its own: rank 0 makes the id
+ * (strom_rccl_unique_id_bytes() bytes), hands it to the others by whatever
+ * channel the host has, every rank calls comm_init_rank with its device */
+size_t		strom_rccl_unique_id_bytes(void);
+int			strom_rccl_get_unique_id(void *id_out, size_t len);
+int			strom_rccl_comm_init_rank(void **p_comm, int nranks, const void *id, size_t len,
+									  int rank, int dindex);
+int			strom_rccl_comm_destroy(void *comm);
+
+/*
+ * Achievable HBM read rate of this box: a read-only streaming kernel over
+ * 'nbytes' of device memory, best of 'nreps' launches, in GB/s (SURVEY.md
+ * section 8d asks for the measured denominator next to the nominal 8 TB/s).
+ */
+int			strom_membw_probe(int dindex, size_t nbytes, int nreps, double *p_gbs);
+
 /* block until the request finished; returns its errcode.  Frees the task. */
 int			strom_task_wait(strom_task *task, strom_perfmon *pfm_out);
+/* the same without the answer: pgstrom_put_message (mqueue.c:533-554) */
+void		strom_task_release(strom_task *task);
 /* device address of the kern_gpuscan / kern_hashjoin image of a task that
  * asked for STROM_RESULTS_ON_DEVICE (valid until strom_task_wait) */
 void	   *strom_task_devptr(strom_task *task);

@@ -1755,6 +1755,8 @@ oracle_gpupreagg(const char *spec_text,
 	int			nkeys = 0, naggs = 0, key_of[64], agg_of[64];
 	preagg_group *groups = NULL;
 	uint32_t	ngroups = 0, cap = 0, i, nrows;
+	uint32_t   *hidx = NULL, hcap = 0, gcap = 0;	/* hash index: slot -> group number */
+	uint64_t   *hval = NULL, *ghash = NULL;
 	int			t, use_map = (krowmap && krowmap->nvalids >= 0);
 	int32_t		status = StromError_Success;
 
@@ -1878,14 +1880,59 @@ oracle_gpupreagg(const char *spec_text,
 			set_error(&status, errcode);
 			break;
 		}
-		/* find or create the group (linear search: fixtures have few groups) */
-		for (g = 0; g < ngroups; g++)
+		/* find or create the group: a hash index over the groups made so far
+		 * (what PostgreSQL's hash aggregate does); groups keep creation order */
 		{
-			int same = 1;
-			for (k = 0; k < nkeys && same; k++)
-				same = (groups[g].keynull[k] == kn[k] && (kn[k] || groups[g].keyval[k] == kv[k]));
-			if (same)
-				break;
+			uint64_t	h = 0x9e3779b97f4a7c15ULL;
+			uint32_t	slot;
+			for (k = 0; k < nkeys; k++)
+			{
+				h ^= (kn[k] ? 0x1234567ULL : (uint64_t)kv[k]) + 0x9e3779b97f4a7c15ULL + (h << 6) + (h >> 2);
+				h *= 0xff51afd7ed558ccdULL;
+				h ^= h >> 33;
+			}
+			if ((ngroups + 1) * 2 > hcap)
+			{
+				uint32_t	j;
+				hcap = hcap ? hcap * 4 : 256;
+				free(hidx);
+				free(hval);
+				hidx = malloc(sizeof(uint32_t) * hcap);
+				hval = malloc(sizeof(uint64_t) * hcap);
+				memset(hidx, 0xff, sizeof(uint32_t) * hcap);
+				for (j = 0; j < ngroups; j++)
+				{
+					for (slot = (uint32_t)(ghash[j] & (hcap - 1)); hidx[slot] != 0xffffffffu;
+						 slot = (slot + 1) & (hcap - 1))
+						;
+					hidx[slot] = j;
+					hval[slot] = ghash[j];
+				}
+			}
+			g = ngroups;
+			for (slot = (uint32_t)(h & (hcap - 1)); hidx[slot] != 0xffffffffu; slot = (slot + 1) & (hcap - 1))
+			{
+				uint32_t	cand = hidx[slot];
+				int			same = (hval[slot] == h);
+				for (k = 0; k < nkeys && same; k++)
+					same = (groups[cand].keynull[k] == kn[k] && (kn[k] || groups[cand].keyval[k] == kv[k]));
+				if (same)
+				{
+					g = cand;
+					break;
+				}
+			}
+			if (g == ngroups)
+			{
+				hidx[slot] = g;
+				hval[slot] = h;
+				if (ngroups == gcap)
+				{
+					gcap = gcap ? gcap * 2 : 64;
+					ghash = realloc(ghash, sizeof(uint64_t) * gcap);
+				}
+				ghash[g] = h;
+			}
 		}
 		if (g == ngroups)
 		{
@@ -1979,6 +2026,9 @@ oracle_gpupreagg(const char *spec_text,
 		free(groups[i].acc);
 	}
 	free(groups);
+	free(hidx);
+	free(hval);
+	free(ghash);
 	preagg_spec_free(&sp);
 	return status;
 }

@@ -178,7 +178,15 @@ PROTOTYPES = {
     "strom_submit_gpupreagg_mapped": (c_void_p, [c_void_p, c_void_p, c_void_p,
                                                  c_void_p, c_void_p, ctypes.POINTER(c_int)]),
     "strom_task_wait": (c_int, [c_void_p, ctypes.POINTER(strom_perfmon)]),
+    "strom_task_release": (None, [c_void_p]),
     "strom_task_devptr": (c_void_p, [c_void_p]),
+    "strom_gpupreagg_allreduce": (c_int, [c_void_p, c_void_p, c_void_p]),
+    "strom_gpupreagg_census_allreduce": (c_int, [c_void_p, c_void_p, c_void_p]),
+    "strom_rccl_unique_id_bytes": (c_size_t, []),
+    "strom_rccl_get_unique_id": (c_int, [c_void_p, c_size_t]),
+    "strom_rccl_comm_init_rank": (c_int, [ctypes.POINTER(c_void_p), c_int, c_void_p, c_size_t, c_int, c_int]),
+    "strom_rccl_comm_destroy": (c_int, [c_void_p]),
+    "strom_membw_probe": (c_int, [c_int, c_size_t, c_int, ctypes.POINTER(ctypes.c_double)]),
     "strom_synchronize": (None, []),
     # strom_codegen.h
     "strom_codegen_gpuscan": (c_int, [c_char_p, ctypes.POINTER(strom_codegen_result)]),

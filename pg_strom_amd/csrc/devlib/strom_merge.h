@@ -1,0 +1,177 @@
+/*
+ * strom_merge.h -- device side of the multi-GPU GpuPreAgg merge, plus the
+ * streaming-read probe the bench uses as its measured HBM ceiling.
+ *
+ * The reference has no collective: one backend's Agg
+ * node adds up the partial rows of all chunks (pg_strom--1.0.sql:247-401).
+ * Here every rank folds its row range into a resident table of identical
+ * dense layout -- section 0: one u32 flags word per group (bit 0 "seen",
+ * bit 1+a "aggregate a has a value"), section 1+a: one 8-byte value per group
+ * -- and the tables are merged in place by RCCL all-reduces, one per section
+ * (csrc/parallel.cpp).  RCCL knows SUM / MIN / MAX on int64 and double; the
+ * kernels below bring every section into a form those operators merge
+ * correctly and back:
+ *
+ *   op 0  nrows                SUM int64 as is
+ *   op 1  psum, integer        SUM int64, entries without a value -> 0
+ *   op 2  psum, float8         SUM double, entries without a value -> 0.0
+ *   op 3/4 pmin/pmax, integer  MIN/MAX int64, entries without a value -> identity
+ *   op 5/6 pmin/pmax, float    the table keeps floats as order-preserving
+ *                              UNSIGNED keys (strom_gpupreagg.h); flipping the
+ *                              sign bit makes signed MIN/MAX order them
+ *   flags                      bitwise OR = MAX over the bits unpacked to bytes
+ *
+ * Nothing here depends on generated code: a fixed-function program.
+ */
+#ifndef STROM_MERGE_DEVICE_H
+#define STROM_MERGE_DEVICE_H
+
+#define PREAGG_MERGE_MAXAGGS	31
+
+typedef struct {
+	cl_uint		ngroups;
+	cl_uint		naggs;
+	cl_uint		op[PREAGG_MERGE_MAXAGGS];
+	cl_uint		__pad;
+	cl_ulong	vals_off[PREAGG_MERGE_MAXAGGS];		/* byte offset of section 1+a in the table */
+} preagg_merge_spec;
+
+#define PREAGG_MERGE_SIGN	0x8000000000000000UL
+
+extern "C" __global__ void
+__launch_bounds__(256)
+preagg_merge_prepare(char *table, const preagg_merge_spec *spec, cl_uchar *bits)
+{
+	cl_uint		ngroups = spec->ngroups;
+	cl_uint		naggs = spec->naggs;
+	cl_uint		nbits = naggs + 1;
+	const cl_uint *flags = (const cl_uint *)table;
+
+	for (cl_uint g = blockIdx.x * blockDim.x + threadIdx.x; g < ngroups; g += gridDim.x * blockDim.x)
+	{
+		cl_uint		f = flags[g];
+		for (cl_uint b = 0; b < nbits; b++)
+			bits[(size_t)b * ngroups + g] = (cl_uchar)((f >> b) & 1);
+		for (cl_uint a = 0; a < naggs; a++)
+		{
+			cl_ulong   *vals = (cl_ulong *)(table + spec->vals_off[a]);
+			bool		has = ((f >> (1 + a)) & 1) != 0;
+			cl_ulong	v = vals[g];
+			switch (spec->op[a])
+			{
+				case 0:		break;
+				case 1:
+				case 2:		if (!has) v = 0; break;
+				case 3:		if (!has) v = 0x7fffffffffffffffUL; break;
+				case 4:		if (!has) v = PREAGG_MERGE_SIGN; break;
+				case 5:		v = (has ? (v ^ PREAGG_MERGE_SIGN) : 0x7fffffffffffffffUL); break;
+				default:	v = (has ? (v ^ PREAGG_MERGE_SIGN) : PREAGG_MERGE_SIGN); break;
+			}
+			vals[g] = v;
+		}
+	}
+}
+
+extern "C" __global__ void
+__launch_bounds__(256)
+preagg_merge_finish(char *table, const preagg_merge_spec *spec, const cl_uchar *bits)
+{
+	cl_uint		ngroups = spec->ngroups;
+	cl_uint		naggs = spec->naggs;
+	cl_uint		nbits = naggs + 1;
+	cl_uint	   *flags = (cl_uint *)table;
+
+	for (cl_uint g = blockIdx.x * blockDim.x + threadIdx.x; g < ngroups; g += gridDim.x * blockDim.x)
+	{
+		cl_uint		f = 0;
+		for (cl_uint b = 0; b < nbits; b++)
+			f |= (bits[(size_t)b * ngroups + g] != 0 ? (1u << b) : 0u);
+		flags[g] = f;
+		for (cl_uint a = 0; a < naggs; a++)
+		{
+			cl_ulong   *vals = (cl_ulong *)(table + spec->vals_off[a]);
+			bool		has = ((f >> (1 + a)) & 1) != 0;
+			cl_uint		op = spec->op[a];
+			if (op >= 3)
+			{
+				/* no rank had a value: back to the table's "untouched = 0" */
+				cl_ulong v = vals[g];
+				if (!has)
+					v = 0;
+				else if (op >= 5)
+					v ^= PREAGG_MERGE_SIGN;
+				vals[g] = v;
+			}
+		}
+	}
+}
+
+/* census bitmaps (one bit per dense id, gpupreagg_census): OR over the ranks
+ * = MAX over the bits unpacked to bytes */
+extern "C" __global__ void
+__launch_bounds__(256)
+preagg_census_unpack(const cl_uint *bitmap, cl_uint nbits, cl_uchar *bytes)
+{
+	for (cl_uint i = blockIdx.x * blockDim.x + threadIdx.x; i < nbits; i += gridDim.x * blockDim.x)
+		bytes[i] = (cl_uchar)((bitmap[i >> 5] >> (i & 31)) & 1);
+}
+
+extern "C" __global__ void
+__launch_bounds__(256)
+preagg_census_pack(cl_uint *bitmap, cl_uint nbits, const cl_uchar *bytes)
+{
+	cl_uint		nwords = (nbits + 31) / 32;
+	for (cl_uint w = blockIdx.x * blockDim.x + threadIdx.x; w < nwords; w += gridDim.x * blockDim.x)
+	{
+		cl_uint		word = 0;
+		for (cl_uint b = 0; b < 32 && w * 32 + b < nbits; b++)
+			word |= (bytes[w * 32 + b] != 0 ? (1u << b) : 0u);
+		bitmap[w] = word;
+	}
+}
+
+/*
+ * Streaming-read probe ("measure the achievable peak on
+ * the box with a read-only streaming kernel and report both nominal and
+ * measured denominators").  Every work-group walks 16 KB tiles (256 threads x
+ * four 16-byte non-temporal loads, all issued before the first use), XORs
+ * what it read and writes ONE word per work-group so that the loads cannot be
+ * dropped.  nbytes is a multiple of 16.
+ */
+typedef cl_uint membw_vec_t __attribute__((ext_vector_type(4)));
+
+extern "C" __global__ void
+__launch_bounds__(256)
+membw_stream_read(const membw_vec_t *src, cl_ulong nvec, cl_uint *sink)
+{
+	cl_ulong	tile = 1024;						/* vectors per work-group and turn */
+	membw_vec_t	acc = {0, 0, 0, 0};
+
+	for (cl_ulong base = (cl_ulong)blockIdx.x * tile; base < nvec; base += (cl_ulong)gridDim.x * tile)
+	{
+		if (base + tile <= nvec)
+		{
+			membw_vec_t	v0 = __builtin_nontemporal_load(src + base + threadIdx.x);
+			membw_vec_t	v1 = __builtin_nontemporal_load(src + base + 256 + threadIdx.x);
+			membw_vec_t	v2 = __builtin_nontemporal_load(src + base + 512 + threadIdx.x);
+			membw_vec_t	v3 = __builtin_nontemporal_load(src + base + 768 + threadIdx.x);
+			acc ^= v0 ^ v1 ^ v2 ^ v3;
+		}
+		else
+		{
+			for (cl_ulong i = base + threadIdx.x; i < nvec; i += 256)
+			{
+				acc ^= __builtin_nontemporal_load(src + i);
+			}
+		}
+	}
+	cl_uint		x = acc.x ^ acc.y ^ acc.z ^ acc.w;
+	/* one store per work-group, and only when the data says so: keeps the
+	 * loads alive without a write stream */
+	for (int off = 32; off > 0; off >>= 1)
+		x ^= __shfl_xor(x, off);
+	if ((threadIdx.x & 63) == 0 && x == 0x9e3779b9u)
+		sink[blockIdx.x] = x;
+}
+
+#endif	/* STROM_MERGE_DEVICE_H */

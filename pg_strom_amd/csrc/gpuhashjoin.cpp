@@ -53,6 +53,7 @@ struct strom_hashjoin_table {
 	size_t				index_len = 0;
 	index_head			head;
 	int					ntables = 0;
+	cl_uint				rel_ncols[8] = {};	/* columns of each inner relation (host-side request validation) */
 	std::atomic<int>	refcnt{1};
 	/* inner columns by slot for the COLUMN projection (DIRECT index, unique
 	 * keys): (0-based column, attlen) -> {values, isnull}, built on first use */
@@ -79,6 +80,35 @@ strom_hashjoin_table_create(strom_devprog_key key, const kern_multihash *kmhash,
 		*p_errcode = (!dev ? StromError_ServerNotReady : StromError_BadRequestMessage);
 		return nullptr;
 	}
+	/* the image is about to be walked by kernels: every offset in it must
+	 * stay inside 'length' (a faulting kernel takes the host process down) */
+	cl_uint		rel_ncols[8] = {};
+	{
+		size_t	mh_head = offsetof(kern_multihash, htable_offset) + sizeof(cl_uint) * (size_t)kmhash->ntables;
+		bool	sane = (mh_head <= length);
+		for (cl_uint t = 0; sane && t < kmhash->ntables; t++)
+		{
+			size_t	off = kmhash->htable_offset[t];
+			if (off < mh_head || (off & 7) != 0 || off + offsetof(kern_hashtable, colmeta) > length)
+			{
+				sane = false;
+				break;
+			}
+			const kern_hashtable *kht = KERN_HASHTABLE(kmhash, t);
+			size_t	kht_head = STROM_LONGALIGN(offsetof(kern_hashtable, colmeta) +
+											   sizeof(kern_colmeta) * (size_t)kht->ncols) +
+				sizeof(cl_uint) * (size_t)kht->nslots;
+			if (kht->ncols < 1 || kht->ncols > 1600 || kht->nslots < 1 ||
+				kht_head > kht->length || off + (size_t)kht->length > length)
+				sane = false;
+			rel_ncols[t] = kht->ncols;
+		}
+		if (!sane)
+		{
+			*p_errcode = StromError_DataStoreCorruption;
+			return nullptr;
+		}
+	}
 	/* the index is built by kernels of the join's own program */
 	{
 		std::unique_lock<std::mutex> g(prog->lock);
@@ -103,6 +133,7 @@ strom_hashjoin_table_create(strom_devprog_key key, const kern_multihash *kmhash,
 	tbl->prog = prog;
 	tbl->dev = dev;
 	tbl->ntables = (int)kmhash->ntables;
+	memcpy(tbl->rel_ncols, rel_ncols, sizeof(rel_ncols));
 	tbl->kmhash_len = length;
 	hipStream_t stream = dev->streams[0];
 	auto fail = [&](int code) -> strom_hashjoin_table * {
@@ -325,7 +356,7 @@ gpuhashjoin_launch(strom_task_impl *task, hashjoin_request req)
 		return;
 	}
 	task->main_devptr = d_khj;
-	task->keep_main = (!task->detached && (req.flags & STROM_RESULTS_ON_DEVICE) != 0);
+	task->keep_main = ((req.flags & STROM_RESULTS_ON_DEVICE) != 0);
 	char	   *stage = (head_len + 64 <= PinnedPool::BLOCK ? dev->pinned.alloc() : nullptr);
 	if (stage)
 	{
@@ -517,6 +548,25 @@ submit_hashjoin_common(strom_hashjoin_table *tbl, kern_hashjoin *khashjoin,
 					   kern_data_store *kds_dest, const int32_t *src_depth, const int32_t *src_colidx,
 					   uint32_t flags, strom_done_cb done, void *arg, int *p_errcode);
 
+/*
+ * a projection mapping names (relation, column) pairs the kernels then
+ * dereference: relation 0 = the outer chunk, d = the d-th inner relation
+ */
+static bool
+projection_mapping_is_sane(const strom_hashjoin_table *tbl, cl_uint outer_ncols,
+						   int ncols, const int32_t *src_depth, const int32_t *src_colidx)
+{
+	for (int i = 0; i < ncols; i++)
+	{
+		int		d = src_depth[i], c = src_colidx[i];
+		if (d < 0 || d > tbl->ntables || c < 0)
+			return false;
+		if ((cl_uint)c >= (d == 0 ? outer_ncols : tbl->rel_ncols[d - 1]))
+			return false;
+	}
+	return true;
+}
+
 extern "C" strom_task *
 strom_submit_gpuhashjoin(strom_hashjoin_table *tbl,
 						 kern_hashjoin *khashjoin,
@@ -585,6 +635,13 @@ submit_hashjoin_common(strom_hashjoin_table *tbl, kern_hashjoin *khashjoin,
 	req.flags = flags;
 	if (kds_dest)
 	{
+		cl_uint	outer_ncols = (kds ? kds->ncols : kds_dev->head.ncols);
+		if (kds_dest->ncols < 1 || kds_dest->ncols > 1600 ||
+			!projection_mapping_is_sane(tbl, outer_ncols, (int)kds_dest->ncols, src_depth, src_colidx))
+		{
+			*p_errcode = StromError_BadRequestMessage;
+			return nullptr;
+		}
 		req.kds_dest = kds_dest;
 		req.map_depth.assign(src_depth, src_depth + kds_dest->ncols);
 		req.map_colidx.assign(src_colidx, src_colidx + kds_dest->ncols);
@@ -750,7 +807,7 @@ strom::hashjoin_table_dimrecs(strom_hashjoin_table *tbl, int n, const int *cols,
  * (0: the key is an expression) */
 int
 strom::hashjoin_table_direct_info(strom_hashjoin_table *tbl, cl_long *p_key_min, cl_uint *p_nslots,
-								  int *p_outer_key_attno, int *p_dindex)
+								  int *p_outer_key_attno, int *p_dindex, int *p_has_outer_qual)
 {
 	if (!tbl || tbl->ntables != 1 || tbl->head.rel[0].mode != 1 || !tbl->head.rel[0].unique ||
 		!strstr(tbl->prog->source.c_str(), "#define HASHJOIN_FAST_ELIGIBLE 1"))
@@ -760,6 +817,9 @@ strom::hashjoin_table_direct_info(strom_hashjoin_table *tbl, cl_long *p_key_min,
 	*p_key_min = tbl->head.rel[0].key_min;
 	*p_nslots = tbl->head.rel[0].nslots;
 	*p_dindex = tbl->dev->dindex;
+	/* a WHERE pulled up into the join program: only the join kernels evaluate it */
+	if (p_has_outer_qual)
+		*p_has_outer_qual = (strstr(tbl->prog->source.c_str(), "#define HASHJOIN_FAST_OUTER_QUAL 1") != nullptr);
 	return 0;
 }
 
@@ -784,15 +844,18 @@ strom_hashjoin_project_column(strom_task *handle, strom_hashjoin_table *tbl, str
 		*p_errcode = StromError_BadRequestMessage;
 		return nullptr;
 	}
-	{
-		std::unique_lock<std::mutex> g(task->lock);
-		task->cond.wait(g, [&]{ return task->completed; });
-	}
+	task_wait_completed(task);
 	if (!task->res_is_join || !task->keep_main || task->errcode != 0 || !task->main_devptr ||
 		outer->dindex != tbl->dev->dindex)
 	{
 		/* not a finished GpuHashJoin with STROM_RESULTS_ON_DEVICE */
 		*p_errcode = (task->errcode ? task->errcode : StromError_BadRequestMessage);
+		return nullptr;
+	}
+	if (!projection_mapping_is_sane(tbl, outer->head.ncols, ncols, src_depth, src_colidx))
+	{
+		/* the kernel indexes colmeta[] / the column directory with these */
+		*p_errcode = StromError_BadRequestMessage;
 		return nullptr;
 	}
 	Device *dev = tbl->dev;

@@ -1168,15 +1168,15 @@ submit_gpupreagg_over_join(strom_gpupreagg *sess, strom_task *join_handle, bool 
 		return nullptr;
 	}
 	if (jtask)
-	{
-		std::unique_lock<std::mutex> g(jtask->lock);
-		jtask->cond.wait(g, [&]{ return jtask->completed; });
-	}
+		task_wait_completed(jtask);
 	cl_long	key_min = 0;
 	cl_uint	nslots = 0;
-	int		key_attno = 0, tbl_dindex = -1;
+	int		key_attno = 0, tbl_dindex = -1, has_outer_qual = 0;
 	if ((jtask && (!jtask->res_is_join || !jtask->keep_main || jtask->errcode != 0 || !jtask->main_devptr)) ||
-		hashjoin_table_direct_info(tbl, &key_min, &nslots, &key_attno, &tbl_dindex) != 0 ||
+		hashjoin_table_direct_info(tbl, &key_min, &nslots, &key_attno, &tbl_dindex, &has_outer_qual) != 0 ||
+		/* lookup mode runs the aggregate program only: a WHERE that lives in the
+		 * join program would silently not be applied */
+		(lookup && has_outer_qual) ||
 		key_attno < 1 || outer->head.format != KDS_FORMAT_COLUMN ||
 		outer->dindex != sess->dev->dindex || tbl_dindex != sess->dev->dindex)
 	{
@@ -1225,8 +1225,8 @@ submit_gpupreagg_over_join(strom_gpupreagg *sess, strom_task *join_handle, bool 
 				return nullptr;
 			}
 		}
-		else if (src_depth[i] == 1)
-			;						/* packed slot records, below */
+		else if (src_depth[i] == 1 && src_colidx[i] >= 0)
+			;						/* packed slot records, below (the build kernel checks the column) */
 		else
 		{
 			*p_errcode = StromError_BadRequestMessage;
@@ -1485,6 +1485,59 @@ strom_gpupreagg_compact(strom_gpupreagg *sess, const uint32_t *bitmap, size_t nw
 	if (rc == 0)
 		rc = alloc_session_buffers(sess);
 	return rc;
+}
+
+/* what parallel.cpp needs to all-reduce the resident table in place */
+int
+strom::gpupreagg_get_merge_plan(strom_gpupreagg *sess, gpupreagg_merge_plan *plan)
+{
+	if (!sess || sess->hashed || !sess->has_domain || !sess->table || sess->agg_resno.size() > 31)
+		return StromError_BadRequestMessage;
+	memset(&plan->spec, 0, sizeof(plan->spec));
+	plan->spec.ngroups = sess->ctl.ngroups;
+	plan->spec.naggs = (cl_uint)sess->agg_resno.size();
+	for (size_t a = 0; a < sess->agg_resno.size(); a++)
+	{
+		const strom_preagg_target &t = sess->targets[sess->agg_resno[a]];
+		bool	isfloat = type_is_float(t.type_oid);
+		cl_uint	op;
+		switch (t.kind)
+		{
+			case STROM_PREAGG_NROWS:	op = 0; break;
+			case STROM_PREAGG_PSUM:		op = (isfloat ? 2 : 1); break;
+			case STROM_PREAGG_PMIN:		op = (isfloat ? 5 : 3); break;
+			case STROM_PREAGG_PMAX:		op = (isfloat ? 6 : 4); break;
+			default:					return StromError_BadRequestMessage;
+		}
+		plan->spec.op[a] = op;
+		plan->spec.vals_off[a] = sess->table_offset(1 + (int)a, sess->ctl.ngroups);
+	}
+	plan->table = sess->table;
+	plan->dindex = sess->dev->dindex;
+	return 0;
+}
+
+int
+strom::gpupreagg_get_census(strom_gpupreagg *sess, void **p_bitmap, cl_uint *p_nbits, int *p_dindex)
+{
+	if (!sess || sess->hashed || !sess->has_domain || sess->ctl.remap != 0)
+		return StromError_BadRequestMessage;
+	if (!sess->d_census)
+	{
+		/* a rank without rows still takes part in the union */
+		size_t	words = ((size_t)sess->ctl.dense_ngroups + 31) / 32;
+		std::lock_guard<std::mutex> g(sess->lock);
+		(void)hipSetDevice(sess->dev->hip_id);
+		sess->d_census = (char *)sess->dev->pool.alloc(words * sizeof(cl_uint));
+		if (!sess->d_census)
+			return StromError_OutOfMemory;
+		if (hipMemset(sess->d_census, 0, words * sizeof(cl_uint)) != hipSuccess)
+			return StromError_HipInternal;
+	}
+	*p_bitmap = sess->d_census;
+	*p_nbits = sess->ctl.dense_ngroups;
+	*p_dindex = sess->dev->dindex;
+	return 0;
 }
 
 extern "C" void

@@ -88,7 +88,7 @@ gpuscan_launch(strom_task_impl *task, Program *prog, gpuscan_request req)
 		return;
 	}
 	task->main_devptr = d_kgs;
-	task->keep_main = (!task->detached && (req.flags & STROM_RESULTS_ON_DEVICE) != 0);
+	task->keep_main = ((req.flags & STROM_RESULTS_ON_DEVICE) != 0);
 
 	/* request head goes down (and the result head comes back) through a
 	 * pinned staging block so that both copies are truly asynchronous */
@@ -364,11 +364,7 @@ strom_rowmap_from_task(strom_task *handle, int *p_errcode)
 		*p_errcode = StromError_BadRequestMessage;
 		return nullptr;
 	}
-	{
-		/* the request may still be parked behind its program build */
-		std::unique_lock<std::mutex> g(task->lock);
-		task->cond.wait(g, [&]{ return task->completed; });
-	}
+	task_wait_completed(task);
 	if (!task->res_is_scan || !task->keep_main)
 	{
 		*p_errcode = (task->errcode ? task->errcode

@@ -154,18 +154,42 @@ struct strom_task_impl : public strom_task {
 	std::mutex	lock;
 	std::condition_variable cond;
 	bool		completed = false;
-	bool		detached = false;		/* callback style: free at completion */
+	/* a request that could not be started (task_fail): the completer thread
+	 * drains its streams, skips the timing events and completes it */
+	bool		failed = false;
+	/* done() is running on the completer thread; strom_task_wait() from inside
+	 * it must not wait for 'completed' (set after done() returns) */
+	bool		cb_running = false;
+	bool		released_in_cb = false;
+	std::thread::id cb_thread;
 	std::chrono::steady_clock::time_point t_enqueue;
 };
 
 /* runtime.cpp */
+/* block until the request is over (also true inside its own done() callback) */
+void		task_wait_completed(strom_task_impl *task);
 Device	   *get_device(int dindex);
 /* gpuhashjoin.cpp, for consumers of join results (gpupreagg.cpp) */
 int			hashjoin_table_dimcol(strom_hashjoin_table *tbl, int col, int attlen, void **p_values, void **p_isnull);
 int			hashjoin_table_dimrecs(strom_hashjoin_table *tbl, int n, const int *cols, const int *attlens,
 								   unsigned *offsets, void **p_recs, unsigned *p_reclen);
 int			hashjoin_table_direct_info(strom_hashjoin_table *tbl, cl_long *p_key_min, cl_uint *p_nslots,
-									   int *p_outer_key_attno, int *p_dindex);
+									   int *p_outer_key_attno, int *p_dindex, int *p_has_outer_qual = nullptr);
+/* gpupreagg.cpp, for the RCCL merge (parallel.cpp): mirrors preagg_merge_spec of
+ * devlib/strom_merge.h */
+struct gpupreagg_merge_plan {
+	struct {
+		cl_uint		ngroups;
+		cl_uint		naggs;
+		cl_uint		op[31];
+		cl_uint		__pad;
+		cl_ulong	vals_off[31];
+	} spec;
+	char	   *table;
+	int			dindex;
+};
+int			gpupreagg_get_merge_plan(strom_gpupreagg *sess, gpupreagg_merge_plan *plan);
+int			gpupreagg_get_census(strom_gpupreagg *sess, void **p_bitmap, cl_uint *p_nbits, int *p_dindex);
 int			num_devices();
 Program	   *lookup_program(strom_devprog_key key);
 bool		perfmon_enabled();

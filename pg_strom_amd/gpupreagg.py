@@ -303,8 +303,23 @@ class GpuPreAgg(object):
         merged = parallel.allreduce_census(bitmap, group, device)
         return self.compact(merged)
 
+    def census_allreduce(self, comm):
+        """union of the ranks' census bitmaps over RCCL inside the C library
+        (strom_gpupreagg_census_allreduce); then compact() with no argument"""
+        rc = lib.strom_gpupreagg_census_allreduce(self.session, comm.handle, None)
+        if rc != 0:
+            raise runtime.StromError(rc, "strom_gpupreagg_census_allreduce")
+
+    def allreduce_rccl(self, comm):
+        """merge the per-GPU tables: strom_gpupreagg_allreduce (csrc/parallel.cpp), ordered
+        behind the folds on the session's own stream; returns when the merge is done"""
+        rc = lib.strom_gpupreagg_allreduce(self.session, comm.handle, None)
+        if rc != 0:
+            raise runtime.StromError(rc, "strom_gpupreagg_allreduce")
+
     def allreduce(self, group=None):
-        """merge the per-GPU partial tables over RCCL (pg_strom_amd.parallel)"""
+        """the same merge stated with torch.distributed collectives (pg_strom_amd.parallel):
+        the gloo rehearsal's path and the GPU cross-check of allreduce_rccl()"""
         import torch
         from . import parallel
         if getattr(self, "_table_tensor", None) is None:

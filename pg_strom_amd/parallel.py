@@ -21,6 +21,8 @@ Entries a rank never touched hold 0; for MIN/MAX they are replaced by the
 identity before the collective.  With ~1e4 groups a section is 80 KB: the
 collectives are latency bound, which is why they are few and whole-section.
 """
+import ctypes
+
 import numpy as np
 
 KIND_KEY, KIND_NROWS, KIND_PSUM, KIND_PMIN, KIND_PMAX = 1, 2, 3, 4, 5
@@ -47,8 +49,47 @@ class TableLayout(object):
         return self.flags_bytes + self.vals_bytes * a
 
 
+class RcclComm(object):
+    """an RCCL communicator owned by libstrom_hip.so (strom_rccl_comm_init_rank): what
+    strom_gpupreagg_allreduce() / _census_allreduce() merge over.  The unique id is
+    made by rank 0 and handed to the others through torch.distributed's store-backed
+    object broadcast (any channel would do: it is 128 bytes); torch is only the
+    rendezvous, the collectives themselves are issued by the C library."""
+
+    def __init__(self, rank, world, dindex=0, group=None, uid=None):
+        from ._lib import lib
+        self.lib = lib
+        self.rank, self.world = rank, world
+        nbytes = lib.strom_rccl_unique_id_bytes()
+        if uid is None:
+            import torch.distributed as dist
+            box = [None]
+            if rank == 0:
+                buf = ctypes.create_string_buffer(nbytes)
+                rc = lib.strom_rccl_get_unique_id(buf, nbytes)
+                if rc != 0:
+                    raise RuntimeError("strom_rccl_get_unique_id: %d" % rc)
+                box[0] = buf.raw
+            if world > 1:
+                dist.broadcast_object_list(box, src=0, group=group)
+            uid = box[0]
+        handle = ctypes.c_void_p()
+        rc = lib.strom_rccl_comm_init_rank(ctypes.byref(handle), world, uid, len(uid), rank, dindex)
+        if rc != 0:
+            raise RuntimeError("strom_rccl_comm_init_rank: %d" % rc)
+        self.handle = handle
+
+    def destroy(self):
+        if self.handle:
+            self.lib.strom_rccl_comm_destroy(self.handle)
+            self.handle = None
+
+
 def allreduce_table(table, layout, group=None):
-    """in-place all-reduce of a table held in a torch uint8 tensor"""
+    """in-place all-reduce of a table held in a torch uint8 tensor -- the torch
+    statement of strom_gpupreagg_allreduce() (csrc/parallel.cpp), kept for the gloo
+    rehearsal on CPU (tests/test_parallel_cpu.py) and as the check the C path is
+    compared with on the GPU"""
     import torch
     import torch.distributed as dist
     n = layout.ngroups
@@ -228,9 +269,12 @@ def merge_partial_rows(targets, parts):
             if kind == KIND_NROWS:
                 has[:] = True
         elif kind == KIND_PMIN:
-            acc = np.full(ng, np.inf if isflt else np.iinfo(np.int64).max, dtype=x.dtype)
-            np.minimum.at(acc, inv[ok], x[ok])
+            # PostgreSQL orders NaN above every number (float8_cmp_internal): the minimum
+            # of {NaN, 1.0} is 1.0, NaN only if nothing else is there -> fmin, seeded with NaN
+            acc = np.full(ng, np.nan if isflt else np.iinfo(np.int64).max, dtype=x.dtype)
+            (np.fmin if isflt else np.minimum).at(acc, inv[ok], x[ok])
         else:
+            # ... and the maximum is NaN as soon as one input is: np.maximum propagates it
             acc = np.full(ng, -np.inf if isflt else np.iinfo(np.int64).min, dtype=x.dtype)
             np.maximum.at(acc, inv[ok], x[ok])
         out_v[:, t] = np.where(has, acc.view(np.uint64), np.uint64(0))

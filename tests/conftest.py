@@ -17,6 +17,7 @@ def _build_everything():
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
     mod.build_library(verbose=False)
+    mod.build_c_tests(verbose=False)
     subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "liboracle.so"])
 
 

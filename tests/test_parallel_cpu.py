@@ -194,3 +194,28 @@ def test_two_rank_merge_of_hashed_group_by_partial_rows():
         p.join(180)
     assert all(p.exitcode == 0 for p in procs)
     assert outq.get(timeout=5) is True
+
+
+def test_merge_partial_rows_orders_nan_like_postgresql():
+    """float8 pmin/pmax across ranks: PostgreSQL sorts NaN above every number
+    (float8_cmp_internal), so min(NaN, 1.0) = 1.0, min(NaN) = NaN, max(NaN, 1.0) = NaN"""
+    from pg_strom_amd import parallel
+    targets = [(parallel.KIND_KEY, 23), (parallel.KIND_PMIN, 701), (parallel.KIND_PMAX, 701)]
+
+    def rows(keys, mins, maxs):
+        v = np.zeros((len(keys), 3), dtype=np.uint64)
+        v[:, 0] = np.array(keys, dtype=np.int64).view(np.uint64)
+        v[:, 1] = np.array(mins, dtype=np.float64).view(np.uint64)
+        v[:, 2] = np.array(maxs, dtype=np.float64).view(np.uint64)
+        return v, np.zeros((len(keys), 3), dtype=bool)
+
+    nan = float("nan")
+    a = rows([1, 2, 3], [nan, nan, 5.0], [nan, 2.0, 5.0])
+    b = rows([1, 2, 3], [1.0, nan, 7.0], [1.0, nan, 7.0])
+    v, n = parallel.merge_partial_rows(targets, [a, b])
+    order = np.argsort(v[:, 0].view(np.int64))
+    mins = v[order, 1].view(np.float64)
+    maxs = v[order, 2].view(np.float64)
+    assert not n.any()
+    assert mins[0] == 1.0 and np.isnan(mins[1]) and mins[2] == 5.0
+    assert np.isnan(maxs[0]) and np.isnan(maxs[1]) and maxs[2] == 7.0
