@@ -24,13 +24,13 @@ Next to the headline, in the same JSON line:
   cpu_baseline  the CPU oracle (oracle/, a port: tuple-at-a-time over ROW
                 format heap pages, expression tree interpreted per row -- the
                 shape of PostgreSQL's SeqScan + ExecQual), bounded sample
-  operators     (N=1) GpuHashJoin C3, GpuPreAgg C4 at 1e9 rows / 1e4 groups,
-                scan+join+group-by in one pass: each with its own roofline
-                block and CPU baselines (1 core and all cores)
-  gpupreagg_sharded  (every N) a second barrier-bracketed region: every rank
-                folds its row range into its resident table and the tables are
-                merged by strom_gpupreagg_allreduce (RCCL over xGMI); merge
-                time reported separately, merged result checked
+  gpupreagg_c4  (every N) a second barrier-bracketed region, BASELINE
+                configs[3]: every rank folds its 1e9-row range (GROUP BY int4,
+                1e4 groups) into its resident table and the tables are merged by
+                strom_gpupreagg_allreduce (RCCL over xGMI); merge time reported
+                separately, merged result checked; roofline + CPU baselines
+  operators     (N=1) GpuHashJoin C3 and scan+join+group-by in one pass: each
+                with its own roofline block and CPU baselines (1 core, all cores)
 """
 import argparse
 import json
@@ -49,6 +49,7 @@ C3_JOIN = "(gpuhashjoin (rel (hashkey (var 1 int4) 1 int4)))"
 C4_AGG = "(gpupreagg (key (var 1 int4)) (nrows) (psum (int8 (var 2 int4))) (psum (var 3 float8)))"
 CHAIN_QUAL = "(and (int4lt (var 2 int4) (param 0 int4)) (float8gt (var 3 float8) (param 1 float8)))"
 CHAIN_AGG = "(gpupreagg (qual " + CHAIN_QUAL + ") " + C4_AGG[len("(gpupreagg "):]
+CHAIN_EXT = [np.int32(2**30), 0.0]
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 CPU_CHUNK_ROWS = 325_000       # the reference's 15 MB ROW chunk
 
@@ -84,6 +85,69 @@ def c4_columns(nrows, seed, ngroups=10_000):
     return g, x, y
 
 
+# ---- the same distributions generated ON the device (torch's CUDA generator): a 1e8-row
+# chunk takes ~10 s of numpy on a host core and ~10 ms here; the chunk is assembled in HBM
+# (strom_kds_column_head + device-to-device copies) and adopted with strom_dstore_wrap.
+# Expected answers come from torch ops on the same tensors, never from this build's kernels.
+def _gen(seed):
+    import torch
+    g = torch.Generator(device="cuda")
+    g.manual_seed(int(seed))
+    return g
+
+
+def _minmax(t):
+    return (t.min().item(), t.max().item())
+
+
+def c2_chunk_device(nrows, seed, k, c):
+    import torch
+    from pg_strom_amd import runtime
+    g = _gen(seed)
+    a = torch.randint(0, 2**31, (nrows,), dtype=torch.int32, device="cuda", generator=g)
+    b = torch.rand(nrows, dtype=torch.float64, device="cuda", generator=g)
+    nsel = int(((a < int(k)) & (b > float(c))).sum().item())
+    ds = runtime.DeviceStore.from_torch_columns(["int4", "float8"], [a, b], [_minmax(a), _minmax(b)])
+    return ds, nsel
+
+
+def c3_chunk_device(nrows, seed, nd=1_000_000):
+    import torch
+    from pg_strom_amd import runtime
+    g = _gen(seed)
+    fk = torch.randint(0, int(nd * 1.25), (nrows,), dtype=torch.int32, device="cuda", generator=g)
+    a = torch.randint(0, 2**31, (nrows,), dtype=torch.int32, device="cuda", generator=g)
+    b = torch.rand(nrows, dtype=torch.float64, device="cuda", generator=g)
+    ds = runtime.DeviceStore.from_torch_columns(["int4", "int4", "float8"], [fk, a, b],
+                                                [_minmax(fk), _minmax(a), _minmax(b)])
+    return ds, (fk, a, b)
+
+
+def c4_chunk_device(nrows, seed, ngroups=10_000):
+    """returns (resident chunk, per-group counts, per-group integer sums) -- int64 tensors"""
+    import torch
+    from pg_strom_amd import runtime
+    g = _gen(seed)
+    grp = torch.randint(0, ngroups, (nrows,), dtype=torch.int32, device="cuda", generator=g)
+    x = torch.randint(-10**6, 10**6, (nrows,), dtype=torch.int32, device="cuda", generator=g)
+    y = torch.rand(nrows, dtype=torch.float64, device="cuda", generator=g) * 100.0
+    gl = grp.long()
+    cnt = torch.bincount(gl, minlength=ngroups)
+    sx = torch.zeros(ngroups, dtype=torch.int64, device="cuda").index_add_(0, gl, x.long())
+    ds = runtime.DeviceStore.from_torch_columns(["int4", "int4", "float8"], [grp, x, y],
+                                                [_minmax(grp), _minmax(x), _minmax(y)])
+    return ds, cnt, sx
+
+
+T_START = time.perf_counter()
+
+
+def log(msg):
+    """progress on stderr (stdout carries the one JSON line)"""
+    if os.environ.get("RANK", "0") == "0":
+        print("[bench %6.1fs] %s" % (time.perf_counter() - T_START, msg), file=sys.stderr, flush=True)
+
+
 def host_cores():
     try:
         return max(1, min(len(os.sched_getaffinity(0)), 64))
@@ -116,7 +180,7 @@ class CpuCase(object):
             # the hash table is built inside every oracle call (PostgreSQL builds it once
             # per query): a larger outer sample per call, and the build-only time of an
             # empty outer chunk is subtracted
-            n = 4 * CPU_CHUNK_ROWS
+            n = 8 * CPU_CHUNK_ROWS
             fk, a, b = c3_columns(n, 0x5eed0003)
             self.buf = kds.build_kds("row", [kds.Column("int4", fk), kds.Column("int4", a), kds.Column("float8", b)])
             dkey, dgrp = c3_dimension()
@@ -146,7 +210,7 @@ class CpuCase(object):
         # chain: WHERE (scan) -> join over the selected rows -> group by the dimension column;
         # the numpy gather that stands for PostgreSQL's projection of the joined rows is not timed
         from pg_strom_amd import kds
-        rc, sel = o.gpuscan(CHAIN_QUAL, self.buf, self.ext)
+        rc, sel = o.gpuscan(CHAIN_QUAL, self.buf, CHAIN_EXT)      # the GPU leg's WHERE: keeps 50 %
         rc, nitems, recs = o.gpuhashjoin(C3_JOIN, self.buf, [self.dim], row_map=np.sort(sel - 1).astype(np.int32),
                                          nrooms=self.rows)
         t_ops = time.perf_counter() - t0 - self.build_s
@@ -172,7 +236,8 @@ def cpu_baseline(kind, k, c, budget_s):
     case = CpuCase(kind, k, c)
     case.run()
     rows, secs, reps = 0, 0.0, 0
-    while secs < budget_s:
+    t_end = time.perf_counter() + budget_s          # wall-clock budget (secs is oracle time only)
+    while time.perf_counter() < t_end:
         secs += case.run()
         rows += case.rows
         reps += 1
@@ -185,7 +250,8 @@ def cpu_worker(kind, k, c, seconds):
     case = CpuCase(kind, k, c)
     case.run()
     rows, secs = 0, 0.0
-    while secs < seconds:
+    t_end = time.perf_counter() + seconds
+    while time.perf_counter() < t_end:
         secs += case.run()
         rows += case.rows
     print(json.dumps({"rows": rows, "seconds": secs}), flush=True)
@@ -206,7 +272,8 @@ def cpu_baseline_all_cores(kind, k, c, seconds):
                 d = json.loads(line)
                 rate += d["rows"] / d["seconds"]
     return {"value": rate / 1e6, "unit": "Mrows/s", "cores": ncores, "kind": "port",
-            "sample": "%d processes x %.0f s of " % (ncores, seconds) + CPU_SAMPLE_TEXT[kind] % CPU_CHUNK_ROWS}
+            "sample": "%d processes x %.0f s of " % (ncores, seconds) +
+                      CPU_SAMPLE_TEXT[kind] % (CPU_CHUNK_ROWS * (1 if kind in ("scan", "agg") else 8))}
 
 
 def cpu_baseline_columnar(k, c, seconds=3.0):
@@ -239,7 +306,7 @@ def roofline_block(kernel, bytes_per_launch, kern_ns, measured_peak, traffic=Non
 # --------------------------------------------------------------------------- #
 # the other operators of the metric, N=1, outside the headline's timed region
 # --------------------------------------------------------------------------- #
-def operator_figures(args, k, c, measured_peak, with_cpu):
+def operator_figures(args, k, c, measured_peak, cpu_blocks):
     from pg_strom_amd import kds, runtime
     from pg_strom_amd.gpuhashjoin import GpuHashJoin, build_multihash
     from pg_strom_amd.gpupreagg import GpuPreAgg
@@ -247,20 +314,13 @@ def operator_figures(args, k, c, measured_peak, with_cpu):
     nd, ngroups = 1_000_000, 10_000
     chunk_rows = min(args.chunk_rows, 100_000_000)
 
-    def cpu_blocks(kind):
-        if not with_cpu:
-            return {}
-        return {"cpu_baseline": cpu_baseline(kind, k, c, args.cpu_seconds),
-                "cpu_baseline_all_cores": cpu_baseline_all_cores(kind, k, c, args.cpu_seconds)}
-
     # ---- C3: 1e8 fact x 1e6 dim on an int4 key -------------------------------
-    fk, a, b = c3_columns(chunk_rows, 0x5eed0003)
-    fact = runtime.DeviceStore.upload(kds.build_kds("column", [kds.Column("int4", fk), kds.Column("int4", a),
-                                                               kds.Column("float8", b)]), 0)
+    import torch
+    fact, (fk, a, b) = c3_chunk_device(chunk_rows, 0x5eed0003, nd)
     dkey, dgrp = c3_dimension(nd, ngroups)
     km = build_multihash([(kds.build_kds("row_flat", [kds.Column("int4", dkey), kds.Column("int4", dgrp)]), [1])])
     join = GpuHashJoin(C3_JOIN, row_population_ratio=0.8).begin(km)
-    nmatch = int(np.count_nonzero(fk < nd))
+    nmatch = int((fk < nd).sum().item())
     ts, walls = [], []
     for _ in range(6):
         t0 = time.perf_counter()
@@ -277,12 +337,13 @@ def operator_figures(args, k, c, measured_peak, with_cpu):
         **cpu_blocks("join"))
 
     # ---- scan + join + group-by, one pass (the metric's shape) ----------------
-    ext = [np.int32(2**30), 0.0]
-    sel = (a < ext[0]) & (b > ext[1]) & (fk < nd)
-    grp = dgrp[np.argsort(dkey)]                                # dimension row of key v
-    g_sel = grp[fk[sel]]
-    cnt_ref = np.bincount(g_sel, minlength=ngroups)
-    sum_ref = np.bincount(g_sel, weights=a[sel].astype(np.float64), minlength=ngroups).astype(np.int64)
+    ext = CHAIN_EXT
+    sel = (a < int(ext[0])) & (b > float(ext[1])) & (fk < nd)
+    grp = torch.from_numpy(dgrp[np.argsort(dkey)].astype(np.int64)).cuda()     # group of dimension key v
+    g_sel = grp[fk[sel].long()]
+    cnt_ref = torch.bincount(g_sel, minlength=ngroups).cpu().numpy()
+    sum_ref = torch.zeros(ngroups, dtype=torch.int64, device="cuda").index_add_(0, g_sel, a[sel].long()).cpu().numpy()
+    del sel, g_sel, grp
     agg = GpuPreAgg(CHAIN_AGG).begin([(0, ngroups)], ext_params=ext)
     cols = [(1, 2, "int4"), (0, 2, "int4"), (0, 3, "float8")]
     walls, kerns = [], []
@@ -308,55 +369,16 @@ def operator_figures(args, k, c, measured_peak, with_cpu):
     agg.end()
     join.end()
     fact.release()
-    del fk, a, b
+    del fk, a, b, fact
+    torch.cuda.empty_cache()
 
-    # ---- C4: GROUP BY int4 (1e4 groups) over args.rows rows in chunks ----------
-    chunks, cnt_ref, sx_ref = [], np.zeros(ngroups, dtype=np.int64), np.zeros(ngroups, dtype=np.int64)
-    nrows = args.rows
-    off = ci = 0
-    while off < nrows:
-        n = min(chunk_rows, nrows - off)
-        g, x, y = c4_columns(n, 0x5eed0004 + ci, ngroups)
-        cnt_ref += np.bincount(g, minlength=ngroups)
-        sx_ref += np.bincount(g, weights=x.astype(np.float64), minlength=ngroups).astype(np.int64)
-        chunks.append(runtime.DeviceStore.upload(
-            kds.build_kds("column", [kds.Column("int4", g), kds.Column("int4", x), kds.Column("float8", y)])))
-        del g, x, y
-        off += n
-        ci += 1
-    agg = GpuPreAgg(C4_AGG).begin([(0, ngroups)])
-    kerns, walls = [], []
-    for it in range(4):
-        agg.reset()
-        t0 = time.perf_counter()
-        pend = [agg.submit(ds) for ds in chunks]
-        for p in pend:
-            st, pfm = agg.collect(p)
-            assert st == 0
-            if it > 0:
-                kerns.append(pfm["time_kern_exec_ns"])
-        walls.append(time.perf_counter() - t0)
-    pr = agg.fetch()
-    order = np.argsort(pr.column(0)[0])
-    assert np.array_equal(pr.column(1)[0][order], cnt_ref), "C4: group counts differ"
-    assert np.array_equal(pr.column(2)[0][order], sx_ref), "C4: integer sums differ"
-    out["gpupreagg_c4"] = dict(
-        workload="GpuPreAgg: GROUP BY int4 (%d groups) COUNT/SUM(int4)/AVG(float8) over %d rows in %d resident "
-                 "COLUMN chunks (BASELINE configs[3], one GPU's share)" % (ngroups, nrows, len(chunks)),
-        value=nrows / float(np.median(walls[1:])) / 1e6, unit="Mrows/s",
-        checked="counts and integer sums equal numpy's",
-        roofline=roofline_block("gpupreagg_dense_column(+merge)", 16.0 * nrows / len(chunks), kerns, measured_peak),
-        **cpu_blocks("agg"))
-    agg.end()
-    for ds in chunks:
-        ds.release()
     return out
 
 
 # --------------------------------------------------------------------------- #
 # every N: row-range sharded GpuPreAgg with the RCCL merge inside the C library
 # --------------------------------------------------------------------------- #
-def sharded_gpupreagg(args, rank, world, local_rank, barrier, dist, torch):
+def sharded_gpupreagg(args, rank, world, local_rank, barrier, dist, torch, measured_peak, cpu_blocks):
     from pg_strom_amd import kds, runtime, parallel
     from pg_strom_amd.gpupreagg import GpuPreAgg
     ngroups = 10_000
@@ -366,25 +388,26 @@ def sharded_gpupreagg(args, rank, world, local_rank, barrier, dist, torch):
     off = ci = 0
     while off < nrows:
         n = min(chunk_rows, nrows - off)
-        g, x, y = c4_columns(n, 0x5eed0400 + 1000 * rank + ci, ngroups)
-        cnt_ref += np.bincount(g, minlength=ngroups)
-        sx_ref += np.bincount(g, weights=x.astype(np.float64), minlength=ngroups).astype(np.int64)
-        chunks.append(runtime.DeviceStore.upload(
-            kds.build_kds("column", [kds.Column("int4", g), kds.Column("int4", x), kds.Column("float8", y)])))
-        del g, x, y
+        ds, cnt, sx = c4_chunk_device(n, 0x5eed0400 + 1000 * rank + ci, ngroups)
+        cnt_ref += cnt.cpu().numpy()
+        sx_ref += sx.cpu().numpy()
+        chunks.append(ds)
         off += n
         ci += 1
+    torch.cuda.empty_cache()
     comm = parallel.RcclComm(rank, world, dindex=0)
     agg = GpuPreAgg(C4_AGG).begin([(0, ngroups)])
     agg.program.wait()
-    merge_s = []
+    merge_s, kern_ns = [], []
 
     def one_step(record):
         agg.reset()
         pend = [agg.submit(ds) for ds in chunks]
         for p in pend:
-            st, _ = agg.collect(p)
+            st, pfm = agg.collect(p)
             assert st == 0
+            if record:
+                kern_ns.append(pfm["time_kern_exec_ns"])
         t0 = time.perf_counter()
         agg.allreduce_rccl(comm)
         if record:
@@ -417,12 +440,18 @@ def sharded_gpupreagg(args, rank, world, local_rank, barrier, dist, torch):
     for ds in chunks:
         ds.release()
     per_step = elapsed / steps
-    return {"workload": "GpuPreAgg C4 sharded by row range: %d rows per GPU x %d GPUs, GROUP BY int4 (%d groups), "
-                        "per-GPU tables merged by strom_gpupreagg_allreduce (RCCL, %d ranks)"
-                        % (nrows, world, ngroups, world),
-            "value": world * nrows / per_step / 1e6, "unit": "Mrows/s", "n_gpus": world, "steps": steps,
-            "ms_per_step": per_step * 1e3, "merge_ms": float(np.mean(merge_s)) * 1e3, "scaling": "weak",
-            "checked": "merged counts and integer sums equal numpy's over all ranks' rows"}
+    out = {"workload": "GpuPreAgg (BASELINE configs[3]): GROUP BY int4 (%d groups) COUNT/SUM(int4)/AVG(float8), "
+                       "%d rows per GPU in %d resident COLUMN chunks x %d GPU(s) sharded by row range, per-GPU "
+                       "tables merged by strom_gpupreagg_allreduce (RCCL, %d rank(s))"
+                       % (ngroups, nrows, len(chunks), world, world),
+           "value": world * nrows / per_step / 1e6, "unit": "Mrows/s", "n_gpus": world, "steps": steps,
+           "ms_per_step": per_step * 1e3, "merge_ms": float(np.mean(merge_s)) * 1e3, "scaling": "weak",
+           "checked": "merged counts and integer sums equal torch's over all ranks' rows"}
+    if rank == 0:
+        out["roofline"] = roofline_block("gpupreagg_dense_column(+merge)", 16.0 * nrows / len(chunks), kern_ns,
+                                         measured_peak)
+        out.update(cpu_blocks("agg"))
+    return out
 
 
 def load_traffic(chunk_rows):
@@ -471,8 +500,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--rows", type=int, default=1_000_000_000, help="rows per GPU (north star: 1e9)")
     ap.add_argument("--chunk-rows", type=int, default=100_000_000)
-    ap.add_argument("--agg-rows", type=int, default=200_000_000,
-                    help="rows per GPU of the sharded GpuPreAgg region (second timed region)")
+    ap.add_argument("--agg-rows", type=int, default=1_000_000_000,
+                    help="rows per GPU of the sharded GpuPreAgg region (second timed region; C4: 1e9)")
     ap.add_argument("--window", type=int, default=2,
                     help="requests kept in flight (pg_strom.max_async_chunks)")
     ap.add_argument("--selectivity", type=float, default=0.10)
@@ -514,6 +543,7 @@ def main():
     import ctypes
 
     runtime.init([local_rank])
+    log("generating the table on the device")
     s1 = 0.5                                    # a<k passes 50 %, b>c the rest
     s2 = args.selectivity / s1
     k = np.int32(int(2**31 * s1))
@@ -525,14 +555,14 @@ def main():
     nsel_expect = off = ci = 0
     while off < nrows:
         n = min(args.chunk_rows, nrows - off)
-        a, b = c2_columns(n, 0x5eed0002 + 1000 * rank + ci)
-        nsel_expect += int(np.count_nonzero((a < k) & (b > c)))
-        buf = kds.build_kds("column", [kds.Column("int4", a), kds.Column("float8", b)])
-        chunks.append(runtime.DeviceStore.upload(buf, 0))
-        del a, b, buf
+        ds, nsel = c2_chunk_device(n, 0x5eed0002 + 1000 * rank + ci, k, c)
+        nsel_expect += nsel
+        chunks.append(ds)
         off += n
         ci += 1
+    torch.cuda.empty_cache()
 
+    log("table resident: %d chunks; timed region" % len(chunks))
     scan = GpuScan(C2_QUAL).begin(ext_params=[k, c])
     scan.program.wait()
 
@@ -595,9 +625,19 @@ def main():
     nchunks = len(chunks)
     del chunks
 
+    with_cpu = (ngpus == 1 and not args.no_cpu_baseline)
+
+    def cpu_blocks(kind):
+        if not with_cpu:
+            return {}
+        log("cpu baselines: %s" % kind)
+        return {"cpu_baseline": cpu_baseline(kind, k, c, args.cpu_seconds),
+                "cpu_baseline_all_cores": cpu_baseline_all_cores(kind, k, c, args.cpu_seconds)}
+
     sharded = None
     if not args.no_sharded:
-        sharded = sharded_gpupreagg(args, rank, world, local_rank, barrier, dist, torch)
+        log("sharded GpuPreAgg + RCCL merge")
+        sharded = sharded_gpupreagg(args, rank, world, local_rank, barrier, dist, torch, measured_peak, cpu_blocks)
 
     if rank == 0:
         per_step = elapsed / args.steps
@@ -638,16 +678,17 @@ def main():
             "roofline": roof,
             "whole_job_gbs": 12.0 * ngpus * nrows / per_step / 1e9,
         }
-        with_cpu = (ngpus == 1 and not args.no_cpu_baseline)
         if with_cpu:
+            log("cpu baselines: scan")
             out["cpu_baseline"] = cpu_baseline("scan", k, c, 2 * args.cpu_seconds)
             out["cpu_baseline_all_cores"] = cpu_baseline_all_cores("scan", k, c, args.cpu_seconds)
             out["cpu_baseline_columnar"] = cpu_baseline_columnar(k, c)
         if sharded is not None:
-            out["gpupreagg_sharded"] = sharded
+            out["gpupreagg_c4"] = sharded
         if ngpus == 1 and not args.no_extras:
             try:
-                out["operators"] = operator_figures(args, k, c, measured_peak, with_cpu)
+                log("other operators")
+                out["operators"] = operator_figures(args, k, c, measured_peak, cpu_blocks)
             except Exception as e:                  # never at the expense of the headline line
                 out["operators"] = {"error": "%s: %s" % (type(e).__name__, e)}
         print(json.dumps(out), flush=True)

@@ -44,6 +44,21 @@ int		strom_kds_build(int format, int ncols,
 						uint32_t nrows, void *buffer, size_t buflen);
 
 /*
+ * Head only of a KDS_FORMAT_COLUMN chunk of 'nrows' rows without NULLs
+ * (init_kern_data_store, datastore.c:312-380, for a chunk whose payload is
+ * produced elsewhere): writes KDS_COLUMN_HEAD_LENGTH(ncols) bytes to 'head'
+ * (16-byte aligned; cols[i].values / isnull are not read) and returns the
+ * length of the whole chunk, 0 on bad input.  values_off[i] (if not NULL)
+ * receives the chunk offset where column i's nrows * attlen value bytes go.
+ * minmax (if not NULL) = zone map {min, max} per column: int64 for
+ * integer-like types, IEEE double bits for float4/float8.  A buffer laid out
+ * this way in device memory becomes a resident chunk with strom_dstore_wrap().
+ */
+size_t	strom_kds_column_head(int ncols, const strom_column_input *cols, uint32_t nrows,
+							  const int64_t *minmax, void *head, size_t headlen,
+							  uint32_t *values_off);
+
+/*
  * ROW / ROW_FLAT / TUPSLOT -> COLUMN on the host (the ingest step).
  * Returns required length when dst == NULL.
  */

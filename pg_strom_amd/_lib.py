@@ -205,6 +205,8 @@ PROTOTYPES = {
                                              c_uint32]),
     "strom_kds_build": (c_int, [c_int, c_int, ctypes.POINTER(strom_column_input), c_uint32,
                                 c_void_p, c_size_t]),
+    "strom_kds_column_head": (c_size_t, [c_int, ctypes.POINTER(strom_column_input), c_uint32, c_void_p,
+                                         c_void_p, c_size_t, c_void_p]),
     "strom_multihash_required_length": (c_size_t, [c_int, ctypes.POINTER(strom_hashtable_input)]),
     "strom_multihash_build": (c_int, [c_int, ctypes.POINTER(strom_hashtable_input), c_void_p,
                                       c_size_t]),

@@ -513,6 +513,49 @@ strom_kds_build(int format, int ncols, const strom_column_input *cols,
 	return StromError_BadRequestMessage;
 }
 
+/*
+ * Head only of a NULL-free COLUMN chunk: the caller fills the column arrays
+ * itself, typically on the device (values of column i start at the returned
+ * chunk offset values_off[i]), and hands the buffer to strom_dstore_wrap().
+ */
+extern "C" size_t
+strom_kds_column_head(int ncols, const strom_column_input *cols, uint32_t nrows,
+					  const int64_t *minmax, void *head, size_t headlen, uint32_t *values_off)
+{
+	if (ncols < 1 || ncols > 1600 || !cols || !head || ((uintptr_t)head & 15) != 0 ||
+		headlen < KDS_COLUMN_HEAD_LENGTH(ncols))
+		return 0;
+	for (int i = 0; i < ncols; i++)
+		if (!(cols[i].attlen == 1 || cols[i].attlen == 2 || cols[i].attlen == 4 || cols[i].attlen == 8))
+			return 0;
+	std::vector<strom_column_input> nonull(cols, cols + ncols);
+	for (auto &c : nonull)
+		c.isnull = nullptr;
+	std::vector<size_t> voff(ncols), noff(ncols);
+	size_t	required = column_layout(ncols, nonull.data(), nrows, &voff, &noff);
+	if (required > 0xffffffffUL)
+		return 0;								/* 'length' is 32 bit */
+	kern_data_store *kds = (kern_data_store *)head;
+	init_kds_head(kds, KDS_FORMAT_COLUMN, ncols, nonull.data(), nrows, 0, required);
+	kern_coldir *cd = KERN_DATA_STORE_COLDIR(kds);
+	memset(cd, 0, KDS_COLUMN_HEAD_LENGTH(ncols) - KDS_HEAD_LENGTH(ncols));
+	for (int i = 0; i < ncols; i++)
+	{
+		bool	isfloat = (cols[i].type_oid == STROM_FLOAT4OID || cols[i].type_oid == STROM_FLOAT8OID);
+		cd[i].values_off = (cl_uint)voff[i];
+		if (values_off)
+			values_off[i] = (uint32_t)voff[i];
+		if (minmax && cols[i].type_oid != 0 && nrows > 0)
+		{
+			cd[i].stat_flags = KDS_COLSTAT_MINMAX | (isfloat ? KDS_COLSTAT_ISFLOAT : 0);
+			cd[i].minval = minmax[2 * i];
+			cd[i].maxval = minmax[2 * i + 1];
+		}
+	}
+	kds->nitems = nrows;
+	return required;
+}
+
 /* ---- host-side datum fetch -------------------------------------------- */
 namespace {
 

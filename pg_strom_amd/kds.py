@@ -102,6 +102,33 @@ def build_kds(fmt, columns):
     return buf
 
 
+def column_head(sqltypes, nrows, minmax=None):
+    """head of a NULL-free KDS_FORMAT_COLUMN chunk whose column arrays are filled
+    elsewhere (strom_kds_column_head): returns (head uint8 array, chunk length,
+    values_off per column).  minmax: [(min, max)] per column -- ints, or floats for
+    float4/float8 columns -- or None for "no zone maps"."""
+    ncols = len(sqltypes)
+    arr = (strom_column_input * ncols)()
+    for i, t in enumerate(sqltypes):
+        oid, attlen, _ = SQL_TYPES[t]
+        arr[i].type_oid, arr[i].attlen, arr[i].attalign, arr[i].attbyval = oid, attlen, attlen, 1
+    mm = None
+    if minmax is not None:
+        mm = np.zeros(2 * ncols, dtype=np.int64)
+        for i, (t, (lo, hi)) in enumerate(zip(sqltypes, minmax)):
+            if SQL_TYPES[t][0] in (700, 701):
+                mm[2 * i:2 * i + 2] = np.array([lo, hi], dtype=np.float64).view(np.int64)
+            else:
+                mm[2 * i:2 * i + 2] = [int(lo), int(hi)]
+    head = aligned_buffer(4096 + 64 * ncols)
+    voff = np.zeros(ncols, dtype=np.uint32)
+    total = lib.strom_kds_column_head(ncols, arr, nrows, mm.ctypes.data if mm is not None else None,
+                                      head.ctypes.data, len(head), voff.ctypes.data)
+    if total == 0:
+        raise ValueError("strom_kds_column_head: bad column description or chunk over 4 GB")
+    return head[:int(voff[0])], int(total), [int(v) for v in voff]
+
+
 def kds_to_column(kds_buf):
     need = lib.strom_kds_to_column(kds_buf.ctypes.data, None, 0)
     if need == 0:

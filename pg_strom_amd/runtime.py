@@ -156,6 +156,26 @@ class DeviceStore(object):
     def wrap(cls, devptr, length, nitems=None, dindex=0):
         return cls(lib.strom_dstore_wrap(devptr, length, dindex), nitems)
 
+    @classmethod
+    def from_torch_columns(cls, sqltypes, tensors, minmax=None, dindex=0):
+        """a resident COLUMN chunk assembled in device memory from torch tensors that
+        already live on the GPU (one per column, NULL-free): the head comes from
+        strom_kds_column_head, the column arrays are device-to-device copies, the
+        buffer is adopted with strom_dstore_wrap (kept alive by this object)"""
+        import torch
+        from .kds import column_head
+        nrows = int(tensors[0].numel())
+        head, total, voff = column_head(sqltypes, nrows, minmax)
+        buf = torch.zeros(total, dtype=torch.uint8, device=tensors[0].device)
+        buf[:len(head)] = torch.from_numpy(head.copy()).to(buf.device)
+        for t, off in zip(tensors, voff):
+            raw = t.contiguous().view(torch.uint8).reshape(-1)
+            buf[off:off + raw.numel()] = raw
+        torch.cuda.synchronize()
+        ds = cls(lib.strom_dstore_wrap(buf.data_ptr(), total, dindex), nrows)
+        ds._keepalive = buf
+        return ds
+
     @property
     def devptr(self):
         return lib.strom_dstore_devptr(self.handle)

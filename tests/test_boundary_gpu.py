@@ -234,9 +234,20 @@ def test_rccl_merge_behind_the_abi_world_size_1():
         finally:
             agg.end()
 
+    def same(va, na, vb, nb):
+        # two folds of the same chunk: everything bit-equal except the float8 sum (column 4),
+        # whose LDS-atomic accumulation order differs from launch to launch (tolerance 1e-12)
+        assert np.array_equal(na, nb)
+        for col in range(va.shape[1]):
+            ok = ~na[:, col]
+            if col == 4:
+                assert np.allclose(va[ok, col].view(np.float64), vb[ok, col].view(np.float64), rtol=1e-12, atol=0)
+            else:
+                assert np.array_equal(va[ok, col], vb[ok, col]), col
+
     v0, n0 = partials(None)
     v1, n1 = partials("rccl")
-    assert np.array_equal(n0, n1) and np.array_equal(v0[~n0], v1[~n1])
+    same(v0, n0, v1, n1)
     if not dist.is_initialized():
         dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29541", rank=0, world_size=1,
                                 device_id=torch.device("cuda", 0))
@@ -244,7 +255,7 @@ def test_rccl_merge_behind_the_abi_world_size_1():
         v2, n2 = partials("torch")
     finally:
         dist.destroy_process_group()
-    assert np.array_equal(n0, n2) and np.array_equal(v0[~n0], v2[~n2])
+    same(v0, n0, v2, n2)
     ds.release()
 
 

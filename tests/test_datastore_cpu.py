@@ -61,3 +61,26 @@ def test_zone_map_of_a_column_chunk():
     mm = np.array([dec[1]["minval"], dec[1]["maxval"]], dtype=np.int64).view(np.float64)
     assert list(mm) == [-2.0, 7.25]
     assert dec[1]["notnull"] is None and list(dec[0]["notnull"]) == [True, True, True, False]
+
+
+def test_column_head_equals_the_head_of_a_built_chunk():
+    """strom_kds_column_head (head only, payload filled elsewhere) lays a NULL-free COLUMN
+    chunk out exactly as strom_kds_build does: same head bytes, offsets and zone maps"""
+    import numpy as np
+    from pg_strom_amd import kds
+    rng = np.random.default_rng(8)
+    n = 100003
+    a = rng.integers(-5, 1000, n).astype(np.int32)
+    b = rng.normal(size=n)
+    c = rng.integers(0, 2**40, n).astype(np.int64)
+    d = rng.integers(0, 3, n).astype(np.int8)
+    full = kds.build_kds("column", [kds.Column("int4", a), kds.Column("float8", b), kds.Column("int8", c),
+                                    kds.Column("char1", d)])
+    head, total, voff = kds.column_head(["int4", "float8", "int8", "char1"], n,
+                                        [(a.min(), a.max()), (b.min(), b.max()), (c.min(), c.max()),
+                                         (d.min(), d.max())])
+    assert total == len(full)
+    # hostptr (first 8 bytes) is the buffer's own address: not comparable
+    assert np.array_equal(head[8:], full[8:len(head)])
+    assert np.array_equal(full[voff[1]:voff[1] + 8 * n].view(np.float64), b)
+    assert np.array_equal(full[voff[3]:voff[3] + n].view(np.int8), d)
