@@ -24,12 +24,45 @@ using namespace strom;
 namespace {
 
 struct target {
+	int			pack_kind = 0;	/* packed accumulators (strom_gpupreagg.h): 1 count(*), 2 psum of a plain
+								 * integer column, 3 psum of a plain float8 column, 0 none of these */
+	int			pack_attno = 0;
 	int			kind;
 	int			type_oid;	/* type of the partial value as the caller sees it */
 	int			acc_oid;	/* type of the device accumulator */
 	int			scale;		/* numeric partials: fixed point at 10^-scale, else -1 */
 	std::string	body;		/* function body text */
 };
+
+/*
+ * (var N T), or a widening cast of one -- (int8 (var N int2|int4|int8)),
+ * (float8 (var N float4|float8)): the value is the column's, it is NULL only
+ * where the column is, and it cannot raise an error.  Returns the attno or 0.
+ */
+int
+plain_column_attno(const sexpr &e, int *p_var_oid)
+{
+	const sexpr *v = &e;
+	std::string cast;
+	if (e.is_list && e.items.size() == 2 && !e.items[0].is_list &&
+		(e.items[0].atom == "int8" || e.items[0].atom == "float8") && e.items[1].is_list)
+	{
+		cast = e.items[0].atom;
+		v = &e.items[1];
+	}
+	if (!v->is_list || v->items.size() != 3 || v->items[0].is_list || v->items[0].atom != "var" ||
+		v->items[1].is_list || v->items[2].is_list)
+		return 0;
+	const std::string &t = v->items[2].atom;
+	bool	is_int = (t == "int2" || t == "int4" || t == "int8");
+	bool	is_flt = (t == "float4" || t == "float8");
+	if ((cast == "int8" && !is_int) || (cast == "float8" && !is_flt) || (cast.empty() && !(t == "int8" || t == "float8")))
+		return 0;
+	int		attno = atoi(v->items[1].atom.c_str());
+	*p_var_oid = (t == "int2" ? STROM_INT2OID : t == "int4" ? STROM_INT4OID : t == "int8" ? STROM_INT8OID :
+				  t == "float4" ? STROM_FLOAT4OID : STROM_FLOAT8OID);
+	return attno >= 1 ? attno : 0;
+}
 
 std::string
 fn_header(const char *rettype, const char *name, int idx)
@@ -107,6 +140,8 @@ strom_codegen_gpupreagg(const char *spec, strom_codegen_result *out,
 				}
 				tg.body = "  pg_int4_t r; bool ok = true;\n" + cond +
 					"  r.isnull = false; r.value = ok ? 1 : 0; return r;\n";
+				if (nargs == 0)
+					tg.pack_kind = 1;
 			}
 			else if (head == "psum" || head == "pmin" || head == "pmax")
 			{
@@ -162,6 +197,14 @@ strom_codegen_gpupreagg(const char *spec, strom_codegen_result *out,
 					if (nargs != 1)
 						codegen_error("only numeric partials take a scale");
 					tg.body = "  return " + e + ";\n";
+					int		var_oid = 0;
+					int		attno = plain_column_attno(t.items[1], &var_oid);
+					if (tg.kind == STROM_PREAGG_PSUM && attno > 0 &&
+						(tg.type_oid == STROM_INT8OID || tg.type_oid == STROM_FLOAT8OID))
+					{
+						tg.pack_kind = (tg.type_oid == STROM_INT8OID ? 2 : 3);
+						tg.pack_attno = attno;
+					}
 				}
 			}
 			else if (head == "psum_x2")
@@ -211,6 +254,8 @@ strom_codegen_gpupreagg(const char *spec, strom_codegen_result *out,
 
 		std::string key_list = "#define GPUPREAGG_KEY_LIST(X)";
 		std::string agg_list = "#define GPUPREAGG_AGG_LIST(X)";
+		std::string pack_list = "#define GPUPREAGG_PACK_LIST(X)";
+		bool	packable = true;
 		std::string funcs;
 		int		nkeys = 0, naggs = 0;
 		char	tmp[160];
@@ -232,6 +277,9 @@ strom_codegen_gpupreagg(const char *spec, strom_codegen_result *out,
 								  tg.kind == STROM_PREAGG_PMIN ? "PMIN" : "PMAX");
 				snprintf(tmp, sizeof(tmp), " X(%d,%zu,%s,%s)", naggs, i, op, tname);
 				agg_list += tmp;
+				snprintf(tmp, sizeof(tmp), " X(%d,%d,%d)", naggs, tg.pack_kind, tg.pack_attno);
+				pack_list += tmp;
+				packable = packable && (tg.pack_kind != 0);
 				funcs += fn_header(tname, "gpupreagg_agg", naggs) + "{\n" + tg.body + "}\n";
 				naggs++;
 			}
@@ -303,6 +351,10 @@ strom_codegen_gpupreagg(const char *spec, strom_codegen_result *out,
 				 targets.size(), nkeys, naggs);
 		src += tmp;
 		src += key_list + "\n" + agg_list + "\n";
+		/* packed accumulators: X(aidx, kind, attno of the source column) -- see strom_gpupreagg.h */
+		snprintf(tmp, sizeof(tmp), "#define GPUPREAGG_PACKABLE %d\n", (packable && naggs > 0 && naggs <= 32) ? 1 : 0);
+		src += tmp;
+		src += pack_list + "\n";
 		{
 			/* wide rows: one quad per thread and tile, two would not leave
 			 * registers for the row body (a -D tunable still wins) */

@@ -478,6 +478,153 @@ gpupreagg_writeback_status(cl_int *status, cl_int chunk_status)
 		atomicMax(status, worst);
 }
 
+/* ---------------------------------------------------------------------- *
+ * packed accumulators (gpupreagg_packed_column)
+ *
+ * The standard LDS image spends 1 (flags) + 4 (nrows) + 8 per other aggregate
+ * bytes per group; BASELINE configs[3] -- GROUP BY int4 with 1e4 groups,
+ * COUNT / SUM(int4) / AVG(float8) -- needs 21 B x 1e4 = 210 KB and therefore
+ * two id-range roles that EACH visit every row (measured 400 us per 1e8 rows
+ * against 258 us for a table that fits one work-group's LDS).  Integer
+ * aggregates rarely need their full width inside ONE work-group and ONE
+ * chunk: the zone map bounds a summed column (max - min < 2^vbits) and the
+ * launch geometry bounds the rows a work-group folds (< 2^cbits), so
+ * count(*) and the integer sums fit bit fields of ONE 64-bit word
+ *
+ *     [ count : cbits ][ sum_k (x - min) : cbits + vbits_k ] ...
+ *
+ * updated by ONE ds_add_u64 per row; a float8 sum keeps a word of its own and
+ * the flags are implied (seen = count > 0; "has a value" = seen, because this
+ * path is taken only when no input column has a NULL in the chunk).  C4 is
+ * then 16 B per group -- 160 KB, one role, every row visited once.  The
+ * fields are unpacked (sum = field + count x min) when the work-group writes
+ * its slab, which has the standard shape: gpupreagg_dense_merge and the
+ * resident table do not know the difference.
+ *
+ * The host takes this path per launch (gpupreagg.cpp: packed_plan) when the
+ * generated code says every aggregate is count(*), or psum of a plain column
+ * (GPUPREAGG_PACK_LIST: kind 1 / 2 integer / 3 float8), the chunk's zone maps
+ * and NULL-free columns allow it, the fields fit 64 bits and the packed image
+ * needs fewer roles than the standard one.
+ * ---------------------------------------------------------------------- */
+#define GPUPREAGG_PACK_MAXAGGS	32
+struct gpupreagg_pack_ctl {
+	cl_uint		count_shift;					/* count field: bits count_shift .. 63 */
+	cl_uint		nwords;							/* 1 (the packed word) + float8 sums */
+	cl_uint		shift[GPUPREAGG_PACK_MAXAGGS];	/* kind 2: position of the field in word 0 */
+	cl_uint		word[GPUPREAGG_PACK_MAXAGGS];	/* kind 3: the aggregate's own word */
+	cl_ulong	mask[GPUPREAGG_PACK_MAXAGGS];	/* kind 2: field mask (after the shift) */
+	cl_ulong	vmax[GPUPREAGG_PACK_MAXAGGS];	/* kind 2: max - min of the column (zone map) */
+	cl_long		bias[GPUPREAGG_PACK_MAXAGGS];	/* kind 2: min of the column */
+};
+
+#if defined(GPUPREAGG_PACKABLE) && GPUPREAGG_PACKABLE
+STROM_DEVICE cl_uint
+gpupreagg_pack_word_offset(cl_uint w, cl_uint G)
+{
+	return w * gpupreagg_align16(8u * G);
+}
+
+STROM_DEVICE void
+gpupreagg_packed_row(char *lds, const gpupreagg_dense_ctl *ctl, const gpupreagg_pack_ctl *pk,
+					 const strom_kparams &KP, const strom_kvars &KV,
+					 cl_uint gid_lo, cl_uint G, cl_int param_error, cl_int *chunk_status)
+{
+	cl_int		errcode = param_error;
+	pg_bool_t	rc = gpupreagg_qual_eval(&errcode, KP, KV);
+	cl_uint		gid = 0;
+	bool		out_of_domain = false;
+
+	if (errcode == StromError_Success && !EVAL(rc))
+		return;
+#define X(kidx,resno,NAME)															\
+	{																				\
+		pg_##NAME##_t kv = gpupreagg_key_##kidx(&errcode, KP, KV);					\
+		cl_long		off64 = (cl_long)kv.value - ctl->key_min[kidx];					\
+		cl_uint		range = ctl->key_range[kidx];									\
+		cl_uint		off = (kv.isnull ? range : (cl_uint)off64);						\
+		if (!kv.isnull && (off64 < 0 || off64 >= (cl_long)range))					\
+			out_of_domain = true;													\
+		gid += off * ctl->key_stride[kidx];											\
+	}
+	GPUPREAGG_KEY_LIST(X)
+#undef X
+	if (errcode == StromError_Success && !out_of_domain && gid - gid_lo >= G)
+		return;							/* another role's slice of the id range */
+	if (errcode != StromError_Success)
+	{
+		STROM_SET_ERROR(chunk_status, errcode);
+		return;
+	}
+	if (out_of_domain)
+	{
+		STROM_SET_ERROR(chunk_status, StromError_DataStoreOutOfRange);
+		return;
+	}
+	cl_uint		slot = gid - gid_lo;
+	cl_ulong	addend = 1UL << pk->count_shift;
+	bool		bad = false;
+	/* a plain column of a NULL-free chunk: the value is there, the only thing
+	 * that can be wrong is a zone map that does not bound it */
+#define X(aidx,kind,attno)															\
+	if (kind == 2)																	\
+	{																				\
+		cl_ulong	f = (cl_ulong)((cl_long)gpupreagg_agg_##aidx(&errcode, KP, KV).value - pk->bias[aidx]);	\
+		bad |= (f > pk->vmax[aidx]);												\
+		addend += f << pk->shift[aidx];												\
+	}
+	GPUPREAGG_PACK_LIST(X)
+#undef X
+	if (bad)
+	{
+		STROM_SET_ERROR(chunk_status, StromError_DataStoreCorruption);
+		return;
+	}
+	__hip_atomic_fetch_add((cl_ulong *)lds + slot, addend, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#define X(aidx,kind,attno)															\
+	if (kind == 3)																	\
+		__hip_atomic_fetch_add((cl_double *)(lds + gpupreagg_pack_word_offset(pk->word[aidx], G)) + slot,	\
+							   (cl_double)gpupreagg_agg_##aidx(&errcode, KP, KV).value,	\
+							   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+	GPUPREAGG_PACK_LIST(X)
+#undef X
+}
+
+/* unpack the work-group's LDS image into a slab of the standard shape */
+STROM_DEVICE void
+gpupreagg_store_slab_packed(const char *lds, const gpupreagg_pack_ctl *pk, char *slab, cl_uint G)
+{
+	__syncthreads();
+	for (cl_uint g = threadIdx.x; g < G; g += GPUPREAGG_BLOCK)
+	{
+		cl_ulong	w0 = ((const cl_ulong *)lds)[g];
+		cl_ulong	n = w0 >> pk->count_shift;
+		cl_uint		flags = 0;
+#define X(aidx,kind,attno)																\
+		{																				\
+			char   *svals = slab + gpupreagg_image_offset(1 + aidx, G, 1);				\
+			if (kind == 1)																\
+				((cl_uint *)svals)[g] = (cl_uint)n;										\
+			else if (kind == 2)															\
+			{																			\
+				cl_ulong f = (w0 >> pk->shift[aidx]) & pk->mask[aidx];					\
+				((cl_long *)svals)[g] = (cl_long)f + (cl_long)n * pk->bias[aidx];		\
+				flags |= (2u << aidx);													\
+			}																			\
+			else																		\
+			{																			\
+				((cl_ulong *)svals)[g] =												\
+					((const cl_ulong *)(lds + gpupreagg_pack_word_offset(pk->word[aidx], G)))[g];	\
+				flags |= (2u << aidx);													\
+			}																			\
+		}
+		GPUPREAGG_PACK_LIST(X)
+#undef X
+		((gpupreagg_flags_t *)slab)[g] = (gpupreagg_flags_t)(n != 0 ? (flags | GPUPREAGG_FLAG_SEEN) : 0u);
+	}
+}
+#endif	/* GPUPREAGG_PACKABLE */
+
 struct gpupreagg_column_tile {
 #define X(attno,colidx,NAME)											\
 	pg_##NAME##_base_t	v_##attno[GPUPREAGG_QUADS][4];					\
@@ -506,12 +653,13 @@ gpupreagg_load_kparams(strom_kparams &KP, const kern_parambuf *kparams, cl_int *
 /* ====================================================================== *
  * dense-id reduction, COLUMN format
  * ====================================================================== */
-extern "C" __global__ void
-__launch_bounds__(GPUPREAGG_BLOCK)
-gpupreagg_dense_column(kern_gpupreagg *kgpreagg,
-					   const kern_data_store *kds,
-					   const gpupreagg_dense_ctl *ctl_in_memory,
-					   char *slabs)
+template <bool PACKED>
+__device__ __forceinline__ void
+gpupreagg_dense_column_body(kern_gpupreagg *kgpreagg,
+							const kern_data_store *kds,
+							const gpupreagg_dense_ctl *ctl_in_memory,
+							const gpupreagg_pack_ctl *pack_in_memory,
+							char *slabs)
 {
 	extern __shared__ __attribute__((aligned(16))) char lds[];
 	/*
@@ -555,9 +703,25 @@ gpupreagg_dense_column(kern_gpupreagg *kgpreagg,
 	gpupreagg_lds_layout L;
 
 	gpupreagg_load_kparams(KP, kparams, &param_error);
-	gpupreagg_remap_init(ctl);
-	gpupreagg_lds_layout_init(L, G, NREP);
-	gpupreagg_lds_init(lds, L, G, NREP);
+#if defined(GPUPREAGG_PACKABLE) && GPUPREAGG_PACKABLE
+	/* (by value, like the control block: its fields are read in every row body) */
+	gpupreagg_pack_ctl pack_by_value;
+	const gpupreagg_pack_ctl *pk = &pack_by_value;
+	if (PACKED)
+	{
+		pack_by_value = *pack_in_memory;
+		cl_uint	total = pk->nwords * gpupreagg_align16(8u * G);
+		for (cl_uint i = threadIdx.x * 16; i < total; i += GPUPREAGG_BLOCK * 16)
+			*(uint4 *)(lds + i) = make_uint4(0, 0, 0, 0);
+		__syncthreads();
+	}
+	else
+#endif
+	{
+		gpupreagg_remap_init(ctl);
+		gpupreagg_lds_layout_init(L, G, NREP);
+		gpupreagg_lds_init(lds, L, G, NREP);
+	}
 
 #define X(attno,colidx,NAME)													\
 	const char *col_##attno = (const char *)kds + coldir[colidx].values_off;	\
@@ -649,15 +813,48 @@ gpupreagg_dense_column(kern_gpupreagg *kgpreagg,
 					STROM_KVAR_LIST(X)
 #undef X
 					KV.__dummy = 0;
-					gpupreagg_dense_row(lds, ctl, L, KP, KV, gid_lo, G, NREP, rep,
-										param_error, &chunk_status);
+#if defined(GPUPREAGG_PACKABLE) && GPUPREAGG_PACKABLE
+					if (PACKED)
+						gpupreagg_packed_row(lds, ctl, pk, KP, KV, gid_lo, G, param_error, &chunk_status);
+					else
+#endif
+						gpupreagg_dense_row(lds, ctl, L, KP, KV, gid_lo, G, NREP, rep,
+											param_error, &chunk_status);
 				}
 			}
 		}
 	}
-	gpupreagg_store_slab(lds, L, slabs + (size_t)(wg_in_split * nsplits + split) * ctl->slab_bytes, G, NREP);
+#if defined(GPUPREAGG_PACKABLE) && GPUPREAGG_PACKABLE
+	if (PACKED)
+		gpupreagg_store_slab_packed(lds, pk, slabs + (size_t)(wg_in_split * nsplits + split) * ctl->slab_bytes, G);
+	else
+#endif
+		gpupreagg_store_slab(lds, L, slabs + (size_t)(wg_in_split * nsplits + split) * ctl->slab_bytes, G, NREP);
 	gpupreagg_writeback_status(&kgpreagg->status, chunk_status);
 }
+
+extern "C" __global__ void
+__launch_bounds__(GPUPREAGG_BLOCK)
+gpupreagg_dense_column(kern_gpupreagg *kgpreagg,
+					   const kern_data_store *kds,
+					   const gpupreagg_dense_ctl *ctl_in_memory,
+					   char *slabs)
+{
+	gpupreagg_dense_column_body<false>(kgpreagg, kds, ctl_in_memory, NULL, slabs);
+}
+
+#if defined(GPUPREAGG_PACKABLE) && GPUPREAGG_PACKABLE
+extern "C" __global__ void
+__launch_bounds__(GPUPREAGG_BLOCK)
+gpupreagg_packed_column(kern_gpupreagg *kgpreagg,
+						const kern_data_store *kds,
+						const gpupreagg_dense_ctl *ctl_in_memory,
+						const gpupreagg_pack_ctl *pack_in_memory,
+						char *slabs)
+{
+	gpupreagg_dense_column_body<true>(kgpreagg, kds, ctl_in_memory, pack_in_memory, slabs);
+}
+#endif
 
 /* ====================================================================== *
  * dense-id reduction, any format / row map (one datum at a time)

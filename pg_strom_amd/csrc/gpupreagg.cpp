@@ -14,6 +14,7 @@
  */
 #include <atomic>
 #include <cstring>
+#include <map>
 #include <memory>
 #include <cstdio>
 #include <algorithm>
@@ -74,6 +75,18 @@ struct strom_gpupreagg {
 	cl_ulong			groups_upper = 0;	/* groups known at the last read-back + rows folded since */
 	std::atomic<cl_uint> groups_known{0};	/* groups at the last read-back (or the caller's hint) */
 	int					reg_groups = 0;		/* 1: register accumulators, 2: lane-private LDS, 0: LDS atomics */
+	/* packed accumulators (gpupreagg_packed_column): what the generated code says
+	 * about every aggregate, and the launch geometry per role count */
+	bool				packable = false;
+	std::vector<int>	pack_kind, pack_attno;
+	struct packed_geom {
+		dense_ctl	ctl;
+		char	   *d_ctl = nullptr;
+		char	   *d_slabs = nullptr;
+		size_t		lds_bytes = 0;
+	};
+	std::map<cl_uint, packed_geom> packed;		/* by number of roles */
+	size_t				packed_static_lds = ~(size_t)0;
 	std::mutex			lock;
 
 	/* mirrors gpupreagg_image_offset / gpupreagg_table_offset of
@@ -282,6 +295,142 @@ alloc_session_buffers(strom_gpupreagg *sess)
 	return 0;
 }
 
+/* mirrors struct gpupreagg_pack_ctl of strom_gpupreagg.h */
+struct pack_ctl {
+	cl_uint		count_shift;
+	cl_uint		nwords;
+	cl_uint		shift[32];
+	cl_uint		word[32];
+	cl_ulong	mask[32];
+	cl_ulong	vmax[32];
+	cl_long		bias[32];
+};
+
+int
+bits_for(cl_ulong v)			/* bits needed to hold values 0..v */
+{
+	int		n = 0;
+	while (v) { n++; v >>= 1; }
+	return n;
+}
+
+/*
+ * Packed accumulators for THIS chunk?  (strom_gpupreagg.h explains the
+ * layout.)  Yes when the generated code says every aggregate is count(*) or
+ * psum of a plain column, no input column has a NULL bitmap in the chunk,
+ * the integer columns' zone maps and the rows one work-group folds bound
+ * all fields to one 64-bit word, and the packed image needs FEWER id-range
+ * roles than the standard one (each role visits every row).
+ * Returns the geometry to launch with, or NULL.
+ */
+strom_gpupreagg::packed_geom *
+packed_plan(strom_gpupreagg *sess, hipFunction_t fn_packed, const kern_coldir *coldir, cl_uint ncols,
+			cl_uint nitems, pack_ctl *pk)
+{
+	Device	   *dev = sess->dev;
+	dense_ctl  &std_ctl = sess->ctl;
+
+	if (!sess->packable || !fn_packed || !coldir || std_ctl.remap != 0 || std_ctl.nsplits < 2 ||
+		getenv("STROM_GPUPREAGG_NO_PACKED"))
+		return nullptr;
+	if (sess->packed_static_lds == ~(size_t)0)
+	{
+		int		v = 0;
+		if (hipFuncGetAttribute(&v, HIP_FUNC_ATTRIBUTE_SHARED_SIZE_BYTES, fn_packed) != hipSuccess || v < 0)
+			v = 8192;
+		sess->packed_static_lds = (size_t)v;
+	}
+	size_t		lds_max = std::min<size_t>(dev->prop.sharedMemPerBlock, 160 * 1024);
+	if (sess->packed_static_lds + 1024 >= lds_max)
+		return nullptr;
+	size_t		lds_budget = lds_max - sess->packed_static_lds - 256;
+	cl_uint		naggs = (cl_uint)sess->agg_resno.size();
+	cl_uint		nwords = 1;
+	memset(pk, 0, sizeof(*pk));
+	for (cl_uint a = 0; a < naggs; a++)
+	{
+		int		kind = sess->pack_kind[a];
+		if (kind == 1)
+			continue;
+		int		col = sess->pack_attno[a] - 1;
+		if (col < 0 || col >= (int)ncols || coldir[col].nulls_off != 0)
+			return nullptr;					/* a NULL input needs the has-value flags */
+		if (kind == 3)
+			pk->word[a] = nwords++;
+		else if (!(coldir[col].stat_flags & KDS_COLSTAT_MINMAX) || (coldir[col].stat_flags & KDS_COLSTAT_ISFLOAT) ||
+				 coldir[col].maxval < coldir[col].minval)
+			return nullptr;					/* no zone map to bound the sum with */
+	}
+	/* roles and work-groups of the packed image */
+	size_t		per_group = 8 * (size_t)nwords;
+	cl_uint		nsplits = 1;
+	cl_uint		G = std_ctl.ngroups;
+	while ((size_t)nwords * align16(8 * (size_t)G) > lds_budget)
+	{
+		nsplits++;
+		G = (std_ctl.ngroups + nsplits - 1) / nsplits;
+	}
+	(void)per_group;
+	if (nsplits >= std_ctl.nsplits)
+		return nullptr;						/* nothing gained */
+	size_t		wgs = (size_t)dev->prop.multiProcessorCount;		/* the image takes a CU's LDS */
+	wgs = std::max<size_t>(nsplits, wgs - wgs % nsplits);
+	if (nsplits > 1 && wgs >= 8 * (size_t)nsplits)
+		wgs -= wgs % (8 * (size_t)nsplits);
+	/* field widths: rows one work-group can fold in this chunk, zone-map ranges */
+	size_t		tile_rows = (size_t)sess->block * 4 * sess->quads;
+	size_t		ntiles = ((size_t)nitems + tile_rows - 1) / tile_rows;
+	size_t		wgs_per_split = wgs / nsplits;
+	cl_ulong	rows_per_wg = (cl_ulong)((ntiles + wgs_per_split - 1) / wgs_per_split) * tile_rows;
+	int			cbits = bits_for(rows_per_wg);
+	int			pos = 0;
+	for (cl_uint a = 0; a < naggs; a++)
+	{
+		if (sess->pack_kind[a] != 2)
+			continue;
+		int			col = sess->pack_attno[a] - 1;
+		cl_ulong	vrange = (cl_ulong)coldir[col].maxval - (cl_ulong)coldir[col].minval;
+		int			width = cbits + bits_for(vrange);
+		if (pos + width > 64)
+			return nullptr;
+		pk->shift[a] = (cl_uint)pos;
+		pk->mask[a] = (width >= 64 ? ~0UL : ((1UL << width) - 1));
+		pk->vmax[a] = vrange;
+		pk->bias[a] = coldir[col].minval;
+		pos += width;
+	}
+	if (pos + cbits > 64)
+		return nullptr;
+	pk->count_shift = (cl_uint)pos;
+	pk->nwords = nwords;
+	/* geometry of this role count: control block + slabs, made once */
+	std::lock_guard<std::mutex> g(sess->lock);
+	auto	it = sess->packed.find(nsplits);
+	if (it == sess->packed.end())
+	{
+		strom_gpupreagg::packed_geom geom;
+		geom.ctl = std_ctl;
+		geom.ctl.nsplits = nsplits;
+		geom.ctl.groups_per_split = G;
+		geom.ctl.nrep = 1;
+		geom.ctl.nslabs = (cl_uint)wgs;
+		geom.ctl.slab_bytes = STROM_TYPEALIGN(256, sess->image_offset(sess->nsections(), G, 1));
+		geom.lds_bytes = (size_t)nwords * align16(8 * (size_t)G);
+		(void)hipSetDevice(dev->hip_id);
+		geom.d_ctl = (char *)dev->pool.alloc(sizeof(dense_ctl));
+		geom.d_slabs = (char *)dev->pool.alloc((size_t)geom.ctl.nslabs * geom.ctl.slab_bytes);
+		if (!geom.d_ctl || !geom.d_slabs ||
+			hipMemcpy(geom.d_ctl, &geom.ctl, sizeof(dense_ctl), hipMemcpyHostToDevice) != hipSuccess)
+		{
+			if (geom.d_ctl) dev->pool.release(geom.d_ctl);
+			if (geom.d_slabs) dev->pool.release(geom.d_slabs);
+			return nullptr;
+		}
+		it = sess->packed.insert({nsplits, geom}).first;
+	}
+	return &it->second;
+}
+
 #define REQ_CHECK(call, what)												\
 	do {																	\
 		hipError_t __rc = (call);											\
@@ -344,11 +493,36 @@ gpupreagg_launch(strom_task_impl *task, preagg_request req)
 		task_fail(task, errcode);
 		return;
 	}
-	/* kern_gpupreagg image: {status, sortbuf_len, pad, kern_parambuf} */
+	/* packed accumulators for this chunk?  (fewer id-range roles: see packed_plan) */
+	pack_ctl	pk;
+	strom_gpupreagg::packed_geom *packed = nullptr;
+	if (use_column && !use_reg && sess->packable && sess->ctl.nsplits > 1)
+	{
+		int		e2 = 0;
+		hipFunction_t fn_packed = prog->get_function(dev, "gpupreagg_packed_column", &e2);
+		std::shared_ptr<std::vector<kern_coldir>> snap;
+		const kern_coldir *coldir = nullptr;
+		cl_uint		ncols = 0;
+		if (req.kds)
+		{
+			coldir = KERN_DATA_STORE_COLDIR(req.kds);
+			ncols = req.kds->ncols;
+		}
+		else if ((snap = dstore_coldir(req.kds_dev)) != nullptr)
+		{
+			coldir = snap->data();
+			ncols = (cl_uint)snap->size();
+		}
+		packed = packed_plan(sess, fn_packed, coldir, ncols, req.nrows, &pk);
+		if (packed)
+			fn = fn_packed;
+	}
+	/* kern_gpupreagg image: {status, sortbuf_len, pad, kern_parambuf} [+ the pack control block] */
 	size_t	kg_len = STROMALIGN(offsetof(kern_gpupreagg, kparams) + sess->kparams.size());
+	size_t	send_len = kg_len + (packed ? STROMALIGN(sizeof(pack_ctl)) : 0);
 	char   *stage = dev->pinned.alloc();
-	char   *d_kg = (char *)dev->pool.alloc(kg_len);
-	if (!stage || !d_kg || kg_len + 64 > PinnedPool::BLOCK)
+	char   *d_kg = (char *)dev->pool.alloc(send_len);
+	if (!stage || !d_kg || send_len + 64 > PinnedPool::BLOCK)
 	{
 		if (stage) dev->pinned.release(stage);
 		if (d_kg) dev->pool.release(d_kg);
@@ -359,12 +533,14 @@ gpupreagg_launch(strom_task_impl *task, preagg_request req)
 	task->main_devptr = d_kg;
 	memset(stage, 0, kg_len);
 	memcpy(stage + offsetof(kern_gpupreagg, kparams), sess->kparams.data(), sess->kparams.size());
+	if (packed)
+		memcpy(stage + kg_len, &pk, sizeof(pk));
 
 	task_event(task);									/* ev[0] */
-	REQ_CHECK(hipMemcpyAsync(d_kg, stage, kg_len, hipMemcpyHostToDevice, task->stream),
+	REQ_CHECK(hipMemcpyAsync(d_kg, stage, send_len, hipMemcpyHostToDevice, task->stream),
 			  "send kern_gpupreagg");
 	task->pfm.num_dma_send++;
-	task->pfm.bytes_dma_send += kg_len;
+	task->pfm.bytes_dma_send += send_len;
 	const void *d_kds;
 	if (req.kds_dev)
 		d_kds = req.kds_dev->devptr;
@@ -421,21 +597,26 @@ gpupreagg_launch(strom_task_impl *task, preagg_request req)
 		const void *a_kds = d_kds;
 		const void *a_toast = nullptr;
 		const void *a_map = d_rowmap;
-		void	   *a_ctl = sess->d_ctl;
-		void	   *a_slabs = sess->d_slabs;
+		const dense_ctl &lctl = (packed ? packed->ctl : sess->ctl);		/* this launch's geometry */
+		void	   *a_ctl = (packed ? packed->d_ctl : sess->d_ctl);
+		void	   *a_slabs = (packed ? packed->d_slabs : sess->d_slabs);
 		void	   *a_table = sess->table;
 		const void *a_res = req.joined_results;
 		const void *a_jmap = d_jmap;
+		const void *a_pack = d_kg + kg_len;
 		void	   *args_col[] = { &a_kg, &a_kds, &a_ctl, &a_slabs };
+		void	   *args_pack[] = { &a_kg, &a_kds, &a_ctl, &a_pack, &a_slabs };
 		void	   *args_gen[] = { &a_kg, &a_kds, &a_toast, &a_map, &a_ctl, &a_slabs };
 		void	   *args_join[] = { &a_kg, &a_res, &a_kds, &a_jmap, &a_ctl, &a_slabs };
 		void	   *args_look[] = { &a_kg, &a_kds, &a_jmap, &a_ctl, &a_slabs };
 		void	   *args_mrg[] = { &a_kg, &a_ctl, &a_slabs, &a_table };
-		REQ_CHECK(hipModuleLaunchKernel(fn, sess->ctl.nslabs, 1, 1, use_reg ? 256 : sess->block, 1, 1,
-										(unsigned)sess->lds_bytes, task->stream,
-										use_lookup ? args_look : use_joined ? args_join
+		REQ_CHECK(hipModuleLaunchKernel(fn, lctl.nslabs, 1, 1, use_reg ? 256 : sess->block, 1, 1,
+										(unsigned)(packed ? packed->lds_bytes : sess->lds_bytes), task->stream,
+										packed ? args_pack : use_lookup ? args_look : use_joined ? args_join
 										: use_column ? args_col : args_gen, nullptr),
 				  "launch gpupreagg reduction");
+		if (packed)
+			task->pfm.num_kern_prep++;			/* (reported: this request took the packed path) */
 		if (task->pfm.enabled)
 		{
 			task_event(task);							/* ev[2]: main kernel done */
@@ -443,11 +624,11 @@ gpupreagg_launch(strom_task_impl *task, preagg_request req)
 		}
 		/* the merge kernel lays 256 threads out as GL group lanes x stripes
 		 * over the slabs (strom_gpupreagg.h) */
-		unsigned ws = 1, per_split = sess->ctl.nslabs / sess->ctl.nsplits;
+		unsigned ws = 1, per_split = lctl.nslabs / lctl.nsplits;
 		while (ws < 64 && ws * 8 < per_split)
 			ws <<= 1;
 		unsigned gl = 256 / ws;
-		unsigned mgrid = std::min<unsigned>((sess->ctl.ngroups + gl - 1) / gl,
+		unsigned mgrid = std::min<unsigned>((lctl.ngroups + gl - 1) / gl,
 											(unsigned)dev->prop.multiProcessorCount * 8);
 		REQ_CHECK(hipModuleLaunchKernel(fn_merge, std::max(1u, mgrid), 1, 1, 256, 1, 1, 0,
 										task->stream, args_mrg, nullptr),
@@ -455,7 +636,7 @@ gpupreagg_launch(strom_task_impl *task, preagg_request req)
 		task->pfm.num_kern_exec += 2;
 	}
 	task_event(task);									/* ev[2] */
-	char   *stage_status = stage + kg_len;
+	char   *stage_status = stage + send_len;
 	REQ_CHECK(hipMemcpyAsync(stage_status, d_kg + offsetof(kern_gpupreagg, status), sizeof(cl_int),
 							 hipMemcpyDeviceToHost, task->stream),
 			  "recv status");
@@ -920,6 +1101,29 @@ gpupreagg_session_new(strom_devprog_key key,
 			sess->agg_resno.push_back(i);
 	}
 	sess->kparams.assign((const char *)kparams, (const char *)kparams + kparams->length);
+	{
+		/* what the code generator says about packed accumulators (codegen_preagg.cpp) */
+		const char *src = prog->source.c_str();
+		const char *lst = strstr(src, "#define GPUPREAGG_PACK_LIST(X)");
+		sess->packable = (strstr(src, "#define GPUPREAGG_PACKABLE 1") != nullptr && lst != nullptr);
+		if (sess->packable)
+		{
+			const char *eol = strchr(lst, '\n');
+			for (const char *p = strstr(lst, " X("); p && (!eol || p < eol); p = strstr(p + 1, " X("))
+			{
+				int		aidx = -1, kind = 0, attno = 0;
+				if (sscanf(p, " X(%d,%d,%d)", &aidx, &kind, &attno) != 3 || aidx != (int)sess->pack_kind.size())
+				{
+					sess->packable = false;
+					break;
+				}
+				sess->pack_kind.push_back(kind);
+				sess->pack_attno.push_back(attno);
+			}
+			if (sess->pack_kind.size() != sess->agg_resno.size() || sess->agg_resno.size() > 32)
+				sess->packable = false;
+		}
+	}
 	if (const char *v = getenv("STROM_GPUPREAGG_BLOCK"))
 		sess->block = atoi(v);
 	if (const char *v = getenv("STROM_GPUPREAGG_QUADS"))
@@ -1578,6 +1782,11 @@ strom_gpupreagg_release(strom_gpupreagg *sess)
 		dev->pool.release(sess->d_census);
 	if (sess->d_remap)
 		dev->pool.release(sess->d_remap);
+	for (auto &kv : sess->packed)
+	{
+		dev->pool.release(kv.second.d_ctl);
+		dev->pool.release(kv.second.d_slabs);
+	}
 	if (sess->htab)
 		dev->pool.release(sess->htab);
 	strom_put_devprog_key(sess->key);

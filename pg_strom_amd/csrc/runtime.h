@@ -107,6 +107,9 @@ struct strom_dstore {
 	int			dindex;
 	bool		owned;
 	kern_data_store head;		/* host snapshot of the fixed head (no colmeta) */
+	/* KDS_FORMAT_COLUMN: host snapshot of the column directory (NULL bitmaps
+	 * present?  zone maps), fetched on first use by strom::dstore_coldir() */
+	std::shared_ptr<std::vector<kern_coldir>> coldir;
 };
 
 /* device-resident kern_row_map (a finished GpuScan's results, in place) */
@@ -166,6 +169,8 @@ struct strom_task_impl : public strom_task {
 };
 
 /* runtime.cpp */
+/* column directory of a resident COLUMN chunk (host snapshot, cached); NULL for other formats */
+std::shared_ptr<std::vector<kern_coldir>> dstore_coldir(strom_dstore *ds);
 /* block until the request is over (also true inside its own done() callback) */
 void		task_wait_completed(strom_task_impl *task);
 Device	   *get_device(int dindex);

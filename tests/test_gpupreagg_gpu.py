@@ -111,7 +111,8 @@ def test_reference_regression_suites_on_device(fmt, nchunks):
     assert total >= 200
 
 
-def compare_with_oracle(spec, bufs, domain, ext=(), float_tol=1e-12, compact=False, hashed=False):
+def compare_with_oracle(spec, bufs, domain, ext=(), float_tol=1e-12, compact=False, hashed=False,
+                        resident=False, pfms=None):
     agg = GpuPreAgg(spec)
     if hashed:
         agg.begin_hashed(ext_params=ext)
@@ -124,8 +125,13 @@ def compare_with_oracle(spec, bufs, domain, ext=(), float_tol=1e-12, compact=Fal
                 agg.census(b)
             agg.compact()
         for b in bufs:
-            status, _ = agg.fold(b)
+            ds = runtime.DeviceStore.upload(b) if resident else None
+            status, pfm = agg.fold(ds if resident else b)
+            if ds is not None:
+                ds.release()
             assert status == 0
+            if pfms is not None:
+                pfms.append(pfm)
         pr = agg.fetch()
     finally:
         agg.end()
@@ -228,6 +234,77 @@ def test_id_range_split_over_workgroup_roles(monkeypatch):
     buf = kds.build_kds("column", cols)
     spec = "(gpupreagg (key (var 1 int4)) (nrows) (psum (int8 (var 3 int4))) (psum (var 4 float8)))"
     compare_with_oracle(spec, [buf], domain_of([buf], [0]))
+
+
+def c4_table(n, seed, ngroups, xlo=-10**6, xhi=10**6, nulls=None):
+    rng = np.random.default_rng(seed)
+    g = rng.integers(0, ngroups, n).astype(np.int32)
+    g[:ngroups] = np.arange(ngroups, dtype=np.int32)           # every group occurs
+    x = rng.integers(xlo, xhi, n).astype(np.int32)
+    y = rng.random(n) * 100
+    return [kds.Column("int4", g), kds.Column("int4", x, None if nulls is None else rng.random(n) < nulls),
+            kds.Column("float8", y)]
+
+
+C4_SPEC = "(gpupreagg (key (var 1 int4)) (nrows) (psum (int8 (var 2 int4))) (psum (var 3 float8)))"
+
+
+@pytest.mark.parametrize("ngroups,resident", [(10000, True), (10000, False), (25000, True), (9000, True)])
+def test_packed_accumulators_c4_shape(ngroups, resident):
+    """BASELINE configs[3]: 1e4 groups do not fit the standard 21 B/group LDS image in one
+    work-group; count(*) and the zone-map bounded integer sum share ONE 64-bit word
+    (gpupreagg_packed_column, 16 B/group) -- bit-exact counts and integer sums, float8 1e-12.
+    25000 groups: packed with id-range roles.  num_kern_prep marks the packed path."""
+    bufs = [kds.build_kds("column", c4_table(150003, 31 + i, ngroups, xlo=-10**6 + 5 * i)) for i in range(2)]
+    pfms = []
+    compare_with_oracle(C4_SPEC, bufs, [(0, ngroups)], resident=resident, pfms=pfms)
+    assert all(p["num_kern_prep"] == 1 for p in pfms)
+
+
+def test_packed_accumulators_with_qual_two_keys_and_wide_values():
+    """a qual, two keys, an int8 column and a float4 -> float8 cast through the packed path;
+    then a value range too wide for one word next to the count: the standard path"""
+    rng = np.random.default_rng(77)
+    n = 120001
+    k1 = rng.integers(-50, 150, n).astype(np.int32)
+    k2 = rng.integers(0, 60, n).astype(np.int16)
+    w = rng.integers(-2**13, 2**13, n).astype(np.int64)        # 15 + 7 value bits + 3 x 14 count bits <= 64
+    f = (rng.random(n) * 8 - 4).astype(np.float32)
+    v = rng.integers(0, 100, n).astype(np.int32)
+    cols = [kds.Column("int4", k1), kds.Column("int2", k2), kds.Column("int8", w), kds.Column("float4", f),
+            kds.Column("int4", v)]
+    buf = kds.build_kds("column", cols)
+    spec = ("(gpupreagg (qual (int4lt (var 5 int4) (const int4 70))) (key (var 1 int4)) (key (var 2 int2)) (nrows)"
+            " (psum (var 3 int8)) (psum (float8 (var 4 float4))) (psum (int8 (var 5 int4))))")
+    pfms = []
+    compare_with_oracle(spec, [buf], [(-50, 200), (0, 60)], resident=True, pfms=pfms, float_tol=1e-9)
+    assert pfms[0]["num_kern_prep"] == 1
+    wide = [kds.Column("int4", k1), kds.Column("int2", k2),
+            kds.Column("int8", rng.integers(-2**50, 2**50, n).astype(np.int64)), kds.Column("float4", f),
+            kds.Column("int4", v)]
+    pfms = []
+    compare_with_oracle(spec, [kds.build_kds("column", wide)], [(-50, 200), (0, 60)], resident=True, pfms=pfms,
+                        float_tol=1e-9)
+    assert pfms[0]["num_kern_prep"] == 0
+
+
+def test_packed_path_is_left_when_an_input_column_has_nulls_and_catches_a_wrong_zone_map():
+    bufs = [kds.build_kds("column", c4_table(100003, 41, 10000, nulls=0.02))]
+    pfms = []
+    compare_with_oracle(C4_SPEC, bufs, [(0, 10000)], resident=True, pfms=pfms)
+    assert pfms[0]["num_kern_prep"] == 0                        # has-value flags needed: standard image
+    # a zone map that does not bound the column: the packed fields would overflow into each other
+    buf = kds.build_kds("column", c4_table(100003, 43, 10000))
+    head = kds.KdsHead(buf)
+    off = ((48 + 8 * head.ncols + 15) & ~15) + 32 * 1            # coldir of column 2
+    buf[off + 16:off + 32] = np.array([0, 1000], dtype=np.int64).view(np.uint8)
+    agg = GpuPreAgg(C4_SPEC).begin([(0, 10000)])
+    try:
+        with pytest.raises(runtime.StromError) as ei:
+            agg.fold(runtime.DeviceStore.upload(buf))
+        assert ei.value.errcode == 300                          # StromError_DataStoreCorruption
+    finally:
+        agg.end()
 
 
 def test_zone_map_domain_and_empty_chunks():
