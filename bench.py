@@ -353,6 +353,7 @@ def operator_figures(args, k, c, measured_peak, cpu_blocks):
         st, pfm = agg.collect(agg.submit_lookup(join, fact, cols))
         walls.append(time.perf_counter() - t0)
         kerns.append(pfm["time_kern_exec_ns"])
+        lookup_packed = bool(pfm["num_kern_prep"])
         assert st == 0
     pr = agg.fetch()
     order = np.argsort(pr.column(0)[0])
@@ -364,7 +365,8 @@ def operator_figures(args, k, c, measured_peak, cpu_blocks):
                  "lookup inside the aggregate kernel (strom_submit_gpupreagg_lookup)" % (chunk_rows, ngroups),
         value=chunk_rows / float(np.median(walls[1:])) / 1e6, unit="Mrows/s", groups=len(pr),
         checked="counts and integer sums equal numpy's",
-        roofline=roofline_block("gpupreagg_dense_lookup(+merge)", 16.0 * chunk_rows, kerns[1:], measured_peak),
+        roofline=roofline_block(("gpupreagg_packed_lookup" if lookup_packed else "gpupreagg_dense_lookup") +
+                                "(+gpupreagg_dense_merge)", 16.0 * chunk_rows, kerns[1:], measured_peak),
         **cpu_blocks("chain"))
     agg.end()
     join.end()
@@ -398,7 +400,7 @@ def sharded_gpupreagg(args, rank, world, local_rank, barrier, dist, torch, measu
     comm = parallel.RcclComm(rank, world, dindex=0)
     agg = GpuPreAgg(C4_AGG).begin([(0, ngroups)])
     agg.program.wait()
-    merge_s, kern_ns = [], []
+    merge_s, kern_ns, packed_launches = [], [], [0]
 
     def one_step(record):
         agg.reset()
@@ -408,6 +410,7 @@ def sharded_gpupreagg(args, rank, world, local_rank, barrier, dist, torch, measu
             assert st == 0
             if record:
                 kern_ns.append(pfm["time_kern_exec_ns"])
+                packed_launches[0] += pfm["num_kern_prep"]
         t0 = time.perf_counter()
         agg.allreduce_rccl(comm)
         if record:
@@ -448,7 +451,8 @@ def sharded_gpupreagg(args, rank, world, local_rank, barrier, dist, torch, measu
            "ms_per_step": per_step * 1e3, "merge_ms": float(np.mean(merge_s)) * 1e3, "scaling": "weak",
            "checked": "merged counts and integer sums equal torch's over all ranks' rows"}
     if rank == 0:
-        out["roofline"] = roofline_block("gpupreagg_dense_column(+merge)", 16.0 * nrows / len(chunks), kern_ns,
+        kname = ("gpupreagg_packed_column" if packed_launches[0] == len(kern_ns) else "gpupreagg_dense_column")
+        out["roofline"] = roofline_block(kname + "(+gpupreagg_dense_merge)", 16.0 * nrows / len(chunks), kern_ns,
                                          measured_peak)
         out.update(cpu_blocks("agg"))
     return out

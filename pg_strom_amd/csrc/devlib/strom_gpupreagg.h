@@ -1135,12 +1135,13 @@ gpupreagg_dense_joined(kern_gpupreagg *kgpreagg,
  * are written or read at all.  The program's (var N ...) and its qual see
  * the same virtual relation as gpupreagg_dense_joined; int4 / int8 keys.
  * ====================================================================== */
-template <typename KEY_T>
+template <typename KEY_T, bool PACKED>
 __device__ __forceinline__ void
 gpupreagg_dense_lookup_body(kern_gpupreagg *kgpreagg,
 							const kern_data_store *kds,
 							const gpupreagg_joined_map *jmap,
 							const gpupreagg_dense_ctl *ctl,
+							const gpupreagg_pack_ctl *pack_in_memory,
 							char *slabs, char *lds)
 {
 	const kern_parambuf *kparams = KERN_GPUPREAGG_PARAMBUF(kgpreagg);
@@ -1161,9 +1162,24 @@ gpupreagg_dense_lookup_body(kern_gpupreagg *kgpreagg,
 	gpupreagg_lds_layout L;
 
 	gpupreagg_load_kparams(KP, kparams, &param_error);
-	gpupreagg_remap_init(ctl);
-	gpupreagg_lds_layout_init(L, G, NREP);
-	gpupreagg_lds_init(lds, L, G, NREP);
+#if defined(GPUPREAGG_PACKABLE) && GPUPREAGG_PACKABLE
+	gpupreagg_pack_ctl pack_by_value;
+	const gpupreagg_pack_ctl *pk = &pack_by_value;
+	if (PACKED)
+	{
+		pack_by_value = *pack_in_memory;
+		cl_uint	total = pk->nwords * gpupreagg_align16(8u * G);
+		for (cl_uint i = threadIdx.x * 16; i < total; i += GPUPREAGG_BLOCK * 16)
+			*(uint4 *)(lds + i) = make_uint4(0, 0, 0, 0);
+		__syncthreads();
+	}
+	else
+#endif
+	{
+		gpupreagg_remap_init(ctl);
+		gpupreagg_lds_layout_init(L, G, NREP);
+		gpupreagg_lds_init(lds, L, G, NREP);
+	}
 #define X(attno,colidx,NAME)													\
 	const bool	inner_##attno = (jmap->c[colidx].depth != 0);					\
 	const cl_uint recoff_##attno = (cl_uint)jmap->c[colidx].dimvalues;			\
@@ -1336,13 +1352,23 @@ gpupreagg_dense_lookup_body(kern_gpupreagg *kgpreagg,
 					STROM_KVAR_LIST(X)
 #undef X
 					KV.__dummy = 0;
-					gpupreagg_dense_row(lds, ctl, L, KP, KV, gid_lo, G, NREP, rep,
-										param_error, &chunk_status);
+#if defined(GPUPREAGG_PACKABLE) && GPUPREAGG_PACKABLE
+					if (PACKED)
+						gpupreagg_packed_row(lds, ctl, pk, KP, KV, gid_lo, G, param_error, &chunk_status);
+					else
+#endif
+						gpupreagg_dense_row(lds, ctl, L, KP, KV, gid_lo, G, NREP, rep,
+											param_error, &chunk_status);
 				}
 			}
 		}
 	}
-	gpupreagg_store_slab(lds, L, slabs + (size_t)blockIdx.x * ctl->slab_bytes, G, NREP);
+#if defined(GPUPREAGG_PACKABLE) && GPUPREAGG_PACKABLE
+	if (PACKED)
+		gpupreagg_store_slab_packed(lds, pk, slabs + (size_t)blockIdx.x * ctl->slab_bytes, G);
+	else
+#endif
+		gpupreagg_store_slab(lds, L, slabs + (size_t)blockIdx.x * ctl->slab_bytes, G, NREP);
 	gpupreagg_writeback_status(&kgpreagg->status, chunk_status);
 }
 
@@ -1359,10 +1385,32 @@ gpupreagg_dense_lookup(kern_gpupreagg *kgpreagg,
 	const gpupreagg_dense_ctl ctl_by_value = *ctl_in_memory;
 	const gpupreagg_dense_ctl *ctl = &ctl_by_value;
 	if (jmap->key_attlen == 8)
-		gpupreagg_dense_lookup_body<cl_long>(kgpreagg, kds, jmap, ctl, slabs, lds);
+		gpupreagg_dense_lookup_body<cl_long, false>(kgpreagg, kds, jmap, ctl, NULL, slabs, lds);
 	else
-		gpupreagg_dense_lookup_body<cl_int>(kgpreagg, kds, jmap, ctl, slabs, lds);
+		gpupreagg_dense_lookup_body<cl_int, false>(kgpreagg, kds, jmap, ctl, NULL, slabs, lds);
 }
+
+#if defined(GPUPREAGG_PACKABLE) && GPUPREAGG_PACKABLE
+/* the same with packed accumulators (see gpupreagg_packed_column): the summed
+ * columns must be OUTER columns without NULLs -- their zone maps bound the fields */
+extern "C" __global__ void
+__launch_bounds__(GPUPREAGG_BLOCK)
+gpupreagg_packed_lookup(kern_gpupreagg *kgpreagg,
+						const kern_data_store *kds,
+						const gpupreagg_joined_map *jmap,
+						const gpupreagg_dense_ctl *ctl_in_memory,
+						const gpupreagg_pack_ctl *pack_in_memory,
+						char *slabs)
+{
+	extern __shared__ __attribute__((aligned(16))) char lds[];
+	const gpupreagg_dense_ctl ctl_by_value = *ctl_in_memory;
+	const gpupreagg_dense_ctl *ctl = &ctl_by_value;
+	if (jmap->key_attlen == 8)
+		gpupreagg_dense_lookup_body<cl_long, true>(kgpreagg, kds, jmap, ctl, pack_in_memory, slabs, lds);
+	else
+		gpupreagg_dense_lookup_body<cl_int, true>(kgpreagg, kds, jmap, ctl, pack_in_memory, slabs, lds);
+}
+#endif
 
 /* ====================================================================== *
  * register accumulators: at most GPUPREAGG_REG_GROUPS dense ids

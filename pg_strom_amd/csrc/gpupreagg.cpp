@@ -295,6 +295,24 @@ alloc_session_buffers(strom_gpupreagg *sess)
 	return 0;
 }
 
+/* host image of struct gpupreagg_joined_map (strom_gpupreagg.h) */
+struct joined_map_image {
+	cl_uint		ncols;
+	cl_int		key_col;
+	cl_int		key_attlen;
+	cl_uint		nslots;
+	cl_long		key_min;
+	struct {
+		cl_int		depth;
+		cl_int		col;
+		cl_ulong	dimvalues;
+		cl_ulong	dimisnull;
+	} c[64];
+	cl_ulong	recs;
+	cl_uint		reclen;
+	cl_uint		pad;
+};
+
 /* mirrors struct gpupreagg_pack_ctl of strom_gpupreagg.h */
 struct pack_ctl {
 	cl_uint		count_shift;
@@ -496,11 +514,13 @@ gpupreagg_launch(strom_task_impl *task, preagg_request req)
 	/* packed accumulators for this chunk?  (fewer id-range roles: see packed_plan) */
 	pack_ctl	pk;
 	strom_gpupreagg::packed_geom *packed = nullptr;
-	if (use_column && !use_reg && sess->packable && sess->ctl.nsplits > 1)
+	if ((use_lookup || (use_column && !use_reg)) && sess->packable && sess->ctl.nsplits > 1)
 	{
 		int		e2 = 0;
-		hipFunction_t fn_packed = prog->get_function(dev, "gpupreagg_packed_column", &e2);
+		hipFunction_t fn_packed = prog->get_function(dev, use_lookup ? "gpupreagg_packed_lookup"
+													 : "gpupreagg_packed_column", &e2);
 		std::shared_ptr<std::vector<kern_coldir>> snap;
+		std::vector<kern_coldir> virt;
 		const kern_coldir *coldir = nullptr;
 		cl_uint		ncols = 0;
 		if (req.kds)
@@ -512,6 +532,23 @@ gpupreagg_launch(strom_task_impl *task, preagg_request req)
 		{
 			coldir = snap->data();
 			ncols = (cl_uint)snap->size();
+		}
+		if (use_lookup && coldir)
+		{
+			/* the program's columns are virtual: an outer column brings its own
+			 * directory entry, an inner column counts as "may be NULL, no zone map" */
+			const joined_map_image *jm = (const joined_map_image *)req.joined_map->data();
+			virt.resize(jm->ncols);
+			for (cl_uint i = 0; i < jm->ncols; i++)
+			{
+				memset(&virt[i], 0, sizeof(kern_coldir));
+				if (jm->c[i].depth == 0 && jm->c[i].col >= 0 && (cl_uint)jm->c[i].col < ncols)
+					virt[i] = coldir[jm->c[i].col];
+				else
+					virt[i].nulls_off = 1;
+			}
+			coldir = virt.data();
+			ncols = jm->ncols;
 		}
 		packed = packed_plan(sess, fn_packed, coldir, ncols, req.nrows, &pk);
 		if (packed)
@@ -606,13 +643,15 @@ gpupreagg_launch(strom_task_impl *task, preagg_request req)
 		const void *a_pack = d_kg + kg_len;
 		void	   *args_col[] = { &a_kg, &a_kds, &a_ctl, &a_slabs };
 		void	   *args_pack[] = { &a_kg, &a_kds, &a_ctl, &a_pack, &a_slabs };
+		void	   *args_plook[] = { &a_kg, &a_kds, &a_jmap, &a_ctl, &a_pack, &a_slabs };
 		void	   *args_gen[] = { &a_kg, &a_kds, &a_toast, &a_map, &a_ctl, &a_slabs };
 		void	   *args_join[] = { &a_kg, &a_res, &a_kds, &a_jmap, &a_ctl, &a_slabs };
 		void	   *args_look[] = { &a_kg, &a_kds, &a_jmap, &a_ctl, &a_slabs };
 		void	   *args_mrg[] = { &a_kg, &a_ctl, &a_slabs, &a_table };
 		REQ_CHECK(hipModuleLaunchKernel(fn, lctl.nslabs, 1, 1, use_reg ? 256 : sess->block, 1, 1,
 										(unsigned)(packed ? packed->lds_bytes : sess->lds_bytes), task->stream,
-										packed ? args_pack : use_lookup ? args_look : use_joined ? args_join
+										packed ? (use_lookup ? args_plook : args_pack)
+										: use_lookup ? args_look : use_joined ? args_join
 										: use_column ? args_col : args_gen, nullptr),
 				  "launch gpupreagg reduction");
 		if (packed)
@@ -1329,25 +1368,6 @@ strom_submit_gpupreagg_mapped(strom_gpupreagg *sess, strom_dstore *kds_dev, stro
 	return submit_gpupreagg_common(sess, nullptr, kds_dev, nullptr, rowmap, done, arg, p_errcode);
 }
 
-/* host image of struct gpupreagg_joined_map (strom_gpupreagg.h) */
-namespace {
-struct joined_map_image {
-	cl_uint		ncols;
-	cl_int		key_col;
-	cl_int		key_attlen;
-	cl_uint		nslots;
-	cl_long		key_min;
-	struct {
-		cl_int		depth;
-		cl_int		col;
-		cl_ulong	dimvalues;
-		cl_ulong	dimisnull;
-	} c[64];
-	cl_ulong	recs;
-	cl_uint		reclen;
-	cl_uint		pad;
-};
-}
 
 /*
  * fold the rows a finished GpuHashJoin produced, straight from its result

@@ -389,3 +389,55 @@ def test_join_as_a_lookup_inside_the_aggregate(ngroups, keytype):
     gmax, gnull = pr.column(4)
     assert np.array_equal(gnull[order], np.isinf(wmax))
     assert np.array_equal(gmax[order][~np.isinf(wmax)], wmax[~np.isinf(wmax)])
+
+
+def test_join_as_a_lookup_with_packed_accumulators():
+    """1e4 groups, summed OUTER columns without NULLs: the lookup aggregate takes the packed
+    LDS image (gpupreagg_packed_lookup, one id-range role instead of two); the grouping key
+    is an inner column with NULLs, rows without a partner are dropped"""
+    runtime.init()
+    n, nd, ngroups = 300007, 40000, 10000
+    rng = np.random.default_rng(97)
+    span = int(nd * 1.25)
+    fk = rng.integers(0, span, n).astype(np.int32)
+    a = rng.integers(-5 * 10**5, 2**20, n).astype(np.int32)
+    b = rng.random(n)
+    fact = kds.build_kds("column", [kds.Column("int4", fk), kds.Column("int4", a), kds.Column("float8", b)])
+    dkey = rng.permutation(span)[:nd].astype(np.int32)
+    dgrp = (dkey % ngroups).astype(np.int32)
+    dgn = rng.random(nd) < 0.02
+    inner = kds.build_kds("row_flat", [kds.Column("int4", dkey), kds.Column("int4", dgrp, dgn)])
+    km = build_multihash([(inner, [1])])
+    ext = [np.int32(2**19), 0.25]
+    ds = runtime.DeviceStore.upload(fact)
+    join = GpuHashJoin("(gpuhashjoin (rel (hashkey (var 1 int4) 1 int4)))").begin(km)
+    spec = ("(gpupreagg (qual " + QUAL + ") (key (var 1 int4)) (nrows) (psum (int8 (var 2 int4)))"
+            " (psum (var 3 float8)))")
+    agg = GpuPreAgg(spec)
+    try:
+        agg.begin([(0, ngroups)], ext_params=ext)
+        pfms = []
+        for _ in range(2):
+            st, pfm = agg.collect(agg.submit_lookup(join, ds, [(1, 2, "int4"), (0, 2, "int4"), (0, 3, "float8")]))
+            assert st == 0
+            pfms.append(pfm)
+        pr = agg.fetch()
+    finally:
+        agg.end()
+        join.end()
+        ds.release()
+    assert all(p["num_kern_prep"] == 1 for p in pfms)             # the packed path was taken
+    pos = np.full(span, -1, dtype=np.int64)
+    pos[dkey] = np.arange(nd)
+    di_all = pos[fk]
+    sel = np.flatnonzero((di_all >= 0) & (a < ext[0]) & (b > ext[1]))
+    di = di_all[sel]
+    g = np.where(dgn[di], 10**6, dgrp[di])
+    ug, inv = np.unique(g, return_inverse=True)
+    keys, knull = pr.column(0)
+    gk = np.where(knull, 10**6, keys)
+    order = np.argsort(gk)
+    assert np.array_equal(gk[order], ug)
+    assert np.array_equal(pr.column(1)[0][order], 2 * np.bincount(inv))
+    assert np.array_equal(pr.column(2)[0][order], 2 * np.bincount(inv, weights=a[sel].astype(np.float64)).astype(np.int64))
+    assert np.allclose(pr.column(3)[0][order], 2 * np.bincount(inv, weights=b[sel]), rtol=1e-12)
