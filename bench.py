@@ -37,6 +37,7 @@ import json
 import os
 import subprocess
 import sys
+import threading
 import time
 
 import numpy as np
@@ -514,6 +515,8 @@ def main():
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the GpuHashJoin / GpuPreAgg / chain figures reported next to the headline")
     ap.add_argument("--no-sharded", action="store_true", help="skip the sharded GpuPreAgg + RCCL merge region")
+    ap.add_argument("--sharded-timeout", type=int, default=240,
+                    help="seconds the sharded GpuPreAgg region may take before the headline is printed without it")
     ap.add_argument("--cpu-worker", default=None, help=argparse.SUPPRESS)
     args = ap.parse_args()
     if args.cpu_worker:
@@ -638,11 +641,9 @@ def main():
         return {"cpu_baseline": cpu_baseline(kind, k, c, args.cpu_seconds),
                 "cpu_baseline_all_cores": cpu_baseline_all_cores(kind, k, c, args.cpu_seconds)}
 
-    sharded = None
-    if not args.no_sharded:
-        log("sharded GpuPreAgg + RCCL merge")
-        sharded = sharded_gpupreagg(args, rank, world, local_rank, barrier, dist, torch, measured_peak, cpu_blocks)
-
+    # the headline is complete at this point: build its line first, so that nothing
+    # measured next to it can cost it
+    out = None
     if rank == 0:
         per_step = elapsed / args.steps
         value = ngpus * nrows / per_step / 1e6
@@ -682,20 +683,51 @@ def main():
             "roofline": roof,
             "whole_job_gbs": 12.0 * ngpus * nrows / per_step / 1e9,
         }
+
+    printed = threading.Lock()
+
+    def emit(extra=None):
+        """rank 0 prints THE line, once"""
+        if rank == 0 and printed.acquire(False):
+            if extra:
+                out.update(extra)
+            print(json.dumps(out), flush=True)
+
+    if not args.no_sharded:
+        # second region: every rank takes part (RCCL).  A rank that does not come back from
+        # it within the limit must not take the headline with it: the watchdog prints the
+        # line (with the failure named) and ends the process.
+        def give_up():
+            log("sharded GpuPreAgg region did not finish in %d s" % args.sharded_timeout)
+            emit({"gpupreagg_c4": {"error": "did not finish within %d s" % args.sharded_timeout}})
+            os._exit(0 if rank == 0 else 3)
+
+        watchdog = threading.Timer(args.sharded_timeout, give_up)
+        watchdog.daemon = True
+        watchdog.start()
+        log("sharded GpuPreAgg + RCCL merge")
+        try:
+            sharded = sharded_gpupreagg(args, rank, world, local_rank, barrier, dist, torch, measured_peak,
+                                        cpu_blocks)
+        except Exception as e:
+            sharded = {"error": "%s: %s" % (type(e).__name__, e)}
+        watchdog.cancel()
+        if rank == 0:
+            out["gpupreagg_c4"] = sharded
+
+    if rank == 0:
         if with_cpu:
             log("cpu baselines: scan")
             out["cpu_baseline"] = cpu_baseline("scan", k, c, 2 * args.cpu_seconds)
             out["cpu_baseline_all_cores"] = cpu_baseline_all_cores("scan", k, c, args.cpu_seconds)
             out["cpu_baseline_columnar"] = cpu_baseline_columnar(k, c)
-        if sharded is not None:
-            out["gpupreagg_c4"] = sharded
         if ngpus == 1 and not args.no_extras:
             try:
                 log("other operators")
                 out["operators"] = operator_figures(args, k, c, measured_peak, cpu_blocks)
             except Exception as e:                  # never at the expense of the headline line
                 out["operators"] = {"error": "%s: %s" % (type(e).__name__, e)}
-        print(json.dumps(out), flush=True)
+        emit()
 
     if world > 1:
         dist.barrier()
