@@ -24,7 +24,10 @@ typedef struct {
 	int16_t			attlen;		/* 1,2,4,8 */
 	int8_t			attalign;	/* 1,2,4,8 */
 	int8_t			attbyval;
-	const void	   *values;		/* nrows * attlen bytes */
+	const void	   *values;		/* nrows * attlen bytes; attlen -1 (heap formats only): NUMERIC as
+								 * nrows 64-bit device images, encoded as PostgreSQL varlena -- or,
+								 * with attalign -1, nrows pointers to complete varlena datums that
+								 * go into the tuples verbatim */
 	const uint8_t  *isnull;		/* nrows bytes, 1 = NULL; may be NULL */
 } strom_column_input;
 

@@ -1706,14 +1706,19 @@ preagg_spec_parse(const char *text, preagg_spec *sp, char *errbuf, size_t errlen
 		if (ps.failed || !expect_char(&ps, ')'))
 			break;
 		if (t->kind == T_NROWS) t->type_oid = STROM_INT4OID;
+		else if (t->x2 && t->nexprs == 1 && t->exprs[0]->type_oid == STROM_NUMERICOID)
+			t->type_oid = STROM_NUMERICOID;		/* sum of squares in the 64-bit numeric form */
 		else if (t->x2 || t->pcov) t->type_oid = STROM_FLOAT8OID;
 		else if (t->nexprs == 1) t->type_oid = t->exprs[0]->type_oid;
 		else { perr(&ps, "%s takes one argument", head); break; }
 		if (t->type_oid == STROM_NUMERICOID && t->kind != T_KEY)
 		{
-			if (t->numeric_scale < 0 || t->numeric_scale > 32)
-			{ perr(&ps, "numeric partial needs a scale: (%s EXPR SCALE)", head); break; }
-			t->type_oid = STROM_INT8OID;	/* accumulated as fixed point */
+			if (t->numeric_scale > 32)
+			{ perr(&ps, "numeric scale out of range in %s", head); break; }
+			/* with a scale: accumulated as fixed point int8; without: in the 64-bit
+			 * numeric form itself (GPUPREAGG_AGGCALC_PSUM_NUMERIC, opencl_gpupreagg.h:965-987) */
+			if (t->numeric_scale >= 0)
+				t->type_oid = STROM_INT8OID;
 		}
 		else
 			t->numeric_scale = -1;
@@ -1862,7 +1867,21 @@ oracle_gpupreagg(const char *spec_text,
 					r.type_oid = STROM_INT8OID;
 					r.v.i = fx;
 				}
-				if (tg->x2 && !r.isnull)
+				if (tg->type_oid == STROM_NUMERICOID && !r.isnull)
+				{
+					/* kept normalised; a square that leaves the form sends the chunk back */
+					uint64_t c = r.v.u;
+					if (tg->x2 && !num_mul(c, c, &c))
+					{
+						set_error(&errcode, StromError_CpuReCheck);
+						r.isnull = 1;
+					}
+					else
+						(void)num_pack(NUM_EXPO(c), NUM_SIGN(c), NUM_MANT(c), &c);
+					r.type_oid = STROM_NUMERICOID;
+					r.v.u = c;
+				}
+				else if (tg->x2 && !r.isnull)
 				{
 					double x = r.v.d, p = x * x;
 					if (float_bad(p, isinf(x), x == 0.0))
@@ -1964,7 +1983,19 @@ oracle_gpupreagg(const char *spec_text,
 			}
 			if (av[a].isnull)
 				continue;
-			if (type_is_float(tg->type_oid))
+			if (tg->type_oid == STROM_NUMERICOID)
+			{
+				uint64_t x = av[a].v.u;
+				if (acc->isnull) acc->v.u = x;
+				else if (tg->kind == T_PSUM)
+				{
+					if (!num_add(acc->v.u, x, &acc->v.u))
+						set_error(&status, StromError_CpuReCheck);
+				}
+				else if (tg->kind == T_PMIN) { if (num_cmp(x, acc->v.u) < 0) acc->v.u = x; }
+				else { if (num_cmp(x, acc->v.u) > 0) acc->v.u = x; }
+			}
+			else if (type_is_float(tg->type_oid))
 			{
 				double x = float_of(av[a]);
 				if (acc->isnull) acc->v.d = x;

@@ -29,6 +29,18 @@ def rewrite(func, coltype, var, scale=None):
     (the aggregate then stays on the CPU).  numeric needs `scale`, the
     number of fractional digits partial sums are kept with."""
     notnull = "(isnotnull %s)" % var
+    if coltype == "numeric" and func != "count" and scale is None:
+        # the reference's own form (gpupreagg.c:169-313, NUMERICOID entries): partials stay
+        # 64-bit numerics, added / compared on the device exact-or-CpuReCheck
+        if func == "avg":
+            return ["(nrows %s)" % notnull, "(psum %s)" % var], "avg_numeric"
+        if func == "sum":
+            return ["(psum %s)" % var], "sum_numeric"
+        if func in ("min", "max"):
+            return ["(p%s %s)" % (func, var)], func + "_numeric"
+        if func in ("stddev", "stddev_samp", "stddev_pop", "variance", "var_samp", "var_pop"):
+            return ["(nrows %s)" % notnull, "(psum %s)" % var, "(psum_x2 %s)" % var], func + "_numeric"
+        return None
     if coltype == "numeric" and func != "count":
         if func == "avg":
             return ["(nrows %s)" % notnull, "(psum %s %d)" % (var, scale)], "avg_numeric"
@@ -114,6 +126,8 @@ def finalize(final, cols):
 
     if final == "count":
         return int(np.sum(cols[0][0].astype(object))) if len(cols[0][0]) else 0
+    if final.endswith("_numeric_exact"):
+        return _finalize_numeric(final[:-14], cols, exact=True)
     if final.endswith("_numeric"):
         return _finalize_numeric(final[:-8], cols)
     if final == "sum_int8":
@@ -157,8 +171,10 @@ def finalize(final, cols):
     return math.sqrt(var) if final.startswith("stddev") else var
 
 
-def _finalize_numeric(final, cols):
-    """numeric aggregates: cols hold python Decimals (object arrays)"""
+def _finalize_numeric(final, cols, exact=False):
+    """numeric aggregates: cols hold python Decimals (object arrays).  exact=True: quotients
+    and roots at the context's full precision (60 digits) instead of PostgreSQL's result scale,
+    for callers that round to a printed value themselves"""
     def nonnull(c):
         v, n = c
         return [x for x, isn in zip(v, n) if not isn]
@@ -173,7 +189,7 @@ def _finalize_numeric(final, cols):
         return None
     sx = sum(sx, Decimal(0))
     if final == "avg":
-        return numeric_div(sx, Decimal(n))
+        return (sx / Decimal(n)) if exact else numeric_div(sx, Decimal(n))
     sxx = sum(nonnull(cols[2]), Decimal(0))
     samp = final in ("stddev", "stddev_samp", "variance", "var_samp")
     if samp and n <= 1:
@@ -183,6 +199,9 @@ def _finalize_numeric(final, cols):
     if numer <= 0:
         return Decimal(0)
     denom = Decimal(n) * (n - 1 if samp else n)
+    if exact:
+        var = numer / denom
+        return var.sqrt() if final.startswith("stddev") else var
     var = numeric_div(numer, denom)
     if final.startswith("stddev"):
         rscale = max(-var.as_tuple().exponent, 0)

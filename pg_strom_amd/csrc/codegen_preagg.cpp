@@ -92,6 +92,7 @@ strom_codegen_gpupreagg(const char *spec, strom_codegen_result *out,
 			codegen_error("(gpupreagg ...) expected");
 		std::string qual_body = "  pg_bool_t r; r.isnull = false; r.value = true; return r;\n";
 		std::vector<target> targets;
+		bool	numeric_aggs = false;		/* a partial accumulated in the 64-bit numeric form */
 		for (size_t i = 1; i < tree.items.size(); i++)
 		{
 			const sexpr &t = tree.items[i];
@@ -178,7 +179,22 @@ strom_codegen_gpupreagg(const char *spec, strom_codegen_result *out,
 					 * reduction tree and re-checks on overflow
 					 * (opencl_gpupreagg.h:933-948).
 					 */
-					if (nargs != 2 || t.items[2].is_list)
+					if (nargs == 1)
+					{
+						/*
+						 * no scale: the partial stays a 64-bit numeric and is folded with
+						 * pgfn_numeric_add / strom_numeric_cmp in a compare-and-swap loop,
+						 * exact or CpuReCheck -- GPUPREAGG_AGGCALC_PSUM_NUMERIC /
+						 * _PMINMAX_NUMERIC of the reference (opencl_gpupreagg.h:882-900,
+						 * 965-987).  Stored normalised.
+						 */
+						if (fixed_scale >= 0)
+							e = codegen_fixed_as_numeric(e, fixed_scale);
+						tg.body = "  return pgfn_numeric_normalize(errcode, " + e + ");\n";
+						numeric_aggs = true;
+						goto target_done;
+					}
+					if (t.items[2].is_list)
 						codegen_error("numeric partial needs a scale: (%s EXPR SCALE)", head.c_str());
 					tg.scale = atoi(t.items[2].atom.c_str());
 					if (tg.scale < 0 || tg.scale > 32)
@@ -213,10 +229,23 @@ strom_codegen_gpupreagg(const char *spec, strom_codegen_result *out,
 					codegen_error("(psum_x2 EXPR) expected");
 				std::string e;
 				tg.kind = STROM_PREAGG_PSUM;
-				if (codegen_expression(t.items[1], ctx, e) != STROM_FLOAT8OID)
-					codegen_error("psum_x2() takes float8");
-				tg.type_oid = STROM_FLOAT8OID;
-				tg.body = "  pg_float8_t x = " + e + ";\n  return pgfn_float8mul(errcode, x, x);\n";
+				int		xtype = codegen_expression(t.items[1], ctx, e);
+				if (xtype == STROM_NUMERICOID)
+				{
+					/* stddev / variance over numeric: sum of squares in the 64-bit form
+					 * (gpupreagg.c:218-313 ALTFUNC_EXPR_PSUM_X2 with NUMERICOID) */
+					tg.type_oid = STROM_NUMERICOID;
+					tg.body = "  pg_numeric_t x = " + e + ";\n"
+						"  return pgfn_numeric_normalize(errcode, pgfn_numeric_mul(errcode, x, x));\n";
+					numeric_aggs = true;
+				}
+				else
+				{
+					if (xtype != STROM_FLOAT8OID)
+						codegen_error("psum_x2() takes float8 or numeric");
+					tg.type_oid = STROM_FLOAT8OID;
+					tg.body = "  pg_float8_t x = " + e + ";\n  return pgfn_float8mul(errcode, x, x);\n";
+				}
 			}
 			else if (head == "pcov_x" || head == "pcov_y" || head == "pcov_x2" ||
 					 head == "pcov_y2" || head == "pcov_xy")
@@ -241,6 +270,7 @@ strom_codegen_gpupreagg(const char *spec, strom_codegen_result *out,
 			}
 			else
 				codegen_error("unknown GpuPreAgg target \"%s\"", head.c_str());
+		target_done:
 			const devtype_info *dt = devtype_lookup(tg.type_oid);
 			ctx.extra_flags |= dt->type_flags;
 			if (tg.acc_oid == 0)
@@ -352,6 +382,8 @@ strom_codegen_gpupreagg(const char *spec, strom_codegen_result *out,
 		src += tmp;
 		src += key_list + "\n" + agg_list + "\n";
 		/* packed accumulators: X(aidx, kind, attno of the source column) -- see strom_gpupreagg.h */
+		snprintf(tmp, sizeof(tmp), "#define GPUPREAGG_NUMERIC_AGGS %d\n", numeric_aggs ? 1 : 0);
+		src += tmp;
 		snprintf(tmp, sizeof(tmp), "#define GPUPREAGG_PACKABLE %d\n", (packable && naggs > 0 && naggs <= 32) ? 1 : 0);
 		src += tmp;
 		src += pack_list + "\n";

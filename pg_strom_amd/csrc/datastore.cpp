@@ -82,6 +82,29 @@ is_varlena_numeric(const strom_column_input &c)
 	return c.attlen == -1 && c.type_oid == STROM_NUMERICOID;
 }
 
+/*
+ * ... or given as the datum itself: attalign == -1 says that 'values' is an
+ * array of pointers to complete varlena datums (1- or 4-byte header, length in
+ * the header) which go into the heap tuple verbatim -- numerics of any
+ * magnitude, also those the 64-bit device form cannot hold (the kernels then
+ * answer CpuReCheck for the row, opencl_numeric.h:166-307).
+ */
+inline bool
+is_varlena_raw(const strom_column_input &c)
+{
+	return c.attlen == -1 && c.attalign == -1;
+}
+
+inline size_t
+varlena_raw_size(const unsigned char *p)
+{
+	if (p[0] & 0x01)
+		return (size_t)(p[0] >> 1);					/* 1-byte header: total length */
+	uint32_t	h;
+	memcpy(&h, p, 4);
+	return (size_t)(h >> 2);						/* 4-byte header, uncompressed */
+}
+
 size_t
 numeric_image_to_varlena(uint64_t image, unsigned char *out)
 {
@@ -156,6 +179,14 @@ heap_tuple_size(int ncols, const strom_column_input *cols, uint32_t row, size_t 
 	{
 		if (is_null(cols[i], row))
 			continue;
+		if (is_varlena_raw(cols[i]))
+		{
+			const unsigned char *datum = ((const unsigned char *const *)cols[i].values)[row];
+			if (!(datum[0] & 0x01))
+				off = STROM_TYPEALIGN(4, off);		/* a 4-byte header is int-aligned */
+			off += varlena_raw_size(datum);
+			continue;
+		}
 		if (is_varlena_numeric(cols[i]))
 		{
 			/* short varlena header: no alignment padding */
@@ -197,6 +228,16 @@ heap_tuple_form(char *dest, int ncols, const strom_column_input *cols, uint32_t 
 			continue;
 		if (hasnull)
 			htup->t_bits[i >> 3] |= (cl_uchar)(1 << (i & 7));
+		if (is_varlena_raw(cols[i]))
+		{
+			const unsigned char *datum = ((const unsigned char *const *)cols[i].values)[row];
+			if (!(datum[0] & 0x01))
+				off = STROM_TYPEALIGN(4, off);
+			memcpy(dest + off, datum, varlena_raw_size(datum));
+			off += varlena_raw_size(datum);
+			hasvarwidth = true;
+			continue;
+		}
 		if (is_varlena_numeric(cols[i]))
 		{
 			off += numeric_image_to_varlena(((const uint64_t *)cols[i].values)[row],
@@ -247,7 +288,7 @@ cols_valid(int ncols, const strom_column_input *cols, int format = 0)
 		int l = cols[i].attlen;
 		if (!cols[i].values)
 			return false;
-		if (is_varlena_numeric(cols[i]))
+		if (is_varlena_numeric(cols[i]) || is_varlena_raw(cols[i]))
 		{
 			/* heap tuples only: COLUMN / TUPSLOT carry the 8-byte form */
 			if (format != KDS_FORMAT_ROW && format != KDS_FORMAT_ROW_FLAT)

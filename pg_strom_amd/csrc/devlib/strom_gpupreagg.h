@@ -155,6 +155,44 @@ gpupreagg_f64_unordered(cl_ulong key)
 template <typename T> struct gpupreagg_is_float { static const bool value = false; };
 template <> struct gpupreagg_is_float<cl_double> { static const bool value = true; };
 template <> struct gpupreagg_is_float<cl_float> { static const bool value = true; };
+/*
+ * NUMERIC partials without a scale -- "(psum EXPR)" over a numeric -- are
+ * accumulated in the reference's own 64-bit form (6-bit exponent, sign, 57-bit
+ * mantissa) with pgfn_numeric_add / strom_numeric_cmp, exact or CpuReCheck, as
+ * GPUPREAGG_AGGCALC_PSUM_NUMERIC / _PMINMAX_NUMERIC do (opencl_gpupreagg.h:
+ * 882-900, 965-987).  There is no LDS atomic for that: a compare-and-swap
+ * loop.  (The fixed-point form "(psum EXPR SCALE)" is an int8 accumulator and
+ * takes the integer atomics.)  pg_numeric_t is the only type whose base is
+ * cl_ulong.
+ */
+template <typename T> struct gpupreagg_is_numeric { static const bool value = false; };
+#ifdef STROM_NUMERIC_DEVICE_H
+template <> struct gpupreagg_is_numeric<cl_ulong> { static const bool value = true; };
+/* "no value yet" in a numeric PMIN / PMAX accumulator: minus zero, which no
+ * arithmetic produces (strom_numeric_pack returns plain 0 for a zero mantissa) */
+#define GPUPREAGG_NUMERIC_EMPTY		PG_NUMERIC_SIGN_MASK
+
+template <int OP>
+STROM_DEVICE cl_ulong
+gpupreagg_numeric_combine(cl_ulong acc, cl_ulong v, cl_int *errcode)
+{
+	pg_numeric_t	a, b;
+	a.isnull = b.isnull = false;
+	a.value = acc;
+	b.value = v;
+	if (OP == GPUPREAGG_OP_PSUM)
+	{
+		pg_numeric_t r = pgfn_numeric_add(errcode, a, b);
+		return r.isnull ? acc : r.value;
+	}
+	if (acc == GPUPREAGG_NUMERIC_EMPTY)
+		return v;
+	if (v == GPUPREAGG_NUMERIC_EMPTY)
+		return acc;
+	int		c = strom_numeric_cmp(b, a);
+	return ((OP == GPUPREAGG_OP_PMIN) ? (c < 0) : (c > 0)) ? v : acc;
+}
+#endif
 
 STROM_DEVICE cl_uint gpupreagg_align16(cl_uint v) { return (v + 15u) & ~15u; }
 
@@ -225,11 +263,40 @@ gpupreagg_table_offset(int sec, cl_uint N)
  */
 template <int OP, int AIDX, typename PGT>
 STROM_DEVICE cl_uint
-gpupreagg_lds_accum(char *lds, cl_uint vals_off, cl_uint slot, PGT v)
+gpupreagg_lds_accum(char *lds, cl_uint vals_off, cl_uint slot, PGT v, cl_int *chunk_status = NULL)
 {
 	typedef decltype(v.value) base_t;
 	bool	has = !v.isnull;
 
+#ifdef STROM_NUMERIC_DEVICE_H
+	if (OP != GPUPREAGG_OP_NROWS && gpupreagg_is_numeric<base_t>::value)
+	{
+		/* one retry loop, no inner wait: a lane that lost the race goes round
+		 * again with what the winner stored */
+		cl_ulong   *addr = (cl_ulong *)(lds + vals_off) + slot;
+		if (has)
+		{
+			cl_ulong	cur = __hip_atomic_load(addr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+			for (;;)
+			{
+				cl_int		e2 = StromError_Success;
+				cl_ulong	next = gpupreagg_numeric_combine<OP>(cur, (cl_ulong)v.value, &e2);
+				if (e2 != StromError_Success)
+				{
+					/* the sum left the 64-bit form: the chunk goes back to the CPU */
+					if (chunk_status)
+						STROM_SET_ERROR(chunk_status, e2);
+					break;
+				}
+				if (next == cur ||
+					__hip_atomic_compare_exchange_strong(addr, &cur, next, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
+														 __HIP_MEMORY_SCOPE_WORKGROUP))
+					break;
+			}
+		}
+		return has ? (2u << AIDX) : 0u;
+	}
+#endif
 	if (OP == GPUPREAGG_OP_NROWS)
 	{
 		__hip_atomic_fetch_add((cl_uint *)(lds + vals_off) + slot, has ? (cl_uint)v.value : 0u,
@@ -273,6 +340,10 @@ template <int OP, typename BASE>
 STROM_DEVICE cl_ulong
 gpupreagg_identity(void)
 {
+#ifdef STROM_NUMERIC_DEVICE_H
+	if (gpupreagg_is_numeric<BASE>::value)
+		return (OP == GPUPREAGG_OP_PSUM ? 0UL : GPUPREAGG_NUMERIC_EMPTY);
+#endif
 	if (OP == GPUPREAGG_OP_PMIN)
 		return gpupreagg_is_float<BASE>::value ? 0xffffffffffffffffUL : 0x7fffffffffffffffUL;
 	if (OP == GPUPREAGG_OP_PMAX)
@@ -285,6 +356,14 @@ template <int OP, typename BASE>
 STROM_DEVICE cl_ulong
 gpupreagg_merge8(cl_ulong a, cl_ulong b)
 {
+#ifdef STROM_NUMERIC_DEVICE_H
+	if (gpupreagg_is_numeric<BASE>::value)
+	{
+		/* (callers that must see a lost sum use gpupreagg_merge8e) */
+		cl_int	ignored = StromError_Success;
+		return gpupreagg_numeric_combine<OP == GPUPREAGG_OP_NROWS ? GPUPREAGG_OP_PSUM : OP>(a, b, &ignored);
+	}
+#endif
 	if (OP == GPUPREAGG_OP_PSUM)
 	{
 		if (gpupreagg_is_float<BASE>::value)
@@ -296,6 +375,18 @@ gpupreagg_merge8(cl_ulong a, cl_ulong b)
 		return (OP == GPUPREAGG_OP_PMIN) ? (a < b ? a : b) : (a > b ? a : b);
 	return (OP == GPUPREAGG_OP_PMIN) ? ((cl_long)a < (cl_long)b ? a : b)
 									 : ((cl_long)a > (cl_long)b ? a : b);
+}
+
+/* the same, reporting a numeric sum that left the 64-bit form */
+template <int OP, typename BASE>
+STROM_DEVICE cl_ulong
+gpupreagg_merge8e(cl_ulong a, cl_ulong b, cl_int *errcode)
+{
+#ifdef STROM_NUMERIC_DEVICE_H
+	if (gpupreagg_is_numeric<BASE>::value)
+		return gpupreagg_numeric_combine<OP == GPUPREAGG_OP_NROWS ? GPUPREAGG_OP_PSUM : OP>(a, b, errcode);
+#endif
+	return gpupreagg_merge8<OP, BASE>(a, b);
 }
 
 /* conservative overflow screen for int8 sums: a partial sum at or beyond
@@ -385,10 +476,11 @@ gpupreagg_dense_row(char *lds, const gpupreagg_dense_ctl *ctl, const gpupreagg_l
 
 #define X(aidx,resno,OP,NAME)														\
 	if (GPUPREAGG_OP_##OP == GPUPREAGG_OP_PSUM &&									\
-		!gpupreagg_is_float<pg_##NAME##_base_t>::value)								\
+		!gpupreagg_is_float<pg_##NAME##_base_t>::value &&							\
+		!gpupreagg_is_numeric<pg_##NAME##_base_t>::value)							\
 		STROM_SET_RECHECK_IF(chunk_status, !av_##aidx.isnull &						\
 							 gpupreagg_int8_near_overflow((cl_long)av_##aidx.value));	\
-	need |= gpupreagg_lds_accum<GPUPREAGG_OP_##OP, aidx>(lds, L.vals_off[aidx], slot, av_##aidx);
+	need |= gpupreagg_lds_accum<GPUPREAGG_OP_##OP, aidx>(lds, L.vals_off[aidx], slot, av_##aidx, chunk_status);
 	GPUPREAGG_AGG_LIST(X)
 #undef X
 	/* flags: read, and only touch the word when something is missing */
@@ -2869,12 +2961,20 @@ gpupreagg_census(const kern_gpupreagg *kgpreagg, const kern_data_store *kds,
 /* ====================================================================== *
  * slabs -> resident table, fixed order; skipped when the chunk failed
  * ====================================================================== */
-extern "C" __global__ void
-__launch_bounds__(256)
-gpupreagg_dense_merge(const kern_gpupreagg *__restrict__ kgpreagg,
-					  const gpupreagg_dense_ctl *__restrict__ ctl,
-					  const char *__restrict__ slabs,
-					  char *__restrict__ table)
+/*
+ * CHECK: compute everything, write nothing, raise the chunk status when a
+ * NUMERIC sum leaves the 64-bit form while slabs are added to each other or to
+ * the table -- the reference discards such a chunk's device result and re-does
+ * it on the CPU (gpupreagg.c:2746-2750), so the table must not have taken part
+ * of it.  Launched in front of the real merge for programs with numeric
+ * partials only; the computation is the same, so the real merge cannot fail.
+ */
+template <bool CHECK>
+__device__ __forceinline__ void
+gpupreagg_dense_merge_body(kern_gpupreagg *__restrict__ kgpreagg,
+						   const gpupreagg_dense_ctl *__restrict__ ctl,
+						   const char *__restrict__ slabs,
+						   char *__restrict__ table)
 {
 	/*
 	 * 256 threads = GL lanes along consecutive groups (coalesced slab
@@ -2892,6 +2992,7 @@ gpupreagg_dense_merge(const kern_gpupreagg *__restrict__ kgpreagg,
 	size_t		slab_bytes = ctl->slab_bytes;
 	cl_uint	   *t_flags = (cl_uint *)table;
 	cl_uint		WS = 1;
+	cl_int		merr = StromError_Success;
 
 	if (kgpreagg->status != StromError_Success)
 		return;
@@ -2945,10 +3046,10 @@ gpupreagg_dense_merge(const kern_gpupreagg *__restrict__ kgpreagg,
 					if (GPUPREAGG_OP_##OP == GPUPREAGG_OP_NROWS)								\
 						acc += ((const cl_uint *)(slab + s_vals))[lgid];						\
 					else if (((const gpupreagg_flags_t *)slab)[lgid] & (2u << aidx))			\
-						acc = gpupreagg_merge8<GPUPREAGG_OP_##OP == GPUPREAGG_OP_NROWS			\
+						acc = gpupreagg_merge8e<GPUPREAGG_OP_##OP == GPUPREAGG_OP_NROWS			\
 											   ? GPUPREAGG_OP_PSUM : GPUPREAGG_OP_##OP,			\
 											   pg_##NAME##_base_t>								\
-							(acc, ((const cl_ulong *)(slab + s_vals))[lgid]);					\
+							(acc, ((const cl_ulong *)(slab + s_vals))[lgid], &merr);			\
 				}																				\
 			}																					\
 			red_val[threadIdx.x] = acc;															\
@@ -2960,9 +3061,9 @@ gpupreagg_dense_merge(const kern_gpupreagg *__restrict__ kgpreagg,
 					cl_ulong o = red_val[threadIdx.x + s * GL];									\
 					red_val[threadIdx.x] = (GPUPREAGG_OP_##OP == GPUPREAGG_OP_NROWS				\
 						? red_val[threadIdx.x] + o												\
-						: gpupreagg_merge8<GPUPREAGG_OP_##OP == GPUPREAGG_OP_NROWS				\
+						: gpupreagg_merge8e<GPUPREAGG_OP_##OP == GPUPREAGG_OP_NROWS				\
 										   ? GPUPREAGG_OP_PSUM : GPUPREAGG_OP_##OP,				\
-										   pg_##NAME##_base_t>(red_val[threadIdx.x], o));		\
+										   pg_##NAME##_base_t>(red_val[threadIdx.x], o, &merr));	\
 				}																				\
 				__syncthreads();																\
 			}																					\
@@ -2970,22 +3071,50 @@ gpupreagg_dense_merge(const kern_gpupreagg *__restrict__ kgpreagg,
 			{																					\
 				acc = red_val[threadIdx.x];														\
 				if (GPUPREAGG_OP_##OP == GPUPREAGG_OP_NROWS)									\
-					t_vals[gid] += acc;															\
+				{																				\
+					if (!CHECK)																	\
+						t_vals[gid] += acc;														\
+				}																				\
 				else																			\
-					t_vals[gid] = (had & (2u << aidx))											\
-						? gpupreagg_merge8<GPUPREAGG_OP_##OP == GPUPREAGG_OP_NROWS				\
+				{																				\
+					cl_ulong merged = (had & (2u << aidx))										\
+						? gpupreagg_merge8e<GPUPREAGG_OP_##OP == GPUPREAGG_OP_NROWS				\
 										   ? GPUPREAGG_OP_PSUM : GPUPREAGG_OP_##OP,				\
-										   pg_##NAME##_base_t>(t_vals[gid], acc)				\
+										   pg_##NAME##_base_t>(t_vals[gid], acc, &merr)			\
 						: acc;																	\
+					if (!CHECK)																	\
+						t_vals[gid] = merged;													\
+				}																				\
 			}																					\
 			__syncthreads();																	\
 		}
 		GPUPREAGG_AGG_LIST(X)
 #undef X
-		if (valid && stripe == 0 && flags != 0)
+		if (!CHECK && valid && stripe == 0 && flags != 0)
 			t_flags[gid] = had | flags;
 	}
+	if (CHECK && __ballot(merr != StromError_Success) != 0 && (threadIdx.x & 63) == 0)
+		atomicMax(&kgpreagg->status, StromError_CpuReCheck);
 }
+
+extern "C" __global__ void
+__launch_bounds__(256)
+gpupreagg_dense_merge(kern_gpupreagg *kgpreagg, const gpupreagg_dense_ctl *ctl,
+					  const char *slabs, char *table)
+{
+	gpupreagg_dense_merge_body<false>(kgpreagg, ctl, slabs, table);
+}
+
+#if defined(GPUPREAGG_NUMERIC_AGGS) && GPUPREAGG_NUMERIC_AGGS
+extern "C" __global__ void
+__launch_bounds__(256)
+gpupreagg_dense_merge_check(kern_gpupreagg *kgpreagg, const gpupreagg_dense_ctl *ctl,
+							const char *slabs, char *table)
+{
+	gpupreagg_dense_merge_body<true>(kgpreagg, ctl, slabs, table);
+}
+#endif
+
 
 #endif	/* !GPUPREAGG_HASHED */
 

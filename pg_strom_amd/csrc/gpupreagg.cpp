@@ -77,6 +77,9 @@ struct strom_gpupreagg {
 	int					reg_groups = 0;		/* 1: register accumulators, 2: lane-private LDS, 0: LDS atomics */
 	/* packed accumulators (gpupreagg_packed_column): what the generated code says
 	 * about every aggregate, and the launch geometry per role count */
+	/* a partial accumulated in the 64-bit numeric form (compare-and-swap in LDS,
+	 * checked merge): LDS-atomics kernel only, one replica, no RCCL SUM */
+	bool				numeric_aggs = false;
 	bool				packable = false;
 	std::vector<int>	pack_kind, pack_attno;
 	struct packed_geom {
@@ -218,6 +221,8 @@ setup_layout(strom_gpupreagg *sess)
 	}
 	if (const char *v = getenv("STROM_GPUPREAGG_NREP"))
 		ctl.nrep = std::max(1, atoi(v));
+	if (sess->numeric_aggs)
+		ctl.nrep = 1;			/* replicas are folded with plain merges: no error path there */
 	/*
 	 * a handful of groups: no LDS atomics at all.  One group (no GROUP BY):
 	 * register accumulators (gpupreagg_reg1_column); up to 32: lane-private
@@ -226,7 +231,7 @@ setup_layout(strom_gpupreagg *sess)
 	 */
 	sess->reg_groups = 0;
 	size_t	priv_bytes = 0;
-	if (ctl.nsplits == 1 && ctl.ngroups <= 32 && !getenv("STROM_GPUPREAGG_NO_REG"))
+	if (ctl.nsplits == 1 && ctl.ngroups <= 32 && !sess->numeric_aggs && !getenv("STROM_GPUPREAGG_NO_REG"))
 	{
 		size_t	priv_budget = 64 * 1024;
 		if (const char *v = getenv("STROM_GPUPREAGG_PRIV_LDS"))
@@ -669,6 +674,22 @@ gpupreagg_launch(strom_task_impl *task, preagg_request req)
 		unsigned gl = 256 / ws;
 		unsigned mgrid = std::min<unsigned>((lctl.ngroups + gl - 1) / gl,
 											(unsigned)dev->prop.multiProcessorCount * 8);
+		if (sess->numeric_aggs)
+		{
+			/* numeric sums may leave the 64-bit form while slabs are added up: find
+			 * out BEFORE the table takes any of it (gpupreagg_dense_merge_body<CHECK>) */
+			int		e3 = 0;
+			hipFunction_t fn_check = prog->get_function(dev, "gpupreagg_dense_merge_check", &e3);
+			if (!fn_check)
+			{
+				task_fail(task, e3);
+				return;
+			}
+			REQ_CHECK(hipModuleLaunchKernel(fn_check, std::max(1u, mgrid), 1, 1, 256, 1, 1, 0,
+											task->stream, args_mrg, nullptr),
+					  "launch gpupreagg merge check");
+			task->pfm.num_kern_exec++;
+		}
 		REQ_CHECK(hipModuleLaunchKernel(fn_merge, std::max(1u, mgrid), 1, 1, 256, 1, 1, 0,
 										task->stream, args_mrg, nullptr),
 				  "launch gpupreagg merge");
@@ -1144,6 +1165,7 @@ gpupreagg_session_new(strom_devprog_key key,
 		/* what the code generator says about packed accumulators (codegen_preagg.cpp) */
 		const char *src = prog->source.c_str();
 		const char *lst = strstr(src, "#define GPUPREAGG_PACK_LIST(X)");
+		sess->numeric_aggs = (strstr(src, "#define GPUPREAGG_NUMERIC_AGGS 1") != nullptr);
 		sess->packable = (strstr(src, "#define GPUPREAGG_PACKABLE 1") != nullptr && lst != nullptr);
 		if (sess->packable)
 		{
@@ -1169,7 +1191,7 @@ gpupreagg_session_new(strom_devprog_key key,
 		sess->quads = atoi(v);
 	strom_retain_devprog_key(key);
 	sess->hashed = hashed;
-	if (hashed && (sess->key_resno.size() > 31 || sess->agg_resno.size() > 30))
+	if (hashed && (sess->key_resno.size() > 31 || sess->agg_resno.size() > 30 || sess->numeric_aggs))
 	{
 		*p_errcode = StromError_BadRequestMessage;
 		strom_gpupreagg_release(sess);
@@ -1715,7 +1737,8 @@ strom_gpupreagg_compact(strom_gpupreagg *sess, const uint32_t *bitmap, size_t nw
 int
 strom::gpupreagg_get_merge_plan(strom_gpupreagg *sess, gpupreagg_merge_plan *plan)
 {
-	if (!sess || sess->hashed || !sess->has_domain || !sess->table || sess->agg_resno.size() > 31)
+	if (!sess || sess->hashed || !sess->has_domain || !sess->table || sess->agg_resno.size() > 31 ||
+		sess->numeric_aggs)				/* (64-bit numerics do not add up with ncclSum: gather the partial rows) */
 		return StromError_BadRequestMessage;
 	memset(&plan->spec, 0, sizeof(plan->spec));
 	plan->spec.ngroups = sess->ctl.ngroups;
@@ -2078,7 +2101,8 @@ strom_gpupreagg_fetch(strom_gpupreagg *sess, kern_data_store *dest, size_t destl
 		for (size_t a = 0; a < sess->agg_resno.size(); a++)
 		{
 			const strom_preagg_target &t = sess->targets[sess->agg_resno[a]];
-			if (t.type_oid != STROM_NUMERICOID || t.kind == STROM_PREAGG_NROWS || !(gflags[g] & (2u << a)))
+			if (t.type_oid != STROM_NUMERICOID || t.scale < 0 || t.kind == STROM_PREAGG_NROWS ||
+				!(gflags[g] & (2u << a)))
 				continue;
 			cl_long v = ((const cl_long *)(host.data() + sess->table_offset(1 + (int)a, N)))[g];
 			cl_ulong img;
@@ -2148,7 +2172,9 @@ strom_gpupreagg_fetch(strom_gpupreagg *sess, kern_data_store *dest, size_t destl
 			else
 			{
 				cl_ulong raw = vals[g];
-				if (t.type_oid == STROM_NUMERICOID)
+				if (t.type_oid == STROM_NUMERICOID && t.scale < 0)
+					values[resno] = raw;			/* accumulated in the 64-bit form itself */
+				else if (t.type_oid == STROM_NUMERICOID)
 				{
 					cl_long v = (cl_long)raw;
 					if (!fixed_to_numeric(v, t.scale, &raw))

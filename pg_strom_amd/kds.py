@@ -39,6 +39,9 @@ SQL_TYPES = {
     # tuples (ROW / ROW_FLAT only); 'values' are the 64-bit images
     "numeric_varlena": (1700, -1, np.uint64),
     "char1": (1042, 1, np.int8),
+    # heap formats only: complete varlena datums (bytes objects), copied verbatim -- numerics of
+    # any magnitude, also those the 64-bit device form cannot hold
+    "numeric_raw": (1700, -1, object),
 }
 
 
@@ -63,7 +66,12 @@ class Column(object):
         self.sqltype = sqltype
         self.type_oid = oid
         self.attlen = attlen
-        self.values = np.ascontiguousarray(values, dtype=dtype)
+        if sqltype == "numeric_raw":
+            # keep the datums and an array of their addresses alive with the column
+            self._datums = [ctypes.create_string_buffer(bytes(v) + b"\0" * 8) for v in values]
+            self.values = np.array([ctypes.addressof(b) for b in self._datums], dtype=np.uint64)
+        else:
+            self.values = np.ascontiguousarray(values, dtype=dtype)
         self.isnull = None
         if isnull is not None:
             self.isnull = np.ascontiguousarray(isnull, dtype=np.uint8)
@@ -78,7 +86,7 @@ def _column_inputs(columns):
     for i, c in enumerate(columns):
         arr[i].type_oid = c.type_oid
         arr[i].attlen = c.attlen
-        arr[i].attalign = c.attlen if c.attlen > 0 else 4
+        arr[i].attalign = c.attlen if c.attlen > 0 else (-1 if c.sqltype == "numeric_raw" else 4)
         arr[i].attbyval = 1 if c.attlen > 0 else 0
         arr[i].values = c.values.ctypes.data
         arr[i].isnull = c.isnull.ctypes.data if c.isnull is not None else None

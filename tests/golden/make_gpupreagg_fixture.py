@@ -117,6 +117,108 @@ def generate():
     return cols
 
 
+def generate_overflow():
+    """gpupreagg_overflow_test (agg_init.sql:122-200): the same seed, columns pinned at the
+    edges of their types -- 32767 / 2147483647 / 9223372036854775807 / 1e38 / 1e308 and
+    21-digit numerics -- so that device partial sums overflow and chunks go back to the CPU"""
+    rng = GlibcRandom(0)
+    rnd = rng.random
+    cols = {k: [] for k in ("id", "key", "smlint_x", "integer_x", "bigint_x", "real_x", "float_x",
+                            "nume_x", "smlsrl_x", "serial_x", "bigsrl_x")}
+    NUM21 = 1000000000000000000000.0          # the literal is numeric, the product float8
+
+    def block(first_id, first_key, mode):
+        sign = {"pos": 1, "neg": -1}.get(mode)
+        for i in range(10001):                 # 10000 stored rows + one discarded evaluation
+            row = {"id": first_id + i, "key": first_key + (i % 10)}
+            if mode in ("pos", "neg"):
+                row["smlint_x"] = None if rnd() > 0.95 else (32767 if sign > 0 else -32768)
+                row["integer_x"] = None if rnd() > 0.95 else (2147483647 if sign > 0 else -2147483648)
+                row["bigint_x"] = None if rnd() > 0.95 else (9223372036854775807 if sign > 0
+                                                             else -9223372036854775808)
+                row["real_x"] = None if rnd() > 0.95 else sign * 1.0e38
+                row["float_x"] = None if rnd() > 0.95 else sign * 1.0e308
+                if rnd() > 0.95:
+                    row["nume_x"] = None
+                else:
+                    v = float8_to_numeric(np.floor(rnd() * NUM21))
+                    row["nume_x"] = v if sign > 0 else v * -1
+                row["smlsrl_x"] = rint(rnd() * (32767 * sign))
+                row["serial_x"] = rint(rnd() * (2147483647 * sign))
+                row["bigsrl_x"] = rint(rnd() * (9223372036854775807 * sign))
+            else:
+                row["smlint_x"] = None if rnd() > 0.95 else rint((rnd() * 2 - 1) * 32767)
+                row["integer_x"] = None if rnd() > 0.95 else rint((rnd() * 2 - 1) * 2147483647)
+                row["bigint_x"] = None if rnd() > 0.95 else rint((rnd() * 2 - 1) * 9223372036854775807)
+                row["real_x"] = None if rnd() > 0.95 else (rnd() * 2 - 1) * 1.0e38
+                row["float_x"] = None if rnd() > 0.95 else (rnd() * 2 - 1) * 1.0e308
+                row["nume_x"] = None if rnd() > 0.95 else float8_to_numeric(np.floor((rnd() * 2 - 1) * NUM21))
+                row["smlsrl_x"] = rint((rnd() * 2 - 1) * 32767)
+                row["serial_x"] = rint((rnd() * 2 - 1) * 2147483647)
+                row["bigsrl_x"] = rint((rnd() * 2 - 1) * 9223372036854775807)
+            if i < 10000:
+                for k in cols:
+                    cols[k].append(row[k])
+
+    block(1, 1, "pos")
+    block(10001, 11, "neg")
+    block(20001, 21, "mix")
+    for i in range(10000):
+        cols["id"].append(30001 + i)
+        for k in ("key", "smlint_x", "integer_x", "bigint_x", "real_x", "float_x", "nume_x"):
+            cols[k].append(None)
+        for k in ("smlsrl_x", "serial_x", "bigsrl_x"):
+            cols[k].append(0)
+    return cols
+
+
+def overflow_to_arrays(cols):
+    out = {}
+
+    def intcol(name, dtype):
+        out[name] = np.array([0 if v is None else v for v in cols[name]], dtype=dtype)
+        out[name + "_isnull"] = np.array([v is None for v in cols[name]], dtype=np.uint8)
+
+    for name, dt in (("id", np.int32), ("key", np.int32), ("smlint_x", np.int16), ("integer_x", np.int32),
+                     ("bigint_x", np.int64), ("smlsrl_x", np.int16), ("serial_x", np.int32), ("bigsrl_x", np.int64)):
+        intcol(name, dt)
+    out["real_x"] = np.array([0.0 if v is None else np.float32(v) for v in cols["real_x"]], dtype=np.float32)
+    out["real_x_isnull"] = np.array([v is None for v in cols["real_x"]], dtype=np.uint8)
+    out["float_x"] = np.array([0.0 if v is None else v for v in cols["float_x"]], dtype=np.float64)
+    out["float_x_isnull"] = np.array([v is None for v in cols["float_x"]], dtype=np.uint8)
+    out["nume_x"] = np.array(["" if v is None else format(v, "f") for v in cols["nume_x"]])
+    out["nume_x_isnull"] = np.array([v is None for v in cols["nume_x"]], dtype=np.uint8)
+    assert len(out["id"]) == 40000
+    return out
+
+
+def verify_overflow(arr, expected):
+    """known answers of expected/overflow_agg.out (stock PostgreSQL) for the regenerated table"""
+    ok = True
+    key, keyn = arr["key"], arr["key_isnull"]
+    for q in expected:
+        m = re.match(r"select key, (count|sum)\((smlint_x|integer_x|bigint_x|nume_x|serial_x)\)::", q["sql"])
+        if not m or q.get("error"):
+            continue
+        func, col = m.group(1), m.group(2)
+        for row in q["rows"]:
+            if row[0] == "":
+                continue
+            sel = (key == int(row[0])) & (keyn == 0) & (arr[col + "_isnull"] == 0)
+            if func == "count":
+                got = int(sel.sum())
+            elif col == "nume_x":
+                got = sum((Decimal(x) for x in arr[col][sel]), Decimal(0))
+            else:
+                got = sum(int(x) for x in arr[col][sel])
+            good = (str(got) == row[1])
+            ok &= good
+            if not good:
+                print("  MISMATCH %s(%s) key %s: %s expected %s" % (func, col, row[0], got, row[1]))
+        print("  %-5s(%-9s) per key: %s" % (func, col, "ok" if ok else "MISMATCH"))
+    return ok
+
+
 def to_arrays(cols):
     out = {}
     n = len(cols["id"])
@@ -174,7 +276,8 @@ def verify(arr):
 
 
 def parse_out(path):
-    """psql regression output -> [{sql, columns, rows}]"""
+    """psql regression output -> [{sql, columns, rows}] (+ "error": text for a query that
+    ended in ERROR, + "notices": [...] for NOTICE lines printed in front of the result)"""
     lines = open(path).read().split("\n")
     res = []
     i = 0
@@ -182,6 +285,15 @@ def parse_out(path):
         ln = lines[i]
         if ln.lower().startswith("select"):
             sql = ln.strip()
+            notices = []
+            while i + 1 < len(lines) and lines[i + 1].startswith("NOTICE:"):
+                notices.append(lines[i + 1][len("NOTICE:"):].strip())
+                i += 1
+            if i + 1 < len(lines) and lines[i + 1].startswith("ERROR:"):
+                res.append({"sql": re.sub(r"\s+", " ", sql), "columns": [], "rows": [],
+                            "error": lines[i + 1][len("ERROR:"):].strip()})
+                i += 2
+                continue
             header = lines[i + 1]
             sep = lines[i + 2] if i + 2 < len(lines) else ""
             if not re.match(r"^-+(\+-+)*$", sep):
@@ -193,7 +305,10 @@ def parse_out(path):
             while j < len(lines) and not re.match(r"^\(\d+ rows?\)$", lines[j]):
                 rows.append([c.strip() for c in lines[j].split("|")])
                 j += 1
-            res.append({"sql": re.sub(r"\s+", " ", sql), "columns": columns, "rows": rows})
+            rec = {"sql": re.sub(r"\s+", " ", sql), "columns": columns, "rows": rows}
+            if notices:
+                rec["notices"] = notices
+            res.append(rec)
             i = j
         i += 1
     return res
@@ -207,9 +322,15 @@ def main():
         sys.exit(1)
     np.savez_compressed(os.path.join(HERE, "gpupreagg_test.npz"), **arr)
     expected = {}
-    for suite in ("nogrp_agg", "group_agg", "where_agg", "zero_agg"):
+    for suite in ("nogrp_agg", "group_agg", "where_agg", "zero_agg", "recheck_agg", "overflow_agg"):
         expected[suite] = parse_out(os.path.join(REF, "expected", suite + ".out"))
         print("  %s: %d queries" % (suite, len(expected[suite])))
+    print("regenerating gpupreagg_overflow_test ...")
+    oarr = overflow_to_arrays(generate_overflow())
+    if not verify_overflow(oarr, expected["overflow_agg"]):
+        print("generator does not reproduce the reference's overflow fixture", file=sys.stderr)
+        sys.exit(1)
+    np.savez_compressed(os.path.join(HERE, "gpupreagg_overflow_test.npz"), **oarr)
     with open(os.path.join(HERE, "expected_agg.json"), "w") as fp:
         json.dump(expected, fp, indent=0)
     print("written")
