@@ -326,8 +326,9 @@ strom_hashjoin_table *strom_hashjoin_table_create(strom_devprog_key key,
 												  const kern_multihash *kmhash, size_t length,
 												  int dindex, int *p_errcode);
 void		strom_hashjoin_table_release(strom_hashjoin_table *tbl);
-/* index form chosen for inner relation 'depth' (1-based): mode 1 = direct
- * (dense integer key), 0 = hashed */
+/* index form chosen for inner relation 'depth' (1-based): mode 1 = direct (one dense
+ * integer-like key), 2 = keyed (one key of any type: 16-byte slots that carry the key
+ * image), 0 = hashed (several keys) */
 int			strom_hashjoin_table_info(strom_hashjoin_table *tbl, int depth,
 									  int *p_mode, uint32_t *p_nslots,
 									  int *p_unique, uint32_t *p_nentries);

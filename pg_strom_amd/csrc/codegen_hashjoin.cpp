@@ -258,7 +258,9 @@ strom_codegen_gpuhashjoin(const char *spec, strom_codegen_result *out, int *p_nr
 			 * and, when the keys are unique too, the entry is not read at all
 			 * -- the probe then costs one 4-byte slot read per outer row.
 			 */
-			bool	direct_ok = (R.keys.size() == 1 && type_is_intlike(R.keys[0].type_oid));
+			/* ... and so does a KEYED index (one key of any type: a slot per distinct
+			 * key image, found by comparing images inside the 16-byte slot) */
+			bool	direct_ok = (R.keys.size() == 1);
 			snprintf(tmp, sizeof(tmp),
 					 "%scl_uint hash_%d;\n"
 					 "%sconst bool direct_%d = %s;\n"
@@ -268,7 +270,7 @@ strom_codegen_gpuhashjoin(const char *spec, strom_codegen_result *out, int *p_nr
 					 "%s     off_%d = next_%d)\n%s{\n",
 					 indent.c_str(), d,
 					 indent.c_str(), d,
-					 direct_ok ? ("(ALL_SINGLE || hjidx->rel[" + std::to_string(d - 1) + "].mode == HASHJOIN_MODE_DIRECT)").c_str() : "false",
+					 direct_ok ? ("(ALL_SINGLE || hjidx->rel[" + std::to_string(d - 1) + "].mode != HASHJOIN_MODE_HASH)").c_str() : "false",
 					 indent.c_str(), d, d, d - 1,
 					 indent.c_str(), d, d - 1, d, R.keys.size(), d, d,
 					 indent.c_str(), d,

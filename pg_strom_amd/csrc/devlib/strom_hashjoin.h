@@ -17,7 +17,14 @@
  *               slots[key - min] -> first entry.  4 bytes per key value:
  *               a 1e6-key dimension is a 4 MB table that lives in L2; no
  *               hashing, no key compare, no touch of the 48-byte entries.
- *       HASH    anything else: slots[mix(key images) & mask], entry->hash
+ *       KEYED   one key of any type and spread (sparse int8, numeric, float):
+ *               open addressing over 16-byte slots {first entry, tag, key
+ *               image}, ONE slot per distinct key -- a probe is one 16-byte
+ *               load that carries the key to compare with, so a lookup of a
+ *               unique key touches no 48-byte entry at all (the HASH form read
+ *               one per candidate: 7.8 ms per 1e8 rows for C3; this one ~1 ms);
+ *               the chain hanging off a slot holds exactly that key's entries.
+ *       HASH    several keys: slots[mix(key images) & mask], entry->hash
  *               rewritten to the same mix, chain walked with key compare.
  *   - result records keep the reference's meaning: {outer_row + 1, byte
  *     offset of the matched kern_hashentry inside its kern_hashtable}.
@@ -48,11 +55,19 @@
 
 #define HASHJOIN_MODE_HASH		0
 #define HASHJOIN_MODE_DIRECT	1
+#define HASHJOIN_MODE_KEYED		2
+
+/* KEYED slot: { x = offset of the key's first entry, y = tag (0 empty, 1 being
+ * written by the index build, 2 ready), z|w = the key's canonical 64-bit image } */
+typedef cl_uint hashjoin_keyed_slot __attribute__((ext_vector_type(4)));
+#define HASHJOIN_KEYED_EMPTY	0u
+#define HASHJOIN_KEYED_BUSY		1u
+#define HASHJOIN_KEYED_READY	2u
 
 /* probe index; gpuhashjoin.cpp mirrors these structs */
 struct hashjoin_index_rel {
 	cl_uint		mode;
-	cl_uint		nslots;			/* HASH: power of two; DIRECT: key range */
+	cl_uint		nslots;			/* HASH / KEYED: power of two; DIRECT: key range */
 	cl_long		key_min;
 	cl_uint		unique;			/* no chain longer than one entry */
 	cl_uint		slots_off;		/* bytes from the index base to cl_uint slots[] */
@@ -131,13 +146,29 @@ hashjoin_first(const hashjoin_index *hjidx, int d0, const cl_ulong *images, int 
 	}
 	cl_uint h = hashjoin_hash_images(images, nkeys);
 	*p_hash = h;
+	if (ir->mode == HASHJOIN_MODE_KEYED)
+	{
+		const hashjoin_keyed_slot *kslots = (const hashjoin_keyed_slot *)slots;
+		cl_uint		mask = ir->nslots - 1;
+		cl_uint		lo = (cl_uint)images[0], hi = (cl_uint)(images[0] >> 32);
+		/* load factor <= 1/2: 1.5 slots on average; an empty slot ends the search */
+		for (cl_uint p = h & mask, n = 0; n <= mask; p = (p + 1) & mask, n++)
+		{
+			hashjoin_keyed_slot s = kslots[p];			/* one 16-byte load: one L2 request */
+			if (s.y == HASHJOIN_KEYED_EMPTY)
+				return 0;
+			if (s.z == lo && s.w == hi)
+				return s.x;
+		}
+		return 0;
+	}
 	return slots[h & (ir->nslots - 1)];
 }
 
 STROM_DEVICE bool
 hashjoin_candidate(const hashjoin_index *hjidx, int d0, const kern_hashentry *ent, cl_uint hash)
 {
-	return hjidx->rel[d0].mode == HASHJOIN_MODE_DIRECT || ent->hash == hash;
+	return hjidx->rel[d0].mode != HASHJOIN_MODE_HASH || ent->hash == hash;
 }
 
 /* generated */
@@ -300,15 +331,61 @@ hashjoin_build_index_kernel(kern_multihash *kmhash, int depth, hashjoin_index *h
 			else
 			{
 				cl_uint	h = 0, idx;
+				cl_uint *head;				/* where this key's chain starts */
 				if (ir->mode == HASHJOIN_MODE_DIRECT)
+				{
 					idx = (cl_uint)((cl_long)images[0] - ir->key_min);
+					head = &slots[idx];
+				}
+				else if (ir->mode == HASHJOIN_MODE_KEYED)
+				{
+					/*
+					 * find or claim THE slot of this key.  One loop without an inner
+					 * wait: a thread that meets a slot another one is filling goes
+					 * round again (the filler may be a lane of its own wave, which
+					 * publishes in the same pass through the loop body)
+					 */
+					cl_uint	   *words = slots;			/* 4 words per slot */
+					cl_uint		mask = ir->nslots - 1;
+					cl_uint		lo = (cl_uint)images[0], hi = (cl_uint)(images[0] >> 32);
+					h = hashjoin_hash_images(images, nkeys);
+					idx = h & mask;
+					for (;;)
+					{
+						cl_uint	   *slot = words + 4 * (size_t)idx;
+						cl_uint		tag = __hip_atomic_load(&slot[1], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+						if (tag == HASHJOIN_KEYED_EMPTY)
+						{
+							cl_uint expect = HASHJOIN_KEYED_EMPTY;
+							if (__hip_atomic_compare_exchange_strong(&slot[1], &expect, HASHJOIN_KEYED_BUSY,
+																	 __ATOMIC_ACQUIRE, __ATOMIC_RELAXED,
+																	 __HIP_MEMORY_SCOPE_AGENT))
+							{
+								slot[2] = lo;
+								slot[3] = hi;
+								__hip_atomic_store(&slot[1], HASHJOIN_KEYED_READY, __ATOMIC_RELEASE,
+												   __HIP_MEMORY_SCOPE_AGENT);
+								break;
+							}
+							continue;				/* lost the race: look at the slot again */
+						}
+						if (tag == HASHJOIN_KEYED_BUSY)
+							continue;
+						if (__hip_atomic_load(&slot[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == lo &&
+							__hip_atomic_load(&slot[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == hi)
+							break;					/* this key's slot */
+						idx = (idx + 1) & mask;		/* another key lives here */
+					}
+					head = words + 4 * (size_t)idx;
+				}
 				else
 				{
 					h = hashjoin_hash_images(images, nkeys);
 					idx = h & (ir->nslots - 1);
+					head = &slots[idx];
 				}
 				ent->hash = h;
-				cl_uint prev = atomicExch(&slots[idx], off);
+				cl_uint prev = atomicExch(head, off);
 				ent->next = prev;
 				if (prev != 0)
 					ir->unique = 0;		/* benign race: every writer stores 0 */
@@ -577,7 +654,7 @@ gpuhashjoin_main(kern_hashjoin *__restrict__ khashjoin,
 	 */
 	bool	all_single = true;
 	for (cl_uint d = 0; d < hjidx->nrels; d++)
-		all_single = all_single && (hjidx->rel[d].mode == HASHJOIN_MODE_DIRECT && hjidx->rel[d].unique != 0);
+		all_single = all_single && (hjidx->rel[d].mode != HASHJOIN_MODE_HASH && hjidx->rel[d].unique != 0);
 	if (kds->format == KDS_FORMAT_COLUMN)
 	{
 		if (all_single)
@@ -596,28 +673,50 @@ gpuhashjoin_main(kern_hashjoin *__restrict__ khashjoin,
 /* ====================================================================== *
  * fast probe: DIRECT index, unique keys, COLUMN outer, no row map
  * ====================================================================== */
+/* quads per thread and tile of the LDS-slots variant: with the slot array in
+ * LDS only ONE 256-thread work-group fits a CU, so a thread keeps 32 rows of
+ * column data in flight instead of 8 to cover the HBM latency */
+#define HASHJOIN_LDS_QUADS		8
+#define HASHJOIN_MAX_QUADS		(HASHJOIN_LDS_QUADS > HASHJOIN_QUADS ? HASHJOIN_LDS_QUADS : HASHJOIN_QUADS)
+/* matches are appended to the stage in groups of quads that fit it */
+#define HASHJOIN_STAGE_ENTRIES	HASHJOIN_STAGE
+#define HASHJOIN_APPEND_QUADS(Q)	((Q) * HASHJOIN_BLOCK * 4 <= HASHJOIN_STAGE ? (Q)		\
+									 : HASHJOIN_STAGE / (HASHJOIN_BLOCK * 4))
+
 struct hashjoin_stage {
-	cl_int		entries[HASHJOIN_STAGE][2];
-	cl_uint		wave_total[HASHJOIN_QUADS][HASHJOIN_NWAVES];
+	cl_int		entries[HASHJOIN_STAGE_ENTRIES][2];
+	cl_uint		wave_total[HASHJOIN_MAX_QUADS][HASHJOIN_NWAVES];
 	cl_uint		flush_base;
 };
 
+template <int QUADS>
 struct hashjoin_column_tile {
 #define X(attno,colidx,NAME)											\
-	pg_##NAME##_base_t	v_##attno[HASHJOIN_QUADS][4];					\
-	cl_uint				nn_##attno[HASHJOIN_QUADS];
+	pg_##NAME##_base_t	v_##attno[QUADS][4];							\
+	cl_uint				nn_##attno[QUADS];
 	STROM_KVAR_LIST(X)
 #undef X
 	int __dummy;
 };
 
-extern "C" __global__ void
-__launch_bounds__(HASHJOIN_BLOCK)
-gpuhashjoin_main_fast(kern_hashjoin *khashjoin,
-					  const hashjoin_index *hjidx,
-					  const kern_data_store *kds)
+/*
+ * LDS_SLOTS: "inner hash staged in LDS" (BASELINE configs[2]; the reference
+ * stages its CRC table there, opencl_hashjoin.h:284-416).  A DIRECT index of
+ * up to ~30 k key values -- date, nation, category dimensions -- is copied
+ * into the work-group's LDS once and every probe is a ds_read: no L2 request
+ * at all, the kernel streams at the rate of its column reads and result
+ * writes.  The L2-resident form below it is bound by the L2 request rate
+ * (~2e11 random 4-byte reads per second chip-wide) whatever the table size.
+ */
+template <bool LDS_SLOTS, int QUADS>
+__device__ __forceinline__ void
+gpuhashjoin_main_fast_body(kern_hashjoin *khashjoin,
+						   const hashjoin_index *hjidx,
+						   const kern_data_store *kds)
 {
 	__shared__ hashjoin_stage stage;
+	extern __shared__ __attribute__((aligned(16))) cl_uint lds_slots[];
+	const cl_uint TILE_ROWS = HASHJOIN_BLOCK * 4 * QUADS;
 	const kern_parambuf *kparams = KERN_HASHJOIN_PARAMBUF(khashjoin);
 	kern_resultbuf *kresults = KERN_HASHJOIN_RESULTBUF(khashjoin);
 	const kern_coldir *coldir = KERN_DATA_STORE_COLDIR(kds);
@@ -627,7 +726,7 @@ gpuhashjoin_main_fast(kern_hashjoin *khashjoin,
 	cl_uint		key_range = ir->nslots;
 	cl_uint		nitems = kds->nitems;
 	cl_uint		nrooms = kresults->nrooms;
-	cl_uint		ntiles = (nitems + HASHJOIN_TILE_ROWS - 1) / HASHJOIN_TILE_ROWS;
+	cl_uint		ntiles = (nitems + TILE_ROWS - 1) / TILE_ROWS;
 	cl_uint		lane = threadIdx.x & (STROM_WAVE - 1);
 	cl_uint		wave = threadIdx.x / STROM_WAVE;
 	cl_int		chunk_error = StromError_Success;
@@ -646,22 +745,32 @@ gpuhashjoin_main_fast(kern_hashjoin *khashjoin,
 #define X(attno,colidx,NAME)	any_nulls = any_nulls || (nul_##attno != NULL);
 	STROM_KVAR_LIST(X)
 #undef X
+	if (LDS_SLOTS)
+	{
+		/* the whole slot array into LDS, 16 bytes per thread and turn (the
+		 * host launches this variant only when it fits: gpuhashjoin.cpp) */
+		typedef cl_uint v4_t __attribute__((ext_vector_type(4)));
+		cl_uint		nvec = (key_range + 3) / 4;		/* the array is padded to 256 bytes */
+		for (cl_uint i = threadIdx.x; i < nvec; i += HASHJOIN_BLOCK)
+			((v4_t *)lds_slots)[i] = ((const v4_t *)slots)[i];
+		__syncthreads();
+	}
 
 	for (cl_uint tile = blockIdx.x; tile < ntiles; tile += gridDim.x)
 	{
-		cl_uint		tile_base = tile * HASHJOIN_TILE_ROWS;
-		bool		full_tile = (tile_base + HASHJOIN_TILE_ROWS <= nitems);
-		hashjoin_column_tile T;
-		cl_uint		match[HASHJOIN_QUADS][4];
-		cl_uint		my_prefix[HASHJOIN_QUADS];
+		cl_uint		tile_base = tile * TILE_ROWS;
+		bool		full_tile = (tile_base + TILE_ROWS <= nitems);
+		hashjoin_column_tile<QUADS> T;
+		cl_uint		match[QUADS][4];
+		cl_uint		my_prefix[QUADS];
 #if HASHJOIN_FAST_OUTER_QUAL
-		cl_int		qual_error[HASHJOIN_QUADS][4];
+		cl_int		qual_error[QUADS][4];
 #endif
 
 		if (full_tile && !any_nulls)
 		{
 #pragma unroll
-			for (int k = 0; k < HASHJOIN_QUADS; k++)
+			for (int k = 0; k < QUADS; k++)
 			{
 				cl_uint	row0 = tile_base + (k * HASHJOIN_BLOCK + threadIdx.x) * 4;
 #define X(attno,colidx,NAME)													\
@@ -675,7 +784,7 @@ gpuhashjoin_main_fast(kern_hashjoin *khashjoin,
 		else if (full_tile)
 		{
 #pragma unroll
-			for (int k = 0; k < HASHJOIN_QUADS; k++)
+			for (int k = 0; k < QUADS; k++)
 			{
 				cl_uint	row0 = tile_base + (k * HASHJOIN_BLOCK + threadIdx.x) * 4;
 #define X(attno,colidx,NAME)													\
@@ -689,7 +798,7 @@ gpuhashjoin_main_fast(kern_hashjoin *khashjoin,
 		else
 		{
 #pragma unroll
-			for (int k = 0; k < HASHJOIN_QUADS; k++)
+			for (int k = 0; k < QUADS; k++)
 			{
 				cl_uint	row0 = tile_base + (k * HASHJOIN_BLOCK + threadIdx.x) * 4;
 #define X(attno,colidx,NAME)													\
@@ -702,7 +811,7 @@ gpuhashjoin_main_fast(kern_hashjoin *khashjoin,
 		}
 		/* every slot read of the tile is issued before the first is used */
 #pragma unroll
-		for (int k = 0; k < HASHJOIN_QUADS; k++)
+		for (int k = 0; k < QUADS; k++)
 		{
 			cl_uint	row0 = tile_base + (k * HASHJOIN_BLOCK + threadIdx.x) * 4;
 #pragma unroll
@@ -739,7 +848,7 @@ gpuhashjoin_main_fast(kern_hashjoin *khashjoin,
 				{
 					cl_ulong idx = (cl_ulong)(key - key_min);
 					if (idx < key_range)
-						match[k][j] = slots[idx];
+						match[k][j] = (LDS_SLOTS ? lds_slots[idx] : slots[idx]);
 				}
 				if (errcode != StromError_Success)
 				{
@@ -750,7 +859,7 @@ gpuhashjoin_main_fast(kern_hashjoin *khashjoin,
 		}
 #if HASHJOIN_FAST_OUTER_QUAL
 #pragma unroll
-		for (int k = 0; k < HASHJOIN_QUADS; k++)
+		for (int k = 0; k < QUADS; k++)
 		{
 #pragma unroll
 			for (int j = 0; j < 4; j++)
@@ -763,7 +872,13 @@ gpuhashjoin_main_fast(kern_hashjoin *khashjoin,
 			}
 		}
 #endif
-		if (fill + HASHJOIN_TILE_ROWS > HASHJOIN_STAGE)
+		const int	GQ = HASHJOIN_APPEND_QUADS(QUADS);
+		static_assert(HASHJOIN_APPEND_QUADS(QUADS) >= 1 && QUADS % HASHJOIN_APPEND_QUADS(QUADS) == 0,
+					  "the LDS stage takes whole groups of quads");
+#pragma unroll
+		for (int g0 = 0; g0 < QUADS; g0 += GQ)
+		{
+		if (fill + GQ * HASHJOIN_BLOCK * 4 > HASHJOIN_STAGE_ENTRIES)
 		{
 			/* flush: one reservation, contiguous store */
 			if (fill > 0)
@@ -791,7 +906,7 @@ gpuhashjoin_main_fast(kern_hashjoin *khashjoin,
 			fill = 0;
 		}
 #pragma unroll
-		for (int k = 0; k < HASHJOIN_QUADS; k++)
+		for (int k = g0; k < g0 + GQ; k++)
 		{
 			cl_uint	prefix = 0, total = 0;
 #pragma unroll
@@ -808,7 +923,7 @@ gpuhashjoin_main_fast(kern_hashjoin *khashjoin,
 		__syncthreads();
 		cl_uint		appended = 0;
 #pragma unroll
-		for (int k = 0; k < HASHJOIN_QUADS; k++)
+		for (int k = g0; k < g0 + GQ; k++)
 		{
 			cl_uint	before = 0, all = 0;
 #pragma unroll
@@ -834,6 +949,7 @@ gpuhashjoin_main_fast(kern_hashjoin *khashjoin,
 		}
 		__syncthreads();
 		fill += appended;
+		}
 	}
 	if (fill > 0)
 	{
@@ -861,6 +977,24 @@ gpuhashjoin_main_fast(kern_hashjoin *khashjoin,
 		if (strom_lane_id() == 0 && worst != StromError_Success)
 			atomicMax(&kresults->errcode, worst);
 	}
+}
+
+extern "C" __global__ void
+__launch_bounds__(HASHJOIN_BLOCK)
+gpuhashjoin_main_fast(kern_hashjoin *khashjoin,
+					  const hashjoin_index *hjidx,
+					  const kern_data_store *kds)
+{
+	gpuhashjoin_main_fast_body<false, HASHJOIN_QUADS>(khashjoin, hjidx, kds);
+}
+
+extern "C" __global__ void
+__launch_bounds__(HASHJOIN_BLOCK)
+gpuhashjoin_main_fast_lds(kern_hashjoin *khashjoin,
+						  const hashjoin_index *hjidx,
+						  const kern_data_store *kds)
+{
+	gpuhashjoin_main_fast_body<true, HASHJOIN_LDS_QUADS>(khashjoin, hjidx, kds);
 }
 
 /* ====================================================================== *

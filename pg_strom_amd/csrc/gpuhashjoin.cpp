@@ -197,19 +197,27 @@ strom_hashjoin_table_create(strom_devprog_key key, const kern_multihash *kmhash,
 				ir.key_min = h_stats[t].key_min;
 			}
 		}
+		size_t	slot_bytes = sizeof(cl_uint);
 		if (!direct)
 		{
 			cl_ulong slots = 1024;
 			while (slots < 2 * n)
 				slots <<= 1;
-			ir.mode = 0;
+			/* one key: a KEYED index (16-byte slots that carry the key image, one per
+			 * distinct key); several keys: the HASH index over the entries' chains */
+			char	def[48];
+			snprintf(def, sizeof(def), "#define HASHJOIN_NKEYS_%d 1\n", t + 1);
+			bool	keyed = (strstr(prog->source.c_str(), def) != nullptr && !getenv("STROM_HASHJOIN_NO_KEYED"));
+			ir.mode = (keyed ? 2 : 0);
 			ir.nslots = (cl_uint)slots;
 			ir.key_min = 0;
+			if (keyed)
+				slot_bytes = 16;
 		}
 		ir.unique = 1;
 		ir.nentries = (cl_uint)n;
 		ir.slots_off = (cl_uint)off;
-		off += STROM_TYPEALIGN(256, sizeof(cl_uint) * (size_t)ir.nslots);
+		off += STROM_TYPEALIGN(256, slot_bytes * (size_t)ir.nslots);
 	}
 	tbl->index_len = off;
 	tbl->d_index = (char *)dev->pool.alloc(off);
@@ -342,6 +350,27 @@ gpuhashjoin_launch(strom_task_impl *task, hashjoin_request req)
 	if (fn && !strstr(prog->source.c_str(), "#define HASHJOIN_FAST_ELIGIBLE 1"))
 		fn = nullptr;
 	fast = (fn != nullptr);
+	/*
+	 * "inner hash staged in LDS": a DIRECT slot array that fits next to the
+	 * kernel's result stage is probed from LDS (gpuhashjoin_main_fast_lds) --
+	 * no L2 request per row at all.  One work-group per CU then (the array
+	 * takes the CU's LDS); the kernel keeps 32 rows per thread in flight.
+	 */
+	size_t		lds_slot_bytes = 0;
+	if (fast && !getenv("STROM_HASHJOIN_NO_LDS_SLOTS"))
+	{
+		int			e2 = 0, static_lds = 0;
+		hipFunction_t fn_lds = prog->get_function(dev, "gpuhashjoin_main_fast_lds", &e2);
+		size_t		need = STROM_TYPEALIGN(256, sizeof(cl_uint) * (size_t)tbl->head.rel[0].nslots);
+		size_t		lds_max = std::min<size_t>(dev->prop.sharedMemPerBlock, 160 * 1024);
+		if (fn_lds &&
+			hipFuncGetAttribute(&static_lds, HIP_FUNC_ATTRIBUTE_SHARED_SIZE_BYTES, fn_lds) == hipSuccess &&
+			static_lds >= 0 && (size_t)static_lds + need + 512 <= lds_max)
+		{
+			fn = fn_lds;
+			lds_slot_bytes = need;
+		}
+	}
 	if (!fn)
 		fn = prog->get_function(dev, "gpuhashjoin_main", &errcode);
 	if (!fn)
@@ -410,10 +439,12 @@ gpuhashjoin_launch(strom_task_impl *task, hashjoin_request req)
 		int		generic_rows = 64;								/* HASHJOIN_GENERIC_ROWS */
 		if (const char *v = getenv("STROM_HASHJOIN_GENERIC_ROWS"))
 			generic_rows = std::max(1, atoi(v));
-		size_t	tile_rows = fast ? (size_t)block * 4 * 2 : (size_t)block * generic_rows;
+		size_t	tile_rows = lds_slot_bytes ? (size_t)block * 4 * 8		/* HASHJOIN_LDS_QUADS */
+			: fast ? (size_t)block * 4 * 2 : (size_t)block * generic_rows;
 		size_t	ntiles = (req.nrows + tile_rows - 1) / tile_rows;
 		int		per_cu = 0;
-		if (hipModuleOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, block, 0) != hipSuccess || per_cu < 1)
+		if (hipModuleOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, block, lds_slot_bytes) != hipSuccess ||
+			per_cu < 1)
 			per_cu = 1;
 		if (const char *v = getenv("STROM_HASHJOIN_BLOCKS_PER_CU"))
 			per_cu = std::max(1, atoi(v));
@@ -426,10 +457,12 @@ gpuhashjoin_launch(strom_task_impl *task, hashjoin_request req)
 		const void *a_map = d_rowmap;
 		void	   *args_fast[] = { &a_khj, &a_ix, &a_kds };
 		void	   *args_gen[] = { &a_khj, &a_km, &a_ix, &a_kds, &a_toast, &a_map };
-		REQ_CHECK(hipModuleLaunchKernel(fn, (unsigned)grid, 1, 1, block, 1, 1, 0, task->stream,
-										fast ? args_fast : args_gen, nullptr),
+		REQ_CHECK(hipModuleLaunchKernel(fn, (unsigned)grid, 1, 1, block, 1, 1, (unsigned)lds_slot_bytes,
+										task->stream, fast ? args_fast : args_gen, nullptr),
 				  "launch gpuhashjoin kernel");
 		task->pfm.num_kern_exec++;
+		if (lds_slot_bytes)
+			task->pfm.num_kern_prep++;			/* (reported: the slot array was staged in LDS) */
 	}
 	task_event(task);									/* ev[2] */
 	char	   *d_dest = nullptr;

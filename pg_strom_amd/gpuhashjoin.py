@@ -97,7 +97,7 @@ class GpuHashJoin(object):
         mode, nslots, uniq, nent = ctypes.c_int(0), ctypes.c_uint32(0), ctypes.c_int(0), ctypes.c_uint32(0)
         lib.strom_hashjoin_table_info(self.table, depth, ctypes.byref(mode), ctypes.byref(nslots),
                                       ctypes.byref(uniq), ctypes.byref(nent))
-        return {"mode": "direct" if mode.value == 1 else "hash", "nslots": nslots.value,
+        return {"mode": {1: "direct", 2: "keyed"}.get(mode.value, "hash"), "nslots": nslots.value,
                 "unique": bool(uniq.value), "nentries": nent.value}
 
     def device_kmhash(self):

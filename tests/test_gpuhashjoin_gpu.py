@@ -64,7 +64,9 @@ def test_single_key_all_outer_formats(ofmt, dup):
     assert info[0]["unique"] == (not dup)
 
 
-def test_sparse_keys_use_the_hashed_index():
+def test_sparse_keys_use_the_keyed_index(monkeypatch):
+    """one key, sparse: 16-byte slots that carry the key image (KEYED); with the switch off the
+    chained HASH index over the same entries must give the same pairs"""
     rng = np.random.default_rng(11)
     pk = rng.integers(-2**31, 2**31, 3000, dtype=np.int64).astype(np.int32)
     fk = np.concatenate([pk[rng.integers(0, 3000, 20000)],
@@ -72,7 +74,9 @@ def test_sparse_keys_use_the_hashed_index():
     inner = kds.build_kds("row_flat", [kds.Column("int4", pk), kds.Column("int4", np.arange(3000, dtype=np.int32))])
     for ofmt in ("column", "row"):
         outer = kds.build_kds(ofmt, [kds.Column("int4", fk)])
-        run_and_compare(C3_SPEC, outer, [inner], [[1]], expect_mode="hash", ratio=1.2)
+        run_and_compare(C3_SPEC, outer, [inner], [[1]], expect_mode="keyed", ratio=1.2)
+    monkeypatch.setenv("STROM_HASHJOIN_NO_KEYED", "1")
+    run_and_compare(C3_SPEC, outer, [inner], [[1]], expect_mode="hash", ratio=1.2)
 
 
 def test_result_overflow_is_retried_with_exact_room():
@@ -125,11 +129,11 @@ def test_float_and_int8_keys():
     f[::89] = 0.0
     outer = kds.build_kds("column", [kds.Column("float8", f)])
     run_and_compare("(gpuhashjoin (rel (hashkey (var 1 float8) 1 float8)))", outer, [inner], [[1]],
-                    expect_mode="hash", ratio=30.0)
+                    expect_mode="keyed", ratio=30.0)
     big = rng.integers(-2**62, 2**62, 1000)
     inner = kds.build_kds("row", [kds.Column("int8", big)])
     outer = kds.build_kds("row_flat", [kds.Column("int8", np.concatenate([big[::3], big[::7] + 1]))])
-    run_and_compare("(gpuhashjoin (rel (hashkey (var 1 int8) 1 int8)))", outer, [inner], [[1]], expect_mode="hash")
+    run_and_compare("(gpuhashjoin (rel (hashkey (var 1 int8) 1 int8)))", outer, [inner], [[1]], expect_mode="keyed")
 
 
 def test_projection_into_tupslot():
@@ -276,3 +280,36 @@ def test_pulled_up_qual_errors_only_count_for_rows_that_match():
                 assert ei.value.errcode == 2
         finally:
             join.end()
+
+
+@pytest.mark.parametrize("nd,span,expect_lds", [(20000, 25000, True), (30000, 31000, True), (40000, 50000, False)])
+def test_small_dimension_is_probed_from_lds(nd, span, expect_lds):
+    """'inner hash staged in LDS' (BASELINE configs[2]): a DIRECT slot array that fits the
+    work-group's LDS next to the result stage is copied there once and probed with ds_reads
+    (gpuhashjoin_main_fast_lds; num_kern_prep marks it); larger ones stay in L2.  NULL keys,
+    keys outside the table, 32-row-per-thread tiles with a ragged tail, tiny result room"""
+    rng = np.random.default_rng(nd)
+    pk = rng.permutation(span)[:nd].astype(np.int32)
+    inner = kds.build_kds("row_flat", [kds.Column("int4", pk), kds.Column("int4", np.arange(nd, dtype=np.int32))])
+    n = 300011
+    fk = rng.integers(-100, span + 100, n).astype(np.int32)
+    outer = kds.build_kds("column", [kds.Column("int4", fk, rng.random(n) < 0.03), kds.Column("float8", rng.random(n))])
+    rc, nwant, want = oracle.gpuhashjoin(C3_SPEC, outer, [inner])
+    assert rc == 0
+    km = build_multihash([(inner, [1])])
+    join = GpuHashJoin(C3_SPEC, row_population_ratio=1.0).begin(km)
+    try:
+        info = join.table_info(1)
+        assert info["mode"] == "direct" and info["unique"]
+        first = join.collect(join.submit(outer, nrooms=1000))         # too small: the room needed comes back
+        assert first.errcode == 301 and first.nitems == nwant
+        res = join.join_chunk(outer)
+        dkm = join.device_kmhash()
+    finally:
+        join.end()
+    assert res.perfmon["num_kern_prep"] == (1 if expect_lds else 0)
+    assert res.errcode == 0 and res.nitems == nwant
+    got = np.stack([res.records[:, 0], entry_rowids(dkm, 1, res.records[:, 1])], axis=1)
+    a = got[np.lexsort(got.T[::-1])]
+    b = want[np.lexsort(want.T[::-1])]
+    assert np.array_equal(a, b)
