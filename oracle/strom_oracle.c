@@ -146,6 +146,8 @@ enum {
 	OP_UMINUS, OP_UPLUS, OP_ABS, OP_BITNOT, OP_BITAND, OP_BITOR, OP_BITXOR,
 	OP_SHL, OP_SHR, OP_CAST,
 	OP_CEIL, OP_FLOOR, OP_ROUND, OP_TRUNC, OP_SIGN, OP_SQRT, OP_PI,
+	OP_CBRT, OP_EXP, OP_LN, OP_LOG10, OP_POW, OP_DEGREES, OP_RADIANS,
+	OP_ACOS, OP_ASIN, OP_ATAN, OP_ATAN2, OP_COS, OP_SIN, OP_TAN,
 	OP_DATE_PLI, OP_DATE_MII, OP_DATE_MI, OP_INT_PL_DATE,
 	OP_DATE_TO_TS, OP_TS_TO_DATE, OP_TS_TO_TIME, OP_DATETIME_PL, OP_TIMEDATE_PL,
 	OP_NUM_ADD, OP_NUM_SUB, OP_NUM_MUL, OP_NUM_UMINUS, OP_NUM_UPLUS, OP_NUM_ABS,
@@ -727,6 +729,11 @@ resolve_func(oracle_expr *e, const char *name)
 			{"ceil", OP_CEIL}, {"ceiling", OP_CEIL}, {"floor", OP_FLOOR},
 			{"round", OP_ROUND}, {"dround", OP_ROUND}, {"trunc", OP_TRUNC}, {"dtrunc", OP_TRUNC},
 			{"sign", OP_SIGN}, {"sqrt", OP_SQRT}, {"dsqrt", OP_SQRT},
+			/* codegen.c:467-503 */
+			{"cbrt", OP_CBRT}, {"dcbrt", OP_CBRT}, {"exp", OP_EXP}, {"dexp", OP_EXP},
+			{"ln", OP_LN}, {"dlog1", OP_LN}, {"log", OP_LOG10}, {"dlog10", OP_LOG10},
+			{"degrees", OP_DEGREES}, {"radians", OP_RADIANS}, {"acos", OP_ACOS}, {"asin", OP_ASIN},
+			{"atan", OP_ATAN}, {"cos", OP_COS}, {"sin", OP_SIN}, {"tan", OP_TAN},
 		};
 		size_t i;
 		for (i = 0; i < sizeof(f) / sizeof(f[0]); i++)
@@ -735,6 +742,13 @@ resolve_func(oracle_expr *e, const char *name)
 	}
 	if (!strcmp(name, "pi") && nargs == 0)
 	{ e->op = OP_PI; e->type_oid = STROM_FLOAT8OID; return 1; }
+	if (nargs == 2 && a0 == STROM_FLOAT8OID && a1 == STROM_FLOAT8OID)
+	{
+		if (!strcmp(name, "power") || !strcmp(name, "pow") || !strcmp(name, "dpow"))
+		{ e->op = OP_POW; e->type_oid = STROM_FLOAT8OID; return 1; }
+		if (!strcmp(name, "atan2"))
+		{ e->op = OP_ATAN2; e->type_oid = STROM_FLOAT8OID; return 1; }
+	}
 	/* date / time / timestamp and bpchar(1): comparisons on the raw value */
 	{
 		static const struct { const char *pfx; int x, y; } cmpfam[] = {
@@ -1280,6 +1294,42 @@ eval_func(const oracle_expr *e, oracle_value *a, int32_t *errcode)
 			r.v.d = sqrt(a[0].v.d);
 			return r;
 		case OP_PI:    r.v.d = 3.14159265358979323846; return r;
+		/* PostgreSQL 9.4 float.c: a domain error, an infinite result of finite arguments or
+		 * an underflow to zero is an ERROR there -- CpuReCheck here (CHECKFLOATVAL) */
+#define ORACLE_MATH1(OPC, BAD, EXPR, INF_OK, ZERO_OK)							\
+		case OPC:																\
+			{																	\
+				double x = a[0].v.d;											\
+				if (BAD) return recheck(rt, errcode);							\
+				r.v.d = (EXPR);													\
+				if ((isinf(r.v.d) && !(INF_OK)) || (r.v.d == 0.0 && !(ZERO_OK)))	\
+					return recheck(rt, errcode);								\
+				return r;														\
+			}
+		ORACLE_MATH1(OP_CBRT, 0, cbrt(x), isinf(x), x == 0.0)
+		ORACLE_MATH1(OP_EXP, 0, exp(x), isinf(x), 0)
+		ORACLE_MATH1(OP_LN, x <= 0.0, log(x), isinf(x), x == 1.0)
+		ORACLE_MATH1(OP_LOG10, x <= 0.0, log10(x), isinf(x), x == 1.0)
+		ORACLE_MATH1(OP_DEGREES, 0, x * (180.0 / 3.14159265358979323846), isinf(x), x == 0.0)
+		ORACLE_MATH1(OP_RADIANS, 0, x * (3.14159265358979323846 / 180.0), isinf(x), x == 0.0)
+		ORACLE_MATH1(OP_ACOS, (x < -1.0 || x > 1.0), acos(x), 0, 1)
+		ORACLE_MATH1(OP_ASIN, (x < -1.0 || x > 1.0), asin(x), 0, 1)
+		ORACLE_MATH1(OP_ATAN, 0, atan(x), 0, 1)
+		ORACLE_MATH1(OP_COS, isinf(x), cos(x), 0, 1)
+		ORACLE_MATH1(OP_SIN, isinf(x), sin(x), 0, 1)
+		ORACLE_MATH1(OP_TAN, isinf(x), tan(x), 0, 1)
+#undef ORACLE_MATH1
+		case OP_POW:
+			{
+				double x = a[0].v.d, y = a[1].v.d;
+				if ((x == 0.0 && y < 0.0) || (x < 0.0 && floor(y) != y))
+					return recheck(rt, errcode);
+				r.v.d = pow(x, y);
+				if ((isinf(r.v.d) && !(isinf(x) || isinf(y))) || (r.v.d == 0.0 && x != 0.0))
+					return recheck(rt, errcode);
+				return r;
+			}
+		case OP_ATAN2: r.v.d = atan2(a[0].v.d, a[1].v.d); return r;
 		case OP_DATE_PLI: case OP_DATE_MII: case OP_INT_PL_DATE: case OP_DATE_MI:
 			{
 				__int128 x = a[0].v.i, y = a[1].v.i, z, lo, hi;

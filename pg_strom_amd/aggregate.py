@@ -77,6 +77,51 @@ def rewrite(func, coltype, var, scale=None):
     return None
 
 
+def rewrite2(func, xtype, xvar, ytype, yvar):
+    """two-argument aggregates of the reference's catalog (gpupreagg.c:303-332): corr,
+    covar_pop, covar_samp over float8 -- other argument types are cast first, as PostgreSQL's
+    parser does.  Returns (targets, final) or None."""
+    if func not in ("corr", "covar_pop", "covar_samp"):
+        return None
+
+    def as8(t, v):
+        if t == "float8":
+            return v
+        if t in INT_TYPES + ("float4", "numeric"):
+            return "(float8 %s)" % v
+        return None
+    x, y = as8(xtype, xvar), as8(ytype, yvar)
+    if x is None or y is None:
+        return None
+    filt = "(and (isnotnull %s) (isnotnull %s))" % (xvar, yvar)
+    targets = ["(nrows (isnotnull %s) (isnotnull %s))" % (xvar, yvar)] + \
+        ["(pcov_%s %s %s %s)" % (k, filt, x, y) for k in ("x", "x2", "y", "y2", "xy")]
+    return targets, func
+
+
+def _finalize_covariance(final, cols):
+    """float8_corr / float8_covar_pop / float8_covar_samp (PostgreSQL float.c) over the merged
+    (N, Sx, Sxx, Sy, Syy, Sxy) -- pgstrom.covariance_float8_accum adds the partial rows up"""
+    def total(c):
+        v, n = c
+        v = v[~n]
+        return float(np.sum(v.astype(np.float64))) if len(v) else 0.0
+    n = int(np.sum(cols[0][0].astype(object))) if len(cols[0][0]) else 0
+    if n < 1:
+        return None
+    sx, sxx, sy, syy, sxy = (total(c) for c in cols[1:6])
+    num_xy = n * sxy - sx * sy
+    if final == "covar_pop":
+        return num_xy / (n * float(n))
+    if final == "covar_samp":
+        return None if n < 2 else num_xy / (n * (n - 1.0))
+    num_x = n * sxx - sx * sx
+    num_y = n * syy - sy * sy
+    if num_x <= 0.0 or num_y <= 0.0:
+        return None
+    return num_xy / math.sqrt(num_x * num_y)
+
+
 def _select_div_scale(num, den):
     """numeric.c select_div_scale(): result scale of num/den so that at
     least NUMERIC_MIN_SIG_DIGITS (16) significant digits survive; base
@@ -126,6 +171,8 @@ def finalize(final, cols):
 
     if final == "count":
         return int(np.sum(cols[0][0].astype(object))) if len(cols[0][0]) else 0
+    if final in ("corr", "covar_pop", "covar_samp"):
+        return _finalize_covariance(final, cols)
     if final.endswith("_numeric_exact"):
         return _finalize_numeric(final[:-14], cols, exact=True)
     if final.endswith("_numeric"):

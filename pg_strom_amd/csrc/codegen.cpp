@@ -187,6 +187,21 @@ build_catalog(void)
 	add_func("sign", {F8}, F8, "sign", M);
 	for (const char *n : {"sqrt","dsqrt"})		add_func(n, {F8}, F8, "dsqrt", M);
 	add_func("pi", {}, F8, "dpi", M);
+	/* transcendental functions (codegen.c:467-503) */
+	for (const char *n : {"cbrt","dcbrt"})			add_func(n, {F8}, F8, "dcbrt", M);
+	for (const char *n : {"exp","dexp"})			add_func(n, {F8}, F8, "dexp", M);
+	for (const char *n : {"ln","dlog1"})			add_func(n, {F8}, F8, "dlog1", M);
+	for (const char *n : {"log","dlog10"})			add_func(n, {F8}, F8, "dlog10", M);
+	for (const char *n : {"power","pow","dpow"})	add_func(n, {F8,F8}, F8, "dpow", M);
+	add_func("degrees", {F8}, F8, "degrees", M);
+	add_func("radians", {F8}, F8, "radians", M);
+	add_func("acos", {F8}, F8, "dacos", M);
+	add_func("asin", {F8}, F8, "dasin", M);
+	add_func("atan", {F8}, F8, "datan", M);
+	add_func("atan2", {F8,F8}, F8, "datan2", M);
+	add_func("cos", {F8}, F8, "dcos", M);
+	add_func("sin", {F8}, F8, "dsin", M);
+	add_func("tan", {F8}, F8, "dtan", M);
 
 	/* date / time / timestamp (timelib) */
 	for (const char *op : {"eq","ne","lt","le","gt","ge"})

@@ -489,4 +489,74 @@ pgfn_dpi(cl_int *errcode)
 	return result;
 }
 
+
+/* ---- transcendental functions (codegen.c:467-503; semantics of PostgreSQL 9.4's
+ * float.c: a domain error, an infinite result of finite arguments or an
+ * underflow to zero is an ERROR there -- here the row goes back to the CPU,
+ * which then raises it).  ocml's double-precision functions are within 1-2 ulp
+ * of glibc's; parity tests compare at 1e-14 relative. --------------------- */
+#define STROM_FLOAT8_MATH1(name, DOMAIN_BAD, EXPR, INF_OK, ZERO_OK)			\
+	STROM_DEVICE pg_float8_t												\
+	pgfn_##name(cl_int *errcode, pg_float8_t arg1)							\
+	{																		\
+		pg_float8_t result = arg1;											\
+		if (!result.isnull)													\
+		{																	\
+			double x = arg1.value;											\
+			if (DOMAIN_BAD)													\
+				STROM_RECHECK();											\
+			else															\
+			{																\
+				result.value = (EXPR);										\
+				if (STROM_CHECKFLOATVAL(result.value, INF_OK, ZERO_OK))		\
+					STROM_RECHECK();										\
+			}																\
+		}																	\
+		return result;														\
+	}
+STROM_FLOAT8_MATH1(dcbrt,   false,               cbrt(x),  __builtin_isinf(x), x == 0.0)
+STROM_FLOAT8_MATH1(dexp,    false,               exp(x),   __builtin_isinf(x), false)
+STROM_FLOAT8_MATH1(dlog1,   (x <= 0.0),          log(x),   __builtin_isinf(x), x == 1.0)
+STROM_FLOAT8_MATH1(dlog10,  (x <= 0.0),          log10(x), __builtin_isinf(x), x == 1.0)
+STROM_FLOAT8_MATH1(degrees, false,               x * (180.0 / 3.14159265358979323846), __builtin_isinf(x), x == 0.0)
+STROM_FLOAT8_MATH1(radians, false,               x * (3.14159265358979323846 / 180.0), __builtin_isinf(x), x == 0.0)
+STROM_FLOAT8_MATH1(dacos,   (x < -1.0 || x > 1.0), acos(x), false, true)
+STROM_FLOAT8_MATH1(dasin,   (x < -1.0 || x > 1.0), asin(x), false, true)
+STROM_FLOAT8_MATH1(datan,   false,               atan(x),  false, true)
+STROM_FLOAT8_MATH1(dcos,    __builtin_isinf(x),  cos(x),   false, true)
+STROM_FLOAT8_MATH1(dsin,    __builtin_isinf(x),  sin(x),   false, true)
+STROM_FLOAT8_MATH1(dtan,    __builtin_isinf(x),  tan(x),   false, true)
+
+STROM_DEVICE pg_float8_t
+pgfn_dpow(cl_int *errcode, pg_float8_t arg1, pg_float8_t arg2)
+{
+	pg_float8_t result;
+	result.isnull = arg1.isnull | arg2.isnull;
+	result.value = 0.0;
+	if (!result.isnull)
+	{
+		double x = arg1.value, y = arg2.value;
+		/* "zero raised to a negative power is undefined", "a negative number
+		 * raised to a non-integer power yields a complex result" (dpow) */
+		if ((x == 0.0 && y < 0.0) || (x < 0.0 && __builtin_floor(y) != y))
+			STROM_RECHECK();
+		else
+		{
+			result.value = pow(x, y);
+			if (STROM_CHECKFLOATVAL(result.value, __builtin_isinf(x) || __builtin_isinf(y), x == 0.0))
+				STROM_RECHECK();
+		}
+	}
+	return result;
+}
+
+STROM_DEVICE pg_float8_t
+pgfn_datan2(cl_int *errcode, pg_float8_t arg1, pg_float8_t arg2)
+{
+	pg_float8_t result;
+	result.isnull = arg1.isnull | arg2.isnull;
+	result.value = (result.isnull ? 0.0 : atan2(arg1.value, arg2.value));
+	return result;
+}
+
 #endif	/* STROM_MATHLIB_DEVICE_H */

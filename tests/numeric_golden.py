@@ -411,3 +411,169 @@ def superset(plan):
 def _empty_result(plan):
     """no row at all reached the aggregate: count() is 0, everything else NULL"""
     return 0 if plan["final"] == "count" else None
+
+
+# ---------------------------------------------------------------------------------------------
+# corr / covar_pop / covar_samp (gpupreagg.c:303-332; finals float8_corr & friends through
+# pgstrom.covariance_float8_accum, pg_strom--1.0.sql:368-401).  gpupreagg_mix is the
+# materialised view of agg_init.sql:205-250: row i of the positive block (x) joined with row i
+# of the negative (y) and of the mixed block (z) on id, key = x.key.
+# ---------------------------------------------------------------------------------------------
+COVAR_RE = re.compile(
+    r"select\s+(key\s*,\s*)?(corr|covar_pop|covar_samp)\((\w+)\s*,\s*(\w+)\)\s+from\s+(\w+)\s*(where key=1\s*)?"
+    r"(group by key\s*(order by key)?)?\s*;?$", re.I)
+
+
+def covar_columns(table, a, b):
+    """(key, key isnull, x values, x isnull, type, y values, y isnull, type) as numpy arrays"""
+    fx = load_table("gpupreagg_test")
+    if table == "gpupreagg_mix":
+        block = {"x": slice(0, 10000), "y": slice(10000, 20000), "z": slice(20000, 30000)}
+
+        def col(name):
+            base, which = name[:-1] + "x", name[-1]
+            rows = block[which]
+            vals = fx["nume_dec"][rows] if base == "nume_x" else fx[base][rows]
+            return vals, fx[base + "_isnull"][rows].astype(bool), COLUMNS[base][1]
+        key, keyn = fx["key"][block["x"]], fx["key_isnull"][block["x"]].astype(bool)
+    else:
+        if table == "gpupreagg_zero_test":
+            fx = load_table("gpupreagg_zero_test")
+
+        def col(name):
+            vals = fx["nume_dec"] if name == "nume_x" else fx[name]
+            return vals, fx[name + "_isnull"].astype(bool), COLUMNS[name][1]
+        key, keyn = fx["key"], fx["key_isnull"].astype(bool)
+    xv, xn, xt = col(a)
+    yv, yn, yt = col(b)
+    return key, keyn, xv, xn, xt, yv, yn, yt
+
+
+def _kds_column(vals, isn, typ):
+    if typ == "numeric":
+        imgs = np.array([0 if (d is None) else kds.numeric_encode(d) for d in vals], dtype=np.uint64)
+        return kds.Column("numeric", imgs, isn)
+    return kds.Column(typ, vals, isn)
+
+
+def plan_covar(sql):
+    m = COVAR_RE.match(sql.strip())
+    if not m:
+        return None
+    has_key, func, a, b, table, where, groupby = (m.group(i) for i in range(1, 8))
+    if table not in ("gpupreagg_test", "gpupreagg_zero_test", "gpupreagg_mix"):
+        return None
+    base_a = a if table != "gpupreagg_mix" else a[:-1] + "x"
+    if base_a not in COLUMNS:
+        return None
+    key, keyn, xv, xn, xt, yv, yn, yt = covar_columns(table, a, b)
+    rw = aggregate.rewrite2(func.lower(), xt, "(var 2 %s)" % xt, yt, "(var 3 %s)" % yt)
+    if rw is None:
+        return None
+    targets, final = rw
+    parts = []
+    if where:
+        parts.append("(qual (int4eq (var 1 int4) (const int4 1)))")
+    if groupby:
+        parts.append("(key (var 1 int4))")
+    return {"spec": "(gpupreagg " + " ".join(parts + targets) + ")", "targets": targets, "final": final,
+            "grouped": bool(groupby), "has_key": bool(has_key), "where": bool(where), "table": table,
+            "cols": (key, keyn, xv, xn, xt, yv, yn, yt), "pair": (table, a, b),
+            "ntargets": len(targets) + (1 if groupby else 0)}
+
+
+def covar_chunks(plan, fmt, nchunks):
+    key, keyn, xv, xn, xt, yv, yn, yt = plan["cols"]
+    n = len(key)
+    bounds = np.linspace(0, n, nchunks + 1).astype(int)
+    out = []
+    for i in range(nchunks):
+        r = slice(bounds[i], bounds[i + 1])
+        out.append((kds.build_kds(fmt, [kds.Column("int4", key[r], keyn[r]), _kds_column(xv[r], xn[r], xt),
+                                        _kds_column(yv[r], yn[r], yt)]), r))
+    return out
+
+
+def covar_cpu_partials(plan, rows):
+    key, keyn, xv, xn, xt, yv, yn, yt = plan["cols"]
+    key, keyn = key[rows], keyn[rows]
+    x = np.array([0.0 if (n or v is None) else float(v) for v, n in zip(xv[rows], xn[rows])])
+    y = np.array([0.0 if (n or v is None) else float(v) for v, n in zip(yv[rows], yn[rows])])
+    ok = ~xn[rows] & ~yn[rows]
+    keep = np.ones(len(key), dtype=bool)
+    if plan["where"]:
+        keep = (key == 1) & ~keyn
+    out = {}
+    if plan["grouped"]:
+        gids = [None if keyn[i] else int(key[i]) for i in np.flatnonzero(keep)]
+        for g in set(gids):
+            idx = np.array([i for i, gg in zip(np.flatnonzero(keep), gids) if gg == g])
+            out[g] = idx
+    elif keep.any():
+        out[0] = np.flatnonzero(keep)
+    res = {}
+    for g, idx in out.items():
+        sel = idx[ok[idx]]
+        xs, ys = x[sel], y[sel]
+        row = [len(sel)] + ([None] * 5 if len(sel) == 0 else
+                            [_fsum(list(xs)), _fsum(list(xs * xs)), _fsum(list(ys)), _fsum(list(ys * ys)),
+                             _fsum(list(xs * ys))])
+        res[g] = row
+    return res
+
+
+def run_covar_query(q, run_chunk, fmt="column", nchunks=2, stats=None, chunk_cache=None):
+    plan = plan_covar(q["sql"])
+    if plan is None:
+        return False
+    ckey = (plan["pair"], fmt, nchunks)
+    if chunk_cache is not None and ckey in chunk_cache:
+        chunks = chunk_cache[ckey]
+    else:
+        chunks = covar_chunks(plan, fmt, nchunks)
+        if chunk_cache is not None:
+            chunk_cache[ckey] = chunks
+    groups = {}
+    first = 1 if plan["grouped"] else 0
+    for ci, (buf, rows) in enumerate(chunks):
+        status, values, isnull = run_chunk(plan, buf, ci)
+        assert status in (0, 2), (q["sql"], status)
+        if status == 2:
+            if stats is not None:
+                stats["rechecked_chunks"] = stats.get("rechecked_chunks", 0) + 1
+            for k, row in covar_cpu_partials(plan, rows).items():
+                groups.setdefault(k, []).append(row)
+            continue
+        if stats is not None:
+            stats["device_chunks"] = stats.get("device_chunks", 0) + 1
+        for r in range(len(values)):
+            k = 0
+            if plan["grouped"]:
+                k = None if isnull[r, 0] else int(np.int32(int(values[r, 0]) & 0xffffffff))
+            row = [int(values[r, first])]
+            for t in range(1, 6):
+                row.append(None if isnull[r, first + t]
+                           else float(np.array([values[r, first + t]], dtype=np.uint64).view(np.float64)[0]))
+            groups.setdefault(k, []).append(row)
+    results = {}
+    for k, rws in groups.items():
+        cols = [(np.array([r[0] for r in rws], dtype=object), np.zeros(len(rws), dtype=bool))]
+        for t in range(1, 6):
+            vals = [r[t] for r in rws]
+            cols.append((np.array([0.0 if v is None else v for v in vals]), np.array([v is None for v in vals])))
+        with np.errstate(all="ignore"):
+            results[k] = aggregate.finalize(plan["final"], cols)
+
+    def close(got, text):
+        if text == "":
+            return got is None
+        return got is not None and abs(got - float(text)) <= 5e-10 * max(abs(float(text)), 1e-300)
+    if plan["grouped"]:
+        want_rows = q["rows"] if plan["has_key"] else [["1", r[0]] for r in q["rows"]]
+        assert len(want_rows) == len(results), (q["sql"], len(want_rows), len(results))
+        for wr in want_rows:
+            k = None if wr[0] == "" else int(wr[0])
+            assert close(results.get(k), wr[1]), (q["sql"], k, results.get(k), wr[1])
+    else:
+        assert close(results.get(0), q["rows"][0][0]), (q["sql"], results.get(0), q["rows"][0][0])
+    return True

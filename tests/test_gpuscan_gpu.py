@@ -184,3 +184,74 @@ def test_full_size_c2_properties():
     assert ids[0] >= 0 and ids[-1] < n and np.all(np.diff(ids) > 0)     # unique
     assert np.all(a[ids] < k) and np.all(b[ids] > c)
     assert res.nitems == int(np.count_nonzero((a < k) & (b > c)))
+
+
+MATH_FUNCS = [   # (expression over column c and c+1, error-free domain, domain with errors)
+    ("(exp (var %d float8))", (-700.0, 700.0), (-760.0, 760.0)),
+    ("(ln (var %d float8))", (1e-3, 1e6), (-1.0, 1e6)),
+    ("(log (var %d float8))", (1e-3, 1e6), (-1.0, 1e6)),
+    ("(cbrt (var %d float8))", (-1e9, 1e9), (-1e9, 1e9)),
+    ("(power (var %d float8) (var %d float8))", (0.1, 20.0), (-20.0, 20.0)),
+    ("(degrees (var %d float8))", (-1e3, 1e3), (-1e3, 1e3)),
+    ("(radians (var %d float8))", (-1e3, 1e3), (-1e3, 1e3)),
+    ("(acos (var %d float8))", (-1.0, 1.0), (-1.2, 1.2)),
+    ("(asin (var %d float8))", (-1.0, 1.0), (-1.2, 1.2)),
+    ("(atan (var %d float8))", (-1e3, 1e3), (-1e3, 1e3)),
+    ("(atan2 (var %d float8) (var %d float8))", (-5.0, 5.0), (-5.0, 5.0)),
+    ("(cos (var %d float8))", (-50.0, 50.0), (-50.0, 50.0)),
+    ("(sin (var %d float8))", (-50.0, 50.0), (-50.0, 50.0)),
+    ("(tan (var %d float8))", (-1.5, 1.5), (-1.5, 1.5)),
+]
+
+
+def _math_table(n, seed, which):
+    """column 1: row number; then one (x, y) pair of columns per function"""
+    rng = np.random.default_rng(seed)
+    cols = [kds.Column("int4", np.arange(n, dtype=np.int32))]
+    exprs = []
+    for f, (expr, safe, wild) in enumerate(MATH_FUNCS):
+        lo, hi = (safe if which == "safe" else wild)
+        x = rng.uniform(lo, hi, n)
+        if which == "wild":
+            x[f * 8:f * 8 + 8] = [0.0, 1.0, -1.0, np.inf, -np.inf, np.nan, 1e-310, 0.5]
+        y = np.round(rng.uniform(-6, 6, n) * 2) / 2             # halves: non-integer powers of negatives
+        cols += [kds.Column("float8", x), kds.Column("float8", y)]
+        c = 2 + 2 * f
+        exprs.append(expr % ((c, c + 1) if expr.count("%d") == 2 else (c,)))
+    return cols, exprs
+
+
+def test_transcendental_functions_on_device():
+    """codegen.c:467-503 on the device (ocml) against the oracle (glibc).  Which rows must go
+    back to the CPU (domain error, infinite result of finite arguments, underflow to zero) --
+    the same set; the values of error-free rows -- 1e-13 relative (both libraries are within a
+    few ulp of the true value; tan and power amplify the argument's last bit)"""
+    from pg_strom_amd.gpupreagg import GpuPreAgg
+    runtime.init()
+    n = 5000
+    cols, exprs = _math_table(n, 20240, "wild")
+    buf = kds.build_kds("column", cols)
+    qual = "(or " + " ".join("(isnotnull %s)" % e for e in exprs) + ")"
+    scan = GpuScan(qual).begin()
+    try:
+        res = scan.scan_chunk(buf)
+    finally:
+        scan.end()
+    rc, want = oracle.gpuscan(qual, buf, [])
+    assert res.errcode == rc and np.array_equal(np.sort(res.results), np.sort(want))
+    assert 100 < len(res.recheck_rows()) < n
+    cols, exprs = _math_table(n, 20241, "safe")
+    buf = kds.build_kds("column", cols)
+    spec = "(gpupreagg (key (var 1 int4)) " + " ".join("(pmax %s)" % e for e in exprs) + ")"
+    agg = GpuPreAgg(spec).begin([(0, n)])
+    try:
+        assert agg.fold(buf)[0] == 0
+        pr = agg.fetch()
+    finally:
+        agg.end()
+    order = np.argsort(pr.column(0)[0])
+    for f, e in enumerate(exprs):
+        oid, v, isn, err = oracle.eval_rows(e, buf)
+        assert not err.any(), e
+        got = pr.column(1 + f)[0][order]
+        assert np.allclose(got, v.view(np.float64), rtol=1e-13, atol=0), (e, np.max(np.abs(got / v.view(np.float64) - 1)))

@@ -86,3 +86,15 @@ def test_overflow_agg_suite(fmt, nchunks):
     # 9 columns: 5 catalog aggregates per int2/int4 column, 4 per int8, 11 per float / numeric column
     assert held == 61 and errors == 16, (held, errors)
     assert stats["rechecked_chunks"] > 0 and stats["device_chunks"] > 0
+
+
+def test_corr_and_covariance_known_answers():
+    """corr / covar_pop / covar_samp of the four suites -- every column with itself over
+    gpupreagg_test, x / y against z over the gpupreagg_mix view -- through the pcov_* partials
+    and the float8_corr / float8_covar_* finals"""
+    exp = ng.load_expected()
+    held, cache = 0, {}
+    for suite in ("nogrp_agg", "group_agg", "where_agg", "zero_agg"):
+        for q in exp[suite]:
+            held += ng.run_covar_query(q, oracle_chunk, "column", 2, chunk_cache=cache)
+    assert held == 135, held                 # 9 columns x 3 functions x 3 suites + 54 over the mix view

@@ -101,3 +101,28 @@ def test_overflow_agg_suite_on_device(fmt, nchunks):
         errors += bool(ok and q.get("error"))
     assert held == 61 and errors == 16, (held, errors)
     assert stats["rechecked_chunks"] > 0 and stats["device_chunks"] > 0
+
+
+def test_corr_and_covariance_known_answers_on_device():
+    """corr / covar_pop / covar_samp through the pcov_* partials on the device (int4, float4,
+    float8 and numeric columns: one program per argument type and query shape)"""
+    runtime.init()
+    exp = ng.load_expected()
+    sessions = {}
+
+    def run_chunk(plan, buf, chunk_no):
+        agg = GpuPreAgg(plan["spec"]).begin([(1, 30)] if plan["grouped"] else [])
+        try:
+            status, _ = agg.fold(buf)
+            v, n = partial_rows_as_raw8(agg.fetch()) if status == 0 else (None, None)
+        finally:
+            agg.end()
+        return status, v, n
+
+    held, cache, stats = 0, {}, {}
+    for suite in ("nogrp_agg", "group_agg", "where_agg", "zero_agg"):
+        for q in exp[suite]:
+            if any(c in q["sql"] for c in ("integer_", "real_", "float_", "nume_")):
+                held += ng.run_covar_query(q, run_chunk, "column", 2, stats=stats, chunk_cache=cache)
+    assert held == 4 * (3 * 3 + 6), held
+    assert stats.get("device_chunks", 0) > 0

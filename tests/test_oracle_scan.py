@@ -140,3 +140,43 @@ def test_nan_orders_above_everything():
     assert list(res) == [2, 3]               # NaN and +inf
     rc, res = oracle.gpuscan("(float8eq (var 1 float8) (var 1 float8))", buf)
     assert list(res) == [1, 2, 3, 4]         # NaN = NaN in PostgreSQL's ordering
+
+
+def test_transcendental_functions_follow_postgresql_float_c():
+    """codegen.c:467-503 (cbrt exp ln log power degrees radians acos asin atan atan2 cos sin
+    tan): values as libm gives them; PostgreSQL 9.4's float.c raises an ERROR for a domain
+    error, an infinite result of finite arguments and an underflow to zero -- CpuReCheck here"""
+    x = np.array([0.5, 2.0, -1.5, 0.0, 1.0, 1e308, np.nan, -0.3, 700.0, -800.0, np.inf, -np.inf, 1e-320])
+    y = np.array([2.0, -1.0, 3.0, -1.0, 0.0, 2.0, 1.0, 0.5, 1.0, 1.0, 1.0, 2.0, 2.0])
+    buf = kds.build_kds("column", [kds.Column("float8", x), kds.Column("float8", y)])
+
+    def run(expr):
+        oid, v, n, err = oracle.eval_rows(expr, buf)
+        assert oid == 701
+        return v.view(np.float64), n, err
+
+    with np.errstate(all="ignore"):
+        v, n, err = run("(exp (var 1 float8))")
+        want = np.exp(x)
+        bad = (np.isinf(want) & ~np.isinf(x)) | (want == 0.0)
+        assert np.array_equal(err != 0, bad) and np.allclose(v[~bad], want[~bad], rtol=1e-15, equal_nan=True)
+        v, n, err = run("(ln (var 1 float8))")
+        bad = x <= 0.0
+        assert np.array_equal(err != 0, bad) and np.allclose(v[~bad], np.log(x[~bad]), rtol=1e-15, equal_nan=True)
+        v, n, err = run("(log (var 1 float8))")
+        assert np.array_equal(err != 0, bad) and np.allclose(v[~bad], np.log10(x[~bad]), rtol=1e-15, equal_nan=True)
+        v, n, err = run("(acos (var 1 float8))")
+        bad = (x < -1) | (x > 1)
+        assert np.array_equal(err != 0, bad) and np.allclose(v[~bad], np.arccos(x[~bad]), rtol=1e-15, equal_nan=True)
+        v, n, err = run("(sin (var 1 float8))")
+        bad = np.isinf(x)
+        assert np.array_equal(err != 0, bad) and np.allclose(v[~bad], np.sin(x[~bad]), rtol=1e-15, equal_nan=True)
+        v, n, err = run("(power (var 1 float8) (var 2 float8))")
+        want = np.power(x, y)
+        bad = ((x == 0) & (y < 0)) | ((x < 0) & (np.floor(y) != y)) | \
+            (np.isinf(want) & ~(np.isinf(x) | np.isinf(y))) | ((want == 0) & (x != 0))
+        assert np.array_equal(err != 0, bad) and np.allclose(v[~bad], want[~bad], rtol=1e-15, equal_nan=True)
+        v, n, err = run("(atan2 (var 1 float8) (var 2 float8))")
+        assert not err.any() and np.allclose(v, np.arctan2(x, y), rtol=1e-15, equal_nan=True)
+        v, n, err = run("(cbrt (var 1 float8))")
+        assert not err.any() and np.allclose(v, np.cbrt(x), rtol=1e-15, equal_nan=True)
