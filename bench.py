@@ -337,25 +337,6 @@ def operator_figures(args, k, c, measured_peak, cpu_blocks):
         roofline=roofline_block("gpuhashjoin_main_fast", 4.0 * chunk_rows + 8.0 * nmatch, ts[1:], measured_peak),
         **cpu_blocks("join"))
 
-    # ---- the same probe with a dimension small enough for LDS ("inner hash staged in LDS") ----
-    nd_small = 25_000
-    dk = np.random.default_rng(0x5eed0023).permutation(nd_small).astype(np.int32)
-    km_s = build_multihash([(kds.build_kds("row_flat", [kds.Column("int4", dk), kds.Column("int4", dk % 7)]), [1])])
-    join_s = GpuHashJoin(C3_JOIN, row_population_ratio=0.03).begin(km_s)
-    nmatch_s = int((fk < nd_small).sum().item())
-    ts, staged = [], False
-    for _ in range(6):
-        r = join_s.join_chunk(fact, flags=1)
-        assert r.nitems == nmatch_s
-        ts.append(r.perfmon["time_kern_exec_ns"])
-        staged = bool(r.perfmon["num_kern_prep"])
-    out["gpuhashjoin_small_dim"] = dict(
-        workload="GpuHashJoin: %d fact x %d dim on int4 key (2%% match), slot array %s"
-                 % (chunk_rows, nd_small, "staged in LDS" if staged else "in L2"),
-        roofline=roofline_block("gpuhashjoin_main_fast_lds" if staged else "gpuhashjoin_main_fast",
-                                4.0 * chunk_rows + 8.0 * nmatch_s, ts[1:], measured_peak))
-    join_s.end()
-
     # ---- scan + join + group-by, one pass (the metric's shape) ----------------
     ext = CHAIN_EXT
     sel = (a < int(ext[0])) & (b > float(ext[1])) & (fk < nd)

@@ -676,7 +676,9 @@ gpuhashjoin_main(kern_hashjoin *__restrict__ khashjoin,
 /* quads per thread and tile of the LDS-slots variant: with the slot array in
  * LDS only ONE 256-thread work-group fits a CU, so a thread keeps 32 rows of
  * column data in flight instead of 8 to cover the HBM latency */
+#ifndef HASHJOIN_LDS_QUADS
 #define HASHJOIN_LDS_QUADS		8
+#endif
 #define HASHJOIN_MAX_QUADS		(HASHJOIN_LDS_QUADS > HASHJOIN_QUADS ? HASHJOIN_LDS_QUADS : HASHJOIN_QUADS)
 /* matches are appended to the stage in groups of quads that fit it */
 #define HASHJOIN_STAGE_ENTRIES	HASHJOIN_STAGE

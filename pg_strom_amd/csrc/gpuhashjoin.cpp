@@ -351,10 +351,14 @@ gpuhashjoin_launch(strom_task_impl *task, hashjoin_request req)
 		fn = nullptr;
 	fast = (fn != nullptr);
 	/*
-	 * "inner hash staged in LDS": a DIRECT slot array that fits next to the
-	 * kernel's result stage is probed from LDS (gpuhashjoin_main_fast_lds) --
-	 * no L2 request per row at all.  One work-group per CU then (the array
-	 * takes the CU's LDS); the kernel keeps 32 rows per thread in flight.
+	 * "inner hash staged in LDS" (gpuhashjoin_main_fast_lds): a DIRECT slot array
+	 * copied into the work-group's LDS and probed with ds_reads.  Measured
+	 * (profiles/r02_hashjoin_lds_probe.txt, 1e8 rows, 80 % match): 2000 slots
+	 * 314 us staged vs 329 us through the caches; 25000 slots 362 vs 340 us --
+	 * a small slot array already lives in the CU's L1, and an LDS image that
+	 * takes the whole CU leaves ONE work-group per CU.  Both sit near the floor
+	 * the 0.64 GB of result pairs set (~330 us), so the staged form is used
+	 * where it wins: arrays up to 32 KB (two work-groups per CU).
 	 */
 	size_t		lds_slot_bytes = 0;
 	if (fast && !getenv("STROM_HASHJOIN_NO_LDS_SLOTS"))
@@ -363,7 +367,10 @@ gpuhashjoin_launch(strom_task_impl *task, hashjoin_request req)
 		hipFunction_t fn_lds = prog->get_function(dev, "gpuhashjoin_main_fast_lds", &e2);
 		size_t		need = STROM_TYPEALIGN(256, sizeof(cl_uint) * (size_t)tbl->head.rel[0].nslots);
 		size_t		lds_max = std::min<size_t>(dev->prop.sharedMemPerBlock, 160 * 1024);
-		if (fn_lds &&
+		size_t		lds_slot_limit = 32 * 1024;
+		if (const char *v = getenv("STROM_HASHJOIN_LDS_SLOT_LIMIT"))
+			lds_slot_limit = (size_t)atol(v);
+		if (fn_lds && need <= lds_slot_limit &&
 			hipFuncGetAttribute(&static_lds, HIP_FUNC_ATTRIBUTE_SHARED_SIZE_BYTES, fn_lds) == hipSuccess &&
 			static_lds >= 0 && (size_t)static_lds + need + 512 <= lds_max)
 		{
@@ -439,7 +446,10 @@ gpuhashjoin_launch(strom_task_impl *task, hashjoin_request req)
 		int		generic_rows = 64;								/* HASHJOIN_GENERIC_ROWS */
 		if (const char *v = getenv("STROM_HASHJOIN_GENERIC_ROWS"))
 			generic_rows = std::max(1, atoi(v));
-		size_t	tile_rows = lds_slot_bytes ? (size_t)block * 4 * 8		/* HASHJOIN_LDS_QUADS */
+		int		lds_quads = 8;									/* HASHJOIN_LDS_QUADS */
+		if (const char *v = getenv("STROM_HASHJOIN_LDS_QUADS"))
+			lds_quads = std::max(1, atoi(v));
+		size_t	tile_rows = lds_slot_bytes ? (size_t)block * 4 * lds_quads
 			: fast ? (size_t)block * 4 * 2 : (size_t)block * generic_rows;
 		size_t	ntiles = (req.nrows + tile_rows - 1) / tile_rows;
 		int		per_cu = 0;

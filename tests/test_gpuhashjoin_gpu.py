@@ -282,12 +282,17 @@ def test_pulled_up_qual_errors_only_count_for_rows_that_match():
             join.end()
 
 
-@pytest.mark.parametrize("nd,span,expect_lds", [(20000, 25000, True), (30000, 31000, True), (40000, 50000, False)])
-def test_small_dimension_is_probed_from_lds(nd, span, expect_lds):
-    """'inner hash staged in LDS' (BASELINE configs[2]): a DIRECT slot array that fits the
-    work-group's LDS next to the result stage is copied there once and probed with ds_reads
-    (gpuhashjoin_main_fast_lds; num_kern_prep marks it); larger ones stay in L2.  NULL keys,
-    keys outside the table, 32-row-per-thread tiles with a ragged tail, tiny result room"""
+@pytest.mark.parametrize("nd,span,limit,expect_lds", [(5000, 6000, None, True), (20000, 25000, None, False),
+                                                       (30000, 31000, "131072", True), (40000, 50000, "1000000", False)])
+def test_small_dimension_is_probed_from_lds(nd, span, limit, expect_lds, monkeypatch):
+    """'inner hash staged in LDS' (BASELINE configs[2]): a DIRECT slot array of up to 32 KB is
+    copied into the work-group's LDS once and probed with ds_reads (gpuhashjoin_main_fast_lds;
+    num_kern_prep marks it); larger ones are probed through the caches, where they measured
+    faster -- STROM_HASHJOIN_LDS_SLOT_LIMIT moves the line up to what fits next to the result
+    stage.  NULL keys, keys outside the table, 32-row-per-thread tiles with a ragged tail,
+    tiny result room"""
+    if limit:
+        monkeypatch.setenv("STROM_HASHJOIN_LDS_SLOT_LIMIT", limit)
     rng = np.random.default_rng(nd)
     pk = rng.permutation(span)[:nd].astype(np.int32)
     inner = kds.build_kds("row_flat", [kds.Column("int4", pk), kds.Column("int4", np.arange(nd, dtype=np.int32))])
