@@ -68,6 +68,7 @@ extern "C" strom_hashjoin_table *
 strom_hashjoin_table_create(strom_devprog_key key, const kern_multihash *kmhash, size_t length,
 							int dindex, int *p_errcode)
 {
+	STROM_ABI_TRY
 	int		dummy;
 	if (!p_errcode)
 		p_errcode = &dummy;
@@ -239,6 +240,7 @@ strom_hashjoin_table_create(strom_devprog_key key, const kern_multihash *kmhash,
 		return fail(StromError_HipInternal);
 	strom_retain_devprog_key(key);
 	return tbl.release();
+	STROM_ABI_CATCH(nullptr, p_errcode)
 }
 
 extern "C" void
@@ -649,6 +651,7 @@ submit_hashjoin_common(strom_hashjoin_table *tbl, kern_hashjoin *khashjoin,
 					   kern_data_store *kds_dest, const int32_t *src_depth, const int32_t *src_colidx,
 					   uint32_t flags, strom_done_cb done, void *arg, int *p_errcode)
 {
+	STROM_ABI_TRY
 	int		dummy;
 	if (!p_errcode)
 		p_errcode = &dummy;
@@ -700,6 +703,7 @@ submit_hashjoin_common(strom_hashjoin_table *tbl, kern_hashjoin *khashjoin,
 	strom_task_impl *task = task_create(tbl->dev, done, arg);
 	gpuhashjoin_launch(task, req);		/* the program is ready: the table needed it */
 	return task;
+	STROM_ABI_CATCH(nullptr, p_errcode)
 }
 
 extern "C" strom_task *
@@ -877,6 +881,7 @@ strom_hashjoin_project_column(strom_task *handle, strom_hashjoin_table *tbl, str
 							  int ncols, const int32_t *src_depth, const int32_t *src_colidx,
 							  const int32_t *type_oids, int *p_errcode)
 {
+	STROM_ABI_TRY
 	int		dummy;
 	if (!p_errcode)
 		p_errcode = &dummy;
@@ -1078,4 +1083,5 @@ strom_hashjoin_project_column(strom_task *handle, strom_hashjoin_table *tbl, str
 	if (d_dimptr) dev->pool.release(d_dimptr);
 	if (!result && d_dst) dev->pool.release(d_dst);
 	return result;
+	STROM_ABI_CATCH(nullptr, p_errcode)
 }

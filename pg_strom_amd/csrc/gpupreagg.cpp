@@ -1128,6 +1128,7 @@ gpupreagg_session_new(strom_devprog_key key,
 					  const strom_preagg_domain *domain, bool hashed,
 					  int dindex, int *p_errcode)
 {
+	STROM_ABI_TRY
 	int		dummy;
 	if (!p_errcode)
 		p_errcode = &dummy;
@@ -1210,6 +1211,7 @@ gpupreagg_session_new(strom_devprog_key key,
 		}
 	}
 	return sess;
+	STROM_ABI_CATCH(nullptr, p_errcode)
 }
 
 extern "C" strom_gpupreagg *
@@ -1324,6 +1326,7 @@ submit_gpupreagg_common(strom_gpupreagg *sess,
 						const kern_row_map *krowmap, strom_rowmap *rowmap_dev,
 						strom_done_cb done, void *arg, int *p_errcode)
 {
+	STROM_ABI_TRY
 	int		dummy;
 	if (!p_errcode)
 		p_errcode = &dummy;
@@ -1366,6 +1369,7 @@ submit_gpupreagg_common(strom_gpupreagg *sess,
 	else
 		program_run_or_park(sess->prog, [task, req]() { gpupreagg_launch(task, req); });
 	return task;
+	STROM_ABI_CATCH(nullptr, p_errcode)
 }
 
 extern "C" strom_task *
@@ -1402,6 +1406,7 @@ submit_gpupreagg_over_join(strom_gpupreagg *sess, strom_task *join_handle, bool 
 						   const int32_t *type_oids,
 						   strom_done_cb done, void *arg, int *p_errcode)
 {
+	STROM_ABI_TRY
 	int		dummy;
 	if (!p_errcode)
 		p_errcode = &dummy;
@@ -1544,6 +1549,7 @@ submit_gpupreagg_over_join(strom_gpupreagg *sess, strom_task *join_handle, bool 
 	strom_task_impl *task = task_create(sess->dev, done, arg);
 	program_run_or_park(sess->prog, [task, req]() { gpupreagg_launch(task, req); });
 	return task;
+	STROM_ABI_CATCH(nullptr, p_errcode)
 }
 
 extern "C" strom_task *

@@ -257,6 +257,7 @@ submit_gpuscan_common(strom_devprog_key key,
 					  strom_done_cb done, void *arg,
 					  int *p_errcode)
 {
+	STROM_ABI_TRY
 	int		dummy;
 	if (!p_errcode)
 		p_errcode = &dummy;
@@ -308,6 +309,7 @@ submit_gpuscan_common(strom_devprog_key key,
 	strom_task_impl *task = task_create(dev, done, arg);
 	program_run_or_park(prog, [task, prog, req]() { gpuscan_launch(task, prog, req); });
 	return task;
+	STROM_ABI_CATCH(nullptr, p_errcode)
 }
 
 extern "C" strom_task *
@@ -354,6 +356,7 @@ const char *rowmap_source =
 extern "C" strom_rowmap *
 strom_rowmap_from_task(strom_task *handle, int *p_errcode)
 {
+	STROM_ABI_TRY
 	int		dummy;
 	if (!p_errcode)
 		p_errcode = &dummy;
@@ -430,6 +433,7 @@ strom_rowmap_from_task(strom_task *handle, int *p_errcode)
 	map->dindex = dev->dindex;
 	task->main_devptr = nullptr;		/* ownership moved; strom_task_wait still frees the task */
 	return map;
+	STROM_ABI_CATCH(nullptr, p_errcode)
 }
 
 extern "C" uint32_t

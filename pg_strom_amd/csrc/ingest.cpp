@@ -31,6 +31,7 @@ extern "C" strom_dstore *
 strom_dstore_to_column(strom_dstore *src, const int32_t *type_oids, int ntypes,
 					   uint64_t *p_kern_ns, int *p_errcode)
 {
+	STROM_ABI_TRY
 	int		dummy;
 	if (!p_errcode)
 		p_errcode = &dummy;
@@ -219,4 +220,5 @@ strom_dstore_to_column(strom_dstore *src, const int32_t *type_oids, int ntypes,
 	if (d_aux) dev->pool.release(d_aux);
 	if (!result && d_dst) dev->pool.release(d_dst);
 	return result;
+	STROM_ABI_CATCH(nullptr, p_errcode)
 }

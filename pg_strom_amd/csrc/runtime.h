@@ -16,6 +16,7 @@
 #include <map>
 #include <memory>
 #include <mutex>
+#include <new>
 #include <string>
 #include <thread>
 #include <vector>
@@ -206,6 +207,24 @@ int			hip_errcode(hipError_t rc, const char *what);
 /* run 'fn' now if the program is ready, park it if the build is in
  * flight; returns the program state */
 int			program_run_or_park(Program *prog, std::function<void()> fn);
+
+/*
+ * No C++ exception crosses the C ABI (a PostgreSQL backend links this library:
+ * an escaping exception is std::terminate -> abort()).  The host code throws
+ * nothing itself; what can still surface is std::bad_alloc from the containers.
+ * Entry points whose allocations scale with their input run inside this guard.
+ */
+#define STROM_ABI_TRY		try {
+#define STROM_ABI_CATCH(retval, p_errcode)									\
+	} catch (const std::bad_alloc &) {										\
+		int *__pe = (p_errcode);											\
+		if (__pe) *__pe = StromError_OutOfMemory;							\
+		return retval;														\
+	} catch (...) {															\
+		int *__pe = (p_errcode);											\
+		if (__pe) *__pe = StromError_HipInternal;							\
+		return retval;														\
+	}
 
 #define STROM_HIP_CHECK(call, task)										\
 	do {																\
