@@ -334,7 +334,8 @@ def operator_figures(args, k, c, measured_peak, cpu_blocks):
         workload="GpuHashJoin: %d fact x %d dim on int4 key, 80%% match (BASELINE configs[2]), index %s"
                  % (chunk_rows, nd, info["mode"]),
         value=chunk_rows / float(np.median(walls[1:])) / 1e6, unit="Mrows/s", results="device-resident",
-        roofline=roofline_block("gpuhashjoin_main_fast", 4.0 * chunk_rows + 8.0 * nmatch, ts[1:], measured_peak),
+        roofline=roofline_block("gpuhashjoin_main_fast", 4.0 * chunk_rows + 8.0 * nmatch, ts[1:], measured_peak,
+                                traffic=load_traffic(chunk_rows, "gpuhashjoin_main_fast")),
         **cpu_blocks("join"))
 
     # ---- scan + join + group-by, one pass (the metric's shape) ----------------
@@ -367,7 +368,9 @@ def operator_figures(args, k, c, measured_peak, cpu_blocks):
         value=chunk_rows / float(np.median(walls[1:])) / 1e6, unit="Mrows/s", groups=len(pr),
         checked="counts and integer sums equal numpy's",
         roofline=roofline_block(("gpupreagg_packed_lookup" if lookup_packed else "gpupreagg_dense_lookup") +
-                                "(+gpupreagg_dense_merge)", 16.0 * chunk_rows, kerns[1:], measured_peak),
+                                "(+gpupreagg_dense_merge)", 16.0 * chunk_rows, kerns[1:], measured_peak,
+                                traffic=load_traffic(chunk_rows, "gpupreagg_packed_lookup" if lookup_packed
+                                                     else "gpupreagg_dense_lookup")),
         **cpu_blocks("chain"))
     agg.end()
     join.end()
@@ -454,21 +457,35 @@ def sharded_gpupreagg(args, rank, world, local_rank, barrier, dist, torch, measu
     if rank == 0:
         kname = ("gpupreagg_packed_column" if packed_launches[0] == len(kern_ns) else "gpupreagg_dense_column")
         out["roofline"] = roofline_block(kname + "(+gpupreagg_dense_merge)", 16.0 * nrows / len(chunks), kern_ns,
-                                         measured_peak)
+                                         measured_peak, traffic=load_traffic(chunk_rows, kname))
         out.update(cpu_blocks("agg"))
     return out
 
 
-def load_traffic(chunk_rows):
-    """per-launch HBM bytes from the committed rocprofv3 --pmc passes, if any"""
+def claim_stdout():
+    """stdout carries exactly ONE JSON line, but RCCL prints a version banner on the C stdout
+    when a communicator is made (whenever that happens: at init, at the first collective).
+    Keep a private handle on the real stdout for the line and point fd 1 at stderr for
+    everything else in this process."""
+    sys.stdout.flush()
+    line_out = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
+    return line_out
+
+
+def load_traffic(chunk_rows, kernel=None):
+    """per-launch HBM bytes from the committed rocprofv3 --pmc passes of this command
+    (scripts/collect_traffic.sh), if any; kernel=None: the headline's gpuscan_qual_column"""
     path = os.path.join(ROOT, "profiles", "gpuscan_traffic.json")
     try:
         rec = json.load(open(path))
-        if rec.get("chunk_rows") == chunk_rows:
+        if rec.get("chunk_rows") != chunk_rows:
+            return None
+        if kernel is None:
             return rec.get("hbm_bytes_per_launch")
+        return rec.get("kernels", {}).get(kernel, {}).get("hbm_bytes_per_launch")
     except Exception:
-        pass
-    return None
+        return None
 
 
 def spawn_ranks(args):
@@ -523,9 +540,11 @@ def main():
         kind, kk, cc, secs = args.cpu_worker.split(",")
         cpu_worker(kind, np.int32(int(kk)), float(cc), float(secs))
         return
-    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
-        spawn_ranks(args)
+    if (args.gpus > 1 or os.environ.get("STROM_BENCH_FORCE_SPAWN")) and "WORLD_SIZE" not in os.environ:
+        spawn_ranks(args)            # (the knob rehearses the launcher with one rank on a one-GPU box)
         return
+
+    line_out = claim_stdout()
 
     import torch
     import torch.distributed as dist
@@ -691,7 +710,7 @@ def main():
         if rank == 0 and printed.acquire(False):
             if extra:
                 out.update(extra)
-            print(json.dumps(out), flush=True)
+            print(json.dumps(out), file=line_out, flush=True)
 
     if not args.no_sharded:
         # second region: every rank takes part (RCCL).  A rank that does not come back from

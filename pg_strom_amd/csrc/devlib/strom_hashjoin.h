@@ -710,7 +710,10 @@ struct hashjoin_column_tile {
  * writes.  The L2-resident form below it is bound by the L2 request rate
  * (~2e11 random 4-byte reads per second chip-wide) whatever the table size.
  */
-template <bool LDS_SLOTS, int QUADS>
+/* LDS_SLOTS: 0 = DIRECT slots read through the caches, 1 = DIRECT slots staged in LDS,
+ * 2 = KEYED index (sparse integer keys): the probe is the 16-byte slot search of
+ * hashjoin_first(), one pass instead of the general kernel's count + emit */
+template <int LDS_SLOTS, int QUADS>
 __device__ __forceinline__ void
 gpuhashjoin_main_fast_body(kern_hashjoin *khashjoin,
 						   const hashjoin_index *hjidx,
@@ -747,7 +750,7 @@ gpuhashjoin_main_fast_body(kern_hashjoin *khashjoin,
 #define X(attno,colidx,NAME)	any_nulls = any_nulls || (nul_##attno != NULL);
 	STROM_KVAR_LIST(X)
 #undef X
-	if (LDS_SLOTS)
+	if (LDS_SLOTS == 1)
 	{
 		/* the whole slot array into LDS, 16 bytes per thread and turn (the
 		 * host launches this variant only when it fits: gpuhashjoin.cpp) */
@@ -848,9 +851,18 @@ gpuhashjoin_main_fast_body(kern_hashjoin *khashjoin,
 				if (row0 + j < nitems &&
 					hashjoin_fast_outer_key(&errcode, KP, KV, &key))
 				{
-					cl_ulong idx = (cl_ulong)(key - key_min);
-					if (idx < key_range)
-						match[k][j] = (LDS_SLOTS ? lds_slots[idx] : slots[idx]);
+					if (LDS_SLOTS == 2)
+					{
+						cl_ulong	image = hashjoin_key_image(key);
+						cl_uint		h;
+						match[k][j] = hashjoin_first(hjidx, 0, &image, 1, &h);
+					}
+					else
+					{
+						cl_ulong idx = (cl_ulong)(key - key_min);
+						if (idx < key_range)
+							match[k][j] = (LDS_SLOTS == 1 ? lds_slots[idx] : slots[idx]);
+					}
 				}
 				if (errcode != StromError_Success)
 				{
@@ -987,7 +999,7 @@ gpuhashjoin_main_fast(kern_hashjoin *khashjoin,
 					  const hashjoin_index *hjidx,
 					  const kern_data_store *kds)
 {
-	gpuhashjoin_main_fast_body<false, HASHJOIN_QUADS>(khashjoin, hjidx, kds);
+	gpuhashjoin_main_fast_body<0, HASHJOIN_QUADS>(khashjoin, hjidx, kds);
 }
 
 extern "C" __global__ void
@@ -996,7 +1008,16 @@ gpuhashjoin_main_fast_lds(kern_hashjoin *khashjoin,
 						  const hashjoin_index *hjidx,
 						  const kern_data_store *kds)
 {
-	gpuhashjoin_main_fast_body<true, HASHJOIN_LDS_QUADS>(khashjoin, hjidx, kds);
+	gpuhashjoin_main_fast_body<1, HASHJOIN_LDS_QUADS>(khashjoin, hjidx, kds);
+}
+
+extern "C" __global__ void
+__launch_bounds__(HASHJOIN_BLOCK)
+gpuhashjoin_main_fast_keyed(kern_hashjoin *khashjoin,
+							const hashjoin_index *hjidx,
+							const kern_data_store *kds)
+{
+	gpuhashjoin_main_fast_body<2, HASHJOIN_QUADS>(khashjoin, hjidx, kds);
 }
 
 /* ====================================================================== *

@@ -336,15 +336,17 @@ gpuhashjoin_launch(strom_task_impl *task, hashjoin_request req)
 		task->stream = dev->streams[0];
 	else
 		task->stream = dev->streams[1 + dev->next_stream++ % (dev->streams.size() - 1)];
-	bool	fast = (tbl->ntables == 1 && tbl->head.rel[0].mode == 1 && tbl->head.rel[0].unique &&
+	bool	fast = (tbl->ntables == 1 && (tbl->head.rel[0].mode == 1 || tbl->head.rel[0].mode == 2) &&
+					tbl->head.rel[0].unique &&
 					req.format == KDS_FORMAT_COLUMN && req.krowmap == nullptr && req.rowmap_dev == nullptr &&
 					!getenv("STROM_HASHJOIN_NO_FAST"));
+	bool	fast_keyed = (fast && tbl->head.rel[0].mode == 2);	/* sparse integer keys: KEYED index */
 	hipFunction_t fn = nullptr;
 	if (fast)
 	{
 		/* only programs whose single clause is "int key = inner key" have it */
 		int e2 = 0;
-		fn = prog->get_function(dev, "gpuhashjoin_main_fast", &e2);
+		fn = prog->get_function(dev, fast_keyed ? "gpuhashjoin_main_fast_keyed" : "gpuhashjoin_main_fast", &e2);
 	}
 	/* a program that is not fast-eligible still exports the symbol; the
 	 * eligibility is baked into hashjoin_fast_outer_key() returning false,
@@ -363,7 +365,7 @@ gpuhashjoin_launch(strom_task_impl *task, hashjoin_request req)
 	 * where it wins: arrays up to 32 KB (two work-groups per CU).
 	 */
 	size_t		lds_slot_bytes = 0;
-	if (fast && !getenv("STROM_HASHJOIN_NO_LDS_SLOTS"))
+	if (fast && !fast_keyed && !getenv("STROM_HASHJOIN_NO_LDS_SLOTS"))
 	{
 		int			e2 = 0, static_lds = 0;
 		hipFunction_t fn_lds = prog->get_function(dev, "gpuhashjoin_main_fast_lds", &e2);

@@ -10,7 +10,7 @@ mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 for CTR in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $CTR --kernel-trace --output-format csv -d $OUT/$CTR -- \
-      python3 $ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras --no-sharded > $OUT/$CTR.log 2>&1
+      python3 $ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $OUT/$CTR.log 2>&1
 done
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- \
       python3 $ROOT/bench.py --steps 10 --warmup 2 --no-cpu-baseline > $OUT/stats.log 2>&1

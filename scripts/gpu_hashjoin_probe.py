@@ -15,7 +15,8 @@ fk = rng.integers(0, int(nd * 1.25), nf, dtype=np.int64).astype(np.int32)
 nmatch = int(np.count_nonzero(fk < nd))
 ds = runtime.DeviceStore.upload(kds.build_kds("column", [kds.Column("int4", fk)]))
 for label, env in (("direct+fast", {}), ("direct generic", {"STROM_HASHJOIN_NO_FAST": "1"}),
-                   ("keyed generic", {"STROM_HASHJOIN_FORCE_HASH": "1"}),
+                   ("keyed one-pass", {"STROM_HASHJOIN_FORCE_HASH": "1"}),
+                   ("keyed generic", {"STROM_HASHJOIN_FORCE_HASH": "1", "STROM_HASHJOIN_NO_FAST": "1"}),
                    ("hashed generic", {"STROM_HASHJOIN_FORCE_HASH": "1", "STROM_HASHJOIN_NO_KEYED": "1"})):
     for k in ("STROM_HASHJOIN_NO_FAST", "STROM_HASHJOIN_FORCE_HASH", "STROM_HASHJOIN_NO_KEYED"):
         os.environ.pop(k, None)

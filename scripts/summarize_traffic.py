@@ -47,5 +47,22 @@ try:
     rec["algorithmic_bytes_per_launch"] = b["roofline"]["bytes_per_launch"]
 except Exception as e:
     rec["bench_line_error"] = str(e)
+# every other kernel of the bench command: HBM bytes per launch with the same corrections
+others = {}
+for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+    for path in glob.glob(os.path.join(out_dir, counter, "**", "*counter_collection.csv"), recursive=True):
+        for row in csv.DictReader(open(path)):
+            name = row.get("Kernel_Name", "").split("(")[0]
+            if row.get("Counter_Name") != counter or not name.startswith(("gpu", "hashjoin", "ingest", "membw")):
+                continue
+            d = others.setdefault(name, {"FETCH_SIZE": [], "WRITE_SIZE": []})
+            d[counter].append(float(row["Counter_Value"]))
+rec["kernels"] = {}
+for name, d in sorted(others.items()):
+    if d["FETCH_SIZE"] and d["WRITE_SIZE"]:
+        f = sum(d["FETCH_SIZE"]) / len(d["FETCH_SIZE"]) * 1024.0
+        w = sum(d["WRITE_SIZE"]) / len(d["WRITE_SIZE"]) * 1024.0
+        rec["kernels"][name] = {"launches": len(d["FETCH_SIZE"]), "fetch_bytes_corrected": 2.0 * f,
+                                "write_bytes": w, "hbm_bytes_per_launch": 2.0 * f + w}
 json.dump(rec, open(dest, "w"), indent=1)
 print(json.dumps(rec, indent=1))
