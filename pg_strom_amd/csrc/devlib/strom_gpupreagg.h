@@ -91,7 +91,7 @@ struct gpupreagg_dense_ctl {
 	 * actually occur, ~0 = absent; 0 = ids are used as they are */
 	cl_ulong	remap;				/* device address of cl_uint[dense_ngroups] */
 	cl_uint		dense_ngroups;		/* product of (key_range + 1) */
-	cl_uint		__pad;
+	cl_uint		merge_ws;			/* stripes of the slab merge (power of two <= 64), 0 = derive */
 };
 
 /*
@@ -3000,6 +3000,8 @@ gpupreagg_dense_merge_body(kern_gpupreagg *__restrict__ kgpreagg,
 	 * slabs are small), at least 4 group lanes for some coalescing */
 	while (WS < 64 && WS * 8 < wgs_per_split)
 		WS <<= 1;
+	if (ctl->merge_ws != 0)
+		WS = ctl->merge_ws;
 	cl_uint		GL = 256 / WS;
 	cl_uint		lane = threadIdx.x % GL;
 	cl_uint		stripe = threadIdx.x / GL;

@@ -111,20 +111,26 @@ merge_function(Device *dev, const char *name, int *p_errcode)
 	return lookup_program(key)->get_function(dev, name, p_errcode);
 }
 
-/* order 'stream' behind everything queued on the session's fold stream */
+/* order 'stream' behind everything queued for the session's table: the folds on
+ * streams[0] and the slab merges that follow them on the merge stream */
 int
 stream_follows(Device *dev, hipStream_t stream)
 {
-	if (stream == dev->streams[0])
-		return 0;
-	hipEvent_t ev;
-	if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess)
-		return StromError_HipInternal;
-	hipError_t rc = hipEventRecord(ev, dev->streams[0]);
-	if (rc == hipSuccess)
-		rc = hipStreamWaitEvent(stream, ev, 0);
-	(void)hipEventDestroy(ev);
-	return (rc == hipSuccess ? 0 : StromError_HipInternal);
+	for (hipStream_t src : { dev->streams[0], dev->merge_stream })
+	{
+		if (!src || src == stream)
+			continue;
+		hipEvent_t ev;
+		if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess)
+			return StromError_HipInternal;
+		hipError_t rc = hipEventRecord(ev, src);
+		if (rc == hipSuccess)
+			rc = hipStreamWaitEvent(stream, ev, 0);
+		(void)hipEventDestroy(ev);
+		if (rc != hipSuccess)
+			return StromError_HipInternal;
+	}
+	return 0;
 }
 
 }	/* namespace */

@@ -83,6 +83,9 @@ struct Device {
 	 * the result head comes back on copy_out, so that on streams[0] one
 	 * chunk's kernel follows the previous one's without a DMA in between */
 	hipStream_t			copy_in = nullptr, copy_out = nullptr;
+	/* GpuPreAgg over resident chunks: the slab merge (and the status read-back)
+	 * of chunk k runs here while chunk k+1 is folded on streams[0] */
+	hipStream_t			merge_stream = nullptr;
 	std::atomic<unsigned> next_stream{0};
 	BufferPool			pool;
 	PinnedPool			pinned;
@@ -139,6 +142,9 @@ struct strom_task_impl : public strom_task {
 	hipEvent_t	ev[8] = {};
 	int			nev = 0;
 	bool		has_ev_prep = false, has_ev_proj = false;
+	/* GpuPreAgg, piped: [0] start [1] head sent (copy-in stream), [2] fold begins [3] fold done
+	 * (streams[0]), [4] merge done [5] status received (merge stream) */
+	bool		ev_preagg_piped = false;
 	/* device buffers to hand back to the pool at completion */
 	std::vector<void *> devbufs;
 	std::vector<char *> pinned_blocks;
