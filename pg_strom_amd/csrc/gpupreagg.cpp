@@ -693,8 +693,20 @@ gpupreagg_launch(strom_task_impl *task, preagg_request req)
 		task_event(task);									/* ev[1] */
 	if (sess->merge_ev_used[turn])
 		REQ_CHECK(hipStreamWaitEvent(task->stream, sess->merge_ev[turn], 0), "wait for the slab buffer");
+	/* piped: the fold kernel carries its own start / stop events (see task_event_slot) */
+	bool		ext_launch = (piped && use_ext_launch());
+	hipEvent_t	ev_fold_begin = nullptr, ev_fold_done = nullptr;
 	if (piped)
-		task_event(task);									/* ev[2]: the fold begins */
+	{
+		ev_fold_begin = (ext_launch ? task_event_slot(task) : task_event(task));	/* ev[2]: the fold begins */
+		if (ext_launch)
+			ev_fold_done = task_event_slot(task);			/* ev[3] */
+		if (ext_launch && (!ev_fold_begin || !ev_fold_done))
+		{
+			task_fail(task, StromError_HipInternal);
+			return;
+		}
+	}
 	{
 		void	   *a_kg = d_kg;
 		const void *a_kds = d_kds;
@@ -715,16 +727,23 @@ gpupreagg_launch(strom_task_impl *task, preagg_request req)
 		void	   *args_join[] = { &a_kg, &a_res, &a_kds, &a_jmap, &a_ctl, &a_slabs };
 		void	   *args_look[] = { &a_kg, &a_kds, &a_jmap, &a_ctl, &a_slabs };
 		void	   *args_mrg[] = { &a_kg, &a_ctl, &a_slabs, &a_table };
-		REQ_CHECK(hipModuleLaunchKernel(fn, lctl.nslabs, 1, 1, use_reg ? 256 : sess->block, 1, 1,
-										(unsigned)(packed ? packed->lds_bytes : sess->lds_bytes), task->stream,
-										packed ? (use_lookup ? args_plook : args_pack)
-										: use_lookup ? args_look : use_joined ? args_join
-										: use_column ? args_col : args_gen, nullptr),
-				  "launch gpupreagg reduction");
+		void	  **fold_args = (packed ? (use_lookup ? args_plook : args_pack)
+								 : use_lookup ? args_look : use_joined ? args_join
+								 : use_column ? args_col : args_gen);
+		unsigned	fold_block = (use_reg ? 256 : (unsigned)sess->block);
+		unsigned	fold_lds = (unsigned)(packed ? packed->lds_bytes : sess->lds_bytes);
+		if (ext_launch)
+			REQ_CHECK(hipExtModuleLaunchKernel(fn, lctl.nslabs * fold_block, 1, 1, fold_block, 1, 1, fold_lds,
+											   task->stream, fold_args, nullptr, ev_fold_begin, ev_fold_done, 0),
+					  "launch gpupreagg reduction");
+		else
+			REQ_CHECK(hipModuleLaunchKernel(fn, lctl.nslabs, 1, 1, fold_block, 1, 1, fold_lds, task->stream,
+											fold_args, nullptr),
+					  "launch gpupreagg reduction");
 		if (packed)
 			task->pfm.num_kern_prep++;			/* (reported: this request took the packed path) */
-		hipEvent_t fold_done = nullptr;
-		if (task->pfm.enabled || piped)
+		hipEvent_t fold_done = ev_fold_done;
+		if (!ext_launch && (task->pfm.enabled || piped))
 		{
 			fold_done = task_event(task);				/* ev[2] (piped: ev[3]): main kernel done */
 			task->has_ev_proj = !piped;

@@ -153,13 +153,23 @@ gpuscan_launch(strom_task_impl *task, Program *prog, gpuscan_request req)
 		task->pfm.bytes_dma_send += len;
 		d_rowmap = p;
 	}
+	/* piped requests with perfmon: the kernel carries its own start / stop events
+	 * (hipExtModuleLaunchKernel) instead of two recorded ones around it */
+	bool		ext_launch = (piped && task->pfm.enabled && use_ext_launch());
+	hipEvent_t	ev_begin = nullptr, ev_done = nullptr;
 	if (piped)
 	{
 		hipEvent_t sent = task_event(task, s_in);		/* ev[1]: head is down */
 		REQ_CHECK(hipStreamWaitEvent(task->stream, sent, 0), "wait for the request head");
 		/* the kernel is timed from the moment the main stream gets to it */
-		hipEvent_t begin = task_event(task);			/* ev[2] */
-		(void)begin;
+		ev_begin = (ext_launch ? task_event_slot(task) : task_event(task));	/* ev[2] */
+		if (ext_launch)
+			ev_done = task_event_slot(task);			/* ev[3] */
+		if (ext_launch && (!ev_begin || !ev_done))
+		{
+			task_fail(task, StromError_HipInternal);
+			return;
+		}
 	}
 	else
 		task_event(task);								/* ev[1] */
@@ -195,12 +205,17 @@ gpuscan_launch(strom_task_impl *task, Program *prog, gpuscan_request req)
 		const void *a_map = d_rowmap;
 		void   *args_col[] = { &a_kgs, &a_kds };
 		void   *args_gen[] = { &a_kgs, &a_kds, &a_toast, &a_map };
-		REQ_CHECK(hipModuleLaunchKernel(fn, (unsigned)grid, 1, 1, block, 1, 1, 0, task->stream,
-										use_column ? args_col : args_gen, nullptr),
-				  "launch gpuscan kernel");
+		if (ext_launch)
+			REQ_CHECK(hipExtModuleLaunchKernel(fn, (uint32_t)(grid * block), 1, 1, block, 1, 1, 0, task->stream,
+											   use_column ? args_col : args_gen, nullptr, ev_begin, ev_done, 0),
+					  "launch gpuscan kernel");
+		else
+			REQ_CHECK(hipModuleLaunchKernel(fn, (unsigned)grid, 1, 1, block, 1, 1, 0, task->stream,
+											use_column ? args_col : args_gen, nullptr),
+					  "launch gpuscan kernel");
 		task->pfm.num_kern_exec++;
 	}
-	hipEvent_t kernel_done = task_event(task);			/* ev[2] (piped: ev[3]) */
+	hipEvent_t kernel_done = (ext_launch ? ev_done : task_event(task));	/* ev[2] (piped: ev[3]) */
 	if (piped)
 		REQ_CHECK(hipStreamWaitEvent(s_out, kernel_done, 0), "wait for the kernel");
 	/* result head first; results[0..nitems) follow once nitems is known */

@@ -9,6 +9,13 @@
 #define STROM_RUNTIME_H
 
 #include <hip/hip_runtime.h>
+/* from <hip/hip_ext.h> (whose C++ half needs hipcc; this library is built with g++) */
+extern "C" hipError_t hipExtModuleLaunchKernel(hipFunction_t f, uint32_t globalWorkSizeX,
+											   uint32_t globalWorkSizeY, uint32_t globalWorkSizeZ,
+											   uint32_t localWorkSizeX, uint32_t localWorkSizeY,
+											   uint32_t localWorkSizeZ, size_t sharedMemBytes,
+											   hipStream_t hStream, void **kernelParams, void **extra,
+											   hipEvent_t startEvent, hipEvent_t stopEvent, uint32_t flags);
 #include <atomic>
 #include <condition_variable>
 #include <deque>
@@ -209,6 +216,12 @@ strom_task_impl *task_create(Device *dev, strom_done_cb done, void *arg);
 void		task_enqueue(strom_task_impl *task);
 void		task_fail(strom_task_impl *task, int errcode);
 hipEvent_t	task_event(strom_task_impl *task, hipStream_t stream = nullptr);
+/* an event of the task that is NOT recorded here: hipExtModuleLaunchKernel attaches a
+ * start / stop pair to the kernel's own dispatch packet (its timestamps are the kernel's),
+ * which spares the two barrier packets hipEventRecord would put around the launch */
+hipEvent_t	task_event_slot(strom_task_impl *task);
+/* launch with the kernel's own start / stop events when the knob allows it */
+bool		use_ext_launch(void);
 int			hip_errcode(hipError_t rc, const char *what);
 /* run 'fn' now if the program is ready, park it if the build is in
  * flight; returns the program state */
