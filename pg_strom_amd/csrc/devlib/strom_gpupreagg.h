@@ -603,6 +603,8 @@ gpupreagg_writeback_status(cl_int *status, cl_int chunk_status)
 struct gpupreagg_pack_ctl {
 	cl_uint		count_shift;					/* count field: bits count_shift .. 63 */
 	cl_uint		nwords;							/* 1 (the packed word) + float8 sums */
+	cl_uint		epoch_tiles;					/* 0, or: tiles a work-group folds before it must flush word 0 */
+	cl_uint		__pad;
 	cl_uint		shift[GPUPREAGG_PACK_MAXAGGS];	/* kind 2: position of the field in word 0 */
 	cl_uint		word[GPUPREAGG_PACK_MAXAGGS];	/* kind 3: the aggregate's own word */
 	cl_ulong	mask[GPUPREAGG_PACK_MAXAGGS];	/* kind 2: field mask (after the shift) */
@@ -682,9 +684,20 @@ gpupreagg_packed_row(char *lds, const gpupreagg_dense_ctl *ctl, const gpupreagg_
 #undef X
 }
 
-/* unpack the work-group's LDS image into a slab of the standard shape */
+/*
+ * Unpack the work-group's LDS image into its slab of the standard shape.
+ *
+ * When the fields are too narrow for all the rows a work-group folds in the
+ * chunk (the host then sets pk->epoch_tiles), the work-group folds in epochs:
+ * after epoch_tiles tiles it moves word 0 -- count and integer sums -- to the
+ * slab (FLUSH: the first time a plain store, afterwards an addition to what
+ * the slab holds) and clears it.  The float8 words cannot run over and stay
+ * in LDS until the last store.  The slab belongs to this work-group alone, so
+ * the additions are plain loads and stores.
+ */
+template <bool FLUSH>
 STROM_DEVICE void
-gpupreagg_store_slab_packed(const char *lds, const gpupreagg_pack_ctl *pk, char *slab, cl_uint G)
+gpupreagg_store_slab_packed(char *lds, const gpupreagg_pack_ctl *pk, char *slab, cl_uint G, bool accumulate)
 {
 	__syncthreads();
 	for (cl_uint g = threadIdx.x; g < G; g += GPUPREAGG_BLOCK)
@@ -692,28 +705,41 @@ gpupreagg_store_slab_packed(const char *lds, const gpupreagg_pack_ctl *pk, char 
 		cl_ulong	w0 = ((const cl_ulong *)lds)[g];
 		cl_ulong	n = w0 >> pk->count_shift;
 		cl_uint		flags = 0;
+		if (FLUSH)
+		{
+			((cl_ulong *)lds)[g] = 0;
+			if (accumulate && n == 0)
+				continue;
+		}
 #define X(aidx,kind,attno)																\
 		{																				\
 			char   *svals = slab + gpupreagg_image_offset(1 + aidx, G, 1);				\
 			if (kind == 1)																\
-				((cl_uint *)svals)[g] = (cl_uint)n;										\
+				((cl_uint *)svals)[g] = (cl_uint)n + (accumulate ? ((cl_uint *)svals)[g] : 0u);	\
 			else if (kind == 2)															\
 			{																			\
 				cl_ulong f = (w0 >> pk->shift[aidx]) & pk->mask[aidx];					\
-				((cl_long *)svals)[g] = (cl_long)f + (cl_long)n * pk->bias[aidx];		\
+				((cl_long *)svals)[g] = (cl_long)f + (cl_long)n * pk->bias[aidx]		\
+					+ (accumulate ? ((cl_long *)svals)[g] : 0L);						\
 				flags |= (2u << aidx);													\
 			}																			\
 			else																		\
 			{																			\
-				((cl_ulong *)svals)[g] =												\
-					((const cl_ulong *)(lds + gpupreagg_pack_word_offset(pk->word[aidx], G)))[g];	\
+				if (!FLUSH)																\
+					((cl_ulong *)svals)[g] =											\
+						((const cl_ulong *)(lds + gpupreagg_pack_word_offset(pk->word[aidx], G)))[g];	\
 				flags |= (2u << aidx);													\
 			}																			\
 		}
 		GPUPREAGG_PACK_LIST(X)
 #undef X
-		((gpupreagg_flags_t *)slab)[g] = (gpupreagg_flags_t)(n != 0 ? (flags | GPUPREAGG_FLAG_SEEN) : 0u);
+		if (n != 0)
+			((gpupreagg_flags_t *)slab)[g] = (gpupreagg_flags_t)(flags | GPUPREAGG_FLAG_SEEN);
+		else if (!accumulate)
+			((gpupreagg_flags_t *)slab)[g] = (gpupreagg_flags_t)0u;
 	}
+	if (FLUSH)
+		__syncthreads();
 }
 #endif	/* GPUPREAGG_PACKABLE */
 
@@ -826,9 +852,26 @@ gpupreagg_dense_column_body(kern_gpupreagg *kgpreagg,
 	STROM_KVAR_LIST(X)
 #undef X
 
+	bool		flushed = false;
+#if defined(GPUPREAGG_PACKABLE) && GPUPREAGG_PACKABLE
+	cl_uint		epoch_left = (PACKED ? pk->epoch_tiles : 0u);
+#endif
 	for (cl_uint tile = wg_in_split; tile < ntiles; tile += wgs_per_split)
 	{
 		cl_uint		tile_base = tile * GPUPREAGG_TILE_ROWS;
+#if defined(GPUPREAGG_PACKABLE) && GPUPREAGG_PACKABLE
+		if (PACKED && pk->epoch_tiles != 0)
+		{
+			/* (uniform over the work-group: every thread counts the same tiles) */
+			if (epoch_left == 0)
+			{
+				gpupreagg_store_slab_packed<true>(lds, pk, slabs + (size_t)(wg_in_split * nsplits + split) * ctl->slab_bytes, G, flushed);
+				flushed = true;
+				epoch_left = pk->epoch_tiles;
+			}
+			epoch_left--;
+		}
+#endif
 		bool		full_tile = (tile_base + GPUPREAGG_TILE_ROWS <= nitems);
 		gpupreagg_column_tile T;
 
@@ -918,7 +961,8 @@ gpupreagg_dense_column_body(kern_gpupreagg *kgpreagg,
 	}
 #if defined(GPUPREAGG_PACKABLE) && GPUPREAGG_PACKABLE
 	if (PACKED)
-		gpupreagg_store_slab_packed(lds, pk, slabs + (size_t)(wg_in_split * nsplits + split) * ctl->slab_bytes, G);
+		gpupreagg_store_slab_packed<false>(lds, pk, slabs + (size_t)(wg_in_split * nsplits + split) * ctl->slab_bytes,
+										   G, flushed);
 	else
 #endif
 		gpupreagg_store_slab(lds, L, slabs + (size_t)(wg_in_split * nsplits + split) * ctl->slab_bytes, G, NREP);
@@ -1299,9 +1343,26 @@ gpupreagg_dense_lookup_body(kern_gpupreagg *kgpreagg,
 	cl_long		key_min = jmap->key_min;
 	cl_uint		nslots = jmap->nslots;
 
+	bool		flushed = false;
+#if defined(GPUPREAGG_PACKABLE) && GPUPREAGG_PACKABLE
+	cl_uint		epoch_left = (PACKED ? pk->epoch_tiles : 0u);
+#endif
 	for (cl_uint tile = wg_in_split; tile < ntiles; tile += wgs_per_split)
 	{
 		cl_uint		tile_base = tile * GPUPREAGG_TILE_ROWS;
+#if defined(GPUPREAGG_PACKABLE) && GPUPREAGG_PACKABLE
+		if (PACKED && pk->epoch_tiles != 0)
+		{
+			/* (uniform over the work-group: every thread counts the same tiles) */
+			if (epoch_left == 0)
+			{
+				gpupreagg_store_slab_packed<true>(lds, pk, slabs + (size_t)blockIdx.x * ctl->slab_bytes, G, flushed);
+				flushed = true;
+				epoch_left = pk->epoch_tiles;
+			}
+			epoch_left--;
+		}
+#endif
 		bool		full_tile = (tile_base + GPUPREAGG_TILE_ROWS <= nitems);
 		gpupreagg_column_tile T;
 		KEY_T		keyq[GPUPREAGG_QUADS][4];
@@ -1457,7 +1518,7 @@ gpupreagg_dense_lookup_body(kern_gpupreagg *kgpreagg,
 	}
 #if defined(GPUPREAGG_PACKABLE) && GPUPREAGG_PACKABLE
 	if (PACKED)
-		gpupreagg_store_slab_packed(lds, pk, slabs + (size_t)blockIdx.x * ctl->slab_bytes, G);
+		gpupreagg_store_slab_packed<false>(lds, pk, slabs + (size_t)blockIdx.x * ctl->slab_bytes, G, flushed);
 	else
 #endif
 		gpupreagg_store_slab(lds, L, slabs + (size_t)blockIdx.x * ctl->slab_bytes, G, NREP);

@@ -351,6 +351,8 @@ struct joined_map_image {
 struct pack_ctl {
 	cl_uint		count_shift;
 	cl_uint		nwords;
+	cl_uint		epoch_tiles;
+	cl_uint		__pad;
 	cl_uint		shift[32];
 	cl_uint		word[32];
 	cl_ulong	mask[32];
@@ -434,7 +436,40 @@ packed_plan(strom_gpupreagg *sess, hipFunction_t fn_packed, const kern_coldir *c
 	size_t		ntiles = ((size_t)nitems + tile_rows - 1) / tile_rows;
 	size_t		wgs_per_split = wgs / nsplits;
 	cl_ulong	rows_per_wg = (cl_ulong)((ntiles + wgs_per_split - 1) / wgs_per_split) * tile_rows;
+	/*
+	 * count field: wide enough for every row the work-group may fold -- or, when
+	 * the sums do not leave that much room, for an EPOCH of tiles after which the
+	 * work-group moves word 0 to its slab and starts over (strom_gpupreagg.h:
+	 * gpupreagg_store_slab_packed).  An epoch shorter than 4 tiles is not worth it.
+	 */
+	int			vbits = 0, nsums = 0;
+	for (cl_uint a = 0; a < naggs; a++)
+	{
+		if (sess->pack_kind[a] != 2)
+			continue;
+		int			col = sess->pack_attno[a] - 1;
+		vbits += bits_for((cl_ulong)coldir[col].maxval - (cl_ulong)coldir[col].minval);
+		nsums++;
+	}
+	if (vbits >= 64)
+		return nullptr;
 	int			cbits = bits_for(rows_per_wg);
+	cl_uint		epoch_tiles = 0;
+	const char *cap = getenv("STROM_GPUPREAGG_PACK_COUNT_BITS");	/* tests: short epochs on small inputs */
+	int			cap_bits = (cap ? atoi(cap) : 0);
+	if (vbits + (nsums + 1) * cbits > 64 || (cap_bits > 0 && cap_bits < cbits))
+	{
+		cbits = (64 - vbits) / (nsums + 1);
+		if (cap_bits > 0)
+			cbits = std::min(cbits, cap_bits);
+		if (cbits < 1 || cbits > 40 || getenv("STROM_GPUPREAGG_NO_EPOCHS"))
+			return nullptr;
+		cl_ulong	tiles = ((1UL << cbits) - 1) / tile_rows;
+		if (tiles < (cap_bits > 0 ? 1u : 4u))
+			return nullptr;
+		epoch_tiles = (cl_uint)std::min<cl_ulong>(tiles, 0x7fffffffUL);
+	}
+	pk->epoch_tiles = epoch_tiles;
 	int			pos = 0;
 	for (cl_uint a = 0; a < naggs; a++)
 	{

@@ -381,7 +381,9 @@ def test_join_as_a_lookup_inside_the_aggregate(ngroups, keytype):
     order = np.argsort(gk)
     assert np.array_equal(gk[order], ug)
     assert np.array_equal(pr.column(1)[0][order], 2 * np.bincount(inv))
-    assert np.array_equal(pr.column(2)[0][order], 2 * np.bincount(inv, weights=a[sel].astype(np.float64)).astype(np.int64))
+    sums = np.zeros(len(ug), dtype=np.int64)
+    np.add.at(sums, inv, a[sel].astype(np.int64))
+    assert np.array_equal(pr.column(2)[0][order], 2 * sums)
     assert np.allclose(pr.column(3)[0][order], 2 * np.bincount(inv, weights=b[sel]), rtol=1e-12)
     wmax = np.full(len(ug), -np.inf)
     ok = ~dvn[di]
@@ -391,16 +393,20 @@ def test_join_as_a_lookup_inside_the_aggregate(ngroups, keytype):
     assert np.array_equal(gmax[order][~np.isinf(wmax)], wmax[~np.isinf(wmax)])
 
 
-def test_join_as_a_lookup_with_packed_accumulators():
+@pytest.mark.parametrize("epochs", [False, True])
+def test_join_as_a_lookup_with_packed_accumulators(epochs, monkeypatch):
     """1e4 groups, summed OUTER columns without NULLs: the lookup aggregate takes the packed
     LDS image (gpupreagg_packed_lookup, one id-range role instead of two); the grouping key
-    is an inner column with NULLs, rows without a partner are dropped"""
+    is an inner column with NULLs, rows without a partner are dropped.  epochs: a 31-bit
+    value range and enough rows that the packed word is moved to the slab between epochs."""
     runtime.init()
-    n, nd, ngroups = 300007, 40000, 10000
+    n, nd, ngroups = (2_500_003 if epochs else 300007), 40000, 10000
+    if epochs:
+        monkeypatch.setenv("STROM_GPUPREAGG_PACK_COUNT_BITS", "14")
     rng = np.random.default_rng(97)
     span = int(nd * 1.25)
     fk = rng.integers(0, span, n).astype(np.int32)
-    a = rng.integers(-5 * 10**5, 2**20, n).astype(np.int32)
+    a = (rng.integers(0, 2**31 - 1, n) if epochs else rng.integers(-5 * 10**5, 2**20, n)).astype(np.int32)
     b = rng.random(n)
     fact = kds.build_kds("column", [kds.Column("int4", fk), kds.Column("int4", a), kds.Column("float8", b)])
     dkey = rng.permutation(span)[:nd].astype(np.int32)
@@ -408,7 +414,7 @@ def test_join_as_a_lookup_with_packed_accumulators():
     dgn = rng.random(nd) < 0.02
     inner = kds.build_kds("row_flat", [kds.Column("int4", dkey), kds.Column("int4", dgrp, dgn)])
     km = build_multihash([(inner, [1])])
-    ext = [np.int32(2**19), 0.25]
+    ext = [np.int32(2**30 if epochs else 2**19), 0.25]
     ds = runtime.DeviceStore.upload(fact)
     join = GpuHashJoin("(gpuhashjoin (rel (hashkey (var 1 int4) 1 int4)))").begin(km)
     spec = ("(gpupreagg (qual " + QUAL + ") (key (var 1 int4)) (nrows) (psum (int8 (var 2 int4)))"
@@ -439,5 +445,7 @@ def test_join_as_a_lookup_with_packed_accumulators():
     order = np.argsort(gk)
     assert np.array_equal(gk[order], ug)
     assert np.array_equal(pr.column(1)[0][order], 2 * np.bincount(inv))
-    assert np.array_equal(pr.column(2)[0][order], 2 * np.bincount(inv, weights=a[sel].astype(np.float64)).astype(np.int64))
+    sums = np.zeros(len(ug), dtype=np.int64)
+    np.add.at(sums, inv, a[sel].astype(np.int64))
+    assert np.array_equal(pr.column(2)[0][order], 2 * sums)
     assert np.allclose(pr.column(3)[0][order], 2 * np.bincount(inv, weights=b[sel]), rtol=1e-12)

@@ -288,6 +288,19 @@ def test_packed_accumulators_with_qual_two_keys_and_wide_values():
     assert pfms[0]["num_kern_prep"] == 0
 
 
+def test_packed_accumulators_fold_in_epochs_when_the_fields_are_narrow(monkeypatch):
+    """the sum of a full-range int4 column next to the count needs more than 64 bits for all the
+    rows of a work-group: the work-group folds in epochs and moves the packed word to its slab
+    in between (gpupreagg_store_slab_packed<true>).  Forced on a small input by capping the
+    count field at 14 bits = one 8192-row tile per epoch; several tiles per work-group."""
+    monkeypatch.setenv("STROM_GPUPREAGG_PACK_COUNT_BITS", "14")
+    bufs = [kds.build_kds("column", c4_table(3_000_017, 51 + i, 10000, xlo=-2**31, xhi=2**31 - 1))
+            for i in range(2)]
+    pfms = []
+    compare_with_oracle(C4_SPEC, bufs, [(0, 10000)], resident=True, pfms=pfms)
+    assert all(p["num_kern_prep"] == 1 for p in pfms)
+
+
 def test_packed_path_is_left_when_an_input_column_has_nulls_and_catches_a_wrong_zone_map():
     bufs = [kds.build_kds("column", c4_table(100003, 41, 10000, nulls=0.02))]
     pfms = []
