@@ -251,6 +251,36 @@ kern_get_datum(const kern_data_store *kds,
 	}
 }
 
+/*
+ * A value every lane of the wave holds alike (launch geometry, column base
+ * addresses, directory entries): say so.  Read through a pointer the compiler
+ * cannot prove invariant, such a value lands in a VECTOR register -- one copy
+ * per lane, vector ALU for every use, spills in the row loops; through
+ * readfirstlane it lives in scalar registers.
+ */
+template <typename T>
+STROM_DEVICE T strom_uniform(T v)
+{
+	if (sizeof(T) == 8)
+	{
+		unsigned long long bits;
+		__builtin_memcpy(&bits, &v, 8);
+		unsigned int lo = (unsigned int)__builtin_amdgcn_readfirstlane((int)(unsigned int)bits);
+		unsigned int hi = (unsigned int)__builtin_amdgcn_readfirstlane((int)(unsigned int)(bits >> 32));
+		bits = ((unsigned long long)hi << 32) | lo;
+		__builtin_memcpy(&v, &bits, 8);
+		return v;
+	}
+	else
+	{
+		unsigned int bits = 0;
+		__builtin_memcpy(&bits, &v, sizeof(T));
+		bits = (unsigned int)__builtin_amdgcn_readfirstlane((int)bits);
+		__builtin_memcpy(&v, &bits, sizeof(T));
+		return v;
+	}
+}
+
 /* unaligned-safe scalar fetch (heap tuples only guarantee attalign) */
 template <typename BASE>
 STROM_DEVICE BASE strom_fetch(const void *addr)

@@ -420,15 +420,18 @@ STROM_DEVICE void
 gpupreagg_dense_row(char *lds, const gpupreagg_dense_ctl *ctl, const gpupreagg_lds_layout &L,
 					const strom_kparams &KP, const strom_kvars &KV,
 					cl_uint gid_lo, cl_uint G, cl_uint NREP, cl_uint rep,
-					cl_int param_error, cl_int *chunk_status)
+					cl_int param_error, cl_int *chunk_status, bool qual_done = false)
 {
 	cl_int		errcode = param_error;
-	pg_bool_t	rc = gpupreagg_qual_eval(&errcode, KP, KV);
 	cl_uint		gid = 0;
 	bool		out_of_domain = false;
 
-	if (errcode == StromError_Success && !EVAL(rc))
-		return;
+	if (!qual_done)				/* (the caller may have seen the qual pass, without an error) */
+	{
+		pg_bool_t	rc = gpupreagg_qual_eval(&errcode, KP, KV);
+		if (errcode == StromError_Success && !EVAL(rc))
+			return;
+	}
 	/* group id: dense, NULL key in its own slot */
 #define X(kidx,resno,NAME)															\
 	{																				\
@@ -438,7 +441,7 @@ gpupreagg_dense_row(char *lds, const gpupreagg_dense_ctl *ctl, const gpupreagg_l
 		cl_uint		off = (kv.isnull ? range : (cl_uint)off64);						\
 		if (!kv.isnull && (off64 < 0 || off64 >= (cl_long)range))					\
 			out_of_domain = true;													\
-		gid += off * ctl->key_stride[kidx];											\
+		gid += (kidx == 0 ? off : off * ctl->key_stride[kidx]);	/* (stride 0 is 1) */											\
 	}
 	GPUPREAGG_KEY_LIST(X)
 #undef X
@@ -622,15 +625,18 @@ gpupreagg_pack_word_offset(cl_uint w, cl_uint G)
 STROM_DEVICE void
 gpupreagg_packed_row(char *lds, const gpupreagg_dense_ctl *ctl, const gpupreagg_pack_ctl *pk,
 					 const strom_kparams &KP, const strom_kvars &KV,
-					 cl_uint gid_lo, cl_uint G, cl_int param_error, cl_int *chunk_status)
+					 cl_uint gid_lo, cl_uint G, cl_int param_error, cl_int *chunk_status, bool qual_done = false)
 {
 	cl_int		errcode = param_error;
-	pg_bool_t	rc = gpupreagg_qual_eval(&errcode, KP, KV);
 	cl_uint		gid = 0;
 	bool		out_of_domain = false;
 
-	if (errcode == StromError_Success && !EVAL(rc))
-		return;
+	if (!qual_done)
+	{
+		pg_bool_t	rc = gpupreagg_qual_eval(&errcode, KP, KV);
+		if (errcode == StromError_Success && !EVAL(rc))
+			return;
+	}
 #define X(kidx,resno,NAME)															\
 	{																				\
 		pg_##NAME##_t kv = gpupreagg_key_##kidx(&errcode, KP, KV);					\
@@ -639,7 +645,7 @@ gpupreagg_packed_row(char *lds, const gpupreagg_dense_ctl *ctl, const gpupreagg_
 		cl_uint		off = (kv.isnull ? range : (cl_uint)off64);						\
 		if (!kv.isnull && (off64 < 0 || off64 >= (cl_long)range))					\
 			out_of_domain = true;													\
-		gid += off * ctl->key_stride[kidx];											\
+		gid += (kidx == 0 ? off : off * ctl->key_stride[kidx]);	/* (stride 0 is 1) */											\
 	}
 	GPUPREAGG_KEY_LIST(X)
 #undef X
@@ -1166,8 +1172,8 @@ gpupreagg_dense_joined(kern_gpupreagg *kgpreagg,
 	cl_uint		reclen = jmap->reclen;
 	const char *keyvals = (const char *)kds + coldir[jmap->key_col].values_off;
 	cl_int		key_attlen = jmap->key_attlen;
-	cl_long		key_min = jmap->key_min;
-	cl_uint		nslots = jmap->nslots;
+	cl_long		key_min = strom_uniform((cl_long)jmap->key_min);
+	cl_uint		nslots = strom_uniform((cl_uint)jmap->nslots);
 
 	for (size_t r = (size_t)wg_in_split * GPUPREAGG_BLOCK + threadIdx.x;
 		 r < nrows;
@@ -1243,7 +1249,7 @@ gpupreagg_dense_joined(kern_gpupreagg *kgpreagg,
 				cl_uint		off = (kv.isnull ? range : (cl_uint)off64);			\
 				if (!kv.isnull && (off64 < 0 || off64 >= (cl_long)range))		\
 					out_of_domain = true;										\
-				gid += off * ctl->key_stride[kidx];								\
+				gid += (kidx == 0 ? off : off * ctl->key_stride[kidx]);	/* (stride 0 is 1) */								\
 			}
 			GPUPREAGG_KEY_LIST(Y)
 #undef Y
@@ -1271,6 +1277,21 @@ gpupreagg_dense_joined(kern_gpupreagg *kgpreagg,
  * are written or read at all.  The program's (var N ...) and its qual see
  * the same virtual relation as gpupreagg_dense_joined; int4 / int8 keys.
  * ====================================================================== */
+#ifndef GPUPREAGG_ABLATE
+#define GPUPREAGG_ABLATE 0
+#endif
+#if GPUPREAGG_ABLATE & 1
+STROM_DEVICE cl_uint
+gpupreagg_ablate_sink(const strom_kvars &KV)
+{
+	cl_uint		acc = 0;
+#define X(attno,colidx,NAME)	acc ^= (cl_uint)KV.KVAR_##attno.value + (cl_uint)KV.KVAR_##attno.isnull;
+	STROM_KVAR_LIST(X)
+#undef X
+	return acc;
+}
+#endif
+
 template <typename KEY_T, bool PACKED>
 __device__ __forceinline__ void
 gpupreagg_dense_lookup_body(kern_gpupreagg *kgpreagg,
@@ -1282,7 +1303,7 @@ gpupreagg_dense_lookup_body(kern_gpupreagg *kgpreagg,
 {
 	const kern_parambuf *kparams = KERN_GPUPREAGG_PARAMBUF(kgpreagg);
 	const kern_coldir *coldir = KERN_DATA_STORE_COLDIR(kds);
-	cl_uint		nitems = kds->nitems;
+	cl_uint		nitems = strom_uniform((cl_uint)kds->nitems);
 	cl_uint		ntiles = (nitems + GPUPREAGG_TILE_ROWS - 1) / GPUPREAGG_TILE_ROWS;
 	cl_uint		nsplits = ctl->nsplits;
 	cl_uint		G = ctl->groups_per_split;
@@ -1316,22 +1337,24 @@ gpupreagg_dense_lookup_body(kern_gpupreagg *kgpreagg,
 		gpupreagg_lds_layout_init(L, G, NREP);
 		gpupreagg_lds_init(lds, L, G, NREP);
 	}
+	/* (all of this is uniform: strom_uniform keeps it in scalar registers) */
 #define X(attno,colidx,NAME)													\
-	const bool	inner_##attno = (jmap->c[colidx].depth != 0);					\
-	const cl_uint recoff_##attno = (cl_uint)jmap->c[colidx].dimvalues;			\
-	const cl_uint recbit_##attno = (cl_uint)jmap->c[colidx].dimisnull;			\
-	const char *val_##attno = (inner_##attno ? NULL								\
+	const bool	inner_##attno = (strom_uniform((cl_int)jmap->c[colidx].depth) != 0);	\
+	const cl_uint recoff_##attno = strom_uniform((cl_uint)jmap->c[colidx].dimvalues);	\
+	const cl_uint recbit_##attno = strom_uniform((cl_uint)jmap->c[colidx].dimisnull);	\
+	const char *val_##attno = strom_uniform(inner_##attno ? (const char *)NULL		\
 							   : (const char *)kds + coldir[jmap->c[colidx].col].values_off);	\
-	const char *nul_##attno = (inner_##attno ? NULL								\
+	const char *nul_##attno = strom_uniform(inner_##attno ? (const char *)NULL		\
 							   : (coldir[jmap->c[colidx].col].nulls_off != 0		\
-								  ? (const char *)kds + coldir[jmap->c[colidx].col].nulls_off : NULL));
+								  ? (const char *)kds + coldir[jmap->c[colidx].col].nulls_off : (const char *)NULL));
 	STROM_KVAR_LIST(X)
 #undef X
-	const char *keyvals = (const char *)kds + coldir[jmap->key_col].values_off;
-	const cl_uint *keynulls = (coldir[jmap->key_col].nulls_off != 0
-							   ? (const cl_uint *)((const char *)kds + coldir[jmap->key_col].nulls_off) : NULL);
-	const char *recs = (const char *)jmap->recs;
-	cl_uint		reclen = jmap->reclen;
+	const char *keyvals = strom_uniform((const char *)kds + coldir[jmap->key_col].values_off);
+	const cl_uint *keynulls = strom_uniform(coldir[jmap->key_col].nulls_off != 0
+							   ? (const cl_uint *)((const char *)kds + coldir[jmap->key_col].nulls_off)
+							   : (const cl_uint *)NULL);
+	const char *recs = strom_uniform((const char *)jmap->recs);
+	cl_uint		reclen = strom_uniform((cl_uint)jmap->reclen);
 	/* a qual that reads outer columns only is evaluated BEFORE the probe: a row it
 	 * rejects (without an error) costs no L2 request; gpupreagg_dense_row evaluates
 	 * it again for the rows that do have a partner, errors included */
@@ -1401,11 +1424,13 @@ gpupreagg_dense_lookup_body(kern_gpupreagg *kgpreagg,
 		 */
 		cl_uint		slot[GPUPREAGG_QUADS][4];
 		cl_uint		gone[GPUPREAGG_QUADS];			/* bit j: no partner */
+		cl_uint		qual_ok[GPUPREAGG_QUADS];		/* bit j: the qual was seen to pass, without an error */
 #pragma unroll
 		for (int k = 0; k < GPUPREAGG_QUADS; k++)
 		{
 			cl_uint	row0 = tile_base + (k * GPUPREAGG_BLOCK + threadIdx.x) * 4;
 			gone[k] = 0;
+			qual_ok[k] = 0;
 #pragma unroll
 			for (int j = 0; j < 4; j++)
 			{
@@ -1424,6 +1449,7 @@ gpupreagg_dense_lookup_body(kern_gpupreagg *kgpreagg,
 					KV.__dummy = 0;
 					pg_bool_t	rc = gpupreagg_qual_eval(&qerr, KP, KV);
 					live = !(qerr == StromError_Success && !EVAL(rc));
+					qual_ok[k] |= ((qerr == StromError_Success && EVAL(rc)) ? (1u << j) : 0u);
 				}
 				slot[k][j] = (live ? (cl_uint)s64 : 0u);
 				gone[k] |= (live ? 0u : (1u << j));
@@ -1441,6 +1467,15 @@ gpupreagg_dense_lookup_body(kern_gpupreagg *kgpreagg,
 				const char *rec = recs + (size_t)reclen * slot[k][j];
 				/* a second load of the same line is a second L2 request, and this
 				 * kernel is bound by the L2 request rate */
+#if GPUPREAGG_ABLATE & 2
+				if (reclen != 0)			/* (measurement only: no record is read) */
+				{
+					words[j][0] = 1;
+					words[j][1] = slot[k][j] % 10000u;
+					words[j][2] = words[j][3] = 0;
+				}
+				else
+#endif
 				if (reclen == 8)
 				{
 					cl_ulong w = *(const cl_ulong *)rec;
@@ -1505,13 +1540,20 @@ gpupreagg_dense_lookup_body(kern_gpupreagg *kgpreagg,
 					STROM_KVAR_LIST(X)
 #undef X
 					KV.__dummy = 0;
+#if GPUPREAGG_ABLATE & 1
+					/* (measurement only: nothing is accumulated) */
+					if (gpupreagg_ablate_sink(KV) == 0x12345677)
+						chunk_status = StromError_CpuReCheck;
+					else if (false)
+#endif
 #if defined(GPUPREAGG_PACKABLE) && GPUPREAGG_PACKABLE
 					if (PACKED)
-						gpupreagg_packed_row(lds, ctl, pk, KP, KV, gid_lo, G, param_error, &chunk_status);
+						gpupreagg_packed_row(lds, ctl, pk, KP, KV, gid_lo, G, param_error, &chunk_status,
+											 (qual_ok[k] >> j) & 1);
 					else
 #endif
 						gpupreagg_dense_row(lds, ctl, L, KP, KV, gid_lo, G, NREP, rep,
-											param_error, &chunk_status);
+											param_error, &chunk_status, (qual_ok[k] >> j) & 1);
 				}
 			}
 		}
@@ -1615,7 +1657,7 @@ gpupreagg_reg_row(gpupreagg_reg_state<NG> &S, const gpupreagg_dense_ctl *ctl,
 		cl_uint		off = (kv.isnull ? range : (cl_uint)off64);						\
 		if (!kv.isnull && (off64 < 0 || off64 >= (cl_long)range))					\
 			out_of_domain = true;													\
-		gid += off * ctl->key_stride[kidx];											\
+		gid += (kidx == 0 ? off : off * ctl->key_stride[kidx]);	/* (stride 0 is 1) */											\
 	}
 	GPUPREAGG_KEY_LIST(X)
 #undef X
@@ -1920,7 +1962,7 @@ gpupreagg_priv_row(char *lds, gpupreagg_priv_state &S, const gpupreagg_dense_ctl
 		cl_uint		off = (kv.isnull ? range : (cl_uint)off64);						\
 		if (!kv.isnull && (off64 < 0 || off64 >= (cl_long)range))					\
 			out_of_domain = true;													\
-		gid += off * ctl->key_stride[kidx];											\
+		gid += (kidx == 0 ? off : off * ctl->key_stride[kidx]);	/* (stride 0 is 1) */											\
 	}
 	GPUPREAGG_KEY_LIST(X)
 #undef X
@@ -2994,7 +3036,7 @@ gpupreagg_census_body(const kern_gpupreagg *kgpreagg, const kern_data_store *kds
 			cl_uint		off = (kv.isnull ? range : (cl_uint)off64);					\
 			if (!kv.isnull && (off64 < 0 || off64 >= (cl_long)range))				\
 				out_of_domain = true;												\
-			gid += off * ctl->key_stride[kidx];										\
+			gid += (kidx == 0 ? off : off * ctl->key_stride[kidx]);	/* (stride 0 is 1) */										\
 		}
 		GPUPREAGG_KEY_LIST(X)
 #undef X
