@@ -301,6 +301,53 @@ strom_gpupreagg *strom_gpupreagg_create_hashed(strom_devprog_key key,
 											   int dindex, int *p_errcode);
 void		strom_gpupreagg_reset(strom_gpupreagg *sess);
 void		strom_gpupreagg_release(strom_gpupreagg *sess);
+/*
+ * The dense domain of ONE chunk: per group key the min and the range of the
+ * values its rows carry after the qual (kernel gpupreagg_keyrange; any chunk
+ * format, key expressions included).  Blocking, planning time.  Answers
+ * StromError_DataStoreOutOfRange when the keys have no dense ids (float /
+ * numeric keys, a spread beyond 32 bits): such a query takes
+ * strom_gpupreagg_create_hashed().
+ */
+int			strom_gpupreagg_chunk_domain(strom_devprog_key key,
+										 const strom_preagg_target *targets, int ntargets,
+										 const kern_parambuf *kparams,
+										 const kern_data_store *kds, strom_dstore *kds_dev,
+										 const kern_row_map *krowmap,
+										 int dindex, strom_preagg_domain *domain_out);
+/*
+ * The reference's own per-chunk message, field by field:
+ *   pgstrom_gpupreagg {msg, dprog_key, needs_grouping, num_groups, pds,
+ *                      pds_dest, kern_gpupreagg}   (opencl_gpupreagg.h:994-1003)
+ *   <- clserv_process_gpupreagg (gpupreagg.c:3849-4240) + clserv_respond_gpupreagg
+ * One chunk in, that chunk's partial rows out; nothing is kept between
+ * requests (a backend that wants the table to stay in HBM across chunks uses
+ * the session calls above).  'kgpreagg' is the host image {status,
+ * sortbuf_len, kern_parambuf, kern_row_map} as KERN_GPUPREAGG_* lay it out
+ * (nvalids < 0: every row; sortbuf_len is not used -- nothing is sorted);
+ * 'kds_dest' is the caller's TUPSLOT buffer of dest_length bytes.  Before
+ * done() runs: kgpreagg->status is the errcode (KERN_GPUPREAGG_DMARECV_*),
+ * and on success kds_dest holds one row per group of this chunk, nitems
+ * set, keys and partial values in target-list order exactly as
+ * strom_gpupreagg_fetch() writes them (the backend reads rows 0..nitems-1,
+ * gpupreagg.c:2610-2664).  StromError_CpuReCheck: kds_dest is untouched, the
+ * backend aggregates the chunk itself (gpupreagg_next_tuple_fallback,
+ * gpupreagg.c:2507-2607).  StromError_DataStoreNoSpace: kds_dest is too small
+ * for the chunk's groups.  needs_grouping must agree with the program (it
+ * has group keys or not); num_groups is the planner's estimate and sizes the
+ * first hash table when the keys have no dense ids.  The request runs on a
+ * runtime thread (key range -> table geometry -> fold -> partial rows); this
+ * call only queues it.
+ */
+strom_task *strom_submit_gpupreagg_chunk(strom_devprog_key key,
+										 const strom_preagg_target *targets, int ntargets,
+										 kern_gpupreagg *kgpreagg,
+										 const kern_data_store *kds, strom_dstore *kds_dev,
+										 kern_data_store *kds_dest, size_t dest_length,
+										 int needs_grouping, double num_groups,
+										 int dindex,
+										 strom_done_cb done, void *arg,
+										 int *p_errcode);
 
 /* ------------------------------------------------------------------ *
  * GpuHashJoin

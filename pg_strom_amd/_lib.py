@@ -155,6 +155,11 @@ PROTOTYPES = {
     "strom_gpupreagg_compact": (c_int, [c_void_p, c_void_p, c_size_t]),
     "strom_gpupreagg_reset": (None, [c_void_p]),
     "strom_gpupreagg_release": (None, [c_void_p]),
+    "strom_gpupreagg_chunk_domain": (c_int, [c_uint64, c_void_p, c_int, c_void_p, c_void_p, c_void_p,
+                                             c_void_p, c_int, ctypes.POINTER(strom_preagg_domain)]),
+    "strom_submit_gpupreagg_chunk": (c_void_p, [c_uint64, c_void_p, c_int, c_void_p, c_void_p, c_void_p,
+                                                c_void_p, c_size_t, c_int, ctypes.c_double, c_int,
+                                                c_void_p, c_void_p, ctypes.POINTER(c_int)]),
     "strom_hashjoin_table_create": (c_void_p, [c_uint64, c_void_p, c_size_t, c_int,
                                                ctypes.POINTER(c_int)]),
     "strom_hashjoin_table_release": (None, [c_void_p]),

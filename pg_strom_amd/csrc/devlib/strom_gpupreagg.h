@@ -3062,6 +3062,131 @@ gpupreagg_census(const kern_gpupreagg *kgpreagg, const kern_data_store *kds,
 }
 
 /* ====================================================================== *
+ * key range of ONE chunk (after the qual): the dense domain of a request
+ * that arrives without one -- the reference's per-chunk message
+ * (pgstrom_gpupreagg, opencl_gpupreagg.h:994-1003) knows nothing about the
+ * other chunks of its query; its kernels sort whatever keys the chunk holds
+ * (opencl_gpupreagg.h:620-856).  Here the host sizes the dense table from
+ * this pass (strom_gpupreagg_chunk_domain / strom_submit_gpupreagg_chunk),
+ * or goes to the hashed GROUP BY when the ranges are too sparse.
+ * Per key: min, max over the rows that pass the qual and have a non-NULL
+ * key; a lane keeps its own pair, a wave combines by shuffles, one atomic
+ * pair per wave and key.
+ * ====================================================================== */
+struct gpupreagg_keyrange_t {
+	cl_long		kmin[GPUPREAGG_MAXKEYS];
+	cl_long		kmax[GPUPREAGG_MAXKEYS];
+	cl_uint		nvalues[GPUPREAGG_MAXKEYS];		/* != 0: the key had a non-NULL value */
+	cl_uint		nrows;							/* != 0: a row passed the qual */
+	cl_uint		__pad;
+};
+
+template <bool IS_COLUMN>
+__device__ __forceinline__ void
+gpupreagg_keyrange_body(const kern_gpupreagg *kgpreagg, const kern_data_store *kds,
+						const kern_data_store *ktoast, const kern_row_map *krowmap,
+						gpupreagg_keyrange_t *out)
+{
+	const kern_parambuf *kparams = KERN_GPUPREAGG_PARAMBUF(kgpreagg);
+	bool		use_map = (krowmap != NULL && krowmap->nvalids >= 0);
+	size_t		nrows = (use_map ? (size_t)krowmap->nvalids : (size_t)kds->nitems);
+	cl_int		param_error = StromError_Success;
+	strom_kparams KP;
+
+	gpupreagg_load_kparams(KP, kparams, &param_error);
+	const bool	is_column = IS_COLUMN;
+	const cl_int chunk_format = kds->format;
+	const bool	row_family = (chunk_format == KDS_FORMAT_ROW || chunk_format == KDS_FORMAT_ROW_FLAT);
+	const kern_coldir *coldir_g = KERN_DATA_STORE_COLDIR(kds);
+#define X(attno,colidx,NAME)													\
+	const char *col_##attno = (is_column ? (const char *)kds + coldir_g[colidx].values_off : NULL);	\
+	const cl_uint *nul_##attno = ((is_column && coldir_g[colidx].nulls_off != 0)	\
+		? (const cl_uint *)((const char *)kds + coldir_g[colidx].nulls_off) : NULL);
+	STROM_KVAR_LIST(X)
+#undef X
+	cl_long		my_min[GPUPREAGG_NKEYS > 0 ? GPUPREAGG_NKEYS : 1];
+	cl_long		my_max[GPUPREAGG_NKEYS > 0 ? GPUPREAGG_NKEYS : 1];
+	cl_uint		my_seen = 0;			/* bit k: key k had a value; bit 31: a row passed */
+	for (int k = 0; k < (GPUPREAGG_NKEYS > 0 ? GPUPREAGG_NKEYS : 1); k++)
+	{
+		my_min[k] = 0x7fffffffffffffffL;
+		my_max[k] = -0x7fffffffffffffffL - 1;
+	}
+	for (size_t r = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+		 r < nrows;
+		 r += (size_t)gridDim.x * blockDim.x)
+	{
+		cl_uint		kds_index = (use_map ? (cl_uint)krowmap->rindex[r] : (cl_uint)r);
+		strom_kvars	KV;
+		cl_int		errcode = param_error;
+		const HeapTupleHeaderData *htup = NULL;
+		if (!is_column && row_family)
+			htup = strom_locate_tuple(kds, chunk_format, kds_index);
+#define X(attno,colidx,NAME)													\
+		KV.KVAR_##attno = (is_column											\
+			? STROM_COLUMN_REF(NAME, col_##attno, nul_##attno, kds_index)		\
+			: row_family ? STROM_TUPLE_REF(NAME, kds, htup, colidx)				\
+			: pg_##NAME##_vref(kds, ktoast, &errcode, colidx, kds_index));
+		STROM_KVAR_LIST(X)
+#undef X
+		KV.__dummy = 0;
+		pg_bool_t	rc = gpupreagg_qual_eval(&errcode, KP, KV);
+		if (errcode == StromError_Success && !EVAL(rc))
+			continue;
+		my_seen |= 0x80000000u;
+#define X(kidx,resno,NAME)															\
+		{																			\
+			pg_##NAME##_t kv = gpupreagg_key_##kidx(&errcode, KP, KV);				\
+			if (!kv.isnull)															\
+			{																		\
+				cl_long	v = (cl_long)kv.value;										\
+				my_min[kidx] = (v < my_min[kidx] ? v : my_min[kidx]);				\
+				my_max[kidx] = (v > my_max[kidx] ? v : my_max[kidx]);				\
+				my_seen |= (1u << kidx);											\
+			}																		\
+		}
+		GPUPREAGG_KEY_LIST(X)
+#undef X
+	}
+	/* wave combine, then one atomic pair per wave and key */
+	for (int off = STROM_WAVE / 2; off > 0; off >>= 1)
+	{
+		my_seen |= (cl_uint)__shfl_xor((int)my_seen, off, STROM_WAVE);
+		for (int k = 0; k < GPUPREAGG_NKEYS; k++)
+		{
+			cl_long	omin = __shfl_xor(my_min[k], off, STROM_WAVE);
+			cl_long	omax = __shfl_xor(my_max[k], off, STROM_WAVE);
+			my_min[k] = (omin < my_min[k] ? omin : my_min[k]);
+			my_max[k] = (omax > my_max[k] ? omax : my_max[k]);
+		}
+	}
+	if ((threadIdx.x & (STROM_WAVE - 1)) == 0 && my_seen != 0)
+	{
+		atomicOr(&out->nrows, 1u);
+		for (int k = 0; k < GPUPREAGG_NKEYS; k++)
+		{
+			if (!(my_seen & (1u << k)))
+				continue;
+			atomicOr(&out->nvalues[k], 1u);
+			atomicMin((long long *)&out->kmin[k], (long long)my_min[k]);
+			atomicMax((long long *)&out->kmax[k], (long long)my_max[k]);
+		}
+	}
+}
+
+extern "C" __global__ void
+__launch_bounds__(256)
+gpupreagg_keyrange(const kern_gpupreagg *kgpreagg, const kern_data_store *kds,
+				   const kern_data_store *ktoast, const kern_row_map *krowmap,
+				   gpupreagg_keyrange_t *out)
+{
+	if (kds->format == KDS_FORMAT_COLUMN)
+		gpupreagg_keyrange_body<true>(kgpreagg, kds, ktoast, krowmap, out);
+	else
+		gpupreagg_keyrange_body<false>(kgpreagg, kds, ktoast, krowmap, out);
+}
+
+/* ====================================================================== *
  * slabs -> resident table, fixed order; skipped when the chunk failed
  * ====================================================================== */
 /*

@@ -2377,3 +2377,278 @@ strom_gpupreagg_fetch(strom_gpupreagg *sess, kern_data_store *dest, size_t destl
 	dest->nitems = row;
 	return (long)row;
 }
+
+/* ================================================================== *
+ * The reference's per-chunk message: pgstrom_gpupreagg {msg, dprog_key,
+ * needs_grouping, num_groups, pds, pds_dest, kern_gpupreagg}
+ * (opencl_gpupreagg.h:994-1003), served by clserv_process_gpupreagg
+ * (gpupreagg.c:3849-4240).  One chunk in, the chunk's partial rows out in
+ * kds_dest -- nothing is kept between requests.  Built from the session
+ * machinery above: key range of the chunk -> dense table geometry (or the
+ * hashed GROUP BY when the keys do not map to dense ids) -> fold -> fetch.
+ * The steps have host decisions in between, so the request runs on the
+ * device's worker thread; the submitter only queues.
+ * ================================================================== */
+namespace {
+
+/* host image of gpupreagg_keyrange_t (strom_gpupreagg.h) */
+struct keyrange_image {
+	cl_long		kmin[STROM_PREAGG_MAXKEYS];
+	cl_long		kmax[STROM_PREAGG_MAXKEYS];
+	cl_uint		nvalues[STROM_PREAGG_MAXKEYS];
+	cl_uint		nrows;
+	cl_uint		pad;
+};
+
+int
+chunk_domain(strom_devprog_key key, Program *prog, Device *dev,
+			 const strom_preagg_target *targets, int ntargets,
+			 const kern_parambuf *kparams, strom_dstore *kds_dev,
+			 const kern_row_map *krowmap, strom_preagg_domain *dom)
+{
+	int		nkeys = 0;
+	memset(dom, 0, sizeof(*dom));
+	for (int i = 0; i < ntargets; i++)
+	{
+		if (targets[i].kind != STROM_PREAGG_KEY)
+			continue;
+		if (type_is_float(targets[i].type_oid) || targets[i].type_oid == STROM_NUMERICOID)
+			return StromError_DataStoreOutOfRange;		/* no dense ids for these */
+		nkeys++;
+	}
+	if (nkeys > STROM_PREAGG_MAXKEYS)
+		return StromError_DataStoreOutOfRange;
+	dom->nkeys = nkeys;
+	if (nkeys == 0)
+		return 0;
+	if (strom_lookup_device_program(key, 1) != STROM_DEVPROG_READY)
+		return StromError_ProgramBuildFailure;
+	(void)hipSetDevice(dev->hip_id);
+	hipStream_t stream = dev->pick_stream();
+	int		errcode = 0;
+	hipFunction_t fn = prog->get_function(dev, "gpupreagg_keyrange", &errcode);
+	if (!fn)
+		return errcode;
+	keyrange_image img;
+	memset(&img, 0, sizeof(img));
+	for (int k = 0; k < STROM_PREAGG_MAXKEYS; k++)
+	{
+		img.kmin[k] = INT64_MAX;
+		img.kmax[k] = INT64_MIN;
+	}
+	size_t	kg_len = STROMALIGN(offsetof(kern_gpupreagg, kparams) + kparams->length);
+	std::vector<char> kg(kg_len, 0);
+	memcpy(kg.data() + offsetof(kern_gpupreagg, kparams), kparams, kparams->length);
+	char   *d_kg = (char *)dev->pool.alloc(kg_len);
+	char   *d_out = (char *)dev->pool.alloc(sizeof(img));
+	void   *d_map = nullptr;
+	int		rc = 0;
+	do {
+		if (!d_kg || !d_out)
+		{
+			rc = StromError_OutOfMemory;
+			break;
+		}
+		if (hipMemcpyAsync(d_kg, kg.data(), kg_len, hipMemcpyHostToDevice, stream) != hipSuccess ||
+			hipMemcpyAsync(d_out, &img, sizeof(img), hipMemcpyHostToDevice, stream) != hipSuccess)
+		{
+			rc = StromError_HipInternal;
+			break;
+		}
+		cl_uint	nrows = kds_dev->head.nitems;
+		const void *a_map = nullptr;
+		if (krowmap && krowmap->nvalids >= 0)
+		{
+			size_t	len = offsetof(kern_row_map, rindex) + sizeof(cl_int) * (size_t)krowmap->nvalids;
+			d_map = dev->pool.alloc(len);
+			if (!d_map || hipMemcpyAsync(d_map, krowmap, len, hipMemcpyHostToDevice, stream) != hipSuccess)
+			{
+				rc = StromError_OutOfMemory;
+				break;
+			}
+			a_map = d_map;
+			nrows = (cl_uint)krowmap->nvalids;
+		}
+		const void *a_kg = d_kg;
+		const void *a_kds = kds_dev->devptr;
+		const void *a_toast = nullptr;
+		void	   *a_out = d_out;
+		void	   *args[] = { &a_kg, &a_kds, &a_toast, &a_map, &a_out };
+		unsigned	grid = (unsigned)std::min<size_t>(((size_t)nrows + 255) / 256,
+													  (size_t)dev->prop.multiProcessorCount * 8);
+		if (grid > 0 &&
+			hipModuleLaunchKernel(fn, grid, 1, 1, 256, 1, 1, 0, stream, args, nullptr) != hipSuccess)
+		{
+			rc = StromError_HipInternal;
+			break;
+		}
+		if (hipMemcpyAsync(&img, d_out, sizeof(img), hipMemcpyDeviceToHost, stream) != hipSuccess)
+			rc = StromError_HipInternal;
+	} while (0);
+	if (hipStreamSynchronize(stream) != hipSuccess && rc == 0)
+		rc = StromError_HipInternal;
+	if (d_kg) dev->pool.release(d_kg);
+	if (d_out) dev->pool.release(d_out);
+	if (d_map) dev->pool.release(d_map);
+	if (rc != 0)
+		return rc;
+	for (int k = 0; k < nkeys; k++)
+	{
+		if (img.nvalues[k] == 0)
+		{
+			dom->key_min[k] = 0;		/* NULL keys only (or no row at all): the NULL slot alone */
+			dom->key_range[k] = 0;
+			continue;
+		}
+		/* (unsigned arithmetic: max - min of two int64 may not fit int64) */
+		cl_ulong span = (cl_ulong)img.kmax[k] - (cl_ulong)img.kmin[k];
+		if (span >= 0xfffffffeUL)
+			return StromError_DataStoreOutOfRange;
+		dom->key_min[k] = img.kmin[k];
+		dom->key_range[k] = (cl_uint)span + 1;
+	}
+	return 0;
+}
+
+}	/* namespace */
+
+extern "C" int
+strom_gpupreagg_chunk_domain(strom_devprog_key key,
+							 const strom_preagg_target *targets, int ntargets,
+							 const kern_parambuf *kparams,
+							 const kern_data_store *kds, strom_dstore *kds_dev,
+							 const kern_row_map *krowmap,
+							 int dindex, strom_preagg_domain *domain_out)
+{
+	STROM_ABI_TRY
+	Program *prog = lookup_program(key);
+	Device *dev = get_device(dindex);
+	if (!prog || !dev || !targets || ntargets < 1 || !kparams || !domain_out || (!kds) == (!kds_dev) ||
+		(kds_dev && kds_dev->dindex != dindex))
+		return (!dev ? StromError_ServerNotReady : StromError_BadRequestMessage);
+	strom_dstore *tmp = nullptr;
+	if (!kds_dev)
+	{
+		tmp = strom_dstore_upload(kds, dindex);
+		if (!tmp)
+			return StromError_OutOfMemory;
+		kds_dev = tmp;
+	}
+	int rc = chunk_domain(key, prog, dev, targets, ntargets, kparams, kds_dev, krowmap, domain_out);
+	if (tmp)
+		strom_dstore_release(tmp);
+	return rc;
+	STROM_ABI_CATCH(StromError_OutOfMemory, (int *)nullptr)
+}
+
+extern "C" strom_task *
+strom_submit_gpupreagg_chunk(strom_devprog_key key,
+							 const strom_preagg_target *targets, int ntargets,
+							 kern_gpupreagg *kgpreagg,
+							 const kern_data_store *kds, strom_dstore *kds_dev,
+							 kern_data_store *kds_dest, size_t dest_length,
+							 int needs_grouping, double num_groups,
+							 int dindex,
+							 strom_done_cb done, void *arg, int *p_errcode)
+{
+	STROM_ABI_TRY
+	int		dummy;
+	if (!p_errcode)
+		p_errcode = &dummy;
+	*p_errcode = 0;
+	Program *prog = lookup_program(key);
+	Device *dev = get_device(dindex);
+	if (!prog || !dev || !targets || ntargets < 1 || !kgpreagg || !kds_dest ||
+		(!kds) == (!kds_dev) || (kds_dev && kds_dev->dindex != dindex) ||
+		kgpreagg->kparams.length < offsetof(kern_parambuf, poffset) ||
+		dest_length < (size_t)KDS_HEAD_LENGTH(ntargets))
+	{
+		*p_errcode = (!dev ? StromError_ServerNotReady : StromError_BadRequestMessage);
+		return nullptr;
+	}
+	int		nkeys = 0;
+	for (int i = 0; i < ntargets; i++)
+		nkeys += (targets[i].kind == STROM_PREAGG_KEY);
+	if ((needs_grouping != 0) != (nkeys > 0))
+	{
+		/* the message says GROUP BY, the program has no key (or the reverse) */
+		*p_errcode = StromError_BadRequestMessage;
+		return nullptr;
+	}
+	std::vector<strom_preagg_target> tg(targets, targets + ntargets);
+	strom_task_impl *task = task_create(dev, done, arg);
+	device_run_async(dev, [=]() {
+		const kern_parambuf *kparams = KERN_GPUPREAGG_PARAMBUF(kgpreagg);
+		const kern_row_map *krowmap = KERN_GPUPREAGG_KROWMAP(kgpreagg);
+		strom_dstore	   *tmp = nullptr, *src = kds_dev;
+		strom_gpupreagg	   *sess = nullptr;
+		strom_perfmon		pfm;
+		int					rc = 0;
+		memset(&pfm, 0, sizeof(pfm));
+		if (krowmap->nvalids < 0)
+			krowmap = nullptr;
+		do {
+			if (strom_lookup_device_program(key, 1) != STROM_DEVPROG_READY)
+			{
+				rc = StromError_ProgramBuildFailure;
+				break;
+			}
+			if (!src)
+			{
+				src = tmp = strom_dstore_upload(kds, dindex);
+				if (!tmp)
+				{
+					rc = StromError_OutOfMemory;
+					break;
+				}
+			}
+			strom_preagg_domain dom;
+			rc = chunk_domain(key, prog, dev, tg.data(), ntargets, kparams, src, krowmap, &dom);
+			if (rc == 0)
+				sess = strom_gpupreagg_create(key, tg.data(), ntargets, kparams, &dom, dindex, &rc);
+			if (!sess && rc == StromError_DataStoreOutOfRange)
+			{
+				/* keys without dense ids (float / numeric / sparse): hashed GROUP BY */
+				uint32_t hint = (num_groups > 0 && num_groups < 4e9 ? (uint32_t)num_groups : 0);
+				rc = 0;
+				sess = strom_gpupreagg_create_hashed(key, tg.data(), ntargets, kparams, hint, dindex, &rc);
+			}
+			if (!sess)
+			{
+				if (rc == 0)
+					rc = StromError_HipInternal;
+				break;
+			}
+			strom_task *fold = strom_submit_gpupreagg(sess, nullptr, src, krowmap, nullptr, nullptr, &rc);
+			if (!fold)
+				break;
+			rc = strom_task_wait(fold, &pfm);
+			if (rc != 0)
+				break;					/* CpuReCheck: the chunk goes back whole (gpupreagg.c:2746-2750) */
+			long	need = strom_gpupreagg_fetch(sess, nullptr, 0);
+			if (need < 0)
+			{
+				rc = (int)-need;
+				break;
+			}
+			if ((size_t)need > dest_length)
+			{
+				rc = StromError_DataStoreNoSpace;
+				break;
+			}
+			long	n = strom_gpupreagg_fetch(sess, kds_dest, dest_length);
+			if (n < 0)
+				rc = (int)-n;
+		} while (0);
+		if (sess)
+			strom_gpupreagg_release(sess);
+		if (tmp)
+			strom_dstore_release(tmp);
+		kgpreagg->status = rc;			/* KERN_GPUPREAGG_DMARECV: the status word */
+		task->pfm = pfm;
+		task->pfm.enabled = perfmon_enabled();
+		task_fail(task, rc);			/* nothing of its own on a stream: completes on the completer thread */
+	});
+	return task;
+	STROM_ABI_CATCH(nullptr, p_errcode)
+}

@@ -106,6 +106,15 @@ struct Device {
 	std::deque<strom_task_impl *> cq;
 	bool				shutting_down = false;
 	size_t				inflight = 0;
+	/* requests that are a SEQUENCE of device steps with host decisions in between
+	 * (the per-chunk GpuPreAgg message: key range -> table geometry -> fold -> partial
+	 * rows) run on this thread, started on first use -- one of the reference's server
+	 * threads (opencl_serv.c:76-90); the submitter only queues */
+	std::thread			worker;
+	std::mutex			wq_lock;
+	std::condition_variable wq_cond;
+	std::deque<std::function<void()>> wq;
+	bool				worker_stop = false;
 
 	hipStream_t pick_stream() { return streams[next_stream++ % streams.size()]; }
 };
@@ -215,6 +224,8 @@ bool		perfmon_enabled();
 strom_task_impl *task_create(Device *dev, strom_done_cb done, void *arg);
 void		task_enqueue(strom_task_impl *task);
 void		task_fail(strom_task_impl *task, int errcode);
+/* queue 'fn' for the device's worker thread (see Device::worker) */
+void		device_run_async(Device *dev, std::function<void()> fn);
 hipEvent_t	task_event(strom_task_impl *task, hipStream_t stream = nullptr);
 /* an event of the task that is NOT recorded here: hipExtModuleLaunchKernel attaches a
  * start / stop pair to the kernel's own dispatch packet (its timestamps are the kernel's),

@@ -247,6 +247,15 @@ class GpuPreAgg(object):
         return self.collect(self.submit(chunk, row_map))
 
     # results ---------------------------------------------------------------
+    def _decode_tupslot(self, buf, n):
+        ncols = len(self.targets)
+        head = (KDS_HEAD_FIXED + 8 * ncols + 15) & ~15
+        stride = (9 * ncols + 7) & ~7
+        body = np.frombuffer(buf[head:head + stride * n].tobytes(), dtype=np.uint8).reshape(n, stride)
+        values = body[:, :8 * ncols].copy().view(np.uint64).reshape(n, ncols)
+        isnull = body[:, 8 * ncols:9 * ncols] != 0
+        return PartialRows(self.targets, values, isnull)
+
     def fetch(self):
         need = lib.strom_gpupreagg_fetch(self.session, None, 0)
         if need < 0:
@@ -255,13 +264,94 @@ class GpuPreAgg(object):
         n = lib.strom_gpupreagg_fetch(self.session, buf.ctypes.data, need)
         if n < 0:
             raise runtime.StromError(-n, "strom_gpupreagg_fetch")
+        return self._decode_tupslot(buf, n)
+
+    # the reference's per-chunk message ---------------------------------------
+    def _begin_program(self, ext_params, ext_isnull):
+        runtime.init()
+        if self.program is None:
+            self.program = runtime.DevProgram(self.codegen.source, self.codegen.extra_flags)
+        return self.codegen.parambuf(ext_params, ext_isnull)
+
+    def chunk_domain(self, chunk, row_map=None, ext_params=(), ext_isnull=None, dindex=0):
+        """[(min, range)] per key of ONE chunk, after the qual (strom_gpupreagg_chunk_domain)"""
+        parambuf = self._begin_program(ext_params, ext_isnull)
+        pb = ctypes.create_string_buffer(parambuf, len(parambuf))
+        if isinstance(chunk, runtime.DeviceStore):
+            kds_host, kds_dev = None, chunk.handle
+        else:
+            kds_host, kds_dev = chunk.ctypes.data, None
+        rm = None
+        if row_map is not None:
+            r = np.ascontiguousarray(row_map, dtype=np.int32)
+            rm = np.concatenate([np.array([len(r)], dtype=np.int32), r])
+        dom = strom_preagg_domain()
+        rc = lib.strom_gpupreagg_chunk_domain(self.program.key, self.codegen._targets_c, len(self.targets),
+                                              pb, kds_host, kds_dev,
+                                              rm.ctypes.data if rm is not None else None,
+                                              dindex, ctypes.byref(dom))
+        if rc != 0:
+            raise runtime.StromError(rc, "strom_gpupreagg_chunk_domain")
+        return [(int(dom.key_min[i]), int(dom.key_range[i])) for i in range(dom.nkeys)]
+
+    def submit_chunk(self, chunk, row_map=None, ext_params=(), ext_isnull=None, dest_rooms=None,
+                     num_groups=0.0, done=None, dindex=0):
+        """One pgstrom_gpupreagg message (opencl_gpupreagg.h:994-1003; built by
+        pgstrom_create_gpupreagg, gpupreagg.c:2329-2498): the kern_gpupreagg image
+        {status, sortbuf_len, kparams, krowmap} and a TUPSLOT kds_dest the caller sizes
+        (dest_rooms rows; default: the chunk's row count, what the reference allocates).
+        Returns a pending request for collect_chunk()."""
+        parambuf = self._begin_program(ext_params, ext_isnull)
+        if isinstance(chunk, runtime.DeviceStore):
+            kds_host, kds_dev = None, chunk.handle
+            nitems = chunk.nitems if hasattr(chunk, "nitems") else None
+        else:
+            kds_host, kds_dev = chunk.ctypes.data, None
+            nitems = KdsHead(chunk).nitems
+        r = (np.ascontiguousarray(row_map, dtype=np.int32) if row_map is not None
+             else np.zeros(0, dtype=np.int32))
+        nvalids = len(r) if row_map is not None else -1
+        # KERN_GPUPREAGG_KROWMAP: STROMALIGN(offsetof(kparams) + kparams.length)
+        map_off = (16 + len(parambuf) + 15) & ~15
+        kg = aligned_buffer(map_off + 4 + 4 * len(r) + 16, 64)
+        kg[:] = 0
+        kg[16:16 + len(parambuf)] = np.frombuffer(parambuf, dtype=np.uint8)
+        kg[map_off:map_off + 4] = np.array([nvalids], dtype=np.int32).view(np.uint8)
+        if len(r):
+            kg[map_off + 4:map_off + 4 + 4 * len(r)] = r.view(np.uint8)
         ncols = len(self.targets)
+        if dest_rooms is None:
+            dest_rooms = max(1, nvalids if nvalids >= 0 else (nitems or 1))
         head = (KDS_HEAD_FIXED + 8 * ncols + 15) & ~15
         stride = (9 * ncols + 7) & ~7
-        body = np.frombuffer(buf[head:head + stride * n].tobytes(), dtype=np.uint8).reshape(n, stride)
-        values = body[:, :8 * ncols].copy().view(np.uint64).reshape(n, ncols)
-        isnull = body[:, 8 * ncols:9 * ncols] != 0
-        return PartialRows(self.targets, values, isnull)
+        dest = aligned_buffer(head + stride * dest_rooms, 64)
+        dest[:head] = 0
+        err = ctypes.c_int(0)
+        nkeys = sum(1 for k, _ in self.targets if k == KIND_KEY)
+        task = lib.strom_submit_gpupreagg_chunk(self.program.key, self.codegen._targets_c, ncols,
+                                                kg.ctypes.data, kds_host, kds_dev,
+                                                dest.ctypes.data, len(dest),
+                                                1 if nkeys else 0, float(num_groups), dindex,
+                                                done, None, ctypes.byref(err))
+        if not task:
+            raise runtime.StromError(err.value, "strom_submit_gpupreagg_chunk")
+        return (task, chunk, kg, dest, r)
+
+    def collect_chunk(self, pending):
+        """(status, PartialRows or None): status 0 -> the chunk's partial rows, 2 CpuReCheck"""
+        task, _, kg, dest, _ = pending
+        pfm = strom_perfmon()
+        rc = lib.strom_task_wait(task, ctypes.byref(pfm))
+        status = int(kg[0:4].view(np.int32)[0])
+        assert status == rc, (status, rc)
+        if rc == -11:
+            raise runtime.StromError(rc, "GpuPreAgg kernel build:\n" + self.program.errmsg())
+        if rc == 2:
+            return rc, None
+        if rc != 0:
+            raise runtime.StromError(rc, "GpuPreAgg (chunk message)")
+        n = KdsHead(dest).nitems
+        return rc, self._decode_tupslot(dest, n)
 
     def table_tensor_info(self):
         """(device pointer, nbytes, ngroups) of the resident table -- what an

@@ -135,10 +135,18 @@ def compare_with_oracle(spec, bufs, domain, ext=(), float_tol=1e-12, compact=Fal
         pr = agg.fetch()
     finally:
         agg.end()
-    # oracle: per chunk partial rows merged with the associative rules
+    assert_matches_oracle(spec, agg, bufs, pr, ext, float_tol)
+
+
+def assert_matches_oracle(spec, agg, bufs, pr, ext=(), float_tol=1e-12, row_maps=None):
+    """device partial rows (one per group over all of 'bufs') against the oracle's
+    per-chunk partial rows merged with the associative rules"""
+    nt = len(agg.targets)
     merged = {}
-    for b in bufs:
-        rc, v, n = oracle.gpupreagg(spec, b, nt, ext)
+    for bi, b in enumerate(bufs):
+        rm = None if row_maps is None else row_maps[bi]
+        rc, v, n = oracle.gpupreagg(spec, b, nt, ext, row_map=rm) if rm is not None \
+            else oracle.gpupreagg(spec, b, nt, ext)
         assert rc == 0
         for i in range(len(v)):
             key = tuple((None if n[i, t] else int(v[i, t].view(np.int64)))
@@ -667,3 +675,135 @@ def test_hashed_roles_split_the_groups_over_lds_tables(hint):
     has = want_min != 2**31 - 1
     assert np.array_equal(got_null[order], ~has)
     assert np.array_equal(got_min[order][has].astype(np.int64), want_min[has])
+
+
+# ---------------------------------------------------------------------------
+# the reference's per-chunk message (strom_submit_gpupreagg_chunk)
+# ---------------------------------------------------------------------------
+def chunk_runner(chunks):
+    """like hip_runner, but every chunk is ONE pgstrom_gpupreagg message: partial rows come
+    back per chunk in the caller's kds_dest and are concatenated -- the reference's Agg
+    node adds them up (pg_strom--1.0.sql:247-401)"""
+    cache = {}
+
+    def run(plan):
+        sup, picks = superset_plan(plan)
+        key = (sup["spec"], plan["table"])
+        if key not in cache:
+            vals, nulls = [], []
+            agg = GpuPreAgg(sup["spec"])
+            nt = len(agg.targets)
+            for buf, rows in chunks[plan["table"]]:
+                status, pr = agg.collect_chunk(agg.submit_chunk(buf))
+                if status == 2:
+                    assert plan["type"] == "int8"       # int8 partial sum overflow
+                    v, n = agg_golden.cpu_fallback_rows(sup, rows)
+                else:
+                    v, n = partial_rows_as_raw8(pr)
+                vals.append(v.reshape(-1, nt))
+                nulls.append(n.reshape(-1, nt))
+            cache[key] = (np.concatenate(vals), np.concatenate(nulls))
+        v, n = cache[key]
+        return v[:, picks], n[:, picks]
+    return run
+
+
+@pytest.mark.parametrize("fmt,nchunks", [("row", 3), ("column", 2)])
+def test_reference_regression_suites_through_the_chunk_message(fmt, nchunks):
+    """the reference's own regression answers with every chunk sent as the reference's own
+    message {kern_gpupreagg, pds, pds_dest}: no session, no domain from the caller"""
+    chunks = {"gpupreagg_test": agg_golden.fixture_chunks(fmt, nchunks),
+              "gpupreagg_zero_test": agg_golden.fixture_chunks(fmt, 1, empty=True)}
+    run = chunk_runner(chunks)
+    total = 0
+    for suite in ("nogrp_agg", "group_agg", "where_agg", "zero_agg"):
+        checked, _ = agg_golden.check_suite(suite, run)
+        total += checked
+    assert total >= 200
+
+
+@pytest.mark.parametrize("fmt", ["column", "row_flat", "tupslot"])
+def test_chunk_message_matches_oracle_per_chunk(fmt):
+    """two keys (one with NULLs and negative values), every partial kind; the library finds
+    the key ranges itself (gpupreagg_keyrange)"""
+    cols = random_table(50000, 77)
+    agg = GpuPreAgg(SPEC_ALL)
+    for i in range(2):
+        buf = kds.build_kds(fmt, [kds.Column(c.sqltype, c.values[i::2],
+                                              None if c.isnull is None else c.isnull[i::2]) for c in cols])
+        assert agg.chunk_domain(buf) == [(-7, 50), (0, 3)]
+        status, pr = agg.collect_chunk(agg.submit_chunk(buf))
+        assert status == 0
+        assert_matches_oracle(SPEC_ALL, agg, [buf], pr)
+
+
+def test_chunk_message_row_map_resident_chunk_and_callback():
+    import threading
+    from pg_strom_amd._lib import DONE_CB
+    cols = random_table(30000, 3)
+    buf = kds.build_kds("column", cols)
+    spec = ("(gpupreagg (qual (int4gt (var 3 int4) (param 0 int4)))"
+            " (key (var 2 int2)) (nrows) (psum (var 4 float8)) (pmax (var 3 int4)))")
+    agg = GpuPreAgg(spec)
+    rm = np.arange(0, 30000, 3, dtype=np.int32)
+    ds = runtime.DeviceStore.upload(buf)
+    seen = []
+    fired = threading.Event()
+
+    def on_done(arg, errcode, pfm):
+        seen.append((errcode, threading.get_ident()))
+        fired.set()
+    cb = DONE_CB(on_done)
+    try:
+        pending = agg.submit_chunk(ds, row_map=rm, ext_params=[np.int32(0)], done=cb)
+        assert fired.wait(60)
+        status, pr = agg.collect_chunk(pending)
+    finally:
+        ds.release()
+    assert status == 0 and seen == [(0, seen[0][1])] and seen[0][1] != threading.get_ident()
+    assert_matches_oracle(spec, agg, [buf], pr, ext=[np.int32(0)], row_maps=[rm])
+
+
+def test_chunk_message_keys_without_dense_ids_take_the_hashed_table():
+    """float8 key and a sparse int8 key: no dense ids -> the library goes to the hashed
+    GROUP BY by itself; results are the oracle's"""
+    rng = np.random.default_rng(8)
+    n = 40000
+    f = rng.integers(0, 40, n).astype(np.float64) / 4
+    f[::97] = np.nan
+    big = rng.integers(0, 50, n).astype(np.int64) * (1 << 40) - (1 << 45)
+    x = rng.integers(-1000, 1000, n).astype(np.int32)
+    buf = kds.build_kds("column", [kds.Column("float8", f), kds.Column("int8", big), kds.Column("int4", x)])
+    for spec in ("(gpupreagg (key (var 1 float8)) (nrows) (psum (int8 (var 3 int4))))",
+                 "(gpupreagg (key (var 2 int8)) (nrows) (pmin (var 3 int4)) (pmax (var 3 int4)))"):
+        agg = GpuPreAgg(spec)
+        with pytest.raises(runtime.StromError) as ei:
+            agg.chunk_domain(buf)
+        assert ei.value.errcode == 302          # DataStoreOutOfRange
+        status, pr = agg.collect_chunk(agg.submit_chunk(buf, num_groups=64))
+        assert status == 0
+        rc, v, nn = oracle.gpupreagg(spec, buf, len(agg.targets))
+        got_v, got_n = partial_rows_as_raw8(pr)
+        assert rc == 0 and len(got_v) == len(v)
+        want = sorted((tuple(int(a) for a in v[i]), tuple(bool(b) for b in nn[i])) for i in range(len(v)))
+        got = sorted((tuple(int(a) for a in got_v[i]), tuple(bool(b) for b in got_n[i])) for i in range(len(v)))
+        assert got == want
+
+
+def test_chunk_message_recheck_and_no_space():
+    n = 5000
+    g = (np.arange(n) % 100).astype(np.int32)
+    x = np.full(n, (1 << 62), dtype=np.int64)           # int8 sum overflows -> CpuReCheck
+    buf = kds.build_kds("row", [kds.Column("int4", g), kds.Column("int8", x)])
+    spec = "(gpupreagg (key (var 1 int4)) (nrows) (psum (var 2 int8)))"
+    agg = GpuPreAgg(spec)
+    status, pr = agg.collect_chunk(agg.submit_chunk(buf))
+    assert status == 2 and pr is None
+    # 100 groups do not fit a 10-row kds_dest
+    spec2 = "(gpupreagg (key (var 1 int4)) (nrows))"
+    agg2 = GpuPreAgg(spec2)
+    with pytest.raises(runtime.StromError) as ei:
+        agg2.collect_chunk(agg2.submit_chunk(buf, dest_rooms=10))
+    assert ei.value.errcode == 301              # DataStoreNoSpace
+    status, pr = agg2.collect_chunk(agg2.submit_chunk(buf, dest_rooms=100))
+    assert status == 0 and len(pr) == 100
