@@ -372,6 +372,9 @@ typedef struct {
 #define STROM_FLOAT4OID		700
 #define STROM_FLOAT8OID		701
 #define STROM_BPCHAROID		1042
+/* character(n) as the varlena PostgreSQL stores (pg_type oid 1042 as well; the
+ * expression IR tells it from the by-value char(1) above by its own tag) */
+#define STROM_BPCHARNOID		(0x10000 | 1042)
 #define STROM_DATEOID		1082
 #define STROM_TIMEOID		1083
 #define STROM_TIMESTAMPOID	1114

@@ -220,12 +220,65 @@ type_by_name(const char *s)
 		{"integer", STROM_INT4OID}, {"int", STROM_INT4OID}, {"smallint", STROM_INT2OID},
 		{"bigint", STROM_INT8OID}, {"real", STROM_FLOAT4OID}, {"double", STROM_FLOAT8OID},
 		{"float", STROM_FLOAT8OID}, {"bpchar", STROM_BPCHAROID},
+		{"text", STROM_TEXTOID}, {"character", STROM_BPCHARNOID},
 	};
 	size_t i;
 	for (i = 0; i < sizeof(t) / sizeof(t[0]); i++)
 		if (strcmp(t[i].n, s) == 0)
 			return t[i].oid;
 	return 0;
+}
+
+static int type_is_varlena(int t)
+{ return t == STROM_TEXTOID || t == STROM_BPCHARNOID; }
+
+/*
+ * text / character(n) values are the address of their varlena datum
+ * (opencl_common.h:1126-1154 pg_varlena_t).  Readable in place: a 1-byte
+ * header or an uncompressed 4-byte header; compressed and external datums go
+ * back to the CPU.
+ */
+static int
+varlena_readable(const void *addr)
+{
+	uint8_t b0 = *(const uint8_t *)addr;
+	return !(b0 == 0x01 || (b0 & 0x03) == 0x02);
+}
+
+static const uint8_t *
+varlena_payload(const void *addr, int *len)
+{
+	const uint8_t *p = (const uint8_t *)addr;
+	uint32_t w;
+	if (p[0] & 0x01)
+	{
+		*len = (int)((p[0] >> 1) & 0x7f) - 1;
+		return p + 1;
+	}
+	memcpy(&w, p, 4);
+	*len = (int)((w >> 2) & 0x3fffffff) - 4;
+	return p + 4;
+}
+
+/* text_compare / bpchar_compare (opencl_textlib.h:150-193, 285-312): bytewise
+ * on unsigned bytes (PostgreSQL's "C" collation = memcmp), the shorter one
+ * first; character(n) ignores trailing blanks */
+static int
+varlena_compare(const void *a, const void *b, int blank_padded)
+{
+	int la, lb, n, c;
+	const uint8_t *pa = varlena_payload(a, &la);
+	const uint8_t *pb = varlena_payload(b, &lb);
+	if (blank_padded)
+	{
+		while (la > 0 && pa[la - 1] == ' ') la--;
+		while (lb > 0 && pb[lb - 1] == ' ') lb--;
+	}
+	n = la < lb ? la : lb;
+	c = n > 0 ? memcmp(pa, pb, (size_t)n) : 0;
+	if (c != 0)
+		return c < 0 ? -1 : 1;
+	return la == lb ? 0 : (la > lb ? 1 : -1);
 }
 
 static int type_is_int(int t)
@@ -474,6 +527,20 @@ parse_literal(parser *ps, int type, const char *lit, oracle_value *out)
 		out->isnull = 1;
 		return 1;
 	}
+	if (type_is_varlena(type))
+	{
+		/* a varlena image with a 4-byte header; lives as long as the process
+		 * (test infrastructure) */
+		size_t		len = strlen(lit);
+		uint32_t	hdr = (uint32_t)((len + 4) << 2);
+		char	   *img = malloc(len + 4);
+		if (!img)
+			return 0;
+		memcpy(img, &hdr, 4);
+		memcpy(img + 4, lit, len);
+		out->v.i = (int64_t)(intptr_t)img;
+		return 1;
+	}
 	switch (type)
 	{
 		case STROM_BOOLOID:
@@ -648,6 +715,23 @@ resolve_func(oracle_expr *e, const char *name)
 			e->type_oid = target;
 			return 1;
 		}
+	}
+	/* character(n) / text (codegen.c:616-629) */
+	if (nargs == 2 && a0 == STROM_BPCHARNOID && a1 == STROM_BPCHARNOID && !strncmp(name, "bpchar", 6))
+	{
+		if (!strcmp(name + 6, "cmp")) { e->op = OP_CMP; e->type_oid = STROM_INT4OID; return 1; }
+		op = binop_by_suffix(name + 6);
+		if (op >= OP_EQ && op <= OP_GE) { e->op = op; e->type_oid = STROM_BOOLOID; return 1; }
+	}
+	if (nargs == 2 && a0 == STROM_TEXTOID && a1 == STROM_TEXTOID)
+	{
+		if (!strcmp(name, "bttextcmp")) { e->op = OP_CMP; e->type_oid = STROM_INT4OID; return 1; }
+		op = -1;
+		if (!strcmp(name, "texteq") || !strcmp(name, "textne"))
+			op = binop_by_suffix(name + 4);
+		else if (!strncmp(name, "text_", 5))
+			op = binop_by_suffix(name + 5);
+		if (op >= OP_EQ && op <= OP_GE) { e->op = op; e->type_oid = STROM_BOOLOID; return 1; }
 	}
 	/* numeric */
 	if (nargs == 2 && a0 == STROM_NUMERICOID && a1 == STROM_NUMERICOID && !strncmp(name, "numeric_", 8))
@@ -1174,7 +1258,10 @@ eval_func(const oracle_expr *e, oracle_value *a, int32_t *errcode)
 			{
 				int c;
 				int t0 = a[0].type_oid, t1 = a[1].type_oid;
-				if (t0 == STROM_NUMERICOID)
+				if (type_is_varlena(t0))
+					c = varlena_compare((const void *)(intptr_t)a[0].v.i, (const void *)(intptr_t)a[1].v.i,
+										t0 == STROM_BPCHARNOID);
+				else if (t0 == STROM_NUMERICOID)
 					c = num_cmp(a[0].v.u, a[1].v.u);
 				else if (type_is_float(t0) || type_is_float(t1))
 					c = float_cmp(as_double(a[0]), as_double(a[1]));
@@ -1472,6 +1559,19 @@ eval_node(const oracle_expr *e, const eval_ctx *cx, int32_t *errcode)
 			if (e->attno < 0 || e->attno >= cx->n_ext ||
 				(cx->ext_isnull && cx->ext_isnull[e->attno]))
 				return make_null(e->type_oid);
+			if (type_is_varlena(e->type_oid))
+			{
+				/* the external value is the address of a varlena datum */
+				const void *vl = (const void *)(uintptr_t)cx->ext_values[e->attno];
+				if (!vl)
+					return make_null(e->type_oid);
+				if (!varlena_readable(vl))
+					return recheck(e->type_oid, errcode);
+				r = make_null(e->type_oid);
+				r.isnull = 0;
+				r.v.i = (int64_t)(intptr_t)vl;
+				return r;
+			}
 			return load_datum(e->type_oid, &cx->ext_values[e->attno]);
 		case N_VAR:
 		case N_IVAR:
@@ -1488,6 +1588,22 @@ eval_node(const oracle_expr *e, const eval_ctx *cx, int32_t *errcode)
 					if (!oracle_numeric_from_varlena(addr, &image))
 						return recheck(e->type_oid, errcode);
 					return load_datum(e->type_oid, &image);
+				}
+				if (type_is_varlena(e->type_oid))
+				{
+					if (!addr)
+						return make_null(e->type_oid);
+					if ((uint32_t)(e->attno - 1) >= k->ncols || k->colmeta[e->attno - 1].attlen >= 0)
+					{
+						set_error(errcode, StromError_DataStoreCorruption);
+						return make_null(e->type_oid);
+					}
+					if (!varlena_readable(addr))
+						return recheck(e->type_oid, errcode);
+					r = make_null(e->type_oid);
+					r.isnull = 0;
+					r.v.i = (int64_t)(intptr_t)addr;
+					return r;
 				}
 				return load_datum(e->type_oid, addr);
 			}

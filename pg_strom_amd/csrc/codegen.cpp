@@ -52,6 +52,9 @@ static const devtype_info devtype_catalog[] = {
 	{ STROM_TIMESTAMPOID, "timestamp", "timestamp", 8, DEVFUNC_NEEDS_TIMELIB },
 	{ STROM_NUMERICOID,   "numeric",   "numeric",   8, DEVFUNC_NEEDS_NUMERIC },
 	{ STROM_BPCHAROID,    "char1",     "char1",     1, 0 },
+	/* varlena: a value is the address of its datum (strom_textlib.h); row formats only */
+	{ STROM_TEXTOID,      "text",      "text",     -1, DEVFUNC_NEEDS_TEXTLIB | DEVTYPE_IS_VARLENA },
+	{ STROM_BPCHARNOID,   "character", "bpcharn",  -1, DEVFUNC_NEEDS_TEXTLIB | DEVTYPE_IS_VARLENA },
 };
 
 const devtype_info *
@@ -251,6 +254,19 @@ build_catalog(void)
 		add_func(std::string("numeric_") + op, {NU,NU}, B, std::string("numeric_") + op, N);
 	add_func("numeric_cmp", {NU,NU}, I4, "numeric_cmp", N);
 
+	/* character(n) and text as PostgreSQL stores them (codegen.c:616-629, opencl_textlib.h) */
+	{
+		const int CN = STROM_BPCHARNOID, TX = STROM_TEXTOID, S = DEVFUNC_NEEDS_TEXTLIB;
+		for (const char *op : {"eq", "ne", "lt", "le", "gt", "ge"})
+		{
+			add_func(std::string("bpchar") + op, {CN,CN}, B, std::string("bpchar") + op, S);
+			bool	eqne = (op[0] == 'e' || op[0] == 'n');
+			add_func(std::string(eqne ? "text" : "text_") + op, {TX,TX}, B,
+					 std::string(eqne ? "text" : "text_") + op, S);
+		}
+		add_func("bpcharcmp", {CN,CN}, I4, "bpcharcmp", S);
+		add_func("bttextcmp", {TX,TX}, I4, "text_cmp", S);
+	}
 	/* bpchar(1) by value: bytewise comparison (textlib's role for Q1 keys) */
 	for (const char *op : {"eq","ne","lt","le","gt","ge"})
 		add_func(std::string("bpchar") + op, {C1,C1}, B, std::string("char1") + op, M);
@@ -570,6 +586,20 @@ literal_to_datum(const devtype_info *dtype, const std::string &lit,
 				codegen_error("char1 literal must be one byte: \"%s\"", s);
 			desc->value[0] = (uint8_t)lit[0];
 			break;
+		case STROM_TEXTOID: case STROM_BPCHARNOID:
+			{
+				/* the varlena image (4-byte header) is kept on the heap, its address in
+				 * value[0..7]; strom_codegen_release() frees it */
+				uint32_t	hdr = (uint32_t)((lit.size() + 4) << 2);
+				char	   *img = (char *)malloc(lit.size() + 4);
+				if (!img)
+					codegen_error("out of memory");
+				memcpy(img, &hdr, 4);
+				memcpy(img + 4, lit.data(), lit.size());
+				memcpy(desc->value, &img, sizeof(img));
+				desc->length = (int32_t)lit.size() + 4;
+			}
+			break;
 		default:
 			codegen_error("no literal syntax for type %s", dtype->sql_name);
 	}
@@ -584,6 +614,20 @@ codegen_context::track_param(const strom_kparam_desc &d)
 	for (size_t i = 0; i < used_params.size(); i++)
 	{
 		const strom_kparam_desc &o = used_params[i];
+		if ((d.type_oid == STROM_TEXTOID || d.type_oid == STROM_BPCHARNOID) && d.is_const && !d.isnull)
+		{
+			/* value[] holds the address of the image: compare what it points to */
+			const char *po, *pd;
+			memcpy(&po, o.value, sizeof(po));
+			memcpy(&pd, d.value, sizeof(pd));
+			if (o.type_oid == d.type_oid && o.is_const && !o.isnull && o.length == d.length &&
+				memcmp(po, pd, d.length) == 0)
+			{
+				free((void *)pd);
+				return (int)i;
+			}
+			continue;
+		}
 		if (o.type_oid == d.type_oid && o.is_const == d.is_const &&
 			o.param_id == d.param_id && o.isnull == d.isnull &&
 			o.length == d.length && memcmp(o.value, d.value, sizeof(d.value)) == 0)
@@ -718,7 +762,7 @@ emit_expr(const sexpr &n, codegen_context &ctx, std::string &out)
 		if (n.items[2].atom == "null" || n.items[2].atom == "NULL")
 		{
 			d.isnull = 1;
-			d.length = t->type_length;
+			d.length = (t->type_length > 0 ? t->type_length : 0);
 		}
 		else
 			literal_to_datum(t, n.items[2].atom, &d);
@@ -1095,6 +1139,7 @@ codegen_includes(int extra_flags)
 		s += "#include \"strom_mathlib.h\"\n";
 	if (extra_flags & DEVFUNC_NEEDS_TIMELIB)	s += "#include \"strom_timelib.h\"\n";
 	if (extra_flags & DEVFUNC_NEEDS_NUMERIC)	s += "#include \"strom_numeric.h\"\n";
+	if (extra_flags & DEVFUNC_NEEDS_TEXTLIB)	s += "#include \"strom_textlib.h\"\n";
 	return s;
 }
 
@@ -1176,10 +1221,34 @@ extern "C" void
 strom_codegen_release(strom_codegen_result *res)
 {
 	free(res->source);
+	for (int i = 0; res->params && i < res->nparams; i++)
+	{
+		const strom_kparam_desc *d = &res->params[i];
+		if ((d->type_oid == STROM_TEXTOID || d->type_oid == STROM_BPCHARNOID) && d->is_const && !d->isnull)
+		{
+			char *img;
+			memcpy(&img, d->value, sizeof(img));
+			free(img);
+		}
+	}
 	free(res->params);
 	free(res->vars);
 	free(res->errmsg);
 	memset(res, 0, sizeof(*res));
+}
+
+/* bytes of a varlena datum a parameter points to (VARSIZE_ANY) */
+static size_t
+varlena_size_any(const void *datum)
+{
+	const uint8_t *p = (const uint8_t *)datum;
+	if (p[0] == 0x01)
+		return 2 + (p[1] == 18 ? 16 : 8);		/* external TOAST pointer: the device re-checks */
+	if (p[0] & 0x01)
+		return (p[0] >> 1) & 0x7f;
+	uint32_t w;
+	memcpy(&w, p, 4);
+	return (w >> 2) & 0x3fffffff;
 }
 
 extern "C" kern_parambuf *
@@ -1190,7 +1259,39 @@ strom_create_kern_parambuf(const strom_codegen_result *res,
 {
 	int		nparams = res->nparams;
 	size_t	offset = STROMALIGN(offsetof(kern_parambuf, poffset) + sizeof(cl_uint) * nparams);
-	size_t	length = offset + (size_t)STROMALIGN_LEN * nparams + STROMALIGN_LEN;
+	std::vector<const void *> srcs(nparams, nullptr);
+	std::vector<size_t>	lens(nparams, 0);
+	size_t	length = offset + STROMALIGN_LEN;
+
+	/*
+	 * by-value parameters: the image itself (d->value / ext_values[id]);
+	 * text / character(n): the varlena datum the image POINTS to (a constant's
+	 * lives in the codegen result, an external one is the caller's; any header
+	 * form, copied verbatim like datastore.c:100-127)
+	 */
+	for (int i = 0; i < nparams; i++)
+	{
+		const strom_kparam_desc *d = &res->params[i];
+		bool	varlena = (d->type_oid == STROM_TEXTOID || d->type_oid == STROM_BPCHARNOID);
+
+		if (d->is_const)
+		{
+			if (!d->isnull)
+				srcs[i] = d->value;
+		}
+		else if (d->param_id < n_ext && !(ext_isnull && ext_isnull[d->param_id]))
+			srcs[i] = &ext_values[d->param_id];
+		lens[i] = (size_t)(d->length > 0 ? d->length : 0);
+		if (varlena && srcs[i])
+		{
+			const void *datum;
+			memcpy(&datum, srcs[i], sizeof(datum));
+			srcs[i] = datum;
+			lens[i] = (datum ? varlena_size_any(datum) : 0);
+		}
+		if (srcs[i])
+			length += STROMALIGN(lens[i]) + STROMALIGN_LEN;
+	}
 	char   *buf = (char *)calloc(1, length);
 	kern_parambuf *kpbuf = (kern_parambuf *)buf;
 
@@ -1198,23 +1299,13 @@ strom_create_kern_parambuf(const strom_codegen_result *res,
 		return nullptr;
 	for (int i = 0; i < nparams; i++)
 	{
-		const strom_kparam_desc *d = &res->params[i];
-		const void *src = nullptr;
-
-		if (d->is_const)
-		{
-			if (!d->isnull)
-				src = d->value;
-		}
-		else if (d->param_id < n_ext && !(ext_isnull && ext_isnull[d->param_id]))
-			src = &ext_values[d->param_id];
-		if (!src)
+		if (!srcs[i])
 			kpbuf->poffset[i] = 0;		/* NULL */
 		else
 		{
 			kpbuf->poffset[i] = (cl_uint)offset;
-			memcpy(buf + offset, src, d->length);
-			offset = STROMALIGN(offset + d->length);
+			memcpy(buf + offset, srcs[i], lens[i]);
+			offset = STROMALIGN(offset + lens[i]);
 		}
 	}
 	kpbuf->length = (cl_uint)offset;

@@ -272,6 +272,13 @@ strom_codegen_gpupreagg(const char *spec, strom_codegen_result *out,
 				codegen_error("unknown GpuPreAgg target \"%s\"", head.c_str());
 		target_done:
 			const devtype_info *dt = devtype_lookup(tg.type_oid);
+			/* a partial row carries by-value datums only (TUPSLOT, 8 bytes per column):
+			 * text / character(n) may be compared in quals and arguments, not grouped or
+			 * aggregated (the reference's keycomp / aggcalc catalogues have no varlena
+			 * entry either, gpupreagg.c:1181-1440) */
+			if (dt->type_flags & DEVTYPE_IS_VARLENA)
+				codegen_error("GpuPreAgg target of type %s: group keys and partial aggregates "
+							  "are fixed-width", dt->sql_name);
 			ctx.extra_flags |= dt->type_flags;
 			if (tg.acc_oid == 0)
 				tg.acc_oid = tg.type_oid;

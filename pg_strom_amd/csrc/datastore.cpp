@@ -51,7 +51,8 @@ init_kds_head(kern_data_store *kds, int format, int ncols,
 				attcacheoff = -1;
 		}
 		cm->attbyval = cols[i].attbyval;
-		cm->attalign = cols[i].attalign;
+		/* datums given verbatim (attalign -1 on input) are int-aligned varlenas like text / numeric */
+		cm->attalign = (cl_char)((cols[i].attlen == -1 && cols[i].attalign == -1) ? 4 : cols[i].attalign);
 		cm->attlen = cols[i].attlen;
 		cm->attnum = (cl_short)(i + 1);
 		cm->attcacheoff = (cl_short)attcacheoff;
@@ -98,6 +99,8 @@ is_varlena_raw(const strom_column_input &c)
 inline size_t
 varlena_raw_size(const unsigned char *p)
 {
+	if (p[0] == 0x01)
+		return 2 + (size_t)(p[1] == 18 ? 16 : 8);	/* external TOAST pointer: tag + payload by tag */
 	if (p[0] & 0x01)
 		return (size_t)(p[0] >> 1);					/* 1-byte header: total length */
 	uint32_t	h;

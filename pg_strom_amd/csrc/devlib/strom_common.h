@@ -295,7 +295,7 @@ STROM_DEVICE BASE strom_fetch(const void *addr)
  * fixed-width types copy attlen bytes, NUMERIC also decodes PostgreSQL's
  * varlena form (strom_numeric.h).
  */
-#define STROM_DECLARE_VARREF_EX(NAME, FROM_ADDR)							\
+#define STROM_DECLARE_VARREF_CORE(NAME, FROM_ADDR)							\
 	STROM_DEVICE pg_##NAME##_t												\
 	pg_##NAME##_vref(const kern_data_store *kds,							\
 					 const kern_data_store *ktoast,							\
@@ -311,25 +311,6 @@ STROM_DEVICE BASE strom_fetch(const void *addr)
 		else																\
 			result = FROM_ADDR(errcode, (const char *)addr,					\
 							   kds->colmeta[colidx].attlen);				\
-		return result;														\
-	}																		\
-	STROM_DEVICE pg_##NAME##_t												\
-	pg_##NAME##_param(const kern_parambuf *kparams,							\
-					  cl_int *errcode, cl_uint param_id)					\
-	{																		\
-		pg_##NAME##_t	result;												\
-		if (param_id < kparams->nparams &&									\
-			kparams->poffset[param_id] > 0)									\
-		{																	\
-			result.value = strom_fetch<pg_##NAME##_base_t>					\
-				((const char *)kparams + kparams->poffset[param_id]);		\
-			result.isnull = false;											\
-		}																	\
-		else																\
-		{																	\
-			result.isnull = true;											\
-			result.value = 0;												\
-		}																	\
 		return result;														\
 	}																		\
 	/* attribute of a bare heap tuple (row formats; inner tuple of a hash	\
@@ -368,6 +349,32 @@ STROM_DEVICE BASE strom_fetch(const void *addr)
 	{																		\
 		pg_bool_t r; r.isnull = false; r.value = !arg.isnull; return r;		\
 	}
+
+/* a by-value parameter: its image sits in the kern_parambuf at poffset[] */
+#define STROM_DECLARE_PARAMREF_BYVAL(NAME)									\
+	STROM_DEVICE pg_##NAME##_t												\
+	pg_##NAME##_param(const kern_parambuf *kparams,							\
+					  cl_int *errcode, cl_uint param_id)					\
+	{																		\
+		pg_##NAME##_t	result;												\
+		if (param_id < kparams->nparams &&									\
+			kparams->poffset[param_id] > 0)									\
+		{																	\
+			result.value = strom_fetch<pg_##NAME##_base_t>					\
+				((const char *)kparams + kparams->poffset[param_id]);		\
+			result.isnull = false;											\
+		}																	\
+		else																\
+		{																	\
+			result.isnull = true;											\
+			result.value = 0;												\
+		}																	\
+		return result;														\
+	}
+
+#define STROM_DECLARE_VARREF_EX(NAME, FROM_ADDR)							\
+	STROM_DECLARE_VARREF_CORE(NAME, FROM_ADDR)								\
+	STROM_DECLARE_PARAMREF_BYVAL(NAME)
 
 #define STROM_DECLARE_VARREF(NAME)											\
 	STROM_DEVICE pg_##NAME##_t												\

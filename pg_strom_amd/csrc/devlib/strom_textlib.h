@@ -1,0 +1,165 @@
+/*
+ * strom_textlib.h -- text / character(n) values on the device
+ *
+ * Stands where opencl_textlib.h stands (bpchar* 150-283, text* 285-399) plus
+ * the varlena reference templates of opencl_common.h:1126-1263.
+ *
+ * A value is the ADDRESS of its varlena datum (inside a heap tuple of a ROW /
+ * ROW_FLAT chunk, inside an inner tuple of a hash table, or inside the
+ * kern_parambuf), exactly what the reference's pg_varlena_t carries.  Only
+ * datums the device can read in place are accepted -- a short (1-byte) or an
+ * uncompressed 4-byte header (VARATT_IS_1B / VARATT_IS_4B_U,
+ * opencl_common.h:1142); a compressed datum or an external TOAST pointer
+ * makes the value NULL and raises CpuReCheck, the row goes back to the CPU.
+ * (The reference's VARATT_IS_1B test also lets the 1-byte EXTERNAL tag
+ * through and would compare the bytes of the TOAST pointer; not reproduced.)
+ *
+ * Comparison is bytewise on UNSIGNED bytes -- what PostgreSQL's "C" collation
+ * does (memcmp), the only collation the reference lets onto the device
+ * (devtype_runnable_collation, codegen.c:148-186).  The reference compares
+ * signed cl_char (opencl_textlib.h:170-193): same answer for ASCII, the wrong
+ * one for bytes >= 0x80; not reproduced.  character(n) ignores trailing
+ * blanks (bpchar_truelen, 154-166); text does not.
+ *
+ * COLUMN chunks hold fixed-width columns only (strom_kds.h); a text column
+ * lives in the row formats the reference itself ships.
+ */
+#ifndef STROM_TEXTLIB_DEVICE_H
+#define STROM_TEXTLIB_DEVICE_H
+
+STROM_DECLARE_SIMPLE_TYPE(text,    cl_ulong)
+STROM_DECLARE_SIMPLE_TYPE(bpcharn, cl_ulong)
+
+/* payload of a varlena the device may read: start and length */
+STROM_DEVICE const cl_uchar *
+strom_varlena_payload(cl_ulong datum, cl_int *p_len)
+{
+	const cl_uchar *p = (const cl_uchar *)datum;
+	cl_uchar	b0 = p[0];
+
+	if (b0 & 0x01)
+	{
+		*p_len = (cl_int)((b0 >> 1) & 0x7f) - 1;
+		return p + 1;
+	}
+	cl_uint w = (cl_uint)p[0] | ((cl_uint)p[1] << 8) | ((cl_uint)p[2] << 16) | ((cl_uint)p[3] << 24);
+	*p_len = (cl_int)((w >> 2) & 0x3fffffff) - 4;
+	return p + 4;
+}
+
+#define STROM_DECLARE_VARLENA_TYPE(NAME)										\
+	STROM_DEVICE pg_##NAME##_t													\
+	pg_##NAME##_from_addr(cl_int *errcode, const char *addr, cl_short attlen)	\
+	{																			\
+		pg_##NAME##_t	result;													\
+		cl_uchar		b0 = ((const cl_uchar *)addr)[0];						\
+		/* 1-byte external tag, or a 4-byte header with the "compressed" bit */	\
+		bool			unreadable = (b0 == 0x01) || ((b0 & 0x03) == 0x02);		\
+		if (attlen >= 0)														\
+		{																		\
+			/* a by-value column declared as text: the chunk lies */			\
+			STROM_SET_ERROR(errcode, StromError_DataStoreCorruption);			\
+			unreadable = true;													\
+		}																		\
+		else if (unreadable)													\
+			STROM_SET_ERROR(errcode, StromError_CpuReCheck);					\
+		result.isnull = unreadable;												\
+		result.value = (unreadable ? 0UL : (cl_ulong)addr);						\
+		return result;															\
+	}																			\
+	STROM_DECLARE_VARREF_CORE(NAME, pg_##NAME##_from_addr)						\
+	STROM_DEVICE pg_##NAME##_t													\
+	pg_##NAME##_param(const kern_parambuf *kparams,								\
+					  cl_int *errcode, cl_uint param_id)						\
+	{																			\
+		if (param_id < kparams->nparams && kparams->poffset[param_id] > 0)		\
+			return pg_##NAME##_from_addr(errcode,								\
+				(const char *)kparams + kparams->poffset[param_id], -1);		\
+		return pg_##NAME##_make(0UL, true);										\
+	}
+
+STROM_DECLARE_VARLENA_TYPE(text)
+STROM_DECLARE_VARLENA_TYPE(bpcharn)
+
+/* memcmp order, then the shorter one first (text_compare, 288-312) */
+STROM_DEVICE cl_int
+strom_bytes_compare(const cl_uchar *s1, cl_int len1, const cl_uchar *s2, cl_int len2)
+{
+	cl_int		len = (len1 < len2 ? len1 : len2);
+
+	for (cl_int i = 0; i < len; i++)
+	{
+		cl_uchar c1 = s1[i], c2 = s2[i];
+		if (c1 != c2)
+			return (c1 < c2 ? -1 : 1);
+	}
+	return (len1 == len2 ? 0 : (len1 > len2 ? 1 : -1));
+}
+
+STROM_DEVICE cl_int
+strom_text_compare(cl_ulong a, cl_ulong b)
+{
+	cl_int		len1, len2;
+	const cl_uchar *s1 = strom_varlena_payload(a, &len1);
+	const cl_uchar *s2 = strom_varlena_payload(b, &len2);
+	return strom_bytes_compare(s1, len1, s2, len2);
+}
+
+/* character(n): trailing blanks do not count (bpchar_truelen, 154-166) */
+STROM_DEVICE cl_int
+strom_bpchar_compare(cl_ulong a, cl_ulong b)
+{
+	cl_int		len1, len2;
+	const cl_uchar *s1 = strom_varlena_payload(a, &len1);
+	const cl_uchar *s2 = strom_varlena_payload(b, &len2);
+	while (len1 > 0 && s1[len1 - 1] == ' ')
+		len1--;
+	while (len2 > 0 && s2[len2 - 1] == ' ')
+		len2--;
+	return strom_bytes_compare(s1, len1, s2, len2);
+}
+
+#define STROM_DECLARE_TEXT_COMPARE(FNAME, NAME, CMPFN, OP)						\
+	STROM_DEVICE pg_bool_t														\
+	pgfn_##FNAME(cl_int *errcode, pg_##NAME##_t arg1, pg_##NAME##_t arg2)		\
+	{																			\
+		pg_bool_t	result;														\
+		result.isnull = (arg1.isnull | arg2.isnull);							\
+		result.value = false;													\
+		if (!result.isnull)														\
+			result.value = (CMPFN(arg1.value, arg2.value) OP 0);				\
+		return result;															\
+	}
+
+STROM_DECLARE_TEXT_COMPARE(bpchareq, bpcharn, strom_bpchar_compare, ==)
+STROM_DECLARE_TEXT_COMPARE(bpcharne, bpcharn, strom_bpchar_compare, !=)
+STROM_DECLARE_TEXT_COMPARE(bpcharlt, bpcharn, strom_bpchar_compare, <)
+STROM_DECLARE_TEXT_COMPARE(bpcharle, bpcharn, strom_bpchar_compare, <=)
+STROM_DECLARE_TEXT_COMPARE(bpchargt, bpcharn, strom_bpchar_compare, >)
+STROM_DECLARE_TEXT_COMPARE(bpcharge, bpcharn, strom_bpchar_compare, >=)
+STROM_DECLARE_TEXT_COMPARE(texteq,   text, strom_text_compare, ==)
+STROM_DECLARE_TEXT_COMPARE(textne,   text, strom_text_compare, !=)
+STROM_DECLARE_TEXT_COMPARE(text_lt,  text, strom_text_compare, <)
+STROM_DECLARE_TEXT_COMPARE(text_le,  text, strom_text_compare, <=)
+STROM_DECLARE_TEXT_COMPARE(text_gt,  text, strom_text_compare, >)
+STROM_DECLARE_TEXT_COMPARE(text_ge,  text, strom_text_compare, >=)
+
+STROM_DEVICE pg_int4_t
+pgfn_bpcharcmp(cl_int *errcode, pg_bpcharn_t arg1, pg_bpcharn_t arg2)
+{
+	pg_int4_t	result;
+	result.isnull = (arg1.isnull | arg2.isnull);
+	result.value = (result.isnull ? 0 : strom_bpchar_compare(arg1.value, arg2.value));
+	return result;
+}
+
+STROM_DEVICE pg_int4_t
+pgfn_text_cmp(cl_int *errcode, pg_text_t arg1, pg_text_t arg2)
+{
+	pg_int4_t	result;
+	result.isnull = (arg1.isnull | arg2.isnull);
+	result.value = (result.isnull ? 0 : strom_text_compare(arg1.value, arg2.value));
+	return result;
+}
+
+#endif	/* STROM_TEXTLIB_DEVICE_H */

@@ -666,7 +666,8 @@ submit_hashjoin_common(strom_hashjoin_table *tbl, kern_hashjoin *khashjoin,
 		return nullptr;
 	}
 	kern_resultbuf *kres = KERN_HASHJOIN_RESULTBUF(khashjoin);
-	if ((int)kres->nrels != tbl->ntables + 1)
+	if ((int)kres->nrels != tbl->ntables + 1 ||
+		!program_accepts_format(tbl->prog, kds ? kds->format : kds_dev->head.format))
 	{
 		*p_errcode = StromError_BadRequestMessage;
 		return nullptr;

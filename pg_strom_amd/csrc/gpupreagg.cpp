@@ -1495,6 +1495,11 @@ submit_gpupreagg_common(strom_gpupreagg *sess,
 	else
 		head = kds_dev->head;
 	req.format = head.format;
+	if (!program_accepts_format(sess->prog, head.format))
+	{
+		*p_errcode = StromError_BadRequestMessage;		/* text columns live in heap tuples */
+		return nullptr;
+	}
 	req.nrows = (rowmap_dev ? rowmap_dev->nvalids
 				 : req.krowmap ? (uint32_t)req.krowmap->nvalids : head.nitems);
 	sess->nfolds++;
@@ -1733,6 +1738,8 @@ strom_gpupreagg_census(strom_gpupreagg *sess,
 	size_t	words = ((size_t)sess->ctl.dense_ngroups + 31) / 32;
 	if (bitmap_out && nwords < words)
 		return StromError_DataStoreNoSpace;
+	if (!program_accepts_format(sess->prog, kds ? kds->format : kds_dev->head.format))
+		return StromError_BadRequestMessage;
 	if (strom_lookup_device_program(sess->key, 1) != STROM_DEVPROG_READY)
 		return StromError_ProgramBuildFailure;
 	std::lock_guard<std::mutex> g(sess->lock);
@@ -2421,6 +2428,8 @@ chunk_domain(strom_devprog_key key, Program *prog, Device *dev,
 	dom->nkeys = nkeys;
 	if (nkeys == 0)
 		return 0;
+	if (!program_accepts_format(prog, kds_dev->head.format))
+		return StromError_BadRequestMessage;
 	if (strom_lookup_device_program(key, 1) != STROM_DEVPROG_READY)
 		return StromError_ProgramBuildFailure;
 	(void)hipSetDevice(dev->hip_id);

@@ -309,6 +309,11 @@ submit_gpuscan_common(strom_devprog_key key,
 	else
 		head = kds_dev->head;
 	req.format = head.format;
+	if (!program_accepts_format(prog, head.format))
+	{
+		*p_errcode = StromError_BadRequestMessage;		/* text columns live in heap tuples */
+		return nullptr;
+	}
 	req.nrows = (rowmap_dev ? rowmap_dev->nvalids
 				 : req.krowmap ? (uint32_t)req.krowmap->nvalids : head.nitems);
 	kern_resultbuf *kres = KERN_GPUSCAN_RESULTBUF(kgpuscan);

@@ -220,6 +220,15 @@ int			gpupreagg_get_merge_plan(strom_gpupreagg *sess, gpupreagg_merge_plan *plan
 int			gpupreagg_get_census(strom_gpupreagg *sess, void **p_bitmap, cl_uint *p_nbits, int *p_dindex);
 int			num_devices();
 Program	   *lookup_program(strom_devprog_key key);
+/* text / character(n) values are addresses of varlena datums inside heap tuples
+ * (strom_textlib.h): a program that uses them reads ROW / ROW_FLAT chunks only --
+ * COLUMN and TUPSLOT chunks hold by-value datums (strom_kds.h) */
+inline bool
+program_accepts_format(const Program *prog, cl_int format)
+{
+	return !(prog->extra_flags & DEVTYPE_IS_VARLENA) ||
+		format == KDS_FORMAT_ROW || format == KDS_FORMAT_ROW_FLAT;
+}
 bool		perfmon_enabled();
 strom_task_impl *task_create(Device *dev, strom_done_cb done, void *arg);
 void		task_enqueue(strom_task_impl *task);

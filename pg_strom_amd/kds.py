@@ -42,7 +42,25 @@ SQL_TYPES = {
     # heap formats only: complete varlena datums (bytes objects), copied verbatim -- numerics of
     # any magnitude, also those the 64-bit device form cannot hold
     "numeric_raw": (1700, -1, object),
+    # text / character(n) as PostgreSQL stores them (heap formats only): 'values' are the
+    # payloads (bytes or str); a short 1-byte header up to 126 bytes, a 4-byte header beyond
+    "text": (25, -1, object),
+    "character": (1042, -1, object),
+    # complete varlena datums copied verbatim (e.g. a compressed or external one)
+    "text_raw": (25, -1, object),
 }
+
+VARLENA_RAW_TYPES = ("numeric_raw", "text", "character", "text_raw")
+
+
+def varlena_datum(payload):
+    """payload bytes -> the varlena datum PostgreSQL would store (short header when it fits)"""
+    if isinstance(payload, str):
+        payload = payload.encode()
+    payload = bytes(payload)
+    if len(payload) + 1 <= 127:
+        return bytes([((len(payload) + 1) << 1) | 1]) + payload
+    return np.array([(len(payload) + 4) << 2], dtype="<u4").tobytes() + payload
 
 
 def stromalign(n):
@@ -66,8 +84,10 @@ class Column(object):
         self.sqltype = sqltype
         self.type_oid = oid
         self.attlen = attlen
-        if sqltype == "numeric_raw":
+        if sqltype in VARLENA_RAW_TYPES:
             # keep the datums and an array of their addresses alive with the column
+            if sqltype in ("text", "character"):
+                values = [varlena_datum(v if v is not None else b"") for v in values]
             self._datums = [ctypes.create_string_buffer(bytes(v) + b"\0" * 8) for v in values]
             self.values = np.array([ctypes.addressof(b) for b in self._datums], dtype=np.uint64)
         else:
@@ -86,7 +106,7 @@ def _column_inputs(columns):
     for i, c in enumerate(columns):
         arr[i].type_oid = c.type_oid
         arr[i].attlen = c.attlen
-        arr[i].attalign = c.attlen if c.attlen > 0 else (-1 if c.sqltype == "numeric_raw" else 4)
+        arr[i].attalign = c.attlen if c.attlen > 0 else (-1 if c.sqltype in VARLENA_RAW_TYPES else 4)
         arr[i].attbyval = 1 if c.attlen > 0 else 0
         arr[i].values = c.values.ctypes.data
         arr[i].isnull = c.isnull.ctypes.data if c.isnull is not None else None

@@ -67,7 +67,14 @@ class Codegen(object):
         n = len(ext_values)
         vals = (ctypes.c_uint64 * max(n, 1))()
         nulls = (ctypes.c_uint8 * max(n, 1))()
+        keep = []
         for i, v in enumerate(ext_values):
+            if isinstance(v, (bytes, str)):
+                # text / character(n): the datum image is the ADDRESS of a varlena datum
+                from .kds import varlena_datum
+                keep.append(ctypes.create_string_buffer(varlena_datum(v) + b"\0" * 8))
+                vals[i] = ctypes.addressof(keep[-1])
+                continue
             vals[i] = datum_image(v)
             nulls[i] = 1 if (ext_isnull is not None and ext_isnull[i]) or v is None else 0
         p = lib.strom_create_kern_parambuf(ctypes.byref(self._res), vals, nulls, n)

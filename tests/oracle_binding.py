@@ -63,10 +63,23 @@ def ext_arrays(ext_params):
     n = len(ext_params)
     vals = np.zeros(max(n, 1), dtype=np.uint64)
     nulls = np.zeros(max(n, 1), dtype=np.uint8)
+    keep = []
     for i, v in enumerate(ext_params):
+        if isinstance(v, (bytes, str)):
+            # text / character(n): the address of a varlena datum (kept alive with 'vals')
+            import ctypes as _ct
+            from pg_strom_amd.kds import varlena_datum
+            keep.append(_ct.create_string_buffer(varlena_datum(v) + b"\0" * 8))
+            vals[i] = _ct.addressof(keep[-1])
+            continue
         vals[i] = datum_image(v)
         nulls[i] = 1 if v is None else 0
+    _KEEPALIVE.append(keep)
+    del _KEEPALIVE[:-64]
     return vals, nulls, n
+
+
+_KEEPALIVE = []
 
 
 def gpuscan(qual, kds_buf, ext_params=(), row_map=None, nitems=None):

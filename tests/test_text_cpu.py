@@ -1,0 +1,74 @@
+"""
+text / character(n) on the CPU side: the oracle's comparison against Python's own bytes
+comparison (PostgreSQL "C" collation = memcmp; character(n) without trailing blanks), the
+expression emitter's catalogue (codegen.c:616-629) and the kern_parambuf of varlena
+constants / parameters (datastore.c:100-127).  The reference holds no fixture for these
+operators (its suites are aggregates over numeric columns): parity is "oracle = restatement
+checked against Python", stated as such in DESIGN.md.
+"""
+import numpy as np
+import pytest
+
+import oracle_binding as oracle
+import text_cases
+from pg_strom_amd import kds, runtime
+
+
+@pytest.mark.parametrize("fmt", ["row", "row_flat"])
+def test_oracle_text_compare_matches_python(fmt):
+    buf, txt, chr10, num, tnull = text_cases.text_table(3000, 5, fmt)
+    for qual, fn, ext in text_cases.CASES:
+        rc, rows = oracle.gpuscan(qual, buf, ext)
+        assert rc == 0, qual
+        want = text_cases.expected_rows(fn, txt, chr10, num, tnull)
+        assert np.array_equal(np.sort(rows) - 1, want), qual
+
+
+def test_oracle_unreadable_varlena_is_rechecked():
+    """a compressed datum (4-byte header, bit 1 set) or an external TOAST pointer cannot be
+    read in place: the row goes back to the CPU (opencl_common.h:1142-1151)"""
+    plain = kds.varlena_datum(b"abc")
+    compressed = np.array([(20 << 2) | 2], dtype="<u4").tobytes() + b"\0" * 16
+    external = bytes([0x01, 18]) + b"\0" * 16
+    buf = kds.build_kds("row", [kds.Column("text_raw", [plain, compressed, external, plain])])
+    rc, rows = oracle.gpuscan("(texteq (var 1 text) (const text 'abc'))", buf)
+    assert rc == 0 and sorted(rows.tolist()) == [-3, -2, 1, 4]
+
+
+def test_codegen_catalogue_and_parambuf():
+    cg = runtime.codegen_gpuscan("(and (texteq (var 2 text) (const text 'hello world'))"
+                                 " (texteq (var 2 text) (const text 'hello world'))"
+                                 " (bpcharlt (var 3 character) (param 1 character)))")
+    assert '#include "strom_textlib.h"' in cg.source
+    assert "pgfn_texteq" in cg.source and "pgfn_bpcharlt" in cg.source
+    assert cg.extra_flags & 0x0010                      # DEVFUNC_NEEDS_TEXTLIB
+    assert len(cg.params) == 2                          # equal literals share one KPARAM
+    pb = np.frombuffer(cg.parambuf([None, b"x" * 200]), dtype=np.uint8)
+    length, nparams = pb[:8].view(np.uint32)
+    assert nparams == 2 and length == len(pb)
+    off = pb[8:16].view(np.uint32)
+    # constant: 4-byte header + 11 bytes
+    assert int(pb[off[0]:off[0] + 4].view(np.uint32)[0]) >> 2 == 15
+    assert pb[off[0] + 4:off[0] + 15].tobytes() == b"hello world"
+    # parameter: the caller's datum verbatim (4-byte header, 200 bytes)
+    assert int(pb[off[1]:off[1] + 4].view(np.uint32)[0]) >> 2 == 204
+    assert pb[off[1] + 4:off[1] + 204].tobytes() == b"x" * 200
+    # NULL parameter
+    pb = np.frombuffer(cg.parambuf([None, None]), dtype=np.uint8)
+    assert pb[8:16].view(np.uint32)[1] == 0
+
+
+def test_codegen_refuses_text_where_the_device_cannot_hold_it():
+    from pg_strom_amd.gpupreagg import codegen_gpupreagg
+    from pg_strom_amd.gpuhashjoin import codegen_gpuhashjoin
+    with pytest.raises(ValueError):
+        codegen_gpupreagg("(gpupreagg (key (var 1 text)) (nrows))")
+    with pytest.raises(ValueError):
+        codegen_gpupreagg("(gpupreagg (key (var 1 int4)) (pmax (var 2 text)))")
+    with pytest.raises(ValueError):
+        codegen_gpuhashjoin("(gpuhashjoin (rel (hashkey (var 1 text) 1 text)))")
+    with pytest.raises(ValueError):
+        runtime.codegen_gpuscan("(texteq (var 1 text) (var 2 character))")
+    # a qual over text inside an aggregate is fine
+    cg = codegen_gpupreagg("(gpupreagg (qual (texteq (var 2 text) (const text 'MAIL'))) (key (var 1 int4)) (nrows))")
+    assert "pgfn_texteq" in cg.source

@@ -1,0 +1,87 @@
+"""
+text / character(n) on the device (needs an MI355X: -m gpu), through the C ABI.  Row
+selection is byte work: bit-exact against the CPU oracle AND against Python's own bytes
+comparison (tests/text_cases.py).  Text columns live in heap tuples (ROW / ROW_FLAT, the
+formats the reference ships); COLUMN / TUPSLOT chunks are refused for such a program.
+"""
+import numpy as np
+import pytest
+
+import oracle_binding as oracle
+import text_cases
+from pg_strom_amd import kds, runtime
+from pg_strom_amd.gpuscan import GpuScan
+from pg_strom_amd.gpupreagg import GpuPreAgg
+from test_gpuscan_gpu import check, canon
+from test_gpuhashjoin_gpu import run_and_compare
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("fmt", ["row", "row_flat"])
+def test_text_quals_match_oracle_and_python(fmt):
+    buf, txt, chr10, num, tnull = text_cases.text_table(20011, 12, fmt)
+    for qual, fn, ext in text_cases.CASES:
+        res = check(qual, buf, ext)
+        assert res.errcode == 0, qual
+        want = text_cases.expected_rows(fn, txt, chr10, num, tnull)
+        assert np.array_equal(np.sort(np.asarray(res.results[:res.nitems])) - 1, want), qual
+
+
+def test_unreadable_varlena_rows_go_back_to_the_cpu():
+    plain = kds.varlena_datum(b"abc")
+    compressed = np.array([(20 << 2) | 2], dtype="<u4").tobytes() + b"\0" * 16
+    external = bytes([0x01, 18]) + b"\0" * 16
+    datums = [plain, compressed, external, plain] * 500
+    buf = kds.build_kds("row", [kds.Column("text_raw", datums)])
+    res = check("(texteq (var 1 text) (const text 'abc'))", buf)
+    assert len(res.passed_rows()) == 1000 and len(res.recheck_rows()) == 1000
+
+
+def test_column_and_tupslot_chunks_are_refused_for_text_programs():
+    """COLUMN / TUPSLOT hold by-value datums: a program with text values must not run on them
+    (a cl_ulong read as an address would fault)"""
+    a = np.arange(1000, dtype=np.int64)
+    scan = GpuScan("(texteq (var 1 text) (const text 'abc'))").begin()
+    try:
+        for fmt in ("column", "tupslot"):
+            buf = kds.build_kds(fmt, [kds.Column("int8", a)])
+            with pytest.raises(runtime.StromError) as ei:
+                scan.scan_chunk(buf)
+            assert ei.value.errcode == 101
+    finally:
+        scan.end()
+
+
+def test_text_qual_inside_gpupreagg_through_the_chunk_message():
+    buf, txt, chr10, num, tnull = text_cases.text_table(30000, 21, "row")
+    spec = ("(gpupreagg (qual (and (text_ge (var 2 text) (const text 'a')) (bpcharne (var 3 character) (param 0 character))))"
+            " (key (var 1 int4)) (nrows) (psum (var 4 int8)))")
+    agg = GpuPreAgg(spec)
+    status, pr = agg.collect_chunk(agg.submit_chunk(buf, ext_params=[b"MAIL"]))
+    assert status == 0
+    from test_gpupreagg_gpu import assert_matches_oracle
+    assert_matches_oracle(spec, agg, [buf], pr, ext=[b"MAIL"])
+    # and against Python
+    keep = [i for i in range(30000) if not tnull[i] and txt[i] >= b"a" and text_cases.bpchar_key(chr10[i]) != b"MAIL"]
+    k, _ = pr.column(0)
+    c, _ = pr.column(1)
+    s, _ = pr.column(2)
+    got = {int(a): (int(b), int(d)) for a, b, d in zip(k, c, s)}
+    want = {}
+    for i in keep:
+        cnt, sm = want.get(int(num[i]), (0, 0))
+        want[int(num[i])] = (cnt + 1, sm + i)
+    assert got == want
+
+
+def test_text_residual_qual_in_a_join():
+    buf, txt, chr10, num, tnull = text_cases.text_table(20000, 33, "row_flat")
+    pk = np.arange(-50, 50, dtype=np.int32)
+    inner = kds.build_kds("row", [kds.Column("int4", pk), kds.Column("int4", pk * 3)])
+    spec = ("(gpuhashjoin (rel (hashkey (var 1 int4) 1 int4)"
+            " (qual (or (bpchareq (var 3 character) (const character 'SHIP')) (text_lt (var 2 text) (const text 'B'))))))")
+    res, _ = run_and_compare(spec, buf, [inner], [[1]])
+    want = sum(1 for i in range(20000)
+               if text_cases.bpchar_key(chr10[i]) == b"SHIP" or (not tnull[i] and txt[i] < b"B"))
+    assert res.nitems == want
