@@ -398,6 +398,16 @@ strom_task *strom_submit_gpuhashjoin(strom_hashjoin_table *tbl,
  * destination column r takes column src_colidx[r] (0-based) of relation
  * src_depth[r] (0 = outer chunk, d = d-th inner relation).  On completion
  * kds_dest holds nitems rows.  Fixed-width by-value columns.
+ * A kds_dest of KDS_FORMAT_ROW_FLAT takes kern_gpuhashjoin_projection_row
+ * instead (opencl_hashjoin.h:437-689): the joined rows as heap tuples that
+ * grow from the tail of the caller's buffer ('length' bytes in all; head with
+ * ncols, colmeta {attlen, attalign}, nrooms, tdtypeid / tdtypmod filled by the
+ * caller), row items behind the head, 'usage' = bytes of tuples.  Varlena
+ * columns (attlen -1: text, character(n), numeric in its heap form) are
+ * copied verbatim.  StromError_DataStoreNoSpace when the records outnumber
+ * nrooms (kern_resultbuf.nitems says how many) or the tuples do not fit
+ * 'length'; DataStoreCorruption when a destination column's attlen is not
+ * its source's.
  */
 strom_task *strom_submit_gpuhashjoin_projection(strom_hashjoin_table *tbl,
 												kern_hashjoin *khashjoin,

@@ -1091,6 +1091,230 @@ gpuhashjoin_projection_slot(kern_hashjoin *khashjoin,
 }
 
 /* ====================================================================== *
+ * projection into a ROW_FLAT kern_data_store: joined rows as heap tuples
+ * (kern_gpuhashjoin_projection_row, opencl_hashjoin.h:437-689), what the
+ * reference hands to a parent node that reads tuples (varlena columns
+ * included: a text datum is copied verbatim, short header or not).
+ *
+ * Per record: (1) the tuple's length from the located source datums --
+ * att_align_datum / att_addlength_datum, NULL bitmap only if a column is
+ * NULL, header and data MAXALIGNed; (2) room: lengths are prefix-summed over
+ * the wave by shuffles, wave totals over the work-group through LDS, ONE
+ * atomic on kds_dest->usage per work-group and tile (the reference's
+ * arithmetic_stairlike_add + atomic, 543-552); tuples grow from the tail of
+ * the buffer, row items from the head; (3) the tuple is built in place.
+ * A tile that does not fit raises DataStoreNoSpace (the host retries with a
+ * larger store); nothing is torn: nitems is the record count either way.
+ * ====================================================================== */
+struct hashjoin_proj_src {
+	const char *addr;
+	cl_int		attlen;
+};
+
+STROM_DEVICE hashjoin_proj_src
+hashjoin_projection_locate(const kern_multihash *kmhash, const kern_data_store *kds,
+						   const kern_data_store *ktoast, const cl_int *rbuffer, cl_uint nrels,
+						   cl_int depth, cl_int col)
+{
+	hashjoin_proj_src s;
+	s.addr = NULL;
+	s.attlen = 0;
+	if (depth == 0)
+	{
+		if (col >= 0 && col < (cl_int)kds->ncols)
+		{
+			s.addr = (const char *)kern_get_datum(kds, ktoast, col, (cl_uint)(rbuffer[0] - 1));
+			s.attlen = kds->colmeta[col].attlen;
+		}
+	}
+	else if (depth > 0 && depth < (cl_int)nrels)
+	{
+		const kern_hashtable *kht = KERN_HASHTABLE(kmhash, depth - 1);
+		const kern_hashentry *ent = (const kern_hashentry *)((const char *)kht + rbuffer[depth]);
+		if (col >= 0 && col < (cl_int)kht->ncols)
+		{
+			s.addr = kern_get_datum_tuple(kht->colmeta, &ent->htup, col);
+			s.attlen = kht->colmeta[col].attlen;
+		}
+	}
+	return s;
+}
+
+extern "C" __global__ void
+__launch_bounds__(256)
+gpuhashjoin_projection_row(kern_hashjoin *khashjoin,
+						   const kern_multihash *kmhash,
+						   const kern_data_store *kds,
+						   const kern_data_store *ktoast,
+						   kern_data_store *kds_dest,
+						   const cl_int *src_depth,
+						   const cl_int *src_colidx)
+{
+	__shared__ cl_uint	wave_total[256 / STROM_WAVE];
+	__shared__ cl_uint	tile_base;
+	__shared__ cl_int	tile_error;
+	kern_resultbuf *kresults = KERN_HASHJOIN_RESULTBUF(khashjoin);
+	const cl_uint	nrels = kresults->nrels;
+	const cl_uint	nitems = kresults->nitems;
+	const cl_uint	ncols = kds_dest->ncols;
+	const cl_uint	dest_length = kds_dest->length;
+	const cl_uint	lane = threadIdx.x & (STROM_WAVE - 1);
+	const cl_uint	wave = threadIdx.x / STROM_WAVE;
+
+	if (kresults->errcode != StromError_Success ||
+		nitems > kresults->nrooms || nitems > kds_dest->nrooms)
+	{
+		if (blockIdx.x == 0 && threadIdx.x == 0 && nitems > kds_dest->nrooms)
+			atomicMax(&kresults->errcode, StromError_DataStoreNoSpace);
+		return;
+	}
+	if (kds_dest->format != KDS_FORMAT_ROW_FLAT)
+	{
+		if (blockIdx.x == 0 && threadIdx.x == 0)
+			atomicMax(&kresults->errcode, StromError_DataStoreCorruption);
+		return;
+	}
+	if (blockIdx.x == 0 && threadIdx.x == 0)
+		kds_dest->nitems = nitems;
+	/* row items end here; tuples must stay above */
+	const cl_uint	usage_head = (cl_uint)(KDS_HEAD_LENGTH(ncols) +
+										   STROMALIGN(sizeof(kern_blkitem) * kds_dest->maxblocks) +
+										   STROMALIGN(sizeof(kern_rowitem) * (size_t)nitems));
+	const cl_uint	ntiles = (nitems + blockDim.x - 1) / blockDim.x;
+
+	for (cl_uint tile = blockIdx.x; tile < ntiles; tile += gridDim.x)
+	{
+		cl_uint		i = tile * blockDim.x + threadIdx.x;
+		bool		valid = (i < nitems);
+		const cl_int *rbuffer = kresults->results + (size_t)nrels * (valid ? i : 0);
+		cl_uint		datalen = 0, t_hoff = 0, required = 0;
+		bool		hasnull = false, bad = false;
+
+		/* step 1: length of the joined tuple */
+		if (valid)
+		{
+			for (cl_uint r = 0; r < ncols; r++)
+			{
+				kern_colmeta	cm = kds_dest->colmeta[r];
+				hashjoin_proj_src src = hashjoin_projection_locate(kmhash, kds, ktoast, rbuffer, nrels,
+																   src_depth[r], src_colidx[r]);
+				if (!src.addr)
+				{
+					hasnull = true;
+					continue;
+				}
+				if ((cm.attlen > 0) != (src.attlen > 0) || (cm.attlen > 0 && cm.attlen != src.attlen))
+				{
+					bad = true;					/* the destination column is not the source's shape */
+					continue;
+				}
+				if (cm.attlen > 0)
+					datalen = STROM_TYPEALIGN(cm.attalign, datalen) + cm.attlen;
+				else
+				{
+					if (!strom_varatt_is_1b(src.addr))
+						datalen = STROM_TYPEALIGN(cm.attalign, datalen);
+					datalen += strom_varsize_any(src.addr);
+				}
+			}
+			t_hoff = HEAPTUPLE_HEADER_FIXED + (hasnull ? (ncols + 7) / 8 : 0);
+			t_hoff = STROM_LONGALIGN(t_hoff);
+			required = t_hoff + STROM_LONGALIGN(datalen);
+			if (t_hoff > 255)
+				bad = true;						/* t_hoff is one byte */
+		}
+		/* step 2: room -- inclusive prefix over the wave, wave totals through LDS */
+		cl_uint		incl = required;
+		for (int off = 1; off < STROM_WAVE; off <<= 1)
+		{
+			cl_uint o = (cl_uint)__shfl_up((int)incl, off, STROM_WAVE);
+			if (lane >= (cl_uint)off)
+				incl += o;
+		}
+		if (lane == STROM_WAVE - 1)
+			wave_total[wave] = incl;
+		if (threadIdx.x == 0)
+			tile_error = StromError_Success;
+		__syncthreads();
+		cl_uint		before = 0, total = 0;
+		for (cl_uint w = 0; w < blockDim.x / STROM_WAVE; w++)
+		{
+			if (w < wave)
+				before += wave_total[w];
+			total += wave_total[w];
+		}
+		if (bad)
+			atomicMax(&tile_error, StromError_DataStoreCorruption);
+		if (threadIdx.x == 0)
+		{
+			cl_uint	prev = (total > 0 ? atomicAdd(&kds_dest->usage, total) : 0);
+			/* (64-bit sum: usage may have run past 4 GB on a hopeless request) */
+			if ((cl_ulong)usage_head + (cl_ulong)prev + (cl_ulong)total > (cl_ulong)dest_length)
+				atomicMax(&tile_error, StromError_DataStoreNoSpace);
+			tile_base = prev;
+		}
+		__syncthreads();
+		cl_int		terr = tile_error;
+		cl_uint		base = tile_base;
+		__syncthreads();						/* tile_base / wave_total are rewritten by the next tile */
+		if (terr != StromError_Success)
+		{
+			if (threadIdx.x == 0)
+				atomicMax(&kresults->errcode, terr);
+			continue;
+		}
+		if (!valid)
+			continue;
+		/* step 3: the tuple, in place */
+		cl_uint		htup_offset = dest_length - (base + before + incl);
+		char	   *tup = (char *)kds_dest + htup_offset;
+		HeapTupleHeaderData *htup = (HeapTupleHeaderData *)tup;
+
+		KERN_DATA_STORE_ROWITEM(kds_dest, i)->htup_offset = htup_offset;
+		for (cl_uint b = 0; b < t_hoff; b++)
+			tup[b] = 0;
+		htup->t_xmin = required << 2;			/* t_choice.t_datum: SET_VARSIZE, typmod, type id */
+		htup->t_xmax = (cl_uint)kds_dest->tdtypmod;
+		htup->t_field3 = kds_dest->tdtypeid;
+		htup->t_infomask2 = (cl_ushort)(ncols & HEAP_NATTS_MASK);
+		htup->t_hoff = (cl_uchar)t_hoff;
+		cl_uint		curr = t_hoff;
+		bool		hasvarwidth = false;
+		for (cl_uint r = 0; r < ncols; r++)
+		{
+			kern_colmeta	cm = kds_dest->colmeta[r];
+			hashjoin_proj_src src = hashjoin_projection_locate(kmhash, kds, ktoast, rbuffer, nrels,
+															   src_depth[r], src_colidx[r]);
+			if (!src.addr)
+				continue;						/* bit stays 0 */
+			if (hasnull)
+				htup->t_bits[r >> 3] |= (cl_uchar)(1 << (r & 7));
+			cl_uint	len;
+			if (cm.attlen > 0)
+			{
+				while (STROM_TYPEALIGN(cm.attalign, curr) != curr)
+					tup[curr++] = 0;
+				len = (cl_uint)cm.attlen;
+			}
+			else
+			{
+				if (!strom_varatt_is_1b(src.addr))
+					while (STROM_TYPEALIGN(cm.attalign, curr) != curr)
+						tup[curr++] = 0;
+				len = strom_varsize_any(src.addr);
+				hasvarwidth = true;
+			}
+			for (cl_uint b = 0; b < len; b++)
+				tup[curr + b] = src.addr[b];
+			curr += len;
+		}
+		while (curr < required)
+			tup[curr++] = 0;
+		htup->t_infomask = (cl_ushort)((hasnull ? HEAP_HASNULL : 0) | (hasvarwidth ? HEAP_HASVARWIDTH : 0));
+	}
+}
+
+/* ====================================================================== *
  * a dimension column by SLOT (DIRECT index, unique keys): values[slot] /
  * isnull[slot] of inner column 'col'.  Built once per table and column, on
  * the first projection that asks for it: reading a joined row's inner column

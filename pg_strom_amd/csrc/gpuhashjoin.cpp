@@ -486,15 +486,21 @@ gpuhashjoin_launch(strom_task_impl *task, hashjoin_request req)
 		/* kern_gpuhashjoin_projection_slot (gpuhashjoin.c:4585-4588, 4883-4968) */
 		kern_data_store *kd = req.kds_dest;
 		int			e2 = 0;
-		hipFunction_t fn_proj = prog->get_function(dev, "gpuhashjoin_projection_slot", &e2);
+		/* TUPSLOT: one fixed-stride slot per record; ROW_FLAT: heap tuples growing from the
+		 * tail of the caller's buffer (kern_gpuhashjoin_projection_row, 437-689) */
+		bool		dest_rows = (kd->format == KDS_FORMAT_ROW_FLAT);
+		hipFunction_t fn_proj = prog->get_function(dev, dest_rows ? "gpuhashjoin_projection_row"
+												   : "gpuhashjoin_projection_slot", &e2);
 		if (!fn_proj)
 		{
 			task_fail(task, e2);
 			return;
 		}
 		dest_head = KDS_HEAD_LENGTH(kd->ncols);
-		dest_stride = KDS_TUPSLOT_STRIDE(kd->ncols);
-		size_t	dest_len = dest_head + dest_stride * (size_t)kd->nrooms;
+		dest_stride = (dest_rows ? 0 : KDS_TUPSLOT_STRIDE(kd->ncols));
+		size_t	dest_len = (dest_rows ? (size_t)kd->length : dest_head + dest_stride * (size_t)kd->nrooms);
+		if (dest_rows)
+			kd->usage = 0;
 		size_t	map_len = sizeof(cl_int) * kd->ncols;
 		d_dest = (char *)dev->pool.alloc(dest_len);
 		cl_int *d_map = (cl_int *)dev->pool.alloc(2 * map_len);
@@ -554,7 +560,38 @@ gpuhashjoin_launch(strom_task_impl *task, hashjoin_request req)
 			t->errcode = kres_host->errcode;
 			return;
 		}
-		if (kds_dest)
+		if (kds_dest && kds_dest->format == KDS_FORMAT_ROW_FLAT)
+		{
+			/* the head (usage, nitems) and the row items, then the tuples at the tail */
+			size_t	items_end = dest_head + STROMALIGN(sizeof(kern_blkitem) * (size_t)kds_dest->maxblocks) +
+				STROMALIGN(sizeof(kern_rowitem) * (size_t)kres_host->nitems);
+			size_t	total = kds_dest->length;
+			hostptr_t hostptr = kds_dest->hostptr;
+			hipError_t rc = hipMemcpyAsync(kds_dest, d_dest, std::min(items_end, total),
+										   hipMemcpyDeviceToHost, t->stream);
+			if (rc == hipSuccess)
+				rc = hipStreamSynchronize(t->stream);
+			kds_dest->hostptr = hostptr;
+			size_t	usage = kds_dest->usage;
+			if (rc == hipSuccess && (items_end + usage > total || kds_dest->nitems != kres_host->nitems))
+			{
+				/* (cannot happen when the kernel reported success) */
+				t->errcode = StromError_DataStoreCorruption;
+				return;
+			}
+			if (rc == hipSuccess && usage > 0)
+			{
+				rc = hipMemcpyAsync((char *)kds_dest + total - usage, d_dest + total - usage, usage,
+									hipMemcpyDeviceToHost, t->stream);
+				if (rc == hipSuccess)
+					rc = hipStreamSynchronize(t->stream);
+			}
+			if (rc != hipSuccess)
+				t->errcode = hip_errcode(rc, "recv kds_dest");
+			t->pfm.num_dma_recv += 2;
+			t->pfm.bytes_dma_recv += items_end + usage;
+		}
+		else if (kds_dest)
 		{
 			size_t	len = dest_stride * (size_t)kres_host->nitems;
 			hipError_t rc = hipSuccess;
@@ -636,7 +673,12 @@ strom_submit_gpuhashjoin_projection(strom_hashjoin_table *tbl,
 									uint32_t flags,
 									strom_done_cb done, void *arg, int *p_errcode)
 {
-	if (!kds_dest || !src_depth || !src_colidx || kds_dest->format != KDS_FORMAT_TUPSLOT)
+	if (!kds_dest || !src_depth || !src_colidx ||
+		(kds_dest->format != KDS_FORMAT_TUPSLOT && kds_dest->format != KDS_FORMAT_ROW_FLAT) ||
+		(kds_dest->format == KDS_FORMAT_ROW_FLAT &&
+		 (size_t)kds_dest->length < KDS_HEAD_LENGTH(kds_dest->ncols) +
+		 STROMALIGN(sizeof(kern_blkitem) * (size_t)kds_dest->maxblocks) +
+		 STROMALIGN(sizeof(kern_rowitem) * (size_t)kds_dest->nrooms)))
 	{
 		if (p_errcode)
 			*p_errcode = StromError_BadRequestMessage;

@@ -239,6 +239,67 @@ class GpuHashJoin(object):
                 out.append((v, isnull[:, i]))
             return nitems, out
 
+    def join_chunk_project_rows(self, chunk, dest_columns, nrooms=None, data_bytes=None):
+        """join + kern_gpuhashjoin_projection_row (opencl_hashjoin.h:437-689): the joined rows
+        as heap tuples in a ROW_FLAT kern_data_store (text / character(n) columns included).
+        dest_columns as in join_chunk_project.  Returns (nitems, dest chunk (uint8 array),
+        result records); DataStoreNoSpace is answered by a larger store, like
+        gpuhashjoin.c:4330-4425."""
+        from .kds import SQL_TYPES, KDS_HEAD_FIXED
+        nrows = chunk.nitems if isinstance(chunk, runtime.DeviceStore) else KdsHead(chunk).nitems
+        if nrooms is None:
+            nrooms = int(nrows * self.ratio * 1.1) + 1
+        ncols = len(dest_columns)
+        if data_bytes is None:
+            data_bytes = 64 * nrooms
+        for attempt in range(8):
+            head_len = (KDS_HEAD_FIXED + 8 * ncols + 15) & ~15
+            items_len = (4 * nrooms + 15) & ~15
+            dest = aligned_buffer(head_len + items_len + data_bytes, 64)
+            dest[:head_len + items_len] = 0
+            u32 = dest[:KDS_HEAD_FIXED].view(np.uint32)
+            u32[2] = len(dest)
+            u32[4] = ncols
+            u32[6] = nrooms
+            dest[36] = 2                                     # KDS_FORMAT_ROW_FLAT
+            dest[40:44] = np.array([2249], dtype=np.uint32).view(np.uint8)     # tdtypeid RECORDOID
+            dest[44:48] = np.array([-1], dtype=np.int32).view(np.uint8)        # tdtypmod
+            for i, (_, _, typ) in enumerate(dest_columns):
+                attlen = SQL_TYPES[typ][1]
+                meta = dest[KDS_HEAD_FIXED + 8 * i: KDS_HEAD_FIXED + 8 * i + 8]
+                meta[0] = 1 if attlen > 0 else 0
+                meta[1] = attlen if attlen > 0 else 4
+                meta[2:4] = np.array([attlen], dtype=np.int16).view(np.uint8)
+                meta[4:6] = np.array([i + 1], dtype=np.int16).view(np.uint8)
+                meta[6:8] = np.array([-1], dtype=np.int16).view(np.uint8)
+            depth = np.array([d for d, _, _ in dest_columns], dtype=np.int32)
+            colidx = np.array([a - 1 for _, a, _ in dest_columns], dtype=np.int32)
+            khj, res_off = self._make_khj(nrooms, True)
+            if isinstance(chunk, runtime.DeviceStore):
+                kds_host, kds_dev = None, chunk.handle
+            else:
+                kds_host, kds_dev = chunk.ctypes.data, None
+            err = ctypes.c_int(0)
+            task = lib.strom_submit_gpuhashjoin_projection(
+                self.table, khj.ctypes.data, kds_host, kds_dev, None, dest.ctypes.data,
+                depth.ctypes.data, colidx.ctypes.data, 0, None, None, ctypes.byref(err))
+            if not task:
+                raise runtime.StromError(err.value, "strom_submit_gpuhashjoin_projection")
+            rc = lib.strom_task_wait(task, None)
+            nitems = int(np.frombuffer(khj[res_off + 8:res_off + 12].tobytes(), dtype=np.uint32)[0])
+            if rc == ERR_NOSPACE and attempt < 7:
+                if nitems > nrooms:
+                    nrooms = nitems                          # more records than rooms
+                else:
+                    data_bytes *= 8                          # the tuples did not fit
+                continue
+            if rc != 0:
+                raise runtime.StromError(rc, "GpuHashJoin projection (rows)")
+            start = res_off + RESULTBUF_HEAD
+            recs = np.frombuffer(khj[start:start + 4 * nitems * self.nrels].tobytes(),
+                                 dtype=np.int32).reshape(nitems, self.nrels)
+            return nitems, dest, recs
+
     def join_to_column(self, chunk, dest_columns, row_map=None, nrooms=None, zone_maps=True):
         """join a RESIDENT chunk and leave the joined rows in HBM as a COLUMN chunk
         for the next operator (strom_hashjoin_project_column): dest_columns as in

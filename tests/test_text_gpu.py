@@ -85,3 +85,76 @@ def test_text_residual_qual_in_a_join():
     want = sum(1 for i in range(20000)
                if text_cases.bpchar_key(chr10[i]) == b"SHIP" or (not tnull[i] and txt[i] < b"B"))
     assert res.nitems == want
+
+
+def _walk_row_flat(dest, nitems, ncols):
+    """every datum of a ROW_FLAT chunk through the ORACLE's tuple walker (independent of the
+    device code that built the tuples): [(bytes or None) per column] per row"""
+    import ctypes
+    lib = oracle.load()
+    lib.oracle_get_datum.restype = ctypes.c_void_p
+    lib.oracle_get_datum.argtypes = [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint32]
+    attlen = [int(dest[48 + 8 * c + 2:48 + 8 * c + 4].view(np.int16)[0]) for c in range(ncols)]
+    base = dest.ctypes.data
+    rows = []
+    for r in range(nitems):
+        row = []
+        for c in range(ncols):
+            addr = lib.oracle_get_datum(base, c, r)
+            if not addr:
+                row.append(None)
+                continue
+            off = addr - base
+            assert 0 <= off < len(dest)
+            if attlen[c] > 0:
+                row.append(dest[off:off + attlen[c]].tobytes())
+            else:
+                b0 = int(dest[off])
+                if b0 & 1:
+                    n = (b0 >> 1) & 0x7f
+                    row.append(dest[off + 1:off + n].tobytes())
+                else:
+                    n = int(dest[off:off + 4].view(np.uint32)[0]) >> 2
+                    row.append(dest[off + 4:off + n].tobytes())
+        rows.append(row)
+    return rows
+
+
+@pytest.mark.parametrize("ofmt", ["row", "row_flat"])
+def test_join_projection_into_heap_tuples(ofmt):
+    """kern_gpuhashjoin_projection_row: joined rows as ROW_FLAT heap tuples, NULLs, short and
+    long text datums, columns of both sides -- every datum checked against the source rows"""
+    from pg_strom_amd.gpuhashjoin import GpuHashJoin, build_multihash, entry_rowids
+    n = 6000
+    buf, txt, chr10, num, tnull = text_cases.text_table(n, 44, ofmt)
+    rng = np.random.default_rng(4)
+    pk = np.arange(-50, 50, dtype=np.int32)
+    pay = rng.integers(0, 1000, 100).astype(np.int32)
+    payn = rng.random(100) < 0.2
+    small = rng.integers(-9, 9, 100).astype(np.int16)
+    inner = kds.build_kds("row", [kds.Column("int4", pk), kds.Column("int4", pay, payn), kds.Column("int2", small)])
+    spec = "(gpuhashjoin (rel (hashkey (var 1 int4) 1 int4)))"
+    km = build_multihash([(inner, [1])])
+    join = GpuHashJoin(spec).begin(km)
+    try:
+        dest_columns = [(0, 2, "text"), (1, 2, "int4"), (0, 1, "int4"), (1, 3, "int2"), (0, 4, "int8"),
+                        (0, 3, "character")]
+        # a deliberately small store first: the tuples do not fit -> DataStoreNoSpace -> retry
+        nitems, dest, recs = join.join_chunk_project_rows(buf, dest_columns, data_bytes=4096)
+        dkm = join.device_kmhash()
+    finally:
+        join.end()
+    assert nitems == n                          # every fact key has its dimension row
+    inner_row = entry_rowids(dkm, 1, recs[:, 1])
+    rows = _walk_row_flat(dest, nitems, len(dest_columns))
+    for i in range(nitems):
+        o = int(recs[i, 0]) - 1
+        d = int(inner_row[i])
+        want = [None if tnull[o] else txt[o],
+                None if payn[d] else pay[d].tobytes(),
+                num[o].tobytes(), small[d].tobytes(), np.int64(o).tobytes(), chr10[o]]
+        assert rows[i] == want, (i, o, d)
+        assert int(pk[d]) == int(num[o])
+    # head bookkeeping: nitems, usage inside the buffer
+    u32 = dest[:48].view(np.uint32)
+    assert u32[5] == nitems and 0 < u32[3] < len(dest)
