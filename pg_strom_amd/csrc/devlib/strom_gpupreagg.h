@@ -1116,7 +1116,12 @@ struct gpupreagg_joined_map {
 	 * c[i].dimisnull = its bit in the record's flags word */
 	cl_ulong	recs;
 	cl_uint		reclen;
-	cl_uint		__pad;
+	/* NARROW records (hashjoin_dimrec_narrow_kernel, lookup only): reclen 2 or 4, the word is
+	 * presence | NULL bits | (value - nmin) fields; inner column i = nmin[i] + field */
+	cl_uint		narrow;
+	cl_uint		nshift[64];
+	cl_uint		nmask[64];
+	cl_long		nmin[64];
 };
 
 extern "C" __global__ void
@@ -1355,6 +1360,13 @@ gpupreagg_dense_lookup_body(kern_gpupreagg *kgpreagg,
 							   : (const cl_uint *)NULL);
 	const char *recs = strom_uniform((const char *)jmap->recs);
 	cl_uint		reclen = strom_uniform((cl_uint)jmap->reclen);
+	const bool	narrow = (strom_uniform((cl_uint)jmap->narrow) != 0);
+#define X(attno,colidx,NAME)													\
+	const cl_uint nshift_##attno = strom_uniform((cl_uint)jmap->nshift[colidx]);	\
+	const cl_uint nmask_##attno = strom_uniform((cl_uint)jmap->nmask[colidx]);	\
+	const cl_long nmin_##attno = strom_uniform((cl_long)jmap->nmin[colidx]);
+	STROM_KVAR_LIST(X)
+#undef X
 	/* a qual that reads outer columns only is evaluated BEFORE the probe: a row it
 	 * rejects (without an error) costs no L2 request; gpupreagg_dense_row evaluates
 	 * it again for the rows that do have a partner, errors included */
@@ -1476,7 +1488,13 @@ gpupreagg_dense_lookup_body(kern_gpupreagg *kgpreagg,
 				}
 				else
 #endif
-				if (reclen == 8)
+				if (narrow)
+				{
+					/* 2- or 4-byte record: flags and value fields in one word */
+					words[j][0] = (reclen == 2 ? (cl_uint)*(const cl_ushort *)rec : *(const cl_uint *)rec);
+					words[j][1] = words[j][2] = words[j][3] = 0;
+				}
+				else if (reclen == 8)
 				{
 					cl_ulong w = *(const cl_ulong *)rec;
 					words[j][0] = (cl_uint)w;
@@ -1505,7 +1523,10 @@ gpupreagg_dense_lookup_body(kern_gpupreagg *kgpreagg,
 				for (int j = 0; j < 4; j++)										\
 				{																\
 					pg_##NAME##_base_t val;										\
-					if (reclen <= 16)											\
+					if (narrow)													\
+						val = (pg_##NAME##_base_t)(nmin_##attno +				\
+							(cl_long)((flags[j] >> nshift_##attno) & nmask_##attno));	\
+					else if (reclen <= 16)										\
 					{															\
 						/* (offsets are uniform: the selects are scalar) */		\
 						cl_uint	wi = recoff_##attno >> 2;						\

@@ -1435,6 +1435,139 @@ hashjoin_build_dimrec_kernel(const kern_multihash *kmhash, const hashjoin_index 
 }
 
 /* ====================================================================== *
+ * NARROW slot records: the same information in 2 or 4 bytes per slot.
+ *
+ * A probe into the slot records is one random read; what it costs depends on
+ * whether the table stays in an XCD's 4 MB L2 while the fact columns stream
+ * past.  8-byte records of a 1e6-row dimension are 10 MB: every fifth probe
+ * misses L2 and fetches a 64-byte line from HBM for 8 useful bytes (PMC:
+ * 1e7 misses per 1e8 fact rows, more HBM traffic than one of the streamed
+ * columns).  Integer columns rarely need their declared width: with the
+ * range of each wanted column known (hashjoin_dimrec_minmax_kernel over the
+ * standard records), a record is  bit 0 presence | bit 1+i NULL of column i |
+ * (value_i - min_i) in just enough bits  -- a GROUP BY column with 1e4
+ * distinct values and its two flag bits fit 16 bits, 2.5 MB for 1.25e6 slots.
+ * The presence / NULL bits sit where the standard record's flags word has
+ * them, so a consumer tests them the same way.
+ * ====================================================================== */
+struct hashjoin_dimrec_range {
+	cl_long		vmin[16];
+	cl_long		vmax[16];
+	cl_uint		nvalues[16];
+};
+
+struct hashjoin_dimrec_narrow_spec {
+	cl_uint		ncols;
+	cl_uint		reclen;				/* 2 or 4 */
+	cl_uint		shift[16];
+	cl_uint		mask[16];
+	cl_long		vmin[16];
+};
+
+STROM_DEVICE cl_long
+hashjoin_dimrec_value(const char *rec, cl_uint offset, cl_int attlen)
+{
+	switch (attlen)
+	{
+		case 1:  return *(const cl_char *)(rec + offset);
+		case 2:  return *(const cl_short *)(rec + offset);
+		case 4:  return *(const cl_int *)(rec + offset);
+		default: return *(const cl_long *)(rec + offset);
+	}
+}
+
+extern "C" __global__ void
+__launch_bounds__(256)
+hashjoin_dimrec_minmax_kernel(const hashjoin_dimrec_spec *spec, const char *recs, cl_uint nslots,
+							  hashjoin_dimrec_range *out)
+{
+	cl_uint		ncols = spec->ncols;
+	cl_uint		reclen = spec->reclen;
+	cl_long		my_min[16], my_max[16];
+	cl_uint		seen = 0;
+
+	for (int i = 0; i < 16; i++)
+	{
+		my_min[i] = 0x7fffffffffffffffL;
+		my_max[i] = -0x7fffffffffffffffL - 1;
+	}
+	for (cl_uint s = blockIdx.x * blockDim.x + threadIdx.x; s < nslots; s += gridDim.x * blockDim.x)
+	{
+		const char *rec = recs + (size_t)reclen * s;
+		cl_uint		flags = *(const cl_uint *)rec;
+		if (!(flags & 1u))
+			continue;
+#pragma unroll
+		for (int i = 0; i < 16; i++)
+		{
+			if (i < (int)ncols && !(flags & (2u << i)))
+			{
+				cl_long v = hashjoin_dimrec_value(rec, spec->c[i].offset, spec->c[i].attlen);
+				my_min[i] = (v < my_min[i] ? v : my_min[i]);
+				my_max[i] = (v > my_max[i] ? v : my_max[i]);
+				seen |= (1u << i);
+			}
+		}
+	}
+	for (int off = STROM_WAVE / 2; off > 0; off >>= 1)
+	{
+		seen |= (cl_uint)__shfl_xor((int)seen, off, STROM_WAVE);
+#pragma unroll
+		for (int i = 0; i < 16; i++)
+		{
+			cl_long	omin = __shfl_xor(my_min[i], off, STROM_WAVE);
+			cl_long	omax = __shfl_xor(my_max[i], off, STROM_WAVE);
+			my_min[i] = (omin < my_min[i] ? omin : my_min[i]);
+			my_max[i] = (omax > my_max[i] ? omax : my_max[i]);
+		}
+	}
+	if ((threadIdx.x & (STROM_WAVE - 1)) == 0)
+	{
+#pragma unroll
+		for (int i = 0; i < 16; i++)
+		{
+			if (!(seen & (1u << i)))
+				continue;
+			atomicOr(&out->nvalues[i], 1u);
+			atomicMin((long long *)&out->vmin[i], (long long)my_min[i]);
+			atomicMax((long long *)&out->vmax[i], (long long)my_max[i]);
+		}
+	}
+}
+
+extern "C" __global__ void
+__launch_bounds__(256)
+hashjoin_dimrec_narrow_kernel(const hashjoin_dimrec_spec *spec, const char *recs, cl_uint nslots,
+							  const hashjoin_dimrec_narrow_spec *nspec, char *out)
+{
+	cl_uint		ncols = spec->ncols;
+	cl_uint		reclen = spec->reclen;
+	cl_uint		flagmask = (2u << ncols) - 1u;
+
+	for (cl_uint s = blockIdx.x * blockDim.x + threadIdx.x; s < nslots; s += gridDim.x * blockDim.x)
+	{
+		const char *rec = recs + (size_t)reclen * s;
+		cl_uint		flags = *(const cl_uint *)rec;
+		cl_uint		w = flags & flagmask;
+
+		if (flags & 1u)
+		{
+			for (cl_uint i = 0; i < ncols; i++)
+			{
+				if (flags & (2u << i))
+					continue;
+				cl_long v = hashjoin_dimrec_value(rec, spec->c[i].offset, spec->c[i].attlen);
+				w |= ((cl_uint)(cl_ulong)(v - nspec->vmin[i]) & nspec->mask[i]) << nspec->shift[i];
+			}
+		}
+		if (nspec->reclen == 2)
+			((cl_ushort *)out)[s] = (cl_ushort)w;
+		else
+			((cl_uint *)out)[s] = w;
+	}
+}
+
+/* ====================================================================== *
  * projection into a COLUMN chunk that stays in HBM
  *
  * What the next operator of a device-resident chain reads (SURVEY.md

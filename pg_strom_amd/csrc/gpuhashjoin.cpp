@@ -62,6 +62,9 @@ struct strom_hashjoin_table {
 	/* the same PACKED, one record per slot, per set of (column, attlen)
 	 * (hashjoin_build_dimrec_kernel): key = the set as text */
 	std::map<std::string, std::pair<char *, unsigned>> dimrecs;
+	/* narrow form of a record set (same key), built on the first lookup that can take it;
+	 * reclen 0 = tried, does not fit */
+	std::map<std::string, dimrec_narrow> dimrecs_narrow;
 };
 
 extern "C" strom_hashjoin_table *
@@ -261,6 +264,9 @@ strom_hashjoin_table_release(strom_hashjoin_table *tbl)
 	}
 	for (auto &kv : tbl->dimrecs)
 		dev->pool.release(kv.second.first);
+	for (auto &kv : tbl->dimrecs_narrow)
+		if (kv.second.recs)
+			dev->pool.release(kv.second.recs);
 	strom_put_devprog_key(tbl->key);
 	delete tbl;
 }
@@ -827,7 +833,8 @@ strom::hashjoin_table_dimcol(strom_hashjoin_table *tbl, int col, int attlen, voi
  */
 int
 strom::hashjoin_table_dimrecs(strom_hashjoin_table *tbl, int n, const int *cols, const int *attlens,
-							  unsigned *offsets, void **p_recs, unsigned *p_reclen)
+							  unsigned *offsets, void **p_recs, unsigned *p_reclen,
+							  const int *narrowable, dimrec_narrow *narrow)
 {
 	struct spec_image {
 		cl_uint		ncols, reclen;
@@ -892,6 +899,99 @@ strom::hashjoin_table_dimrecs(strom_hashjoin_table *tbl, int n, const int *cols,
 	}
 	*p_recs = it->second.first;
 	*p_reclen = it->second.second;
+	if (narrow)
+	{
+		narrow->reclen = 0;
+		bool	candidate = (narrowable != nullptr && n >= 1 && !getenv("STROM_HASHJOIN_NO_NARROW_RECS"));
+		for (int i = 0; candidate && i < n; i++)
+			candidate = (narrowable[i] != 0);
+		auto	nit = tbl->dimrecs_narrow.find(key);
+		if (candidate && nit == tbl->dimrecs_narrow.end())
+		{
+			/*
+			 * ranges of the wanted columns over the present, non-NULL values -> field widths;
+			 * 1 + n flag bits + the fields must fit 16 or 32 bits
+			 */
+			struct range_image { cl_long vmin[16]; cl_long vmax[16]; cl_uint nvalues[16]; } rg;
+			struct nspec_image { cl_uint ncols, reclen; cl_uint shift[16]; cl_uint mask[16]; cl_long vmin[16]; } ns;
+			dimrec_narrow	nw;
+			int			errcode = 0;
+			cl_uint		nslots = tbl->head.rel[0].nslots;
+			hipStream_t	stream = dev->streams[0];
+			(void)hipSetDevice(dev->hip_id);
+			hipFunction_t fn_mm = tbl->prog->get_function(dev, "hashjoin_dimrec_minmax_kernel", &errcode);
+			hipFunction_t fn_nw = tbl->prog->get_function(dev, "hashjoin_dimrec_narrow_kernel", &errcode);
+			char   *d_spec = (char *)dev->pool.alloc(sizeof(spec));
+			char   *d_rg = (char *)dev->pool.alloc(sizeof(rg));
+			char   *d_ns = (char *)dev->pool.alloc(sizeof(ns));
+			unsigned	grid = std::max(1u, std::min<unsigned>((nslots + 255) / 256,
+														   (unsigned)dev->prop.multiProcessorCount * 8));
+			memset(&rg, 0, sizeof(rg));
+			for (int i = 0; i < 16; i++)
+			{
+				rg.vmin[i] = INT64_MAX;
+				rg.vmax[i] = INT64_MIN;
+			}
+			bool	ok = (fn_mm && fn_nw && d_spec && d_rg && d_ns);
+			if (ok)
+			{
+				const void *a_spec = d_spec;
+				const void *a_recs = it->second.first;
+				void	   *a_rg = d_rg;
+				void	   *args[] = { &a_spec, &a_recs, &nslots, &a_rg };
+				ok = (hipMemcpyAsync(d_spec, &spec, sizeof(spec), hipMemcpyHostToDevice, stream) == hipSuccess &&
+					  hipMemcpyAsync(d_rg, &rg, sizeof(rg), hipMemcpyHostToDevice, stream) == hipSuccess &&
+					  hipModuleLaunchKernel(fn_mm, grid, 1, 1, 256, 1, 1, 0, stream, args, nullptr) == hipSuccess &&
+					  hipMemcpyAsync(&rg, d_rg, sizeof(rg), hipMemcpyDeviceToHost, stream) == hipSuccess &&
+					  hipStreamSynchronize(stream) == hipSuccess);
+			}
+			unsigned	bits = 1 + (unsigned)n;
+			memset(&ns, 0, sizeof(ns));
+			for (int i = 0; ok && i < n; i++)
+			{
+				cl_ulong span = (rg.nvalues[i] ? (cl_ulong)rg.vmax[i] - (cl_ulong)rg.vmin[i] : 0);
+				unsigned w = 0;
+				while (w < 64 && (span >> w) != 0)
+					w++;
+				if (w > 31 || bits + w > 32)
+				{
+					ok = false;
+					break;
+				}
+				ns.shift[i] = nw.shift[i] = bits;
+				ns.mask[i] = nw.mask[i] = (w == 0 ? 0u : (cl_uint)((1UL << w) - 1));
+				ns.vmin[i] = nw.vmin[i] = (rg.nvalues[i] ? rg.vmin[i] : 0);
+				bits += w;
+			}
+			if (ok)
+			{
+				ns.ncols = (cl_uint)n;
+				ns.reclen = nw.reclen = (bits <= 16 ? 2 : 4);
+				char   *d_out = (char *)dev->pool.alloc((size_t)nw.reclen * nslots + 64);
+				const void *a_spec = d_spec;
+				const void *a_recs = it->second.first;
+				const void *a_ns = d_ns;
+				void	   *a_out = d_out;
+				void	   *args[] = { &a_spec, &a_recs, &nslots, &a_ns, &a_out };
+				ok = (d_out &&
+					  hipMemcpyAsync(d_ns, &ns, sizeof(ns), hipMemcpyHostToDevice, stream) == hipSuccess &&
+					  hipModuleLaunchKernel(fn_nw, grid, 1, 1, 256, 1, 1, 0, stream, args, nullptr) == hipSuccess &&
+					  hipStreamSynchronize(stream) == hipSuccess);
+				if (ok)
+					nw.recs = d_out;
+				else if (d_out)
+					dev->pool.release(d_out);
+			}
+			if (!ok)
+				nw.reclen = 0;
+			if (d_spec) dev->pool.release(d_spec);
+			if (d_rg) dev->pool.release(d_rg);
+			if (d_ns) dev->pool.release(d_ns);
+			nit = tbl->dimrecs_narrow.insert({key, nw}).first;
+		}
+		if (candidate && nit != tbl->dimrecs_narrow.end())
+			*narrow = nit->second;
+	}
 	return 0;
 }
 

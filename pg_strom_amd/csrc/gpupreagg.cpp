@@ -344,7 +344,10 @@ struct joined_map_image {
 	} c[64];
 	cl_ulong	recs;
 	cl_uint		reclen;
-	cl_uint		pad;
+	cl_uint		narrow;
+	cl_uint		nshift[64];
+	cl_uint		nmask[64];
+	cl_long		nmin[64];
 };
 
 /* mirrors struct gpupreagg_pack_ctl of strom_gpupreagg.h */
@@ -1632,9 +1635,10 @@ submit_gpupreagg_over_join(strom_gpupreagg *sess, strom_task *join_handle, bool 
 	}
 	{
 		/* one packed record per slot: presence, NULL bits and the wanted inner columns */
-		int		cols[16], lens[16], which[16], n = 0;
+		int		cols[16], lens[16], which[16], ints[16], n = 0;
 		unsigned offs[16], reclen = 0;
 		void   *recs = nullptr;
+		dimrec_narrow nw;
 		for (int i = 0; i < ncols; i++)
 		{
 			if (src_depth[i] != 1)
@@ -1648,9 +1652,13 @@ submit_gpupreagg_over_join(strom_gpupreagg *sess, strom_task *join_handle, bool 
 			cols[n] = src_colidx[i];
 			lens[n] = ((oid == STROM_BOOLOID || oid == STROM_BPCHAROID) ? 1 : oid == STROM_INT2OID ? 2
 					   : (oid == STROM_INT4OID || oid == STROM_FLOAT4OID || oid == STROM_DATEOID) ? 4 : 8);
+			ints[n] = !(oid == STROM_FLOAT4OID || oid == STROM_FLOAT8OID || oid == STROM_NUMERICOID);
 			which[n++] = i;
 		}
-		int		rc = hashjoin_table_dimrecs(tbl, n, cols, lens, offs, &recs, &reclen);
+		/* the lookup kernel also reads the narrow form (2 / 4 bytes per slot: more of the table
+		 * stays in L2 while the fact columns stream past) */
+		int		rc = hashjoin_table_dimrecs(tbl, n, cols, lens, offs, &recs, &reclen,
+											ints, lookup ? &nw : nullptr);
 		if (rc != 0)
 		{
 			*p_errcode = rc;
@@ -1663,6 +1671,19 @@ submit_gpupreagg_over_join(strom_gpupreagg *sess, strom_task *join_handle, bool 
 		}
 		jm->recs = (cl_ulong)(uintptr_t)recs;
 		jm->reclen = reclen;
+		if (lookup && nw.reclen != 0)
+		{
+			jm->recs = (cl_ulong)(uintptr_t)nw.recs;
+			jm->reclen = nw.reclen;
+			jm->narrow = 1;
+			for (int k = 0; k < n; k++)
+			{
+				jm->c[which[k]].dimvalues = 0;
+				jm->nshift[which[k]] = nw.shift[k];
+				jm->nmask[which[k]] = nw.mask[k];
+				jm->nmin[which[k]] = nw.vmin[k];
+			}
+		}
 	}
 	preagg_request req;
 	req.sess = sess;

@@ -199,8 +199,19 @@ void		task_wait_completed(strom_task_impl *task);
 Device	   *get_device(int dindex);
 /* gpuhashjoin.cpp, for consumers of join results (gpupreagg.cpp) */
 int			hashjoin_table_dimcol(strom_hashjoin_table *tbl, int col, int attlen, void **p_values, void **p_isnull);
+/* narrow form of the slot records (strom_hashjoin.h): reclen 2 or 4, or 0 = not available */
+struct dimrec_narrow {
+	unsigned	reclen = 0;
+	void	   *recs = nullptr;
+	cl_uint		shift[16] = {};
+	cl_uint		mask[16] = {};
+	cl_long		vmin[16] = {};
+};
+/* narrowable (n flags, may be NULL): column i holds integers (not float bits); narrow (may be
+ * NULL) receives the narrow records when every column is narrowable and the fields fit 32 bits */
 int			hashjoin_table_dimrecs(strom_hashjoin_table *tbl, int n, const int *cols, const int *attlens,
-								   unsigned *offsets, void **p_recs, unsigned *p_reclen);
+								   unsigned *offsets, void **p_recs, unsigned *p_reclen,
+								   const int *narrowable = nullptr, dimrec_narrow *narrow = nullptr);
 int			hashjoin_table_direct_info(strom_hashjoin_table *tbl, cl_long *p_key_min, cl_uint *p_nslots,
 									   int *p_outer_key_attno, int *p_dindex, int *p_has_outer_qual = nullptr);
 /* gpupreagg.cpp, for the RCCL merge (parallel.cpp): mirrors preagg_merge_spec of

@@ -393,9 +393,11 @@ def test_join_as_a_lookup_inside_the_aggregate(ngroups, keytype):
     assert np.array_equal(gmax[order][~np.isinf(wmax)], wmax[~np.isinf(wmax)])
 
 
-@pytest.mark.parametrize("epochs", [False, True])
-def test_join_as_a_lookup_with_packed_accumulators(epochs, monkeypatch):
-    """1e4 groups, summed OUTER columns without NULLs: the lookup aggregate takes the packed
+@pytest.mark.parametrize("epochs,narrow", [(False, True), (True, True), (False, False)])
+def test_join_as_a_lookup_with_packed_accumulators(epochs, narrow, monkeypatch):
+    """narrow: the slot records are 2 bytes (presence, NULL bit, 14 bits of the group column:
+    hashjoin_dimrec_narrow_kernel) instead of 8 -- same answers either way.
+    1e4 groups, summed OUTER columns without NULLs: the lookup aggregate takes the packed
     LDS image (gpupreagg_packed_lookup, one id-range role instead of two); the grouping key
     is an inner column with NULLs, rows without a partner are dropped.  epochs: a 31-bit
     value range and enough rows that the packed word is moved to the slab between epochs."""
@@ -403,6 +405,8 @@ def test_join_as_a_lookup_with_packed_accumulators(epochs, monkeypatch):
     n, nd, ngroups = (2_500_003 if epochs else 300007), 40000, 10000
     if epochs:
         monkeypatch.setenv("STROM_GPUPREAGG_PACK_COUNT_BITS", "14")
+    if not narrow:
+        monkeypatch.setenv("STROM_HASHJOIN_NO_NARROW_RECS", "1")
     rng = np.random.default_rng(97)
     span = int(nd * 1.25)
     fk = rng.integers(0, span, n).astype(np.int32)
@@ -449,3 +453,66 @@ def test_join_as_a_lookup_with_packed_accumulators(epochs, monkeypatch):
     np.add.at(sums, inv, a[sel].astype(np.int64))
     assert np.array_equal(pr.column(2)[0][order], 2 * sums)
     assert np.allclose(pr.column(3)[0][order], 2 * np.bincount(inv, weights=b[sel]), rtol=1e-12)
+
+
+def test_narrow_slot_records_negative_values_two_inner_columns():
+    """two integer inner columns in one 4-byte record: a group column with negative values
+    and NULLs, an int2 column the WHERE reads (so the qual runs after the probe); the same
+    query with the standard records must give the same partial rows"""
+    runtime.init()
+    n, nd = 400003, 30000
+    rng = np.random.default_rng(5)
+    span = int(nd * 1.2)
+    fk = rng.integers(0, span, n).astype(np.int32)
+    a = rng.integers(-10**6, 10**6, n).astype(np.int32)
+    fact = kds.build_kds("column", [kds.Column("int4", fk), kds.Column("int4", a)])
+    dkey = rng.permutation(span)[:nd].astype(np.int32)
+    dgrp = (dkey % 300 - 150).astype(np.int32)
+    dgn = rng.random(nd) < 0.03
+    dflag = rng.integers(-3, 4, nd).astype(np.int16)
+    dfn = rng.random(nd) < 0.03
+    inner = kds.build_kds("row", [kds.Column("int4", dkey), kds.Column("int4", dgrp, dgn),
+                                  kds.Column("int2", dflag, dfn)])
+    km = build_multihash([(inner, [1])])
+    spec = ("(gpupreagg (qual (int2gt (var 3 int2) (const int2 -2))) (key (var 1 int4)) (nrows)"
+            " (psum (int8 (var 2 int4))) (pmin (var 3 int2)))")
+    cols = [(1, 2, "int4"), (0, 2, "int4"), (1, 3, "int2")]
+    got = {}
+    import os
+    for narrow in (True, False):
+        if narrow:
+            os.environ.pop("STROM_HASHJOIN_NO_NARROW_RECS", None)
+        else:
+            os.environ["STROM_HASHJOIN_NO_NARROW_RECS"] = "1"
+        ds = runtime.DeviceStore.upload(fact)
+        join = GpuHashJoin("(gpuhashjoin (rel (hashkey (var 1 int4) 1 int4)))").begin(km)
+        agg = GpuPreAgg(spec)
+        try:
+            agg.begin([(-150, 300)])
+            assert agg.collect(agg.submit_lookup(join, ds, cols))[0] == 0
+            pr = agg.fetch()
+        finally:
+            agg.end()
+            join.end()
+            ds.release()
+            os.environ.pop("STROM_HASHJOIN_NO_NARROW_RECS", None)
+        rows = sorted((None if pr.isnull[i, 0] else int(pr.column(0)[0][i]), int(pr.column(1)[0][i]),
+                       int(pr.column(2)[0][i]), None if pr.isnull[i, 3] else int(pr.column(3)[0][i]))
+                      for i in range(len(pr)))
+        got[narrow] = rows
+    assert got[True] == got[False]
+    # and numpy
+    pos = np.full(span, -1, dtype=np.int64)
+    pos[dkey] = np.arange(nd)
+    di = pos[fk]
+    sel = np.flatnonzero((di >= 0) & ~dfn[np.clip(di, 0, nd - 1)] & (dflag[np.clip(di, 0, nd - 1)] > -2))
+    want = {}
+    for i in sel:
+        d = di[i]
+        k = None if dgn[d] else int(dgrp[d])
+        c, sm, mn = want.get(k, (0, 0, 99))
+        want[k] = (c + 1, sm + int(a[i]), min(mn, int(dflag[d])))
+    wrows = sorted(((k, c, sm, mn) for k, (c, sm, mn) in want.items()),
+                   key=lambda r: (r[0] is not None, r[0] if r[0] is not None else 0))
+    grows = sorted(got[True], key=lambda r: (r[0] is not None, r[0] if r[0] is not None else 0))
+    assert grows == wrows
