@@ -186,6 +186,14 @@ ingest_to_column_varnum(const kern_data_store *__restrict__ src, kern_data_store
 }
 
 /*
+ * (Tried and removed in round 2: heap pages staged in LDS -- 4 pages per 256-row tile,
+ * coalesced 16-byte loads, tuples walked with ds_read.  185 us per 1e7 rows against 140 us
+ * for the walk through global memory above: 34 KB of LDS per work-group halve the waves a
+ * CU holds, and it was those waves that hid the walk's dependent loads.
+ * profiles/r02_ingest_staged_probe.txt)
+ */
+
+/*
  * zone maps in a pass of their own over the transposed columns (coalesced
  * 4-12 B/row, mostly still in L2 / Infinity Cache): blockIdx.y = column.  A
  * thread keeps a running min / max of the order-preserving u64 image of
@@ -205,7 +213,7 @@ ingest_minmax(kern_data_store *dst, const cl_int *type_oids)
 	cl_int		oid = (type_oids ? type_oids[c] : 0);
 	int			attlen = dst->colmeta[c].attlen;
 
-	if (oid == 0 || oid == STROM_NUMERICOID || attlen < 1 || attlen > 8)
+	if (oid == 0 || oid == STROM_NUMERICOID || !(attlen == 1 || attlen == 2 || attlen == 4 || attlen == 8))
 		return;
 	bool		isflt = (oid == STROM_FLOAT4OID || oid == STROM_FLOAT8OID);
 	const char *values = (const char *)dst + coldir[c].values_off;
@@ -219,18 +227,18 @@ ingest_minmax(kern_data_store *dst, const cl_int *type_oids)
 		s_max = 0UL;
 	}
 	__syncthreads();
-	for (cl_uint row = blockIdx.x * blockDim.x + threadIdx.x;
-		 row < nitems;
-		 row += gridDim.x * blockDim.x)
+	/*
+	 * 16 bytes per lane and load (the value arrays are 256-byte aligned), four loads in flight,
+	 * ONE work-group per CU and column: the pass ends in an atomic min / max pair per work-group
+	 * on the column's directory entry, and same-address atomics are served at tens of millions
+	 * per second -- with 1024 work-groups per column they, not the 120 MB read, were the 74 us
+	 * this pass took (profiles/r02_ingest_staged_probe.txt)
+	 */
+	typedef cl_uint ingest_vec4 __attribute__((ext_vector_type(4)));
+	const cl_uint	per_vec = 16u / (cl_uint)attlen;			/* rows per 16 bytes */
+	const cl_uint	nvec = nitems / per_vec;
+	auto fold = [&](cl_long v, cl_uint row)
 	{
-		cl_long		v;
-		switch (attlen)
-		{
-			case 1: v = ((const cl_char *)values)[row]; break;
-			case 2: v = ((const cl_short *)values)[row]; break;
-			case 4: v = ((const cl_int *)values)[row]; break;
-			default: v = ((const cl_long *)values)[row]; break;
-		}
 		bool		ok = (!notnull || ((notnull[row >> 5] >> (row & 31)) & 1));
 		cl_ulong	key;
 		if (isflt)
@@ -248,6 +256,63 @@ ingest_minmax(kern_data_store *dst, const cl_int *type_oids)
 			mn = (key < mn ? key : mn);
 			mx = (key > mx ? key : mx);
 		}
+	};
+	auto fold_vec = [&](ingest_vec4 q, cl_uint i)
+	{
+		cl_uint		row0 = i * per_vec;
+		cl_uint		w[4] = { q.x, q.y, q.z, q.w };
+		switch (attlen)
+		{
+			case 1:
+				_Pragma("unroll")
+				for (int k = 0; k < 16; k++)
+					fold((cl_long)(cl_char)(w[k >> 2] >> ((k & 3) * 8)), row0 + k);
+				break;
+			case 2:
+				_Pragma("unroll")
+				for (int k = 0; k < 8; k++)
+					fold((cl_long)(cl_short)(w[k >> 1] >> ((k & 1) * 16)), row0 + k);
+				break;
+			case 4:
+				_Pragma("unroll")
+				for (int k = 0; k < 4; k++)
+					fold((cl_long)(cl_int)w[k], row0 + k);
+				break;
+			default:
+				_Pragma("unroll")
+				for (int k = 0; k < 2; k++)
+					fold((cl_long)(((cl_ulong)w[2 * k + 1] << 32) | w[2 * k]), row0 + k);
+				break;
+		}
+	};
+	const ingest_vec4 *vecs = (const ingest_vec4 *)values;
+	cl_uint		stride = gridDim.x * blockDim.x;
+	cl_uint		i = blockIdx.x * blockDim.x + threadIdx.x;
+	for (; i + 3 * stride < nvec; i += 4 * stride)
+	{
+		ingest_vec4 q0 = vecs[i];
+		ingest_vec4 q1 = vecs[i + stride];
+		ingest_vec4 q2 = vecs[i + 2 * stride];
+		ingest_vec4 q3 = vecs[i + 3 * stride];
+		fold_vec(q0, i);
+		fold_vec(q1, i + stride);
+		fold_vec(q2, i + 2 * stride);
+		fold_vec(q3, i + 3 * stride);
+	}
+	for (; i < nvec; i += stride)
+		fold_vec(vecs[i], i);
+	/* the rows behind the last whole vector */
+	for (cl_uint row = nvec * per_vec + blockIdx.x * blockDim.x + threadIdx.x; row < nitems; row += stride)
+	{
+		cl_long		v;
+		switch (attlen)
+		{
+			case 1: v = ((const cl_char *)values)[row]; break;
+			case 2: v = ((const cl_short *)values)[row]; break;
+			case 4: v = ((const cl_int *)values)[row]; break;
+			default: v = ((const cl_long *)values)[row]; break;
+		}
+		fold(v, row);
 	}
 #pragma unroll
 	for (int m = 32; m > 0; m >>= 1)

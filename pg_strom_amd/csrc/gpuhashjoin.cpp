@@ -1191,7 +1191,7 @@ strom_hashjoin_project_column(strom_task *handle, strom_hashjoin_table *tbl, str
 		if (grid > 0 &&
 			(hipModuleLaunchKernel(fn_proj, pgrid, 1, 1, 256, 1, 1, 0, stream, args, nullptr) != hipSuccess ||
 			 (any_zone_map &&
-			  hipModuleLaunchKernel(fn_mm, std::min(grid, (unsigned)dev->prop.multiProcessorCount * 4),
+			  hipModuleLaunchKernel(fn_mm, std::min(grid, (unsigned)dev->prop.multiProcessorCount),
 									(unsigned)ncols, 1, 256, 1, 1, 0, stream, args_mm, nullptr) != hipSuccess)))
 		{
 			*p_errcode = StromError_HipInternal;

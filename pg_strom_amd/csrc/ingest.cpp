@@ -172,7 +172,7 @@ strom_dstore_to_column(strom_dstore *src, const int32_t *type_oids, int ntypes,
 		/* zone maps from the transposed columns, one grid row per column */
 		void	   *args_mm[] = { &a_dst, &a_oids };
 		unsigned	mmgrid = (unsigned)std::min<size_t>(((size_t)nitems + 255) / 256,
-														(size_t)dev->prop.multiProcessorCount * 4);
+														(size_t)dev->prop.multiProcessorCount);	/* one work-group per CU and column: see ingest_minmax */
 		if (type_oids && mmgrid > 0 &&
 			hipModuleLaunchKernel(fn_mm, mmgrid, (unsigned)ncols, 1, 256, 1, 1, 0, stream,
 								  args_mm, nullptr) != hipSuccess)

@@ -496,10 +496,10 @@ def test_narrow_slot_records_negative_values_two_inner_columns():
             join.end()
             ds.release()
             os.environ.pop("STROM_HASHJOIN_NO_NARROW_RECS", None)
-        rows = sorted((None if pr.isnull[i, 0] else int(pr.column(0)[0][i]), int(pr.column(1)[0][i]),
-                       int(pr.column(2)[0][i]), None if pr.isnull[i, 3] else int(pr.column(3)[0][i]))
-                      for i in range(len(pr)))
-        got[narrow] = rows
+        rows = [(None if pr.isnull[i, 0] else int(pr.column(0)[0][i]), int(pr.column(1)[0][i]),
+                 int(pr.column(2)[0][i]), None if pr.isnull[i, 3] else int(pr.column(3)[0][i]))
+                for i in range(len(pr))]
+        got[narrow] = sorted(rows, key=lambda r: (r[0] is not None, r[0] if r[0] is not None else 0))
     assert got[True] == got[False]
     # and numpy
     pos = np.full(span, -1, dtype=np.int64)
