@@ -512,6 +512,75 @@ main(int argc, char **argv)
 		}
 		printf("ok: gpupreagg %d folds with callbacks, %ld groups, counts and integer sums exact\n", NFOLD, ngroups);
 		strom_gpupreagg_release(sess);
+
+		/* --------------------------------------------------------- *
+		 * 4. the reference's own per-chunk message (pgstrom_gpupreagg,
+		 *    opencl_gpupreagg.h:994-1003): kern_gpupreagg image + pds +
+		 *    pds_dest, no session, no domain; three in flight, callbacks
+		 * --------------------------------------------------------- */
+		enum { NMSG = 3 };
+		size_t	map_off = STROMALIGN(offsetof(kern_gpupreagg, kparams) + kparams->length);
+		size_t	kg_len = map_off + sizeof(kern_row_map);
+		size_t	dest_len = KDS_HEAD_LENGTH(ntargets) + KDS_TUPSLOT_STRIDE(ntargets) * (size_t)2500;
+		kern_gpupreagg *kg[NMSG];
+		kern_data_store *pds_dest[NMSG];
+		request		mq[NMSG];
+		atomic_int	mpend = NMSG;
+		memset(mq, 0, sizeof(mq));
+		for (int i = 0; i < NMSG; i++)
+		{
+			kg[i] = (kern_gpupreagg *)xaligned(kg_len);
+			memset(kg[i], 0, kg_len);
+			memcpy(&kg[i]->kparams, kparams, kparams->length);
+			KERN_GPUPREAGG_KROWMAP(kg[i])->nvalids = -1;		/* every row */
+			kg[i]->status = 12345;								/* must be overwritten */
+			pds_dest[i] = (kern_data_store *)xaligned(dest_len);
+			memset(pds_dest[i], 0, KDS_HEAD_LENGTH(ntargets));
+			mq[i].pending = &mpend;
+			strom_task *t = strom_submit_gpupreagg_chunk(key, targets, ntargets, kg[i], kds_col, NULL,
+														 pds_dest[i], dest_len, 1, 2500.0, 0,
+														 on_done, &mq[i], &errcode);
+			CHECK(t != NULL && errcode == 0);
+			mq[i].task = t;
+		}
+		wait_all(&mpend);
+		for (int i = 0; i < NMSG; i++)
+		{
+			CHECK(atomic_load(&mq[i].calls) == 1 && mq[i].errcode == 0 && kg[i]->status == 0);
+			CHECK(!pthread_equal(mq[i].cb_thread, pthread_self()));
+			CHECK(strom_task_wait(mq[i].task, NULL) == 0);
+			CHECK((long)pds_dest[i]->nitems == expect_groups && pds_dest[i]->format == KDS_FORMAT_TUPSLOT);
+			for (long g = 0; g < expect_groups; g++)
+			{
+				uint64_t v[4];
+				for (int cidx = 0; cidx < 4; cidx++)
+					CHECK(strom_kds_fetch(pds_dest[i], (uint32_t)g, (uint32_t)cidx, &v[cidx]) == 0);
+				int32_t gk = (int32_t)v[0];
+				CHECK(gk >= 0 && gk < 2500);
+				CHECK((int64_t)v[1] == cnt[gk] && (int64_t)v[2] == sx[gk]);
+			}
+		}
+		/* a store that is too small for the chunk's groups: DataStoreNoSpace, status says so */
+		{
+			request		one;
+			atomic_int	p1 = 1;
+			memset(&one, 0, sizeof(one));
+			one.pending = &p1;
+			kg[0]->status = 12345;
+			strom_task *t = strom_submit_gpupreagg_chunk(key, targets, ntargets, kg[0], kds_col, NULL,
+														 pds_dest[0], KDS_HEAD_LENGTH(ntargets) + 64, 1, 0.0, 0,
+														 on_done, &one, &errcode);
+			CHECK(t != NULL);
+			wait_all(&p1);
+			CHECK(one.errcode == StromError_DataStoreNoSpace && kg[0]->status == StromError_DataStoreNoSpace);
+			CHECK(strom_task_wait(t, NULL) == StromError_DataStoreNoSpace);
+			/* needs_grouping that contradicts the program is refused at once, no callback */
+			CHECK(strom_submit_gpupreagg_chunk(key, targets, ntargets, kg[0], kds_col, NULL, pds_dest[0], dest_len,
+											   0, 0.0, 0, on_done, &one, &errcode) == NULL &&
+				  errcode == StromError_BadRequestMessage);
+		}
+		printf("ok: %d per-chunk gpupreagg messages in flight, %ld groups each, status word and pds_dest filled "
+			   "before the callback\n", NMSG, expect_groups);
 		strom_put_devprog_key(key);
 	}
 	strom_shutdown();

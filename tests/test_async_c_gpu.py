@@ -31,4 +31,4 @@ def test_async_boundary_from_c():
     p = subprocess.run([EXE], capture_output=True, text=True, timeout=600, env=env)
     assert p.returncode == 0, "stdout:\n%s\nstderr:\n%s" % (p.stdout, p.stderr)
     assert "ALL OK" in p.stdout
-    assert p.stdout.count("ok:") == 4
+    assert p.stdout.count("ok:") == 5
