@@ -140,6 +140,58 @@ def c4_chunk_device(nrows, seed, ngroups=10_000):
     return ds, cnt, sx
 
 
+def numeric_images_device(v, scale):
+    """int64 tensor 'v' at 10^-scale -> the 64-bit device numeric images (normalised: trailing
+    decimal zeros moved into the exponent), what kds.numeric_from_scaled does on the host"""
+    import torch
+    sign = (v < 0).to(torch.int64)
+    mant = v.abs()
+    exp = torch.full_like(v, -int(scale))
+    for _ in range(19):
+        strip = (mant != 0) & (mant % 10 == 0)
+        if not bool(strip.any().item()):
+            break
+        mant = torch.where(strip, mant // 10, mant)
+        exp = exp + strip.to(torch.int64)
+    img = ((exp & 0x3f) << 58) | (sign << 57) | mant
+    return torch.where(mant == 0, torch.zeros_like(img), img)
+
+
+def c5_chunk_device(nrows, seed):
+    """TPC-H Q1-shaped lineitem columns: returnflag, linestatus as
+    char(1), quantity / extendedprice / discount / tax as 8-byte numerics, shipdate; returns
+    (resident chunk, per-group row counts and quantity sums of the rows the date filter keeps)"""
+    import torch
+    from pg_strom_amd import runtime
+    g = _gen(seed)
+
+    def rnd(lo, hi, dtype=torch.int64):
+        return torch.randint(lo, hi, (nrows,), dtype=dtype, device="cuda", generator=g)
+    rf = torch.tensor([65, 78, 82], dtype=torch.int8, device="cuda")[rnd(0, 3)]
+    ls = torch.tensor([70, 79], dtype=torch.int8, device="cuda")[rnd(0, 2)]
+    qty = rnd(1, 51)
+    cols = [rf, ls, numeric_images_device(qty, 0), numeric_images_device(rnd(90000, 10494951), 2),
+            numeric_images_device(rnd(0, 11), 2), numeric_images_device(rnd(0, 9), 2)]
+    ship = rnd(-2922, -2922 + 2526, torch.int32)
+    cutoff = -486                                   # date '1998-09-02' in days since 2000-01-01
+    keep = ship <= cutoff
+    gid = ((rf.long() - 65) * 16 + (ls.long() - 70))[keep]
+    cnt = torch.bincount(gid, minlength=18 * 16)
+    sq = torch.zeros(18 * 16, dtype=torch.int64, device="cuda").index_add_(0, gid, qty[keep])
+    ds = runtime.DeviceStore.from_torch_columns(["char1", "char1", "numeric", "numeric", "numeric", "numeric", "date"],
+                                                cols + [ship])
+    return ds, cnt.cpu().numpy(), sq.cpu().numpy()
+
+
+Q1_AGG = ("(gpupreagg (qual (date_le (var 7 date) (const date '1998-09-02')))"
+          " (key (var 1 char1)) (key (var 2 char1))"
+          " (psum (var 3 numeric 0) 0) (psum (var 4 numeric 2) 2)"
+          " (psum (numeric_mul (var 4 numeric 2) (numeric_sub (const numeric 1) (var 5 numeric 2))) 4)"
+          " (psum (numeric_mul (numeric_mul (var 4 numeric 2) (numeric_sub (const numeric 1) (var 5 numeric 2)))"
+          " (numeric_add (const numeric 1) (var 6 numeric 2))) 6)"
+          " (nrows (isnotnull (var 3 numeric 0))) (nrows (isnotnull (var 4 numeric 2)))"
+          " (psum (var 5 numeric 2) 2) (nrows (isnotnull (var 5 numeric 2))) (nrows))")
+
 T_START = time.perf_counter()
 
 
@@ -399,6 +451,41 @@ def operator_figures(args, k, c, measured_peak, cpu_blocks):
     for f in facts:
         f.release()
     del facts, fact
+    torch.cuda.empty_cache()
+
+    # ---- C5: TPC-H Q1-shaped scan + filter + group-by on numeric / date columns ----------
+    q1rows = chunk_rows
+    q1, q1cnt, q1sq = c5_chunk_device(q1rows, 0x5eed0005)
+    agg = GpuPreAgg(Q1_AGG).begin([(65, 18), (70, 10)])
+    agg.census(q1)
+    nslots = agg.compact()
+    walls, kerns = [], []
+    for step in range(6):
+        agg.reset()
+        t0 = time.perf_counter()
+        st, pfm = agg.fold(q1)
+        walls.append(time.perf_counter() - t0)
+        assert st == 0, "Q1 fold status %d" % st
+        kerns.append(pfm["time_kern_exec_ns"] - pfm["time_kern_proj_ns"])
+    pr = agg.fetch()
+    k1, k2 = pr.column(0)[0].astype(np.int64), pr.column(1)[0].astype(np.int64)
+    gids = (k1 - 65) * 16 + (k2 - 70)
+    assert np.array_equal(np.sort(gids), np.flatnonzero(q1cnt)), "Q1: groups differ"
+    assert np.array_equal(pr.column(10)[0], q1cnt[gids]), "Q1: row counts differ"
+    # sum(quantity) comes back as a numeric in the 64-bit device form: mantissa x 10^exponent
+    img = pr.column(2)[0].astype(np.uint64)
+    q1sum = (img & np.uint64((1 << 57) - 1)).astype(np.int64) * 10 ** (img.view(np.int64) >> 58)
+    assert np.array_equal(q1sum, q1sq[gids]), "Q1: sum(quantity) differs"
+    out["q1_shape_c5"] = dict(
+        workload="TPC-H Q1-shaped GpuPreAgg (BASELINE configs[4], one GPU's share): %d lineitem-like rows, "
+                 "WHERE shipdate <= date, GROUP BY returnflag, linestatus (%d groups), 9 partial aggregates over "
+                 "4 numeric(*,2) columns as 8-byte numerics (38 B/row)" % (q1rows, len(pr)),
+        value=q1rows / float(np.median(walls[1:])) / 1e6, unit="Mrows/s", groups=len(pr), table_slots=int(nslots),
+        checked="groups, row counts and sum(quantity) equal torch's",
+        roofline=roofline_block("gpupreagg_priv_column", 38.0 * q1rows, kerns[1:], measured_peak))
+    agg.end()
+    q1.release()
+    del q1
     torch.cuda.empty_cache()
 
     return out
