@@ -884,19 +884,34 @@ cl_uint
 hash_lds_slots(const strom_gpupreagg *sess, size_t *p_bytes)
 {
 	size_t		nkeys = sess->key_resno.size();
-	cl_uint		slots = 4096;
-	size_t		bytes;
 	/* after the table: 256 queued row numbers per wave (GPUPREAGG_HASH_QUEUE, used with roles) */
 	size_t		queue = ((size_t)sess->block / 64) * 256 * sizeof(cl_uint);
-	for (;;)
-	{
-		bytes = sess->image_offset(sess->nsections(), slots, 1) + (size_t)slots * (8 + 8 * nkeys) + queue;
-		if (bytes <= 64 * 1024 || slots == 64)
-			break;
-		slots >>= 1;
-	}
-	*p_bytes = bytes;
-	return slots;
+	auto fit = [&](size_t budget, size_t *p_b) -> cl_uint {
+		cl_uint	slots = 16384;
+		for (;;)
+		{
+			*p_b = sess->image_offset(sess->nsections(), slots, 1) + (size_t)slots * (8 + 8 * nkeys) + queue;
+			if (*p_b <= budget || slots == 64)
+				return slots;
+			slots >>= 1;
+		}
+	};
+	/*
+	 * LDS per work-group: ONE work-group per CU with a table of up to 136 KB, four times the
+	 * slots of the 64 KB table two work-groups per CU had.  Every doubling of the table halves
+	 * the hash roles, and each role is a scan of every row's key columns: 1e4 groups 5.1 ->
+	 * 3.4 ms per 1e8 rows, 3e4 groups 13.2 -> 7.1 ms; a fuller small table also probes longer,
+	 * so the big one wins from 100 groups on (698 -> 656 us; 600 groups 1463 -> 932 us).
+	 * profiles/r02_hashed_lds_tables.txt
+	 */
+	size_t		small_bytes, big_bytes;
+	cl_uint		small_slots = fit(64 * 1024, &small_bytes);
+	cl_uint		big_slots = fit(136 * 1024, &big_bytes);
+	bool		big = true;
+	if (const char *v = getenv("STROM_GPUPREAGG_HASH_LDS_KB"))
+		big = (atol(v) > 64);
+	*p_bytes = (big ? big_bytes : small_bytes);
+	return (big ? big_slots : small_slots);
 }
 
 /* a zeroed, initialised table of 'capacity' slots on the session's stream */
@@ -1034,7 +1049,7 @@ gpupreagg_launch_hashed(strom_task_impl *task, preagg_request req)
 	size_t		lds_bytes = 0;
 	cl_uint		lds_slots = hash_lds_slots(sess, &lds_bytes);
 	unsigned	block = (unsigned)sess->block;
-	unsigned	fold_grid = (unsigned)dev->prop.multiProcessorCount * 2;
+	unsigned	fold_grid = (unsigned)dev->prop.multiProcessorCount * (lds_bytes <= 72 * 1024 ? 2 : 1);
 	cl_ulong	headroom = (cl_ulong)fold_grid * block + (cl_ulong)fold_grid * lds_slots;
 	if (!sess->htab)
 	{
