@@ -2330,6 +2330,9 @@ gpupreagg_reg1_column(kern_gpupreagg *kgpreagg, const kern_data_store *kds,
 #endif
 /* queued row numbers per wave (roles): a power of two, >= 64 * (UNROLL + 1) */
 #define GPUPREAGG_HASH_QUEUE	256
+/* role map (one byte per row, written by the check pass): low 6 bits = the row's role among
+ * up to 64; this value = no role folds the row (the qual dropped it, or padding) */
+#define GPUPREAGG_ROLE_NONE		0xffu
 #ifndef GPUPREAGG_HASH_LDS_PROBES
 #define GPUPREAGG_HASH_LDS_PROBES	64	/* a key that finds no room in LDS sends ALL its rows to one
 										 * global record: same-address atomics, to be avoided */
@@ -2553,7 +2556,7 @@ gpupreagg_hash_body(kern_gpupreagg *kgpreagg,
 					const kern_data_store *ktoast,
 					const kern_row_map *krowmap,
 					char *htab, cl_uint claim_limit, kern_row_map *deferred,
-					cl_uint lds_slots, cl_uint nroles, char *lds)
+					cl_uint lds_slots, cl_uint nroles, char *lds, cl_uchar *rolemap)
 {
 	const kern_parambuf *kparams = KERN_GPUPREAGG_PARAMBUF(kgpreagg);
 	gpupreagg_hash_head *head = (gpupreagg_hash_head *)htab;
@@ -2596,13 +2599,17 @@ gpupreagg_hash_body(kern_gpupreagg *kgpreagg,
 	 * one row, its columns loaded: qual, keys, partial inputs, then into the
 	 * work-group's LDS table or, without room there, the global one
 	 */
-	auto fold_loaded = [&](const strom_kvars &KV, cl_int errcode, cl_uint kds_index)
+	auto fold_loaded = [&](const strom_kvars &KV, cl_int errcode, cl_uint kds_index, size_t pos)
 	{
 		cl_ulong	kimg[GPUPREAGG_NKEYS + 1];
 		cl_uint		knull = 0;
 		pg_bool_t	rc = gpupreagg_qual_eval(&errcode, KP, KV);
 		if (errcode == StromError_Success && !EVAL(rc))
+		{
+			if (!FOLD && rolemap != NULL)
+				rolemap[pos] = GPUPREAGG_ROLE_NONE;		/* filtered: no role folds it */
 			return;
+		}
 #define X(kidx,resno,NAME)															\
 		{																			\
 			pg_##NAME##_t kv = gpupreagg_key_##kidx(&errcode, KP, KV);				\
@@ -2628,7 +2635,14 @@ gpupreagg_hash_body(kern_gpupreagg *kgpreagg,
 		GPUPREAGG_AGG_LIST(X)
 #undef X
 		if (!FOLD)
+		{
+			/* the check pass has the row's hash at hand: leave its role (6 bits: up to 64
+			 * roles) for the fold's role scans, which then read one byte per row instead
+			 * of the qual's and the keys' columns */
+			if (rolemap != NULL)
+				rolemap[pos] = (cl_uchar)((gpupreagg_hash_of(kimg, knull) >> 7) & 63u);
 			return;
+		}
 		cl_uint		hash = gpupreagg_hash_of(kimg, knull);
 		cl_uint		lslot = gpupreagg_hash_lds_slot(T, hash, kimg, knull);
 		cl_uint		need = GPUPREAGG_FLAG_SEEN;
@@ -2731,9 +2745,52 @@ gpupreagg_hash_body(kern_gpupreagg *kgpreagg,
 #undef X
 		KV.__dummy = 0;
 		if (active)
-			fold_loaded(KV, param_error, kds_index);
+			fold_loaded(KV, param_error, kds_index, 0);
 		qhead += nready;
 	};
+	/*
+	 * ROLES with a role map (the check pass wrote one byte per row: the row's role, or
+	 * GPUPREAGG_ROLE_NONE for a row the qual drops): the scan is 16 bytes per lane and
+	 * load and a compare per row -- 0.1 GB per 1e8 rows and role instead of the qual's and
+	 * keys' columns plus a hash per row.  The host pads the map with ROLE_NONE to whole
+	 * tiles; row maps and deferred rows take the scan below.
+	 */
+	if (ROLES && rolemap != NULL)
+	{
+		/*
+		 * a tile is 16 x blockDim rows; in turn j a wave looks at 64 CONSECUTIVE rows (one
+		 * byte per lane), so the rows it queues are neighbours and the loads that fetch
+		 * their columns in drain() share cache lines.  (16 bytes per lane in one load put
+		 * rows 16 apart next to each other in the queue: every queued row then cost a
+		 * line of its own per column -- 3000 groups, two roles: 1.8 -> 2.8 ms.)
+		 */
+		size_t		tile_rows = (size_t)16 * blockDim.x;
+		for (size_t tile = xcd + 8 * (size_t)member;
+			 tile * tile_rows < nrows;
+			 tile += 8 * (size_t)nmembers)
+		{
+			size_t		r0 = tile * tile_rows + threadIdx.x;
+			cl_uint		b[16];
+			/* (the map is padded to whole tiles: no bounds test on the loads) */
+#pragma unroll
+			for (int j = 0; j < 16; j++)
+				b[j] = rolemap[r0 + (size_t)j * blockDim.x];
+#pragma unroll
+			for (int j = 0; j < 16; j++)
+			{
+				bool		own = (b[j] != GPUPREAGG_ROLE_NONE && (b[j] & (nroles - 1)) == role);
+				cl_ulong	mask = __ballot(own);
+				if (own)
+					queue[(qtail + (cl_uint)__popcll(mask & ((1UL << strom_lane_id()) - 1)))
+						  & (GPUPREAGG_HASH_QUEUE - 1)] = (cl_uint)(r0 + (size_t)j * blockDim.x);
+				qtail += (cl_uint)__popcll(mask);
+				__builtin_amdgcn_wave_barrier();
+				while (qtail - qhead >= STROM_WAVE)
+					drain(STROM_WAVE);
+			}
+		}
+	}
+	else
 	/*
 	 * a tile is GPUPREAGG_HASH_UNROLL x blockDim rows: a thread first loads
 	 * its rows of the tile, then works on them one by one (with one row per
@@ -2781,7 +2838,8 @@ gpupreagg_hash_body(kern_gpupreagg *kgpreagg,
 			if (!ROLES)
 			{
 				if (live[j])
-					fold_loaded(KVs[j], errs[j], kidx[j]);
+					fold_loaded(KVs[j], errs[j], kidx[j],
+								(tile * GPUPREAGG_HASH_UNROLL + j) * blockDim.x + threadIdx.x);
 				continue;
 			}
 			/* scan: is this row the role's?  (every lane stays for the ballot) */
@@ -2867,32 +2925,34 @@ extern "C" __global__ void
 __launch_bounds__(256)
 gpupreagg_hash_check(kern_gpupreagg *kgpreagg, const kern_data_store *kds,
 					 const kern_data_store *ktoast, const kern_row_map *krowmap, char *htab,
-					 cl_uint claim_limit, kern_row_map *deferred, cl_uint lds_slots, cl_uint nroles)
+					 cl_uint claim_limit, kern_row_map *deferred, cl_uint lds_slots, cl_uint nroles,
+					 cl_uchar *rolemap)
 {
 	if (kds->format == KDS_FORMAT_COLUMN)
-		gpupreagg_hash_body<true, false, false>(kgpreagg, kds, ktoast, krowmap, htab, 0, NULL, 0, 1, NULL);
+		gpupreagg_hash_body<true, false, false>(kgpreagg, kds, ktoast, krowmap, htab, 0, NULL, 0, 1, NULL, rolemap);
 	else
-		gpupreagg_hash_body<false, false, false>(kgpreagg, kds, ktoast, krowmap, htab, 0, NULL, 0, 1, NULL);
+		gpupreagg_hash_body<false, false, false>(kgpreagg, kds, ktoast, krowmap, htab, 0, NULL, 0, 1, NULL, rolemap);
 }
 
 extern "C" __global__ void
 __launch_bounds__(GPUPREAGG_BLOCK)
 gpupreagg_hash_fold(kern_gpupreagg *kgpreagg, const kern_data_store *kds,
 					const kern_data_store *ktoast, const kern_row_map *krowmap, char *htab,
-					cl_uint claim_limit, kern_row_map *deferred, cl_uint lds_slots, cl_uint nroles)
+					cl_uint claim_limit, kern_row_map *deferred, cl_uint lds_slots, cl_uint nroles,
+					cl_uchar *rolemap)
 {
 	extern __shared__ __attribute__((aligned(16))) char lds[];
 	/* (decided once per launch; with roles a row is read by several
 	 * work-groups of the XCD, so its lines should stay in L2) */
 	if (kds->format != KDS_FORMAT_COLUMN)
 		gpupreagg_hash_body<false, true, false>(kgpreagg, kds, ktoast, krowmap, htab, claim_limit, deferred,
-												lds_slots, nroles, lds);
+												lds_slots, nroles, lds, NULL);
 	else if (nroles > 1)
 		gpupreagg_hash_body<true, true, true>(kgpreagg, kds, ktoast, krowmap, htab, claim_limit, deferred,
-											  lds_slots, nroles, lds);
+											  lds_slots, nroles, lds, rolemap);
 	else
 		gpupreagg_hash_body<true, true, false>(kgpreagg, kds, ktoast, krowmap, htab, claim_limit, deferred,
-											   lds_slots, nroles, lds);
+											   lds_slots, nroles, lds, NULL);
 }
 
 /* min / max accumulators start from their identities (sums from the zeroed table) */

@@ -1130,12 +1130,35 @@ gpupreagg_launch_hashed(strom_task_impl *task, preagg_request req)
 		unsigned	maxgrid = (unsigned)dev->prop.multiProcessorCount * 8;
 		cl_uint		no_limit = ~0u;
 		void	   *a_nodefer = nullptr;
+		/*
+		 * role map: when the fold will run with hash roles (COLUMN chunk, no row map, more
+		 * groups than one LDS table takes) the check pass leaves one byte per row -- the
+		 * row's role -- and the roles' scans read that instead of the qual's and the keys'
+		 * columns.  Padded with ROLE_NONE to whole scan tiles (16 rows per lane of a
+		 * fold work-group).
+		 */
+		void	   *a_rolemap = nullptr;
+		{
+			cl_ulong	per_role0 = (cl_ulong)lds_slots * 5 / 8;
+			if (req.format == KDS_FORMAT_COLUMN && !d_rowmap && nrows > 0 &&
+				(cl_ulong)sess->groups_known > per_role0 && !getenv("STROM_GPUPREAGG_HASH_NO_ROLEMAP"))
+			{
+				size_t	tile = (size_t)block * 16;
+				size_t	len = (((size_t)nrows + tile - 1) / tile) * tile;
+				a_rolemap = dev->pool.alloc(len);
+				if (a_rolemap)
+				{
+					task->devbufs.push_back(a_rolemap);
+					REQ_CHECK(hipMemsetAsync(a_rolemap, 0xff, len, task->stream), "pad the role map");
+				}
+			}
+		}
 		/* pass 1: errors only -- a chunk with a CpuReCheck row is not folded at all */
 		{
 			void	   *a_tab = sess->htab;
 			cl_uint		one_role = 1;
 			void	   *args[] = { &a_kg, &a_kds, &a_toast, &a_map, &a_tab, &no_limit, &a_nodefer, &lds_slots,
-								   &one_role };
+								   &one_role, &a_rolemap };
 			/* (the kernels deal tiles to 8 XCDs: grids are multiples of 8) */
 			unsigned	grid = std::max(8u, std::min<unsigned>((nrows + 255) / 256 + 7, maxgrid) & ~7u);
 			REQ_CHECK(hipModuleLaunchKernel(fn_check, grid, 1, 1, 256, 1, 1, 0, task->stream, args, nullptr),
@@ -1220,8 +1243,10 @@ gpupreagg_launch_hashed(strom_task_impl *task, preagg_request req)
 				if (req.format == KDS_FORMAT_COLUMN && want >= 1 && want <= 64 && (want & (want - 1)) == 0)
 					nroles = (cl_uint)want;
 			}
+			/* (deferred rows of a later turn are a row map: the scan over the columns) */
+			void	   *a_rm = (turn == 0 && nroles > 1 ? a_rolemap : nullptr);
 			void	   *args[] = { &a_kg, &a_kds, &a_toast, &a_map, &a_tab, &claim_limit, &a_defer, &lds_slots,
-								   &nroles };
+								   &nroles, &a_rm };
 			unsigned	unit = 8 * nroles;
 			unsigned	grid = std::min<unsigned>(((todo + block - 1) / block + unit - 1) / unit * unit, fold_grid);
 			grid = std::max(unit, grid / unit * unit);

@@ -643,17 +643,20 @@ def test_hashed_session_refuses_the_dense_table_calls():
         GpuPreAgg("(gpupreagg (key (var 1 float8)) (nrows))").begin([(0, 10)])
 
 
-@pytest.mark.parametrize("hint", [0, 5000])
-def test_hashed_roles_split_the_groups_over_lds_tables(hint):
+@pytest.mark.parametrize("hint,qual", [(0, False), (5000, False), (5000, True)])
+def test_hashed_roles_split_the_groups_over_lds_tables(hint, qual):
     """5000 float8 keys: with the hint (or, without it, from the second chunk on,
     when the group count is known) the work-groups take hash roles so that a
-    role's groups fit its LDS table; the result must not depend on it"""
+    role's groups fit its LDS table; the result must not depend on it.  With roles the
+    check pass leaves a one-byte role map per row (rows the qual drops: no role) and the
+    roles scan that instead of the key column."""
     rng = np.random.default_rng(53)
     n = 400000
     key = rng.integers(0, 5000, n).astype(np.float64) * 0.25 - 300.0
     x = rng.integers(-1000, 1000, n).astype(np.int32)
     isn = rng.random(n) < 0.02
-    agg = GpuPreAgg("(gpupreagg (key (var 1 float8)) (nrows) (psum (int8 (var 2 int4))) (pmin (var 2 int4)))")
+    agg = GpuPreAgg("(gpupreagg " + ("(qual (int4gt (var 2 int4) (const int4 -600))) " if qual else "") +
+                    "(key (var 1 float8)) (nrows) (psum (int8 (var 2 int4))) (pmin (var 2 int4)))")
     agg.begin_hashed(ngroups_hint=hint)
     for i in range(2):
         sl = slice(i * n // 2, (i + 1) * n // 2)
@@ -661,6 +664,9 @@ def test_hashed_roles_split_the_groups_over_lds_tables(hint):
         assert agg.fold(buf)[0] == 0
     pr = agg.fetch()
     agg.end()
+    if qual:
+        keep = (~isn) & (x > -600)                  # a NULL x makes the qual NULL: row dropped
+        key, x, isn = key[keep], x[keep], isn[keep]
     uk, inv = np.unique(key, return_inverse=True)
     assert len(pr) == len(uk)
     k, _ = pr.column(0)
