@@ -108,9 +108,12 @@ struct Device {
 	size_t				inflight = 0;
 	/* requests that are a SEQUENCE of device steps with host decisions in between
 	 * (the per-chunk GpuPreAgg message: key range -> table geometry -> fold -> partial
-	 * rows) run on this thread, started on first use -- one of the reference's server
-	 * threads (opencl_serv.c:76-90); the submitter only queues */
-	std::thread			worker;
+	 * rows) run on these threads, started on first use -- the reference's server threads
+	 * (opencl_serv.c:76-90, one per CPU there); the submitter only queues.  Requests are
+	 * independent of each other (every message has a session of its own), so several
+	 * are in their host-side steps at once: one thread answered ~1500 messages a second
+	 * whatever was in flight (profiles/r02_chunk_message_probe.txt) */
+	std::vector<std::thread> workers;		/* STROM_HIP_NUM_WORKERS, default 4 */
 	std::mutex			wq_lock;
 	std::condition_variable wq_cond;
 	std::deque<std::function<void()>> wq;
