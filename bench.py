@@ -453,6 +453,43 @@ def operator_figures(args, k, c, measured_peak, cpu_blocks):
     del facts, fact
     torch.cuda.empty_cache()
 
+    # ---- the ROW-format variant of C2 ("for honesty"): heap pages, the
+    # format the reference ships -- the row-at-a-time kernel, and the device ingest + COLUMN scan
+    from pg_strom_amd.gpuscan import GpuScan, STROM_RESULTS_ON_DEVICE
+    nrow = 10_000_000
+    ra, rb = c2_columns(nrow, 0x5eed0012)
+    row_img = kds.build_kds("row", [kds.Column("int4", ra), kds.Column("float8", rb)])
+    row_bytes = len(row_img)
+    rds = runtime.DeviceStore.upload(row_img)
+    del row_img
+    nsel_row = int(np.count_nonzero((ra < k) & (rb > c)))
+    scan = GpuScan(C2_QUAL).begin(ext_params=[k, c])
+    gen_ns, col_ns, ing_ns = [], [], []
+    for _ in range(4):
+        res = scan.scan_chunk(rds, flags=STROM_RESULTS_ON_DEVICE)
+        assert res.nitems == nsel_row, "ROW scan: %d rows, expected %d" % (res.nitems, nsel_row)
+        gen_ns.append(res.perfmon["time_kern_exec_ns"])
+    for _ in range(3):
+        cds, ns = rds.to_column([23, 701])
+        ing_ns.append(ns)
+        res = scan.scan_chunk(cds, flags=STROM_RESULTS_ON_DEVICE)
+        assert res.nitems == nsel_row
+        col_ns.append(res.perfmon["time_kern_exec_ns"])
+        cds.release()
+    scan.end()
+    rds.release()
+    out["gpuscan_row_format"] = dict(
+        workload="the ROW-format variant of C2: %d rows as PostgreSQL heap pages (KDS_FORMAT_ROW, %.1f B/row in "
+                 "the chunk for 12 B referenced), resident; (1) the row-at-a-time kernel, (2) device ingest to "
+                 "COLUMN once, then the streaming kernel" % (nrow, row_bytes / nrow),
+        rows=nrow, chunk_bytes=row_bytes,
+        generic_kernel_us=float(np.median(gen_ns[1:])) * 1e-3,
+        ingest_us=float(np.median(ing_ns[1:])) * 1e-3,
+        column_kernel_us=float(np.median(col_ns[1:])) * 1e-3,
+        roofline=roofline_block("gpuscan_qual_generic", float(row_bytes) + 4.0 * nsel_row, gen_ns[1:], measured_peak),
+        roofline_ingest=roofline_block("ingest_to_column(+ingest_minmax)", float(row_bytes) + 12.0 * nrow,
+                                       ing_ns[1:], measured_peak))
+
     # ---- C5: TPC-H Q1-shaped scan + filter + group-by on numeric / date columns ----------
     q1rows = chunk_rows
     q1, q1cnt, q1sq = c5_chunk_device(q1rows, 0x5eed0005)

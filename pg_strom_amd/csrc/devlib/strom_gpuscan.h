@@ -148,7 +148,10 @@ gpuscan_stage_flush(STAGE &stage, kern_resultbuf *kresults, cl_uint fill)
  * order: (k, wave, lane, j).  Returns the number of entries appended; the
  * value is identical in every thread.
  */
-template <typename STAGE>
+/* LANE_ROWS: st[k][j] belongs to row tile_base + (k*4 + j)*BLOCK + tid instead -- consecutive
+ * lanes, consecutive rows (the row-at-a-time kernel: neighbouring lanes then walk neighbouring
+ * heap tuples) */
+template <bool LANE_ROWS = false, typename STAGE>
 STROM_DEVICE cl_uint
 gpuscan_stage_append(STAGE &stage, cl_uint fill,
 					 cl_uint tile_base, const int (&st)[GPUSCAN_QUADS][4])
@@ -193,7 +196,9 @@ gpuscan_stage_append(STAGE &stage, cl_uint fill,
 		{
 			if (st[k][j] != 0)
 			{
-				cl_int	rowid = (cl_int)(row0 + j + 1);
+				cl_int	rowid = (LANE_ROWS
+								 ? (cl_int)(tile_base + (k * 4 + j) * GPUSCAN_BLOCK + threadIdx.x + 1)
+								 : (cl_int)(row0 + j + 1));
 				stage.entries[pos++] = (st[k][j] > 0 ? rowid : -rowid);
 			}
 		}
@@ -374,11 +379,15 @@ gpuscan_qual_generic_body(kern_gpuscan *kgpuscan,
 #pragma unroll
 		for (int k = 0; k < GPUSCAN_QUADS; k++)
 		{
-			cl_uint	row0 = tile_base + (k * GPUSCAN_BLOCK + threadIdx.x) * 4;
 #pragma unroll
 			for (int j = 0; j < 4; j++)
 			{
-				cl_uint		r = row0 + j;
+				/*
+				 * consecutive lanes, consecutive rows: with a quad of rows per lane (the
+				 * streaming kernel's layout) a wave's 64 lanes reach for heap tuples 4 rows
+				 * apart -- 80 cache lines per load of a 40-byte-tuple table instead of 20
+				 */
+				cl_uint		r = tile_base + (k * 4 + j) * GPUSCAN_BLOCK + threadIdx.x;
 
 				st[k][j] = 0;
 				if (r < nrows)
@@ -407,11 +416,11 @@ gpuscan_qual_generic_body(kern_gpuscan *kgpuscan,
 		 * input order translated back to the chunk's row: patch below
 		 */
 		if (!use_map)
-			fill += gpuscan_stage_append(stage, fill, tile_base, st);
+			fill += gpuscan_stage_append<true>(stage, fill, tile_base, st);
 		else
 		{
 			cl_uint	before = fill;
-			cl_uint	n = gpuscan_stage_append(stage, fill, tile_base, st);
+			cl_uint	n = gpuscan_stage_append<true>(stage, fill, tile_base, st);
 			/* translate map positions -> chunk rows, in place */
 			for (cl_uint i = before + threadIdx.x; i < before + n; i += GPUSCAN_BLOCK)
 			{
