@@ -530,7 +530,8 @@ def operator_figures(args, k, c, measured_peak, cpu_blocks):
         value=q1rows / float(np.median(walls[1:])) / 1e6, unit="Mrows/s", groups=ngroups_q1, partial_rows=len(pr),
         table_slots=int(nslots),
         checked="groups, row counts and sum(quantity) equal torch's",
-        roofline=roofline_block("gpupreagg_priv_column", 38.0 * q1rows, kerns[1:], measured_peak))
+        roofline=roofline_block("gpupreagg_dense_column", 38.0 * q1rows, kerns[1:], measured_peak,
+                                traffic=load_traffic(chunk_rows, "gpupreagg_dense_column")))
     agg.end()
     q1.release()
     del q1
