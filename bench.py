@@ -683,8 +683,10 @@ def spawn_ranks(args):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    # (a step is 2.1 ms: 200 of them keep the GPU busy for 0.4 s, long enough for an outside
+    # utilisation sampler to see the timed region at all)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--rows", type=int, default=1_000_000_000, help="rows per GPU (north star: 1e9)")
     ap.add_argument("--chunk-rows", type=int, default=100_000_000)
     ap.add_argument("--agg-rows", type=int, default=1_000_000_000,
