@@ -166,6 +166,10 @@ struct oracle_expr {
 	struct oracle_expr **args;	/* N_CASE: cond0,res0,cond1,res1,...,[else] */
 	int			has_else;
 	struct oracle_expr *case_arg;	/* simple CASE subject */
+	/* N_VAR of a column stored as int8 at 10^-dscale ((var N decimal S), STROM_DECIMALOID):
+	 * its SQL value is the numeric, which is what the checker computes with */
+	int			is_decimal;
+	int			dscale;
 };
 
 typedef struct { const char *p; char *err; size_t errlen; int failed; } parser;
@@ -945,15 +949,26 @@ parse_expr(parser *ps)
 		if (!read_atom(ps, buf, sizeof(buf)))
 		{ perr(ps, "number expected"); goto fail; }
 		e->attno = atoi(buf);
-		if (!read_atom(ps, buf, sizeof(buf)) || !(e->type_oid = type_by_name(buf)))
+		if (!read_atom(ps, buf, sizeof(buf)))
+		{ perr(ps, "bad type"); goto fail; }
+		if (head[0] == 'v' && !strcmp(buf, "decimal"))
+		{
+			e->type_oid = STROM_NUMERICOID;
+			e->is_decimal = 1;
+		}
+		else if (!(e->type_oid = type_by_name(buf)))
 		{ perr(ps, "bad type"); goto fail; }
 		/* (var ATTNO numeric SCALE): the column's typmod scale -- a promise
 		 * the device emitter uses to pick fixed-point code; the value is the
-		 * same, so the checker ignores it */
+		 * same, so the checker ignores it.  (var ATTNO decimal SCALE): the scale
+		 * the stored integers are at */
 		if (head[0] == 'v' && !peek_close(ps))
 		{
 			if (!read_atom(ps, buf, sizeof(buf))) { perr(ps, "scale expected"); goto fail; }
+			e->dscale = atoi(buf);
 		}
+		if (e->is_decimal && (e->dscale < 0 || e->dscale > 18))
+		{ perr(ps, "(var N decimal SCALE): scale 0..18 expected"); goto fail; }
 	}
 	else if (!strcmp(head, "ivar"))
 	{
@@ -1588,6 +1603,17 @@ eval_node(const oracle_expr *e, const eval_ctx *cx, int32_t *errcode)
 					if (!oracle_numeric_from_varlena(addr, &image))
 						return recheck(e->type_oid, errcode);
 					return load_datum(e->type_oid, &image);
+				}
+				if (e->kind == N_VAR && e->is_decimal)
+				{
+					int64_t		v;
+					uint64_t	image;
+					if (!addr)
+						return make_null(STROM_NUMERICOID);
+					memcpy(&v, addr, 8);
+					if (!num_pack(-e->dscale, v < 0, v < 0 ? (uint64_t)0 - (uint64_t)v : (uint64_t)v, &image))
+						return recheck(STROM_NUMERICOID, errcode);
+					return load_datum(STROM_NUMERICOID, &image);
 				}
 				if (type_is_varlena(e->type_oid))
 				{

@@ -52,6 +52,8 @@ static const devtype_info devtype_catalog[] = {
 	{ STROM_TIMESTAMPOID, "timestamp", "timestamp", 8, DEVFUNC_NEEDS_TIMELIB },
 	{ STROM_NUMERICOID,   "numeric",   "numeric",   8, DEVFUNC_NEEDS_NUMERIC },
 	{ STROM_BPCHAROID,    "char1",     "char1",     1, 0 },
+	/* numeric(p,s) stored as int8 at 10^-s ("decimal64", COLUMN chunks): (var N decimal S) */
+	{ STROM_DECIMALOID,   "decimal",   "decimal",   8, DEVFUNC_NEEDS_NUMERIC },
 	/* varlena: a value is the address of its datum (strom_textlib.h); row formats only */
 	{ STROM_TEXTOID,      "text",      "text",     -1, DEVFUNC_NEEDS_TEXTLIB | DEVTYPE_IS_VARLENA },
 	{ STROM_BPCHARNOID,   "character", "bpcharn",  -1, DEVFUNC_NEEDS_TEXTLIB | DEVTYPE_IS_VARLENA },
@@ -830,6 +832,15 @@ emit_expr(const sexpr &n, codegen_context &ctx, std::string &out)
 		ctx.extra_flags |= t->type_flags;
 		snprintf(tmp, sizeof(tmp), "%s.%s_%d", ctx.var_struct.c_str(),
 				 ctx.var_label.c_str(), attno);
+		if (t->type_oid == STROM_DECIMALOID)
+		{
+			/* the column IS the fixed-point value: nothing to convert */
+			int		scale = ((nargs == 3 && !n.items[3].is_list) ? atoi(n.items[3].atom.c_str()) : -1);
+			if (scale < 0 || scale > 18)
+				codegen_error("(var ATTNO decimal SCALE): the scale 0..18 the column is stored at expected");
+			out += std::string("pg_fixed_from_decimal(") + tmp + ")";
+			return STROM_FIXED_BASE + scale;
+		}
 		if (nargs == 3)
 		{
 			/* typmod scale of a numeric column: fixed-point from here on */

@@ -607,6 +607,17 @@ pg_fixed_lit(cl_long value, pg_numeric_t asnumeric)
 	return pg_fixed_make(value, false);
 }
 
+/* a numeric(p,s) column stored as int8 at 10^-s (STROM_DECIMALOID, (var N decimal S)): the
+ * datum is the fixed-point value */
+STROM_DECLARE_SIMPLE_TYPE(decimal, cl_long)
+STROM_DECLARE_VARREF(decimal)
+
+STROM_DEVICE pg_fixed_t
+pg_fixed_from_decimal(pg_decimal_t arg)
+{
+	return pg_fixed_make(arg.value, arg.isnull);
+}
+
 STROM_DEVICE pg_fixed_t
 pg_fixed_recheck(cl_int *errcode)
 {

@@ -35,6 +35,9 @@ SQL_TYPES = {
     "time": (1083, 8, np.int64),
     "timestamp": (1114, 8, np.int64),
     "numeric": (1700, 8, np.uint64),   # 64-bit device form
+    # numeric(p,s) as int8 at 10^-s ("decimal64"; COLUMN chunks; IR: (var N decimal S)):
+    # 'values' are the scaled integers
+    "decimal": (0x10000 | 1700, 8, np.int64),
     # the same values laid out as PostgreSQL's varlena numeric inside heap
     # tuples (ROW / ROW_FLAT only); 'values' are the 64-bit images
     "numeric_varlena": (1700, -1, np.uint64),

@@ -1,0 +1,60 @@
+"""
+(var N decimal S) on the device (needs an MI355X: -m gpu): numeric(p,s) columns held as int8 at
+10^-s.  The same table in both encodings through GpuScan and GpuPreAgg: identical row sets,
+identical partial rows (integers: bit-exact), and both equal the oracle.
+"""
+import numpy as np
+import pytest
+
+import decimal_cases
+import oracle_binding as oracle
+from pg_strom_amd import kds, runtime
+from pg_strom_amd.gpupreagg import GpuPreAgg
+from test_gpuscan_gpu import check
+from test_gpupreagg_gpu import partial_rows_as_raw8
+
+pytestmark = pytest.mark.gpu
+
+
+def test_scan_quals_over_both_encodings():
+    num, dec = decimal_cases.tables(50003, 11)
+    bn, bd = kds.build_kds("column", num), kds.build_kds("column", dec)
+    for q in decimal_cases.SCAN_QUALS:
+        rn = check(q.replace("{T}", "numeric"), bn)
+        rd = check(q.replace("{T}", "decimal"), bd)            # (check: HIP == oracle)
+        assert np.array_equal(np.sort(rn.results[:rn.nitems]), np.sort(rd.results[:rd.nitems])), q
+
+
+@pytest.mark.parametrize("resident", [False, True])
+def test_preagg_partial_rows_are_identical_over_both_encodings(resident):
+    num, dec = decimal_cases.tables(120007, 12)
+    bn, bd = kds.build_kds("column", num), kds.build_kds("column", dec)
+    for sn, sd in decimal_cases.specs():
+        rows = []
+        for spec, buf in ((sn, bn), (sd, bd)):
+            agg = GpuPreAgg(spec).begin([(0, 7)])
+            ds = runtime.DeviceStore.upload(buf) if resident else None
+            try:
+                assert agg.fold(ds if resident else buf)[0] == 0
+                v, n = partial_rows_as_raw8(agg.fetch())
+            finally:
+                agg.end()
+                if ds is not None:
+                    ds.release()
+            o = np.argsort(v[:, 0])
+            rows.append((v[o], n[o]))
+        assert np.array_equal(rows[0][0], rows[1][0]) and np.array_equal(rows[0][1], rows[1][1])
+        # and the oracle over the numeric-image form: its scaled partials are int8 at 10^-scale,
+        # the device's fetched rows carry them as numerics (tests/test_numeric_gpu.py)
+        from decimal import Decimal
+        rc, ov, on = oracle.gpupreagg(sn, bn, rows[0][0].shape[1])
+        oo = np.argsort(ov[:, 0])
+        assert rc == 0 and np.array_equal(on[oo], rows[0][1])
+        scales = [None, None, None, 0, 2, 4, 2, 4, 4]
+        for t, sc in enumerate(scales):
+            a, b, isn = ov[oo][:, t], rows[0][0][:, t], rows[0][1][:, t]
+            if sc is None:
+                assert np.array_equal(a, b), t
+                continue
+            for i in np.flatnonzero(~isn):
+                assert kds.numeric_decode(b[i]) == Decimal(int(a[i].view(np.int64))).scaleb(-sc), (t, i)
