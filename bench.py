@@ -157,7 +157,7 @@ def numeric_images_device(v, scale):
     return torch.where(mant == 0, torch.zeros_like(img), img)
 
 
-def c5_chunk_device(nrows, seed):
+def c5_chunk_device(nrows, seed, decimal=True):
     """TPC-H Q1-shaped lineitem columns: returnflag, linestatus as
     char(1), quantity / extendedprice / discount / tax as 8-byte numerics, shipdate; returns
     (resident chunk, per-group row counts and quantity sums of the rows the date filter keeps)"""
@@ -170,27 +170,38 @@ def c5_chunk_device(nrows, seed):
     rf = torch.tensor([65, 78, 82], dtype=torch.int8, device="cuda")[rnd(0, 3)]
     ls = torch.tensor([70, 79], dtype=torch.int8, device="cuda")[rnd(0, 2)]
     qty = rnd(1, 51)
-    cols = [rf, ls, numeric_images_device(qty, 0), numeric_images_device(rnd(90000, 10494951), 2),
-            numeric_images_device(rnd(0, 11), 2), numeric_images_device(rnd(0, 9), 2)]
+    prc, dsc, tax = rnd(90000, 10494951), rnd(0, 11), rnd(0, 9)
+    if decimal:
+        # numeric(p,s) held as int8 at 10^-s ("8-byte fixed-scale numerics")
+        cols, ntype = [rf, ls, qty, prc, dsc, tax], "decimal"
+    else:
+        # the reference's 64-bit float-decimal images (opencl_numeric.h:122-160)
+        cols, ntype = [rf, ls, numeric_images_device(qty, 0), numeric_images_device(prc, 2),
+                       numeric_images_device(dsc, 2), numeric_images_device(tax, 2)], "numeric"
     ship = rnd(-2922, -2922 + 2526, torch.int32)
     cutoff = -486                                   # date '1998-09-02' in days since 2000-01-01
     keep = ship <= cutoff
     gid = ((rf.long() - 65) * 16 + (ls.long() - 70))[keep]
     cnt = torch.bincount(gid, minlength=18 * 16)
     sq = torch.zeros(18 * 16, dtype=torch.int64, device="cuda").index_add_(0, gid, qty[keep])
-    ds = runtime.DeviceStore.from_torch_columns(["char1", "char1", "numeric", "numeric", "numeric", "numeric", "date"],
+    ds = runtime.DeviceStore.from_torch_columns(["char1", "char1", ntype, ntype, ntype, ntype, "date"],
                                                 cols + [ship])
     return ds, cnt.cpu().numpy(), sq.cpu().numpy()
 
 
-Q1_AGG = ("(gpupreagg (qual (date_le (var 7 date) (const date '1998-09-02')))"
-          " (key (var 1 char1)) (key (var 2 char1))"
-          " (psum (var 3 numeric 0) 0) (psum (var 4 numeric 2) 2)"
-          " (psum (numeric_mul (var 4 numeric 2) (numeric_sub (const numeric 1) (var 5 numeric 2))) 4)"
-          " (psum (numeric_mul (numeric_mul (var 4 numeric 2) (numeric_sub (const numeric 1) (var 5 numeric 2)))"
-          " (numeric_add (const numeric 1) (var 6 numeric 2))) 6)"
-          " (nrows (isnotnull (var 3 numeric 0))) (nrows (isnotnull (var 4 numeric 2)))"
-          " (psum (var 5 numeric 2) 2) (nrows (isnotnull (var 5 numeric 2))) (nrows))")
+def q1_agg(T):
+    return ("(gpupreagg (qual (date_le (var 7 date) (const date '1998-09-02')))"
+            " (key (var 1 char1)) (key (var 2 char1))"
+            " (psum (var 3 {T} 0) 0) (psum (var 4 {T} 2) 2)"
+            " (psum (numeric_mul (var 4 {T} 2) (numeric_sub (const numeric 1) (var 5 {T} 2))) 4)"
+            " (psum (numeric_mul (numeric_mul (var 4 {T} 2) (numeric_sub (const numeric 1) (var 5 {T} 2)))"
+            " (numeric_add (const numeric 1) (var 6 {T} 2))) 6)"
+            " (nrows (isnotnull (var 3 {T} 0))) (nrows (isnotnull (var 4 {T} 2)))"
+            " (psum (var 5 {T} 2) 2) (nrows (isnotnull (var 5 {T} 2))) (nrows))").replace("{T}", T)
+
+
+Q1_AGG = q1_agg("decimal")              # the columns as int8 at their typmod scale
+Q1_AGG_NUMERIC = q1_agg("numeric")      # the same query over 64-bit numeric images
 
 T_START = time.perf_counter()
 
@@ -491,51 +502,55 @@ def operator_figures(args, k, c, measured_peak, cpu_blocks):
                                        ing_ns[1:], measured_peak))
 
     # ---- C5: TPC-H Q1-shaped scan + filter + group-by on numeric / date columns ----------
+    # twice: the numeric(p,s) columns as int8 at their scale (decimal columns: what the device
+    # ingest makes of typmod-scaled numerics), and as the reference's 64-bit numeric images
     q1rows = chunk_rows
-    q1, q1cnt, q1sq = c5_chunk_device(q1rows, 0x5eed0005)
-    agg = GpuPreAgg(Q1_AGG).begin([(65, 18), (70, 10)])
-    agg.census(q1)
-    nslots = agg.compact()
-    walls, kerns = [], []
-    for step in range(6):
-        agg.reset()
-        t0 = time.perf_counter()
-        st, pfm = agg.fold(q1)
-        walls.append(time.perf_counter() - t0)
-        assert st == 0, "Q1 fold status %d" % st
-        kerns.append(pfm["time_kern_exec_ns"] - pfm["time_kern_proj_ns"])
-    pr = agg.fetch()
-    # one partial row per group -- plus extra rows for sums that outgrow the 57-bit numeric
-    # mantissa (sum(charge) at scale 6 over 1e8 rows does): the final aggregate adds them up
-    k1, k2 = pr.column(0)[0].astype(np.int64), pr.column(1)[0].astype(np.int64)
-    gids = (k1 - 65) * 16 + (k2 - 70)
-    ugid = np.unique(gids)
-    assert np.array_equal(ugid, np.flatnonzero(q1cnt)), \
-        "Q1: groups differ: %s vs %s" % (ugid.tolist(), np.flatnonzero(q1cnt).tolist())
-    got_cnt = np.zeros(18 * 16, dtype=np.int64)
-    np.add.at(got_cnt, gids, pr.column(10)[0].astype(np.int64))
-    assert np.array_equal(got_cnt, q1cnt), "Q1: row counts differ"
-    # sum(quantity) comes back as a numeric in the 64-bit device form: mantissa x 10^exponent
-    img, inull = pr.column(2)
-    img = img.astype(np.uint64)
-    q1sum = (img & np.uint64((1 << 57) - 1)).astype(np.int64) * 10 ** np.maximum(img.view(np.int64) >> 58, 0)
-    got_sq = np.zeros(18 * 16, dtype=np.int64)
-    np.add.at(got_sq, gids[~inull], q1sum[~inull])
-    assert np.array_equal(got_sq, q1sq), "Q1: sum(quantity) differs"
-    ngroups_q1 = len(ugid)
-    out["q1_shape_c5"] = dict(
-        workload="TPC-H Q1-shaped GpuPreAgg (BASELINE configs[4], one GPU's share): %d lineitem-like rows, "
-                 "WHERE shipdate <= date, GROUP BY returnflag, linestatus (%d groups), 9 partial aggregates over "
-                 "4 numeric(*,2) columns as 8-byte numerics (38 B/row)" % (q1rows, ngroups_q1),
-        value=q1rows / float(np.median(walls[1:])) / 1e6, unit="Mrows/s", groups=ngroups_q1, partial_rows=len(pr),
-        table_slots=int(nslots),
-        checked="groups, row counts and sum(quantity) equal torch's",
-        roofline=roofline_block("gpupreagg_dense_column", 38.0 * q1rows, kerns[1:], measured_peak,
-                                traffic=load_traffic(chunk_rows, "gpupreagg_dense_column")))
-    agg.end()
-    q1.release()
-    del q1
-    torch.cuda.empty_cache()
+    for label, decimal, spec in (("q1_shape_c5", True, Q1_AGG), ("q1_shape_c5_numeric_images", False, Q1_AGG_NUMERIC)):
+        q1, q1cnt, q1sq = c5_chunk_device(q1rows, 0x5eed0005, decimal)
+        agg = GpuPreAgg(spec).begin([(65, 18), (70, 10)])
+        agg.census(q1)
+        nslots = agg.compact()
+        walls, kerns = [], []
+        for step in range(6):
+            agg.reset()
+            t0 = time.perf_counter()
+            st, pfm = agg.fold(q1)
+            walls.append(time.perf_counter() - t0)
+            assert st == 0, "Q1 fold status %d" % st
+            kerns.append(pfm["time_kern_exec_ns"] - pfm["time_kern_proj_ns"])
+        pr = agg.fetch()
+        # one partial row per group -- plus extra rows for sums that outgrow the 57-bit numeric
+        # mantissa (sum(charge) at scale 6 over 1e8 rows does): the final aggregate adds them up
+        k1, k2 = pr.column(0)[0].astype(np.int64), pr.column(1)[0].astype(np.int64)
+        gids = (k1 - 65) * 16 + (k2 - 70)
+        ugid = np.unique(gids)
+        assert np.array_equal(ugid, np.flatnonzero(q1cnt)), \
+            "Q1: groups differ: %s vs %s" % (ugid.tolist(), np.flatnonzero(q1cnt).tolist())
+        got_cnt = np.zeros(18 * 16, dtype=np.int64)
+        np.add.at(got_cnt, gids, pr.column(10)[0].astype(np.int64))
+        assert np.array_equal(got_cnt, q1cnt), "Q1: row counts differ"
+        # sum(quantity) comes back as a numeric in the 64-bit device form: mantissa x 10^exponent
+        img, inull = pr.column(2)
+        img = img.astype(np.uint64)
+        q1sum = (img & np.uint64((1 << 57) - 1)).astype(np.int64) * 10 ** np.maximum(img.view(np.int64) >> 58, 0)
+        got_sq = np.zeros(18 * 16, dtype=np.int64)
+        np.add.at(got_sq, gids[~inull], q1sum[~inull])
+        assert np.array_equal(got_sq, q1sq), "Q1: sum(quantity) differs"
+        out[label] = dict(
+            workload="TPC-H Q1-shaped GpuPreAgg (BASELINE configs[4], one GPU's share): %d lineitem-like rows, "
+                     "WHERE shipdate <= date, GROUP BY returnflag, linestatus (%d groups), 9 partial aggregates "
+                     "over 4 numeric(*,2) columns held as %s (38 B/row)"
+                     % (q1rows, len(ugid), "int8 at their scale (decimal columns)" if decimal
+                        else "64-bit numeric images (the reference's device form)"),
+            value=q1rows / float(np.median(walls[1:])) / 1e6, unit="Mrows/s", groups=len(ugid),
+            partial_rows=len(pr), table_slots=int(nslots),
+            checked="groups, row counts and sum(quantity) equal torch's",
+            roofline=roofline_block("gpupreagg_dense_column", 38.0 * q1rows, kerns[1:], measured_peak,
+                                    traffic=load_traffic(chunk_rows, "gpupreagg_dense_column")))
+        agg.end()
+        q1.release()
+        del q1
+        torch.cuda.empty_cache()
 
     return out
 

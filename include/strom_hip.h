@@ -145,6 +145,11 @@ int			strom_dstore_download(strom_dstore *ds, void *host, size_t length);
  * reference has no need for because its kernels walk heap tuples
  * (kern_get_datum_rs, opencl_common.h:886-907).  'type_oids' (ncols
  * entries, may be NULL) enables the zone maps GpuPreAgg / GpuHashJoin use.
+ * A numeric column tagged STROM_NUMERICOID becomes the 8-byte device form;
+ * tagged STROM_DECIMAL_TYPE(scale) -- a typmod-scaled numeric(p,s) -- it
+ * becomes a DECIMAL column, int8 at 10^-scale, which programs read as
+ * (var N decimal S) without any per-row decode (exact, or the whole
+ * conversion answers StromError_CpuReCheck and the chunk stays as it is).
  * Blocks until the chunk is ready; *p_kern_ns receives the device time.
  */
 strom_dstore *strom_dstore_to_column(strom_dstore *src, const int32_t *type_oids, int ntypes,

@@ -385,5 +385,9 @@ typedef struct {
  * arithmetic from the first instruction instead of decoding the 64-bit float-decimal image
  * per row (TPC-H Q1 shape: 1.44 -> 0.83 ms per 1e8 rows). */
 #define STROM_DECIMALOID	(0x10000 | 1700)
+/* strom_dstore_to_column(): "turn this numeric column into a decimal column at SCALE" */
+#define STROM_DECIMAL_TYPE(scale)		(STROM_DECIMALOID | ((scale) << 20))
+#define STROM_TYPE_IS_DECIMAL(oid)		(((oid) & 0xfffff) == STROM_DECIMALOID)
+#define STROM_DECIMAL_TYPE_SCALE(oid)	(((oid) >> 20) & 0x3f)
 
 #endif	/* STROM_KDS_H */

@@ -105,7 +105,9 @@ ingest_to_column_body(const kern_data_store *__restrict__ src, kern_data_store *
 			}
 			/* a varlena NUMERIC becomes the 8-byte device form (canonical
 			 * image); one that does not fit fails the whole conversion */
-			if (VARNUM && cm.attlen < 0 && type_oids != NULL && type_oids[c] == STROM_NUMERICOID)
+			const cl_int oid_c = ((VARNUM && type_oids != NULL) ? type_oids[c] : 0);
+			const bool	to_decimal = (VARNUM && STROM_TYPE_IS_DECIMAL(oid_c));
+			if (VARNUM && ((cm.attlen < 0 && oid_c == STROM_NUMERICOID) || to_decimal))
 			{
 				if (valid)
 				{
@@ -114,18 +116,42 @@ ingest_to_column_body(const kern_data_store *__restrict__ src, kern_data_store *
 					if (addr)
 					{
 						cl_int		e = StromError_Success;
-						pg_numeric_t nv = pgfn_numeric_normalize(&e, strom_numeric_from_varlena(&e, addr));
-						if (nv.isnull)
-							s_failed = 1;
+						pg_numeric_t nv;
+						if (cm.attlen < 0)
+							nv = strom_numeric_from_varlena(&e, addr);
 						else
-							image = nv.value;
+						{
+							nv.isnull = false;
+							nv.value = strom_fetch<cl_ulong>(addr);		/* the 64-bit device form */
+						}
+						if (to_decimal)
+						{
+							/* numeric(p,s) -> int8 at 10^-s, exactly; a value that is finer than
+							 * the scale or beyond 57 bits fails the whole conversion */
+							pg_int8_t fx = strom_numeric_to_fixed(&e, nv, STROM_DECIMAL_TYPE_SCALE(oid_c));
+							cl_long	mag = (fx.value < 0 ? -fx.value : fx.value);
+							if (nv.isnull || fx.isnull || e != StromError_Success || mag >= (1L << 57))
+								s_failed = 1;
+							else
+								image = (cl_ulong)fx.value;
+						}
+						else
+						{
+							nv = pgfn_numeric_normalize(&e, nv);
+							if (nv.isnull)
+								s_failed = 1;
+							else
+								image = nv.value;
+						}
 					}
 					*out = image;
 				}
 			}
 			/* value */
 			cl_long		v = 0;
-			if (addr && cm.attlen > 0 && cm.attlen <= 8)
+			if (to_decimal)
+				;						/* stored above */
+			else if (addr && cm.attlen > 0 && cm.attlen <= 8)
 			{
 				char *out = (char *)dst + s_values_off[c] + (size_t)cm.attlen * row;
 				switch (cm.attlen)

@@ -71,7 +71,7 @@ strom_dstore_to_column(strom_dstore *src, const int32_t *type_oids, int ntypes,
 	/* the decoder for varlena NUMERIC columns rides only when one is there */
 	bool	varnum = false;
 	for (int i = 0; type_oids && i < ncols; i++)
-		varnum = varnum || (type_oids[i] == STROM_NUMERICOID);
+		varnum = varnum || (type_oids[i] == STROM_NUMERICOID) || STROM_TYPE_IS_DECIMAL(type_oids[i]);
 	hipFunction_t fn_main = prog->get_function(dev, varnum ? "ingest_to_column_varnum" : "ingest_to_column",
 											   &errcode);
 	hipFunction_t fn_fin = fn_main ? prog->get_function(dev, "ingest_finish", &errcode) : nullptr;
@@ -96,7 +96,13 @@ strom_dstore_to_column(strom_dstore *src, const int32_t *type_oids, int ntypes,
 	for (int i = 0; i < ncols; i++)
 	{
 		int attlen = head->colmeta[i].attlen;
-		if (attlen == -1 && type_oids && type_oids[i] == STROM_NUMERICOID)
+		if (type_oids && STROM_TYPE_IS_DECIMAL(type_oids[i]) && !(attlen == -1 || attlen == 8))
+		{
+			*p_errcode = StromError_BadRequestMessage;		/* not a numeric column */
+			return nullptr;
+		}
+		if (attlen == -1 && type_oids &&
+			(type_oids[i] == STROM_NUMERICOID || STROM_TYPE_IS_DECIMAL(type_oids[i])))
 		{
 			/* PostgreSQL's varlena numeric -> the 8-byte by-value device form
 			 * (what the reference does to colmeta, datastore.c:355-363) */

@@ -247,6 +247,12 @@ def numeric_encode(value):
     return ((exp & 0x3f) << 58) | (sign << 57) | mant
 
 
+def decimal_type(scale):
+    """type tag for strom_dstore_to_column(): turn this numeric column into a decimal column
+    (int8 at 10^-scale) -- STROM_DECIMAL_TYPE(scale) of strom_kds.h"""
+    return (0x10000 | 1700) | (int(scale) << 20)
+
+
 def numeric_decode(image):
     """uint64 image -> Decimal"""
     from decimal import Decimal

@@ -58,3 +58,50 @@ def test_preagg_partial_rows_are_identical_over_both_encodings(resident):
                 continue
             for i in np.flatnonzero(~isn):
                 assert kds.numeric_decode(b[i]) == Decimal(int(a[i].view(np.int64))).scaleb(-sc), (t, i)
+
+
+@pytest.mark.parametrize("fmt,coltype", [("row", "numeric_varlena"), ("row_flat", "numeric_varlena"),
+                                         ("tupslot", "numeric")])
+def test_ingest_turns_numeric_columns_into_decimal_columns(fmt, coltype):
+    """strom_dstore_to_column with STROM_DECIMAL_TYPE(scale): heap numerics (varlena) and 8-byte
+    numeric images become int8 at 10^-scale, exactly; the decimal program over the result gives
+    the numeric program's partial rows"""
+    n = 30011
+    num, dec = decimal_cases.tables(n, 21)
+    src_cols = [num[0]] + [kds.Column(coltype, c.values, c.isnull) for c in num[1:]]
+    src = runtime.DeviceStore.upload(kds.build_kds(fmt, src_cols))
+    col, _ = src.to_column([23, kds.decimal_type(0), kds.decimal_type(2), kds.decimal_type(2), kds.decimal_type(4)])
+    try:
+        img = col.download()
+        head = kds.KdsHead(img)
+        assert head.format == 4 and head.nitems == n
+        sn, sd = decimal_cases.specs()[0]
+        rows = []
+        for spec, chunk in ((sd, col), (sn, kds.build_kds("column", num))):
+            agg = GpuPreAgg(spec).begin([(0, 7)])
+            try:
+                assert agg.fold(chunk)[0] == 0
+                v, nn = partial_rows_as_raw8(agg.fetch())
+            finally:
+                agg.end()
+            o = np.argsort(v[:, 0])
+            rows.append((v[o], nn[o]))
+        assert np.array_equal(rows[0][0], rows[1][0]) and np.array_equal(rows[0][1], rows[1][1])
+    finally:
+        col.release()
+        src.release()
+
+
+def test_ingest_refuses_a_scale_the_values_do_not_fit():
+    """1.234 is not a numeric(*,2): the conversion fails as a whole (CpuReCheck), the chunk stays
+    in its row format"""
+    vals = kds.numeric_from_scaled(np.array([100, 1234, 5], dtype=np.int64), 3)
+    src = runtime.DeviceStore.upload(kds.build_kds("row", [kds.Column("numeric_varlena", vals.values)]))
+    try:
+        with pytest.raises(runtime.StromError) as ei:
+            src.to_column([kds.decimal_type(2)])
+        assert ei.value.errcode == 2
+        col, _ = src.to_column([kds.decimal_type(3)])
+        col.release()
+    finally:
+        src.release()
