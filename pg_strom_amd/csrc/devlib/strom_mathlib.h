@@ -339,13 +339,25 @@ STROM_DEVICE int strom_float_cmp(double x, double y)
 {
 	return devfunc_float_comp(x, y);
 }
+/*
+ * The six comparisons written out for the same order (NaN above everything, NaN = NaN):
+ * two IEEE compares each -- an unordered-aware one and an "is it a number" test -- instead
+ * of the three-way compare's four and its selects.  x > y: x is NaN and y is not, or both are
+ * numbers and x > y  ==  !(x <= y) && y == y.
+ */
+STROM_DEVICE bool strom_float_gt(double x, double y) { return !(x <= y) & !__builtin_isnan(y); }
+STROM_DEVICE bool strom_float_lt(double x, double y) { return !(x >= y) & !__builtin_isnan(x); }
+STROM_DEVICE bool strom_float_ge(double x, double y) { return !strom_float_lt(x, y); }
+STROM_DEVICE bool strom_float_le(double x, double y) { return !strom_float_gt(x, y); }
+STROM_DEVICE bool strom_float_eq(double x, double y) { return (x == y) | (__builtin_isnan(x) & __builtin_isnan(y)); }
+STROM_DEVICE bool strom_float_ne(double x, double y) { return !strom_float_eq(x, y); }
 #define STROM_FLOAT_COMPARE_FAMILY(pfx,x_type,y_type)										\
-	STROM_SIMPLE_BINARY(pfx##eq, bool, x_type, y_type, strom_float_cmp(x, y) == 0)			\
-	STROM_SIMPLE_BINARY(pfx##ne, bool, x_type, y_type, strom_float_cmp(x, y) != 0)			\
-	STROM_SIMPLE_BINARY(pfx##lt, bool, x_type, y_type, strom_float_cmp(x, y) <  0)			\
-	STROM_SIMPLE_BINARY(pfx##le, bool, x_type, y_type, strom_float_cmp(x, y) <= 0)			\
-	STROM_SIMPLE_BINARY(pfx##gt, bool, x_type, y_type, strom_float_cmp(x, y) >  0)			\
-	STROM_SIMPLE_BINARY(pfx##ge, bool, x_type, y_type, strom_float_cmp(x, y) >= 0)
+	STROM_SIMPLE_BINARY(pfx##eq, bool, x_type, y_type, strom_float_eq(x, y))				\
+	STROM_SIMPLE_BINARY(pfx##ne, bool, x_type, y_type, strom_float_ne(x, y))				\
+	STROM_SIMPLE_BINARY(pfx##lt, bool, x_type, y_type, strom_float_lt(x, y))				\
+	STROM_SIMPLE_BINARY(pfx##le, bool, x_type, y_type, strom_float_le(x, y))				\
+	STROM_SIMPLE_BINARY(pfx##gt, bool, x_type, y_type, strom_float_gt(x, y))				\
+	STROM_SIMPLE_BINARY(pfx##ge, bool, x_type, y_type, strom_float_ge(x, y))
 STROM_FLOAT_COMPARE_FAMILY(float4,  float4, float4)
 STROM_FLOAT_COMPARE_FAMILY(float48, float4, float8)
 STROM_FLOAT_COMPARE_FAMILY(float84, float8, float4)
