@@ -768,7 +768,7 @@ emit_expr(const sexpr &n, codegen_context &ctx, std::string &out)
 		}
 		else
 			literal_to_datum(t, n.items[2].atom, &d);
-		ctx.extra_flags |= t->type_flags;
+		ctx.extra_flags |= (t->type_flags & ~DEVTYPE_IS_VARLENA);	/* (only a chunk COLUMN of that type binds the chunk format) */
 		snprintf(tmp, sizeof(tmp), "KP.KPARAM_%d", ctx.track_param(d));
 		if (t->type_oid == STROM_NUMERICOID && !d.isnull)
 		{
@@ -815,7 +815,7 @@ emit_expr(const sexpr &n, codegen_context &ctx, std::string &out)
 		d.length = t->type_length;
 		if (d.param_id < 0)
 			codegen_error("negative parameter number");
-		ctx.extra_flags |= t->type_flags;
+		ctx.extra_flags |= (t->type_flags & ~DEVTYPE_IS_VARLENA);	/* (only a chunk COLUMN of that type binds the chunk format) */
 		snprintf(tmp, sizeof(tmp), "KP.KPARAM_%d", ctx.track_param(d));
 		out += tmp;
 		return t->type_oid;
@@ -874,7 +874,7 @@ emit_expr(const sexpr &n, codegen_context &ctx, std::string &out)
 			}
 		if (!known)
 			ctx.used_ivars.push_back({depth, attno, t->type_oid});
-		ctx.extra_flags |= t->type_flags;
+		ctx.extra_flags |= (t->type_flags & ~DEVTYPE_IS_VARLENA);	/* (only a chunk COLUMN of that type binds the chunk format) */
 		snprintf(tmp, sizeof(tmp), "IVAR_%d_%d", depth, attno);
 		out += tmp;
 		return t->type_oid;

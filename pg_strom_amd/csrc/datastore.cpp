@@ -814,6 +814,11 @@ row_image_init(row_image &ri, const kern_data_store *kds)
 		ri.cols[i].attbyval = kds->colmeta[i].attbyval;
 		ri.cols[i].values = &ri.values[i];
 		ri.cols[i].isnull = &ri.nulls[i];
+		/* a varlena column (text, character(n), heap-form numeric): values[i] holds the
+		 * ADDRESS of the row's datum, which goes into the entry's tuple verbatim -- the
+		 * reference copies whole inner heap tuples (gpuhashjoin.c:3717-3805) */
+		if (kds->colmeta[i].attlen < 0)
+			ri.cols[i].attalign = -1;
 	}
 }
 
@@ -825,7 +830,9 @@ row_image_load(row_image &ri, const kern_data_store *kds, uint32_t row)
 		const char *p = host_get_datum(kds, row, i);
 		ri.nulls[i] = (p == nullptr);
 		ri.values[i] = 0;
-		if (p)
+		if (p && kds->colmeta[i].attlen < 0)
+			ri.values[i] = (uint64_t)(uintptr_t)p;
+		else if (p)
 			memcpy(&ri.values[i], p, kds->colmeta[i].attlen);
 	}
 }
@@ -861,7 +868,17 @@ strom_multihash_required_length(int ntables, const strom_hashtable_input *tables
 		for (uint32_t c = 0; c < kds->ncols; c++)
 		{
 			int l = kds->colmeta[c].attlen;
+			/* varlena columns: heap formats only (that is where their datums are) */
+			if (l == -1 && (kds->format == KDS_FORMAT_ROW || kds->format == KDS_FORMAT_ROW_FLAT))
+				continue;
 			if (!(l == 1 || l == 2 || l == 4 || l == 8))
+				return 0;
+		}
+		for (int k = 0; k < tables[t].nkeys; k++)
+		{
+			/* hash keys are fixed-width here (the emitter has no varlena hash key either) */
+			int col = tables[t].key_attnos[k] - 1;
+			if (col >= 0 && col < (int)kds->ncols && kds->colmeta[col].attlen < 0)
 				return 0;
 		}
 		len += hashtable_head_length(kds->ncols, hashtable_nslots(kds->nitems));

@@ -72,3 +72,25 @@ def test_codegen_refuses_text_where_the_device_cannot_hold_it():
     # a qual over text inside an aggregate is fine
     cg = codegen_gpupreagg("(gpupreagg (qual (texteq (var 2 text) (const text 'MAIL'))) (key (var 1 int4)) (nrows))")
     assert "pgfn_texteq" in cg.source
+
+
+def test_multihash_entries_carry_varlena_inner_columns():
+    """the inner side of a join may have text / character(n) columns: the builder copies the
+    datum into the entry's heap tuple verbatim (the reference copies whole inner tuples,
+    gpuhashjoin.c:3717-3805); hash keys stay fixed-width"""
+    from pg_strom_amd.gpuhashjoin import build_multihash
+    words = [text_cases.WORDS[i % len(text_cases.WORDS)] for i in range(300)]
+    pk = np.arange(300, dtype=np.int32)
+    inner = kds.build_kds("row", [kds.Column("int4", pk), kds.Column("text", words, np.arange(300) % 11 == 5),
+                                  kds.Column("int2", (pk % 5).astype(np.int16))])
+    km = build_multihash([(inner, [1])])
+    assert oracle.check_hashtable(km, 1, inner, [1], [4]) == 300
+    outer = kds.build_kds("column", [kds.Column("int4", np.arange(-20, 400, dtype=np.int32))])
+    spec = ("(gpuhashjoin (rel (hashkey (var 1 int4) 1 int4)"
+            " (qual (and (text_ge (ivar 1 2 text) (const text 'a')) (int2ne (ivar 1 3 int2) (const int2 0))))))")
+    rc, n, recs = oracle.gpuhashjoin(spec, outer, [inner])
+    want = [i for i in range(300) if i % 11 != 5 and words[i] >= b"a" and i % 5 != 0]
+    assert rc == 0 and n == len(want) and sorted(recs[:, 1].tolist()) == want
+    # a varlena hash key is refused by the builder
+    with pytest.raises(Exception):
+        build_multihash([(inner, [2])])

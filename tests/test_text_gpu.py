@@ -158,3 +158,39 @@ def test_join_projection_into_heap_tuples(ofmt):
     # head bookkeeping: nitems, usage inside the buffer
     u32 = dest[:48].view(np.uint32)
     assert u32[5] == nitems and 0 < u32[3] < len(dest)
+
+
+def test_inner_text_columns_in_join_quals_and_in_projected_tuples():
+    """a dimension with a text column: the multihash entries carry the datum, a residual qual
+    compares it on the device, and the ROW_FLAT projection copies it into the joined tuples"""
+    from pg_strom_amd.gpuhashjoin import GpuHashJoin, build_multihash, entry_rowids
+    nd, n = 400, 20000
+    rng = np.random.default_rng(9)
+    words = [text_cases.WORDS[i % len(text_cases.WORDS)] for i in range(nd)]
+    wnull = np.arange(nd) % 13 == 4
+    pk = rng.permutation(nd).astype(np.int32)
+    inner = kds.build_kds("row_flat", [kds.Column("int4", pk), kds.Column("text", words, wnull),
+                                       kds.Column("int2", (pk % 5).astype(np.int16))])
+    fk = rng.integers(-10, nd + 50, n).astype(np.int32)
+    outer = kds.build_kds("column", [kds.Column("int4", fk), kds.Column("int8", np.arange(n, dtype=np.int64))])
+    spec = ("(gpuhashjoin (rel (hashkey (var 1 int4) 1 int4)"
+            " (qual (or (text_lt (ivar 1 2 text) (const text 'b')) (isnull (ivar 1 2 text))))))")
+    res, _ = run_and_compare(spec, outer, [inner], [[1]])          # HIP == oracle
+    pos = np.full(nd + 60, -1, dtype=np.int64)
+    pos[pk] = np.arange(nd)
+    di = np.where((fk >= 0) & (fk < nd), pos[np.clip(fk, 0, nd + 59)], -1)
+    want = sum(1 for d in di if d >= 0 and (wnull[d] or words[d] < b"b"))
+    assert res.nitems == want
+    # and the joined rows as heap tuples: outer int8, inner text, inner int2
+    join = GpuHashJoin(spec).begin(build_multihash([(inner, [1])]))
+    try:
+        nitems, dest, recs = join.join_chunk_project_rows(outer, [(0, 2, "int8"), (1, 2, "text"), (1, 3, "int2")])
+        dkm = join.device_kmhash()
+    finally:
+        join.end()
+    assert nitems == want
+    rows = _walk_row_flat(dest, nitems, 3)
+    irow = entry_rowids(dkm, 1, recs[:, 1])
+    for i in range(nitems):
+        o, d = int(recs[i, 0]) - 1, int(irow[i])
+        assert rows[i] == [np.int64(o).tobytes(), None if wnull[d] else words[d], np.int16(pk[d] % 5).tobytes()], i
