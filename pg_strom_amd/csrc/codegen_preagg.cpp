@@ -203,8 +203,28 @@ strom_codegen_gpupreagg(const char *spec, strom_codegen_result *out,
 					char sb[16];
 					snprintf(sb, sizeof(sb), "%d", tg.scale);
 					if (fixed_scale >= 0)
+					{
 						tg.body = "  return pgfn_fixed_to_int8(errcode, " +
 							codegen_fixed_rescale(e, fixed_scale, tg.scale) + ");\n";
+						/*
+						 * sum of a DECIMAL column at the column's own scale: the accumulator adds
+						 * the stored integers as they are, and the column's zone map bounds them
+						 * -- a packed-accumulator input like an int8 column (count and bounded
+						 * sums in one LDS word, strom_gpupreagg.h)
+						 */
+						const sexpr &x = t.items[1];
+						if (tg.kind == STROM_PREAGG_PSUM && fixed_scale == tg.scale &&
+							x.is_list && x.items.size() == 4 && !x.items[0].is_list && x.items[0].atom == "var" &&
+							!x.items[1].is_list && !x.items[2].is_list && x.items[2].atom == "decimal")
+						{
+							int attno = atoi(x.items[1].atom.c_str());
+							if (attno >= 1)
+							{
+								tg.pack_kind = 2;
+								tg.pack_attno = attno;
+							}
+						}
+					}
 					else
 						tg.body = "  return strom_numeric_to_fixed(errcode, " + e + ", " + sb + ");\n";
 				}

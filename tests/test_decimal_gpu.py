@@ -105,3 +105,52 @@ def test_ingest_refuses_a_scale_the_values_do_not_fit():
         col.release()
     finally:
         src.release()
+
+
+@pytest.mark.parametrize("ngroups", [10000, 25000])
+def test_sum_of_a_decimal_column_at_its_own_scale_is_a_packed_accumulator_input(ngroups, monkeypatch):
+    """sum(numeric(p,2)) over a decimal column is the sum of an int8 column bounded by its zone
+    map: it shares the packed 64-bit word with count(*) (num_kern_prep marks the packed path),
+    and gives the standard image's partial rows bit for bit -- and numpy's"""
+    from decimal import Decimal
+    n = 200003
+    rng = np.random.default_rng(5)
+    g = rng.integers(0, ngroups, n).astype(np.int32)
+    g[:ngroups] = np.arange(ngroups, dtype=np.int32)
+    x = rng.integers(-10**6, 10**6, n)
+    y = rng.random(n) * 100
+    buf = kds.build_kds("column", [kds.Column("int4", g), kds.Column("decimal", x), kds.Column("float8", y)])
+    spec = "(gpupreagg (key (var 1 int4)) (nrows) (psum (var 2 decimal 2) 2) (psum (var 3 float8)))"
+    rows = []
+    for packed in (True, False):
+        if not packed:
+            monkeypatch.setenv("STROM_GPUPREAGG_NO_PACKED", "1")
+        agg = GpuPreAgg(spec).begin([(0, ngroups)])
+        ds = runtime.DeviceStore.upload(buf)
+        try:
+            status, pfm = agg.fold(ds)
+            assert status == 0 and pfm["num_kern_prep"] == (1 if packed else 0)
+            v, isn = partial_rows_as_raw8(agg.fetch())
+        finally:
+            agg.end()
+            ds.release()
+        o = np.argsort(v[:, 0])
+        rows.append((v[o], isn[o]))
+    assert np.array_equal(rows[0][0][:, :3], rows[1][0][:, :3]) and np.array_equal(rows[0][1], rows[1][1])
+    assert np.allclose(rows[0][0][:, 3].view(np.float64), rows[1][0][:, 3].view(np.float64), rtol=1e-12)
+    want_n = np.bincount(g, minlength=ngroups)
+    want_x = np.zeros(ngroups, dtype=np.int64)
+    np.add.at(want_x, g, x)
+    v = rows[0][0]
+    assert np.array_equal(v[:, 0].view(np.int64), np.arange(ngroups)) and np.array_equal(v[:, 1].view(np.int64), want_n)
+    for i in range(0, ngroups, 37):
+        assert kds.numeric_decode(v[i, 2]) == Decimal(int(want_x[i])).scaleb(-2), i
+    # a sum at another scale than the column's is an expression: the standard image
+    other = "(gpupreagg (key (var 1 int4)) (nrows) (psum (var 2 decimal 2) 4) (psum (var 3 float8)))"
+    monkeypatch.delenv("STROM_GPUPREAGG_NO_PACKED")
+    agg = GpuPreAgg(other).begin([(0, ngroups)])
+    try:
+        status, pfm = agg.fold(buf)
+        assert status == 0 and pfm["num_kern_prep"] == 0
+    finally:
+        agg.end()
