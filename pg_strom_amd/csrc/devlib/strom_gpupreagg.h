@@ -2419,7 +2419,14 @@ gpupreagg_hash_slot(char *htab, cl_uint hash, const cl_ulong *kimg, cl_uint knul
 	for (cl_uint turns = 0; !done && turns < (1u << 28); turns++)
 	{
 		char   *rec = gpupreagg_hash_rec(htab, slot);
-		cl_uint	st = __hip_atomic_load(HASH_REC_STATE(rec), __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+		/*
+		 * No acquire here: at agent scope that is an invalidate of the caches in front of
+		 * the table for every probe (the flush of a work-group's LDS table spent 2.9 of
+		 * its 3.6 ms per 1e8 rows and 1e6 groups there).  The record's state, NULL bits
+		 * and keys are read with agent-scope atomic loads instead, which are served where
+		 * the claimer's release made them visible before it stored state 2.
+		 */
+		cl_uint	st = __hip_atomic_load(HASH_REC_STATE(rec), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 
 		if (st == 0 && claim_limit != ~0u &&
 			__hip_atomic_load(&head->ngroups, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= claim_limit)
@@ -2431,7 +2438,7 @@ gpupreagg_hash_slot(char *htab, cl_uint hash, const cl_ulong *kimg, cl_uint knul
 		{
 			cl_uint	expect = 0;
 			if (__hip_atomic_compare_exchange_strong(HASH_REC_STATE(rec), &expect, 1u,
-													 __ATOMIC_ACQUIRE, __ATOMIC_ACQUIRE,
+													 __ATOMIC_RELAXED, __ATOMIC_RELAXED,
 													 __HIP_MEMORY_SCOPE_AGENT))
 			{
 				for (int k = 0; k < GPUPREAGG_NKEYS; k++)
@@ -2446,11 +2453,13 @@ gpupreagg_hash_slot(char *htab, cl_uint hash, const cl_ulong *kimg, cl_uint knul
 		}
 		else if (st == 2)
 		{
-			bool	same = (MATCH && *HASH_REC_KNULL(rec) == knull);
+			bool	same = (MATCH && __hip_atomic_load(HASH_REC_KNULL(rec), __ATOMIC_RELAXED,
+													   __HIP_MEMORY_SCOPE_AGENT) == knull);
 			if (MATCH)
 			{
 				for (int k = 0; k < GPUPREAGG_NKEYS; k++)
-					same = same && (HASH_REC_KEYS(rec)[k] == kimg[k]);
+					same = same && (__hip_atomic_load(HASH_REC_KEYS(rec) + k, __ATOMIC_RELAXED,
+													  __HIP_MEMORY_SCOPE_AGENT) == kimg[k]);
 			}
 			if (same)
 			{
@@ -2953,6 +2962,635 @@ gpupreagg_hash_fold(kern_gpupreagg *kgpreagg, const kern_data_store *kds,
 	else
 		gpupreagg_hash_body<true, true, false>(kgpreagg, kds, ktoast, krowmap, htab, claim_limit, deferred,
 											   lds_slots, nroles, lds, NULL);
+}
+
+/* ---------------------------------------------------------------------- *
+ * hashed GROUP BY over hash PARTITIONS (more groups than the hash roles' LDS
+ * tables take together)
+ *
+ * Past ~1e5 groups the rows of a chunk meet the global table one by one: three
+ * atomics on a random 64-byte record per row, 23-47 ms per 1e8 rows.  Here the
+ * chunk is first ordered by a slice of the hash, so that the groups of a run
+ * of rows fit a work-group's LDS table again:
+ *
+ *   gpupreagg_hash_check_parts  the check pass; also leaves every row's
+ *                               partition (2 bytes; NONE = dropped by the
+ *                               qual) and the partitions' row counts
+ *   gpupreagg_hash_part_plan    counts -> partition offsets and the list of
+ *                               UNITS (a partition, cut at unit_rows so that
+ *                               one heavy key is not one work-group's job)
+ *   gpupreagg_hash_scatter      rows -> RECORDS { knull, value bits, key
+ *                               images, raw values } in partition order: a
+ *                               tile of 32 x blockDim rows reserves its share
+ *                               of every partition with one atomic each
+ *   gpupreagg_hash_fold_parts   a work-group takes a unit: LDS table, then
+ *                               one find-or-claim and one merge per group
+ *                               and unit.  Run first as CLAIM pass (keys
+ *                               only, under the table's fill limit: a new
+ *                               group that does not fit raises 'deferred',
+ *                               the host grows the table and claims again
+ *                               -- claiming is idempotent), then as the
+ *                               fold, where every group is found.
+ *
+ * The partition is the top of the row's slot index in the global table
+ * (hash >> pshift), so a unit's groups also sit in one slice of the table.
+ * ---------------------------------------------------------------------- */
+#define GPUPREAGG_PART_NONE			0xffffu
+#ifndef GPUPREAGG_ABLATE
+#define GPUPREAGG_ABLATE 0		/* probes: 16 no record stores, 32 no row loads in the scatter, 64 no flush, 128 no accumulate */
+#endif
+#define GPUPREAGG_PART_MAX			4096
+#define GPUPREAGG_SCATTER_ROWS		32		/* rows per thread and tile of the scatter */
+
+struct gpupreagg_part_ctl {
+	cl_uint		nparts;				/* power of two, <= GPUPREAGG_PART_MAX */
+	cl_uint		pshift;
+	cl_uint		unit_rows;
+	cl_uint		nunits;				/* by gpupreagg_hash_part_plan */
+	cl_uint		nrecords;
+	cl_uint		deferred;			/* by the claim pass */
+	cl_uint		max_units;
+	cl_uint		reclen;				/* checked by the host */
+};
+
+/* words of a record: { knull | value bits << 32, key images, raw values of the
+ * aggregates that are not NROWS (those are a bit: this row counts) } */
+STROM_DEVICE constexpr int gpupreagg_rec_nvals()
+{
+	int		n = 0;
+#define X(aidx,resno,OP,NAME)	n += (GPUPREAGG_OP_##OP != GPUPREAGG_OP_NROWS ? 1 : 0);
+	GPUPREAGG_AGG_LIST(X)
+#undef X
+	return n;
+}
+#define GPUPREAGG_REC_WORDS		(1 + GPUPREAGG_NKEYS + gpupreagg_rec_nvals())
+
+/* a record moves in 16-byte pieces where its length allows (records are 16-byte aligned
+ * then): a scattered 8-byte store is a request of its own at the L2 */
+typedef cl_ulong gpupreagg_rec2_t __attribute__((ext_vector_type(2)));
+template <int NWORDS>
+STROM_DEVICE void gpupreagg_rec_copy(cl_ulong *dst, const cl_ulong *src)
+{
+	if ((NWORDS & 1) == 0)
+	{
+#pragma unroll
+		for (int q = 0; q < NWORDS; q += 2)
+		{
+			gpupreagg_rec2_t v = { src[q], src[q + 1] };
+			*(gpupreagg_rec2_t *)(dst + q) = v;
+		}
+	}
+	else
+	{
+#pragma unroll
+		for (int q = 0; q < NWORDS; q++)
+			dst[q] = src[q];
+	}
+}
+template <int NWORDS>
+STROM_DEVICE void gpupreagg_rec_load(cl_ulong *dst, const cl_ulong *src)
+{
+	if ((NWORDS & 1) == 0)
+	{
+#pragma unroll
+		for (int q = 0; q < NWORDS; q += 2)
+		{
+			gpupreagg_rec2_t v = *(const gpupreagg_rec2_t *)(src + q);
+			dst[q] = v.x;
+			dst[q + 1] = v.y;
+		}
+	}
+	else
+	{
+#pragma unroll
+		for (int q = 0; q < NWORDS; q++)
+			dst[q] = src[q];
+	}
+}
+
+STROM_DEVICE cl_ulong gpupreagg_raw_image(cl_char v)	{ return (cl_ulong)(cl_long)v; }
+STROM_DEVICE cl_ulong gpupreagg_raw_image(cl_short v)	{ return (cl_ulong)(cl_long)v; }
+STROM_DEVICE cl_ulong gpupreagg_raw_image(cl_int v)		{ return (cl_ulong)(cl_long)v; }
+STROM_DEVICE cl_ulong gpupreagg_raw_image(cl_long v)	{ return (cl_ulong)v; }
+STROM_DEVICE cl_ulong gpupreagg_raw_image(cl_ulong v)	{ return v; }
+STROM_DEVICE cl_ulong gpupreagg_raw_image(cl_float v)	{ return (cl_ulong)__float_as_uint(v); }
+STROM_DEVICE cl_ulong gpupreagg_raw_image(cl_double v)	{ return (cl_ulong)__double_as_longlong(v); }
+STROM_DEVICE void gpupreagg_raw_value(cl_ulong x, cl_char *v)	{ *v = (cl_char)x; }
+STROM_DEVICE void gpupreagg_raw_value(cl_ulong x, cl_short *v)	{ *v = (cl_short)x; }
+STROM_DEVICE void gpupreagg_raw_value(cl_ulong x, cl_int *v)	{ *v = (cl_int)x; }
+STROM_DEVICE void gpupreagg_raw_value(cl_ulong x, cl_long *v)	{ *v = (cl_long)x; }
+STROM_DEVICE void gpupreagg_raw_value(cl_ulong x, cl_ulong *v)	{ *v = x; }
+STROM_DEVICE void gpupreagg_raw_value(cl_ulong x, cl_float *v)	{ *v = __uint_as_float((cl_uint)x); }
+STROM_DEVICE void gpupreagg_raw_value(cl_ulong x, cl_double *v)	{ *v = __longlong_as_double((long long)x); }
+
+/*
+ * check pass and scatter pass: both walk the chunk (any format, row map or
+ * not) and evaluate the keys and partial inputs of a row
+ */
+template <bool IS_COLUMN, bool SCATTER>
+__device__ __forceinline__ void
+gpupreagg_hash_parts_body(kern_gpupreagg *kgpreagg,
+						  const kern_data_store *kds,
+						  const kern_data_store *ktoast,
+						  const kern_row_map *krowmap,
+						  cl_ushort *partmap, cl_uint *hist, cl_uint *cursor, cl_ulong *records,
+						  const gpupreagg_part_ctl *ctl, cl_uint *lds_words)
+{
+	const kern_parambuf *kparams = KERN_GPUPREAGG_PARAMBUF(kgpreagg);
+	bool		use_map = (krowmap != NULL && krowmap->nvalids >= 0);
+	cl_uint		nrows = (use_map ? (cl_uint)krowmap->nvalids : kds->nitems);
+	cl_int		chunk_status = StromError_Success;
+	cl_int		param_error = StromError_Success;
+	const cl_uint nparts = ctl->nparts;
+	const cl_uint pshift = ctl->pshift;
+	strom_kparams KP;
+
+	if (SCATTER && kgpreagg->status != StromError_Success)
+		return;							/* the check pass sends the chunk back */
+	gpupreagg_load_kparams(KP, kparams, &param_error);
+	const bool	is_column = IS_COLUMN;
+	const cl_int chunk_format = kds->format;
+	const bool	row_family = (chunk_format == KDS_FORMAT_ROW || chunk_format == KDS_FORMAT_ROW_FLAT);
+	const kern_coldir *coldir_g = KERN_DATA_STORE_COLDIR(kds);
+#define X(attno,colidx,NAME)													\
+	const char *col_##attno = (is_column ? (const char *)kds + coldir_g[colidx].values_off : NULL);	\
+	const cl_uint *nul_##attno = ((is_column && coldir_g[colidx].nulls_off != 0)	\
+		? (const cl_uint *)((const char *)kds + coldir_g[colidx].nulls_off) : NULL);
+	STROM_KVAR_LIST(X)
+#undef X
+	auto load_row = [&](size_t r, strom_kvars &KV, cl_int &errcode)
+	{
+		cl_uint		kds_index = (use_map ? (cl_uint)krowmap->rindex[r] : (cl_uint)r);
+		const HeapTupleHeaderData *htup = NULL;
+		errcode = param_error;
+		if (!is_column && row_family)
+			htup = strom_locate_tuple(kds, chunk_format, kds_index);
+#define X(attno,colidx,NAME)													\
+		KV.KVAR_##attno = (is_column											\
+			? STROM_COLUMN_REF(NAME, col_##attno, nul_##attno, kds_index)		\
+			: row_family ? STROM_TUPLE_REF(NAME, kds, htup, colidx)				\
+			: pg_##NAME##_vref(kds, ktoast, &errcode, colidx, kds_index));
+		STROM_KVAR_LIST(X)
+#undef X
+		KV.__dummy = 0;
+	};
+	/* keys of a row -> images; false when an expression failed */
+	auto eval_keys = [&](const strom_kvars &KV, cl_int &errcode, cl_ulong *kimg, cl_uint &knull)
+	{
+		knull = 0;
+#define X(kidx,resno,NAME)															\
+		{																			\
+			pg_##NAME##_t kv = gpupreagg_key_##kidx(&errcode, KP, KV);				\
+			kimg[kidx] = (kv.isnull ? 0UL : strom_key_image(kv.value));				\
+			knull |= (kv.isnull ? (1u << kidx) : 0u);								\
+		}
+		GPUPREAGG_KEY_LIST(X)
+#undef X
+	};
+
+	if (!SCATTER)
+	{
+		/*
+		 * check: errors as gpupreagg_hash_check finds them, the row's partition,
+		 * the partitions' row counts (LDS, merged once per work-group)
+		 */
+		for (cl_uint i = threadIdx.x; i < nparts; i += blockDim.x)
+			lds_words[i] = 0;
+		__syncthreads();
+		for (size_t tile = blockIdx.x;
+			 tile * GPUPREAGG_HASH_UNROLL * blockDim.x < nrows;
+			 tile += gridDim.x)
+		{
+			strom_kvars	KVs[GPUPREAGG_HASH_UNROLL];
+			cl_int		errs[GPUPREAGG_HASH_UNROLL];
+			size_t		pos[GPUPREAGG_HASH_UNROLL];
+#pragma unroll
+			for (int j = 0; j < GPUPREAGG_HASH_UNROLL; j++)
+			{
+				pos[j] = (tile * GPUPREAGG_HASH_UNROLL + j) * blockDim.x + threadIdx.x;
+				load_row(pos[j] < nrows ? pos[j] : 0, KVs[j], errs[j]);
+			}
+#pragma unroll
+			for (int j = 0; j < GPUPREAGG_HASH_UNROLL; j++)
+			{
+				if (pos[j] >= nrows)
+					continue;
+				cl_int		errcode = errs[j];
+				cl_ulong	kimg[GPUPREAGG_NKEYS + 1];
+				cl_uint		knull;
+				cl_uint		part = GPUPREAGG_PART_NONE;
+				pg_bool_t	rc = gpupreagg_qual_eval(&errcode, KP, KVs[j]);
+				if (errcode != StromError_Success || EVAL(rc))
+				{
+					eval_keys(KVs[j], errcode, kimg, knull);
+#define X(aidx,resno,OP,NAME)														\
+					pg_##NAME##_t av_##aidx = gpupreagg_agg_##aidx(&errcode, KP, KVs[j]);
+					GPUPREAGG_AGG_LIST(X)
+#undef X
+					if (errcode != StromError_Success)
+						STROM_SET_ERROR(&chunk_status, errcode);
+					else
+					{
+#define X(aidx,resno,OP,NAME)														\
+						if (GPUPREAGG_OP_##OP == GPUPREAGG_OP_PSUM &&						\
+							!gpupreagg_is_float<pg_##NAME##_base_t>::value)					\
+							STROM_SET_RECHECK_IF(&chunk_status, !av_##aidx.isnull &			\
+												 gpupreagg_int8_near_overflow((cl_long)av_##aidx.value));
+						GPUPREAGG_AGG_LIST(X)
+#undef X
+						part = (gpupreagg_hash_of(kimg, knull) >> pshift) & (nparts - 1);
+						__hip_atomic_fetch_add(&lds_words[part], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+					}
+				}
+				partmap[pos[j]] = (cl_ushort)part;
+			}
+		}
+		__syncthreads();
+		for (cl_uint i = threadIdx.x; i < nparts; i += blockDim.x)
+		{
+			cl_uint		c = lds_words[i];
+			if (c != 0)
+				__hip_atomic_fetch_add(&hist[i], c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		}
+		gpupreagg_writeback_status(&kgpreagg->status, chunk_status);
+		return;
+	}
+	/*
+	 * scatter.  A tile is GPUPREAGG_SCATTER_ROWS x blockDim rows: (A) its rows per
+	 * partition, from the partition map; (B) one reservation per partition that
+	 * occurs; (C) the rows' records go to their partition's reserved run.
+	 */
+	cl_uint	   *lcount = lds_words;
+	cl_uint	   *lbase = lds_words + nparts;
+	size_t		tile_rows = (size_t)GPUPREAGG_SCATTER_ROWS * blockDim.x;
+	for (cl_uint i = threadIdx.x; i < nparts; i += blockDim.x)
+		lcount[i] = 0;
+	__syncthreads();
+	for (size_t tile = blockIdx.x; tile * tile_rows < nrows; tile += gridDim.x)
+	{
+		size_t		r0 = tile * tile_rows + threadIdx.x;
+#pragma unroll 1
+		for (int j0 = 0; j0 < GPUPREAGG_SCATTER_ROWS; j0 += 8)
+		{
+			cl_uint		parts[8];
+#pragma unroll
+			for (int j = 0; j < 8; j++)
+			{
+				size_t		r = r0 + (size_t)(j0 + j) * blockDim.x;
+				parts[j] = (r < nrows ? (cl_uint)partmap[r] : GPUPREAGG_PART_NONE);
+			}
+#pragma unroll
+			for (int j = 0; j < 8; j++)
+			{
+				if (parts[j] != GPUPREAGG_PART_NONE)
+					__hip_atomic_fetch_add(&lcount[parts[j]], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+			}
+		}
+		/* (phase C reads the map again -- two bytes per row out of L2 -- instead of keeping
+		 * the partition numbers alive across the row loads) */
+		__syncthreads();
+		for (cl_uint i = threadIdx.x; i < nparts; i += blockDim.x)
+		{
+			cl_uint		c = lcount[i];
+			if (c != 0)
+				lbase[i] = __hip_atomic_fetch_add(&cursor[i], c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			lcount[i] = 0;
+		}
+		__syncthreads();
+#pragma unroll 1
+		for (int j0 = 0; j0 < GPUPREAGG_SCATTER_ROWS; j0 += GPUPREAGG_HASH_UNROLL)
+		{
+			strom_kvars	KVs[GPUPREAGG_HASH_UNROLL];
+			cl_int		errs[GPUPREAGG_HASH_UNROLL];
+			cl_uint		part[GPUPREAGG_HASH_UNROLL];
+#pragma unroll
+			for (int j = 0; j < GPUPREAGG_HASH_UNROLL; j++)
+			{
+				size_t		r = r0 + (size_t)(j0 + j) * blockDim.x;
+				part[j] = (r < nrows ? (cl_uint)partmap[r] : GPUPREAGG_PART_NONE);
+				load_row((GPUPREAGG_ABLATE & 32) ? (size_t)threadIdx.x : part[j] != GPUPREAGG_PART_NONE ? r : 0, KVs[j], errs[j]);
+			}
+#pragma unroll
+			for (int j = 0; j < GPUPREAGG_HASH_UNROLL; j++)
+			{
+				if (part[j] == GPUPREAGG_PART_NONE)
+					continue;
+				cl_int		errcode = errs[j];
+				cl_ulong	kimg[GPUPREAGG_NKEYS + 1];
+				cl_uint		knull;
+				cl_uint		abits = 0;
+				eval_keys(KVs[j], errcode, kimg, knull);
+				cl_uint		rank = __hip_atomic_fetch_add(&lcount[part[j]], 1u, __ATOMIC_RELAXED,
+														  __HIP_MEMORY_SCOPE_WORKGROUP);
+				cl_ulong   *dst = records + (size_t)(lbase[part[j]] + rank) * GPUPREAGG_REC_WORDS;
+				cl_ulong	rec[GPUPREAGG_REC_WORDS];
+				int			vp = 1 + GPUPREAGG_NKEYS;
+				for (int k = 0; k < GPUPREAGG_NKEYS; k++)
+					rec[1 + k] = kimg[k];
+#define X(aidx,resno,OP,NAME)														\
+				{																	\
+					pg_##NAME##_t av = gpupreagg_agg_##aidx(&errcode, KP, KVs[j]);	\
+					if (GPUPREAGG_OP_##OP == GPUPREAGG_OP_NROWS)					\
+						abits |= ((!av.isnull && av.value != 0) ? (1u << aidx) : 0u);	\
+					else															\
+					{																\
+						abits |= (!av.isnull ? (1u << aidx) : 0u);					\
+						rec[vp++] = (av.isnull ? 0UL : gpupreagg_raw_image(av.value));	\
+					}																\
+				}
+				GPUPREAGG_AGG_LIST(X)
+#undef X
+				rec[0] = (cl_ulong)knull | ((cl_ulong)abits << 32);
+				if (!(GPUPREAGG_ABLATE & 16) || rec[0] == 0x123456789abcdefUL)
+					gpupreagg_rec_copy<GPUPREAGG_REC_WORDS>(dst, rec);
+			}
+		}
+		__syncthreads();
+		for (cl_uint i = threadIdx.x; i < nparts; i += blockDim.x)
+			lcount[i] = 0;
+		__syncthreads();
+	}
+}
+
+extern "C" __global__ void
+__launch_bounds__(256)
+gpupreagg_hash_check_parts(kern_gpupreagg *kgpreagg, const kern_data_store *kds,
+						   const kern_data_store *ktoast, const kern_row_map *krowmap,
+						   cl_ushort *partmap, cl_uint *hist, const gpupreagg_part_ctl *ctl)
+{
+	__shared__ cl_uint lds_words[GPUPREAGG_PART_MAX];
+	if (kds->format == KDS_FORMAT_COLUMN)
+		gpupreagg_hash_parts_body<true, false>(kgpreagg, kds, ktoast, krowmap, partmap, hist, NULL, NULL, ctl, lds_words);
+	else
+		gpupreagg_hash_parts_body<false, false>(kgpreagg, kds, ktoast, krowmap, partmap, hist, NULL, NULL, ctl, lds_words);
+}
+
+extern "C" __global__ void
+__launch_bounds__(GPUPREAGG_BLOCK)
+gpupreagg_hash_scatter(kern_gpupreagg *kgpreagg, const kern_data_store *kds,
+					   const kern_data_store *ktoast, const kern_row_map *krowmap,
+					   cl_ushort *partmap, cl_uint *cursor, cl_ulong *records, const gpupreagg_part_ctl *ctl)
+{
+	__shared__ cl_uint lds_words[2 * GPUPREAGG_PART_MAX];
+	if (kds->format == KDS_FORMAT_COLUMN)
+		gpupreagg_hash_parts_body<true, true>(kgpreagg, kds, ktoast, krowmap, partmap, NULL, cursor, records, ctl, lds_words);
+	else
+		gpupreagg_hash_parts_body<false, true>(kgpreagg, kds, ktoast, krowmap, partmap, NULL, cursor, records, ctl, lds_words);
+}
+
+/*
+ * counts -> offsets (the scatter's cursors) and units { first record, records }.
+ * One work-group; a thread owns nparts / blockDim consecutive partitions.
+ */
+extern "C" __global__ void
+__launch_bounds__(256)
+gpupreagg_hash_part_plan(const cl_uint *hist, cl_uint *cursor, cl_uint *units, gpupreagg_part_ctl *ctl)
+{
+	__shared__ cl_uint s_rows[256], s_units[256];
+	cl_uint		nparts = ctl->nparts;
+	cl_uint		unit_rows = ctl->unit_rows;
+	cl_uint		per = (nparts + 255) / 256;
+	cl_uint		p0 = threadIdx.x * per;
+	cl_uint		rows = 0, nunits = 0;
+
+	for (cl_uint p = p0; p < p0 + per && p < nparts; p++)
+	{
+		rows += hist[p];
+		nunits += (hist[p] + unit_rows - 1) / unit_rows;
+	}
+	s_rows[threadIdx.x] = rows;
+	s_units[threadIdx.x] = nunits;
+	__syncthreads();
+	/* exclusive scans over the 256 threads */
+	for (cl_uint d = 1; d < 256; d <<= 1)
+	{
+		cl_uint	a = (threadIdx.x >= d ? s_rows[threadIdx.x - d] : 0);
+		cl_uint	b = (threadIdx.x >= d ? s_units[threadIdx.x - d] : 0);
+		__syncthreads();
+		s_rows[threadIdx.x] += a;
+		s_units[threadIdx.x] += b;
+		__syncthreads();
+	}
+	cl_uint		row_off = s_rows[threadIdx.x] - rows;
+	cl_uint		unit_off = s_units[threadIdx.x] - nunits;
+	for (cl_uint p = p0; p < p0 + per && p < nparts; p++)
+	{
+		cl_uint		c = hist[p];
+		cursor[p] = row_off;
+		for (cl_uint done = 0; done < c; done += unit_rows)
+		{
+			if (unit_off < ctl->max_units)
+			{
+				units[2 * unit_off] = row_off + done;
+				units[2 * unit_off + 1] = (c - done < unit_rows ? c - done : unit_rows);
+			}
+			unit_off++;
+		}
+		row_off += c;
+	}
+	if (threadIdx.x == 255)
+	{
+		ctl->nunits = (s_units[255] < ctl->max_units ? s_units[255] : ctl->max_units);
+		ctl->nrecords = s_rows[255];
+		ctl->reclen = 8 * GPUPREAGG_REC_WORDS;
+	}
+}
+
+/*
+ * a work-group takes units: the unit's records into a fresh LDS table, then the
+ * table's groups to the global one.  CLAIM_ONLY: keys only, under claim_limit.
+ */
+template <bool CLAIM_ONLY>
+__device__ __forceinline__ void
+gpupreagg_hash_fold_units(kern_gpupreagg *kgpreagg, char *htab, cl_uint claim_limit,
+						  gpupreagg_part_ctl *ctl, const cl_uint *units, const cl_ulong *records,
+						  cl_uint lds_slots, char *lds)
+{
+	gpupreagg_hash_head *head = (gpupreagg_hash_head *)htab;
+	gpupreagg_lds_layout L;
+	gpupreagg_hash_lds T;
+	cl_uint		nunits = ctl->nunits;
+
+	if (kgpreagg->status != StromError_Success)
+		return;
+	gpupreagg_lds_layout_init(L, lds_slots, 1);
+	T.state = (cl_uint *)(lds + L.total);
+	T.knull = T.state + lds_slots;
+	T.keys = (cl_ulong *)(T.knull + lds_slots);
+	T.mask = lds_slots - 1;
+	T.shift = 32 - (31 - __clz((int)lds_slots));
+	for (cl_uint unit = blockIdx.x; unit < nunits; unit += gridDim.x)
+	{
+		const cl_ulong *base = records + (size_t)units[2 * unit] * GPUPREAGG_REC_WORDS;
+		cl_uint		count = units[2 * unit + 1];
+
+		if (!CLAIM_ONLY)
+			gpupreagg_lds_init(lds, L, lds_slots, 1);
+		for (cl_uint i = threadIdx.x; i < lds_slots; i += blockDim.x)
+			T.state[i] = 0;
+		__syncthreads();
+		for (cl_uint i0 = 0; i0 < count; i0 += GPUPREAGG_HASH_UNROLL * blockDim.x)
+		{
+			cl_ulong	w[GPUPREAGG_HASH_UNROLL][GPUPREAGG_REC_WORDS];
+#pragma unroll
+			for (int j = 0; j < GPUPREAGG_HASH_UNROLL; j++)
+			{
+				cl_uint		i = i0 + j * blockDim.x + threadIdx.x;
+				const cl_ulong *rec = base + (size_t)(i < count ? i : 0) * GPUPREAGG_REC_WORDS;
+				/* (the claim pass needs the head and the keys only: the same lines, fewer registers) */
+				if (!CLAIM_ONLY)
+					gpupreagg_rec_load<GPUPREAGG_REC_WORDS>(w[j], rec);
+				else if ((GPUPREAGG_REC_WORDS & 1) == 0)
+					gpupreagg_rec_load<((2 + GPUPREAGG_NKEYS) & ~1)>(w[j], rec);	/* whole 16-byte pieces */
+				else
+				{
+					for (int q = 0; q < 1 + GPUPREAGG_NKEYS; q++)
+						w[j][q] = rec[q];
+				}
+			}
+#pragma unroll
+			for (int j = 0; j < GPUPREAGG_HASH_UNROLL; j++)
+			{
+				if (i0 + j * blockDim.x + threadIdx.x >= count)
+					continue;
+				cl_ulong	kimg[GPUPREAGG_NKEYS + 1];
+				cl_uint		knull = (cl_uint)w[j][0];
+				cl_uint		abits = (cl_uint)(w[j][0] >> 32);
+				for (int k = 0; k < GPUPREAGG_NKEYS; k++)
+					kimg[k] = w[j][1 + k];
+				cl_uint		hash = gpupreagg_hash_of(kimg, knull);
+				if ((GPUPREAGG_ABLATE & 128) && hash != 12345u)
+					continue;
+				cl_uint		lslot = gpupreagg_hash_lds_slot(T, hash, kimg, knull);
+				if (lslot != ~0u && CLAIM_ONLY)
+					continue;
+				/* the row's partial inputs, typed again */
+				int			vp = 1 + GPUPREAGG_NKEYS;
+#define X(aidx,resno,OP,NAME)														\
+				pg_##NAME##_t av_##aidx;											\
+				av_##aidx.isnull = false;											\
+				av_##aidx.value = 0;												\
+				if (GPUPREAGG_OP_##OP == GPUPREAGG_OP_NROWS)						\
+					av_##aidx.value = (pg_##NAME##_base_t)((abits >> aidx) & 1u);	\
+				else if (!CLAIM_ONLY)												\
+				{																	\
+					av_##aidx.isnull = !((abits >> aidx) & 1u);						\
+					gpupreagg_raw_value(w[j][vp++], &av_##aidx.value);				\
+				}
+				GPUPREAGG_AGG_LIST(X)
+#undef X
+				(void)vp;
+				cl_uint		need = GPUPREAGG_FLAG_SEEN;
+				if (lslot != ~0u)
+				{
+#define X(aidx,resno,OP,NAME)														\
+					need |= gpupreagg_lds_accum<GPUPREAGG_OP_##OP, aidx>(lds, L.vals_off[aidx], lslot, av_##aidx);
+					GPUPREAGG_AGG_LIST(X)
+#undef X
+					gpupreagg_flags_t *flags = (gpupreagg_flags_t *)lds;
+					if ((flags[lslot] & need) != need)
+					{
+						cl_uint *word = (cl_uint *)(lds + ((lslot * (cl_uint)sizeof(gpupreagg_flags_t)) & ~3u));
+						cl_uint	 shift = ((lslot * (cl_uint)sizeof(gpupreagg_flags_t)) & 3u) * 8u;
+						__hip_atomic_fetch_or(word, need << shift, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+					}
+					continue;
+				}
+				/* no room in the LDS table: the global one, this row alone */
+				cl_uint		slot = gpupreagg_hash_slot<true>(htab, hash, kimg, knull, claim_limit);
+				if (slot == GPUPREAGG_HASH_DEFER)
+				{
+					ctl->deferred = 1;
+					continue;
+				}
+				if (slot == GPUPREAGG_HASH_FULL)
+				{
+					head->overflow = 1;
+					continue;
+				}
+				if (CLAIM_ONLY)
+					continue;
+				char	   *grec = gpupreagg_hash_rec(htab, slot);
+#define X(aidx,resno,OP,NAME)														\
+				{																	\
+					typedef pg_##NAME##_base_t base_t;								\
+					bool		has = !av_##aidx.isnull;							\
+					cl_ulong	x;													\
+					if (GPUPREAGG_OP_##OP == GPUPREAGG_OP_NROWS)					\
+						x = (has ? (cl_ulong)(cl_uint)av_##aidx.value : 0);			\
+					else if (gpupreagg_is_float<base_t>::value)						\
+						x = (GPUPREAGG_OP_##OP == GPUPREAGG_OP_PSUM					\
+							 ? (cl_ulong)__double_as_longlong((cl_double)av_##aidx.value)	\
+							 : gpupreagg_f64_ordered((cl_double)av_##aidx.value));	\
+					else															\
+						x = (cl_ulong)(cl_long)av_##aidx.value;						\
+					if (GPUPREAGG_OP_##OP != GPUPREAGG_OP_NROWS && has)				\
+						need |= (2u << aidx);										\
+					if (has && !(GPUPREAGG_OP_##OP == GPUPREAGG_OP_NROWS && x == 0))	\
+						gpupreagg_hash_merge8<GPUPREAGG_OP_##OP, base_t>(HASH_REC_VALS(grec) + aidx, x);	\
+				}
+				GPUPREAGG_AGG_LIST(X)
+#undef X
+				if ((*HASH_REC_FLAGS(grec) & need) != need)
+					atomicOr(HASH_REC_FLAGS(grec), need);
+			}
+		}
+		/* the unit's groups: found or claimed, merged */
+		const gpupreagg_flags_t *lflags = (const gpupreagg_flags_t *)lds;
+		__syncthreads();
+		for (cl_uint s = threadIdx.x; s < lds_slots; s += blockDim.x)
+		{
+			if (T.state[s] != 2 || ((GPUPREAGG_ABLATE & 64) && unit > 0))
+				continue;
+			cl_ulong	kimg[GPUPREAGG_NKEYS + 1];
+			cl_uint		knull = T.knull[s];
+			for (int k = 0; k < GPUPREAGG_NKEYS; k++)
+				kimg[k] = T.keys[s * GPUPREAGG_NKEYS + k];
+			cl_uint		slot = gpupreagg_hash_slot<true>(htab, gpupreagg_hash_of(kimg, knull), kimg, knull, claim_limit);
+			if (slot == GPUPREAGG_HASH_DEFER)
+			{
+				ctl->deferred = 1;
+				continue;
+			}
+			if (slot == GPUPREAGG_HASH_FULL)
+			{
+				head->overflow = 1;
+				continue;
+			}
+			if (CLAIM_ONLY)
+				continue;
+			char	   *grec = gpupreagg_hash_rec(htab, slot);
+			cl_uint		lf = lflags[s];
+#define X(aidx,resno,OP,NAME)														\
+			if (GPUPREAGG_OP_##OP == GPUPREAGG_OP_NROWS)							\
+			{																		\
+				cl_uint c = ((const cl_uint *)(lds + L.vals_off[aidx]))[s];			\
+				if (c != 0)															\
+					gpupreagg_hash_merge8<GPUPREAGG_OP_NROWS, cl_long>(HASH_REC_VALS(grec) + aidx, (cl_ulong)c);	\
+			}																		\
+			else if (lf & (2u << aidx))												\
+				gpupreagg_hash_merge8<GPUPREAGG_OP_##OP, pg_##NAME##_base_t>		\
+					(HASH_REC_VALS(grec) + aidx, ((const cl_ulong *)(lds + L.vals_off[aidx]))[s]);
+			GPUPREAGG_AGG_LIST(X)
+#undef X
+			if ((*HASH_REC_FLAGS(grec) & lf) != lf)
+				atomicOr(HASH_REC_FLAGS(grec), lf);
+		}
+		__syncthreads();
+	}
+}
+
+extern "C" __global__ void
+__launch_bounds__(GPUPREAGG_BLOCK)
+gpupreagg_hash_fold_parts(kern_gpupreagg *kgpreagg, char *htab, cl_uint claim_limit,
+						  gpupreagg_part_ctl *ctl, const cl_uint *units, const cl_ulong *records,
+						  cl_uint lds_slots, cl_uint claim_only)
+{
+	extern __shared__ __attribute__((aligned(16))) char lds[];
+	if (claim_only)
+		gpupreagg_hash_fold_units<true>(kgpreagg, htab, claim_limit, ctl, units, records, lds_slots, lds);
+	else
+		gpupreagg_hash_fold_units<false>(kgpreagg, htab, claim_limit, ctl, units, records, lds_slots, lds);
 }
 
 /* min / max accumulators start from their identities (sums from the zeroed table) */

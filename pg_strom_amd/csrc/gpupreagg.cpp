@@ -881,11 +881,11 @@ hash_table_layout(const strom_gpupreagg *sess, cl_uint capacity)
 
 /* slots of the work-group's LDS table in front of the global one, and its bytes */
 cl_uint
-hash_lds_slots(const strom_gpupreagg *sess, size_t *p_bytes)
+hash_lds_slots(const strom_gpupreagg *sess, size_t *p_bytes, bool for_units = false)
 {
 	size_t		nkeys = sess->key_resno.size();
 	/* after the table: 256 queued row numbers per wave (GPUPREAGG_HASH_QUEUE, used with roles) */
-	size_t		queue = ((size_t)sess->block / 64) * 256 * sizeof(cl_uint);
+	size_t		queue = (for_units ? 0 : ((size_t)sess->block / 64) * 256 * sizeof(cl_uint));
 	auto fit = [&](size_t budget, size_t *p_b) -> cl_uint {
 		cl_uint	slots = 16384;
 		for (;;)
@@ -904,6 +904,12 @@ hash_lds_slots(const strom_gpupreagg *sess, size_t *p_bytes)
 	 * so the big one wins from 100 groups on (698 -> 656 us; 600 groups 1463 -> 932 us).
 	 * profiles/r02_hashed_lds_tables.txt
 	 */
+	if (for_units)
+	{
+		/* the partition plan's units: no role queues, and as much of the CU's 160 KB as a
+		 * power of two of slots takes */
+		return fit(159 * 1024, p_bytes);
+	}
 	size_t		small_bytes, big_bytes;
 	cl_uint		small_slots = fit(64 * 1024, &small_bytes);
 	cl_uint		big_slots = fit(136 * 1024, &big_bytes);
@@ -1121,6 +1127,167 @@ gpupreagg_launch_hashed(strom_task_impl *task, preagg_request req)
 		d_rowmap = p;
 	}
 	task_event(task);									/* ev[1] */
+	/*
+	 * More groups than the hash roles' LDS tables take together (or than a few roles, each a
+	 * scan of the chunk, are worth): the chunk is ordered by hash partition first and folded
+	 * unit by unit (strom_gpupreagg.h: gpupreagg_hash_check_parts ... _fold_parts).  1e8 rows,
+	 * 1e5 / 1e6 groups: 23 / 42 ms through the global table; profiles/r02_hashed_partitions.txt
+	 */
+	cl_ulong	parts_min = 20000;
+	if (const char *v = getenv("STROM_GPUPREAGG_HASH_PARTS_MIN"))
+		parts_min = strtoul(v, nullptr, 10);
+	bool		use_parts = (req.nrows > 0 && (cl_ulong)sess->groups_known >= parts_min &&
+							 !getenv("STROM_GPUPREAGG_HASH_NO_PARTS"));
+	if (use_parts)
+	{
+		hipFunction_t fn_pcheck = prog->get_function(dev, "gpupreagg_hash_check_parts", &errcode);
+		hipFunction_t fn_plan = fn_pcheck ? prog->get_function(dev, "gpupreagg_hash_part_plan", &errcode) : nullptr;
+		hipFunction_t fn_scatter = fn_plan ? prog->get_function(dev, "gpupreagg_hash_scatter", &errcode) : nullptr;
+		hipFunction_t fn_units = fn_scatter ? prog->get_function(dev, "gpupreagg_hash_fold_parts", &errcode) : nullptr;
+		if (!fn_units)
+		{
+			task_fail(task, errcode);
+			return;
+		}
+		cl_uint		nrows = req.nrows;
+		/* partitions: a unit's groups should fill at most ~5/16 of the LDS table */
+		cl_uint		nparts = 2048;
+		{
+			size_t	b;
+			if ((cl_ulong)sess->groups_known > (cl_ulong)nparts * hash_lds_slots(sess, &b, true) * 5 / 16)
+				nparts = 4096;
+		}
+		if (const char *v = getenv("STROM_GPUPREAGG_HASH_PARTS"))
+		{
+			int want = atoi(v);
+			if (want >= 64 && want <= 4096 && (want & (want - 1)) == 0)
+				nparts = (cl_uint)want;
+		}
+		cl_uint		unit_rows = 32768;
+		if (const char *v = getenv("STROM_GPUPREAGG_HASH_UNIT_ROWS"))
+			unit_rows = std::max(1024, atoi(v));
+		cl_uint		log2cap = 0, log2parts = 0;
+		while ((1UL << (log2cap + 1)) <= sess->hash_capacity)
+			log2cap++;
+		while ((1u << (log2parts + 1)) <= nparts)
+			log2parts++;
+		size_t		nvals = 0;
+		for (int resno : sess->agg_resno)
+			nvals += (sess->targets[resno].kind != STROM_PREAGG_NROWS ? 1 : 0);
+		size_t		reclen = 8 * (1 + sess->key_resno.size() + nvals);
+		cl_uint		max_units = nparts + nrows / unit_rows + 1;
+		struct part_ctl { cl_uint nparts, pshift, unit_rows, nunits, nrecords, deferred, max_units, reclen; } ctl_img;
+		ctl_img = part_ctl{ nparts, (log2cap > log2parts ? log2cap - log2parts : 0), unit_rows, 0, 0, 0, max_units, 0 };
+		size_t		ctl_len = sizeof(part_ctl) + sizeof(cl_uint) * ((size_t)2 * nparts + (size_t)2 * max_units);
+		char	   *d_ctl = (char *)dev->pool.alloc(ctl_len);
+		char	   *d_partmap = (char *)dev->pool.alloc(STROMALIGN((size_t)nrows * sizeof(cl_ushort)));
+		char	   *d_records = (char *)dev->pool.alloc((size_t)nrows * reclen);
+		if (d_ctl) task->devbufs.push_back(d_ctl);
+		if (d_partmap) task->devbufs.push_back(d_partmap);
+		if (d_records) task->devbufs.push_back(d_records);
+		if (!d_ctl || !d_partmap || !d_records || kg_len + 128 + sizeof(part_ctl) > PinnedPool::BLOCK)
+		{
+			task_fail(task, StromError_OutOfMemory);
+			return;
+		}
+		char	   *stage_ctl = stage + kg_len + 64;
+		memcpy(stage_ctl, &ctl_img, sizeof(ctl_img));
+		REQ_CHECK(hipMemsetAsync(d_ctl, 0, sizeof(part_ctl) + sizeof(cl_uint) * nparts, task->stream),
+				  "reset partition counts");
+		REQ_CHECK(hipMemcpyAsync(d_ctl, stage_ctl, sizeof(part_ctl), hipMemcpyHostToDevice, task->stream),
+				  "send partition plan");
+		void	   *a_kg = d_kg;
+		const void *a_kds = d_kds;
+		const void *a_toast = nullptr;
+		const void *a_map = d_rowmap;
+		void	   *a_ctl = d_ctl;
+		void	   *a_hist = d_ctl + sizeof(part_ctl);
+		void	   *a_cursor = d_ctl + sizeof(part_ctl) + sizeof(cl_uint) * nparts;
+		void	   *a_units = d_ctl + sizeof(part_ctl) + sizeof(cl_uint) * 2 * nparts;
+		void	   *a_partmap = d_partmap;
+		void	   *a_records = d_records;
+		unsigned	ncus = (unsigned)dev->prop.multiProcessorCount;
+		{
+			void	   *args[] = { &a_kg, &a_kds, &a_toast, &a_map, &a_partmap, &a_hist, &a_ctl };
+			unsigned	grid = std::max(1u, std::min<unsigned>((nrows + 511) / 512, ncus * 4));
+			REQ_CHECK(hipModuleLaunchKernel(fn_pcheck, grid, 1, 1, 256, 1, 1, 0, task->stream, args, nullptr),
+					  "launch gpupreagg hash check (partitions)");
+		}
+		{
+			void	   *args[] = { &a_hist, &a_cursor, &a_units, &a_ctl };
+			REQ_CHECK(hipModuleLaunchKernel(fn_plan, 1, 1, 1, 256, 1, 1, 0, task->stream, args, nullptr),
+					  "launch gpupreagg partition plan");
+		}
+		{
+			void	   *args[] = { &a_kg, &a_kds, &a_toast, &a_map, &a_partmap, &a_cursor, &a_records, &a_ctl };
+			size_t		tile = (size_t)block * 32;
+			unsigned	grid = (unsigned)std::max<size_t>(1, std::min<size_t>((nrows + tile - 1) / tile, (size_t)ncus * 2));
+			REQ_CHECK(hipModuleLaunchKernel(fn_scatter, grid, 1, 1, block, 1, 1, 0, task->stream, args, nullptr),
+					  "launch gpupreagg hash scatter");
+		}
+		task->pfm.num_kern_exec += 3;
+		task->pfm.num_kern_prep++;				/* (reported: this request took the partition plan) */
+		/*
+		 * claim pass(es): after them every group of the chunk has its slot.  Needed only
+		 * while nrows new groups would not fit under the fill limit.
+		 */
+		void	   *a_tab;
+		cl_uint		claim_only = 1;
+		size_t		lds_bytes = 0;				/* (the units' table, not the roles') */
+		cl_uint		lds_slots = hash_lds_slots(sess, &lds_bytes, true);
+		unsigned	fold_grid = ncus * (lds_bytes <= 72 * 1024 ? 2 : 1);
+		for (int turn = 0;; turn++)
+		{
+			cl_ulong	fill_limit = (cl_ulong)sess->hash_capacity / 8 * 7 - headroom;
+			if (sess->groups_upper + nrows > fill_limit)
+			{
+				cl_uint	ngroups = 0;
+				int		rc = hash_table_ngroups(sess, &ngroups, nullptr);
+				if (rc == 0)
+				{
+					sess->groups_upper = ngroups;
+					if (turn > 0 || (cl_ulong)ngroups * 2 > fill_limit)
+						rc = hash_table_grow(sess, (cl_ulong)sess->hash_capacity * 4);
+				}
+				if (rc)
+				{
+					task_fail(task, rc);
+					return;
+				}
+				fill_limit = (cl_ulong)sess->hash_capacity / 8 * 7 - headroom;
+			}
+			if (sess->groups_upper + nrows <= fill_limit)
+				break;
+			cl_uint		claim_limit = (cl_uint)fill_limit;
+			cl_int		deferred = 0;
+			a_tab = sess->htab;
+			REQ_CHECK(hipMemsetAsync(d_ctl + offsetof(part_ctl, deferred), 0, sizeof(cl_uint), task->stream),
+					  "reset the claim pass");
+			void	   *args[] = { &a_kg, &a_tab, &claim_limit, &a_ctl, &a_units, &a_records, &lds_slots, &claim_only };
+			REQ_CHECK(hipModuleLaunchKernel(fn_units, fold_grid, 1, 1, block, 1, 1, (unsigned)lds_bytes,
+											task->stream, args, nullptr),
+					  "launch gpupreagg hash claim");
+			task->pfm.num_kern_exec++;
+			REQ_CHECK(hipMemcpyAsync(&deferred, d_ctl + offsetof(part_ctl, deferred), sizeof(cl_int),
+									 hipMemcpyDeviceToHost, task->stream),
+					  "recv claim pass");
+			REQ_CHECK(hipStreamSynchronize(task->stream), "claim pass");
+			if (!deferred)
+				break;
+		}
+		{
+			cl_uint		no_limit = ~0u;
+			cl_uint		fold_all = 0;
+			a_tab = sess->htab;
+			void	   *args[] = { &a_kg, &a_tab, &no_limit, &a_ctl, &a_units, &a_records, &lds_slots, &fold_all };
+			REQ_CHECK(hipModuleLaunchKernel(fn_units, fold_grid, 1, 1, block, 1, 1, (unsigned)lds_bytes,
+											task->stream, args, nullptr),
+					  "launch gpupreagg hash fold (partitions)");
+			task->pfm.num_kern_exec++;
+			sess->groups_upper = std::min<cl_ulong>(sess->groups_upper + nrows, sess->hash_capacity);
+		}
+	}
+	else
 	{
 		void	   *a_kg = d_kg;
 		const void *a_kds = d_kds;

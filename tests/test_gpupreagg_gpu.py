@@ -684,6 +684,98 @@ def test_hashed_roles_split_the_groups_over_lds_tables(hint, qual):
 
 
 # ---------------------------------------------------------------------------
+# hashed GROUP BY over hash partitions (gpupreagg_hash_check_parts .. _fold_parts): the plan
+# for more groups than the hash roles' LDS tables take.  STROM_GPUPREAGG_HASH_PARTS_MIN=0
+# sends every chunk through it, whatever the group count; num_kern_prep reports it.
+# ---------------------------------------------------------------------------
+@pytest.fixture
+def partitions(monkeypatch):
+    monkeypatch.setenv("STROM_GPUPREAGG_HASH_PARTS_MIN", "0")
+
+
+@pytest.mark.parametrize("fmt", ["column", "row", "tupslot"])
+def test_partition_plan_any_keys_every_partial_kind(partitions, fmt):
+    cols = any_key_table(40000, 61)
+    bufs = [kds.build_kds(fmt, [kds.Column(c.sqltype, c.values[i::2], None if c.isnull is None else c.isnull[i::2])
+                                for c in cols]) for i in range(2)]
+    pfms = []
+    compare_with_oracle(SPEC_ANY_KEYS, bufs, None, hashed=True, pfms=pfms)
+    assert all(p["num_kern_prep"] == 1 for p in pfms)
+    spec = ("(gpupreagg (qual (int4gt (var 4 int4) (param 0 int4)))"
+            " (key (var 3 numeric)) (key (var 6 float4)) (nrows) (psum (int8 (var 4 int4))) (pmax (var 5 float8)))")
+    if fmt == "column":
+        compare_with_oracle(spec, bufs, None, ext=[np.int32(-250000)], hashed=True, resident=True)
+
+
+def test_partition_plan_claims_new_groups_and_grows_the_table(partitions):
+    test_hashed_table_grows_with_the_group_count()
+
+
+def test_partition_plan_row_maps_and_recheck(partitions):
+    test_hashed_row_map_inputs_host_and_device()
+    test_hashed_recheck_chunk_is_not_folded_and_reset()
+
+
+@pytest.mark.parametrize("unit_rows", [1024, 32768])
+def test_partition_plan_cuts_a_heavy_key_into_units(partitions, monkeypatch, unit_rows):
+    """60 % of the rows carry one key: its partition is cut into units of unit_rows records,
+    several work-groups fold it and meet in the global table"""
+    monkeypatch.setenv("STROM_GPUPREAGG_HASH_UNIT_ROWS", str(unit_rows))
+    rng = np.random.default_rng(67)
+    n = 600000
+    key = (rng.integers(0, 50000, n).astype(np.int64) - 25000) * (2**33 + 7)
+    key[rng.random(n) < 0.6] = 123456789012345
+    knull = rng.random(n) < 0.01                              # NULL is a group of its own
+    x = rng.integers(-1000, 1000, n).astype(np.int32)
+    y = rng.random(n)
+    spec = "(gpupreagg (key (var 1 int8)) (nrows) (psum (int8 (var 2 int4))) (pmin (var 3 float8)) (psum (var 3 float8)))"
+    agg = GpuPreAgg(spec).begin_hashed()
+    for i in range(3):
+        sl = slice(i * n // 3, (i + 1) * n // 3)
+        st, pfm = agg.fold(kds.build_kds("column", [kds.Column("int8", key[sl], knull[sl]), kds.Column("int4", x[sl]),
+                                                    kds.Column("float8", y[sl])]))
+        assert st == 0 and pfm["num_kern_prep"] == 1
+    pr = agg.fetch()
+    agg.end()
+    kk = np.where(knull, np.int64(2**62), key)               # (no real key has this value)
+    uk, inv = np.unique(kk, return_inverse=True)
+    k, kn = pr.column(0)
+    k = np.where(kn, np.int64(2**62), k)
+    order = np.argsort(k)
+    assert len(pr) == len(uk) and np.array_equal(k[order], uk)
+    assert np.array_equal(pr.column(1)[0][order], np.bincount(inv))
+    assert np.array_equal(pr.column(2)[0][order], np.bincount(inv, weights=x.astype(np.float64)).astype(np.int64))
+    want_min = np.full(len(uk), np.inf)
+    np.minimum.at(want_min, inv, y)
+    assert np.array_equal(pr.column(3)[0][order], want_min)
+    assert np.allclose(pr.column(4)[0][order], np.bincount(inv, weights=y), rtol=1e-11)
+
+
+def test_partition_plan_is_the_default_beyond_the_roles(monkeypatch):
+    """a hint of 30000 groups: the partition plan without any knob; the same partial rows as
+    the global-table path gives (integers bit for bit)"""
+    rng = np.random.default_rng(71)
+    n = 500000
+    key = rng.integers(0, 30000, n).astype(np.float64) * 0.5 - 7000.0
+    x = rng.integers(-1000, 1000, n).astype(np.int32)
+    buf = kds.build_kds("column", [kds.Column("float8", key), kds.Column("int4", x, rng.random(n) < 0.02)])
+    spec = "(gpupreagg (key (var 1 float8)) (nrows) (psum (int8 (var 2 int4))) (pmax (var 2 int4)))"
+    rows = []
+    for parts in (True, False):
+        if not parts:
+            monkeypatch.setenv("STROM_GPUPREAGG_HASH_NO_PARTS", "1")
+        agg = GpuPreAgg(spec).begin_hashed(ngroups_hint=30000)
+        st, pfm = agg.fold(buf)
+        assert st == 0 and pfm["num_kern_prep"] == (1 if parts else 0)
+        v, isn = partial_rows_as_raw8(agg.fetch())
+        agg.end()
+        o = np.argsort(v[:, 0].view(np.float64))
+        rows.append((v[o], isn[o]))
+    assert len(rows[0][0]) == len(np.unique(key))
+    assert np.array_equal(rows[0][0], rows[1][0]) and np.array_equal(rows[0][1], rows[1][1])
+
+
+# ---------------------------------------------------------------------------
 # the reference's per-chunk message (strom_submit_gpupreagg_chunk)
 # ---------------------------------------------------------------------------
 def chunk_runner(chunks):
