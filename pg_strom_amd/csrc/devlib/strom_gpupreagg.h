@@ -3087,14 +3087,14 @@ STROM_DEVICE void gpupreagg_raw_value(cl_ulong x, cl_double *v)	{ *v = __longlon
  * check pass and scatter pass: both walk the chunk (any format, row map or
  * not) and evaluate the keys and partial inputs of a row
  */
-template <bool IS_COLUMN, bool SCATTER>
+template <bool IS_COLUMN, int MODE>		/* 0 check, 1 scatter, 2 scatter through LDS */
 __device__ __forceinline__ void
 gpupreagg_hash_parts_body(kern_gpupreagg *kgpreagg,
 						  const kern_data_store *kds,
 						  const kern_data_store *ktoast,
 						  const kern_row_map *krowmap,
 						  cl_ushort *partmap, cl_uint *hist, cl_uint *cursor, cl_ulong *records,
-						  const gpupreagg_part_ctl *ctl, cl_uint *lds_words)
+						  const gpupreagg_part_ctl *ctl, cl_uint *lds_words, cl_uint lds_rows = 0)
 {
 	const kern_parambuf *kparams = KERN_GPUPREAGG_PARAMBUF(kgpreagg);
 	bool		use_map = (krowmap != NULL && krowmap->nvalids >= 0);
@@ -3105,7 +3105,7 @@ gpupreagg_hash_parts_body(kern_gpupreagg *kgpreagg,
 	const cl_uint pshift = ctl->pshift;
 	strom_kparams KP;
 
-	if (SCATTER && kgpreagg->status != StromError_Success)
+	if (MODE != 0 && kgpreagg->status != StromError_Success)
 		return;							/* the check pass sends the chunk back */
 	gpupreagg_load_kparams(KP, kparams, &param_error);
 	const bool	is_column = IS_COLUMN;
@@ -3148,7 +3148,7 @@ gpupreagg_hash_parts_body(kern_gpupreagg *kgpreagg,
 #undef X
 	};
 
-	if (!SCATTER)
+	if (MODE == 0)
 	{
 		/*
 		 * check: errors as gpupreagg_hash_check finds them, the row's partition,
@@ -3213,6 +3213,158 @@ gpupreagg_hash_parts_body(kern_gpupreagg *kgpreagg,
 				__hip_atomic_fetch_add(&hist[i], c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 		}
 		gpupreagg_writeback_status(&kgpreagg->status, chunk_status);
+		return;
+	}
+	if (MODE == 2)
+	{
+		/*
+		 * scatter through LDS.  A scattered 16-byte store is one request at the L2, and
+		 * the chip serves ~1e11 of those per second: records written where they belong
+		 * one by one cost 2.7 ms per 1e8 rows, everything else in the pass 0.14 ms.  So
+		 * a tile (lds_rows rows per thread) is put in partition order in LDS first and
+		 * leaves in runs: consecutive lanes write consecutive 16 bytes.
+		 *   LDS: lcount[P] lstart[P] lbase[P] | wave sums | records[T] | lpart[T] (u16)
+		 */
+		const cl_uint T = lds_rows * blockDim.x;
+		cl_uint	   *lcount = lds_words;
+		cl_uint	   *lstart = lcount + nparts;
+		cl_uint	   *lbase = lstart + nparts;
+		cl_uint	   *wsum = lbase + nparts;					/* 32 words */
+		cl_ulong   *lrec = (cl_ulong *)(wsum + 32);
+		cl_ushort  *lpart = (cl_ushort *)(lrec + (size_t)T * GPUPREAGG_REC_WORDS);
+		const cl_uint per = (nparts + blockDim.x - 1) / blockDim.x;		/* counters per thread in the scan */
+
+		for (cl_uint i = threadIdx.x; i < nparts; i += blockDim.x)
+			lcount[i] = 0;
+		__syncthreads();
+		for (size_t tile = blockIdx.x; tile * T < nrows; tile += gridDim.x)
+		{
+			size_t		r0 = tile * T + threadIdx.x;
+			cl_uint		part[4], rank[4];
+			/* (A) partition and rank inside the tile's share of it */
+#pragma unroll
+			for (int j = 0; j < 4; j++)
+			{
+				size_t		r = r0 + (size_t)j * blockDim.x;
+				part[j] = ((cl_uint)j < lds_rows && r < nrows ? (cl_uint)partmap[r] : GPUPREAGG_PART_NONE);
+			}
+#pragma unroll
+			for (int j = 0; j < 4; j++)
+			{
+				rank[j] = 0;
+				if (part[j] != GPUPREAGG_PART_NONE)
+					rank[j] = __hip_atomic_fetch_add(&lcount[part[j]], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+			}
+			/* the rows' columns are on their way while the counters are scanned */
+			strom_kvars	KVs[4];
+			cl_int		errs[4];
+#pragma unroll
+			for (int j = 0; j < 4; j++)
+			{
+				if ((cl_uint)j < lds_rows)
+					load_row(part[j] != GPUPREAGG_PART_NONE ? r0 + (size_t)j * blockDim.x : 0, KVs[j], errs[j]);
+			}
+			__syncthreads();
+			/* (B) exclusive scan of the counters; one reservation per partition that occurs */
+			cl_uint		c[4], mine = 0;
+#pragma unroll
+			for (int q = 0; q < 4; q++)
+			{
+				cl_uint		i = threadIdx.x * per + q;
+				c[q] = ((cl_uint)q < per && i < nparts ? lcount[i] : 0);
+				mine += c[q];
+			}
+			cl_uint		incl = mine;
+			for (int d = 1; d < STROM_WAVE; d <<= 1)
+			{
+				cl_uint	up = __shfl_up(incl, d, STROM_WAVE);
+				if ((int)strom_lane_id() >= d)
+					incl += up;
+			}
+			if (strom_lane_id() == STROM_WAVE - 1)
+				wsum[threadIdx.x / STROM_WAVE] = incl;
+			__syncthreads();
+			cl_uint		before = 0, total = 0;
+			for (cl_uint w = 0; w < blockDim.x / STROM_WAVE; w++)
+			{
+				cl_uint	v = wsum[w];
+				before += (w < threadIdx.x / STROM_WAVE ? v : 0);
+				total += v;
+			}
+			cl_uint		off = before + incl - mine;
+#pragma unroll
+			for (int q = 0; q < 4; q++)
+			{
+				cl_uint		i = threadIdx.x * per + q;
+				if ((cl_uint)q < per && i < nparts)
+				{
+					lstart[i] = off;
+					if (c[q] != 0)
+						lbase[i] = __hip_atomic_fetch_add(&cursor[i], c[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+					lcount[i] = 0;
+					off += c[q];
+				}
+			}
+			__syncthreads();
+			/* (C) records into LDS at their place in partition order */
+#pragma unroll
+			for (int j = 0; j < 4; j++)
+			{
+				if (part[j] == GPUPREAGG_PART_NONE)
+					continue;
+				cl_int		errcode = errs[j];
+				cl_ulong	kimg[GPUPREAGG_NKEYS + 1];
+				cl_uint		knull;
+				cl_uint		abits = 0;
+				cl_ulong	rec[GPUPREAGG_REC_WORDS];
+				int			vp = 1 + GPUPREAGG_NKEYS;
+				eval_keys(KVs[j], errcode, kimg, knull);
+				for (int k = 0; k < GPUPREAGG_NKEYS; k++)
+					rec[1 + k] = kimg[k];
+#define X(aidx,resno,OP,NAME)														\
+				{																	\
+					pg_##NAME##_t av = gpupreagg_agg_##aidx(&errcode, KP, KVs[j]);	\
+					if (GPUPREAGG_OP_##OP == GPUPREAGG_OP_NROWS)					\
+						abits |= ((!av.isnull && av.value != 0) ? (1u << aidx) : 0u);	\
+					else															\
+					{																\
+						abits |= (!av.isnull ? (1u << aidx) : 0u);					\
+						rec[vp++] = (av.isnull ? 0UL : gpupreagg_raw_image(av.value));	\
+					}																\
+				}
+				GPUPREAGG_AGG_LIST(X)
+#undef X
+				rec[0] = (cl_ulong)knull | ((cl_ulong)abits << 32);
+				cl_uint		pos = lstart[part[j]] + rank[j];
+				gpupreagg_rec_copy<GPUPREAGG_REC_WORDS>(lrec + (size_t)pos * GPUPREAGG_REC_WORDS, rec);
+				lpart[pos] = (cl_ushort)part[j];
+			}
+			__syncthreads();
+			/* (D) out in runs: piece q of the tile's records, 16 bytes where the record length allows */
+			if ((GPUPREAGG_REC_WORDS & 1) == 0)
+			{
+				const cl_uint ppr = GPUPREAGG_REC_WORDS / 2;
+				for (cl_uint q = threadIdx.x; q < total * ppr; q += blockDim.x)
+				{
+					cl_uint		i = q / ppr, piece = q - i * ppr;
+					cl_uint		p = lpart[i];
+					size_t		g = (size_t)lbase[p] + (i - lstart[p]);
+					*(gpupreagg_rec2_t *)(records + g * GPUPREAGG_REC_WORDS + 2 * piece) =
+						*(const gpupreagg_rec2_t *)(lrec + (size_t)i * GPUPREAGG_REC_WORDS + 2 * piece);
+				}
+			}
+			else
+			{
+				for (cl_uint q = threadIdx.x; q < total * GPUPREAGG_REC_WORDS; q += blockDim.x)
+				{
+					cl_uint		i = q / GPUPREAGG_REC_WORDS, piece = q - i * GPUPREAGG_REC_WORDS;
+					cl_uint		p = lpart[i];
+					size_t		g = (size_t)lbase[p] + (i - lstart[p]);
+					records[g * GPUPREAGG_REC_WORDS + piece] = lrec[(size_t)i * GPUPREAGG_REC_WORDS + piece];
+				}
+			}
+			__syncthreads();
+		}
 		return;
 	}
 	/*
@@ -3320,9 +3472,9 @@ gpupreagg_hash_check_parts(kern_gpupreagg *kgpreagg, const kern_data_store *kds,
 {
 	__shared__ cl_uint lds_words[GPUPREAGG_PART_MAX];
 	if (kds->format == KDS_FORMAT_COLUMN)
-		gpupreagg_hash_parts_body<true, false>(kgpreagg, kds, ktoast, krowmap, partmap, hist, NULL, NULL, ctl, lds_words);
+		gpupreagg_hash_parts_body<true, 0>(kgpreagg, kds, ktoast, krowmap, partmap, hist, NULL, NULL, ctl, lds_words);
 	else
-		gpupreagg_hash_parts_body<false, false>(kgpreagg, kds, ktoast, krowmap, partmap, hist, NULL, NULL, ctl, lds_words);
+		gpupreagg_hash_parts_body<false, 0>(kgpreagg, kds, ktoast, krowmap, partmap, hist, NULL, NULL, ctl, lds_words);
 }
 
 extern "C" __global__ void
@@ -3333,9 +3485,25 @@ gpupreagg_hash_scatter(kern_gpupreagg *kgpreagg, const kern_data_store *kds,
 {
 	__shared__ cl_uint lds_words[2 * GPUPREAGG_PART_MAX];
 	if (kds->format == KDS_FORMAT_COLUMN)
-		gpupreagg_hash_parts_body<true, true>(kgpreagg, kds, ktoast, krowmap, partmap, NULL, cursor, records, ctl, lds_words);
+		gpupreagg_hash_parts_body<true, 1>(kgpreagg, kds, ktoast, krowmap, partmap, NULL, cursor, records, ctl, lds_words);
 	else
-		gpupreagg_hash_parts_body<false, true>(kgpreagg, kds, ktoast, krowmap, partmap, NULL, cursor, records, ctl, lds_words);
+		gpupreagg_hash_parts_body<false, 1>(kgpreagg, kds, ktoast, krowmap, partmap, NULL, cursor, records, ctl, lds_words);
+}
+
+extern "C" __global__ void
+__launch_bounds__(GPUPREAGG_BLOCK)
+gpupreagg_hash_scatter_lds(kern_gpupreagg *kgpreagg, const kern_data_store *kds,
+						   const kern_data_store *ktoast, const kern_row_map *krowmap,
+						   cl_ushort *partmap, cl_uint *cursor, cl_ulong *records, const gpupreagg_part_ctl *ctl,
+						   cl_uint lds_rows)
+{
+	extern __shared__ __attribute__((aligned(16))) char lds[];
+	if (kds->format == KDS_FORMAT_COLUMN)
+		gpupreagg_hash_parts_body<true, 2>(kgpreagg, kds, ktoast, krowmap, partmap, NULL, cursor, records, ctl,
+										   (cl_uint *)lds, lds_rows);
+	else
+		gpupreagg_hash_parts_body<false, 2>(kgpreagg, kds, ktoast, krowmap, partmap, NULL, cursor, records, ctl,
+											(cl_uint *)lds, lds_rows);
 }
 
 /*
@@ -3396,20 +3564,56 @@ gpupreagg_hash_part_plan(const cl_uint *hist, cl_uint *cursor, cl_uint *units, g
 	}
 }
 
+/* the slot of a key in the LDS table, or ~0u: a look, no claim (states >= 2 are taken slots) */
+STROM_DEVICE cl_uint
+gpupreagg_hash_lds_find(const gpupreagg_hash_lds &T, cl_uint hash, const cl_ulong *kimg, cl_uint knull)
+{
+	cl_uint		slot = (hash * 0x9e3779b1u) >> T.shift;
+
+	for (cl_uint probes = 0; probes <= GPUPREAGG_HASH_LDS_PROBES; probes++)
+	{
+		if (T.state[slot] == 0)
+			return ~0u;
+		bool	same = (T.knull[slot] == knull);
+		for (int k = 0; k < GPUPREAGG_NKEYS; k++)
+			same = same && (T.keys[slot * GPUPREAGG_NKEYS + k] == kimg[k]);
+		if (same)
+			return slot;
+		slot = (slot + 1) & T.mask;
+	}
+	return ~0u;
+}
+
+/* one record's partial inputs into the global record of its group */
+#define GPUPREAGG_HASH_MERGE_ROW(grec)													\
+	do {																				\
+		cl_uint		need_ = GPUPREAGG_FLAG_SEEN;										\
+		GPUPREAGG_AGG_LIST(X)															\
+		if ((*HASH_REC_FLAGS(grec) & need_) != need_)									\
+			atomicOr(HASH_REC_FLAGS(grec), need_);										\
+	} while (0)
+
 /*
- * a work-group takes units: the unit's records into a fresh LDS table, then the
- * table's groups to the global one.  CLAIM_ONLY: keys only, under claim_limit.
+ * A work-group takes units.  A unit is all or nothing:
+ *   accumulate  the unit's records into a fresh LDS table (a record that finds no room
+ *               there only makes sure its group has a slot in the global table)
+ *   resolve     every group of the LDS table finds or claims its global slot, under
+ *               claim_limit.  A new group that does not fit: the unit goes on the redo
+ *               list with nothing merged -- the host grows the table and runs the list
+ *   merge       the LDS table's accumulators to the resolved slots; if some records had
+ *               no room in LDS, the unit's records are read again and those (the ones
+ *               the LDS table does not know) are merged one by one
+ * so no claim pass over the whole chunk is needed to keep the fill limit.
  */
-template <bool CLAIM_ONLY>
 __device__ __forceinline__ void
 gpupreagg_hash_fold_units(kern_gpupreagg *kgpreagg, char *htab, cl_uint claim_limit,
 						  gpupreagg_part_ctl *ctl, const cl_uint *units, const cl_ulong *records,
-						  cl_uint lds_slots, char *lds)
+						  cl_uint lds_slots, const cl_uint *todo, cl_uint ntodo, cl_uint *redo, char *lds)
 {
 	gpupreagg_hash_head *head = (gpupreagg_hash_head *)htab;
 	gpupreagg_lds_layout L;
 	gpupreagg_hash_lds T;
-	cl_uint		nunits = ctl->nunits;
+	cl_uint		nunits = (todo ? ntodo : ctl->nunits);
 
 	if (kgpreagg->status != StromError_Success)
 		return;
@@ -3419,162 +3623,173 @@ gpupreagg_hash_fold_units(kern_gpupreagg *kgpreagg, char *htab, cl_uint claim_li
 	T.keys = (cl_ulong *)(T.knull + lds_slots);
 	T.mask = lds_slots - 1;
 	T.shift = 32 - (31 - __clz((int)lds_slots));
-	for (cl_uint unit = blockIdx.x; unit < nunits; unit += gridDim.x)
+	cl_uint	   *uflags = (cl_uint *)(T.keys + (size_t)lds_slots * GPUPREAGG_NKEYS);	/* deferred, spilled */
+	for (cl_uint u = blockIdx.x; u < nunits; u += gridDim.x)
 	{
+		cl_uint		unit = (todo ? todo[u] : u);
 		const cl_ulong *base = records + (size_t)units[2 * unit] * GPUPREAGG_REC_WORDS;
 		cl_uint		count = units[2 * unit + 1];
 
-		if (!CLAIM_ONLY)
-			gpupreagg_lds_init(lds, L, lds_slots, 1);
+		gpupreagg_lds_init(lds, L, lds_slots, 1);
 		for (cl_uint i = threadIdx.x; i < lds_slots; i += blockDim.x)
 			T.state[i] = 0;
+		if (threadIdx.x < 2)
+			uflags[threadIdx.x] = 0;
 		__syncthreads();
-		for (cl_uint i0 = 0; i0 < count; i0 += GPUPREAGG_HASH_UNROLL * blockDim.x)
+		/* pass 0: accumulate.  pass 1 (only after a merge with spilled records): those records */
+		for (int pass = 0; pass < 2; pass++)
 		{
-			cl_ulong	w[GPUPREAGG_HASH_UNROLL][GPUPREAGG_REC_WORDS];
-#pragma unroll
-			for (int j = 0; j < GPUPREAGG_HASH_UNROLL; j++)
+			for (cl_uint i0 = 0; i0 < count; i0 += GPUPREAGG_HASH_UNROLL * blockDim.x)
 			{
-				cl_uint		i = i0 + j * blockDim.x + threadIdx.x;
-				const cl_ulong *rec = base + (size_t)(i < count ? i : 0) * GPUPREAGG_REC_WORDS;
-				/* (the claim pass needs the head and the keys only: the same lines, fewer registers) */
-				if (!CLAIM_ONLY)
-					gpupreagg_rec_load<GPUPREAGG_REC_WORDS>(w[j], rec);
-				else if ((GPUPREAGG_REC_WORDS & 1) == 0)
-					gpupreagg_rec_load<((2 + GPUPREAGG_NKEYS) & ~1)>(w[j], rec);	/* whole 16-byte pieces */
-				else
-				{
-					for (int q = 0; q < 1 + GPUPREAGG_NKEYS; q++)
-						w[j][q] = rec[q];
-				}
-			}
+				cl_ulong	w[GPUPREAGG_HASH_UNROLL][GPUPREAGG_REC_WORDS];
 #pragma unroll
-			for (int j = 0; j < GPUPREAGG_HASH_UNROLL; j++)
-			{
-				if (i0 + j * blockDim.x + threadIdx.x >= count)
-					continue;
-				cl_ulong	kimg[GPUPREAGG_NKEYS + 1];
-				cl_uint		knull = (cl_uint)w[j][0];
-				cl_uint		abits = (cl_uint)(w[j][0] >> 32);
-				for (int k = 0; k < GPUPREAGG_NKEYS; k++)
-					kimg[k] = w[j][1 + k];
-				cl_uint		hash = gpupreagg_hash_of(kimg, knull);
-				if ((GPUPREAGG_ABLATE & 128) && hash != 12345u)
-					continue;
-				cl_uint		lslot = gpupreagg_hash_lds_slot(T, hash, kimg, knull);
-				if (lslot != ~0u && CLAIM_ONLY)
-					continue;
-				/* the row's partial inputs, typed again */
-				int			vp = 1 + GPUPREAGG_NKEYS;
-#define X(aidx,resno,OP,NAME)														\
-				pg_##NAME##_t av_##aidx;											\
-				av_##aidx.isnull = false;											\
-				av_##aidx.value = 0;												\
-				if (GPUPREAGG_OP_##OP == GPUPREAGG_OP_NROWS)						\
-					av_##aidx.value = (pg_##NAME##_base_t)((abits >> aidx) & 1u);	\
-				else if (!CLAIM_ONLY)												\
-				{																	\
-					av_##aidx.isnull = !((abits >> aidx) & 1u);						\
-					gpupreagg_raw_value(w[j][vp++], &av_##aidx.value);				\
-				}
-				GPUPREAGG_AGG_LIST(X)
-#undef X
-				(void)vp;
-				cl_uint		need = GPUPREAGG_FLAG_SEEN;
-				if (lslot != ~0u)
+				for (int j = 0; j < GPUPREAGG_HASH_UNROLL; j++)
 				{
+					cl_uint		i = i0 + j * blockDim.x + threadIdx.x;
+					gpupreagg_rec_load<GPUPREAGG_REC_WORDS>(w[j], base + (size_t)(i < count ? i : 0) * GPUPREAGG_REC_WORDS);
+				}
+#pragma unroll
+				for (int j = 0; j < GPUPREAGG_HASH_UNROLL; j++)
+				{
+					if (i0 + j * blockDim.x + threadIdx.x >= count)
+						continue;
+					cl_ulong	kimg[GPUPREAGG_NKEYS + 1];
+					cl_uint		knull = (cl_uint)w[j][0];
+					cl_uint		abits = (cl_uint)(w[j][0] >> 32);
+					for (int k = 0; k < GPUPREAGG_NKEYS; k++)
+						kimg[k] = w[j][1 + k];
+					cl_uint		hash = gpupreagg_hash_of(kimg, knull);
+					if ((GPUPREAGG_ABLATE & 128) && hash != 12345u)
+						continue;
+					cl_uint		lslot = (pass == 0 ? gpupreagg_hash_lds_slot(T, hash, kimg, knull)
+											   : gpupreagg_hash_lds_find(T, hash, kimg, knull));
+					if (pass == 1 && lslot != ~0u)
+						continue;			/* merged with its group's LDS accumulators */
+					/* the row's partial inputs, typed again */
+					int			vp = 1 + GPUPREAGG_NKEYS;
 #define X(aidx,resno,OP,NAME)														\
-					need |= gpupreagg_lds_accum<GPUPREAGG_OP_##OP, aidx>(lds, L.vals_off[aidx], lslot, av_##aidx);
+					pg_##NAME##_t av_##aidx;										\
+					av_##aidx.isnull = false;										\
+					av_##aidx.value = 0;											\
+					if (GPUPREAGG_OP_##OP == GPUPREAGG_OP_NROWS)					\
+						av_##aidx.value = (pg_##NAME##_base_t)((abits >> aidx) & 1u);	\
+					else															\
+					{																\
+						av_##aidx.isnull = !((abits >> aidx) & 1u);					\
+						gpupreagg_raw_value(w[j][vp++], &av_##aidx.value);			\
+					}
 					GPUPREAGG_AGG_LIST(X)
 #undef X
-					gpupreagg_flags_t *flags = (gpupreagg_flags_t *)lds;
-					if ((flags[lslot] & need) != need)
+					(void)vp;
+					if (lslot != ~0u)
 					{
-						cl_uint *word = (cl_uint *)(lds + ((lslot * (cl_uint)sizeof(gpupreagg_flags_t)) & ~3u));
-						cl_uint	 shift = ((lslot * (cl_uint)sizeof(gpupreagg_flags_t)) & 3u) * 8u;
-						__hip_atomic_fetch_or(word, need << shift, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-					}
-					continue;
-				}
-				/* no room in the LDS table: the global one, this row alone */
-				cl_uint		slot = gpupreagg_hash_slot<true>(htab, hash, kimg, knull, claim_limit);
-				if (slot == GPUPREAGG_HASH_DEFER)
-				{
-					ctl->deferred = 1;
-					continue;
-				}
-				if (slot == GPUPREAGG_HASH_FULL)
-				{
-					head->overflow = 1;
-					continue;
-				}
-				if (CLAIM_ONLY)
-					continue;
-				char	   *grec = gpupreagg_hash_rec(htab, slot);
+						cl_uint		need = GPUPREAGG_FLAG_SEEN;
 #define X(aidx,resno,OP,NAME)														\
-				{																	\
-					typedef pg_##NAME##_base_t base_t;								\
-					bool		has = !av_##aidx.isnull;							\
-					cl_ulong	x;													\
-					if (GPUPREAGG_OP_##OP == GPUPREAGG_OP_NROWS)					\
-						x = (has ? (cl_ulong)(cl_uint)av_##aidx.value : 0);			\
-					else if (gpupreagg_is_float<base_t>::value)						\
-						x = (GPUPREAGG_OP_##OP == GPUPREAGG_OP_PSUM					\
-							 ? (cl_ulong)__double_as_longlong((cl_double)av_##aidx.value)	\
-							 : gpupreagg_f64_ordered((cl_double)av_##aidx.value));	\
-					else															\
-						x = (cl_ulong)(cl_long)av_##aidx.value;						\
-					if (GPUPREAGG_OP_##OP != GPUPREAGG_OP_NROWS && has)				\
-						need |= (2u << aidx);										\
-					if (has && !(GPUPREAGG_OP_##OP == GPUPREAGG_OP_NROWS && x == 0))	\
-						gpupreagg_hash_merge8<GPUPREAGG_OP_##OP, base_t>(HASH_REC_VALS(grec) + aidx, x);	\
+						need |= gpupreagg_lds_accum<GPUPREAGG_OP_##OP, aidx>(lds, L.vals_off[aidx], lslot, av_##aidx);
+						GPUPREAGG_AGG_LIST(X)
+#undef X
+						gpupreagg_flags_t *flags = (gpupreagg_flags_t *)lds;
+						if ((flags[lslot] & need) != need)
+						{
+							cl_uint *word = (cl_uint *)(lds + ((lslot * (cl_uint)sizeof(gpupreagg_flags_t)) & ~3u));
+							cl_uint	 shift = ((lslot * (cl_uint)sizeof(gpupreagg_flags_t)) & 3u) * 8u;
+							__hip_atomic_fetch_or(word, need << shift, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+						}
+						continue;
+					}
+					/* no room in the LDS table.  pass 0: a slot for the group; pass 1: merge */
+					cl_uint		slot = gpupreagg_hash_slot<true>(htab, hash, kimg, knull, pass == 0 ? claim_limit : ~0u);
+					if (slot == GPUPREAGG_HASH_DEFER)
+					{
+						uflags[0] = 1;
+						continue;
+					}
+					if (slot == GPUPREAGG_HASH_FULL)
+					{
+						head->overflow = 1;
+						continue;
+					}
+					if (pass == 0)
+					{
+						uflags[1] = 1;
+						continue;
+					}
+					char	   *grec = gpupreagg_hash_rec(htab, slot);
+#define X(aidx,resno,OP,NAME)														\
+					{																\
+						typedef pg_##NAME##_base_t base_t;							\
+						bool		has = !av_##aidx.isnull;						\
+						cl_ulong	x;												\
+						if (GPUPREAGG_OP_##OP == GPUPREAGG_OP_NROWS)				\
+							x = (has ? (cl_ulong)(cl_uint)av_##aidx.value : 0);		\
+						else if (gpupreagg_is_float<base_t>::value)					\
+							x = (GPUPREAGG_OP_##OP == GPUPREAGG_OP_PSUM				\
+								 ? (cl_ulong)__double_as_longlong((cl_double)av_##aidx.value)	\
+								 : gpupreagg_f64_ordered((cl_double)av_##aidx.value));	\
+						else														\
+							x = (cl_ulong)(cl_long)av_##aidx.value;					\
+						if (GPUPREAGG_OP_##OP != GPUPREAGG_OP_NROWS && has)			\
+							need_ |= (2u << aidx);									\
+						if (has && !(GPUPREAGG_OP_##OP == GPUPREAGG_OP_NROWS && x == 0))	\
+							gpupreagg_hash_merge8<GPUPREAGG_OP_##OP, base_t>(HASH_REC_VALS(grec) + aidx, x);	\
+					}
+					GPUPREAGG_HASH_MERGE_ROW(grec);
+#undef X
 				}
+			}
+			if (pass == 1)
+				break;
+			/* resolve: the LDS table's groups find or claim their global slots */
+			const gpupreagg_flags_t *lflags = (const gpupreagg_flags_t *)lds;
+			__syncthreads();
+			for (cl_uint s = threadIdx.x; s < lds_slots; s += blockDim.x)
+			{
+				if (T.state[s] != 2 || ((GPUPREAGG_ABLATE & 64) && unit > 0))
+					continue;
+				cl_ulong	kimg[GPUPREAGG_NKEYS + 1];
+				cl_uint		knull = T.knull[s];
+				for (int k = 0; k < GPUPREAGG_NKEYS; k++)
+					kimg[k] = T.keys[s * GPUPREAGG_NKEYS + k];
+				cl_uint		slot = gpupreagg_hash_slot<true>(htab, gpupreagg_hash_of(kimg, knull), kimg, knull, claim_limit);
+				if (slot == GPUPREAGG_HASH_DEFER)
+					uflags[0] = 1;
+				else if (slot == GPUPREAGG_HASH_FULL)
+					head->overflow = 1;
+				else
+					T.state[s] = 3 + slot;
+			}
+			__syncthreads();
+			if (uflags[0] != 0)
+			{
+				/* a new group did not fit under the limit: nothing of this unit is merged */
+				if (threadIdx.x == 0)
+					redo[__hip_atomic_fetch_add(&ctl->deferred, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)] = unit;
+				break;
+			}
+			for (cl_uint s = threadIdx.x; s < lds_slots; s += blockDim.x)
+			{
+				cl_uint		st = T.state[s];
+				if (st < 3)
+					continue;
+				char	   *grec = gpupreagg_hash_rec(htab, st - 3);
+				cl_uint		lf = lflags[s];
+#define X(aidx,resno,OP,NAME)														\
+				if (GPUPREAGG_OP_##OP == GPUPREAGG_OP_NROWS)						\
+				{																	\
+					cl_uint c = ((const cl_uint *)(lds + L.vals_off[aidx]))[s];		\
+					if (c != 0)														\
+						gpupreagg_hash_merge8<GPUPREAGG_OP_NROWS, cl_long>(HASH_REC_VALS(grec) + aidx, (cl_ulong)c);	\
+				}																	\
+				else if (lf & (2u << aidx))											\
+					gpupreagg_hash_merge8<GPUPREAGG_OP_##OP, pg_##NAME##_base_t>	\
+						(HASH_REC_VALS(grec) + aidx, ((const cl_ulong *)(lds + L.vals_off[aidx]))[s]);
 				GPUPREAGG_AGG_LIST(X)
 #undef X
-				if ((*HASH_REC_FLAGS(grec) & need) != need)
-					atomicOr(HASH_REC_FLAGS(grec), need);
+				if ((*HASH_REC_FLAGS(grec) & lf) != lf)
+					atomicOr(HASH_REC_FLAGS(grec), lf);
 			}
-		}
-		/* the unit's groups: found or claimed, merged */
-		const gpupreagg_flags_t *lflags = (const gpupreagg_flags_t *)lds;
-		__syncthreads();
-		for (cl_uint s = threadIdx.x; s < lds_slots; s += blockDim.x)
-		{
-			if (T.state[s] != 2 || ((GPUPREAGG_ABLATE & 64) && unit > 0))
-				continue;
-			cl_ulong	kimg[GPUPREAGG_NKEYS + 1];
-			cl_uint		knull = T.knull[s];
-			for (int k = 0; k < GPUPREAGG_NKEYS; k++)
-				kimg[k] = T.keys[s * GPUPREAGG_NKEYS + k];
-			cl_uint		slot = gpupreagg_hash_slot<true>(htab, gpupreagg_hash_of(kimg, knull), kimg, knull, claim_limit);
-			if (slot == GPUPREAGG_HASH_DEFER)
-			{
-				ctl->deferred = 1;
-				continue;
-			}
-			if (slot == GPUPREAGG_HASH_FULL)
-			{
-				head->overflow = 1;
-				continue;
-			}
-			if (CLAIM_ONLY)
-				continue;
-			char	   *grec = gpupreagg_hash_rec(htab, slot);
-			cl_uint		lf = lflags[s];
-#define X(aidx,resno,OP,NAME)														\
-			if (GPUPREAGG_OP_##OP == GPUPREAGG_OP_NROWS)							\
-			{																		\
-				cl_uint c = ((const cl_uint *)(lds + L.vals_off[aidx]))[s];			\
-				if (c != 0)															\
-					gpupreagg_hash_merge8<GPUPREAGG_OP_NROWS, cl_long>(HASH_REC_VALS(grec) + aidx, (cl_ulong)c);	\
-			}																		\
-			else if (lf & (2u << aidx))												\
-				gpupreagg_hash_merge8<GPUPREAGG_OP_##OP, pg_##NAME##_base_t>		\
-					(HASH_REC_VALS(grec) + aidx, ((const cl_ulong *)(lds + L.vals_off[aidx]))[s]);
-			GPUPREAGG_AGG_LIST(X)
-#undef X
-			if ((*HASH_REC_FLAGS(grec) & lf) != lf)
-				atomicOr(HASH_REC_FLAGS(grec), lf);
+			if (uflags[1] == 0)
+				break;						/* (uniform: read after the barrier above) */
 		}
 		__syncthreads();
 	}
@@ -3584,13 +3799,10 @@ extern "C" __global__ void
 __launch_bounds__(GPUPREAGG_BLOCK)
 gpupreagg_hash_fold_parts(kern_gpupreagg *kgpreagg, char *htab, cl_uint claim_limit,
 						  gpupreagg_part_ctl *ctl, const cl_uint *units, const cl_ulong *records,
-						  cl_uint lds_slots, cl_uint claim_only)
+						  cl_uint lds_slots, const cl_uint *todo, cl_uint ntodo, cl_uint *redo)
 {
 	extern __shared__ __attribute__((aligned(16))) char lds[];
-	if (claim_only)
-		gpupreagg_hash_fold_units<true>(kgpreagg, htab, claim_limit, ctl, units, records, lds_slots, lds);
-	else
-		gpupreagg_hash_fold_units<false>(kgpreagg, htab, claim_limit, ctl, units, records, lds_slots, lds);
+	gpupreagg_hash_fold_units(kgpreagg, htab, claim_limit, ctl, units, records, lds_slots, todo, ntodo, redo, lds);
 }
 
 /* min / max accumulators start from their identities (sums from the zeroed table) */

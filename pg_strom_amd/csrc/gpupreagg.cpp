@@ -885,7 +885,7 @@ hash_lds_slots(const strom_gpupreagg *sess, size_t *p_bytes, bool for_units = fa
 {
 	size_t		nkeys = sess->key_resno.size();
 	/* after the table: 256 queued row numbers per wave (GPUPREAGG_HASH_QUEUE, used with roles) */
-	size_t		queue = (for_units ? 0 : ((size_t)sess->block / 64) * 256 * sizeof(cl_uint));
+	size_t		queue = (for_units ? 16 /* the unit's flags */ : ((size_t)sess->block / 64) * 256 * sizeof(cl_uint));
 	auto fit = [&](size_t budget, size_t *p_b) -> cl_uint {
 		cl_uint	slots = 16384;
 		for (;;)
@@ -1133,7 +1133,7 @@ gpupreagg_launch_hashed(strom_task_impl *task, preagg_request req)
 	 * unit by unit (strom_gpupreagg.h: gpupreagg_hash_check_parts ... _fold_parts).  1e8 rows,
 	 * 1e5 / 1e6 groups: 23 / 42 ms through the global table; profiles/r02_hashed_partitions.txt
 	 */
-	cl_ulong	parts_min = 20000;
+	cl_ulong	parts_min = 10000;
 	if (const char *v = getenv("STROM_GPUPREAGG_HASH_PARTS_MIN"))
 		parts_min = strtoul(v, nullptr, 10);
 	bool		use_parts = (req.nrows > 0 && (cl_ulong)sess->groups_known >= parts_min &&
@@ -1143,19 +1143,25 @@ gpupreagg_launch_hashed(strom_task_impl *task, preagg_request req)
 		hipFunction_t fn_pcheck = prog->get_function(dev, "gpupreagg_hash_check_parts", &errcode);
 		hipFunction_t fn_plan = fn_pcheck ? prog->get_function(dev, "gpupreagg_hash_part_plan", &errcode) : nullptr;
 		hipFunction_t fn_scatter = fn_plan ? prog->get_function(dev, "gpupreagg_hash_scatter", &errcode) : nullptr;
-		hipFunction_t fn_units = fn_scatter ? prog->get_function(dev, "gpupreagg_hash_fold_parts", &errcode) : nullptr;
+		hipFunction_t fn_scatter_lds = fn_scatter ? prog->get_function(dev, "gpupreagg_hash_scatter_lds", &errcode) : nullptr;
+		hipFunction_t fn_units = fn_scatter_lds ? prog->get_function(dev, "gpupreagg_hash_fold_parts", &errcode) : nullptr;
 		if (!fn_units)
 		{
 			task_fail(task, errcode);
 			return;
 		}
 		cl_uint		nrows = req.nrows;
-		/* partitions: a unit's groups should fill at most ~5/16 of the LDS table */
-		cl_uint		nparts = 2048;
+		/*
+		 * partitions: as few as keep a partition's groups within 5/8 of a unit's LDS table --
+		 * the fewer, the longer the runs the scatter writes (a tile of ~4096 rows leaves in
+		 * runs of 4096 / nparts records)
+		 */
+		cl_uint		nparts = 512;
 		{
 			size_t	b;
-			if ((cl_ulong)sess->groups_known > (cl_ulong)nparts * hash_lds_slots(sess, &b, true) * 5 / 16)
-				nparts = 4096;
+			cl_ulong per_unit = (cl_ulong)hash_lds_slots(sess, &b, true) * 5 / 8;
+			while (nparts < 4096 && (cl_ulong)sess->groups_known > (cl_ulong)nparts * per_unit)
+				nparts <<= 1;
 		}
 		if (const char *v = getenv("STROM_GPUPREAGG_HASH_PARTS"))
 		{
@@ -1163,7 +1169,10 @@ gpupreagg_launch_hashed(strom_task_impl *task, preagg_request req)
 			if (want >= 64 && want <= 4096 && (want & (want - 1)) == 0)
 				nparts = (cl_uint)want;
 		}
-		cl_uint		unit_rows = 32768;
+		/* a unit is a whole partition unless the partition is four times the average (one
+		 * heavy key must not be one work-group's job): every unit ends in a flush of its
+		 * groups to the global table, the fewer the better */
+		cl_uint		unit_rows = std::max<cl_uint>(32768, (cl_uint)std::min<cl_ulong>(1u << 30, 4 * (cl_ulong)nrows / nparts));
 		if (const char *v = getenv("STROM_GPUPREAGG_HASH_UNIT_ROWS"))
 			unit_rows = std::max(1024, atoi(v));
 		cl_uint		log2cap = 0, log2parts = 0;
@@ -1178,7 +1187,8 @@ gpupreagg_launch_hashed(strom_task_impl *task, preagg_request req)
 		cl_uint		max_units = nparts + nrows / unit_rows + 1;
 		struct part_ctl { cl_uint nparts, pshift, unit_rows, nunits, nrecords, deferred, max_units, reclen; } ctl_img;
 		ctl_img = part_ctl{ nparts, (log2cap > log2parts ? log2cap - log2parts : 0), unit_rows, 0, 0, 0, max_units, 0 };
-		size_t		ctl_len = sizeof(part_ctl) + sizeof(cl_uint) * ((size_t)2 * nparts + (size_t)2 * max_units);
+		/* ctl | hist[P] | cursor[P] | units[2 * max_units] | two redo lists of max_units */
+		size_t		ctl_len = sizeof(part_ctl) + sizeof(cl_uint) * ((size_t)2 * nparts + (size_t)4 * max_units);
 		char	   *d_ctl = (char *)dev->pool.alloc(ctl_len);
 		char	   *d_partmap = (char *)dev->pool.alloc(STROMALIGN((size_t)nrows * sizeof(cl_ushort)));
 		char	   *d_records = (char *)dev->pool.alloc((size_t)nrows * reclen);
@@ -1218,6 +1228,25 @@ gpupreagg_launch_hashed(strom_task_impl *task, preagg_request req)
 			REQ_CHECK(hipModuleLaunchKernel(fn_plan, 1, 1, 1, 256, 1, 1, 0, task->stream, args, nullptr),
 					  "launch gpupreagg partition plan");
 		}
+		/* the scatter goes through LDS (records leave in runs) when a tile of at least one row
+		 * per thread fits next to the partitions' counters */
+		size_t		stage_fixed = 12 * (size_t)nparts + 128;
+		size_t		stage_budget = 159 * 1024;
+		cl_uint		lds_rows = 0;
+		if (nparts <= 4 * block && stage_fixed < stage_budget && !getenv("STROM_GPUPREAGG_HASH_NO_LDS_SCATTER"))
+			lds_rows = (cl_uint)std::min<size_t>(4, (stage_budget - stage_fixed) / ((reclen + 2) * block));
+		if (lds_rows > 0)
+		{
+			size_t		stage_bytes = stage_fixed + (size_t)lds_rows * block * (reclen + 2);
+			void	   *args[] = { &a_kg, &a_kds, &a_toast, &a_map, &a_partmap, &a_cursor, &a_records, &a_ctl, &lds_rows };
+			size_t		tile = (size_t)block * lds_rows;
+			unsigned	grid = (unsigned)std::max<size_t>(1, std::min<size_t>((nrows + tile - 1) / tile,
+																			   (size_t)ncus * (stage_bytes <= 72 * 1024 ? 2 : 1)));
+			REQ_CHECK(hipModuleLaunchKernel(fn_scatter_lds, grid, 1, 1, block, 1, 1, (unsigned)stage_bytes,
+											task->stream, args, nullptr),
+					  "launch gpupreagg hash scatter (LDS)");
+		}
+		else
 		{
 			void	   *args[] = { &a_kg, &a_kds, &a_toast, &a_map, &a_partmap, &a_cursor, &a_records, &a_ctl };
 			size_t		tile = (size_t)block * 32;
@@ -1228,14 +1257,16 @@ gpupreagg_launch_hashed(strom_task_impl *task, preagg_request req)
 		task->pfm.num_kern_exec += 3;
 		task->pfm.num_kern_prep++;				/* (reported: this request took the partition plan) */
 		/*
-		 * claim pass(es): after them every group of the chunk has its slot.  Needed only
-		 * while nrows new groups would not fit under the fill limit.
+		 * fold, unit by unit.  While even nrows new groups fit under the fill limit the
+		 * task stays asynchronous; otherwise a unit with a new group beyond the limit comes
+		 * back on the redo list with nothing merged: the table grows and the list is run.
 		 */
-		void	   *a_tab;
-		cl_uint		claim_only = 1;
 		size_t		lds_bytes = 0;				/* (the units' table, not the roles') */
 		cl_uint		lds_slots = hash_lds_slots(sess, &lds_bytes, true);
 		unsigned	fold_grid = ncus * (lds_bytes <= 72 * 1024 ? 2 : 1);
+		char	   *d_lists = d_ctl + sizeof(part_ctl) + sizeof(cl_uint) * ((size_t)2 * nparts + (size_t)2 * max_units);
+		void	   *a_todo = nullptr;
+		cl_uint		ntodo = 0;
 		for (int turn = 0;; turn++)
 		{
 			cl_ulong	fill_limit = (cl_ulong)sess->hash_capacity / 8 * 7 - headroom;
@@ -1256,35 +1287,34 @@ gpupreagg_launch_hashed(strom_task_impl *task, preagg_request req)
 				}
 				fill_limit = (cl_ulong)sess->hash_capacity / 8 * 7 - headroom;
 			}
-			if (sess->groups_upper + nrows <= fill_limit)
-				break;
-			cl_uint		claim_limit = (cl_uint)fill_limit;
-			cl_int		deferred = 0;
-			a_tab = sess->htab;
-			REQ_CHECK(hipMemsetAsync(d_ctl + offsetof(part_ctl, deferred), 0, sizeof(cl_uint), task->stream),
-					  "reset the claim pass");
-			void	   *args[] = { &a_kg, &a_tab, &claim_limit, &a_ctl, &a_units, &a_records, &lds_slots, &claim_only };
-			REQ_CHECK(hipModuleLaunchKernel(fn_units, fold_grid, 1, 1, block, 1, 1, (unsigned)lds_bytes,
-											task->stream, args, nullptr),
-					  "launch gpupreagg hash claim");
-			task->pfm.num_kern_exec++;
-			REQ_CHECK(hipMemcpyAsync(&deferred, d_ctl + offsetof(part_ctl, deferred), sizeof(cl_int),
-									 hipMemcpyDeviceToHost, task->stream),
-					  "recv claim pass");
-			REQ_CHECK(hipStreamSynchronize(task->stream), "claim pass");
-			if (!deferred)
-				break;
-		}
-		{
-			cl_uint		no_limit = ~0u;
-			cl_uint		fold_all = 0;
-			a_tab = sess->htab;
-			void	   *args[] = { &a_kg, &a_tab, &no_limit, &a_ctl, &a_units, &a_records, &lds_slots, &fold_all };
+			bool		may_defer = (sess->groups_upper + nrows > fill_limit);
+			cl_uint		claim_limit = (may_defer ? (cl_uint)fill_limit : ~0u);
+			void	   *a_tab = sess->htab;
+			void	   *a_redo = d_lists + sizeof(cl_uint) * (size_t)max_units * (turn & 1);
+			if (may_defer)
+				REQ_CHECK(hipMemsetAsync(d_ctl + offsetof(part_ctl, deferred), 0, sizeof(cl_uint), task->stream),
+						  "reset the redo list");
+			void	   *args[] = { &a_kg, &a_tab, &claim_limit, &a_ctl, &a_units, &a_records, &lds_slots,
+								   &a_todo, &ntodo, &a_redo };
 			REQ_CHECK(hipModuleLaunchKernel(fn_units, fold_grid, 1, 1, block, 1, 1, (unsigned)lds_bytes,
 											task->stream, args, nullptr),
 					  "launch gpupreagg hash fold (partitions)");
 			task->pfm.num_kern_exec++;
+			if (!may_defer)
+			{
+				sess->groups_upper += nrows;
+				break;
+			}
+			cl_uint		nredo = 0;
+			REQ_CHECK(hipMemcpyAsync(&nredo, d_ctl + offsetof(part_ctl, deferred), sizeof(cl_uint),
+									 hipMemcpyDeviceToHost, task->stream),
+					  "recv redo list");
+			REQ_CHECK(hipStreamSynchronize(task->stream), "fold (partitions)");
 			sess->groups_upper = std::min<cl_ulong>(sess->groups_upper + nrows, sess->hash_capacity);
+			if (nredo == 0)
+				break;
+			a_todo = a_redo;
+			ntodo = nredo;
 		}
 	}
 	else
