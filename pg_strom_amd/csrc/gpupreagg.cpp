@@ -1156,7 +1156,7 @@ gpupreagg_launch_hashed(strom_task_impl *task, preagg_request req)
 		 * the fewer, the longer the runs the scatter writes (a tile of ~4096 rows leaves in
 		 * runs of 4096 / nparts records)
 		 */
-		cl_uint		nparts = 512;
+		cl_uint		nparts = 256;
 		{
 			size_t	b;
 			cl_ulong per_unit = (cl_ulong)hash_lds_slots(sess, &b, true) * 5 / 8;
@@ -1235,6 +1235,8 @@ gpupreagg_launch_hashed(strom_task_impl *task, preagg_request req)
 		cl_uint		lds_rows = 0;
 		if (nparts <= 4 * block && stage_fixed < stage_budget && !getenv("STROM_GPUPREAGG_HASH_NO_LDS_SCATTER"))
 			lds_rows = (cl_uint)std::min<size_t>(4, (stage_budget - stage_fixed) / ((reclen + 2) * block));
+		if (const char *v = getenv("STROM_GPUPREAGG_HASH_SCATTER_ROWS"))
+			lds_rows = std::min<cl_uint>(lds_rows, (cl_uint)std::max(1, atoi(v)));
 		if (lds_rows > 0)
 		{
 			size_t		stage_bytes = stage_fixed + (size_t)lds_rows * block * (reclen + 2);
