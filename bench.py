@@ -47,6 +47,7 @@ sys.path.insert(0, ROOT)
 
 C2_QUAL = "(and (int4lt (var 1 int4) (param 0 int4)) (float8gt (var 2 float8) (param 1 float8)))"
 C3_JOIN = "(gpuhashjoin (rel (hashkey (var 1 int4) 1 int4)))"
+HASHED_AGG = "(gpupreagg (key (var 1 int8)) (nrows) (psum (int8 (var 2 int4))) (psum (var 3 float8)))"
 C4_AGG = "(gpupreagg (key (var 1 int4)) (nrows) (psum (int8 (var 2 int4))) (psum (var 3 float8)))"
 CHAIN_QUAL = "(and (int4lt (var 2 int4) (param 0 int4)) (float8gt (var 3 float8) (param 1 float8)))"
 CHAIN_AGG = "(gpupreagg (qual " + CHAIN_QUAL + ") " + C4_AGG[len("(gpupreagg "):]
@@ -500,6 +501,48 @@ def operator_figures(args, k, c, measured_peak, cpu_blocks):
         roofline=roofline_block("gpuscan_qual_generic", float(row_bytes) + 4.0 * nsel_row, gen_ns[1:], measured_peak),
         roofline_ingest=roofline_block("ingest_to_column(+ingest_minmax)", float(row_bytes) + 12.0 * nrow,
                                        ing_ns[1:], measured_peak))
+
+    # ---- hashed GROUP BY: a key the dense ids cannot express (sparse int8), 1e6 groups ----
+    # (C4's targets; the chunk is ordered by hash partition through LDS and folded unit by unit)
+    hg = 1_000_000
+    gen = _gen(0x5eed0014)
+    grp = torch.randint(0, hg, (chunk_rows,), dtype=torch.int64, device="cuda", generator=gen)
+    hx = torch.randint(-10**6, 10**6, (chunk_rows,), dtype=torch.int32, device="cuda", generator=gen)
+    hy = torch.rand(chunk_rows, dtype=torch.float64, device="cuda", generator=gen) * 100.0
+    hkey = grp * (1000003 * 65537) - 2**59
+    hcnt = torch.bincount(grp, minlength=hg)
+    hsx = torch.zeros(hg, dtype=torch.int64, device="cuda").index_add_(0, grp, hx.long())
+    hds = runtime.DeviceStore.from_torch_columns(["int8", "int4", "float8"], [hkey, hx, hy],
+                                                 [_minmax(hkey), _minmax(hx), _minmax(hy)])
+    del grp, hx, hy
+    agg = GpuPreAgg(HASHED_AGG).begin_hashed(ngroups_hint=hg)
+    walls, kerns, plan = [], [], True
+    nfold = 5
+    for step in range(nfold):
+        t0 = time.perf_counter()
+        st, pfm = agg.fold(hds)
+        walls.append(time.perf_counter() - t0)
+        assert st == 0, "hashed fold status %d" % st
+        kerns.append(pfm["time_kern_exec_ns"])
+        plan = plan and bool(pfm["num_kern_prep"])
+    pr = agg.fetch()
+    agg.end()
+    hds.release()
+    order = np.argsort(pr.column(0)[0])
+    hcnt, hsx = hcnt.cpu().numpy(), hsx.cpu().numpy()
+    assert np.array_equal(pr.column(0)[0][order], np.sort(hkey.unique().cpu().numpy())), "hashed GROUP BY: keys differ"
+    assert np.array_equal(pr.column(1)[0][order], hcnt[hcnt > 0] * nfold), "hashed GROUP BY: counts differ"
+    assert np.array_equal(pr.column(2)[0][order], hsx[hcnt > 0] * nfold), "hashed GROUP BY: integer sums differ"
+    del hkey
+    torch.cuda.empty_cache()
+    out["hashed_groupby_1e6"] = dict(
+        workload="GpuPreAgg, hashed GROUP BY: %d rows, int8 key spread over 2^60 (%d groups), COUNT/SUM(int4)/SUM(float8); "
+                 "%s" % (chunk_rows, len(pr), "hash partitions through LDS, folded unit by unit (check + plan + scatter + fold)"
+                         if plan else "global table"),
+        value=chunk_rows / float(np.median(walls[2:])) / 1e6, unit="Mrows/s", groups=len(pr),
+        checked="keys, counts and integer sums equal torch's",
+        roofline=roofline_block("gpupreagg_hash_check_parts+_scatter_lds+_fold_parts (whole chunk)",
+                                20.0 * chunk_rows, kerns[2:], measured_peak))
 
     # ---- C5: TPC-H Q1-shaped scan + filter + group-by on numeric / date columns ----------
     # twice: the numeric(p,s) columns as int8 at their scale (decimal columns: what the device
