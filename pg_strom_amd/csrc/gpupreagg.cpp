@@ -2873,12 +2873,36 @@ strom_submit_gpupreagg_chunk(strom_devprog_key key,
 			}
 			strom_preagg_domain dom;
 			rc = chunk_domain(key, prog, dev, tg.data(), ntargets, kparams, src, krowmap, &dom);
+			uint32_t hint = (num_groups > 0 && num_groups < 4e9 ? (uint32_t)num_groups : 0);
 			if (rc == 0)
+			{
+				/*
+				 * dense ids past ~1.6e5: the dense kernels split them over id-range roles that
+				 * each read every row (1e5 ids: 1.4 ms per 1e8 rows, 64 roles at most), the
+				 * hashed GROUP BY's partition plan takes 2.3 ms whatever the count
+				 * (profiles/r02_dense_vs_hashed.txt)
+				 */
+				double	ids = 1.0;
+				int		nk = 0;
+				for (int i = 0; i < ntargets; i++)
+				{
+					if (tg[i].kind == STROM_PREAGG_KEY && nk < STROM_PREAGG_MAXKEYS)
+						ids *= (double)dom.key_range[nk++];
+				}
+				if (ids > 160000.0 && !getenv("STROM_GPUPREAGG_CHUNK_DENSE_ONLY"))
+				{
+					double	bound = std::min(ids, std::max(1.0, (double)src->head.nitems / 8));
+					int		rc2 = 0;
+					sess = strom_gpupreagg_create_hashed(key, tg.data(), ntargets, kparams,
+														 hint ? hint : (uint32_t)std::min(bound, 4.0e6), dindex, &rc2);
+					/* (what the hashed kernels do not take -- 64-bit numeric partials -- stays dense) */
+				}
+			}
+			if (rc == 0 && !sess)
 				sess = strom_gpupreagg_create(key, tg.data(), ntargets, kparams, &dom, dindex, &rc);
 			if (!sess && rc == StromError_DataStoreOutOfRange)
 			{
 				/* keys without dense ids (float / numeric / sparse): hashed GROUP BY */
-				uint32_t hint = (num_groups > 0 && num_groups < 4e9 ? (uint32_t)num_groups : 0);
 				rc = 0;
 				sess = strom_gpupreagg_create_hashed(key, tg.data(), ntargets, kparams, hint, dindex, &rc);
 			}

@@ -707,7 +707,14 @@ def test_partition_plan_any_keys_every_partial_kind(partitions, fmt):
         compare_with_oracle(spec, bufs, None, ext=[np.int32(-250000)], hashed=True, resident=True)
 
 
-def test_partition_plan_claims_new_groups_and_grows_the_table(partitions):
+@pytest.mark.parametrize("lds_scatter", [True, False])
+def test_partition_plan_claims_new_groups_and_grows_the_table(partitions, monkeypatch, lds_scatter):
+    """4M distinct keys from an empty table: units with a new group beyond the fill limit come back
+    on the redo list, the table grows; 256 partitions of ~6000 new keys each overflow the units' LDS
+    tables, so the second pass over a unit (records the LDS table does not know) runs too.  Also
+    with the direct scatter (records too long for an LDS tile take it)."""
+    if not lds_scatter:
+        monkeypatch.setenv("STROM_GPUPREAGG_HASH_NO_LDS_SCATTER", "1")
     test_hashed_table_grows_with_the_group_count()
 
 
@@ -886,6 +893,33 @@ def test_chunk_message_keys_without_dense_ids_take_the_hashed_table():
         want = sorted((tuple(int(a) for a in v[i]), tuple(bool(b) for b in nn[i])) for i in range(len(v)))
         got = sorted((tuple(int(a) for a in got_v[i]), tuple(bool(b) for b in got_n[i])) for i in range(len(v)))
         assert got == want
+
+
+def test_chunk_message_with_very_many_dense_ids_takes_the_partition_plan(monkeypatch):
+    """two int4 keys whose ranges multiply to 1e6 ids: the dense kernels would split them over
+    dozens of id-range roles, each reading every row; the message goes to the hashed GROUP BY's
+    partition plan instead (num_kern_prep reports it) -- and gives the dense path's partial rows"""
+    rng = np.random.default_rng(15)
+    n = 700000
+    k1 = rng.integers(-500, 500, n).astype(np.int32)
+    k2 = rng.integers(0, 1000, n).astype(np.int32)
+    x = rng.integers(-1000, 1000, n).astype(np.int32)
+    buf = kds.build_kds("column", [kds.Column("int4", k1), kds.Column("int4", k2), kds.Column("int4", x, rng.random(n) < 0.02)])
+    spec = "(gpupreagg (key (var 1 int4)) (key (var 2 int4)) (nrows) (psum (int8 (var 3 int4))) (pmax (var 3 int4)))"
+    rows = []
+    for dense_only in (False, True):
+        if dense_only:
+            monkeypatch.setenv("STROM_GPUPREAGG_CHUNK_DENSE_ONLY", "1")
+        agg = GpuPreAgg(spec)
+        pending = agg.submit_chunk(buf, dest_rooms=n)
+        status, pr = agg.collect_chunk(pending)
+        assert status == 0
+        v, isn = partial_rows_as_raw8(pr)
+        o = np.lexsort((v[:, 1].view(np.int64), v[:, 0].view(np.int64)))
+        rows.append((v[o], isn[o]))
+    assert np.array_equal(rows[0][0], rows[1][0]) and np.array_equal(rows[0][1], rows[1][1])
+    uk, inv = np.unique(k1.astype(np.int64) * 4096 + k2, return_inverse=True)
+    assert len(rows[0][0]) == len(uk) and np.array_equal(rows[0][0][:, 2].view(np.int64), np.bincount(inv))
 
 
 def test_chunk_message_recheck_and_no_space():
