@@ -540,6 +540,15 @@ strom_task *strom_submit_gpupreagg_mapped(strom_gpupreagg *sess, strom_dstore *k
  * RCCL is loaded on first use (librccl.so.1); no RCCL type crosses the ABI.
  * ------------------------------------------------------------------ */
 int			strom_gpupreagg_allreduce(strom_gpupreagg *sess, void *comm, void *stream);
+/*
+ * Hashed GROUP BY sessions (strom_gpupreagg_create_hashed) have no common table layout:
+ * strom_gpupreagg_allreduce() packs each rank's groups on the device, all-gathers the
+ * counts and the records (padded to the largest rank) and merges the other ranks' records
+ * into the rank's own table -- every rank ends up with every group, as above.
+ * strom_gpupreagg_merge() is the same merge between two hashed sessions of ONE device
+ * (same program): src's groups are added to dst's table, src is left as it is.
+ */
+int			strom_gpupreagg_merge(strom_gpupreagg *dst, strom_gpupreagg *src);
 int			strom_gpupreagg_census_allreduce(strom_gpupreagg *sess, void *comm, void *stream);
 /* communicator bootstrap for a host without its own: rank 0 makes the id
  * (strom_rccl_unique_id_bytes() bytes), hands it to the others by whatever

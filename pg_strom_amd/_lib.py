@@ -186,6 +186,7 @@ PROTOTYPES = {
     "strom_task_release": (None, [c_void_p]),
     "strom_task_devptr": (c_void_p, [c_void_p]),
     "strom_gpupreagg_allreduce": (c_int, [c_void_p, c_void_p, c_void_p]),
+    "strom_gpupreagg_merge": (c_int, [c_void_p, c_void_p]),
     "strom_gpupreagg_census_allreduce": (c_int, [c_void_p, c_void_p, c_void_p]),
     "strom_rccl_unique_id_bytes": (c_size_t, []),
     "strom_rccl_get_unique_id": (c_int, [c_void_p, c_size_t]),

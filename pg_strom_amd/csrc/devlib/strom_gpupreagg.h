@@ -3867,6 +3867,58 @@ gpupreagg_hash_export(const char *htab, char *out, cl_uint *counter)
 	}
 }
 
+/*
+ * the other way round: packed groups (another session's, another GPU's -- all-gathered by
+ * strom_gpupreagg_allreduce) merged into this table.  recs[] is nsegs segments of seg_len
+ * records of which the first counts[seg] are set; segment skip_seg (this rank's own) is left
+ * out.  The host has made room for every incoming group.
+ */
+extern "C" __global__ void
+__launch_bounds__(256)
+gpupreagg_hash_import(char *htab, const char *recs, cl_uint seg_len, cl_uint nsegs,
+					  const cl_uint *counts, cl_uint skip_seg)
+{
+	gpupreagg_hash_head *head = (gpupreagg_hash_head *)htab;
+	const size_t	reclen = 8 + 8 * (GPUPREAGG_NKEYS + GPUPREAGG_NAGGS);
+	size_t		total = (size_t)seg_len * nsegs;
+
+	for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x)
+	{
+		cl_uint		seg = (cl_uint)(i / seg_len);
+		cl_uint		j = (cl_uint)(i - (size_t)seg * seg_len);
+		if (seg == skip_seg || j >= counts[seg])
+			continue;
+		const char *rec = recs + reclen * i;
+		cl_uint		knull = ((const cl_uint *)rec)[0];
+		cl_uint		flags = ((const cl_uint *)rec)[1];
+		const cl_ulong *body = (const cl_ulong *)(rec + 8);
+		cl_ulong	kimg[GPUPREAGG_NKEYS + 1];
+		for (int k = 0; k < GPUPREAGG_NKEYS; k++)
+			kimg[k] = body[k];
+		cl_uint		slot = gpupreagg_hash_slot<true>(htab, gpupreagg_hash_of(kimg, knull), kimg, knull, ~0u);
+		if (slot == GPUPREAGG_HASH_FULL)
+		{
+			head->overflow = 1;
+			continue;
+		}
+		char	   *grec = gpupreagg_hash_rec(htab, slot);
+		const cl_ulong *vals = body + GPUPREAGG_NKEYS;
+#define X(aidx,resno,OP,NAME)														\
+		if (GPUPREAGG_OP_##OP == GPUPREAGG_OP_NROWS)								\
+		{																			\
+			if (vals[aidx] != 0)													\
+				gpupreagg_hash_merge8<GPUPREAGG_OP_NROWS, cl_long>(HASH_REC_VALS(grec) + aidx, vals[aidx]);	\
+		}																			\
+		else if (flags & (2u << aidx))												\
+			gpupreagg_hash_merge8<GPUPREAGG_OP_##OP, pg_##NAME##_base_t>(HASH_REC_VALS(grec) + aidx, vals[aidx]);
+		GPUPREAGG_AGG_LIST(X)
+#undef X
+		(void)vals;
+		if ((*HASH_REC_FLAGS(grec) & flags) != flags)
+			atomicOr(HASH_REC_FLAGS(grec), flags);
+	}
+}
+
 /* growth: every group of the old table moves to a (zeroed, initialised) larger one */
 extern "C" __global__ void
 __launch_bounds__(256)

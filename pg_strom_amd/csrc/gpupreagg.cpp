@@ -2142,6 +2142,129 @@ strom_gpupreagg_compact(strom_gpupreagg *sess, const uint32_t *bitmap, size_t nw
 }
 
 /* what parallel.cpp needs to all-reduce the resident table in place */
+bool
+strom::gpupreagg_is_hashed(strom_gpupreagg *sess, int *p_dindex)
+{
+	if (!sess || !sess->hashed)
+		return false;
+	if (p_dindex)
+		*p_dindex = sess->dev->dindex;
+	return true;
+}
+
+/* the groups of a hashed session packed on the device: { knull, flags, keys[], vals[] } each */
+int
+strom::gpupreagg_hash_export_device(strom_gpupreagg *sess, char **p_recs, cl_uint *p_count, size_t *p_reclen)
+{
+	Device *dev = sess->dev;
+	size_t	reclen = 8 + 8 * (sess->key_resno.size() + sess->agg_resno.size());
+	cl_uint	ngroups = 0, overflow = 0;
+	std::lock_guard<std::mutex> g(sess->lock);
+
+	*p_recs = nullptr;
+	*p_count = 0;
+	*p_reclen = reclen;
+	(void)hipSetDevice(dev->hip_id);
+	if (!sess->htab)
+		return 0;
+	int rc = hash_table_ngroups(sess, &ngroups, &overflow);
+	if (rc)
+		return rc;
+	if (overflow)
+		return StromError_DataStoreNoSpace;
+	if (ngroups == 0)
+		return 0;
+	int		errcode = 0;
+	hipFunction_t fn = sess->prog->get_function(dev, "gpupreagg_hash_export", &errcode);
+	if (!fn)
+		return errcode;
+	char   *d_out = (char *)dev->pool.alloc(reclen * ngroups + 16);
+	if (!d_out)
+		return StromError_OutOfMemory;
+	char   *d_counter = d_out + reclen * ngroups;
+	const void *a_tab = sess->htab;
+	void	   *a_out = d_out, *a_cnt = d_counter;
+	void	   *args[] = { &a_tab, &a_out, &a_cnt };
+	unsigned	grid = std::min<unsigned>((sess->hash_capacity + 255) / 256, (unsigned)dev->prop.multiProcessorCount * 8);
+	cl_uint		count = 0;
+	bool ok = (hipMemsetAsync(d_counter, 0, 16, dev->streams[0]) == hipSuccess &&
+			   hipModuleLaunchKernel(fn, grid, 1, 1, 256, 1, 1, 0, dev->streams[0], args, nullptr) == hipSuccess &&
+			   hipStreamSynchronize(dev->streams[0]) == hipSuccess &&
+			   hipMemcpy(&count, d_counter, sizeof(count), hipMemcpyDeviceToHost) == hipSuccess &&
+			   count == ngroups);
+	if (!ok)
+	{
+		dev->pool.release(d_out);
+		return StromError_HipInternal;
+	}
+	*p_recs = d_out;
+	*p_count = ngroups;
+	return 0;
+}
+
+void
+strom::gpupreagg_hash_release(strom_gpupreagg *sess, char *recs)
+{
+	if (recs)
+		sess->dev->pool.release(recs);
+}
+
+/* packed groups (nsegs segments of seg_len records, h_counts[seg] of them set) into the table */
+int
+strom::gpupreagg_hash_import_device(strom_gpupreagg *sess, const char *d_recs, cl_uint seg_len, cl_uint nsegs,
+									const cl_uint *h_counts, cl_uint skip_seg)
+{
+	Device *dev = sess->dev;
+	std::lock_guard<std::mutex> g(sess->lock);
+	cl_ulong	incoming = 0;
+
+	for (cl_uint s = 0; s < nsegs; s++)
+		incoming += (s == skip_seg ? 0 : h_counts[s]);
+	if (incoming == 0)
+		return 0;
+	(void)hipSetDevice(dev->hip_id);
+	int		errcode = 0;
+	hipFunction_t fn = sess->prog->get_function(dev, "gpupreagg_hash_import", &errcode);
+	if (!fn)
+		return errcode;
+	/* room for every incoming group, should all of them be new */
+	cl_uint		ngroups = 0;
+	int			rc = 0;
+	if (!sess->htab)
+		rc = hash_table_new(sess, sess->hash_capacity, &sess->htab, &sess->htab_bytes, nullptr);
+	if (rc == 0)
+		rc = hash_table_ngroups(sess, &ngroups, nullptr);
+	if (rc == 0 && ((cl_ulong)ngroups + incoming) * 8 / 7 + 4096 > sess->hash_capacity)
+		rc = hash_table_grow(sess, ((cl_ulong)ngroups + incoming) * 2 + 4096);
+	if (rc)
+		return rc;
+	cl_uint	   *d_counts = (cl_uint *)dev->pool.alloc(sizeof(cl_uint) * nsegs);
+	if (!d_counts)
+		return StromError_OutOfMemory;
+	void	   *a_tab = sess->htab;
+	const void *a_recs = d_recs;
+	const void *a_counts = d_counts;
+	void	   *args[] = { &a_tab, &a_recs, &seg_len, &nsegs, &a_counts, &skip_seg };
+	size_t		total = (size_t)seg_len * nsegs;
+	unsigned	grid = (unsigned)std::max<size_t>(1, std::min<size_t>((total + 255) / 256, (size_t)dev->prop.multiProcessorCount * 8));
+	bool ok = (hipMemcpy(d_counts, h_counts, sizeof(cl_uint) * nsegs, hipMemcpyHostToDevice) == hipSuccess &&
+			   hipModuleLaunchKernel(fn, grid, 1, 1, 256, 1, 1, 0, dev->streams[0], args, nullptr) == hipSuccess &&
+			   hipStreamSynchronize(dev->streams[0]) == hipSuccess);
+	dev->pool.release(d_counts);
+	if (!ok)
+		return StromError_HipInternal;
+	cl_uint		overflow = 0;
+	rc = hash_table_ngroups(sess, &ngroups, &overflow);
+	if (rc == 0)
+	{
+		sess->groups_upper = ngroups;
+		sess->groups_known = std::max<cl_uint>(sess->groups_known, ngroups);
+		if (overflow)
+			rc = StromError_DataStoreNoSpace;
+	}
+	return rc;
+}
+
 int
 strom::gpupreagg_get_merge_plan(strom_gpupreagg *sess, gpupreagg_merge_plan *plan)
 {

@@ -22,6 +22,8 @@
 #include <cstring>
 #include <cstdio>
 #include <mutex>
+#include <vector>
+#include <algorithm>
 
 #include <rccl/rccl.h>
 
@@ -38,6 +40,9 @@ struct rccl_api {
 	ncclResult_t  (*CommDestroy)(ncclComm_t) = nullptr;
 	ncclResult_t  (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t,
 							   ncclComm_t, hipStream_t) = nullptr;
+	ncclResult_t  (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+	ncclResult_t  (*CommCount)(const ncclComm_t, int *) = nullptr;
+	ncclResult_t  (*CommUserRank)(const ncclComm_t, int *) = nullptr;
 	ncclResult_t  (*GroupStart)(void) = nullptr;
 	ncclResult_t  (*GroupEnd)(void) = nullptr;
 	const char   *(*GetErrorString)(ncclResult_t) = nullptr;
@@ -67,11 +72,15 @@ rccl(void)
 		BIND(CommInitRank, "ncclCommInitRank");
 		BIND(CommDestroy, "ncclCommDestroy");
 		BIND(AllReduce, "ncclAllReduce");
+		BIND(AllGather, "ncclAllGather");
+		BIND(CommCount, "ncclCommCount");
+		BIND(CommUserRank, "ncclCommUserRank");
 		BIND(GroupStart, "ncclGroupStart");
 		BIND(GroupEnd, "ncclGroupEnd");
 		BIND(GetErrorString, "ncclGetErrorString");
 #undef BIND
 		api.ok = (api.GetUniqueId && api.CommInitRank && api.CommDestroy && api.AllReduce &&
+				  api.AllGather && api.CommCount && api.CommUserRank &&
 				  api.GroupStart && api.GroupEnd && api.GetErrorString);
 	});
 	return api;
@@ -186,9 +195,113 @@ strom_rccl_comm_destroy(void *comm)
 /* ------------------------------------------------------------------ *
  * merge of the resident tables
  * ------------------------------------------------------------------ */
+/*
+ * hashed GROUP BY sessions: the tables of the ranks have no common layout, so the groups
+ * travel -- every rank packs its groups (gpupreagg_hash_export), the counts and then the
+ * records are all-gathered (padded to the largest rank), and every rank merges the others'
+ * records into its table (gpupreagg_hash_import).  Afterwards every rank holds every group.
+ */
+static int
+hashed_allreduce(strom_gpupreagg *sess, int dindex, ncclComm_t comm, hipStream_t stream_or_null)
+{
+	Device	   *dev = get_device(dindex);
+	hipStream_t	stream = (stream_or_null ? stream_or_null : dev->streams[0]);
+	int			world = 0, rank = 0;
+	char	   *d_mine = nullptr, *d_all = nullptr;
+	cl_uint	   *d_counts = nullptr;
+	cl_uint		mine = 0;
+	size_t		reclen = 0;
+	int			rc;
+
+	(void)hipSetDevice(dev->hip_id);
+	if ((rc = rccl_errcode(rccl().CommCount(comm, &world), "ncclCommCount")) != 0 ||
+		(rc = rccl_errcode(rccl().CommUserRank(comm, &rank), "ncclCommUserRank")) != 0)
+		return rc;
+	if ((rc = stream_follows(dev, stream)) != 0)
+		return rc;
+	if ((rc = gpupreagg_hash_export_device(sess, &d_mine, &mine, &reclen)) != 0)
+		return rc;
+	std::vector<cl_uint> counts((size_t)world, 0);
+	do {
+		d_counts = (cl_uint *)dev->pool.alloc(sizeof(cl_uint) * (size_t)(world + 1));
+		if (!d_counts)
+		{
+			rc = StromError_OutOfMemory;
+			break;
+		}
+		/* counts: this rank's at d_counts[world], all of them in d_counts[0 .. world) */
+		if (hipMemcpyAsync(d_counts + world, &mine, sizeof(cl_uint), hipMemcpyHostToDevice, stream) != hipSuccess ||
+			(rc = rccl_errcode(rccl().AllGather(d_counts + world, d_counts, 1, ncclUint32, comm, stream),
+							   "ncclAllGather (group counts)")) != 0 ||
+			hipMemcpyAsync(counts.data(), d_counts, sizeof(cl_uint) * (size_t)world, hipMemcpyDeviceToHost, stream) != hipSuccess ||
+			hipStreamSynchronize(stream) != hipSuccess)
+		{
+			if (rc == 0)
+				rc = StromError_HipInternal;
+			break;
+		}
+		cl_uint		seg_len = 0;
+		for (cl_uint c : counts)
+			seg_len = std::max(seg_len, c);
+		if (seg_len == 0 || world == 1)
+			break;							/* nothing to merge */
+		d_all = (char *)dev->pool.alloc(reclen * (size_t)seg_len * (size_t)(world + 1));
+		if (!d_all)
+		{
+			rc = StromError_OutOfMemory;
+			break;
+		}
+		/* the send buffer is the padded copy of this rank's records behind the gather area */
+		char	   *d_send = d_all + reclen * (size_t)seg_len * (size_t)world;
+		if ((mine > 0 && hipMemcpyAsync(d_send, d_mine, reclen * mine, hipMemcpyDeviceToDevice, stream) != hipSuccess) ||
+			(rc = rccl_errcode(rccl().AllGather(d_send, d_all, reclen * (size_t)seg_len, ncclUint8, comm, stream),
+							   "ncclAllGather (groups)")) != 0 ||
+			hipStreamSynchronize(stream) != hipSuccess)
+		{
+			if (rc == 0)
+				rc = StromError_HipInternal;
+			break;
+		}
+		rc = gpupreagg_hash_import_device(sess, d_all, seg_len, (cl_uint)world, counts.data(), (cl_uint)rank);
+	} while (0);
+	if (hipStreamSynchronize(stream) != hipSuccess && rc == 0)
+		rc = StromError_HipInternal;
+	gpupreagg_hash_release(sess, d_mine);
+	if (d_all) dev->pool.release(d_all);
+	if (d_counts) dev->pool.release(d_counts);
+	return rc;
+}
+
+/* one hashed session's groups merged into another's (same program, same device): per-stream or
+ * per-range sessions of one GPU added up without leaving HBM */
+extern "C" int
+strom_gpupreagg_merge(strom_gpupreagg *dst, strom_gpupreagg *src)
+{
+	int		d1 = -1, d2 = -1;
+	if (!gpupreagg_is_hashed(dst, &d1) || !gpupreagg_is_hashed(src, &d2) || d1 != d2 || dst == src)
+		return StromError_BadRequestMessage;
+	char	   *d_recs = nullptr;
+	cl_uint		count = 0;
+	size_t		reclen = 0;
+	int			rc = gpupreagg_hash_export_device(src, &d_recs, &count, &reclen);
+	if (rc == 0 && count > 0)
+		rc = gpupreagg_hash_import_device(dst, d_recs, count, 1, &count, ~0u);
+	gpupreagg_hash_release(src, d_recs);
+	return rc;
+}
+
 extern "C" int
 strom_gpupreagg_allreduce(strom_gpupreagg *sess, void *comm_handle, void *stream_handle)
 {
+	int		hashed_dindex = -1;
+	if (gpupreagg_is_hashed(sess, &hashed_dindex))
+	{
+		if (!comm_handle)
+			return StromError_BadRequestMessage;
+		if (!rccl().ok)
+			return StromError_ServerNotReady;
+		return hashed_allreduce(sess, hashed_dindex, (ncclComm_t)comm_handle, (hipStream_t)stream_handle);
+	}
 	gpupreagg_merge_plan plan;
 	int		rc = gpupreagg_get_merge_plan(sess, &plan);
 

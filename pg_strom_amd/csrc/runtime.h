@@ -232,6 +232,13 @@ struct gpupreagg_merge_plan {
 };
 int			gpupreagg_get_merge_plan(strom_gpupreagg *sess, gpupreagg_merge_plan *plan);
 int			gpupreagg_get_census(strom_gpupreagg *sess, void **p_bitmap, cl_uint *p_nbits, int *p_dindex);
+/* hashed sessions (gpupreagg.cpp): the groups packed on the device (records of *p_reclen bytes in a
+ * pool buffer the caller releases with gpupreagg_hash_release), and packed groups merged into the table */
+bool		gpupreagg_is_hashed(strom_gpupreagg *sess, int *p_dindex);
+int			gpupreagg_hash_export_device(strom_gpupreagg *sess, char **p_recs, cl_uint *p_count, size_t *p_reclen);
+void		gpupreagg_hash_release(strom_gpupreagg *sess, char *recs);
+int			gpupreagg_hash_import_device(strom_gpupreagg *sess, const char *d_recs, cl_uint seg_len, cl_uint nsegs,
+										 const cl_uint *h_counts, cl_uint skip_seg);
 int			num_devices();
 Program	   *lookup_program(strom_devprog_key key);
 /* text / character(n) values are addresses of varlena datums inside heap tuples

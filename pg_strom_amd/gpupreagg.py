@@ -407,6 +407,13 @@ class GpuPreAgg(object):
         if rc != 0:
             raise runtime.StromError(rc, "strom_gpupreagg_allreduce")
 
+    def merge_from(self, other):
+        """hashed sessions of one device: other's groups are added to this session's table
+        (strom_gpupreagg_merge); other is left as it is"""
+        rc = lib.strom_gpupreagg_merge(self.session, other.session)
+        if rc != 0:
+            raise runtime.StromError(rc, "strom_gpupreagg_merge")
+
     def allreduce(self, group=None):
         """the same merge stated with torch.distributed collectives (pg_strom_amd.parallel):
         the gloo rehearsal's path and the GPU cross-check of allreduce_rccl()"""

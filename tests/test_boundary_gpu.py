@@ -197,6 +197,30 @@ def test_callback_then_chain_the_device_results():
     assert np.array_equal(pr.column(1)[0][order], np.bincount(g[sel], minlength=40))
 
 
+def test_rccl_merge_of_a_hashed_session_world_size_1():
+    """hashed GROUP BY sessions merge by all-gathering their packed groups: over a 1-rank
+    communicator the export, the count gather and the early exit run, and the table is as before"""
+    runtime.init()
+    rng = np.random.default_rng(4)
+    n = 80000
+    key = rng.integers(0, 3000, n).astype(np.float64) * 0.5
+    x = rng.integers(-1000, 1000, n).astype(np.int32)
+    buf = kds.build_kds("column", [kds.Column("float8", key), kds.Column("int4", x, rng.random(n) < 0.05)])
+    agg = GpuPreAgg("(gpupreagg (key (var 1 float8)) (nrows) (psum (int8 (var 2 int4))) (pmax (var 2 int4)))").begin_hashed()
+    try:
+        assert agg.fold(buf)[0] == 0
+        before = agg.fetch()
+        comm = parallel.RcclComm(0, 1)
+        agg.allreduce_rccl(comm)
+        comm.destroy()
+        after = agg.fetch()
+    finally:
+        agg.end()
+    ob, oa = np.argsort(before.column(0)[0]), np.argsort(after.column(0)[0])
+    assert len(before) == len(after) == len(np.unique(key))
+    assert np.array_equal(before.values[ob], after.values[oa]) and np.array_equal(before.isnull[ob], after.isnull[oa])
+
+
 def test_rccl_merge_behind_the_abi_world_size_1():
     """strom_gpupreagg_allreduce over a 1-rank RCCL communicator made by the library:
     fetch() after the merge == fetch() without it (every section goes through its

@@ -783,6 +783,70 @@ def test_partition_plan_is_the_default_beyond_the_roles(monkeypatch):
 
 
 # ---------------------------------------------------------------------------
+# merge of hashed sessions: the groups travel (export -> import), on one device here; between
+# GPUs strom_gpupreagg_allreduce all-gathers the exported records and runs the same import
+# ---------------------------------------------------------------------------
+@pytest.mark.parametrize("plan", ["table", "partitions"])
+def test_hashed_sessions_merge_on_the_device(plan, monkeypatch):
+    """two sessions fold two chunks whose key sets overlap in part (every partial kind, NULL keys,
+    NaN keys, groups whose inputs are all NULL on one side); a.merge_from(b) == one session that
+    folded both chunks == the oracle; b is unchanged; merging into an EMPTY session copies"""
+    if plan == "partitions":
+        monkeypatch.setenv("STROM_GPUPREAGG_HASH_PARTS_MIN", "0")
+    cols = any_key_table(60000, 83)
+    half = [kds.build_kds("column", [kds.Column(c.sqltype, c.values[sl], None if c.isnull is None else c.isnull[sl])
+                                      for c in cols]) for sl in (slice(0, 35000), slice(25000, 60000))]
+    a = GpuPreAgg(SPEC_ANY_KEYS).begin_hashed()
+    b = GpuPreAgg(SPEC_ANY_KEYS).begin_hashed()
+    empty = GpuPreAgg(SPEC_ANY_KEYS).begin_hashed()
+    try:
+        assert a.fold(half[0])[0] == 0 and b.fold(half[1])[0] == 0
+        nb = b.num_groups()
+        a.merge_from(b)
+        assert b.num_groups() == nb
+        assert_matches_oracle(SPEC_ANY_KEYS, a, half, a.fetch())
+        assert_matches_oracle(SPEC_ANY_KEYS, b, half[1:], b.fetch())
+        empty.merge_from(b)
+        assert_matches_oracle(SPEC_ANY_KEYS, empty, half[1:], empty.fetch())
+        with pytest.raises(runtime.StromError):
+            a.merge_from(a)
+    finally:
+        a.end(); b.end(); empty.end()
+
+
+def test_hashed_merge_of_many_groups_grows_the_table():
+    """3e5 + 3e5 sparse int8 keys, half of them shared: the destination table grows before the
+    import; counts and sums are numpy's"""
+    rng = np.random.default_rng(89)
+    universe = rng.permutation(np.arange(450000, dtype=np.int64) * 1000003 - 5 * 10**10)
+    parts = [universe[:300000], universe[150000:]]
+    spec = "(gpupreagg (key (var 1 int8)) (nrows) (psum (int8 (var 2 int4))) (pmin (var 2 int4)))"
+    sess, vals = [], []
+    try:
+        for p in parts:
+            v = rng.integers(-1000, 1000, len(p)).astype(np.int32)
+            vals.append(v)
+            s_ = GpuPreAgg(spec).begin_hashed()
+            sess.append(s_)
+            assert s_.fold(kds.build_kds("column", [kds.Column("int8", p), kds.Column("int4", v)]))[0] == 0
+        sess[0].merge_from(sess[1])
+        pr = sess[0].fetch()
+    finally:
+        for s_ in sess:
+            s_.end()
+    allk, allv = np.concatenate(parts), np.concatenate(vals).astype(np.int64)
+    uk, inv = np.unique(allk, return_inverse=True)
+    k, _ = pr.column(0)
+    order = np.argsort(k)
+    assert len(pr) == 450000 and np.array_equal(k[order], uk)
+    assert np.array_equal(pr.column(1)[0][order], np.bincount(inv))
+    assert np.array_equal(pr.column(2)[0][order], np.bincount(inv, weights=allv).astype(np.int64))
+    want_min = np.full(len(uk), 2**31, dtype=np.int64)
+    np.minimum.at(want_min, inv, allv)
+    assert np.array_equal(pr.column(3)[0][order].astype(np.int64), want_min)
+
+
+# ---------------------------------------------------------------------------
 # the reference's per-chunk message (strom_submit_gpupreagg_chunk)
 # ---------------------------------------------------------------------------
 def chunk_runner(chunks):
