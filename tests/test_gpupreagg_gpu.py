@@ -758,6 +758,30 @@ def test_partition_plan_cuts_a_heavy_key_into_units(partitions, monkeypatch, uni
     assert np.allclose(pr.column(4)[0][order], np.bincount(inv, weights=y), rtol=1e-11)
 
 
+def test_partition_plan_for_a_large_chunk_of_unknown_group_count():
+    """no hint, first chunk, 4.5M rows: the plan whose cost does not depend on the group count;
+    the second chunk knows there are 300 groups and goes back to the LDS table"""
+    rng = np.random.default_rng(73)
+    n = 4_500_000
+    key = (rng.integers(0, 300, n).astype(np.int64) - 150) * (2**35 + 3)
+    x = rng.integers(-1000, 1000, n).astype(np.int32)
+    buf = kds.build_kds("column", [kds.Column("int8", key), kds.Column("int4", x)])
+    agg = GpuPreAgg("(gpupreagg (key (var 1 int8)) (nrows) (psum (int8 (var 2 int4))) (pmin (var 2 int4)))").begin_hashed()
+    try:
+        st, pfm = agg.fold(buf)
+        assert st == 0 and pfm["num_kern_prep"] == 1
+        st, pfm = agg.fold(buf)
+        assert st == 0 and pfm["num_kern_prep"] == 0
+        pr = agg.fetch()
+    finally:
+        agg.end()
+    uk, inv = np.unique(key, return_inverse=True)
+    order = np.argsort(pr.column(0)[0])
+    assert len(pr) == 300 and np.array_equal(pr.column(0)[0][order], uk)
+    assert np.array_equal(pr.column(1)[0][order], 2 * np.bincount(inv))
+    assert np.array_equal(pr.column(2)[0][order], 2 * np.bincount(inv, weights=x.astype(np.float64)).astype(np.int64))
+
+
 def test_partition_plan_is_the_default_beyond_the_roles(monkeypatch):
     """a hint of 30000 groups: the partition plan without any knob; the same partial rows as
     the global-table path gives (integers bit for bit)"""
