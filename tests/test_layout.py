@@ -114,3 +114,12 @@ def test_c_abi_exports_every_declared_symbol():
     for sym in sorted(declared):
         assert hasattr(lib, sym), "libstrom_hip.so does not export " + sym
         assert sym in PROTOTYPES, "binding lacks a prototype for " + sym
+
+
+def test_merge_entry_points_refuse_null_sessions_without_a_gpu():
+    """the multi-GPU / hashed merge calls answer BadRequestMessage for a missing session or
+    communicator before anything touches a device (a backend must get an error code, never a crash)"""
+    from pg_strom_amd._lib import lib
+    assert lib.strom_gpupreagg_merge(None, None) == 101
+    assert lib.strom_gpupreagg_allreduce(None, None, None) == 101
+    assert lib.strom_gpupreagg_census_allreduce(None, None, None) != 0
