@@ -3868,6 +3868,75 @@ gpupreagg_hash_export(const char *htab, char *out, cl_uint *counter)
 }
 
 /*
+ * the groups as TUPSLOT rows, written where the host will copy them from: what a fetch needs
+ * when no partial is a 64-bit numeric (those may split into two rows: host).  rows = the
+ * first row of the destination image, stride = KDS_TUPSLOT_STRIDE(ncols); tmeta[i] describes
+ * target i: bits 0-7 datum length, 8 key, 9 float, 10 float4 output, 11 NROWS, 12 stored as
+ * order-preserving key (float pmin / pmax), 16-23 its index among the keys / the aggregates.
+ * Without codegen macros: the stored forms are 8-byte images whatever the type.
+ */
+extern "C" __global__ void
+__launch_bounds__(256)
+gpupreagg_hash_export_rows(const char *htab, char *rows, cl_uint stride, cl_uint ncols,
+						   const cl_uint *tmeta, cl_uint *counter)
+{
+	const gpupreagg_hash_head *head = (const gpupreagg_hash_head *)htab;
+	cl_uint		C = head->capacity;
+
+	for (cl_uint base = blockIdx.x * blockDim.x; base < C; base += gridDim.x * blockDim.x)
+	{
+		cl_uint		i = base + threadIdx.x;
+		const char *src = gpupreagg_hash_rec(htab, i < C ? i : 0);
+		bool		ready = (i < C && *HASH_REC_STATE(src) == 2);
+		cl_ulong	mask = __ballot(ready);
+		cl_uint		first = 0;
+		if (mask == 0)
+			continue;
+		if (strom_lane_id() == 0)
+			first = atomicAdd(counter, (cl_uint)__popcll(mask));
+		first = __shfl(first, 0, STROM_WAVE);
+		if (!ready)
+			continue;
+		cl_uint		idx = first + (cl_uint)__popcll(mask & ((1UL << strom_lane_id()) - 1));
+		cl_ulong   *values = (cl_ulong *)(rows + (size_t)stride * idx);
+		cl_char	   *isnull = (cl_char *)(values + ncols);
+		cl_uint		knull = *HASH_REC_KNULL(src);
+		cl_uint		flags = *HASH_REC_FLAGS(src);
+		for (cl_uint w = ncols; w < stride / 8; w++)
+			values[w] = 0;						/* the NULL flags and the padding behind them */
+		for (cl_uint c = 0; c < ncols; c++)
+		{
+			cl_uint		m = tmeta[c];
+			cl_uint		len = m & 0xffu, which = (m >> 16) & 0xffu;
+			cl_ulong	raw;
+			bool		null;
+			if (m & 0x100u)
+			{
+				raw = HASH_REC_KEYS(src)[which];
+				null = ((knull >> which) & 1u) != 0;
+			}
+			else
+			{
+				raw = HASH_REC_KEYS(src)[GPUPREAGG_NKEYS + which];
+				null = (!(m & 0x800u) && !(flags & (2u << which)));
+			}
+			if (!null && (m & 0x200u))
+			{
+				if (m & 0x1000u)				/* order-preserving key -> IEEE bits */
+					raw = (raw & 0x8000000000000000UL) ? (raw & 0x7fffffffffffffffUL) : ~raw;
+				if (m & 0x400u)
+					raw = (cl_ulong)__float_as_uint((cl_float)__longlong_as_double((long long)raw));
+			}
+			else if (!null && len < 8)
+				raw &= (1UL << (8 * len)) - 1;
+			values[c] = (null ? 0UL : raw);
+			if (null)
+				isnull[c] = 1;
+		}
+	}
+}
+
+/*
  * the other way round: packed groups (another session's, another GPU's -- all-gathered by
  * strom_gpupreagg_allreduce) merged into this table.  recs[] is nsegs segments of seg_len
  * records of which the first counts[seg] are set; segment skip_seg (this rank's own) is left
