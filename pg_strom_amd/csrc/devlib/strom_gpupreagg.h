@@ -2441,10 +2441,18 @@ gpupreagg_hash_slot(char *htab, cl_uint hash, const cl_ulong *kimg, cl_uint knul
 													 __ATOMIC_RELAXED, __ATOMIC_RELAXED,
 													 __HIP_MEMORY_SCOPE_AGENT))
 			{
+				/*
+				 * publish: the keys and NULL bits go out as agent-scope atomic stores (written
+				 * through to where the probes' agent-scope loads read), the wave waits for
+				 * them to be acknowledged, then the state follows.  An agent-scope RELEASE
+				 * here is a write-back of the XCD's whole L2 per claim: a first chunk with 1e6
+				 * new groups spent 5 of its 7 ms in it (profiles/r02_hashed_fetch.txt).
+				 */
 				for (int k = 0; k < GPUPREAGG_NKEYS; k++)
-					HASH_REC_KEYS(rec)[k] = kimg[k];
-				*HASH_REC_KNULL(rec) = knull;
-				__hip_atomic_store(HASH_REC_STATE(rec), 2u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+					__hip_atomic_store(HASH_REC_KEYS(rec) + k, kimg[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				__hip_atomic_store(HASH_REC_KNULL(rec), knull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				__builtin_amdgcn_s_waitcnt(0x0f70);		/* vmcnt(0): the stores above are acknowledged; no cache maintenance */
+				__hip_atomic_store(HASH_REC_STATE(rec), 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 				atomicAdd(&head->ngroups, 1u);
 				result = slot;
 				done = true;
