@@ -353,17 +353,22 @@ hashjoin_build_index_kernel(kern_multihash *kmhash, int depth, hashjoin_index *h
 					for (;;)
 					{
 						cl_uint	   *slot = words + 4 * (size_t)idx;
-						cl_uint		tag = __hip_atomic_load(&slot[1], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+						/* (no agent-scope acquire / release: those are a cache invalidate and an L2
+						 * write-back per probe and per claim, DESIGN section 9.27.  Tag and key words
+						 * are read and written with agent-scope atomics, served at the coherence
+						 * point; the claimer waits for its key stores before it stores READY) */
+						cl_uint		tag = __hip_atomic_load(&slot[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 						if (tag == HASHJOIN_KEYED_EMPTY)
 						{
 							cl_uint expect = HASHJOIN_KEYED_EMPTY;
 							if (__hip_atomic_compare_exchange_strong(&slot[1], &expect, HASHJOIN_KEYED_BUSY,
-																	 __ATOMIC_ACQUIRE, __ATOMIC_RELAXED,
+																	 __ATOMIC_RELAXED, __ATOMIC_RELAXED,
 																	 __HIP_MEMORY_SCOPE_AGENT))
 							{
-								slot[2] = lo;
-								slot[3] = hi;
-								__hip_atomic_store(&slot[1], HASHJOIN_KEYED_READY, __ATOMIC_RELEASE,
+								__hip_atomic_store(&slot[2], lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+								__hip_atomic_store(&slot[3], hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+								__builtin_amdgcn_s_waitcnt(0x0f70);		/* vmcnt(0) */
+								__hip_atomic_store(&slot[1], HASHJOIN_KEYED_READY, __ATOMIC_RELAXED,
 												   __HIP_MEMORY_SCOPE_AGENT);
 								break;
 							}
