@@ -95,6 +95,11 @@ typedef uint64_t	Datum;
 #define StromError_Success				0
 #define StromError_RowFiltered			1
 #define StromError_CpuReCheck			2
+/* internal to GpuPreAgg (never returned to a caller): the device could not prove that the
+ * integer sums of a chunk stay inside int8, nothing was merged, the runtime folds the chunk
+ * again with checked additions -- the value of StromError_RowFiltered, which GpuPreAgg has no
+ * use for: below CpuReCheck, above Success ("worst wins" is a max) */
+#define StromError_SumRangeUnproven		1
 #define StromError_ServerNotReady		100
 #define StromError_BadRequestMessage	101
 #define StromError_OpenCLInternal		102		/* kept for value compat */

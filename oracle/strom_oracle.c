@@ -2206,9 +2206,6 @@ oracle_gpupreagg(const char *spec_text,
 				}
 				else if (tg->kind == T_PMIN) { if (x < acc->v.i) acc->v.i = x; }
 				else { if (x > acc->v.i) acc->v.i = x; }
-				/* the device screens |partial| >= 2^62 conservatively */
-				if (tg->kind == T_PSUM && (x >= (1LL << 62) || x <= -(1LL << 62)))
-					set_error(&status, StromError_CpuReCheck);
 			}
 			acc->isnull = 0;
 		}

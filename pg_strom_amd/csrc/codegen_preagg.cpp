@@ -27,6 +27,12 @@ struct target {
 	int			pack_kind = 0;	/* packed accumulators (strom_gpupreagg.h): 1 count(*), 2 psum of a plain
 								 * integer column, 3 psum of a plain float8 column, 0 none of these */
 	int			pack_attno = 0;
+	/*
+	 * integer sums (strom_gpupreagg.h, "integer sums never wrap"): 0 = not one; 1..63 = every
+	 * input is below 2^sumbits in magnitude whatever the data (a sum over int2 / int4 values
+	 * cast to int8); 64 = no static bound, the kernels measure the inputs
+	 */
+	int			sumbits = 0;
 	int			kind;
 	int			type_oid;	/* type of the partial value as the caller sees it */
 	int			acc_oid;	/* type of the device accumulator */
@@ -39,6 +45,32 @@ struct target {
  * (float8 (var N float4|float8)): the value is the column's, it is NULL only
  * where the column is, and it cannot raise an error.  Returns the attno or 0.
  */
+/*
+ * (int8 X) with X of type int2 / int4 (or narrower): |value| <= 2^15 / 2^31, so
+ * its magnitude (v >= 0 ? v : -v - 1) is below 2^15 / 2^31 -- returns the bits, or 64
+ */
+int
+static_sum_bits(const sexpr &e, const codegen_context &ctx)
+{
+	if (!e.is_list || e.items.size() != 2 || e.items[0].is_list || e.items[0].atom != "int8")
+		return 64;
+	codegen_context scratch = ctx;			/* (the argument is generated again for real by the caller) */
+	std::string		text;
+	int		inner = 0;
+	try {
+		inner = codegen_expression(e.items[1], scratch, text);
+	} catch (...) {
+		return 64;
+	}
+	if (inner == STROM_INT4OID || inner == STROM_DATEOID)
+		return 31;
+	if (inner == STROM_INT2OID)
+		return 15;
+	if (inner == STROM_BOOLOID)
+		return 1;
+	return 64;
+}
+
 int
 plain_column_attno(const sexpr &e, int *p_var_oid)
 {
@@ -200,6 +232,8 @@ strom_codegen_gpupreagg(const char *spec, strom_codegen_result *out,
 					if (tg.scale < 0 || tg.scale > 32)
 						codegen_error("numeric scale out of range");
 					tg.acc_oid = STROM_INT8OID;
+					if (tg.kind == STROM_PREAGG_PSUM)
+						tg.sumbits = 64;			/* fixed point in an int8 accumulator */
 					char sb[16];
 					snprintf(sb, sizeof(sb), "%d", tg.scale);
 					if (fixed_scale >= 0)
@@ -233,6 +267,8 @@ strom_codegen_gpupreagg(const char *spec, strom_codegen_result *out,
 					if (nargs != 1)
 						codegen_error("only numeric partials take a scale");
 					tg.body = "  return " + e + ";\n";
+					if (tg.kind == STROM_PREAGG_PSUM && tg.type_oid == STROM_INT8OID)
+						tg.sumbits = static_sum_bits(t.items[1], ctx);
 					int		var_oid = 0;
 					int		attno = plain_column_attno(t.items[1], &var_oid);
 					if (tg.kind == STROM_PREAGG_PSUM && attno > 0 &&
@@ -312,6 +348,7 @@ strom_codegen_gpupreagg(const char *spec, strom_codegen_result *out,
 		std::string key_list = "#define GPUPREAGG_KEY_LIST(X)";
 		std::string agg_list = "#define GPUPREAGG_AGG_LIST(X)";
 		std::string pack_list = "#define GPUPREAGG_PACK_LIST(X)";
+		std::string sumbits_defs;
 		bool	packable = true;
 		std::string funcs;
 		int		nkeys = 0, naggs = 0;
@@ -337,6 +374,8 @@ strom_codegen_gpupreagg(const char *spec, strom_codegen_result *out,
 				snprintf(tmp, sizeof(tmp), " X(%d,%d,%d)", naggs, tg.pack_kind, tg.pack_attno);
 				pack_list += tmp;
 				packable = packable && (tg.pack_kind != 0);
+				snprintf(tmp, sizeof(tmp), "#define GPUPREAGG_SUMBITS_%d %d\n", naggs, tg.sumbits);
+				sumbits_defs += tmp;
 				funcs += fn_header(tname, "gpupreagg_agg", naggs) + "{\n" + tg.body + "}\n";
 				naggs++;
 			}
@@ -414,6 +453,8 @@ strom_codegen_gpupreagg(const char *spec, strom_codegen_result *out,
 		snprintf(tmp, sizeof(tmp), "#define GPUPREAGG_PACKABLE %d\n", (packable && naggs > 0 && naggs <= 32) ? 1 : 0);
 		src += tmp;
 		src += pack_list + "\n";
+		/* integer sums: static magnitude bound per aggregate (see struct target) */
+		src += sumbits_defs;
 		{
 			/* wide rows: one quad per thread and tile, two would not leave
 			 * registers for the row body (a -D tunable still wins) */

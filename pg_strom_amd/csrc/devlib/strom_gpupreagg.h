@@ -238,8 +238,12 @@ gpupreagg_image_offset(int sec, cl_uint G, cl_uint REP)
 
 /*
  * resident table for N groups, 256-byte aligned sections:
- *   section 0        flags as u32[N]
- *   section 1+a      8-byte values[N] (NROWS widened to i64)
+ *   section 0          flags as u32[N]
+ *   section 1+a        8-byte values[N] (NROWS widened to i64)
+ *   section 1+NAGGS+j  the j-th INTEGER sum's high word, i64[N]: such a sum is
+ *                      128 bits wide in the table (low word in its section 1+a,
+ *                      two's complement), so a total over any number of chunks
+ *                      cannot wrap ("integer sums never wrap", below)
  */
 STROM_DEVICE size_t
 gpupreagg_table_offset(int sec, cl_uint N)
@@ -321,8 +325,21 @@ gpupreagg_lds_accum(char *lds, cl_uint vals_off, cl_uint slot, PGT v, cl_int *ch
 	else
 	{
 		if (OP == GPUPREAGG_OP_PSUM)
+		{
+#if defined(GPUPREAGG_CHECKED) && GPUPREAGG_CHECKED
+			/* the returning form: the add is checked against what it was added to
+			 * (CHECK_OVERFLOW_INT of the reference's PSUM template).  The atomics of a
+			 * slot are one sequence of additions; each link of it is checked here. */
+			cl_long		x = (has ? (cl_long)v.value : 0L), sum;
+			cl_long		old = __hip_atomic_fetch_add((cl_long *)(lds + vals_off) + slot, x,
+													 __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+			if (chunk_status)
+				STROM_SET_RECHECK_IF(chunk_status, __builtin_add_overflow(old, x, &sum));
+#else
 			__hip_atomic_fetch_add((cl_long *)(lds + vals_off) + slot, has ? (cl_long)v.value : 0L,
 								   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#endif
+		}
 		else if (OP == GPUPREAGG_OP_PMIN)
 			__hip_atomic_fetch_min((cl_long *)(lds + vals_off) + slot,
 								   has ? (cl_long)v.value : 0x7fffffffffffffffL,
@@ -386,16 +403,107 @@ gpupreagg_merge8e(cl_ulong a, cl_ulong b, cl_int *errcode)
 	if (gpupreagg_is_numeric<BASE>::value)
 		return gpupreagg_numeric_combine<OP == GPUPREAGG_OP_NROWS ? GPUPREAGG_OP_PSUM : OP>(a, b, errcode);
 #endif
+#if defined(GPUPREAGG_CHECKED) && GPUPREAGG_CHECKED
+	if (OP == GPUPREAGG_OP_PSUM && !gpupreagg_is_float<BASE>::value)
+	{
+		cl_long	sum;
+		if (__builtin_add_overflow((cl_long)a, (cl_long)b, &sum))
+			STROM_SET_ERROR(errcode, StromError_CpuReCheck);
+		return (cl_ulong)sum;
+	}
+#endif
 	return gpupreagg_merge8<OP, BASE>(a, b);
 }
 
-/* conservative overflow screen for int8 sums: a partial sum at or beyond
- * 2^62 in magnitude sends the chunk to the CPU before int64 can wrap
- * (CHECK_OVERFLOW_INT, opencl_gpupreagg.h:142-143) */
-STROM_DEVICE bool
-gpupreagg_int8_near_overflow(cl_long v)
+/* ---------------------------------------------------------------------- *
+ * integer sums never wrap silently
+ *
+ * The reference checks every accumulate of its reduction (CHECK_OVERFLOW_INT,
+ * opencl_gpupreagg.h:142-143, used by GPUPREAGG_AGGCALC_PSUM_TEMPLATE 933-948)
+ * and sends the chunk back to the CPU when an int8 partial sum leaves its
+ * type.  A check per LDS atomic would need the returning form of every
+ * ds_add_u64; instead the common case is PROVEN not to wrap and only the rest
+ * is checked add by add:
+ *
+ *   range proof.  |x| <= M for every summed input of the chunk and n rows
+ *   give |any partial sum of the chunk| <= n * M.  M comes from the type
+ *   (a sum over int2 / int4 values cast to int8: GPUPREAGG_SUMBITS_<a>, from
+ *   the code generator), from the zone map (packed accumulators), or is
+ *   measured: the fold ORs the magnitudes of the inputs it adds into
+ *   kern_gpupreagg.sum_magnitude.  When n * (M + 1) < 2^63 nothing in the
+ *   chunk -- LDS accumulators, replicas, slabs, the chunk's total -- can have
+ *   wrapped, and gpupreagg_dense_merge takes the slabs.  The resident table
+ *   itself is 128 bits wide for these sums (a "hi" section per integer sum),
+ *   so a total over many chunks never wraps either; the fetch hands a total
+ *   that does not fit int8 out as several partial rows.
+ *
+ *   otherwise the merge leaves the table alone and answers
+ *   StromError_SumRangeUnproven -- an internal status between Success and
+ *   CpuReCheck that never reaches the caller: the host folds the chunk again
+ *   with the program built with GPUPREAGG_CHECKED, whose LDS adds return the
+ *   old value and are checked one by one, replicas and slabs likewise
+ *   (gpupreagg_dense_merge_check); an add that leaves int8 is CpuReCheck, as
+ *   in the reference.
+ * ---------------------------------------------------------------------- */
+/* (StromError_SumRangeUnproven: strom_kds.h) */
+
+template <int OP, typename BASE> struct gpupreagg_is_intsum {
+	static const bool value = (OP == GPUPREAGG_OP_PSUM && !gpupreagg_is_float<BASE>::value &&
+							   !gpupreagg_is_numeric<BASE>::value);
+};
+
+/* v >= 0: v; v < 0: -v - 1 -- so |v| <= magnitude + 1, and an OR of magnitudes
+ * is at least their maximum */
+STROM_DEVICE cl_ulong
+gpupreagg_sum_magnitude(cl_long v)
 {
-	return (v >= (1L << 62)) | (v <= -(1L << 62));
+	return (cl_ulong)(v ^ (v >> 63));
+}
+
+/* where the fold leaves what it measured: the 8 padding bytes of kern_gpupreagg
+ * (zeroed, or preset with the static bounds, by the host per request);
+ * sortbuf_len -- the reference's sort buffer length, no use here -- carries the
+ * number of rows the request folds */
+#define KERN_GPUPREAGG_SUM_MAGNITUDE(kgp)	((cl_ulong *)__builtin_assume_aligned((kgp)->__padding, 8))
+#define KERN_GPUPREAGG_FOLD_NROWS(kgp)		((cl_uint)(kgp)->sortbuf_len)
+
+STROM_DEVICE void
+gpupreagg_writeback_summag(kern_gpupreagg *kgpreagg, cl_ulong summag)
+{
+#pragma unroll
+	for (int m = 32; m > 0; m >>= 1)
+	{
+		cl_uint lo = __shfl_xor((cl_uint)summag, m, STROM_WAVE);
+		cl_uint hi = __shfl_xor((cl_uint)(summag >> 32), m, STROM_WAVE);
+		summag |= ((cl_ulong)hi << 32) | lo;
+	}
+	if (strom_lane_id() == 0 && summag != 0)
+		__hip_atomic_fetch_or(KERN_GPUPREAGG_SUM_MAGNITUDE(kgpreagg), summag,
+							  __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+/* the position of aggregate aidx among the integer sums (its high-word section in the table) */
+STROM_DEVICE constexpr int
+gpupreagg_intsum_index(int aidx)
+{
+	int		n = 0;
+#define X(a,resno,OP,NAME)																\
+	n += ((a) < aidx && gpupreagg_is_intsum<GPUPREAGG_OP_##OP, pg_##NAME##_base_t>::value ? 1 : 0);
+	GPUPREAGG_AGG_LIST(X)
+#undef X
+	return n;
+}
+
+/* n rows of magnitude <= summag: can a sum of them leave int8? */
+STROM_DEVICE bool
+gpupreagg_sum_range_proven(cl_uint nrows, cl_ulong summag)
+{
+	cl_ulong	bound;
+	if (nrows == 0 || summag == 0)
+		return true;
+	if (summag >= (1UL << 62))
+		return false;
+	return !__builtin_mul_overflow((cl_ulong)nrows, summag + 1, &bound) && bound < (1UL << 63);
 }
 
 /* LDS section offsets, computed once per kernel */
@@ -420,7 +528,7 @@ STROM_DEVICE void
 gpupreagg_dense_row(char *lds, const gpupreagg_dense_ctl *ctl, const gpupreagg_lds_layout &L,
 					const strom_kparams &KP, const strom_kvars &KV,
 					cl_uint gid_lo, cl_uint G, cl_uint NREP, cl_uint rep,
-					cl_int param_error, cl_int *chunk_status, bool qual_done = false)
+					cl_int param_error, cl_int *chunk_status, cl_ulong &summag, bool qual_done = false)
 {
 	cl_int		errcode = param_error;
 	cl_uint		gid = 0;
@@ -478,11 +586,9 @@ gpupreagg_dense_row(char *lds, const gpupreagg_dense_ctl *ctl, const gpupreagg_l
 	cl_uint		need = GPUPREAGG_FLAG_SEEN;
 
 #define X(aidx,resno,OP,NAME)														\
-	if (GPUPREAGG_OP_##OP == GPUPREAGG_OP_PSUM &&									\
-		!gpupreagg_is_float<pg_##NAME##_base_t>::value &&							\
-		!gpupreagg_is_numeric<pg_##NAME##_base_t>::value)							\
-		STROM_SET_RECHECK_IF(chunk_status, !av_##aidx.isnull &						\
-							 gpupreagg_int8_near_overflow((cl_long)av_##aidx.value));	\
+	/* an integer sum without a static bound: measure (see "integer sums never wrap") */	\
+	if (gpupreagg_is_intsum<GPUPREAGG_OP_##OP, pg_##NAME##_base_t>::value && GPUPREAGG_SUMBITS_##aidx >= 64)	\
+		summag |= (av_##aidx.isnull ? 0UL : gpupreagg_sum_magnitude((cl_long)av_##aidx.value));	\
 	need |= gpupreagg_lds_accum<GPUPREAGG_OP_##OP, aidx>(lds, L.vals_off[aidx], slot, av_##aidx, chunk_status);
 	GPUPREAGG_AGG_LIST(X)
 #undef X
@@ -519,7 +625,7 @@ gpupreagg_lds_init(char *lds, const gpupreagg_lds_layout &L, cl_uint G, cl_uint 
 /* fold replicas and store the work-group's slab (REP = 1 image) */
 STROM_DEVICE void
 gpupreagg_store_slab(const char *lds, const gpupreagg_lds_layout &L, char *slab,
-					 cl_uint G, cl_uint NREP)
+					 cl_uint G, cl_uint NREP, cl_int *chunk_status)
 {
 	const gpupreagg_flags_t *lflags = (const gpupreagg_flags_t *)lds;
 
@@ -551,8 +657,8 @@ gpupreagg_store_slab(const char *lds, const gpupreagg_lds_layout &L, char *slab,
 			{																				\
 				cl_ulong acc = ((const cl_ulong *)lvals)[g * NREP];							\
 				for (cl_uint r = 1; r < NREP; r++)											\
-					acc = gpupreagg_merge8<GPUPREAGG_OP_##OP, pg_##NAME##_base_t>			\
-						(acc, ((const cl_ulong *)lvals)[g * NREP + r]);						\
+					acc = gpupreagg_merge8e<GPUPREAGG_OP_##OP, pg_##NAME##_base_t>			\
+						(acc, ((const cl_ulong *)lvals)[g * NREP + r], chunk_status);		\
 				((cl_ulong *)svals)[g] = acc;												\
 			}																				\
 		}																					\
@@ -822,6 +928,7 @@ gpupreagg_dense_column_body(kern_gpupreagg *kgpreagg,
 	cl_uint		gid_lo = split * G;
 	cl_uint		rep = threadIdx.x & (NREP - 1);
 	cl_int		chunk_status = StromError_Success;
+	cl_ulong	summag = 0;			/* OR of the integer sums' input magnitudes */
 	cl_int		param_error = StromError_Success;
 	strom_kparams KP;
 	gpupreagg_lds_layout L;
@@ -960,7 +1067,7 @@ gpupreagg_dense_column_body(kern_gpupreagg *kgpreagg,
 					else
 #endif
 						gpupreagg_dense_row(lds, ctl, L, KP, KV, gid_lo, G, NREP, rep,
-											param_error, &chunk_status);
+											param_error, &chunk_status, summag);
 				}
 			}
 		}
@@ -971,8 +1078,9 @@ gpupreagg_dense_column_body(kern_gpupreagg *kgpreagg,
 										   G, flushed);
 	else
 #endif
-		gpupreagg_store_slab(lds, L, slabs + (size_t)(wg_in_split * nsplits + split) * ctl->slab_bytes, G, NREP);
+		gpupreagg_store_slab(lds, L, slabs + (size_t)(wg_in_split * nsplits + split) * ctl->slab_bytes, G, NREP, &chunk_status);
 	gpupreagg_writeback_status(&kgpreagg->status, chunk_status);
+	gpupreagg_writeback_summag(kgpreagg, summag);
 }
 
 extern "C" __global__ void
@@ -1023,6 +1131,7 @@ gpupreagg_dense_generic_body(kern_gpupreagg *kgpreagg,
 	cl_uint		wgs_per_split = gridDim.x / nsplits;
 	cl_uint		rep = threadIdx.x & (NREP - 1);
 	cl_int		chunk_status = StromError_Success;
+	cl_ulong	summag = 0;			/* OR of the integer sums' input magnitudes */
 	cl_int		param_error = StromError_Success;
 	strom_kparams KP;
 	gpupreagg_lds_layout L;
@@ -1061,10 +1170,11 @@ gpupreagg_dense_generic_body(kern_gpupreagg *kgpreagg,
 		STROM_KVAR_LIST(X)
 #undef X
 		KV.__dummy = 0;
-		gpupreagg_dense_row(lds, ctl, L, KP, KV, gid_lo, G, NREP, rep, errcode, &chunk_status);
+		gpupreagg_dense_row(lds, ctl, L, KP, KV, gid_lo, G, NREP, rep, errcode, &chunk_status, summag);
 	}
-	gpupreagg_store_slab(lds, L, slabs + (size_t)blockIdx.x * ctl->slab_bytes, G, NREP);
+	gpupreagg_store_slab(lds, L, slabs + (size_t)blockIdx.x * ctl->slab_bytes, G, NREP, &chunk_status);
 	gpupreagg_writeback_status(&kgpreagg->status, chunk_status);
+	gpupreagg_writeback_summag(kgpreagg, summag);
 }
 
 extern "C" __global__ void
@@ -1151,6 +1261,7 @@ gpupreagg_dense_joined(kern_gpupreagg *kgpreagg,
 	cl_uint		wgs_per_split = gridDim.x / nsplits;
 	cl_uint		rep = threadIdx.x & (NREP - 1);
 	cl_int		chunk_status = StromError_Success;
+	cl_ulong	summag = 0;			/* OR of the integer sums' input magnitudes */
 	cl_int		param_error = StromError_Success;
 	strom_kparams KP;
 	gpupreagg_lds_layout L;
@@ -1264,10 +1375,11 @@ gpupreagg_dense_joined(kern_gpupreagg *kgpreagg,
 		}
 		STROM_KVAR_LIST_REST(X)
 #undef X
-		gpupreagg_dense_row(lds, ctl, L, KP, KV, gid_lo, G, NREP, rep, errcode, &chunk_status);
+		gpupreagg_dense_row(lds, ctl, L, KP, KV, gid_lo, G, NREP, rep, errcode, &chunk_status, summag);
 	}
-	gpupreagg_store_slab(lds, L, slabs + (size_t)blockIdx.x * ctl->slab_bytes, G, NREP);
+	gpupreagg_store_slab(lds, L, slabs + (size_t)blockIdx.x * ctl->slab_bytes, G, NREP, &chunk_status);
 	gpupreagg_writeback_status(&kgpreagg->status, chunk_status);
+	gpupreagg_writeback_summag(kgpreagg, summag);
 }
 
 /* ====================================================================== *
@@ -1319,6 +1431,7 @@ gpupreagg_dense_lookup_body(kern_gpupreagg *kgpreagg,
 	cl_uint		gid_lo = split * G;
 	cl_uint		rep = threadIdx.x & (NREP - 1);
 	cl_int		chunk_status = StromError_Success;
+	cl_ulong	summag = 0;			/* OR of the integer sums' input magnitudes */
 	cl_int		param_error = StromError_Success;
 	strom_kparams KP;
 	gpupreagg_lds_layout L;
@@ -1574,7 +1687,7 @@ gpupreagg_dense_lookup_body(kern_gpupreagg *kgpreagg,
 					else
 #endif
 						gpupreagg_dense_row(lds, ctl, L, KP, KV, gid_lo, G, NREP, rep,
-											param_error, &chunk_status, (qual_ok[k] >> j) & 1);
+											param_error, &chunk_status, summag, (qual_ok[k] >> j) & 1);
 				}
 			}
 		}
@@ -1584,8 +1697,9 @@ gpupreagg_dense_lookup_body(kern_gpupreagg *kgpreagg,
 		gpupreagg_store_slab_packed<false>(lds, pk, slabs + (size_t)blockIdx.x * ctl->slab_bytes, G, flushed);
 	else
 #endif
-		gpupreagg_store_slab(lds, L, slabs + (size_t)blockIdx.x * ctl->slab_bytes, G, NREP);
+		gpupreagg_store_slab(lds, L, slabs + (size_t)blockIdx.x * ctl->slab_bytes, G, NREP, &chunk_status);
 	gpupreagg_writeback_status(&kgpreagg->status, chunk_status);
+	gpupreagg_writeback_summag(kgpreagg, summag);
 }
 
 extern "C" __global__ void
@@ -1661,7 +1775,7 @@ template <int NG>
 STROM_DEVICE void
 gpupreagg_reg_row(gpupreagg_reg_state<NG> &S, const gpupreagg_dense_ctl *ctl,
 				  const strom_kparams &KP, const strom_kvars &KV,
-				  cl_int param_error, cl_int *chunk_status)
+				  cl_int param_error, cl_int *chunk_status, cl_ulong &summag)
 {
 	cl_int		errcode = param_error;
 	pg_bool_t	rc = gpupreagg_qual_eval(&errcode, KP, KV);
@@ -1712,9 +1826,8 @@ gpupreagg_reg_row(gpupreagg_reg_state<NG> &S, const gpupreagg_dense_ctl *ctl,
 				 : gpupreagg_f64_ordered((cl_double)av_##aidx.value));				\
 		else																		\
 			x = (cl_ulong)(cl_long)av_##aidx.value;									\
-		if (GPUPREAGG_OP_##OP == GPUPREAGG_OP_PSUM && !gpupreagg_is_float<base_t>::value &&	\
-			has && gpupreagg_int8_near_overflow((cl_long)x))						\
-			STROM_SET_ERROR(chunk_status, StromError_CpuReCheck);					\
+		if (gpupreagg_is_intsum<GPUPREAGG_OP_##OP, base_t>::value && GPUPREAGG_SUMBITS_##aidx >= 64)	\
+			summag |= (has ? gpupreagg_sum_magnitude((cl_long)x) : 0UL);			\
 		if (GPUPREAGG_OP_##OP != GPUPREAGG_OP_NROWS && has)							\
 			need |= (2u << aidx);													\
 		_Pragma("unroll")															\
@@ -1754,6 +1867,7 @@ gpupreagg_reg_kernel_body(kern_gpupreagg *kgpreagg, const kern_data_store *kds,
 	cl_uint		ntiles = (nitems + GPUPREAGG_REG_TILE_ROWS - 1) / GPUPREAGG_REG_TILE_ROWS;
 	cl_uint		G = ctl->groups_per_split;
 	cl_int		chunk_status = StromError_Success;
+	cl_ulong	summag = 0;			/* OR of the integer sums' input magnitudes */
 	cl_int		param_error = StromError_Success;
 	strom_kparams KP;
 	gpupreagg_lds_layout L;
@@ -1860,7 +1974,7 @@ gpupreagg_reg_kernel_body(kern_gpupreagg *kgpreagg, const kern_data_store *kds,
 					STROM_KVAR_LIST(X)
 #undef X
 					KV.__dummy = 0;
-					gpupreagg_reg_row<NG>(S, ctl, KP, KV, param_error, &chunk_status);
+					gpupreagg_reg_row<NG>(S, ctl, KP, KV, param_error, &chunk_status, summag);
 				}
 			}
 		}
@@ -1941,6 +2055,7 @@ gpupreagg_reg_kernel_body(kern_gpupreagg *kgpreagg, const kern_data_store *kds,
 			*(cl_uint *)(slab + i) = *(const cl_uint *)(lds + i);
 	}
 	gpupreagg_writeback_status(&kgpreagg->status, chunk_status);
+	gpupreagg_writeback_summag(kgpreagg, summag);
 }
 
 /* ====================================================================== *
@@ -1966,7 +2081,7 @@ struct gpupreagg_priv_state {
 STROM_DEVICE void
 gpupreagg_priv_row(char *lds, gpupreagg_priv_state &S, const gpupreagg_dense_ctl *ctl,
 				   const strom_kparams &KP, const strom_kvars &KV, cl_uint G,
-				   cl_int param_error, cl_int *chunk_status)
+				   cl_int param_error, cl_int *chunk_status, cl_ulong &summag)
 {
 	cl_int		errcode = param_error;
 	pg_bool_t	rc = gpupreagg_qual_eval(&errcode, KP, KV);
@@ -2031,9 +2146,8 @@ gpupreagg_priv_row(char *lds, gpupreagg_priv_state &S, const gpupreagg_dense_ctl
 			else																	\
 			{																		\
 				x = (cl_ulong)(cl_long)av_##aidx.value;								\
-				if (GPUPREAGG_OP_##OP == GPUPREAGG_OP_PSUM &&						\
-					gpupreagg_int8_near_overflow((cl_long)x))						\
-					STROM_SET_ERROR(chunk_status, StromError_CpuReCheck);			\
+				if (gpupreagg_is_intsum<GPUPREAGG_OP_##OP, base_t>::value && GPUPREAGG_SUMBITS_##aidx >= 64)	\
+					summag |= gpupreagg_sum_magnitude((cl_long)x);					\
 			}																		\
 			cur_##aidx = gpupreagg_merge8<GPUPREAGG_OP_##OP == GPUPREAGG_OP_NROWS	\
 										  ? GPUPREAGG_OP_PSUM : GPUPREAGG_OP_##OP,	\
@@ -2068,6 +2182,7 @@ gpupreagg_priv_column(kern_gpupreagg *kgpreagg, const kern_data_store *kds,
 	cl_uint		ntiles = (nitems + GPUPREAGG_REG_TILE_ROWS - 1) / GPUPREAGG_REG_TILE_ROWS;
 	cl_uint		G = ctl->groups_per_split;		/* 2 .. 32, one split */
 	cl_int		chunk_status = StromError_Success;
+	cl_ulong	summag = 0;			/* OR of the integer sums' input magnitudes */
 	cl_int		param_error = StromError_Success;
 	strom_kparams KP;
 	gpupreagg_lds_layout L;
@@ -2179,7 +2294,7 @@ gpupreagg_priv_column(kern_gpupreagg *kgpreagg, const kern_data_store *kds,
 					STROM_KVAR_LIST(X)
 #undef X
 					KV.__dummy = 0;
-					gpupreagg_priv_row(lds, S, ctl, KP, KV, G, param_error, &chunk_status);
+					gpupreagg_priv_row(lds, S, ctl, KP, KV, G, param_error, &chunk_status, summag);
 				}
 			}
 		}
@@ -2276,6 +2391,7 @@ gpupreagg_priv_column(kern_gpupreagg *kgpreagg, const kern_data_store *kds,
 			*(cl_uint *)(slab + i) = *(const cl_uint *)(lds + i);
 	}
 	gpupreagg_writeback_status(&kgpreagg->status, chunk_status);
+	gpupreagg_writeback_summag(kgpreagg, summag);
 }
 
 extern "C" __global__ void
@@ -2348,7 +2464,52 @@ struct gpupreagg_hash_head {
 	cl_uint		overflow;			/* set when a probe found no free slot */
 	cl_uint		stride;				/* GPUPREAGG_HASH_STRIDE, checked by the host */
 	cl_uint		naggs;
+	cl_uint		__pad[2];
+	/*
+	 * integer sums never wrap ("integer sums never wrap", above -- here for a table whose
+	 * accumulators are 64 bits wide and are updated by atomics all over the chip): an upper
+	 * bound of |any partial sum in this table|, the sum over the folded chunks of
+	 * rows x (largest input magnitude + 1).  While it stays below 2^63 nothing can have
+	 * wrapped and nothing is checked.  Two slots: the fold of chunk k reads slot k & 1 and
+	 * (its first work-group) writes the other, which the fold of chunk k + 1 reads -- no
+	 * work-group of a launch reads what another one of it writes.
+	 */
+	cl_ulong	sum_bound[2];
 };
+
+/* n rows of magnitude <= summag add up to at most this (saturating at 2^63) */
+STROM_DEVICE cl_ulong
+gpupreagg_sum_bound(cl_uint nrows, cl_ulong summag)
+{
+	cl_ulong	bound;
+	if (summag >= (1UL << 62) || __builtin_mul_overflow((cl_ulong)nrows, summag + 1, &bound) || bound > (1UL << 63))
+		return (nrows == 0 ? 0UL : (1UL << 63));
+	return bound;
+}
+
+/*
+ * a fold is about to add the request's rows to the table: is the bound still below
+ * 2^63 afterwards?  No: nothing is folded; the status becomes SumRangeUnproven (the host
+ * measures the table's true largest |sum| -- gpupreagg_hash_sum_refresh -- and sends the
+ * chunk once more), or CpuReCheck on that second attempt (turn bit 2).  turn bit 1: a
+ * relaunch for rows the table had no room for -- the chunk is accounted already.
+ */
+STROM_DEVICE bool
+gpupreagg_hash_sum_account(kern_gpupreagg *kgpreagg, gpupreagg_hash_head *head, cl_uint sum_turn)
+{
+	if (gpupreagg_intsum_index(GPUPREAGG_NAGGS) == 0 || (sum_turn & 2u) != 0)
+		return true;
+	cl_ulong	prev = head->sum_bound[sum_turn & 1u];
+	cl_ulong	add = gpupreagg_sum_bound(KERN_GPUPREAGG_FOLD_NROWS(kgpreagg), *KERN_GPUPREAGG_SUM_MAGNITUDE(kgpreagg));
+	bool		ok = (prev < (1UL << 63) && add < (1UL << 63) && prev + add < (1UL << 63));
+	if (blockIdx.x == 0 && threadIdx.x == 0)
+	{
+		head->sum_bound[(sum_turn & 1u) ^ 1u] = (ok ? prev + add : prev);
+		if (!ok)
+			atomicMax(&kgpreagg->status, (sum_turn & 4u) ? StromError_CpuReCheck : StromError_SumRangeUnproven);
+	}
+	return ok;
+}
 
 STROM_DEVICE char *gpupreagg_hash_rec(char *htab, cl_uint slot)
 { return htab + GPUPREAGG_HASH_HEAD + (size_t)slot * GPUPREAGG_HASH_STRIDE; }
@@ -2573,13 +2734,14 @@ gpupreagg_hash_body(kern_gpupreagg *kgpreagg,
 					const kern_data_store *ktoast,
 					const kern_row_map *krowmap,
 					char *htab, cl_uint claim_limit, kern_row_map *deferred,
-					cl_uint lds_slots, cl_uint nroles, char *lds, cl_uchar *rolemap)
+					cl_uint lds_slots, cl_uint nroles, char *lds, cl_uchar *rolemap, cl_uint sum_turn)
 {
 	const kern_parambuf *kparams = KERN_GPUPREAGG_PARAMBUF(kgpreagg);
 	gpupreagg_hash_head *head = (gpupreagg_hash_head *)htab;
 	bool		use_map = (krowmap != NULL && krowmap->nvalids >= 0);
 	cl_uint		nrows = (use_map ? (cl_uint)krowmap->nvalids : kds->nitems);
 	cl_int		chunk_status = StromError_Success;
+	cl_ulong	summag = 0;			/* OR of the integer sums' input magnitudes */
 	cl_int		param_error = StromError_Success;
 	strom_kparams KP;
 	gpupreagg_lds_layout L;
@@ -2587,6 +2749,8 @@ gpupreagg_hash_body(kern_gpupreagg *kgpreagg,
 
 	if (FOLD && kgpreagg->status != StromError_Success)
 		return;							/* the check pass found a reason to send the chunk back */
+	if (FOLD && !gpupreagg_hash_sum_account(kgpreagg, head, sum_turn))
+		return;							/* an integer sum could leave int8: nothing is folded */
 	gpupreagg_load_kparams(KP, kparams, &param_error);
 	if (FOLD)
 	{
@@ -2644,15 +2808,14 @@ gpupreagg_hash_body(kern_gpupreagg *kgpreagg,
 			STROM_SET_ERROR(&chunk_status, errcode);
 			return;
 		}
-#define X(aidx,resno,OP,NAME)														\
-		if (GPUPREAGG_OP_##OP == GPUPREAGG_OP_PSUM &&								\
-			!gpupreagg_is_float<pg_##NAME##_base_t>::value)							\
-			STROM_SET_RECHECK_IF(&chunk_status, !av_##aidx.isnull &					\
-								 gpupreagg_int8_near_overflow((cl_long)av_##aidx.value));
-		GPUPREAGG_AGG_LIST(X)
-#undef X
 		if (!FOLD)
 		{
+			/* integer sums without a static bound: the check pass measures their inputs */
+#define X(aidx,resno,OP,NAME)														\
+			if (gpupreagg_is_intsum<GPUPREAGG_OP_##OP, pg_##NAME##_base_t>::value && GPUPREAGG_SUMBITS_##aidx >= 64)	\
+				summag |= (av_##aidx.isnull ? 0UL : gpupreagg_sum_magnitude((cl_long)av_##aidx.value));
+			GPUPREAGG_AGG_LIST(X)
+#undef X
 			/* the check pass has the row's hash at hand: leave its role (6 bits: up to 64
 			 * roles) for the fold's role scans, which then read one byte per row instead
 			 * of the qual's and the keys' columns */
@@ -2936,6 +3099,7 @@ gpupreagg_hash_body(kern_gpupreagg *kgpreagg,
 		}
 	}
 	gpupreagg_writeback_status(&kgpreagg->status, chunk_status);
+	gpupreagg_writeback_summag(kgpreagg, summag);
 }
 
 extern "C" __global__ void
@@ -2946,9 +3110,9 @@ gpupreagg_hash_check(kern_gpupreagg *kgpreagg, const kern_data_store *kds,
 					 cl_uchar *rolemap)
 {
 	if (kds->format == KDS_FORMAT_COLUMN)
-		gpupreagg_hash_body<true, false, false>(kgpreagg, kds, ktoast, krowmap, htab, 0, NULL, 0, 1, NULL, rolemap);
+		gpupreagg_hash_body<true, false, false>(kgpreagg, kds, ktoast, krowmap, htab, 0, NULL, 0, 1, NULL, rolemap, 0);
 	else
-		gpupreagg_hash_body<false, false, false>(kgpreagg, kds, ktoast, krowmap, htab, 0, NULL, 0, 1, NULL, rolemap);
+		gpupreagg_hash_body<false, false, false>(kgpreagg, kds, ktoast, krowmap, htab, 0, NULL, 0, 1, NULL, rolemap, 0);
 }
 
 extern "C" __global__ void
@@ -2956,20 +3120,20 @@ __launch_bounds__(GPUPREAGG_BLOCK)
 gpupreagg_hash_fold(kern_gpupreagg *kgpreagg, const kern_data_store *kds,
 					const kern_data_store *ktoast, const kern_row_map *krowmap, char *htab,
 					cl_uint claim_limit, kern_row_map *deferred, cl_uint lds_slots, cl_uint nroles,
-					cl_uchar *rolemap)
+					cl_uchar *rolemap, cl_uint sum_turn)
 {
 	extern __shared__ __attribute__((aligned(16))) char lds[];
 	/* (decided once per launch; with roles a row is read by several
 	 * work-groups of the XCD, so its lines should stay in L2) */
 	if (kds->format != KDS_FORMAT_COLUMN)
 		gpupreagg_hash_body<false, true, false>(kgpreagg, kds, ktoast, krowmap, htab, claim_limit, deferred,
-												lds_slots, nroles, lds, NULL);
+												lds_slots, nroles, lds, NULL, sum_turn);
 	else if (nroles > 1)
 		gpupreagg_hash_body<true, true, true>(kgpreagg, kds, ktoast, krowmap, htab, claim_limit, deferred,
-											  lds_slots, nroles, lds, rolemap);
+											  lds_slots, nroles, lds, rolemap, sum_turn);
 	else
 		gpupreagg_hash_body<true, true, false>(kgpreagg, kds, ktoast, krowmap, htab, claim_limit, deferred,
-											   lds_slots, nroles, lds, NULL);
+											   lds_slots, nroles, lds, NULL, sum_turn);
 }
 
 /* ---------------------------------------------------------------------- *
@@ -3108,6 +3272,7 @@ gpupreagg_hash_parts_body(kern_gpupreagg *kgpreagg,
 	bool		use_map = (krowmap != NULL && krowmap->nvalids >= 0);
 	cl_uint		nrows = (use_map ? (cl_uint)krowmap->nvalids : kds->nitems);
 	cl_int		chunk_status = StromError_Success;
+	cl_ulong	summag = 0;			/* OR of the integer sums' input magnitudes */
 	cl_int		param_error = StromError_Success;
 	const cl_uint nparts = ctl->nparts;
 	const cl_uint pshift = ctl->pshift;
@@ -3200,10 +3365,8 @@ gpupreagg_hash_parts_body(kern_gpupreagg *kgpreagg,
 					else
 					{
 #define X(aidx,resno,OP,NAME)														\
-						if (GPUPREAGG_OP_##OP == GPUPREAGG_OP_PSUM &&						\
-							!gpupreagg_is_float<pg_##NAME##_base_t>::value)					\
-							STROM_SET_RECHECK_IF(&chunk_status, !av_##aidx.isnull &			\
-												 gpupreagg_int8_near_overflow((cl_long)av_##aidx.value));
+						if (gpupreagg_is_intsum<GPUPREAGG_OP_##OP, pg_##NAME##_base_t>::value && GPUPREAGG_SUMBITS_##aidx >= 64)	\
+							summag |= (av_##aidx.isnull ? 0UL : gpupreagg_sum_magnitude((cl_long)av_##aidx.value));
 						GPUPREAGG_AGG_LIST(X)
 #undef X
 						part = (gpupreagg_hash_of(kimg, knull) >> pshift) & (nparts - 1);
@@ -3221,6 +3384,7 @@ gpupreagg_hash_parts_body(kern_gpupreagg *kgpreagg,
 				__hip_atomic_fetch_add(&hist[i], c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 		}
 		gpupreagg_writeback_status(&kgpreagg->status, chunk_status);
+		gpupreagg_writeback_summag(kgpreagg, summag);
 		return;
 	}
 	if (MODE == 2)
@@ -3616,7 +3780,8 @@ gpupreagg_hash_lds_find(const gpupreagg_hash_lds &T, cl_uint hash, const cl_ulon
 __device__ __forceinline__ void
 gpupreagg_hash_fold_units(kern_gpupreagg *kgpreagg, char *htab, cl_uint claim_limit,
 						  gpupreagg_part_ctl *ctl, const cl_uint *units, const cl_ulong *records,
-						  cl_uint lds_slots, const cl_uint *todo, cl_uint ntodo, cl_uint *redo, char *lds)
+						  cl_uint lds_slots, const cl_uint *todo, cl_uint ntodo, cl_uint *redo, char *lds,
+						  cl_uint sum_turn)
 {
 	gpupreagg_hash_head *head = (gpupreagg_hash_head *)htab;
 	gpupreagg_lds_layout L;
@@ -3625,6 +3790,8 @@ gpupreagg_hash_fold_units(kern_gpupreagg *kgpreagg, char *htab, cl_uint claim_li
 
 	if (kgpreagg->status != StromError_Success)
 		return;
+	if (!gpupreagg_hash_sum_account(kgpreagg, head, sum_turn))
+		return;							/* an integer sum could leave int8: nothing is folded */
 	gpupreagg_lds_layout_init(L, lds_slots, 1);
 	T.state = (cl_uint *)(lds + L.total);
 	T.knull = T.state + lds_slots;
@@ -3807,10 +3974,11 @@ extern "C" __global__ void
 __launch_bounds__(GPUPREAGG_BLOCK)
 gpupreagg_hash_fold_parts(kern_gpupreagg *kgpreagg, char *htab, cl_uint claim_limit,
 						  gpupreagg_part_ctl *ctl, const cl_uint *units, const cl_ulong *records,
-						  cl_uint lds_slots, const cl_uint *todo, cl_uint ntodo, cl_uint *redo)
+						  cl_uint lds_slots, const cl_uint *todo, cl_uint ntodo, cl_uint *redo, cl_uint sum_turn)
 {
 	extern __shared__ __attribute__((aligned(16))) char lds[];
-	gpupreagg_hash_fold_units(kgpreagg, htab, claim_limit, ctl, units, records, lds_slots, todo, ntodo, redo, lds);
+	gpupreagg_hash_fold_units(kgpreagg, htab, claim_limit, ctl, units, records, lds_slots, todo, ntodo, redo, lds,
+							  sum_turn);
 }
 
 /* min / max accumulators start from their identities (sums from the zeroed table) */
@@ -4005,6 +4173,11 @@ gpupreagg_hash_rehash(const char *otab, char *ntab)
 	gpupreagg_hash_head *nhead = (gpupreagg_hash_head *)ntab;
 	cl_uint		C = ohead->capacity;
 
+	if (blockIdx.x == 0 && threadIdx.x == 0)
+	{
+		nhead->sum_bound[0] = ohead->sum_bound[0];
+		nhead->sum_bound[1] = ohead->sum_bound[1];
+	}
 	for (cl_uint i = blockIdx.x * blockDim.x + threadIdx.x; i < C; i += gridDim.x * blockDim.x)
 	{
 		const char *src = gpupreagg_hash_rec(otab, i);
@@ -4024,6 +4197,51 @@ gpupreagg_hash_rehash(const char *otab, char *ntab)
 		*HASH_REC_FLAGS(dst) = *HASH_REC_FLAGS(src);
 		for (int a = 0; a < GPUPREAGG_NAGGS; a++)
 			HASH_REC_VALS(dst)[a] = HASH_REC_VALS(src)[a];
+	}
+}
+
+/*
+ * the bound of the integer sums, measured: the largest |sum| the table holds now.  The
+ * host zeroes BOTH slots first and runs this after groups arrived otherwise than by a fold
+ * (merge / import), or when a fold found the running bound at 2^63 (see
+ * gpupreagg_hash_sum_account): the bound restarts from what is really there.
+ */
+extern "C" __global__ void
+__launch_bounds__(256)
+gpupreagg_hash_sum_refresh(char *htab)
+{
+	gpupreagg_hash_head *head = (gpupreagg_hash_head *)htab;
+	cl_uint		C = head->capacity;
+	cl_ulong	most = 0;
+
+	for (cl_uint i = blockIdx.x * blockDim.x + threadIdx.x; i < C; i += gridDim.x * blockDim.x)
+	{
+		const char *rec = gpupreagg_hash_rec(htab, i);
+		if (*HASH_REC_STATE(rec) != 2)
+			continue;
+		cl_uint		flags = *HASH_REC_FLAGS(rec);
+#define X(aidx,resno,OP,NAME)															\
+		if (gpupreagg_is_intsum<GPUPREAGG_OP_##OP, pg_##NAME##_base_t>::value && (flags & (2u << aidx)))	\
+		{																				\
+			cl_ulong m = gpupreagg_sum_magnitude((cl_long)HASH_REC_VALS(rec)[aidx]);	\
+			most = (m >= most ? m : most);												\
+		}
+		GPUPREAGG_AGG_LIST(X)
+#undef X
+	}
+#pragma unroll
+	for (int m = 32; m > 0; m >>= 1)
+	{
+		cl_ulong o = ((cl_ulong)__shfl_xor((cl_uint)(most >> 32), m, STROM_WAVE) << 32) |
+			__shfl_xor((cl_uint)most, m, STROM_WAVE);
+		most = (o > most ? o : most);
+	}
+	if (strom_lane_id() == 0 && most != 0)
+	{
+		/* |sum| <= magnitude + 1 */
+		cl_ulong	bound = (most >= (1UL << 63) - 1 ? (1UL << 63) : most + 1);
+		__hip_atomic_fetch_max(&head->sum_bound[0], bound, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		__hip_atomic_fetch_max(&head->sum_bound[1], bound, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 	}
 }
 
@@ -4284,6 +4502,19 @@ gpupreagg_dense_merge_body(kern_gpupreagg *__restrict__ kgpreagg,
 
 	if (kgpreagg->status != StromError_Success)
 		return;
+#if !(defined(GPUPREAGG_CHECKED) && GPUPREAGG_CHECKED)
+	/*
+	 * integer sums: the slabs are taken only when no sum of this chunk's inputs can
+	 * have left int8 (every work-group decides the same from the same two words).
+	 * Otherwise nothing is merged and the host folds the chunk again, checked.
+	 */
+	if (!gpupreagg_sum_range_proven(KERN_GPUPREAGG_FOLD_NROWS(kgpreagg), *KERN_GPUPREAGG_SUM_MAGNITUDE(kgpreagg)))
+	{
+		if (blockIdx.x == 0 && threadIdx.x == 0)
+			atomicMax(&kgpreagg->status, StromError_SumRangeUnproven);
+		return;
+	}
+#endif
 	/* stripes: about 8 slabs per thread (the loop is latency bound: the
 	 * slabs are small), at least 4 group lanes for some coalescing */
 	while (WS < 64 && WS * 8 < wgs_per_split)
@@ -4365,6 +4596,21 @@ gpupreagg_dense_merge_body(kern_gpupreagg *__restrict__ kgpreagg,
 					if (!CHECK)																	\
 						t_vals[gid] += acc;														\
 				}																				\
+				else if (gpupreagg_is_intsum<GPUPREAGG_OP_##OP, pg_##NAME##_base_t>::value)		\
+				{																				\
+					/* 128-bit total: the chunk's sum (exact in 64 bits, see above) is added		\
+					 * with carry into {low word, high word} */									\
+					if (!CHECK)																	\
+					{																			\
+						cl_long	   *t_hi = (cl_long *)(table + gpupreagg_table_offset			\
+							(1 + GPUPREAGG_NAGGS + gpupreagg_intsum_index(aidx), N));			\
+						cl_ulong	lo = ((had & (2u << aidx)) ? t_vals[gid] : 0UL);				\
+						cl_long		hi = ((had & (2u << aidx)) ? t_hi[gid] : 0L);					\
+						cl_ulong	nlo = lo + acc;													\
+						t_vals[gid] = nlo;														\
+						t_hi[gid] = hi + ((cl_long)acc >> 63) + (nlo < lo ? 1L : 0L);			\
+					}																			\
+				}																				\
 				else																			\
 				{																				\
 					cl_ulong merged = (had & (2u << aidx))										\
@@ -4395,7 +4641,7 @@ gpupreagg_dense_merge(kern_gpupreagg *kgpreagg, const gpupreagg_dense_ctl *ctl,
 	gpupreagg_dense_merge_body<false>(kgpreagg, ctl, slabs, table);
 }
 
-#if defined(GPUPREAGG_NUMERIC_AGGS) && GPUPREAGG_NUMERIC_AGGS
+#if (defined(GPUPREAGG_NUMERIC_AGGS) && GPUPREAGG_NUMERIC_AGGS) || (defined(GPUPREAGG_CHECKED) && GPUPREAGG_CHECKED)
 extern "C" __global__ void
 __launch_bounds__(256)
 gpupreagg_dense_merge_check(kern_gpupreagg *kgpreagg, const gpupreagg_dense_ctl *ctl,

@@ -102,6 +102,21 @@ struct strom_gpupreagg {
 	std::map<cl_uint, packed_geom> packed;		/* by number of roles */
 	size_t				packed_static_lds = ~(size_t)0;
 	std::mutex			lock;
+	/*
+	 * integer sums never wrap (strom_gpupreagg.h): per aggregate the static magnitude bound
+	 * the code generator found (GPUPREAGG_SUMBITS_<a>: 0 not an integer sum, 1..63 bits, 64
+	 * none), the OR of the static bounds (preset in every request's kern_gpupreagg), the
+	 * aggregates whose sums are 128 bits wide in the resident table, and the program built
+	 * with GPUPREAGG_CHECKED that folds a chunk whose range proof failed
+	 */
+	std::vector<int>	sumbits;
+	cl_ulong			static_summag = 0;
+	std::vector<int>	intsum_of;			/* aggregate -> index among the integer sums, or -1 */
+	int					nintsums = 0;
+	strom_devprog_key	key_checked = 0;
+	Program			   *prog_checked = nullptr;
+	std::atomic<cl_uint> checked_folds{0};	/* (reported: chunks that took the checked program) */
+	cl_uint				sum_turn = 0;		/* hashed: parity of the next fold (gpupreagg_hash_sum_account) */
 
 	/* mirrors gpupreagg_image_offset / gpupreagg_table_offset of
 	 * strom_gpupreagg.h: section 0 = flags, 1+a = values of aggregate a,
@@ -134,6 +149,10 @@ struct strom_gpupreagg {
 		return flags + vals * (size_t)(sec - 1);
 	}
 	int nsections() const { return 1 + (int)agg_resno.size(); }
+	/* the table has one more section per integer sum: its high word (section 1 + naggs + j) */
+	int table_sections() const { return nsections() + nintsums; }
+	size_t table_hi_offset(int a, cl_uint N) const { return table_offset(nsections() + intsum_of[a], N); }
+	bool is_intsum(int a) const { return intsum_of[a] >= 0; }
 };
 
 namespace {
@@ -274,7 +293,7 @@ setup_layout(strom_gpupreagg *sess)
 	if (sess->reg_groups == 2)
 		sess->lds_bytes = priv_bytes;
 	ctl.slab_bytes = STROM_TYPEALIGN(256, sess->image_offset(sess->nsections(), ctl.groups_per_split, 1));
-	sess->table_bytes = sess->table_offset(sess->nsections(), ctl.ngroups);
+	sess->table_bytes = sess->table_offset(sess->table_sections(), ctl.ngroups);
 	/* work-groups: fill the CUs at the occupancy LDS allows */
 	size_t	per_cu = std::max<size_t>(1, std::min<size_t>((size_t)dev->prop.sharedMemPerBlock / (sess->lds_bytes + 4608),	/* + static LDS */
 														  2048 / sess->block));
@@ -546,16 +565,45 @@ struct preagg_request {
 	std::shared_ptr<std::vector<char>> joined_map;	/* host image of gpupreagg_joined_map */
 };
 
+/* OR of the magnitudes a zone map allows (strom_gpupreagg.h: gpupreagg_sum_magnitude) */
+cl_ulong
+zone_magnitude(const kern_coldir &cd)
+{
+	cl_long		lo = cd.minval, hi = cd.maxval;
+	return (cl_ulong)(lo ^ (lo >> 63)) | (cl_ulong)(hi ^ (hi >> 63));
+}
+
+/*
+ * the program that folds a chunk whose integer sums could not be proven to stay in
+ * int8 (strom_gpupreagg.h, "integer sums never wrap"): the session's own source built with
+ * GPUPREAGG_CHECKED.  Made on first use -- such chunks are rare -- and kept with the session.
+ */
+int
+ensure_checked_program(strom_gpupreagg *sess)
+{
+	std::lock_guard<std::mutex> g(sess->lock);
+	if (sess->prog_checked)
+		return 0;
+	std::string	source = "#define GPUPREAGG_CHECKED 1\n" + sess->prog->source;
+	strom_devprog_key key = strom_get_devprog_key(source.c_str(), sess->prog->extra_flags);
+	Program	   *prog = (key ? lookup_program(key) : nullptr);
+	if (!prog)
+		return StromError_OutOfMemory;
+	sess->key_checked = key;
+	sess->prog_checked = prog;
+	return 0;
+}
+
 void
-gpupreagg_launch(strom_task_impl *task, preagg_request req)
+gpupreagg_launch(strom_task_impl *task, preagg_request req, bool checked = false)
 {
 	strom_gpupreagg *sess = req.sess;
 	Device	   *dev = task->dev;
-	Program	   *prog = sess->prog;
+	Program	   *prog = (checked ? sess->prog_checked : sess->prog);
 	int			errcode = 0;
 
 	(void)hipSetDevice(dev->hip_id);
-	if (req.joined_buffer)
+	if (req.joined_buffer && !checked)
 		task->devbufs.push_back(req.joined_buffer);		/* released with this task, whatever happens */
 	if (prog->state != STROM_DEVPROG_READY)
 	{
@@ -583,7 +631,8 @@ gpupreagg_launch(strom_task_impl *task, preagg_request req)
 	bool	use_joined = (req.joined_results != nullptr);
 	bool	use_column = (!use_joined && !use_lookup && req.format == KDS_FORMAT_COLUMN &&
 						  req.krowmap == nullptr && req.rowmap_dev == nullptr);
-	bool	use_reg = (use_column && sess->reg_groups != 0);
+	/* (the checked program adds in LDS with returning atomics: the LDS-atomics kernels only) */
+	bool	use_reg = (use_column && sess->reg_groups != 0 && !checked);
 	hipFunction_t fn = prog->get_function(dev, use_lookup ? "gpupreagg_dense_lookup"
 										  : use_joined ? "gpupreagg_dense_joined"
 										  : use_reg ? (sess->reg_groups == 1 ? "gpupreagg_reg1_column"
@@ -596,10 +645,12 @@ gpupreagg_launch(strom_task_impl *task, preagg_request req)
 		task_fail(task, errcode);
 		return;
 	}
+	/* what is known about the integer sums' inputs before the fold measures the rest */
+	cl_ulong	summag = sess->static_summag;
 	/* packed accumulators for this chunk?  (fewer id-range roles: see packed_plan) */
 	pack_ctl	pk;
 	strom_gpupreagg::packed_geom *packed = nullptr;
-	if ((use_lookup || (use_column && !use_reg)) && sess->packable && sess->ctl.nsplits > 1)
+	if ((use_lookup || (use_column && !use_reg)) && sess->packable && sess->ctl.nsplits > 1 && !checked)
 	{
 		int		e2 = 0;
 		hipFunction_t fn_packed = prog->get_function(dev, use_lookup ? "gpupreagg_packed_lookup"
@@ -637,7 +688,14 @@ gpupreagg_launch(strom_task_impl *task, preagg_request req)
 		}
 		packed = packed_plan(sess, fn_packed, coldir, ncols, req.nrows, &pk);
 		if (packed)
+		{
 			fn = fn_packed;
+			/* the packed fold measures nothing: the zone maps that bound its fields bound
+			 * the integer sums' inputs too */
+			for (size_t a = 0; a < sess->agg_resno.size(); a++)
+				if (sess->pack_kind[a] == 2 && sess->sumbits[a] >= 64)
+					summag |= zone_magnitude(coldir[sess->pack_attno[a] - 1]);
+		}
 	}
 	/* kern_gpupreagg image: {status, sortbuf_len, pad, kern_parambuf} [+ the pack control block] */
 	size_t	kg_len = STROMALIGN(offsetof(kern_gpupreagg, kparams) + sess->kparams.size());
@@ -655,6 +713,9 @@ gpupreagg_launch(strom_task_impl *task, preagg_request req)
 	task->main_devptr = d_kg;
 	memset(stage, 0, kg_len);
 	memcpy(stage + offsetof(kern_gpupreagg, kparams), sess->kparams.data(), sess->kparams.size());
+	/* KERN_GPUPREAGG_FOLD_NROWS / _SUM_MAGNITUDE of strom_gpupreagg.h */
+	((kern_gpupreagg *)stage)->sortbuf_len = (cl_int)req.nrows;
+	memcpy(((kern_gpupreagg *)stage)->__padding, &summag, sizeof(summag));
 	if (packed)
 		memcpy(stage + kg_len, &pk, sizeof(pk));
 
@@ -808,7 +869,7 @@ gpupreagg_launch(strom_task_impl *task, preagg_request req)
 		unsigned gl = 256 / ws;
 		unsigned mgrid = std::min<unsigned>((lctl.ngroups + gl - 1) / gl,
 											(unsigned)dev->prop.multiProcessorCount * 8);
-		if (sess->numeric_aggs)
+		if (sess->numeric_aggs || checked)
 		{
 			/* numeric sums may leave the 64-bit form while slabs are added up: find
 			 * out BEFORE the table takes any of it (gpupreagg_dense_merge_body<CHECK>) */
@@ -840,10 +901,34 @@ gpupreagg_launch(strom_task_impl *task, preagg_request req)
 	task->pfm.bytes_dma_recv += sizeof(cl_int);
 	task_event(task, s_mrg);							/* ev[3] (+1; piped: ev[5]) */
 	task->ev_preagg_piped = piped;
-	task->finish = [stage_status](strom_task_impl *t)
+	if (checked)
+		sess->checked_folds++;
+	task->finish = [stage_status, req, checked](strom_task_impl *t)
 	{
 		cl_int status;
 		memcpy(&status, stage_status, sizeof(status));
+		if (status == StromError_SumRangeUnproven && !checked)
+		{
+			/*
+			 * the merge could not prove that the chunk's integer sums stay in int8 and left
+			 * the table alone: the chunk is folded again by the checked program (on a worker
+			 * thread: the program may have to be built first), and this request completes
+			 * when that is through
+			 */
+			t->retry = [t, req]()
+			{
+				int		rc = ensure_checked_program(req.sess);
+				if (rc != 0)
+				{
+					task_fail(t, rc);
+					return;
+				}
+				program_run_or_park(req.sess->prog_checked, [t, req]() { gpupreagg_launch(t, req, true); });
+			};
+			return;
+		}
+		if (status == StromError_SumRangeUnproven)
+			status = StromError_CpuReCheck;		/* (not reached: the checked merge has no proof to fail) */
 		t->errcode = status;		/* 0, CpuReCheck, or significant */
 	};
 	task_enqueue(task);
@@ -1022,8 +1107,33 @@ hash_table_grow(strom_gpupreagg *sess, cl_ulong min_capacity)
 	return 0;
 }
 
+/*
+ * the bound of the table's integer sums restarts from what the table really holds
+ * (gpupreagg_hash_sum_refresh; queued on the session's stream, sess->lock held)
+ */
+int
+hash_sum_refresh(strom_gpupreagg *sess)
+{
+	Device	   *dev = sess->dev;
+	int			errcode = 0;
+	if (sess->nintsums == 0 || !sess->htab)
+		return 0;
+	hipFunction_t fn = sess->prog->get_function(dev, "gpupreagg_hash_sum_refresh", &errcode);
+	if (!fn)
+		return errcode;
+	void	   *a_tab = sess->htab;
+	void	   *args[] = { &a_tab };
+	unsigned	grid = std::max(1u, std::min<unsigned>((sess->hash_capacity + 255) / 256,
+													(unsigned)dev->prop.multiProcessorCount * 8));
+	/* sum_bound[2] sits 32 bytes into the head (struct gpupreagg_hash_head) */
+	if (hipMemsetAsync(sess->htab + 32, 0, 16, dev->streams[0]) != hipSuccess ||
+		hipModuleLaunchKernel(fn, grid, 1, 1, 256, 1, 1, 0, dev->streams[0], args, nullptr) != hipSuccess)
+		return StromError_HipInternal;
+	return 0;
+}
+
 void
-gpupreagg_launch_hashed(strom_task_impl *task, preagg_request req)
+gpupreagg_launch_hashed(strom_task_impl *task, preagg_request req, bool second = false)
 {
 	strom_gpupreagg *sess = req.sess;
 	Device	   *dev = task->dev;
@@ -1084,6 +1194,22 @@ gpupreagg_launch_hashed(strom_task_impl *task, preagg_request req)
 	task->main_devptr = d_kg;
 	memset(stage, 0, kg_len);
 	memcpy(stage + offsetof(kern_gpupreagg, kparams), sess->kparams.data(), sess->kparams.size());
+	/* integer sums never wrap (strom_gpupreagg.h): rows of the request, what is known about
+	 * the inputs before the check pass measures the rest */
+	((kern_gpupreagg *)stage)->sortbuf_len = (cl_int)req.nrows;
+	memcpy(((kern_gpupreagg *)stage)->__padding, &sess->static_summag, sizeof(cl_ulong));
+	/* the fold's turn (gpupreagg_hash_sum_account): parity; 4 = second attempt, after the
+	 * bound was measured; relaunches for deferred rows add 2 */
+	cl_uint		sum_turn = (sess->sum_turn++ & 1u) | (second ? 4u : 0u);
+	if (second)
+	{
+		int rc = hash_sum_refresh(sess);
+		if (rc)
+		{
+			task_fail(task, rc);
+			return;
+		}
+	}
 
 	task_event(task);									/* ev[0] */
 	REQ_CHECK(hipMemcpyAsync(d_kg, stage, kg_len, hipMemcpyHostToDevice, task->stream),
@@ -1300,8 +1426,9 @@ gpupreagg_launch_hashed(strom_task_impl *task, preagg_request req)
 			if (may_defer)
 				REQ_CHECK(hipMemsetAsync(d_ctl + offsetof(part_ctl, deferred), 0, sizeof(cl_uint), task->stream),
 						  "reset the redo list");
+			cl_uint		a_turn = sum_turn | (turn > 0 ? 2u : 0u);
 			void	   *args[] = { &a_kg, &a_tab, &claim_limit, &a_ctl, &a_units, &a_records, &lds_slots,
-								   &a_todo, &ntodo, &a_redo };
+								   &a_todo, &ntodo, &a_redo, &a_turn };
 			REQ_CHECK(hipModuleLaunchKernel(fn_units, fold_grid, 1, 1, block, 1, 1, (unsigned)lds_bytes,
 											task->stream, args, nullptr),
 					  "launch gpupreagg hash fold (partitions)");
@@ -1448,8 +1575,9 @@ gpupreagg_launch_hashed(strom_task_impl *task, preagg_request req)
 			}
 			/* (deferred rows of a later turn are a row map: the scan over the columns) */
 			void	   *a_rm = (turn == 0 && nroles > 1 ? a_rolemap : nullptr);
+			cl_uint		a_turn = sum_turn | (turn > 0 ? 2u : 0u);
 			void	   *args[] = { &a_kg, &a_kds, &a_toast, &a_map, &a_tab, &claim_limit, &a_defer, &lds_slots,
-								   &nroles, &a_rm };
+								   &nroles, &a_rm, &a_turn };
 			unsigned	unit = 8 * nroles;
 			unsigned	grid = std::min<unsigned>(((todo + block - 1) / block + unit - 1) / unit * unit, fold_grid);
 			grid = std::max(unit, grid / unit * unit);
@@ -1482,12 +1610,21 @@ gpupreagg_launch_hashed(strom_task_impl *task, preagg_request req)
 	task->pfm.num_dma_recv += 2;
 	task->pfm.bytes_dma_recv += sizeof(cl_int) + 16;
 	task_event(task);									/* ev[3] */
-	task->finish = [stage_status, sess](strom_task_impl *t)
+	task->finish = [stage_status, sess, req, second](strom_task_impl *t)
 	{
 		cl_int	status;
 		cl_uint	words[4];
 		memcpy(&status, stage_status, sizeof(status));
 		memcpy(words, stage_status + 16, sizeof(words));
+		if (status == StromError_SumRangeUnproven && !second)
+		{
+			/* the running bound of the integer sums reached 2^63 and nothing was folded:
+			 * once more, with the bound measured from the table (hash_sum_refresh) */
+			t->retry = [t, req]() { gpupreagg_launch_hashed(t, req, true); };
+			return;
+		}
+		if (status == StromError_SumRangeUnproven)
+			status = StromError_CpuReCheck;
 		if (status == StromError_Success && words[3] != 0)
 			status = StromError_DataStoreNoSpace;	/* cannot happen: headroom is kept for every claim */
 		sess->groups_known = std::max<cl_uint>(sess->groups_known, words[2]);
@@ -1564,6 +1701,30 @@ gpupreagg_session_new(strom_devprog_key key,
 			}
 			if (sess->pack_kind.size() != sess->agg_resno.size() || sess->agg_resno.size() > 32)
 				sess->packable = false;
+		}
+		/* integer sums: which aggregates, and what the code generator knows about their inputs */
+		for (size_t a = 0; a < sess->agg_resno.size(); a++)
+		{
+			const strom_preagg_target &t = sess->targets[sess->agg_resno[a]];
+			bool	intsum = (t.kind == STROM_PREAGG_PSUM &&
+							  (t.type_oid == STROM_INT8OID || (t.type_oid == STROM_NUMERICOID && t.scale >= 0)));
+			char	name[64];
+			int		bits = 64;
+			snprintf(name, sizeof(name), "#define GPUPREAGG_SUMBITS_%zu ", a);
+			const char *def = strstr(src, name);
+			if (def)
+				bits = atoi(def + strlen(name));
+			if (intsum != (bits != 0))
+			{
+				/* the caller's targets do not describe this program */
+				*p_errcode = StromError_BadRequestMessage;
+				delete sess;
+				return nullptr;
+			}
+			sess->sumbits.push_back(bits);
+			sess->intsum_of.push_back(intsum ? sess->nintsums++ : -1);
+			if (bits >= 1 && bits <= 63)
+				sess->static_summag |= ((1UL << bits) - 1);
 		}
 	}
 	if (const char *v = getenv("STROM_GPUPREAGG_BLOCK"))
@@ -2257,6 +2418,10 @@ strom::gpupreagg_hash_import_device(strom_gpupreagg *sess, const char *d_recs, c
 	dev->pool.release(d_counts);
 	if (!ok)
 		return StromError_HipInternal;
+	/* groups arrived otherwise than by a fold: the integer sums' bound is measured anew */
+	rc = hash_sum_refresh(sess);
+	if (rc)
+		return rc;
 	cl_uint		overflow = 0;
 	rc = hash_table_ngroups(sess, &ngroups, &overflow);
 	if (rc == 0)
@@ -2370,6 +2535,8 @@ strom_gpupreagg_release(strom_gpupreagg *sess)
 			(void)hipEventDestroy(sess->merge_ev[b]);
 	if (sess->htab)
 		dev->pool.release(sess->htab);
+	if (sess->key_checked)
+		strom_put_devprog_key(sess->key_checked);
 	strom_put_devprog_key(sess->key);
 	delete sess;
 }
@@ -2406,6 +2573,62 @@ struct numeric_spill {
 	int			resno;
 	cl_ulong	image;
 };
+
+/*
+ * An integer sum of the resident table is 128 bits wide {lo, hi} (strom_gpupreagg.h:
+ * "integer sums never wrap"); a partial row carries an int8, or a 64-bit numeric with a
+ * 57-bit mantissa.  A total that does not fit leaves as SEVERAL partial rows of its group --
+ * partial rows add up, so the final aggregate is unchanged: datum images of the pieces, the
+ * first for the group's own row.  int8: pieces of +-(2^63 - 1); numeric at 10^-scale: the
+ * total's base-10^17 digits (each a 57-bit mantissa with its own exponent).
+ */
+int
+sum_pieces(const strom_preagg_target &t, cl_ulong lo, cl_long hi, std::vector<cl_ulong> &out)
+{
+	__int128	total = ((__int128)hi << 64) | (__int128)(unsigned __int128)lo;
+	out.clear();
+	if (t.type_oid != STROM_NUMERICOID)
+	{
+		const __int128 most = (__int128)INT64_MAX;
+		for (int n = 0; ; n++)
+		{
+			if (n == 4096)
+				return StromError_DataStoreOutOfRange;	/* (a total beyond 2^75: not a sum of int8 rows) */
+			if (total >= -most - 1 && total <= most)
+			{
+				out.push_back((cl_ulong)(cl_long)total);
+				return 0;
+			}
+			cl_long piece = (total > 0 ? INT64_MAX : -INT64_MAX);
+			out.push_back((cl_ulong)piece);
+			total -= piece;
+		}
+	}
+	bool		neg = (total < 0);
+	unsigned __int128 mag = (neg ? (unsigned __int128)0 - (unsigned __int128)total : (unsigned __int128)total);
+	cl_ulong	img;
+	if (mag < ((unsigned __int128)1 << 63) &&
+		fixed_to_numeric(neg ? -(cl_long)(cl_ulong)mag : (cl_long)(cl_ulong)mag, t.scale, &img))
+	{
+		out.push_back(img);
+		return 0;
+	}
+	const cl_ulong P17 = 100000000000000000UL;
+	for (int k = 0; mag != 0; k++)
+	{
+		cl_long		digit = (cl_long)(cl_ulong)(mag % P17);
+		mag /= P17;
+		if (digit == 0 && !(mag == 0 && out.empty()))
+			continue;
+		/* digit x 10^(17k) at 10^-scale = digit at 10^-(scale - 17k) */
+		if (!fixed_to_numeric(neg ? -digit : digit, t.scale - 17 * k, &img))
+			return StromError_DataStoreOutOfRange;
+		out.push_back(img);
+	}
+	if (out.empty())
+		out.push_back(0);
+	return 0;
+}
 
 }	/* namespace */
 
@@ -2701,7 +2924,7 @@ strom_gpupreagg_fetch(strom_gpupreagg *sess, kern_data_store *dest, size_t destl
 	const cl_uint *gflags = (const cl_uint *)host.data();
 	size_t	ngroups = 0;
 	std::vector<numeric_spill> spills;
-	const cl_long P17 = 100000000000000000L;
+	std::vector<cl_ulong> pieces;
 	for (cl_uint g = 0; g < N; g++)
 	{
 		if (!(gflags[g] & 1))
@@ -2709,19 +2932,18 @@ strom_gpupreagg_fetch(strom_gpupreagg *sess, kern_data_store *dest, size_t destl
 		ngroups++;
 		for (size_t a = 0; a < sess->agg_resno.size(); a++)
 		{
+			/* an integer sum (128 bits in the table) that does not fit its datum leaves as
+			 * several partial rows: see sum_pieces */
 			const strom_preagg_target &t = sess->targets[sess->agg_resno[a]];
-			if (t.type_oid != STROM_NUMERICOID || t.scale < 0 || t.kind == STROM_PREAGG_NROWS ||
-				!(gflags[g] & (2u << a)))
+			if (!sess->is_intsum((int)a) || !(gflags[g] & (2u << a)))
 				continue;
-			cl_long v = ((const cl_long *)(host.data() + sess->table_offset(1 + (int)a, N)))[g];
-			cl_ulong img;
-			if (!fixed_to_numeric(v, t.scale, &img))
-			{
-				cl_long hi = (v / P17) * P17;
-				if (!fixed_to_numeric(hi, t.scale, &img))
-					return -StromError_DataStoreOutOfRange;
-				spills.push_back(numeric_spill{g, sess->agg_resno[a], img});
-			}
+			cl_ulong lo = ((const cl_ulong *)(host.data() + sess->table_offset(1 + (int)a, N)))[g];
+			cl_long	 hi = ((const cl_long *)(host.data() + sess->table_hi_offset((int)a, N)))[g];
+			int		rc = sum_pieces(t, lo, hi, pieces);
+			if (rc != 0)
+				return -rc;
+			for (size_t k = 1; k < pieces.size(); k++)
+				spills.push_back(numeric_spill{g, sess->agg_resno[a], pieces[k]});
 		}
 	}
 	ngroups += spills.size();
@@ -2783,14 +3005,18 @@ strom_gpupreagg_fetch(strom_gpupreagg *sess, kern_data_store *dest, size_t destl
 				cl_ulong raw = vals[g];
 				if (t.type_oid == STROM_NUMERICOID && t.scale < 0)
 					values[resno] = raw;			/* accumulated in the 64-bit form itself */
+				else if (sess->is_intsum((int)a))
+				{
+					/* the first piece; the others went to spill rows above */
+					cl_long	 hi = ((const cl_long *)(host.data() + sess->table_hi_offset((int)a, N)))[g];
+					(void)sum_pieces(t, raw, hi, pieces);
+					values[resno] = pieces[0];
+				}
 				else if (t.type_oid == STROM_NUMERICOID)
 				{
-					cl_long v = (cl_long)raw;
-					if (!fixed_to_numeric(v, t.scale, &raw))
-					{
-						cl_long lo = v - (v / P17) * P17;	/* high part: spill row */
-						(void)fixed_to_numeric(lo, t.scale, &raw);
-					}
+					/* pmin / pmax of a fixed-point numeric: one int8 value */
+					if (!fixed_to_numeric((cl_long)raw, t.scale, &raw))
+						return -StromError_DataStoreOutOfRange;
 					values[resno] = raw;
 				}
 				else if (type_is_float(t.type_oid))

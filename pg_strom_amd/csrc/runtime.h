@@ -179,6 +179,11 @@ struct strom_task_impl : public strom_task {
 	 * first event fired; may issue further copies on 'stream' and must
 	 * leave the stream idle when it returns */
 	std::function<void(strom_task_impl *)> finish;
+	/* set by finish(): the request is not over -- its device steps are issued once more
+	 * (GpuPreAgg: the checked fold of a chunk whose integer sums were not proven to stay
+	 * in range).  The completer hands it to a worker thread; whatever it queues ends in
+	 * task_enqueue() / task_fail() again, and done() still runs exactly once. */
+	std::function<void()> retry;
 	/* waiter side */
 	std::mutex	lock;
 	std::condition_variable cond;

@@ -76,6 +76,29 @@ def test_recheck_makes_the_chunk_recheck():
     assert rc == 2 and len(v) == 0
 
 
+def test_integer_sum_overflow_is_the_reference_rule_and_nothing_else():
+    """CHECK_OVERFLOW_INT(accum, newval) of GPUPREAGG_AGGCALC_PSUM_TEMPLATE
+    (opencl_gpupreagg.h:142-143, 933-948): an accumulate that leaves int8 is CpuReCheck --
+    and ONLY that: a single row of 2^63 - 1, or of -2^63, or four times 2^61 minus one, is a
+    sum like any other (round 2's oracle also sent every |input| >= 2^62 back, mirroring a
+    screen of the device; the reference has no such rule)"""
+    spec = "(gpupreagg (key (var 1 int4)) (nrows) (psum (var 2 int8)))"
+    big = (1 << 63) - 1
+    g = np.array([0, 1, 2, 2, 2, 2, 3], dtype=np.int32)
+    x = np.array([big, -big - 1, 1 << 61, 1 << 61, 1 << 61, (1 << 61) - 1, 5], dtype=np.int64)
+    rc, v, n = oracle.gpupreagg(spec, kds.build_kds("column", [kds.Column("int4", g), kds.Column("int8", x)]), 3)
+    assert rc == 0
+    got = {int(v[i, 0]): (int(v[i, 1].view(np.int64)), int(v[i, 2].view(np.int64))) for i in range(len(v))}
+    assert got == {0: (1, big), 1: (1, -big - 1), 2: (4, big), 3: (1, 5)}
+    x[6], g[6] = 1, 2                    # ... and one more is one too many
+    rc, v, n = oracle.gpupreagg(spec, kds.build_kds("row", [kds.Column("int4", g), kds.Column("int8", x)]), 3)
+    assert rc == 2 and len(v) == 0
+    g5 = np.zeros(5, dtype=np.int32)
+    x5 = np.full(5, 1 << 61, dtype=np.int64)
+    rc, v, n = oracle.gpupreagg(spec, kds.build_kds("column", [kds.Column("int4", g5), kds.Column("int8", x5)]), 3)
+    assert rc == 2
+
+
 def test_group_identity_is_the_keys_canonical_image():
     """float keys: -0 = +0, every NaN is one group; numeric keys: 1.50 = 1.5
     (what the types' comparators call equal, gpupreagg_keycomp
