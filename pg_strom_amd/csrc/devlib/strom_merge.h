@@ -13,7 +13,13 @@
  * correctly and back:
  *
  *   op 0  nrows                SUM int64 as is
- *   op 1  psum, integer        SUM int64, entries without a value -> 0
+ *   op 1  psum, integer        the table keeps such a sum 128 bits wide {low word in section
+ *                              1+a, high word in a section of its own: hi_off} so that it
+ *                              never wraps (strom_gpupreagg.h, "integer sums never wrap") --
+ *                              and neither may the merge: the value travels as THREE
+ *                              carry-free limbs, low 32 bits | next 32 bits | high word, each
+ *                              summed as int64 (2^32 x 2^31 ranks < 2^63), recombined with
+ *                              carries afterwards.  Entries without a value -> 0.
  *   op 2  psum, float8         SUM double, entries without a value -> 0.0
  *   op 3/4 pmin/pmax, integer  MIN/MAX int64, entries without a value -> identity
  *   op 5/6 pmin/pmax, float    the table keeps floats as order-preserving
@@ -34,13 +40,16 @@ typedef struct {
 	cl_uint		op[PREAGG_MERGE_MAXAGGS];
 	cl_uint		__pad;
 	cl_ulong	vals_off[PREAGG_MERGE_MAXAGGS];		/* byte offset of section 1+a in the table */
+	cl_ulong	hi_off[PREAGG_MERGE_MAXAGGS];		/* op 1: byte offset of the sum's high-word section */
+	cl_uint		mid_idx[PREAGG_MERGE_MAXAGGS];		/* op 1: which ngroups-long lane of 'mid' takes bits 32..63 */
+	cl_uint		__pad2;
 } preagg_merge_spec;
 
 #define PREAGG_MERGE_SIGN	0x8000000000000000UL
 
 extern "C" __global__ void
 __launch_bounds__(256)
-preagg_merge_prepare(char *table, const preagg_merge_spec *spec, cl_uchar *bits)
+preagg_merge_prepare(char *table, const preagg_merge_spec *spec, cl_uchar *bits, cl_ulong *mid)
 {
 	cl_uint		ngroups = spec->ngroups;
 	cl_uint		naggs = spec->naggs;
@@ -61,6 +70,18 @@ preagg_merge_prepare(char *table, const preagg_merge_spec *spec, cl_uchar *bits)
 			{
 				case 0:		break;
 				case 1:
+				{
+					/* {lo, hi} -> limbs: lo & 2^32-1 (stays here) | lo >> 32 (mid) | hi (its section) */
+					cl_long	   *hi = (cl_long *)(table + spec->hi_off[a]);
+					if (!has)
+					{
+						v = 0;
+						hi[g] = 0;
+					}
+					mid[(size_t)spec->mid_idx[a] * ngroups + g] = v >> 32;
+					v &= 0xffffffffUL;
+					break;
+				}
 				case 2:		if (!has) v = 0; break;
 				case 3:		if (!has) v = 0x7fffffffffffffffUL; break;
 				case 4:		if (!has) v = PREAGG_MERGE_SIGN; break;
@@ -74,7 +95,7 @@ preagg_merge_prepare(char *table, const preagg_merge_spec *spec, cl_uchar *bits)
 
 extern "C" __global__ void
 __launch_bounds__(256)
-preagg_merge_finish(char *table, const preagg_merge_spec *spec, const cl_uchar *bits)
+preagg_merge_finish(char *table, const preagg_merge_spec *spec, const cl_uchar *bits, const cl_ulong *mid)
 {
 	cl_uint		ngroups = spec->ngroups;
 	cl_uint		naggs = spec->naggs;
@@ -92,6 +113,15 @@ preagg_merge_finish(char *table, const preagg_merge_spec *spec, const cl_uchar *
 			cl_ulong   *vals = (cl_ulong *)(table + spec->vals_off[a]);
 			bool		has = ((f >> (1 + a)) & 1) != 0;
 			cl_uint		op = spec->op[a];
+			if (op == 1)
+			{
+				/* limbs (each a sum over the ranks, none of them wrapped) -> {lo, hi} */
+				cl_long	   *hi = (cl_long *)(table + spec->hi_off[a]);
+				cl_ulong	l0 = vals[g];
+				cl_ulong	t = mid[(size_t)spec->mid_idx[a] * ngroups + g] + (l0 >> 32);
+				vals[g] = (has ? ((l0 & 0xffffffffUL) | (t << 32)) : 0UL);
+				hi[g] = (has ? hi[g] + (cl_long)(t >> 32) : 0L);
+			}
 			if (op >= 3)
 			{
 				/* no rank had a value: back to the table's "untouched = 0" */
@@ -102,6 +132,34 @@ preagg_merge_finish(char *table, const preagg_merge_spec *spec, const cl_uchar *
 					v ^= PREAGG_MERGE_SIGN;
 				vals[g] = v;
 			}
+		}
+	}
+}
+
+/*
+ * dst = dst (op) src, element by element: what ONE RCCL all-reduce of a lane does between two
+ * ranks.  strom_gpupreagg_merge() adds the tables of two sessions of one GPU with exactly the
+ * lanes, operators, prepare and finish steps strom_gpupreagg_allreduce() hands to RCCL -- which is
+ * also how that path is tested on a single GPU.  kind: 0 SUM int64, 1 SUM float64, 2 MIN int64,
+ * 3 MAX int64, 4 MAX uint8 (count bytes).
+ */
+extern "C" __global__ void
+__launch_bounds__(256)
+preagg_merge_apply(void *dst, const void *src, cl_ulong count, cl_uint kind)
+{
+	for (cl_ulong i = (cl_ulong)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (cl_ulong)gridDim.x * blockDim.x)
+	{
+		if (kind == 4)
+		{
+			cl_uchar a = ((cl_uchar *)dst)[i], b = ((const cl_uchar *)src)[i];
+			((cl_uchar *)dst)[i] = (a > b ? a : b);
+		}
+		else if (kind == 1)
+			((cl_double *)dst)[i] += ((const cl_double *)src)[i];
+		else
+		{
+			cl_long a = ((cl_long *)dst)[i], b = ((const cl_long *)src)[i];
+			((cl_long *)dst)[i] = (kind == 0 ? (cl_long)((cl_ulong)a + (cl_ulong)b) : kind == 2 ? (a < b ? a : b) : (a > b ? a : b));
 		}
 	}
 }

@@ -2458,10 +2458,41 @@ strom::gpupreagg_get_merge_plan(strom_gpupreagg *sess, gpupreagg_merge_plan *pla
 		}
 		plan->spec.op[a] = op;
 		plan->spec.vals_off[a] = sess->table_offset(1 + (int)a, sess->ctl.ngroups);
+		if (sess->is_intsum((int)a))
+		{
+			/* 128 bits wide in the table: travels as three carry-free limbs (strom_merge.h) */
+			plan->spec.hi_off[a] = sess->table_hi_offset((int)a, sess->ctl.ngroups);
+			plan->spec.mid_idx[a] = (cl_uint)sess->intsum_of[a];
+		}
 	}
 	plan->table = sess->table;
+	plan->table_bytes = sess->table_bytes;
+	plan->nmid = (cl_uint)sess->nintsums;
 	plan->dindex = sess->dev->dindex;
 	return 0;
+}
+
+bool
+strom::gpupreagg_sessions_mergeable(strom_gpupreagg *dst, strom_gpupreagg *src)
+{
+	if (!dst || !src || dst == src || dst->dev != src->dev || dst->prog != src->prog ||
+		dst->hashed != src->hashed || dst->targets.size() != src->targets.size())
+		return false;
+	for (size_t i = 0; i < dst->targets.size(); i++)
+		if (dst->targets[i].kind != src->targets[i].kind || dst->targets[i].type_oid != src->targets[i].type_oid ||
+			dst->targets[i].scale != src->targets[i].scale)
+			return false;
+	if (dst->hashed)
+		return true;
+	/* dense tables: slot i must be the same group in both */
+	const dense_ctl &a = dst->ctl, &b = src->ctl;
+	if (!dst->has_domain || !src->has_domain || a.ngroups != b.ngroups || a.nkeys != b.nkeys ||
+		a.dense_ngroups != b.dense_ngroups || dst->present != src->present)
+		return false;
+	for (cl_uint k = 0; k < a.nkeys; k++)
+		if (a.key_min[k] != b.key_min[k] || a.key_range[k] != b.key_range[k] || a.key_stride[k] != b.key_stride[k])
+			return false;
+	return true;
 }
 
 int

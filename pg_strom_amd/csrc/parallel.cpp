@@ -212,41 +212,65 @@ hashed_allreduce(strom_gpupreagg *sess, int dindex, ncclComm_t comm, hipStream_t
 	cl_uint		mine = 0;
 	size_t		reclen = 0;
 	int			rc;
+	const cl_uint FAILED = 0xffffffffu;
 
 	(void)hipSetDevice(dev->hip_id);
 	if ((rc = rccl_errcode(rccl().CommCount(comm, &world), "ncclCommCount")) != 0 ||
 		(rc = rccl_errcode(rccl().CommUserRank(comm, &rank), "ncclCommUserRank")) != 0)
 		return rc;
-	if ((rc = stream_follows(dev, stream)) != 0)
-		return rc;
-	if ((rc = gpupreagg_hash_export_device(sess, &d_mine, &mine, &reclen)) != 0)
-		return rc;
+	/*
+	 * A failure of ONE rank must fail all of them: a rank that left early would leave the others
+	 * inside a collective for good.  So every rank takes part in every collective up to the point
+	 * where all have agreed to go on: a rank whose export failed sends FAILED instead of its group
+	 * count, a rank that cannot allocate the gather area says so in a second, one-word round, and
+	 * the records are gathered only when every rank is ready.  (What is left are failures of RCCL
+	 * itself, which are not a rank's own.)
+	 */
+	int			local_rc = stream_follows(dev, stream);
+	if (local_rc == 0)
+		local_rc = gpupreagg_hash_export_device(sess, &d_mine, &mine, &reclen);
 	std::vector<cl_uint> counts((size_t)world, 0);
-	do {
-		d_counts = (cl_uint *)dev->pool.alloc(sizeof(cl_uint) * (size_t)(world + 1));
+	/* gather words: [0 .. world) the answer, [world] this rank's contribution */
+	d_counts = (cl_uint *)dev->pool.alloc(sizeof(cl_uint) * (size_t)(world + 1));
+	auto gather_word = [&](cl_uint word, const char *what) -> int
+	{
 		if (!d_counts)
-		{
-			rc = StromError_OutOfMemory;
-			break;
-		}
-		/* counts: this rank's at d_counts[world], all of them in d_counts[0 .. world) */
-		if (hipMemcpyAsync(d_counts + world, &mine, sizeof(cl_uint), hipMemcpyHostToDevice, stream) != hipSuccess ||
-			(rc = rccl_errcode(rccl().AllGather(d_counts + world, d_counts, 1, ncclUint32, comm, stream),
-							   "ncclAllGather (group counts)")) != 0 ||
-			hipMemcpyAsync(counts.data(), d_counts, sizeof(cl_uint) * (size_t)world, hipMemcpyDeviceToHost, stream) != hipSuccess ||
+			return StromError_OutOfMemory;		/* (cannot even say so: the one failure that is not agreed on) */
+		if (hipMemcpyAsync(d_counts + world, &word, sizeof(cl_uint), hipMemcpyHostToDevice, stream) != hipSuccess)
+			return StromError_HipInternal;
+		int r = rccl_errcode(rccl().AllGather(d_counts + world, d_counts, 1, ncclUint32, comm, stream), what);
+		if (r != 0)
+			return r;
+		if (hipMemcpyAsync(counts.data(), d_counts, sizeof(cl_uint) * (size_t)world, hipMemcpyDeviceToHost, stream) != hipSuccess ||
 			hipStreamSynchronize(stream) != hipSuccess)
+			return StromError_HipInternal;
+		return 0;
+	};
+	do {
+		if ((rc = gather_word(local_rc == 0 ? mine : FAILED, "ncclAllGather (group counts)")) != 0)
+			break;
+		cl_uint		seg_len = 0;
+		bool		somebody_failed = false;
+		for (cl_uint c : counts)
 		{
-			if (rc == 0)
-				rc = StromError_HipInternal;
+			somebody_failed = somebody_failed || (c == FAILED);
+			if (c != FAILED)
+				seg_len = std::max(seg_len, c);
+		}
+		if (somebody_failed)
+		{
+			rc = (local_rc != 0 ? local_rc : StromError_HipInternal);	/* every rank returns an error */
 			break;
 		}
-		cl_uint		seg_len = 0;
-		for (cl_uint c : counts)
-			seg_len = std::max(seg_len, c);
 		if (seg_len == 0 || world == 1)
 			break;							/* nothing to merge */
+		std::vector<cl_uint> group_counts = counts;
 		d_all = (char *)dev->pool.alloc(reclen * (size_t)seg_len * (size_t)(world + 1));
-		if (!d_all)
+		if ((rc = gather_word(d_all ? 1u : FAILED, "ncclAllGather (ready)")) != 0)
+			break;
+		for (cl_uint c : counts)
+			somebody_failed = somebody_failed || (c == FAILED);
+		if (somebody_failed)
 		{
 			rc = StromError_OutOfMemory;
 			break;
@@ -262,7 +286,7 @@ hashed_allreduce(strom_gpupreagg *sess, int dindex, ncclComm_t comm, hipStream_t
 				rc = StromError_HipInternal;
 			break;
 		}
-		rc = gpupreagg_hash_import_device(sess, d_all, seg_len, (cl_uint)world, counts.data(), (cl_uint)rank);
+		rc = gpupreagg_hash_import_device(sess, d_all, seg_len, (cl_uint)world, group_counts.data(), (cl_uint)rank);
 	} while (0);
 	if (hipStreamSynchronize(stream) != hipSuccess && rc == 0)
 		rc = StromError_HipInternal;
@@ -272,14 +296,173 @@ hashed_allreduce(strom_gpupreagg *sess, int dindex, ncclComm_t comm, hipStream_t
 	return rc;
 }
 
-/* one hashed session's groups merged into another's (same program, same device): per-stream or
- * per-range sessions of one GPU added up without leaving HBM */
+/*
+ * The resident table of a dense session as the merge sees it: LANES of ngroups elements, each
+ * merged by one operator -- what is handed to RCCL as one all-reduce each, or applied between two
+ * tables of one GPU by preagg_merge_apply (devlib/strom_merge.h).  An integer sum is three lanes
+ * (low 32 bits in the sum's own section, the next 32 bits in the scratch area 'mid', the high
+ * word in its section); the flags travel as bytes in the scratch area 'bits'.
+ */
+namespace {
+
+enum lane_kind { LANE_SUM_I64 = 0, LANE_SUM_F64 = 1, LANE_MIN_I64 = 2, LANE_MAX_I64 = 3, LANE_MAX_U8 = 4 };
+
+struct merge_lane {
+	int			where;			/* 0 table, 1 mid, 2 bits */
+	size_t		offset;			/* bytes */
+	size_t		count;			/* elements */
+	lane_kind	kind;
+};
+
+std::vector<merge_lane>
+merge_lanes(const gpupreagg_merge_plan &plan)
+{
+	std::vector<merge_lane> lanes;
+	size_t		n = plan.spec.ngroups;
+	for (cl_uint a = 0; a < plan.spec.naggs; a++)
+	{
+		cl_uint		op = plan.spec.op[a];
+		lane_kind	kind = (op == 2 ? LANE_SUM_F64 : op <= 1 ? LANE_SUM_I64 :
+							(op == 3 || op == 5) ? LANE_MIN_I64 : LANE_MAX_I64);
+		lanes.push_back(merge_lane{0, (size_t)plan.spec.vals_off[a], n, kind});
+		if (op == 1)
+		{
+			lanes.push_back(merge_lane{1, (size_t)plan.spec.mid_idx[a] * n * sizeof(cl_ulong), n, LANE_SUM_I64});
+			lanes.push_back(merge_lane{0, (size_t)plan.spec.hi_off[a], n, LANE_SUM_I64});
+		}
+	}
+	lanes.push_back(merge_lane{2, 0, (size_t)(plan.spec.naggs + 1) * n, LANE_MAX_U8});
+	return lanes;
+}
+
+/* the scratch areas of one table taking part in a merge */
+struct merge_scratch {
+	char	   *d_spec = nullptr;
+	cl_uchar   *d_bits = nullptr;
+	cl_ulong   *d_mid = nullptr;
+
+	int alloc(Device *dev, const gpupreagg_merge_plan &plan, bool with_spec)
+	{
+		size_t	n = plan.spec.ngroups;
+		if (with_spec)
+			d_spec = (char *)dev->pool.alloc(sizeof(plan.spec));
+		d_bits = (cl_uchar *)dev->pool.alloc((size_t)(plan.spec.naggs + 1) * n);
+		d_mid = (cl_ulong *)dev->pool.alloc(std::max<size_t>(1, plan.nmid) * n * sizeof(cl_ulong));
+		return ((with_spec && !d_spec) || !d_bits || !d_mid) ? StromError_OutOfMemory : 0;
+	}
+	void release(Device *dev)
+	{
+		if (d_spec) dev->pool.release(d_spec);
+		if (d_bits) dev->pool.release(d_bits);
+		if (d_mid) dev->pool.release(d_mid);
+	}
+	void *lane_ptr(char *table, const merge_lane &l) const
+	{
+		return (l.where == 0 ? (void *)(table + l.offset) : l.where == 1 ? (void *)((char *)d_mid + l.offset)
+				: (void *)(d_bits + l.offset));
+	}
+};
+
+int
+launch_prepare_or_finish(Device *dev, hipStream_t stream, hipFunction_t fn, char *table, const char *d_spec,
+						 const merge_scratch &sc, cl_uint ngroups)
+{
+	void	   *a_table = table;
+	const void *a_spec = d_spec;
+	void	   *a_bits = sc.d_bits;
+	void	   *a_mid = sc.d_mid;
+	void	   *args[] = { &a_table, &a_spec, &a_bits, &a_mid };
+	unsigned	grid = std::max(1u, std::min<unsigned>((ngroups + 255) / 256, (unsigned)dev->prop.multiProcessorCount * 4));
+	return hipModuleLaunchKernel(fn, grid, 1, 1, 256, 1, 1, 0, stream, args, nullptr) == hipSuccess
+		? 0 : StromError_HipInternal;
+}
+
+/*
+ * dense sessions of one GPU: dst += src through the multi-GPU merge's own steps -- both tables
+ * prepared (src as a copy: its session keeps its table), every lane combined by the operator RCCL
+ * would be given, dst finished.  Order: behind everything queued for either table.
+ */
+int
+dense_merge_local(strom_gpupreagg *dst, strom_gpupreagg *src)
+{
+	gpupreagg_merge_plan pd, ps;
+	int		rc;
+	if ((rc = gpupreagg_get_merge_plan(dst, &pd)) != 0 || (rc = gpupreagg_get_merge_plan(src, &ps)) != 0)
+		return rc;
+	if (pd.dindex != ps.dindex || pd.table_bytes != ps.table_bytes ||
+		memcmp(&pd.spec, &ps.spec, sizeof(pd.spec)) != 0)
+		return StromError_BadRequestMessage;
+	Device	   *dev = get_device(pd.dindex);
+	hipStream_t	stream = dev->streams[0];
+	int			errcode = 0;
+
+	(void)hipSetDevice(dev->hip_id);
+	hipFunction_t fn_prep = merge_function(dev, "preagg_merge_prepare", &errcode);
+	hipFunction_t fn_fin = fn_prep ? merge_function(dev, "preagg_merge_finish", &errcode) : nullptr;
+	hipFunction_t fn_apply = fn_fin ? merge_function(dev, "preagg_merge_apply", &errcode) : nullptr;
+	if (!fn_apply)
+		return errcode;
+	merge_scratch sd, ss;
+	char	   *d_copy = (char *)dev->pool.alloc(ps.table_bytes);
+	do {
+		if (!d_copy || (rc = sd.alloc(dev, pd, true)) != 0 || (rc = ss.alloc(dev, ps, false)) != 0)
+		{
+			rc = StromError_OutOfMemory;
+			break;
+		}
+		if ((rc = stream_follows(dev, stream)) != 0)
+			break;
+		if (hipMemcpy(sd.d_spec, &pd.spec, sizeof(pd.spec), hipMemcpyHostToDevice) != hipSuccess ||
+			hipMemcpyAsync(d_copy, ps.table, ps.table_bytes, hipMemcpyDeviceToDevice, stream) != hipSuccess)
+		{
+			rc = StromError_HipInternal;
+			break;
+		}
+		if ((rc = launch_prepare_or_finish(dev, stream, fn_prep, pd.table, sd.d_spec, sd, pd.spec.ngroups)) != 0 ||
+			(rc = launch_prepare_or_finish(dev, stream, fn_prep, d_copy, sd.d_spec, ss, pd.spec.ngroups)) != 0)
+			break;
+		for (const merge_lane &l : merge_lanes(pd))
+		{
+			void	   *a_dst = sd.lane_ptr(pd.table, l);
+			const void *a_src = ss.lane_ptr(d_copy, l);
+			cl_ulong	a_count = l.count;
+			cl_uint		a_kind = (cl_uint)l.kind;
+			void	   *args[] = { &a_dst, &a_src, &a_count, &a_kind };
+			unsigned	grid = (unsigned)std::max<size_t>(1, std::min<size_t>((l.count + 255) / 256,
+																			  (size_t)dev->prop.multiProcessorCount * 4));
+			if (hipModuleLaunchKernel(fn_apply, grid, 1, 1, 256, 1, 1, 0, stream, args, nullptr) != hipSuccess)
+			{
+				rc = StromError_HipInternal;
+				break;
+			}
+		}
+		if (rc == 0)
+			rc = launch_prepare_or_finish(dev, stream, fn_fin, pd.table, sd.d_spec, sd, pd.spec.ngroups);
+	} while (0);
+	if (hipStreamSynchronize(stream) != hipSuccess && rc == 0)
+		rc = StromError_HipInternal;
+	sd.release(dev);
+	ss.release(dev);
+	if (d_copy) dev->pool.release(d_copy);
+	return rc;
+}
+
+}	/* namespace */
+
+/*
+ * one session's groups merged into another's (same program, same device): per-stream or
+ * per-range sessions of one GPU added up without leaving HBM.  Hashed sessions: src's groups are
+ * packed and imported (gpupreagg_hash_export / _import, the steps of the all-gather merge);
+ * dense sessions: the tables are added lane by lane with the all-reduce merge's own prepare /
+ * operator / finish steps (dense_merge_local).
+ */
 extern "C" int
 strom_gpupreagg_merge(strom_gpupreagg *dst, strom_gpupreagg *src)
 {
-	int		d1 = -1, d2 = -1;
-	if (!gpupreagg_is_hashed(dst, &d1) || !gpupreagg_is_hashed(src, &d2) || d1 != d2 || dst == src)
+	if (!gpupreagg_sessions_mergeable(dst, src))
 		return StromError_BadRequestMessage;
+	if (!gpupreagg_is_hashed(dst, nullptr))
+		return dense_merge_local(dst, src);
 	char	   *d_recs = nullptr;
 	cl_uint		count = 0;
 	size_t		reclen = 0;
@@ -321,60 +504,42 @@ strom_gpupreagg_allreduce(strom_gpupreagg *sess, void *comm_handle, void *stream
 	hipFunction_t fn_fin = fn_prep ? merge_function(dev, "preagg_merge_finish", &errcode) : nullptr;
 	if (!fn_prep || !fn_fin)
 		return errcode;
-	cl_uint		nbits = plan.spec.naggs + 1;
-	size_t		bits_len = (size_t)nbits * plan.spec.ngroups;
-	char	   *d_spec = (char *)dev->pool.alloc(sizeof(plan.spec));
-	cl_uchar   *d_bits = (cl_uchar *)dev->pool.alloc(bits_len);
+	merge_scratch sc;
 	do {
-		if (!d_spec || !d_bits)
-		{
-			rc = StromError_OutOfMemory;
+		if ((rc = sc.alloc(dev, plan, true)) != 0)
 			break;
-		}
 		if ((rc = stream_follows(dev, stream)) != 0)
 			break;
 		/* (the spec is a few hundred bytes of pageable memory: synchronous copy) */
-		if (hipMemcpy(d_spec, &plan.spec, sizeof(plan.spec), hipMemcpyHostToDevice) != hipSuccess)
+		if (hipMemcpy(sc.d_spec, &plan.spec, sizeof(plan.spec), hipMemcpyHostToDevice) != hipSuccess)
 		{
 			rc = StromError_HipInternal;
 			break;
 		}
-		void	   *a_table = plan.table;
-		const void *a_spec = d_spec;
-		void	   *a_bits = d_bits;
-		void	   *args[] = { &a_table, &a_spec, &a_bits };
-		unsigned	grid = std::max(1u, std::min<unsigned>((plan.spec.ngroups + 255) / 256,
-														   (unsigned)dev->prop.multiProcessorCount * 4));
-		if (hipModuleLaunchKernel(fn_prep, grid, 1, 1, 256, 1, 1, 0, stream, args, nullptr) != hipSuccess)
-		{
-			rc = StromError_HipInternal;
+		if ((rc = launch_prepare_or_finish(dev, stream, fn_prep, plan.table, sc.d_spec, sc, plan.spec.ngroups)) != 0)
 			break;
-		}
-		/* one collective per section, fused into one RCCL launch */
+		/* one collective per lane, fused into one RCCL launch; no lane's sum can wrap */
 		ncclResult_t nrc = rccl().GroupStart();
-		for (cl_uint a = 0; nrc == ncclSuccess && a < plan.spec.naggs; a++)
+		for (const merge_lane &l : merge_lanes(plan))
 		{
-			void		   *vals = plan.table + plan.spec.vals_off[a];
-			cl_uint			op = plan.spec.op[a];
-			ncclDataType_t	dt = (op == 2 ? ncclFloat64 : ncclInt64);
-			ncclRedOp_t		red = (op <= 2 ? ncclSum : (op == 3 || op == 5) ? ncclMin : ncclMax);
-			nrc = rccl().AllReduce(vals, vals, plan.spec.ngroups, dt, red, comm, stream);
+			if (nrc != ncclSuccess)
+				break;
+			void		   *ptr = sc.lane_ptr(plan.table, l);
+			ncclDataType_t	dt = (l.kind == LANE_SUM_F64 ? ncclFloat64 : l.kind == LANE_MAX_U8 ? ncclUint8 : ncclInt64);
+			ncclRedOp_t		red = (l.kind <= LANE_SUM_F64 ? ncclSum : l.kind == LANE_MIN_I64 ? ncclMin : ncclMax);
+			nrc = rccl().AllReduce(ptr, ptr, l.count, dt, red, comm, stream);
 		}
-		if (nrc == ncclSuccess)
-			nrc = rccl().AllReduce(d_bits, d_bits, bits_len, ncclUint8, ncclMax, comm, stream);
 		ncclResult_t erc = rccl().GroupEnd();
 		if (nrc == ncclSuccess)
 			nrc = erc;
 		if ((rc = rccl_errcode(nrc, "ncclAllReduce (GpuPreAgg table)")) != 0)
 			break;
-		if (hipModuleLaunchKernel(fn_fin, grid, 1, 1, 256, 1, 1, 0, stream, args, nullptr) != hipSuccess)
-			rc = StromError_HipInternal;
+		rc = launch_prepare_or_finish(dev, stream, fn_fin, plan.table, sc.d_spec, sc, plan.spec.ngroups);
 	} while (0);
 	/* the scratch buffers go back to the pool: the stream must be through with them */
 	if (hipStreamSynchronize(stream) != hipSuccess && rc == 0)
 		rc = StromError_HipInternal;
-	if (d_spec) dev->pool.release(d_spec);
-	if (d_bits) dev->pool.release(d_bits);
+	sc.release(dev);
 	return rc;
 }
 

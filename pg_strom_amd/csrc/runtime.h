@@ -231,10 +231,18 @@ struct gpupreagg_merge_plan {
 		cl_uint		op[31];
 		cl_uint		__pad;
 		cl_ulong	vals_off[31];
+		cl_ulong	hi_off[31];
+		cl_uint		mid_idx[31];
+		cl_uint		__pad2;
 	} spec;
 	char	   *table;
+	size_t		table_bytes;
+	cl_uint		nmid;				/* integer sums: lanes of ngroups words the merge needs as scratch */
 	int			dindex;
 };
+/* may 'src' be merged into 'dst' (strom_gpupreagg_merge)?  Same program, same targets, same device,
+ * both hashed or both dense with the same group slots */
+bool		gpupreagg_sessions_mergeable(strom_gpupreagg *dst, strom_gpupreagg *src);
 int			gpupreagg_get_merge_plan(strom_gpupreagg *sess, gpupreagg_merge_plan *plan);
 int			gpupreagg_get_census(strom_gpupreagg *sess, void **p_bitmap, cl_uint *p_nbits, int *p_dindex);
 /* hashed sessions (gpupreagg.cpp): the groups packed on the device (records of *p_reclen bytes in a

@@ -10,7 +10,11 @@ folds its row range into a resident table with an identical dense layout
 values of aggregate a), so the merge is an all-reduce on the table itself,
 one collective per section:
 
-    nrows, psum(int8)   SUM on int64     exact, order independent
+    nrows               SUM on int64     exact, order independent
+    psum(int8)          128 bits wide in the table {low word, high word}: never wraps
+                        (strom_gpupreagg.h, "integer sums never wrap") and neither may the
+                        merge -- three carry-free limbs (low 32 bits | next 32 bits | high
+                        word), each a SUM on int64, recombined with carries afterwards
     psum(float8)        SUM on float64   tolerance: summation order
     pmin / pmax         MIN / MAX on int64 (float keys are order-preserving
                         u64; the sign bit is flipped so that signed MIN/MAX
@@ -43,10 +47,22 @@ class TableLayout(object):
         self.aggs = [(i, k, oid) for i, (k, oid) in enumerate(self.targets) if k != KIND_KEY]
         self.flags_bytes = align(4 * ngroups, 256)
         self.vals_bytes = align(8 * ngroups, 256)
-        self.nbytes = self.flags_bytes + self.vals_bytes * len(self.aggs)
+        # integer sums have a second section: their high word (gpupreagg_table_offset)
+        self.intsums = [a for a, (_, k, oid) in enumerate(self.aggs) if k == KIND_PSUM and oid not in FLOAT_OIDS]
+        self.nbytes = self.flags_bytes + self.vals_bytes * (len(self.aggs) + len(self.intsums))
 
     def vals_offset(self, a):
         return self.flags_bytes + self.vals_bytes * a
+
+    def hi_offset(self, a):
+        return self.flags_bytes + self.vals_bytes * (len(self.aggs) + self.intsums.index(a))
+
+    def int_sum(self, tbl, a, gid):
+        """the 128-bit sum of aggregate a in group gid as a Python int (numpy table bytes)"""
+        n = self.ngroups
+        lo = int(tbl[self.vals_offset(a):self.vals_offset(a) + 8 * n].view(np.uint64)[gid])
+        hi = int(tbl[self.hi_offset(a):self.hi_offset(a) + 8 * n].view(np.int64)[gid])
+        return (hi << 64) + lo
 
 
 class RcclComm(object):
@@ -101,10 +117,23 @@ def allreduce_table(table, layout, group=None):
         off = layout.vals_offset(a)
         vals = table[off:off + 8 * n]
         has = bits[:, a + 1] != 0
-        if kind == KIND_NROWS or (kind == KIND_PSUM and oid not in FLOAT_OIDS):
+        if kind == KIND_NROWS:
             v = vals.view(torch.int64)
-            v.mul_(has.to(torch.int64) if kind != KIND_NROWS else 1)
             dist.all_reduce(v, op=dist.ReduceOp.SUM, group=group)
+        elif kind == KIND_PSUM and oid not in FLOAT_OIDS:
+            # {lo, hi} -> limbs that cannot wrap under SUM, and back (strom_merge.h)
+            lo = vals.view(torch.int64)
+            hoff = layout.hi_offset(a)
+            hi = table[hoff:hoff + 8 * n].view(torch.int64)
+            lo.mul_(has.to(torch.int64))
+            hi.mul_(has.to(torch.int64))
+            l0 = lo & 0xffffffff
+            l1 = (lo >> 32) & 0xffffffff            # (arithmetic shift, then the low 32 bits: logical)
+            for limb in (l0, l1, hi):
+                dist.all_reduce(limb, op=dist.ReduceOp.SUM, group=group)
+            t = l1 + (l0 >> 32)
+            lo.copy_((l0 & 0xffffffff) | (t << 32))
+            hi.add_(t >> 32)
         elif kind == KIND_PSUM:
             v = vals.view(torch.float64)
             v.copy_(torch.where(has, v, torch.zeros_like(v)))
@@ -152,7 +181,10 @@ def pack_rows(layout, domain, values, isnull):
                     cur = vals[gid:gid + 1].view(np.float64)
                     cur[0] = (cur[0] if had else 0.0) + x.view(np.float64)
                 else:
-                    vals[gid] = np.uint64((int(vals[gid]) + int(x)) & 0xFFFFFFFFFFFFFFFF)
+                    total = (layout.int_sum(tbl, a, gid) if had else 0) + int(x.view(np.int64))
+                    vals[gid] = np.uint64(total & 0xFFFFFFFFFFFFFFFF)
+                    hoff = layout.hi_offset(a)
+                    tbl[hoff:hoff + 8 * layout.ngroups].view(np.int64)[gid] = total >> 64
             else:
                 if oid in FLOAT_OIDS:
                     x = f64_ordered(x.view(np.float64))
@@ -205,6 +237,11 @@ def unpack_rows(layout, domain, tbl):
                 isnull[r, t] = True
             elif kind != KIND_PSUM and oid in FLOAT_OIDS:
                 values[r, t] = np.array([f64_unordered(vals[gid])], dtype=np.float64).view(np.uint64)[0]
+            elif kind == KIND_PSUM and oid not in FLOAT_OIDS:
+                total = layout.int_sum(tbl, a, gid)
+                if not -2**63 <= total < 2**63:
+                    raise OverflowError("sum of group %d does not fit one partial row: use TableLayout.int_sum" % gid)
+                values[r, t] = np.uint64(total & 0xFFFFFFFFFFFFFFFF)
             else:
                 values[r, t] = vals[gid]
     return values, isnull

@@ -75,6 +75,58 @@ def test_two_rank_merge_matches_single_reduction():
     assert q.get(timeout=5) is True
 
 
+def _wide_worker(rank, world, port, outq):
+    sys.path.insert(0, os.path.dirname(HERE))
+    import torch
+    import torch.distributed as dist
+    from pg_strom_amd import parallel
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    try:
+        # key int4, nrows, psum(int8): group 0 near +2^63 on both ranks, group 1 near -2^63,
+        # group 2 only on rank 1, group 3 opposite signs that cancel, group 4 already beyond int8
+        # on rank 0 (a table that has folded several chunks)
+        targets = [(1, 23), (2, 23), (3, 20)]
+        layout = parallel.TableLayout(targets, 6)
+        big = 2**63 - 5
+        mine = {0: {0: big, 1: -big - 3, 3: big, 4: 3 * big}, 1: {0: big - 1, 1: -big, 2: 17, 3: -big}}[rank]
+        tbl = np.zeros(layout.nbytes, dtype=np.uint8)
+        flags = tbl[:4 * 6].view(np.uint32)
+        n = layout.ngroups
+        for gid, total in mine.items():
+            flags[gid] = 1 | (2 << 1)
+            tbl[layout.vals_offset(0):layout.vals_offset(0) + 8 * n].view(np.int64)[gid] = 1 + rank
+            tbl[layout.vals_offset(1):layout.vals_offset(1) + 8 * n].view(np.uint64)[gid] = total & (2**64 - 1)
+            tbl[layout.hi_offset(1):layout.hi_offset(1) + 8 * n].view(np.int64)[gid] = total >> 64
+        t = torch.from_numpy(tbl)
+        parallel.allreduce_table(t, layout)
+        got = {g: layout.int_sum(t.numpy(), 1, g) for g in range(5)}
+        outq.put((rank, got, [int(x) for x in t.numpy()[:24].view(np.uint32)]))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_merge_of_integer_sums_never_wraps():
+    """psum(int8) is 128 bits wide in the table and travels as three carry-free limbs
+    (strom_merge.h / parallel.allreduce_table): two ranks whose sums are each at the edge of int8
+    merge to the exact big-integer total -- ncclSum on the raw int64 would have wrapped"""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 33500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_wide_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(180)
+        assert p.exitcode == 0
+    res = [q.get(timeout=5) for _ in range(2)]
+    big = 2**63 - 5
+    want = {0: 2 * big - 1, 1: -2 * big - 3, 2: 17, 3: 0, 4: 3 * big}
+    for rank, got, flags in res:
+        assert got == want, (rank, got)
+        assert flags == [5, 5, 5, 5, 5, 0]
+
+
 def test_pack_unpack_round_trip():
     sys.path.insert(0, HERE)
     import agg_golden

@@ -107,8 +107,10 @@ def test_sum_that_leaves_int8_is_cpu_recheck(fmt, ngroups, hashed):
     assert oracle_status(SPEC, buf, 4) == 2
     statuses, _, _ = run_dense(SPEC, [buf], [(0, ngroups)], hashed)
     assert statuses == [2]
-    # four of them fit: the same chunk without one of the five is summed on the device
+    # 3 x 2^61 + 2^60 fit: the same chunk with two of the five rows made smaller is summed on
+    # the device
     x[hot[0]] = 7
+    x[hot[1]] = 1 << 60
     buf = table(g, x, fmt)
     assert oracle_status(SPEC, buf, 4) == 0
     statuses, pr, targets = run_dense(SPEC, [buf], [(0, ngroups)], hashed)
@@ -132,7 +134,8 @@ def test_sum_without_group_by_is_checked_too():
     assert oracle_status(SPEC_NOKEY, buf, 3) == 2
     statuses, _, _ = run_dense(SPEC_NOKEY, [buf], [])
     assert statuses == [2]
-    x[7] = -5                       # 4 x 2^61 + small change: fits
+    x[7] = -5                       # 3 x 2^61 + 2^60 + small change: fits
+    x[77] = 1 << 60
     buf = table(g, x, "column")
     assert oracle_status(SPEC_NOKEY, buf, 3) == 0
     statuses, pr, targets = run_dense(SPEC_NOKEY, [buf], [])
@@ -214,7 +217,7 @@ def test_per_chunk_message_rechecks_and_sums():
     n = 30000
     g = rng.integers(0, 60, n)
     x = rng.integers(0, 10**6, n)
-    x[:3] = I64_MAX // 2
+    x[:3] = I64_MAX // 2 - 10**10        # two of them (and the group's other rows) fit, three do not
     g[:3] = 11
     buf = table(g, x, "row")
     assert oracle_status(SPEC, buf, 4) == 2
