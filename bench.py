@@ -183,11 +183,61 @@ def c5_chunk_device(nrows, seed, decimal=True):
     cutoff = -486                                   # date '1998-09-02' in days since 2000-01-01
     keep = ship <= cutoff
     gid = ((rf.long() - 65) * 16 + (ls.long() - 70))[keep]
-    cnt = torch.bincount(gid, minlength=18 * 16)
-    sq = torch.zeros(18 * 16, dtype=torch.int64, device="cuda").index_add_(0, gid, qty[keep])
+    cnt = torch.bincount(gid, minlength=Q1_SLOTS)
+
+    def exact_sums(v):
+        # per-group sums as Python integers: two carry-free limbs, so that a total beyond int64
+        # (sum(charge) over one GPU's share of the table is) is still exact
+        v = v[keep]
+        hi = torch.zeros(Q1_SLOTS, dtype=torch.int64, device="cuda").index_add_(0, gid, v >> 32)
+        lo = torch.zeros(Q1_SLOTS, dtype=torch.int64, device="cuda").index_add_(0, gid, v & 0xffffffff)
+        return [(int(h) << 32) + int(l) for h, l in zip(hi.cpu().tolist(), lo.cpu().tolist())]
+    disc_price = prc * (100 - dsc)                  # scale 4
+    ref = dict(count=cnt.cpu().tolist(), sum_qty=exact_sums(qty), sum_base_price=exact_sums(prc),
+               sum_disc_price=exact_sums(disc_price), sum_charge=exact_sums(disc_price * (100 + tax)),
+               sum_discount=exact_sums(dsc))
     ds = runtime.DeviceStore.from_torch_columns(["char1", "char1", ntype, ntype, ntype, ntype, "date"],
                                                 cols + [ship])
-    return ds, cnt.cpu().numpy(), sq.cpu().numpy()
+    return ds, ref
+
+
+Q1_SLOTS = 18 * 16
+# target number -> (reference name, scale of the numeric partial) / row counts, in q1_agg()'s order
+Q1_SUMS = {2: ("sum_qty", 0), 3: ("sum_base_price", 2), 4: ("sum_disc_price", 4), 5: ("sum_charge", 6),
+           8: ("sum_discount", 2)}
+Q1_COUNTS = (6, 7, 9, 10)
+
+
+def q1_add_reference(total, ref):
+    if total is None:
+        return {k: list(v) for k, v in ref.items()}
+    return {k: [a + b for a, b in zip(total[k], ref[k])] for k in ref}
+
+
+def q1_check(pr, ref):
+    """every aggregate of the Q1 program against torch's exact per-group answers: the partial
+    rows of a group (one, plus extra rows for sums beyond the 57-bit numeric mantissa or beyond
+    int8) add up to the reference -- big-integer arithmetic on both sides"""
+    from pg_strom_amd import kds
+    k1, k2 = pr.column(0)[0].astype(np.int64), pr.column(1)[0].astype(np.int64)
+    gids = ((k1 - 65) * 16 + (k2 - 70)).tolist()
+    want_groups = [g for g in range(Q1_SLOTS) if ref["count"][g]]
+    assert sorted(set(gids)) == want_groups, "Q1: groups differ: %s vs %s" % (sorted(set(gids)), want_groups)
+    for t in Q1_COUNTS:
+        got = [0] * Q1_SLOTS
+        for g, v in zip(gids, pr.column(t)[0].tolist()):
+            got[g] += int(v)
+        assert got == ref["count"], "Q1: row counts (target %d) differ" % t
+    for t, (name, scale) in Q1_SUMS.items():
+        img, isnull = pr.column(t)
+        got = [0] * Q1_SLOTS
+        for g, v, n in zip(gids, img.tolist(), isnull.tolist()):
+            if not n:
+                d = kds.numeric_decode(v).scaleb(scale)
+                assert d == d.to_integral_value(), "Q1: %s is not at scale %d" % (name, scale)
+                got[g] += int(d)
+        assert got == ref[name], "Q1: %s differs: %s vs %s" % (name, got, ref[name])
+    return len(want_groups)
 
 
 def q1_agg(T):
@@ -549,7 +599,7 @@ def operator_figures(args, k, c, measured_peak, cpu_blocks):
     # ingest makes of typmod-scaled numerics), and as the reference's 64-bit numeric images
     q1rows = chunk_rows
     for label, decimal, spec in (("q1_shape_c5", True, Q1_AGG), ("q1_shape_c5_numeric_images", False, Q1_AGG_NUMERIC)):
-        q1, q1cnt, q1sq = c5_chunk_device(q1rows, 0x5eed0005, decimal)
+        q1, q1ref = c5_chunk_device(q1rows, 0x5eed0005, decimal)
         agg = GpuPreAgg(spec).begin([(65, 18), (70, 10)])
         agg.census(q1)
         nslots = agg.compact()
@@ -562,37 +612,67 @@ def operator_figures(args, k, c, measured_peak, cpu_blocks):
             assert st == 0, "Q1 fold status %d" % st
             kerns.append(pfm["time_kern_exec_ns"] - pfm["time_kern_proj_ns"])
         pr = agg.fetch()
-        # one partial row per group -- plus extra rows for sums that outgrow the 57-bit numeric
-        # mantissa (sum(charge) at scale 6 over 1e8 rows does): the final aggregate adds them up
-        k1, k2 = pr.column(0)[0].astype(np.int64), pr.column(1)[0].astype(np.int64)
-        gids = (k1 - 65) * 16 + (k2 - 70)
-        ugid = np.unique(gids)
-        assert np.array_equal(ugid, np.flatnonzero(q1cnt)), \
-            "Q1: groups differ: %s vs %s" % (ugid.tolist(), np.flatnonzero(q1cnt).tolist())
-        got_cnt = np.zeros(18 * 16, dtype=np.int64)
-        np.add.at(got_cnt, gids, pr.column(10)[0].astype(np.int64))
-        assert np.array_equal(got_cnt, q1cnt), "Q1: row counts differ"
-        # sum(quantity) comes back as a numeric in the 64-bit device form: mantissa x 10^exponent
-        img, inull = pr.column(2)
-        img = img.astype(np.uint64)
-        q1sum = (img & np.uint64((1 << 57) - 1)).astype(np.int64) * 10 ** np.maximum(img.view(np.int64) >> 58, 0)
-        got_sq = np.zeros(18 * 16, dtype=np.int64)
-        np.add.at(got_sq, gids[~inull], q1sum[~inull])
-        assert np.array_equal(got_sq, q1sq), "Q1: sum(quantity) differs"
+        ngrp = q1_check(pr, q1ref)
         out[label] = dict(
-            workload="TPC-H Q1-shaped GpuPreAgg (BASELINE configs[4], one GPU's share): %d lineitem-like rows, "
+            workload="TPC-H Q1-shaped GpuPreAgg (BASELINE configs[4]): %d lineitem-like rows, "
                      "WHERE shipdate <= date, GROUP BY returnflag, linestatus (%d groups), 9 partial aggregates "
                      "over 4 numeric(*,2) columns held as %s (38 B/row)"
-                     % (q1rows, len(ugid), "int8 at their scale (decimal columns)" if decimal
+                     % (q1rows, ngrp, "int8 at their scale (decimal columns)" if decimal
                         else "64-bit numeric images (the reference's device form)"),
-            value=q1rows / float(np.median(walls[1:])) / 1e6, unit="Mrows/s", groups=len(ugid),
-            partial_rows=len(pr), table_slots=int(nslots),
-            checked="groups, row counts and sum(quantity) equal torch's",
+            value=q1rows / float(np.median(walls[1:])) / 1e6, unit="Mrows/s", groups=ngrp,
+            partial_rows=len(pr), table_slots=int(nslots), checked_folds=int(agg.checked_folds()),
+            checked="groups, all four row counts and all five sums (quantity, base price, discounted price, "
+                    "charge, discount) equal torch's exact integers",
             roofline=roofline_block("gpupreagg_dense_column", 38.0 * q1rows, kerns[1:], measured_peak,
                                     traffic=load_traffic(chunk_rows, "gpupreagg_dense_column")))
         agg.end()
         q1.release()
         del q1
+        torch.cuda.empty_cache()
+
+    # ---- C5 at one GPU's real share: 6e9 / 8 = 7.5e8 rows, 28.5 GB, in 8 resident chunks --------
+    # sum(charge) at scale 6 passes 2^63 per group on the way (1.9e8 rows x ~5.5e10): the table's
+    # 128-bit integer sums take it, no chunk comes back CpuReCheck, the fetch hands the totals out
+    # as several partial rows each of which fits its numeric
+    share = 750_000_000
+    if args.rows >= 1_000_000_000 and not os.environ.get("STROM_BENCH_NO_Q1_SHARE"):
+        nq = 8
+        per = share // nq
+        parts, ref_total = [], None
+        for i in range(nq):
+            ds, ref = c5_chunk_device(per, 0x5eed0050 + i, True)
+            parts.append(ds)
+            ref_total = q1_add_reference(ref_total, ref)
+        agg = GpuPreAgg(Q1_AGG).begin([(65, 18), (70, 10)])
+        agg.census(parts[0])
+        nslots = agg.compact()
+        walls, kerns = [], []
+        for step in range(4):
+            agg.reset()
+            t0 = time.perf_counter()
+            pend = [agg.submit(ds) for ds in parts]
+            res = [agg.collect(p) for p in pend]
+            walls.append(time.perf_counter() - t0)
+            assert all(st == 0 for st, _ in res), "Q1 share: fold status %s" % [st for st, _ in res]
+            kerns.extend(pfm["time_kern_exec_ns"] - pfm["time_kern_proj_ns"] for _, pfm in res)
+        pr = agg.fetch()
+        ngrp = q1_check(pr, ref_total)
+        beyond = sum(1 for v in ref_total["sum_charge"] if v >= 2**63)
+        out["q1_shape_c5_one_gpu_share"] = dict(
+            workload="TPC-H Q1-shaped GpuPreAgg, ONE GPU's share of BASELINE configs[4]: 6e9 / 8 = %d lineitem-like "
+                     "rows (%.1f GB) in %d resident chunks folded into one session, decimal columns (38 B/row)"
+                     % (per * nq, 38.0 * per * nq / 1e9, nq),
+            value=per * nq / float(np.median(walls[1:])) / 1e6, unit="Mrows/s", groups=ngrp,
+            partial_rows=len(pr), table_slots=int(nslots), checked_folds=int(agg.checked_folds()),
+            groups_whose_sum_charge_exceeds_int8=beyond,
+            checked="groups, row counts and all five sums equal torch's exact integers (two-limb sums: sum(charge) "
+                    "does not fit int8)",
+            ms_per_pass=float(np.median(walls[1:])) * 1e3,
+            roofline=roofline_block("gpupreagg_dense_column", 38.0 * per, kerns[nq:], measured_peak))
+        agg.end()
+        for ds in parts:
+            ds.release()
+        del parts
         torch.cuda.empty_cache()
 
     return out

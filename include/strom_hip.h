@@ -240,6 +240,16 @@ size_t		strom_gpupreagg_table_length(strom_gpupreagg *sess);
 int			strom_gpupreagg_bind_table(strom_gpupreagg *sess, void *table_devptr);
 void	   *strom_gpupreagg_table_devptr(strom_gpupreagg *sess);
 uint32_t	strom_gpupreagg_num_groups(strom_gpupreagg *sess);
+/*
+ * Integer partial sums never wrap silently -- CHECK_OVERFLOW_INT of the reference's
+ * GPUPREAGG_AGGCALC_PSUM_TEMPLATE (opencl_gpupreagg.h:142-143, 933-948) answers CpuReCheck
+ * when an accumulate leaves int8.  Here a range proof (rows x largest input magnitude
+ * < 2^63) lets unchecked kernels run; a chunk it cannot cover is folded a second time,
+ * add by add, by a program built with GPUPREAGG_CHECKED, inside the same request
+ * (devlib/strom_gpupreagg.h, "integer sums never wrap").  How many requests of this session
+ * took that second fold: a statistic (EXPLAIN ANALYZE material, like the reference's perfmon).
+ */
+uint32_t	strom_gpupreagg_checked_folds(strom_gpupreagg *sess);
 /* byte offset / element kind of target 'resno' inside the table:
  * *p_bits_off  offset of its has-value bitmap (seen bitmap for keys)
  * *p_vals_off  offset of its 8-byte value array (0 for keys)          */

@@ -145,6 +145,7 @@ PROTOTYPES = {
     "strom_gpupreagg_bind_table": (c_int, [c_void_p, c_void_p]),
     "strom_gpupreagg_table_devptr": (c_void_p, [c_void_p]),
     "strom_gpupreagg_num_groups": (c_uint32, [c_void_p]),
+    "strom_gpupreagg_checked_folds": (c_uint32, [c_void_p]),
     "strom_gpupreagg_table_layout": (c_int, [c_void_p, c_int, ctypes.POINTER(c_size_t),
                                              ctypes.POINTER(c_size_t)]),
     "strom_submit_gpupreagg": (c_void_p, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,

@@ -456,6 +456,12 @@ strom_codegen_gpupreagg(const char *spec, strom_codegen_result *out,
 		/* integer sums: static magnitude bound per aggregate (see struct target) */
 		src += sumbits_defs;
 		{
+			bool	any = false;
+			for (auto &tg : targets)
+				any = any || (tg.kind != STROM_PREAGG_KEY && tg.sumbits != 0);
+			src += (any ? "#define GPUPREAGG_HAS_INTSUMS 1\n" : "#define GPUPREAGG_HAS_INTSUMS 0\n");
+		}
+		{
 			/* wide rows: one quad per thread and tile, two would not leave
 			 * registers for the row body (a -D tunable still wins) */
 			int		row_bytes = 0;

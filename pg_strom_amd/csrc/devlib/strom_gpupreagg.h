@@ -421,29 +421,33 @@ gpupreagg_merge8e(cl_ulong a, cl_ulong b, cl_int *errcode)
  * The reference checks every accumulate of its reduction (CHECK_OVERFLOW_INT,
  * opencl_gpupreagg.h:142-143, used by GPUPREAGG_AGGCALC_PSUM_TEMPLATE 933-948)
  * and sends the chunk back to the CPU when an int8 partial sum leaves its
- * type.  A check per LDS atomic would need the returning form of every
- * ds_add_u64; instead the common case is PROVEN not to wrap and only the rest
- * is checked add by add:
+ * type.  A check per LDS atomic needs the returning form of every ds_add_u64;
+ * instead the common case is PROVEN not to wrap and only the rest is checked:
  *
- *   range proof.  |x| <= M for every summed input of the chunk and n rows
- *   give |any partial sum of the chunk| <= n * M.  M comes from the type
- *   (a sum over int2 / int4 values cast to int8: GPUPREAGG_SUMBITS_<a>, from
- *   the code generator), from the zone map (packed accumulators), or is
- *   measured: the fold ORs the magnitudes of the inputs it adds into
- *   kern_gpupreagg.sum_magnitude.  When n * (M + 1) < 2^63 nothing in the
- *   chunk -- LDS accumulators, replicas, slabs, the chunk's total -- can have
- *   wrapped, and gpupreagg_dense_merge takes the slabs.  The resident table
- *   itself is 128 bits wide for these sums (a "hi" section per integer sum),
- *   so a total over many chunks never wraps either; the fetch hands a total
- *   that does not fit int8 out as several partial rows.
+ *   Every summed input of the request has magnitude below 2^B -- B from the
+ *   type (a sum over int2 / int4 values cast to int8: GPUPREAGG_SUMBITS_<a>, by
+ *   the code generator), from the zone map (packed accumulators), or measured:
+ *   the fold ORs the magnitudes of the inputs it adds and leaves the bit count
+ *   in kern_gpupreagg (KERN_GPUPREAGG_SUM_MAGBITS).  N rows then give
+ *   |any partial sum| <= N * 2^B.
  *
- *   otherwise the merge leaves the table alone and answers
- *   StromError_SumRangeUnproven -- an internal status between Success and
- *   CpuReCheck that never reaches the caller: the host folds the chunk again
- *   with the program built with GPUPREAGG_CHECKED, whose LDS adds return the
- *   old value and are checked one by one, replicas and slabs likewise
- *   (gpupreagg_dense_merge_check); an add that leaves int8 is CpuReCheck, as
- *   in the reference.
+ *   tier 1  rows of the CHUNK x 2^B < 2^63: nothing in the chunk -- LDS
+ *           accumulators, replicas, slabs, the chunk's total per group -- can
+ *           have wrapped.  gpupreagg_dense_merge takes the slabs; nothing else runs.
+ *   tier 2  only rows of ONE WORK-GROUP x 2^B < 2^63 (KERN_GPUPREAGG_WG_ROWS, from
+ *           the launch geometry): every slab is exact, their sum may not be.
+ *           gpupreagg_dense_merge_check adds the slabs up in 128 bits first and
+ *           answers CpuReCheck when a group's chunk total leaves int8 -- the
+ *           reference's answer for such a chunk -- before the table takes any of it.
+ *   tier 3  not even that: the merge leaves the table alone and answers
+ *           StromError_SumRangeUnproven, an internal status that never reaches
+ *           the caller: the host folds the chunk again with the program built with
+ *           GPUPREAGG_CHECKED, whose LDS adds return the old value and are checked
+ *           one by one, replicas likewise, then tier 2's slab check.
+ *
+ *   The resident table itself keeps such a sum 128 bits wide (a "hi" section
+ *   per integer sum): the total over any number of chunks cannot wrap, and the
+ *   fetch hands a total beyond int8 out as several partial rows.
  * ---------------------------------------------------------------------- */
 /* (StromError_SumRangeUnproven: strom_kds.h) */
 
@@ -452,19 +456,23 @@ template <int OP, typename BASE> struct gpupreagg_is_intsum {
 							   !gpupreagg_is_numeric<BASE>::value);
 };
 
-/* v >= 0: v; v < 0: -v - 1 -- so |v| <= magnitude + 1, and an OR of magnitudes
- * is at least their maximum */
+/* v >= 0: v; v < 0: -v - 1 -- below 2^B means |v| <= 2^B, and an OR of magnitudes
+ * has the bit count of their maximum */
 STROM_DEVICE cl_ulong
 gpupreagg_sum_magnitude(cl_long v)
 {
 	return (cl_ulong)(v ^ (v >> 63));
 }
 
-/* where the fold leaves what it measured: the 8 padding bytes of kern_gpupreagg
- * (zeroed, or preset with the static bounds, by the host per request);
- * sortbuf_len -- the reference's sort buffer length, no use here -- carries the
- * number of rows the request folds */
-#define KERN_GPUPREAGG_SUM_MAGNITUDE(kgp)	((cl_ulong *)__builtin_assume_aligned((kgp)->__padding, 8))
+/*
+ * what the range proof reads, in the 8 padding bytes of kern_gpupreagg (written by
+ * the host per request): the bit count B of the largest input magnitude -- preset with
+ * what is known statically, raised by the folds (atomic max) -- and the rows ONE
+ * work-group folds at most; sortbuf_len -- the reference's sort buffer length, no use
+ * here -- carries the rows of the whole request
+ */
+#define KERN_GPUPREAGG_SUM_MAGBITS(kgp)		((cl_uint *)((kgp)->__padding))
+#define KERN_GPUPREAGG_WG_ROWS(kgp)			(*(const cl_uint *)((kgp)->__padding + 4))
 #define KERN_GPUPREAGG_FOLD_NROWS(kgp)		((cl_uint)(kgp)->sortbuf_len)
 
 STROM_DEVICE void
@@ -478,8 +486,8 @@ gpupreagg_writeback_summag(kern_gpupreagg *kgpreagg, cl_ulong summag)
 		summag |= ((cl_ulong)hi << 32) | lo;
 	}
 	if (strom_lane_id() == 0 && summag != 0)
-		__hip_atomic_fetch_or(KERN_GPUPREAGG_SUM_MAGNITUDE(kgpreagg), summag,
-							  __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		__hip_atomic_fetch_max(KERN_GPUPREAGG_SUM_MAGBITS(kgpreagg), (cl_uint)(64 - __builtin_clzl(summag)),
+							   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 /* the position of aggregate aidx among the integer sums (its high-word section in the table) */
@@ -494,16 +502,22 @@ gpupreagg_intsum_index(int aidx)
 	return n;
 }
 
-/* n rows of magnitude <= summag: can a sum of them leave int8? */
-STROM_DEVICE bool
-gpupreagg_sum_range_proven(cl_uint nrows, cl_ulong summag)
+/* nrows inputs below 2^magbits in magnitude add up to at most this (saturating at 2^63) */
+STROM_DEVICE cl_ulong
+gpupreagg_sum_bound(cl_uint nrows, cl_uint magbits)
 {
-	cl_ulong	bound;
-	if (nrows == 0 || summag == 0)
-		return true;
-	if (summag >= (1UL << 62))
-		return false;
-	return !__builtin_mul_overflow((cl_ulong)nrows, summag + 1, &bound) && bound < (1UL << 63);
+	if (nrows == 0)
+		return 0;
+	if (magbits >= 63 || ((cl_ulong)nrows >> (63 - magbits)) != 0)
+		return (1UL << 63);
+	return (cl_ulong)nrows << magbits;
+}
+
+/* can a sum of nrows such inputs leave int8? */
+STROM_DEVICE bool
+gpupreagg_sum_range_proven(cl_uint nrows, cl_uint magbits)
+{
+	return gpupreagg_sum_bound(nrows, magbits) < (1UL << 63);
 }
 
 /* LDS section offsets, computed once per kernel */
@@ -2469,23 +2483,13 @@ struct gpupreagg_hash_head {
 	 * integer sums never wrap ("integer sums never wrap", above -- here for a table whose
 	 * accumulators are 64 bits wide and are updated by atomics all over the chip): an upper
 	 * bound of |any partial sum in this table|, the sum over the folded chunks of
-	 * rows x (largest input magnitude + 1).  While it stays below 2^63 nothing can have
+	 * rows x 2^(bits of the largest input magnitude).  While it stays below 2^63 nothing can have
 	 * wrapped and nothing is checked.  Two slots: the fold of chunk k reads slot k & 1 and
 	 * (its first work-group) writes the other, which the fold of chunk k + 1 reads -- no
 	 * work-group of a launch reads what another one of it writes.
 	 */
 	cl_ulong	sum_bound[2];
 };
-
-/* n rows of magnitude <= summag add up to at most this (saturating at 2^63) */
-STROM_DEVICE cl_ulong
-gpupreagg_sum_bound(cl_uint nrows, cl_ulong summag)
-{
-	cl_ulong	bound;
-	if (summag >= (1UL << 62) || __builtin_mul_overflow((cl_ulong)nrows, summag + 1, &bound) || bound > (1UL << 63))
-		return (nrows == 0 ? 0UL : (1UL << 63));
-	return bound;
-}
 
 /*
  * a fold is about to add the request's rows to the table: is the bound still below
@@ -2500,7 +2504,7 @@ gpupreagg_hash_sum_account(kern_gpupreagg *kgpreagg, gpupreagg_hash_head *head, 
 	if (gpupreagg_intsum_index(GPUPREAGG_NAGGS) == 0 || (sum_turn & 2u) != 0)
 		return true;
 	cl_ulong	prev = head->sum_bound[sum_turn & 1u];
-	cl_ulong	add = gpupreagg_sum_bound(KERN_GPUPREAGG_FOLD_NROWS(kgpreagg), *KERN_GPUPREAGG_SUM_MAGNITUDE(kgpreagg));
+	cl_ulong	add = gpupreagg_sum_bound(KERN_GPUPREAGG_FOLD_NROWS(kgpreagg), *KERN_GPUPREAGG_SUM_MAGBITS(kgpreagg));
 	bool		ok = (prev < (1UL << 63) && add < (1UL << 63) && prev + add < (1UL << 63));
 	if (blockIdx.x == 0 && threadIdx.x == 0)
 	{
@@ -4470,10 +4474,12 @@ gpupreagg_keyrange(const kern_gpupreagg *kgpreagg, const kern_data_store *kds,
 /*
  * CHECK: compute everything, write nothing, raise the chunk status when a
  * NUMERIC sum leaves the 64-bit form while slabs are added to each other or to
- * the table -- the reference discards such a chunk's device result and re-does
- * it on the CPU (gpupreagg.c:2746-2750), so the table must not have taken part
- * of it.  Launched in front of the real merge for programs with numeric
- * partials only; the computation is the same, so the real merge cannot fail.
+ * the table, or when an INTEGER sum's chunk total leaves int8 (tier 2 of
+ * "integer sums never wrap": the slabs are exact, they are added up in 128 bits
+ * here) -- the reference discards such a chunk's device result and re-does it
+ * on the CPU (gpupreagg.c:2746-2750), so the table must not have taken part of
+ * it.  Launched in front of the real merge for programs that can need it; the
+ * real merge computes the same and cannot fail.
  */
 template <bool CHECK>
 __device__ __forceinline__ void
@@ -4490,6 +4496,7 @@ gpupreagg_dense_merge_body(kern_gpupreagg *__restrict__ kgpreagg,
 	 * only, never on timing -- float sums are reproducible.
 	 */
 	__shared__ cl_ulong	red_val[256];
+	__shared__ cl_long	red_hi[256];
 	__shared__ cl_uint	red_flags[256];
 	cl_uint		N = ctl->ngroups;
 	cl_uint		G = ctl->groups_per_split;
@@ -4502,18 +4509,28 @@ gpupreagg_dense_merge_body(kern_gpupreagg *__restrict__ kgpreagg,
 
 	if (kgpreagg->status != StromError_Success)
 		return;
-#if !(defined(GPUPREAGG_CHECKED) && GPUPREAGG_CHECKED)
-	/*
-	 * integer sums: the slabs are taken only when no sum of this chunk's inputs can
-	 * have left int8 (every work-group decides the same from the same two words).
-	 * Otherwise nothing is merged and the host folds the chunk again, checked.
-	 */
-	if (!gpupreagg_sum_range_proven(KERN_GPUPREAGG_FOLD_NROWS(kgpreagg), *KERN_GPUPREAGG_SUM_MAGNITUDE(kgpreagg)))
+	/* integer sums: which tier of the range proof holds (every work-group decides the same
+	 * from the same words) */
+	const bool	has_intsums = (gpupreagg_intsum_index(GPUPREAGG_NAGGS) > 0);
+	bool		chunk_proven = true;
+	if (has_intsums)
 	{
-		if (blockIdx.x == 0 && threadIdx.x == 0)
-			atomicMax(&kgpreagg->status, StromError_SumRangeUnproven);
-		return;
+		cl_uint		magbits = *KERN_GPUPREAGG_SUM_MAGBITS(kgpreagg);
+		chunk_proven = gpupreagg_sum_range_proven(KERN_GPUPREAGG_FOLD_NROWS(kgpreagg), magbits);
+#if !(defined(GPUPREAGG_CHECKED) && GPUPREAGG_CHECKED)
+		if (!gpupreagg_sum_range_proven(KERN_GPUPREAGG_WG_ROWS(kgpreagg), magbits))
+		{
+			/* tier 3: a work-group's own sums may have wrapped -- nothing is merged, the
+			 * host folds the chunk again with the checked program */
+			if (blockIdx.x == 0 && threadIdx.x == 0)
+				atomicMax(&kgpreagg->status, StromError_SumRangeUnproven);
+			return;
+		}
+#endif
 	}
+#if !(defined(GPUPREAGG_NUMERIC_AGGS) && GPUPREAGG_NUMERIC_AGGS)
+	if (CHECK && chunk_proven)
+		return;							/* tier 1: nothing to check */
 #endif
 	/* stripes: about 8 slabs per thread (the loop is latency bound: the
 	 * slabs are small), at least 4 group lanes for some coalescing */
@@ -4559,6 +4576,45 @@ gpupreagg_dense_merge_body(kern_gpupreagg *__restrict__ kgpreagg,
 												  pg_##NAME##_base_t>());						\
 			bool		live = (valid && (GPUPREAGG_OP_##OP == GPUPREAGG_OP_NROWS				\
 										  ? flags != 0 : (flags & (2u << aidx)) != 0));			\
+			if (CHECK && !chunk_proven &&														\
+				gpupreagg_is_intsum<GPUPREAGG_OP_##OP, pg_##NAME##_base_t>::value)				\
+			{																					\
+				/* tier 2: the slabs are exact; their sum, in 128 bits, must fit int8 */		\
+				cl_ulong	lo = 0;																\
+				cl_long		hi = 0;																\
+				if (live)																		\
+					for (cl_uint w = stripe; w < wgs_per_split; w += WS)						\
+					{																			\
+						const char *slab = slab0 + w * slab_step;								\
+						if (((const gpupreagg_flags_t *)slab)[lgid] & (2u << aidx))				\
+						{																		\
+							cl_ulong x = ((const cl_ulong *)(slab + s_vals))[lgid];				\
+							cl_ulong nlo = lo + x;												\
+							hi += ((cl_long)x >> 63) + (nlo < lo ? 1L : 0L);					\
+							lo = nlo;															\
+						}																		\
+					}																			\
+				red_val[threadIdx.x] = lo;														\
+				red_hi[threadIdx.x] = hi;														\
+				__syncthreads();																\
+				for (cl_uint s = WS / 2; s > 0; s >>= 1)										\
+				{																				\
+					if (stripe < s)																\
+					{																			\
+						cl_ulong a0 = red_val[threadIdx.x], b0 = red_val[threadIdx.x + s * GL];	\
+						cl_ulong n0 = a0 + b0;													\
+						red_val[threadIdx.x] = n0;												\
+						red_hi[threadIdx.x] += red_hi[threadIdx.x + s * GL] + (n0 < a0 ? 1L : 0L);	\
+					}																			\
+					__syncthreads();															\
+				}																				\
+				if (live && stripe == 0 &&														\
+					red_hi[threadIdx.x] != ((cl_long)red_val[threadIdx.x] >> 63))				\
+					merr = StromError_CpuReCheck;												\
+				__syncthreads();																\
+			}																					\
+			else																				\
+			{																					\
 			if (live)																			\
 			{																					\
 				for (cl_uint w = stripe; w < wgs_per_split; w += WS)							\
@@ -4623,6 +4679,7 @@ gpupreagg_dense_merge_body(kern_gpupreagg *__restrict__ kgpreagg,
 				}																				\
 			}																					\
 			__syncthreads();																	\
+			}																					\
 		}
 		GPUPREAGG_AGG_LIST(X)
 #undef X
@@ -4641,7 +4698,8 @@ gpupreagg_dense_merge(kern_gpupreagg *kgpreagg, const gpupreagg_dense_ctl *ctl,
 	gpupreagg_dense_merge_body<false>(kgpreagg, ctl, slabs, table);
 }
 
-#if (defined(GPUPREAGG_NUMERIC_AGGS) && GPUPREAGG_NUMERIC_AGGS) || (defined(GPUPREAGG_CHECKED) && GPUPREAGG_CHECKED)
+#if (defined(GPUPREAGG_NUMERIC_AGGS) && GPUPREAGG_NUMERIC_AGGS) || (defined(GPUPREAGG_CHECKED) && GPUPREAGG_CHECKED) || \
+	(defined(GPUPREAGG_HAS_INTSUMS) && GPUPREAGG_HAS_INTSUMS)
 extern "C" __global__ void
 __launch_bounds__(256)
 gpupreagg_dense_merge_check(kern_gpupreagg *kgpreagg, const gpupreagg_dense_ctl *ctl,

@@ -110,7 +110,8 @@ struct strom_gpupreagg {
 	 * with GPUPREAGG_CHECKED that folds a chunk whose range proof failed
 	 */
 	std::vector<int>	sumbits;
-	cl_ulong			static_summag = 0;
+	cl_uint				static_magbits = 0;		/* the largest static bound, in bits */
+	bool				sums_measured = false;	/* an integer sum without a static bound */
 	std::vector<int>	intsum_of;			/* aggregate -> index among the integer sums, or -1 */
 	int					nintsums = 0;
 	strom_devprog_key	key_checked = 0;
@@ -565,12 +566,12 @@ struct preagg_request {
 	std::shared_ptr<std::vector<char>> joined_map;	/* host image of gpupreagg_joined_map */
 };
 
-/* OR of the magnitudes a zone map allows (strom_gpupreagg.h: gpupreagg_sum_magnitude) */
-cl_ulong
-zone_magnitude(const kern_coldir &cd)
+/* bits of the largest magnitude a zone map allows (strom_gpupreagg.h: gpupreagg_sum_magnitude) */
+cl_uint
+zone_magbits(const kern_coldir &cd)
 {
 	cl_long		lo = cd.minval, hi = cd.maxval;
-	return (cl_ulong)(lo ^ (lo >> 63)) | (cl_ulong)(hi ^ (hi >> 63));
+	return (cl_uint)bits_for((cl_ulong)(lo ^ (lo >> 63)) | (cl_ulong)(hi ^ (hi >> 63)));
 }
 
 /*
@@ -646,7 +647,7 @@ gpupreagg_launch(strom_task_impl *task, preagg_request req, bool checked = false
 		return;
 	}
 	/* what is known about the integer sums' inputs before the fold measures the rest */
-	cl_ulong	summag = sess->static_summag;
+	cl_uint		magbits = sess->static_magbits;
 	/* packed accumulators for this chunk?  (fewer id-range roles: see packed_plan) */
 	pack_ctl	pk;
 	strom_gpupreagg::packed_geom *packed = nullptr;
@@ -694,7 +695,7 @@ gpupreagg_launch(strom_task_impl *task, preagg_request req, bool checked = false
 			 * the integer sums' inputs too */
 			for (size_t a = 0; a < sess->agg_resno.size(); a++)
 				if (sess->pack_kind[a] == 2 && sess->sumbits[a] >= 64)
-					summag |= zone_magnitude(coldir[sess->pack_attno[a] - 1]);
+					magbits = std::max(magbits, zone_magbits(coldir[sess->pack_attno[a] - 1]));
 		}
 	}
 	/* kern_gpupreagg image: {status, sortbuf_len, pad, kern_parambuf} [+ the pack control block] */
@@ -713,9 +714,24 @@ gpupreagg_launch(strom_task_impl *task, preagg_request req, bool checked = false
 	task->main_devptr = d_kg;
 	memset(stage, 0, kg_len);
 	memcpy(stage + offsetof(kern_gpupreagg, kparams), sess->kparams.data(), sess->kparams.size());
-	/* KERN_GPUPREAGG_FOLD_NROWS / _SUM_MAGNITUDE of strom_gpupreagg.h */
-	((kern_gpupreagg *)stage)->sortbuf_len = (cl_int)req.nrows;
-	memcpy(((kern_gpupreagg *)stage)->__padding, &summag, sizeof(summag));
+	{
+		/*
+		 * the range proof's inputs (strom_gpupreagg.h, "integer sums never wrap"): rows of the
+		 * request, bits of the largest input magnitude known so far, and the rows ONE work-group
+		 * folds at most -- tiles (or, row by row, blocks) are dealt round-robin to the work-groups
+		 * of a role; one unit of slack
+		 */
+		const dense_ctl &g = (packed ? packed->ctl : sess->ctl);
+		size_t		unit = (use_reg ? (size_t)256 * 4 * sess->quads
+							: (use_column || use_lookup) ? (size_t)sess->block * 4 * sess->quads
+							: (size_t)sess->block);
+		size_t		units = ((size_t)req.nrows + unit - 1) / unit;
+		size_t		wgs_per_role = std::max<size_t>(1, g.nslabs / std::max<cl_uint>(1, g.nsplits));
+		size_t		wg_rows = std::min<size_t>(((units + wgs_per_role - 1) / wgs_per_role + 1) * unit, 0xffffffffUL);
+		cl_uint		words[2] = { magbits, (cl_uint)wg_rows };
+		((kern_gpupreagg *)stage)->sortbuf_len = (cl_int)req.nrows;
+		memcpy(((kern_gpupreagg *)stage)->__padding, words, sizeof(words));
+	}
 	if (packed)
 		memcpy(stage + kg_len, &pk, sizeof(pk));
 
@@ -869,7 +885,10 @@ gpupreagg_launch(strom_task_impl *task, preagg_request req, bool checked = false
 		unsigned gl = 256 / ws;
 		unsigned mgrid = std::min<unsigned>((lctl.ngroups + gl - 1) / gl,
 											(unsigned)dev->prop.multiProcessorCount * 8);
-		if (sess->numeric_aggs || checked)
+		/* the slab check: numeric sums; integer sums whose chunk totals the range proof may
+		 * not cover (tier 2: the kernel leaves at once when it does) */
+		if (sess->numeric_aggs || checked ||
+			(sess->nintsums > 0 && (sess->sums_measured || sess->static_magbits > 31)))
 		{
 			/* numeric sums may leave the 64-bit form while slabs are added up: find
 			 * out BEFORE the table takes any of it (gpupreagg_dense_merge_body<CHECK>) */
@@ -1197,7 +1216,7 @@ gpupreagg_launch_hashed(strom_task_impl *task, preagg_request req, bool second =
 	/* integer sums never wrap (strom_gpupreagg.h): rows of the request, what is known about
 	 * the inputs before the check pass measures the rest */
 	((kern_gpupreagg *)stage)->sortbuf_len = (cl_int)req.nrows;
-	memcpy(((kern_gpupreagg *)stage)->__padding, &sess->static_summag, sizeof(cl_ulong));
+	memcpy(((kern_gpupreagg *)stage)->__padding, &sess->static_magbits, sizeof(cl_uint));
 	/* the fold's turn (gpupreagg_hash_sum_account): parity; 4 = second attempt, after the
 	 * bound was measured; relaunches for deferred rows add 2 */
 	cl_uint		sum_turn = (sess->sum_turn++ & 1u) | (second ? 4u : 0u);
@@ -1724,7 +1743,9 @@ gpupreagg_session_new(strom_devprog_key key,
 			sess->sumbits.push_back(bits);
 			sess->intsum_of.push_back(intsum ? sess->nintsums++ : -1);
 			if (bits >= 1 && bits <= 63)
-				sess->static_summag |= ((1UL << bits) - 1);
+				sess->static_magbits = std::max(sess->static_magbits, (cl_uint)bits);
+			if (intsum && bits >= 64)
+				sess->sums_measured = true;
 		}
 	}
 	if (const char *v = getenv("STROM_GPUPREAGG_BLOCK"))
@@ -1841,6 +1862,9 @@ strom_gpupreagg_num_groups(strom_gpupreagg *sess)
 	}
 	return (sess && sess->has_domain) ? sess->ctl.ngroups : 0;
 }
+
+extern "C" uint32_t
+strom_gpupreagg_checked_folds(strom_gpupreagg *sess) { return sess ? sess->checked_folds.load() : 0; }
 
 extern "C" uint32_t
 strom_gpupreagg_dense_groups(strom_gpupreagg *sess) { return (sess && sess->has_domain) ? sess->ctl.dense_ngroups : 0; }

@@ -142,6 +142,11 @@ class GpuPreAgg(object):
     def num_groups(self):
         return lib.strom_gpupreagg_num_groups(self.session)
 
+    def checked_folds(self):
+        """requests whose integer sums the range proof did not cover: folded again by the
+        GPUPREAGG_CHECKED program (strom_gpupreagg_checked_folds)"""
+        return lib.strom_gpupreagg_checked_folds(self.session)
+
     # group-slot agreement ---------------------------------------------------
     def census(self, chunk, row_map=None):
         """mark the dense ids that occur in 'chunk' (after the qual); returns

@@ -81,9 +81,13 @@ def run_dense(spec, bufs, domain, hashed=False):
     try:
         statuses = [agg.fold(b)[0] for b in bufs]
         pr = agg.fetch()
+        LAST["checked_folds"] = agg.checked_folds()
     finally:
         agg.end()
     return statuses, pr, agg.targets
+
+
+LAST = {}       # which tier the last run_dense() took: folds by the GPUPREAGG_CHECKED program
 
 
 # the shapes of the dense path: LDS atomics with and without replicas, lane-private LDS
@@ -107,6 +111,8 @@ def test_sum_that_leaves_int8_is_cpu_recheck(fmt, ngroups, hashed):
     assert oracle_status(SPEC, buf, 4) == 2
     statuses, _, _ = run_dense(SPEC, [buf], [(0, ngroups)], hashed)
     assert statuses == [2]
+    # (inputs of 2^61: not even a work-group's own sums are covered by the proof -- tier 3)
+    assert hashed or LAST["checked_folds"] == 1
     # 3 x 2^61 + 2^60 fit: the same chunk with two of the five rows made smaller is summed on
     # the device
     x[hot[0]] = 7
@@ -148,7 +154,8 @@ def test_sum_without_group_by_is_checked_too():
 def test_values_at_the_edges_of_int8_that_fit_are_exact(fmt, ngroups):
     """a group that IS int8's largest value, one that is its smallest, sums that end one short
     of the edge: nothing overflows, the oracle says Success, and so must the device (the range
-    proof fails, the checked program folds the chunk and finds every addition in range)"""
+    proof fails even for one work-group: tier 3, the checked program folds the chunk and finds
+    every addition in range)"""
     rng = np.random.default_rng(4)
     n = 20000
     g = rng.integers(4, ngroups, n) if ngroups > 4 else np.full(n, 4)
@@ -169,6 +176,7 @@ def test_values_at_the_edges_of_int8_that_fit_are_exact(fmt, ngroups):
     got = totals([pr], targets)
     assert got == {k: [None] + v for k, v in expected(g, x).items()}
     assert got[(0,)][2] == I64_MAX and got[(1,)][2] == I64_MIN and got[(3,)][2] == I64_MIN
+    assert LAST["checked_folds"] == 1
 
 
 @pytest.mark.parametrize("nrows,status", [(2000000, 2), (900000, 0)])
@@ -184,6 +192,9 @@ def test_many_rows_of_1e13(nrows, status):
     assert oracle_status(SPEC, buf, 4) == status
     statuses, pr, targets = run_dense(SPEC, [buf], [(5, 20)])
     assert statuses == [status]
+    # tier 2: a work-group's rows x 2^44 stay far below 2^63 -- the slabs are exact and the slab
+    # check decides; the checked program is not needed
+    assert LAST["checked_folds"] == 0
     if status == 0:
         assert totals([pr], targets) == {k: [None] + v for k, v in expected(g, x).items()}
 
@@ -193,14 +204,14 @@ def test_many_rows_of_1e13(nrows, status):
 def test_sum_that_crosses_int8_only_when_a_later_chunk_is_folded(sign, n, value, nchunks):
     """each chunk's partial sums fit int8 (the oracle, like the reference, works chunk by
     chunk); the session's table adds them up over all chunks -- 128 bits wide, so 6 x 1.7e18
-    (range proven per chunk: the unchecked kernels) and 3 x 5e18 (not proven: the checked
-    program) are exact, and the fetch hands the total out as partial rows that each fit int8"""
+    (range proven per chunk: tier 1) and 3 x 5e18 (proven per work-group only: tier 2, the slab
+    check adds the slabs up in 128 bits) are exact, and the fetch hands the total out as partial rows that each fit int8"""
     g = np.arange(n) % 3
     x = np.where(g == 0, sign * value, np.arange(n) - 7)
     bufs = [table(g, x, "column") for _ in range(nchunks)]
     assert oracle_status(SPEC, bufs[0], 4) == 0
     statuses, pr, targets = run_dense(SPEC, bufs, [(0, 3)])
-    assert statuses == [0] * nchunks
+    assert statuses == [0] * nchunks and LAST["checked_folds"] == 0     # tiers 1 and 2
     got = totals([pr], targets)
     want = expected(np.tile(g, nchunks), np.tile(x, nchunks))
     assert got == {k: [None] + v for k, v in want.items()}
