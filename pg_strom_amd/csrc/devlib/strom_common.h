@@ -24,6 +24,61 @@
 typedef unsigned long long	strom_lanemask_t;
 
 /* ---------------------------------------------------------------- *
+ * publishing a record other work-groups (other XCDs) probe
+ *
+ * The open-addressing tables in HBM -- the hashed GROUP BY's records
+ * (strom_gpupreagg.h) and the KEYED join index (strom_hashjoin.h) -- are
+ * claimed with a compare-and-swap on a state word, filled, and marked ready.
+ * Formally that is: payload stores, then a RELEASE store of the state;
+ * probes: an ACQUIRE load of the state, then the payload.  At agent scope on
+ * a chip whose eight L2s are kept coherent by write-back / invalidate those
+ * two are an L2 write-back per claim and a cache invalidate per probe
+ * (measured: 28 of 42 ms).  Neither is needed when EVERY
+ * access to the record -- state and payload, reads and writes -- is an
+ * agent-scope atomic: those are performed at the coherence point itself.  What
+ * is left is ordering the claimer's own stores: the payload stores must have
+ * been acknowledged before the state store is issued.
+ *
+ *   STROM_PUBLISH_STATE(ptr, val)   store 'val' to the state word once all
+ *                                   earlier stores of this wave are acknowledged
+ *   STROM_PROBE_STATE(ptr)          load the state word
+ *
+ * Fast form: s_waitcnt vmcnt(0), in the gfx9 encoding (vmcnt bits 3:0 and
+ * 15:14, expcnt 6:4, lgkmcnt 11:8 -> 0x0f70 leaves the other counters alone;
+ * stores count in vmcnt on gfx9, gfx10+ moved them to vscnt): gfx9 family
+ * ONLY, asserted below.  -DSTROM_FORMAL_PUBLISH=1 (runtime knob
+ * STROM_FORMAL_PUBLISH) builds the RELEASE / ACQUIRE form instead -- the
+ * reference semantics to test the fast form against, and the fallback for
+ * any other target.  The payload of a record lies in the 64-byte line of its
+ * state word (16-byte KEYED slots; GROUP BY records are aligned to their
+ * power-of-two stride and keep state, NULL bits and up to 6 keys in the first
+ * 64 bytes); a probe that matched re-reads the state word after the payload
+ * and goes round again if it changed (it cannot: states only move
+ * empty -> busy -> ready; the re-read costs an L2 hit and closes the door on
+ * a payload that was read before the state it belongs to).
+ * ---------------------------------------------------------------- */
+#if !defined(STROM_FORMAL_PUBLISH)
+#define STROM_FORMAL_PUBLISH	0
+#endif
+#if !STROM_FORMAL_PUBLISH && !defined(__GFX9__)
+#error "STROM_PUBLISH_STATE's s_waitcnt encoding is gfx9's: build with -DSTROM_FORMAL_PUBLISH=1 for this target"
+#endif
+#if STROM_FORMAL_PUBLISH
+#define STROM_PUBLISH_STATE(ptr, val)	\
+	__hip_atomic_store((ptr), (val), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT)
+#define STROM_PROBE_STATE(ptr)			\
+	__hip_atomic_load((ptr), __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT)
+#else
+#define STROM_PUBLISH_STATE(ptr, val)	\
+	do {								\
+		__builtin_amdgcn_s_waitcnt(0x0f70);		/* vmcnt(0): the payload stores are acknowledged */	\
+		__hip_atomic_store((ptr), (val), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);	\
+	} while (0)
+#define STROM_PROBE_STATE(ptr)			\
+	__hip_atomic_load((ptr), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+#endif
+
+/* ---------------------------------------------------------------- *
  * error priority: significant (>=100 or <0) sticks, first one wins;
  * among minor codes the larger wins (CpuReCheck=2 > RowFiltered=1 > 0)
  * ---------------------------------------------------------------- */

@@ -1411,6 +1411,9 @@ gpupreagg_dense_joined(kern_gpupreagg *kgpreagg,
 #ifndef GPUPREAGG_ABLATE
 #define GPUPREAGG_ABLATE 0
 #endif
+#if (GPUPREAGG_ABLATE != 0) && !defined(STROM_DIAGNOSTIC_BUILD)
+#error "GPUPREAGG_ABLATE builds leave work out and give wrong results: measurement only (set STROM_DIAGNOSTIC_BUILD=1, as scripts/gpu_*_ablate* do)"
+#endif
 #if GPUPREAGG_ABLATE & 1
 STROM_DEVICE cl_uint
 gpupreagg_ablate_sink(const strom_kvars &KV)
@@ -2588,10 +2591,11 @@ gpupreagg_hash_slot(char *htab, cl_uint hash, const cl_ulong *kimg, cl_uint knul
 		 * No acquire here: at agent scope that is an invalidate of the caches in front of
 		 * the table for every probe (the flush of a work-group's LDS table spent 2.9 of
 		 * its 3.6 ms per 1e8 rows and 1e6 groups there).  The record's state, NULL bits
-		 * and keys are read with agent-scope atomic loads instead, which are served where
-		 * the claimer's release made them visible before it stored state 2.
+		 * and keys are read with agent-scope atomic loads instead, served at the coherence
+		 * point -- where the claimer's key stores had been acknowledged before it stored
+		 * state 2 (STROM_PUBLISH_STATE / STROM_PROBE_STATE, strom_common.h).
 		 */
-		cl_uint	st = __hip_atomic_load(HASH_REC_STATE(rec), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		cl_uint	st = STROM_PROBE_STATE(HASH_REC_STATE(rec));
 
 		if (st == 0 && claim_limit != ~0u &&
 			__hip_atomic_load(&head->ngroups, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= claim_limit)
@@ -2616,8 +2620,7 @@ gpupreagg_hash_slot(char *htab, cl_uint hash, const cl_ulong *kimg, cl_uint knul
 				for (int k = 0; k < GPUPREAGG_NKEYS; k++)
 					__hip_atomic_store(HASH_REC_KEYS(rec) + k, kimg[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 				__hip_atomic_store(HASH_REC_KNULL(rec), knull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-				__builtin_amdgcn_s_waitcnt(0x0f70);		/* vmcnt(0): the stores above are acknowledged; no cache maintenance */
-				__hip_atomic_store(HASH_REC_STATE(rec), 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				STROM_PUBLISH_STATE(HASH_REC_STATE(rec), 2u);	/* behind the stores above; no cache maintenance */
 				atomicAdd(&head->ngroups, 1u);
 				result = slot;
 				done = true;
@@ -2634,6 +2637,10 @@ gpupreagg_hash_slot(char *htab, cl_uint hash, const cl_ulong *kimg, cl_uint knul
 					same = same && (__hip_atomic_load(HASH_REC_KEYS(rec) + k, __ATOMIC_RELAXED,
 													  __HIP_MEMORY_SCOPE_AGENT) == kimg[k]);
 			}
+			/* the keys were read after the state they belong to?  (see strom_common.h: a
+			 * ready record never changes, so this re-read only ever confirms) */
+			if (MATCH && STROM_PROBE_STATE(HASH_REC_STATE(rec)) != 2u)
+				continue;
 			if (same)
 			{
 				result = slot;

@@ -112,6 +112,9 @@ gpuscan_stage_flush(STAGE &stage, kern_resultbuf *kresults, cl_uint fill)
 	/* caller guarantees a barrier since the last write into the stage */
 	if (fill == 0)
 		return;
+#if (defined(GPUSCAN_ABLATE) && GPUSCAN_ABLATE != 0) && !defined(STROM_DIAGNOSTIC_BUILD)
+#error "GPUSCAN_ABLATE builds leave work out and give wrong results: measurement only (set STROM_DIAGNOSTIC_BUILD=1, as scripts/gpu_*_ablate* do)"
+#endif
 #if defined(GPUSCAN_ABLATE) && GPUSCAN_ABLATE == 2
 	/* diagnostic build (wrong results): no reservation atomic */
 	if (threadIdx.x == 0)

@@ -357,7 +357,7 @@ hashjoin_build_index_kernel(kern_multihash *kmhash, int depth, hashjoin_index *h
 						 * write-back per probe and per claim, DESIGN section 9.27.  Tag and key words
 						 * are read and written with agent-scope atomics, served at the coherence
 						 * point; the claimer waits for its key stores before it stores READY) */
-						cl_uint		tag = __hip_atomic_load(&slot[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+						cl_uint		tag = STROM_PROBE_STATE(&slot[1]);
 						if (tag == HASHJOIN_KEYED_EMPTY)
 						{
 							cl_uint expect = HASHJOIN_KEYED_EMPTY;
@@ -367,9 +367,7 @@ hashjoin_build_index_kernel(kern_multihash *kmhash, int depth, hashjoin_index *h
 							{
 								__hip_atomic_store(&slot[2], lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 								__hip_atomic_store(&slot[3], hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-								__builtin_amdgcn_s_waitcnt(0x0f70);		/* vmcnt(0) */
-								__hip_atomic_store(&slot[1], HASHJOIN_KEYED_READY, __ATOMIC_RELAXED,
-												   __HIP_MEMORY_SCOPE_AGENT);
+								STROM_PUBLISH_STATE(&slot[1], HASHJOIN_KEYED_READY);	/* strom_common.h */
 								break;
 							}
 							continue;				/* lost the race: look at the slot again */
@@ -542,6 +540,9 @@ gpuhashjoin_main_body(kern_hashjoin *__restrict__ khashjoin,
 					STROM_KVAR_LIST(X)
 #undef X
 					KV.__dummy = 0;
+#if (defined(HASHJOIN_ABLATE) && HASHJOIN_ABLATE != 0) && !defined(STROM_DIAGNOSTIC_BUILD)
+#error "HASHJOIN_ABLATE builds leave work out and give wrong results: measurement only (set STROM_DIAGNOSTIC_BUILD=1, as scripts/gpu_*_ablate* do)"
+#endif
 #if defined(HASHJOIN_ABLATE) && HASHJOIN_ABLATE == 2
 					n = 1;				/* diagnostic build (wrong results): no probe */
 #else

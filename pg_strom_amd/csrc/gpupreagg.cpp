@@ -1014,6 +1014,17 @@ hash_lds_slots(const strom_gpupreagg *sess, size_t *p_bytes, bool for_units = fa
 		 * power of two of slots takes */
 		return fit(159 * 1024, p_bytes);
 	}
+	if (const char *v = getenv("STROM_GPUPREAGG_HASH_LDS_SLOTS"))
+	{
+		/* tests: a tiny table in front of the global one sends (nearly) every row to the
+		 * global table's claim / probe protocol */
+		cl_uint		want = (cl_uint)atoi(v);
+		if (want >= 64 && want <= 16384 && (want & (want - 1)) == 0)
+		{
+			*p_bytes = sess->image_offset(sess->nsections(), want, 1) + (size_t)want * (8 + 8 * nkeys) + queue;
+			return want;
+		}
+	}
 	size_t		small_bytes, big_bytes;
 	cl_uint		small_slots = fit(64 * 1024, &small_bytes);
 	cl_uint		big_slots = fit(136 * 1024, &big_bytes);
@@ -1059,6 +1070,16 @@ hash_table_new(strom_gpupreagg *sess, cl_uint capacity, char **p_tab, size_t *p_
 	*p_tab = tab;
 	*p_bytes = L.total;
 	return 0;
+}
+
+/* groups the table takes before it must grow: 7/8 of the slots minus what racing threads and
+ * the work-groups' final LDS flushes can still claim (never negative: a table made by an
+ * import may be smaller than a fold's headroom -- the fold grows it first, see the callers) */
+cl_ulong
+hash_fill_limit(const strom_gpupreagg *sess, cl_ulong headroom)
+{
+	cl_ulong	room = (cl_ulong)sess->hash_capacity / 8 * 7;
+	return room > headroom ? room - headroom : 0;
 }
 
 /* groups claimed so far (drains the session's stream) */
@@ -1193,6 +1214,17 @@ gpupreagg_launch_hashed(strom_task_impl *task, preagg_request req, bool second =
 			capacity <<= 1;
 		sess->hash_capacity = (cl_uint)capacity;
 		int rc = hash_table_new(sess, sess->hash_capacity, &sess->htab, &sess->htab_bytes, nullptr);
+		if (rc)
+		{
+			task_fail(task, rc);
+			return;
+		}
+	}
+	else if ((cl_ulong)sess->hash_capacity < 4 * headroom)
+	{
+		/* a table made by a merge / import before the first fold (at the session's initial
+		 * size): a fold needs its headroom of free slots whatever made the table */
+		int rc = hash_table_grow(sess, 4 * headroom);
 		if (rc)
 		{
 			task_fail(task, rc);
@@ -1420,7 +1452,7 @@ gpupreagg_launch_hashed(strom_task_impl *task, preagg_request req, bool second =
 		cl_uint		ntodo = 0;
 		for (int turn = 0;; turn++)
 		{
-			cl_ulong	fill_limit = (cl_ulong)sess->hash_capacity / 8 * 7 - headroom;
+			cl_ulong	fill_limit = hash_fill_limit(sess, headroom);
 			if (sess->groups_upper + nrows > fill_limit)
 			{
 				cl_uint	ngroups = 0;
@@ -1436,7 +1468,7 @@ gpupreagg_launch_hashed(strom_task_impl *task, preagg_request req, bool second =
 					task_fail(task, rc);
 					return;
 				}
-				fill_limit = (cl_ulong)sess->hash_capacity / 8 * 7 - headroom;
+				fill_limit = hash_fill_limit(sess, headroom);
 			}
 			bool		may_defer = (sess->groups_upper + nrows > fill_limit);
 			cl_uint		claim_limit = (may_defer ? (cl_uint)fill_limit : ~0u);
@@ -1525,7 +1557,7 @@ gpupreagg_launch_hashed(strom_task_impl *task, preagg_request req, bool second =
 		int			turn = 0;
 		while (todo > 0)
 		{
-			cl_ulong	fill_limit = (cl_ulong)sess->hash_capacity / 8 * 7 - headroom;
+			cl_ulong	fill_limit = hash_fill_limit(sess, headroom);
 			if (sess->groups_upper + todo > fill_limit)
 			{
 				/* the bound is stale or the table is small: look */
@@ -1544,7 +1576,7 @@ gpupreagg_launch_hashed(strom_task_impl *task, preagg_request req, bool second =
 					task_fail(task, rc);
 					return;
 				}
-				fill_limit = (cl_ulong)sess->hash_capacity / 8 * 7 - headroom;
+				fill_limit = hash_fill_limit(sess, headroom);
 			}
 			bool		may_defer = (sess->groups_upper + todo > fill_limit);
 			cl_uint		claim_limit = (may_defer ? (cl_uint)fill_limit : no_limit);
@@ -3419,7 +3451,11 @@ strom_submit_gpupreagg_chunk(strom_devprog_key key,
 		kgpreagg->status = rc;			/* KERN_GPUPREAGG_DMARECV: the status word */
 		task->pfm = pfm;
 		task->pfm.enabled = perfmon_enabled();
-		task_fail(task, rc);			/* nothing of its own on a stream: completes on the completer thread */
+		/* nothing of its own on a stream (every step above was waited for): it completes on
+		 * the completer thread with this status, without the drain of all streams a request
+		 * that failed in mid-launch needs (task_fail) */
+		task->errcode = rc;
+		task_enqueue(task);
 	});
 	return task;
 	STROM_ABI_CATCH(nullptr, p_errcode)

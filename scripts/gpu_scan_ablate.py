@@ -13,6 +13,7 @@ runtime.init()
 ds = runtime.DeviceStore.upload(kds.build_kds("column", [kds.Column("int4", a), kds.Column("float8", b)]))
 for abl in ("0", "1", "2"):
     os.environ["STROM_GPUSCAN_ABLATE"] = abl
+    os.environ["STROM_DIAGNOSTIC_BUILD"] = "1"      # the headers refuse *_ABLATE builds otherwise
     scan = GpuScan(QUAL).begin(ext_params=[np.int32(0), 0.0]); scan.program.wait()
     out = []
     for sa, sb in ((0.02, 0.5), (0.5, 0.8), (0.7, 0.3), (1.0, -1.0)):

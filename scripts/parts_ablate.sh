@@ -6,6 +6,7 @@ OUT=$GRAFT_REPO_ROOT/gpurun_out/parts_ablate
 rm -rf $OUT; mkdir -p $OUT
 for A in $1; do
   export STROM_GPUPREAGG_ABLATE=$A
+  export STROM_DIAGNOSTIC_BUILD=1   # the headers refuse *_ABLATE builds otherwise
   rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/a$A -o run -- \
       python3 $GRAFT_REPO_ROOT/scripts/gpu_preagg_parts_probe.py 1e8 ${2:-1000000} parts > $OUT/a$A.log 2>&1 || { tail -5 $OUT/a$A.log; exit 1; }
   echo "== ablate=$A"; grep ngroups $OUT/a$A.log

@@ -1027,3 +1027,74 @@ def test_chunk_message_recheck_and_no_space():
     assert ei.value.errcode == 301              # DataStoreNoSpace
     status, pr = agg2.collect_chunk(agg2.submit_chunk(buf, dest_rooms=100))
     assert status == 0 and len(pr) == 100
+
+
+@pytest.mark.parametrize("formal", [False, True])
+def test_hashed_claims_and_probes_race_across_the_chip(monkeypatch, formal):
+    """the global table's publish protocol under contention (strom_common.h: STROM_PUBLISH_STATE /
+    STROM_PROBE_STATE): every work-group of the chip finds or claims the SAME few thousand keys at
+    the same time -- a 64-slot LDS table in front leaves nearly every row to the global path, no
+    partition plan, no roles.  A probe that saw 'ready' with stale keys would claim a second slot
+    for a key: more groups than keys, sums split.  Both forms must give exactly the distinct keys
+    and exact sums: the fast one (payload stores acknowledged, then the state) and the formal
+    RELEASE / ACQUIRE one (STROM_FORMAL_PUBLISH=1, a program of its own)."""
+    monkeypatch.setenv("STROM_GPUPREAGG_HASH_LDS_SLOTS", "64")
+    monkeypatch.setenv("STROM_GPUPREAGG_HASH_NO_PARTS", "1")
+    monkeypatch.setenv("STROM_GPUPREAGG_HASH_ROLES", "1")
+    if formal:
+        monkeypatch.setenv("STROM_FORMAL_PUBLISH", "1")
+    rng = np.random.default_rng(41)
+    n, nkeys = 3000000, 3000
+    keys = rng.integers(-2**62, 2**62, nkeys)
+    k2 = rng.integers(0, 7, nkeys).astype(np.int32)
+    pick = rng.integers(0, nkeys, n)
+    x = rng.integers(-10**6, 10**6, n).astype(np.int32)
+    buf = kds.build_kds("column", [kds.Column("int8", keys[pick]), kds.Column("int4", k2[pick]), kds.Column("int4", x)])
+    spec = "(gpupreagg (key (var 1 int8)) (key (var 2 int4)) (nrows) (psum (int8 (var 3 int4))) (pmax (var 3 int4)))"
+    agg = GpuPreAgg(spec).begin_hashed()
+    try:
+        for _ in range(3):
+            assert agg.fold(buf)[0] == 0
+        assert agg.num_groups() == nkeys
+        pr = agg.fetch()
+    finally:
+        agg.end()
+    assert len(pr) == nkeys
+    order = np.argsort(pr.column(0)[0])
+    kord = np.argsort(keys)
+    assert np.array_equal(pr.column(0)[0][order], keys[kord]) and np.array_equal(pr.column(1)[0][order], k2[kord])
+    cnt = np.bincount(pick, minlength=nkeys)
+    sx = np.bincount(pick, weights=x.astype(np.float64), minlength=nkeys).astype(np.int64)
+    mx = np.full(nkeys, -2**31, dtype=np.int64)
+    np.maximum.at(mx, pick, x)
+    assert np.array_equal(pr.column(2)[0][order], 3 * cnt[kord])
+    assert np.array_equal(pr.column(3)[0][order], 3 * sx[kord])
+    assert np.array_equal(pr.column(4)[0][order].astype(np.int64), mx[kord])
+
+
+def test_hashed_merge_into_an_empty_session_then_fold_many_groups():
+    """a table made by strom_gpupreagg_merge before the session's first fold has the initial
+    65536 slots; the fold that follows brings 150000 new groups: it must grow the table first
+    (round 2's fill limit -- slots * 7/8 minus the fold's headroom -- went below zero, unsigned,
+    for such a table: never deferred, never grew, ended in DataStoreNoSpace)"""
+    rng = np.random.default_rng(42)
+    spec = "(gpupreagg (key (var 1 int8)) (nrows) (psum (int8 (var 2 int4))))"
+    small_k = rng.integers(-2**60, 2**60, 500)
+    small = kds.build_kds("column", [kds.Column("int8", small_k[rng.integers(0, 500, 20000)]),
+                                     kds.Column("int4", np.ones(20000, dtype=np.int32))])
+    many_k = rng.integers(-2**60, 2**60, 150000)
+    many = kds.build_kds("column", [kds.Column("int8", many_k[np.arange(600000) % 150000]),
+                                    kds.Column("int4", np.full(600000, 2, dtype=np.int32))])
+    src = GpuPreAgg(spec).begin_hashed()
+    dst = GpuPreAgg(spec).begin_hashed()
+    try:
+        assert src.fold(small)[0] == 0
+        dst.merge_from(src)                      # the table is made here
+        assert dst.num_groups() == len(np.unique(small_k))
+        assert dst.fold(many)[0] == 0
+        pr = dst.fetch()
+    finally:
+        src.end()
+        dst.end()
+    assert len(pr) == len(np.unique(np.concatenate([small_k, many_k])))
+    assert int(pr.column(1)[0].sum()) == 620000 and int(pr.column(2)[0].sum()) == 20000 + 2 * 600000
