@@ -726,8 +726,8 @@ gpupreagg_writeback_status(cl_int *status, cl_int chunk_status)
 struct gpupreagg_pack_ctl {
 	cl_uint		count_shift;					/* count field: bits count_shift .. 63 */
 	cl_uint		nwords;							/* 1 (the packed word) + float8 sums */
-	cl_uint		epoch_tiles;					/* 0, or: tiles a work-group folds before it must flush word 0 */
-	cl_uint		__pad;
+	cl_uint		spill_at;						/* 0, or: a group whose count field reaches this moves to the slab */
+	cl_uint		count_limit;					/* spill_at != 0: the count field's largest value */
 	cl_uint		shift[GPUPREAGG_PACK_MAXAGGS];	/* kind 2: position of the field in word 0 */
 	cl_uint		word[GPUPREAGG_PACK_MAXAGGS];	/* kind 3: the aggregate's own word */
 	cl_ulong	mask[GPUPREAGG_PACK_MAXAGGS];	/* kind 2: field mask (after the shift) */
@@ -742,10 +742,40 @@ gpupreagg_pack_word_offset(cl_uint w, cl_uint G)
 	return w * gpupreagg_align16(8u * G);
 }
 
+/*
+ * a group's packed word V (the value right after the add that brought its count to spill_at)
+ * leaves LDS: V is subtracted from the word -- its fields only grow, so every field of the word
+ * is at least V's and nothing borrows -- and its count and sums are added to the work-group's
+ * own slab, which the kernel zeroed at its start (atomics: another thread may spill the same
+ * group a quarter field later).  Exactly one thread sees a count BECOME spill_at.
+ */
+STROM_DEVICE void
+gpupreagg_packed_spill(char *lds, const gpupreagg_pack_ctl *pk, char *slab, cl_uint slot, cl_ulong V, cl_uint G)
+{
+	__hip_atomic_fetch_add((cl_ulong *)lds + slot, (cl_ulong)0 - V, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+	cl_ulong	n = V >> pk->count_shift;
+#define X(aidx,kind,attno)																\
+	{																					\
+		char   *svals = slab + gpupreagg_image_offset(1 + aidx, G, 1);					\
+		if (kind == 1)																	\
+			__hip_atomic_fetch_add((cl_uint *)svals + slot, (cl_uint)n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);	\
+		else if (kind == 2)																\
+			__hip_atomic_fetch_add((cl_ulong *)svals + slot,							\
+								   ((V >> pk->shift[aidx]) & pk->mask[aidx]) + n * (cl_ulong)pk->bias[aidx],	\
+								   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);			\
+	}
+	GPUPREAGG_PACK_LIST(X)
+#undef X
+	/* "rows of this group were seen": all the final store needs when no row follows */
+	__hip_atomic_store((gpupreagg_flags_t *)slab + slot, (gpupreagg_flags_t)GPUPREAGG_FLAG_SEEN,
+					   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 STROM_DEVICE void
 gpupreagg_packed_row(char *lds, const gpupreagg_dense_ctl *ctl, const gpupreagg_pack_ctl *pk,
 					 const strom_kparams &KP, const strom_kvars &KV,
-					 cl_uint gid_lo, cl_uint G, cl_int param_error, cl_int *chunk_status, bool qual_done = false)
+					 cl_uint gid_lo, cl_uint G, cl_int param_error, cl_int *chunk_status, char *slab,
+					 bool qual_done = false)
 {
 	cl_int		errcode = param_error;
 	cl_uint		gid = 0;
@@ -800,7 +830,25 @@ gpupreagg_packed_row(char *lds, const gpupreagg_dense_ctl *ctl, const gpupreagg_
 		STROM_SET_ERROR(chunk_status, StromError_DataStoreCorruption);
 		return;
 	}
-	__hip_atomic_fetch_add((cl_ulong *)lds + slot, addend, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+	if (pk->spill_at == 0)			/* (uniform) the fields hold every row the work-group folds */
+		__hip_atomic_fetch_add((cl_ulong *)lds + slot, addend, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+	else
+	{
+		/*
+		 * narrow fields (count + sums of the work-group's rows would need more than 64 bits):
+		 * the add returns what it was added to.  The ONE add that takes a group's count to
+		 * spill_at -- a quarter of the field -- moves the group's word to the slab
+		 * (gpupreagg_packed_spill); three quarters of the field are the margin for the adds
+		 * that land in between.  Should the field fill up all the same, the chunk goes back
+		 * (never a wrong sum).
+		 */
+		cl_ulong	old = __hip_atomic_fetch_add((cl_ulong *)lds + slot, addend, __ATOMIC_RELAXED,
+												 __HIP_MEMORY_SCOPE_WORKGROUP);
+		cl_uint		n = (cl_uint)(old >> pk->count_shift) + 1u;
+		STROM_SET_RECHECK_IF(chunk_status, n >= pk->count_limit);
+		if (n == pk->spill_at)
+			gpupreagg_packed_spill(lds, pk, slab, slot, old + addend, G);
+	}
 #define X(aidx,kind,attno)															\
 	if (kind == 3)																	\
 		__hip_atomic_fetch_add((cl_double *)(lds + gpupreagg_pack_word_offset(pk->word[aidx], G)) + slot,	\
@@ -813,17 +861,30 @@ gpupreagg_packed_row(char *lds, const gpupreagg_dense_ctl *ctl, const gpupreagg_
 /*
  * Unpack the work-group's LDS image into its slab of the standard shape.
  *
- * When the fields are too narrow for all the rows a work-group folds in the
- * chunk (the host then sets pk->epoch_tiles), the work-group folds in epochs:
- * after epoch_tiles tiles it moves word 0 -- count and integer sums -- to the
- * slab (FLUSH: the first time a plain store, afterwards an addition to what
- * the slab holds) and clears it.  The float8 words cannot run over and stay
- * in LDS until the last store.  The slab belongs to this work-group alone, so
- * the additions are plain loads and stores.
+ * spilled: the fields were too narrow for all the rows a work-group folds in the chunk
+ * (pk->spill_at != 0) -- the slab's count / integer-sum sections and flags were zeroed by
+ * gpupreagg_packed_slab_zero at the start of the kernel and hold what gpupreagg_packed_spill
+ * moved out of LDS; what is left in LDS is added to it.  (Read with agent-scope atomic loads:
+ * the spills were atomics at the L2, this CU's L1 may still hold the zeroes.)
  */
-template <bool FLUSH>
 STROM_DEVICE void
-gpupreagg_store_slab_packed(char *lds, const gpupreagg_pack_ctl *pk, char *slab, cl_uint G, bool accumulate)
+gpupreagg_packed_slab_zero(const gpupreagg_pack_ctl *pk, char *slab, cl_uint G)
+{
+	for (cl_uint g = threadIdx.x; g < G; g += GPUPREAGG_BLOCK)
+	{
+		((gpupreagg_flags_t *)slab)[g] = (gpupreagg_flags_t)0u;
+#define X(aidx,kind,attno)																\
+		if (kind == 1)																	\
+			((cl_uint *)(slab + gpupreagg_image_offset(1 + aidx, G, 1)))[g] = 0u;		\
+		else if (kind == 2)																\
+			((cl_ulong *)(slab + gpupreagg_image_offset(1 + aidx, G, 1)))[g] = 0UL;
+		GPUPREAGG_PACK_LIST(X)
+#undef X
+	}
+}
+
+STROM_DEVICE void
+gpupreagg_store_slab_packed(char *lds, const gpupreagg_pack_ctl *pk, char *slab, cl_uint G, bool spilled)
 {
 	__syncthreads();
 	for (cl_uint g = threadIdx.x; g < G; g += GPUPREAGG_BLOCK)
@@ -831,41 +892,35 @@ gpupreagg_store_slab_packed(char *lds, const gpupreagg_pack_ctl *pk, char *slab,
 		cl_ulong	w0 = ((const cl_ulong *)lds)[g];
 		cl_ulong	n = w0 >> pk->count_shift;
 		cl_uint		flags = 0;
-		if (FLUSH)
-		{
-			((cl_ulong *)lds)[g] = 0;
-			if (accumulate && n == 0)
-				continue;
-		}
+		bool		seen = (n != 0);
+		if (spilled)
+			seen = seen || (__hip_atomic_load((gpupreagg_flags_t *)slab + g, __ATOMIC_RELAXED,
+											  __HIP_MEMORY_SCOPE_AGENT) != 0);
 #define X(aidx,kind,attno)																\
 		{																				\
 			char   *svals = slab + gpupreagg_image_offset(1 + aidx, G, 1);				\
 			if (kind == 1)																\
-				((cl_uint *)svals)[g] = (cl_uint)n + (accumulate ? ((cl_uint *)svals)[g] : 0u);	\
+				((cl_uint *)svals)[g] = (cl_uint)n +									\
+					(spilled ? __hip_atomic_load((cl_uint *)svals + g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u);	\
 			else if (kind == 2)															\
 			{																			\
 				cl_ulong f = (w0 >> pk->shift[aidx]) & pk->mask[aidx];					\
 				((cl_long *)svals)[g] = (cl_long)f + (cl_long)n * pk->bias[aidx]		\
-					+ (accumulate ? ((cl_long *)svals)[g] : 0L);						\
+					+ (spilled ? (cl_long)__hip_atomic_load((cl_ulong *)svals + g, __ATOMIC_RELAXED,	\
+															__HIP_MEMORY_SCOPE_AGENT) : 0L);	\
 				flags |= (2u << aidx);													\
 			}																			\
 			else																		\
 			{																			\
-				if (!FLUSH)																\
-					((cl_ulong *)svals)[g] =											\
-						((const cl_ulong *)(lds + gpupreagg_pack_word_offset(pk->word[aidx], G)))[g];	\
+				((cl_ulong *)svals)[g] =												\
+					((const cl_ulong *)(lds + gpupreagg_pack_word_offset(pk->word[aidx], G)))[g];	\
 				flags |= (2u << aidx);													\
 			}																			\
 		}
 		GPUPREAGG_PACK_LIST(X)
 #undef X
-		if (n != 0)
-			((gpupreagg_flags_t *)slab)[g] = (gpupreagg_flags_t)(flags | GPUPREAGG_FLAG_SEEN);
-		else if (!accumulate)
-			((gpupreagg_flags_t *)slab)[g] = (gpupreagg_flags_t)0u;
+		((gpupreagg_flags_t *)slab)[g] = (gpupreagg_flags_t)(seen ? (flags | GPUPREAGG_FLAG_SEEN) : 0u);
 	}
-	if (FLUSH)
-		__syncthreads();
 }
 #endif	/* GPUPREAGG_PACKABLE */
 
@@ -979,26 +1034,18 @@ gpupreagg_dense_column_body(kern_gpupreagg *kgpreagg,
 	STROM_KVAR_LIST(X)
 #undef X
 
-	bool		flushed = false;
+	char	   *my_slab = slabs + (size_t)(wg_in_split * nsplits + split) * ctl->slab_bytes;
 #if defined(GPUPREAGG_PACKABLE) && GPUPREAGG_PACKABLE
-	cl_uint		epoch_left = (PACKED ? pk->epoch_tiles : 0u);
+	if (PACKED && pk->spill_at != 0)
+	{
+		/* narrow fields: groups move to the slab as their counts fill up (gpupreagg_packed_spill) */
+		gpupreagg_packed_slab_zero(pk, my_slab, G);
+		__syncthreads();
+	}
 #endif
 	for (cl_uint tile = wg_in_split; tile < ntiles; tile += wgs_per_split)
 	{
 		cl_uint		tile_base = tile * GPUPREAGG_TILE_ROWS;
-#if defined(GPUPREAGG_PACKABLE) && GPUPREAGG_PACKABLE
-		if (PACKED && pk->epoch_tiles != 0)
-		{
-			/* (uniform over the work-group: every thread counts the same tiles) */
-			if (epoch_left == 0)
-			{
-				gpupreagg_store_slab_packed<true>(lds, pk, slabs + (size_t)(wg_in_split * nsplits + split) * ctl->slab_bytes, G, flushed);
-				flushed = true;
-				epoch_left = pk->epoch_tiles;
-			}
-			epoch_left--;
-		}
-#endif
 		bool		full_tile = (tile_base + GPUPREAGG_TILE_ROWS <= nitems);
 		gpupreagg_column_tile T;
 
@@ -1077,7 +1124,7 @@ gpupreagg_dense_column_body(kern_gpupreagg *kgpreagg,
 					KV.__dummy = 0;
 #if defined(GPUPREAGG_PACKABLE) && GPUPREAGG_PACKABLE
 					if (PACKED)
-						gpupreagg_packed_row(lds, ctl, pk, KP, KV, gid_lo, G, param_error, &chunk_status);
+						gpupreagg_packed_row(lds, ctl, pk, KP, KV, gid_lo, G, param_error, &chunk_status, my_slab);
 					else
 #endif
 						gpupreagg_dense_row(lds, ctl, L, KP, KV, gid_lo, G, NREP, rep,
@@ -1088,11 +1135,10 @@ gpupreagg_dense_column_body(kern_gpupreagg *kgpreagg,
 	}
 #if defined(GPUPREAGG_PACKABLE) && GPUPREAGG_PACKABLE
 	if (PACKED)
-		gpupreagg_store_slab_packed<false>(lds, pk, slabs + (size_t)(wg_in_split * nsplits + split) * ctl->slab_bytes,
-										   G, flushed);
+		gpupreagg_store_slab_packed(lds, pk, my_slab, G, pk->spill_at != 0);
 	else
 #endif
-		gpupreagg_store_slab(lds, L, slabs + (size_t)(wg_in_split * nsplits + split) * ctl->slab_bytes, G, NREP, &chunk_status);
+		gpupreagg_store_slab(lds, L, my_slab, G, NREP, &chunk_status);
 	gpupreagg_writeback_status(&kgpreagg->status, chunk_status);
 	gpupreagg_writeback_summag(kgpreagg, summag);
 }
@@ -1505,29 +1551,25 @@ gpupreagg_dense_lookup_body(kern_gpupreagg *kgpreagg,
 	STROM_KVAR_LIST(X)
 #undef X
 	const bool	qual_first = ((GPUPREAGG_QUAL_VARMASK & inner_mask) == 0 && GPUPREAGG_QUAL_VARMASK != 0);
+	bool		any_nulls = (keynulls != NULL);		/* wave-uniform: picks the bitmap-free loader */
+#define X(attno,colidx,NAME)	any_nulls = any_nulls || (nul_##attno != NULL);
+	STROM_KVAR_LIST(X)
+#undef X
 	cl_long		key_min = jmap->key_min;
 	cl_uint		nslots = jmap->nslots;
 
-	bool		flushed = false;
+	char	   *my_slab = slabs + (size_t)blockIdx.x * ctl->slab_bytes;
 #if defined(GPUPREAGG_PACKABLE) && GPUPREAGG_PACKABLE
-	cl_uint		epoch_left = (PACKED ? pk->epoch_tiles : 0u);
+	if (PACKED && pk->spill_at != 0)
+	{
+		/* narrow fields: groups move to the slab as their counts fill up (gpupreagg_packed_spill) */
+		gpupreagg_packed_slab_zero(pk, my_slab, G);
+		__syncthreads();
+	}
 #endif
 	for (cl_uint tile = wg_in_split; tile < ntiles; tile += wgs_per_split)
 	{
 		cl_uint		tile_base = tile * GPUPREAGG_TILE_ROWS;
-#if defined(GPUPREAGG_PACKABLE) && GPUPREAGG_PACKABLE
-		if (PACKED && pk->epoch_tiles != 0)
-		{
-			/* (uniform over the work-group: every thread counts the same tiles) */
-			if (epoch_left == 0)
-			{
-				gpupreagg_store_slab_packed<true>(lds, pk, slabs + (size_t)blockIdx.x * ctl->slab_bytes, G, flushed);
-				flushed = true;
-				epoch_left = pk->epoch_tiles;
-			}
-			epoch_left--;
-		}
-#endif
 		bool		full_tile = (tile_base + GPUPREAGG_TILE_ROWS <= nitems);
 		gpupreagg_column_tile T;
 		KEY_T		keyq[GPUPREAGG_QUADS][4];
@@ -1537,7 +1579,19 @@ gpupreagg_dense_lookup_body(kern_gpupreagg *kgpreagg,
 		for (int k = 0; k < GPUPREAGG_QUADS; k++)
 		{
 			cl_uint	row0 = tile_base + (k * GPUPREAGG_BLOCK + threadIdx.x) * 4;
-			if (full_tile)
+			if (full_tile && !any_nulls)
+			{
+				/* no column of the chunk has a NULL bitmap: no bitmap words are fetched (one
+				 * request per quad and column otherwise, in a kernel bound by requests) */
+				strom_column_load_quad<KEY_T, true, true>(keyvals, keynulls, row0, nitems, keyq[k], keynn[k]);
+#define X(attno,colidx,NAME)													\
+				if (!inner_##attno)												\
+					strom_column_load_quad<pg_##NAME##_base_t, true, true>(val_##attno, (const cl_uint *)nul_##attno,	\
+															   row0, nitems, T.v_##attno[k], T.nn_##attno[k]);
+				STROM_KVAR_LIST(X)
+#undef X
+			}
+			else if (full_tile)
 			{
 				strom_column_load_quad<KEY_T, true>(keyvals, keynulls, row0, nitems, keyq[k], keynn[k]);
 #define X(attno,colidx,NAME)													\
@@ -1699,7 +1753,7 @@ gpupreagg_dense_lookup_body(kern_gpupreagg *kgpreagg,
 #endif
 #if defined(GPUPREAGG_PACKABLE) && GPUPREAGG_PACKABLE
 					if (PACKED)
-						gpupreagg_packed_row(lds, ctl, pk, KP, KV, gid_lo, G, param_error, &chunk_status,
+						gpupreagg_packed_row(lds, ctl, pk, KP, KV, gid_lo, G, param_error, &chunk_status, my_slab,
 											 (qual_ok[k] >> j) & 1);
 					else
 #endif
@@ -1711,10 +1765,10 @@ gpupreagg_dense_lookup_body(kern_gpupreagg *kgpreagg,
 	}
 #if defined(GPUPREAGG_PACKABLE) && GPUPREAGG_PACKABLE
 	if (PACKED)
-		gpupreagg_store_slab_packed<false>(lds, pk, slabs + (size_t)blockIdx.x * ctl->slab_bytes, G, flushed);
+		gpupreagg_store_slab_packed(lds, pk, my_slab, G, pk->spill_at != 0);
 	else
 #endif
-		gpupreagg_store_slab(lds, L, slabs + (size_t)blockIdx.x * ctl->slab_bytes, G, NREP, &chunk_status);
+		gpupreagg_store_slab(lds, L, my_slab, G, NREP, &chunk_status);
 	gpupreagg_writeback_status(&kgpreagg->status, chunk_status);
 	gpupreagg_writeback_summag(kgpreagg, summag);
 }

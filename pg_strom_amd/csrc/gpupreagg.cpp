@@ -374,8 +374,8 @@ struct joined_map_image {
 struct pack_ctl {
 	cl_uint		count_shift;
 	cl_uint		nwords;
-	cl_uint		epoch_tiles;
-	cl_uint		__pad;
+	cl_uint		spill_at;
+	cl_uint		count_limit;
 	cl_uint		shift[32];
 	cl_uint		word[32];
 	cl_ulong	mask[32];
@@ -460,10 +460,14 @@ packed_plan(strom_gpupreagg *sess, hipFunction_t fn_packed, const kern_coldir *c
 	size_t		wgs_per_split = wgs / nsplits;
 	cl_ulong	rows_per_wg = (cl_ulong)((ntiles + wgs_per_split - 1) / wgs_per_split) * tile_rows;
 	/*
-	 * count field: wide enough for every row the work-group may fold -- or, when
-	 * the sums do not leave that much room, for an EPOCH of tiles after which the
-	 * work-group moves word 0 to its slab and starts over (strom_gpupreagg.h:
-	 * gpupreagg_store_slab_packed).  An epoch shorter than 4 tiles is not worth it.
+	 * count field: wide enough for every row the work-group may fold -- or, when the sums do not
+	 * leave that much room, NARROW: the fold then adds with the returning atomic and moves a group
+	 * to the slab when its count reaches a quarter of the field (strom_gpupreagg.h:
+	 * gpupreagg_packed_spill; three quarters of the field are the margin for the adds in flight, so
+	 * the field must hold a few tiles' worth of rows).  Uniform keys never get there: 1e4 groups
+	 * share the 4e5 rows of a work-group.  (Round 2 flushed the whole table every few tiles
+	 * instead -- "epochs": 0.7 GB of extra slab traffic per 1e8 rows and two barriers in the tile
+	 * loop, whatever the key distribution.)
 	 */
 	int			vbits = 0, nsums = 0;
 	for (cl_uint a = 0; a < naggs; a++)
@@ -477,22 +481,22 @@ packed_plan(strom_gpupreagg *sess, hipFunction_t fn_packed, const kern_coldir *c
 	if (vbits >= 64)
 		return nullptr;
 	int			cbits = bits_for(rows_per_wg);
-	cl_uint		epoch_tiles = 0;
-	const char *cap = getenv("STROM_GPUPREAGG_PACK_COUNT_BITS");	/* tests: short epochs on small inputs */
+	cl_uint		spill_at = 0, count_limit = 0;
+	const char *cap = getenv("STROM_GPUPREAGG_PACK_COUNT_BITS");	/* tests: narrow fields on small inputs */
 	int			cap_bits = (cap ? atoi(cap) : 0);
 	if (vbits + (nsums + 1) * cbits > 64 || (cap_bits > 0 && cap_bits < cbits))
 	{
 		cbits = (64 - vbits) / (nsums + 1);
 		if (cap_bits > 0)
 			cbits = std::min(cbits, cap_bits);
-		if (cbits < 1 || cbits > 40 || getenv("STROM_GPUPREAGG_NO_EPOCHS"))
+		/* 2^cbits rows: at least 4 tiles (a quarter to get there, three for the adds in flight) */
+		if (cbits > 31 || (1UL << cbits) < 4 * tile_rows || getenv("STROM_GPUPREAGG_NO_SPILL"))
 			return nullptr;
-		cl_ulong	tiles = ((1UL << cbits) - 1) / tile_rows;
-		if (tiles < (cap_bits > 0 ? 1u : 4u))
-			return nullptr;
-		epoch_tiles = (cl_uint)std::min<cl_ulong>(tiles, 0x7fffffffUL);
+		spill_at = 1u << (cbits - 2);
+		count_limit = (1u << cbits) - 1;
 	}
-	pk->epoch_tiles = epoch_tiles;
+	pk->spill_at = spill_at;
+	pk->count_limit = count_limit;
 	int			pos = 0;
 	for (cl_uint a = 0; a < naggs; a++)
 	{

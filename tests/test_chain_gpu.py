@@ -399,12 +399,15 @@ def test_join_as_a_lookup_with_packed_accumulators(epochs, narrow, monkeypatch):
     hashjoin_dimrec_narrow_kernel) instead of 8 -- same answers either way.
     1e4 groups, summed OUTER columns without NULLs: the lookup aggregate takes the packed
     LDS image (gpupreagg_packed_lookup, one id-range role instead of two); the grouping key
-    is an inner column with NULLs, rows without a partner are dropped.  epochs: a 31-bit
-    value range and enough rows that the packed word is moved to the slab between epochs."""
+    is an inner column with NULLs, rows without a partner are dropped.  epochs (the name of
+    round 2's mechanism): a 31-bit value range next to the count does not fit the packed word
+    for all rows of a work-group -- narrow fields (capped at 15 bits here), returning LDS adds,
+    and most of the fact rows point at ONE dimension row, so that group's word is moved to the
+    slab again and again while the fold runs (gpupreagg_packed_spill)."""
     runtime.init()
-    n, nd, ngroups = (2_500_003 if epochs else 300007), 40000, 10000
+    n, nd, ngroups = (16_000_003 if epochs else 300007), 40000, 10000
     if epochs:
-        monkeypatch.setenv("STROM_GPUPREAGG_PACK_COUNT_BITS", "14")
+        monkeypatch.setenv("STROM_GPUPREAGG_PACK_COUNT_BITS", "15")
     if not narrow:
         monkeypatch.setenv("STROM_HASHJOIN_NO_NARROW_RECS", "1")
     rng = np.random.default_rng(97)
@@ -417,6 +420,9 @@ def test_join_as_a_lookup_with_packed_accumulators(epochs, narrow, monkeypatch):
     dgrp = (dkey % ngroups).astype(np.int32)
     dgn = rng.random(nd) < 0.02
     inner = kds.build_kds("row_flat", [kds.Column("int4", dkey), kds.Column("int4", dgrp, dgn)])
+    if epochs:
+        fk[rng.random(n) < 0.6] = dkey[np.flatnonzero(~dgn)[0]]        # the hot group: ~14000 surviving rows per work-group
+    fact = kds.build_kds("column", [kds.Column("int4", fk), kds.Column("int4", a), kds.Column("float8", b)])
     km = build_multihash([(inner, [1])])
     ext = [np.int32(2**30 if epochs else 2**19), 0.25]
     ds = runtime.DeviceStore.upload(fact)

@@ -296,14 +296,23 @@ def test_packed_accumulators_with_qual_two_keys_and_wide_values():
     assert pfms[0]["num_kern_prep"] == 0
 
 
-def test_packed_accumulators_fold_in_epochs_when_the_fields_are_narrow(monkeypatch):
+@pytest.mark.parametrize("hot", [0.0, 0.4])
+def test_packed_accumulators_spill_groups_when_the_fields_are_narrow(monkeypatch, hot):
     """the sum of a full-range int4 column next to the count needs more than 64 bits for all the
-    rows of a work-group: the work-group folds in epochs and moves the packed word to its slab
-    in between (gpupreagg_store_slab_packed<true>).  Forced on a small input by capping the
-    count field at 14 bits = one 8192-row tile per epoch; several tiles per work-group."""
-    monkeypatch.setenv("STROM_GPUPREAGG_PACK_COUNT_BITS", "14")
-    bufs = [kds.build_kds("column", c4_table(3_000_017, 51 + i, 10000, xlo=-2**31, xhi=2**31 - 1))
-            for i in range(2)]
+    rows of a work-group: narrow fields, the adds return the old word, and the add that brings a
+    group's count to a quarter of its field moves the group to the slab (gpupreagg_packed_spill).
+    Forced on a modest input by capping the count field at 15 bits (spill at 8192 rows).
+    hot = 0: uniform keys, no group ever gets there -- the fold costs what the wide fields cost;
+    hot = 0.4: one group holds 40 % of the rows, ~30000 per work-group: it is moved out three
+    or four times per work-group while the others keep adding to it."""
+    monkeypatch.setenv("STROM_GPUPREAGG_PACK_COUNT_BITS", "15")
+    bufs = []
+    for i in range(2):
+        cols = c4_table(20_000_003 if i == 0 else 1_000_003, 51 + i, 10000, xlo=-2**31, xhi=2**31 - 1)
+        if hot:
+            g = cols[0].values
+            g[np.random.default_rng(7 + i).random(len(g)) < hot] = 4242
+        bufs.append(kds.build_kds("column", cols))
     pfms = []
     compare_with_oracle(C4_SPEC, bufs, [(0, 10000)], resident=True, pfms=pfms)
     assert all(p["num_kern_prep"] == 1 for p in pfms)
