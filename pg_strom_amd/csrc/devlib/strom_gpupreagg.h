@@ -1143,6 +1143,7 @@ gpupreagg_dense_column_body(kern_gpupreagg *kgpreagg,
 	gpupreagg_writeback_summag(kgpreagg, summag);
 }
 
+#if !defined(GPUPREAGG_LOOKUP_ONLY)
 extern "C" __global__ void
 __launch_bounds__(GPUPREAGG_BLOCK)
 gpupreagg_dense_column(kern_gpupreagg *kgpreagg,
@@ -1152,8 +1153,10 @@ gpupreagg_dense_column(kern_gpupreagg *kgpreagg,
 {
 	gpupreagg_dense_column_body<false>(kgpreagg, kds, ctl_in_memory, NULL, slabs);
 }
+#endif	/* !GPUPREAGG_LOOKUP_ONLY */
 
 #if defined(GPUPREAGG_PACKABLE) && GPUPREAGG_PACKABLE
+#if !defined(GPUPREAGG_LOOKUP_ONLY)
 extern "C" __global__ void
 __launch_bounds__(GPUPREAGG_BLOCK)
 gpupreagg_packed_column(kern_gpupreagg *kgpreagg,
@@ -1164,6 +1167,7 @@ gpupreagg_packed_column(kern_gpupreagg *kgpreagg,
 {
 	gpupreagg_dense_column_body<true>(kgpreagg, kds, ctl_in_memory, pack_in_memory, slabs);
 }
+#endif	/* !GPUPREAGG_LOOKUP_ONLY */
 #endif
 
 /* ====================================================================== *
@@ -1237,6 +1241,7 @@ gpupreagg_dense_generic_body(kern_gpupreagg *kgpreagg,
 	gpupreagg_writeback_summag(kgpreagg, summag);
 }
 
+#if !defined(GPUPREAGG_LOOKUP_ONLY)
 extern "C" __global__ void
 __launch_bounds__(GPUPREAGG_BLOCK)
 gpupreagg_dense_generic(kern_gpupreagg *kgpreagg,
@@ -1256,6 +1261,7 @@ gpupreagg_dense_generic(kern_gpupreagg *kgpreagg,
 	else
 		gpupreagg_dense_generic_body<false>(kgpreagg, kds, ktoast, krowmap, ctl, slabs, lds);
 }
+#endif	/* !GPUPREAGG_LOOKUP_ONLY */
 
 /* ====================================================================== *
  * dense-id reduction straight over a GpuHashJoin's result pairs
@@ -1294,6 +1300,7 @@ struct gpupreagg_joined_map {
 	cl_long		nmin[64];
 };
 
+#if !defined(GPUPREAGG_LOOKUP_ONLY)
 extern "C" __global__ void
 __launch_bounds__(GPUPREAGG_BLOCK)
 gpupreagg_dense_joined(kern_gpupreagg *kgpreagg,
@@ -1441,6 +1448,7 @@ gpupreagg_dense_joined(kern_gpupreagg *kgpreagg,
 	gpupreagg_writeback_status(&kgpreagg->status, chunk_status);
 	gpupreagg_writeback_summag(kgpreagg, summag);
 }
+#endif	/* !GPUPREAGG_LOOKUP_ONLY */
 
 /* ====================================================================== *
  * join lookup + dense-id reduction in ONE pass over the outer chunk
@@ -1518,25 +1526,50 @@ gpupreagg_dense_lookup_body(kern_gpupreagg *kgpreagg,
 		gpupreagg_lds_layout_init(L, G, NREP);
 		gpupreagg_lds_init(lds, L, G, NREP);
 	}
-	/* (all of this is uniform: strom_uniform keeps it in scalar registers) */
+	/*
+	 * Which virtual column is an inner one, how long a slot record is and whether it is the
+	 * narrow form are facts of the request (the column mapping, the table) -- as run-time values
+	 * they were ~40 scalar registers per kernel (spilled into VGPR lanes), a maze of scalar
+	 * branches around the record decode with a full s_waitcnt at every join, and flat loads.
+	 * The host therefore builds the program FOR the mapping (GPUPREAGG_LOOKUP_INNER_MASK / _RECLEN
+	 * / _NARROW / _KEYLEN: compile-time constants, gpupreagg.cpp: lookup_program) and the compiler
+	 * keeps one straight path; without those defines the same code reads the values from the
+	 * map (any mapping, no build).
+	 */
+#if defined(GPUPREAGG_LOOKUP_INNER_MASK)
+#define LOOKUP_INNER(colidx)	((((GPUPREAGG_LOOKUP_INNER_MASK) >> (colidx)) & 1UL) != 0)
+	/* (pointers computed from kernel arguments and scalar loads ARE uniform, and keep their
+	 * address space: through strom_uniform's readfirstlane they come back as flat pointers) */
+#define LOOKUP_PTR(x)			(x)
+#else
+#define LOOKUP_INNER(colidx)	(strom_uniform((cl_int)jmap->c[colidx].depth) != 0)
+#define LOOKUP_PTR(x)			strom_uniform(x)
+#endif
+	/* (the slot records are global memory: said so, the loads are global_load, not flat_load) */
+#define LOOKUP_GLOBAL(T, p)		(*(const __attribute__((address_space(1))) T *)(p))
 #define X(attno,colidx,NAME)													\
-	const bool	inner_##attno = (strom_uniform((cl_int)jmap->c[colidx].depth) != 0);	\
+	const bool	inner_##attno = LOOKUP_INNER(colidx);								\
 	const cl_uint recoff_##attno = strom_uniform((cl_uint)jmap->c[colidx].dimvalues);	\
 	const cl_uint recbit_##attno = strom_uniform((cl_uint)jmap->c[colidx].dimisnull);	\
-	const char *val_##attno = strom_uniform(inner_##attno ? (const char *)NULL		\
+	const char *val_##attno = LOOKUP_PTR(inner_##attno ? (const char *)NULL		\
 							   : (const char *)kds + coldir[jmap->c[colidx].col].values_off);	\
-	const char *nul_##attno = strom_uniform(inner_##attno ? (const char *)NULL		\
+	const char *nul_##attno = LOOKUP_PTR(inner_##attno ? (const char *)NULL		\
 							   : (coldir[jmap->c[colidx].col].nulls_off != 0		\
 								  ? (const char *)kds + coldir[jmap->c[colidx].col].nulls_off : (const char *)NULL));
 	STROM_KVAR_LIST(X)
 #undef X
-	const char *keyvals = strom_uniform((const char *)kds + coldir[jmap->key_col].values_off);
-	const cl_uint *keynulls = strom_uniform(coldir[jmap->key_col].nulls_off != 0
+	const char *keyvals = LOOKUP_PTR((const char *)kds + coldir[jmap->key_col].values_off);
+	const cl_uint *keynulls = LOOKUP_PTR(coldir[jmap->key_col].nulls_off != 0
 							   ? (const cl_uint *)((const char *)kds + coldir[jmap->key_col].nulls_off)
 							   : (const cl_uint *)NULL);
-	const char *recs = strom_uniform((const char *)jmap->recs);
+	const char *recs = LOOKUP_PTR((const char *)jmap->recs);
+#if defined(GPUPREAGG_LOOKUP_INNER_MASK)
+	const cl_uint reclen = GPUPREAGG_LOOKUP_RECLEN;
+	const bool	narrow = (GPUPREAGG_LOOKUP_NARROW != 0);
+#else
 	cl_uint		reclen = strom_uniform((cl_uint)jmap->reclen);
 	const bool	narrow = (strom_uniform((cl_uint)jmap->narrow) != 0);
+#endif
 #define X(attno,colidx,NAME)													\
 	const cl_uint nshift_##attno = strom_uniform((cl_uint)jmap->nshift[colidx]);	\
 	const cl_uint nmask_##attno = strom_uniform((cl_uint)jmap->nmask[colidx]);	\
@@ -1675,24 +1708,24 @@ gpupreagg_dense_lookup_body(kern_gpupreagg *kgpreagg,
 				if (narrow)
 				{
 					/* 2- or 4-byte record: flags and value fields in one word */
-					words[j][0] = (reclen == 2 ? (cl_uint)*(const cl_ushort *)rec : *(const cl_uint *)rec);
+					words[j][0] = (reclen == 2 ? (cl_uint)LOOKUP_GLOBAL(cl_ushort, rec) : LOOKUP_GLOBAL(cl_uint, rec));
 					words[j][1] = words[j][2] = words[j][3] = 0;
 				}
 				else if (reclen == 8)
 				{
-					cl_ulong w = *(const cl_ulong *)rec;
+					cl_ulong w = LOOKUP_GLOBAL(cl_ulong, rec);
 					words[j][0] = (cl_uint)w;
 					words[j][1] = (cl_uint)(w >> 32);
 					words[j][2] = words[j][3] = 0;
 				}
 				else if (reclen == 16)
 				{
-					uint4 q = *(const uint4 *)rec;
+					uint4 q = LOOKUP_GLOBAL(uint4, rec);
 					words[j][0] = q.x; words[j][1] = q.y; words[j][2] = q.z; words[j][3] = q.w;
 				}
 				else
 				{
-					words[j][0] = *(const cl_uint *)rec;
+					words[j][0] = LOOKUP_GLOBAL(cl_uint, rec);
 					words[j][1] = words[j][2] = words[j][3] = 0;
 				}
 				flags[j] = words[j][0];
@@ -1785,10 +1818,16 @@ gpupreagg_dense_lookup(kern_gpupreagg *kgpreagg,
 	/* the control block by value (see gpupreagg_dense_column) */
 	const gpupreagg_dense_ctl ctl_by_value = *ctl_in_memory;
 	const gpupreagg_dense_ctl *ctl = &ctl_by_value;
+#if defined(GPUPREAGG_LOOKUP_KEYLEN) && GPUPREAGG_LOOKUP_KEYLEN == 8
+	gpupreagg_dense_lookup_body<cl_long, false>(kgpreagg, kds, jmap, ctl, NULL, slabs, lds);
+#elif defined(GPUPREAGG_LOOKUP_KEYLEN)
+	gpupreagg_dense_lookup_body<cl_int, false>(kgpreagg, kds, jmap, ctl, NULL, slabs, lds);
+#else
 	if (jmap->key_attlen == 8)
 		gpupreagg_dense_lookup_body<cl_long, false>(kgpreagg, kds, jmap, ctl, NULL, slabs, lds);
 	else
 		gpupreagg_dense_lookup_body<cl_int, false>(kgpreagg, kds, jmap, ctl, NULL, slabs, lds);
+#endif
 }
 
 #if defined(GPUPREAGG_PACKABLE) && GPUPREAGG_PACKABLE
@@ -1806,10 +1845,16 @@ gpupreagg_packed_lookup(kern_gpupreagg *kgpreagg,
 	extern __shared__ __attribute__((aligned(16))) char lds[];
 	const gpupreagg_dense_ctl ctl_by_value = *ctl_in_memory;
 	const gpupreagg_dense_ctl *ctl = &ctl_by_value;
+#if defined(GPUPREAGG_LOOKUP_KEYLEN) && GPUPREAGG_LOOKUP_KEYLEN == 8
+	gpupreagg_dense_lookup_body<cl_long, true>(kgpreagg, kds, jmap, ctl, pack_in_memory, slabs, lds);
+#elif defined(GPUPREAGG_LOOKUP_KEYLEN)
+	gpupreagg_dense_lookup_body<cl_int, true>(kgpreagg, kds, jmap, ctl, pack_in_memory, slabs, lds);
+#else
 	if (jmap->key_attlen == 8)
 		gpupreagg_dense_lookup_body<cl_long, true>(kgpreagg, kds, jmap, ctl, pack_in_memory, slabs, lds);
 	else
 		gpupreagg_dense_lookup_body<cl_int, true>(kgpreagg, kds, jmap, ctl, pack_in_memory, slabs, lds);
+#endif
 }
 #endif
 
@@ -2237,6 +2282,7 @@ gpupreagg_priv_row(char *lds, gpupreagg_priv_state &S, const gpupreagg_dense_ctl
 #undef X
 }
 
+#if !defined(GPUPREAGG_LOOKUP_ONLY)
 extern "C" __global__ void
 __launch_bounds__(GPUPREAGG_REG_BLOCK)
 gpupreagg_priv_column(kern_gpupreagg *kgpreagg, const kern_data_store *kds,
@@ -2464,7 +2510,9 @@ gpupreagg_priv_column(kern_gpupreagg *kgpreagg, const kern_data_store *kds,
 	gpupreagg_writeback_status(&kgpreagg->status, chunk_status);
 	gpupreagg_writeback_summag(kgpreagg, summag);
 }
+#endif	/* !GPUPREAGG_LOOKUP_ONLY */
 
+#if !defined(GPUPREAGG_LOOKUP_ONLY)
 extern "C" __global__ void
 __launch_bounds__(GPUPREAGG_REG_BLOCK)
 gpupreagg_reg1_column(kern_gpupreagg *kgpreagg, const kern_data_store *kds,
@@ -2476,6 +2524,7 @@ gpupreagg_reg1_column(kern_gpupreagg *kgpreagg, const kern_data_store *kds,
 	const gpupreagg_dense_ctl *ctl = &ctl_by_value;
 	gpupreagg_reg_kernel_body<1>(kgpreagg, kds, ctl, slabs, lds);
 }
+#endif	/* !GPUPREAGG_LOOKUP_ONLY */
 
 #endif	/* !GPUPREAGG_HASHED */
 
@@ -4391,6 +4440,7 @@ gpupreagg_census_body(const kern_gpupreagg *kgpreagg, const kern_data_store *kds
 	}
 }
 
+#if !defined(GPUPREAGG_LOOKUP_ONLY)
 extern "C" __global__ void
 __launch_bounds__(256)
 gpupreagg_census(const kern_gpupreagg *kgpreagg, const kern_data_store *kds,
@@ -4403,6 +4453,7 @@ gpupreagg_census(const kern_gpupreagg *kgpreagg, const kern_data_store *kds,
 	else
 		gpupreagg_census_body<false>(kgpreagg, kds, ktoast, krowmap, ctl, bitmap);
 }
+#endif	/* !GPUPREAGG_LOOKUP_ONLY */
 
 /* ====================================================================== *
  * key range of ONE chunk (after the qual): the dense domain of a request
@@ -4517,6 +4568,7 @@ gpupreagg_keyrange_body(const kern_gpupreagg *kgpreagg, const kern_data_store *k
 	}
 }
 
+#if !defined(GPUPREAGG_LOOKUP_ONLY)
 extern "C" __global__ void
 __launch_bounds__(256)
 gpupreagg_keyrange(const kern_gpupreagg *kgpreagg, const kern_data_store *kds,
@@ -4528,6 +4580,7 @@ gpupreagg_keyrange(const kern_gpupreagg *kgpreagg, const kern_data_store *kds,
 	else
 		gpupreagg_keyrange_body<false>(kgpreagg, kds, ktoast, krowmap, out);
 }
+#endif	/* !GPUPREAGG_LOOKUP_ONLY */
 
 /* ====================================================================== *
  * slabs -> resident table, fixed order; skipped when the chunk failed

@@ -118,6 +118,8 @@ struct strom_gpupreagg {
 	Program			   *prog_checked = nullptr;
 	std::atomic<cl_uint> checked_folds{0};	/* (reported: chunks that took the checked program) */
 	cl_uint				sum_turn = 0;		/* hashed: parity of the next fold (gpupreagg_hash_sum_account) */
+	/* join-as-a-lookup: the program built FOR a column mapping (lookup_program), by its defines */
+	std::map<std::string, std::pair<strom_devprog_key, Program *>> lookup_programs;	/* (lookup_mapping_program) */
 
 	/* mirrors gpupreagg_image_offset / gpupreagg_table_offset of
 	 * strom_gpupreagg.h: section 0 = flags, 1+a = values of aggregate a,
@@ -567,6 +569,7 @@ struct preagg_request {
 	const void		   *joined_results = nullptr;	/* device kern_resultbuf */
 	void			   *joined_buffer = nullptr;	/* the join's device image, owned by this request now */
 	bool				lookup = false;				/* no result pairs: the join is a lookup in the aggregate's pass */
+	Program			   *prog = nullptr;				/* lookup: the session's program built for this column mapping */
 	std::shared_ptr<std::vector<char>> joined_map;	/* host image of gpupreagg_joined_map */
 };
 
@@ -576,6 +579,41 @@ zone_magbits(const kern_coldir &cd)
 {
 	cl_long		lo = cd.minval, hi = cd.maxval;
 	return (cl_uint)bits_for((cl_ulong)(lo ^ (lo >> 63)) | (cl_ulong)(hi ^ (hi >> 63)));
+}
+
+/*
+ * join-as-a-lookup: the session's source built FOR a column mapping -- which virtual column is an
+ * inner one, the slot records' length and form, the key's width become compile-time constants
+ * (strom_gpupreagg.h: gpupreagg_dense_lookup_body says what that is worth), and only the lookup
+ * and merge kernels are built.  One program per distinct mapping, kept with the session; the first
+ * request of a mapping parks behind its build like any request behind a cold program.
+ */
+Program *
+lookup_mapping_program(strom_gpupreagg *sess, const joined_map_image *jm)
+{
+	if (getenv("STROM_GPUPREAGG_LOOKUP_GENERIC"))
+		return nullptr;						/* the run-time form: any mapping, no build */
+	cl_ulong	inner_mask = 0;
+	for (cl_uint i = 0; i < jm->ncols && i < 64; i++)
+		if (jm->c[i].depth != 0)
+			inner_mask |= (1UL << i);
+	char		defs[512];
+	snprintf(defs, sizeof(defs),
+			 "#define GPUPREAGG_LOOKUP_ONLY 1\n#define GPUPREAGG_LOOKUP_INNER_MASK 0x%lxUL\n"
+			 "#define GPUPREAGG_LOOKUP_RECLEN %u\n#define GPUPREAGG_LOOKUP_NARROW %u\n"
+			 "#define GPUPREAGG_LOOKUP_KEYLEN %d\n",
+			 (unsigned long)inner_mask, jm->reclen, jm->narrow ? 1u : 0u, jm->key_attlen);
+	std::lock_guard<std::mutex> g(sess->lock);
+	auto	it = sess->lookup_programs.find(defs);
+	if (it != sess->lookup_programs.end())
+		return it->second.second;
+	std::string	source = std::string(defs) + sess->prog->source;
+	strom_devprog_key key = strom_get_devprog_key(source.c_str(), sess->prog->extra_flags);
+	Program	   *prog = (key ? lookup_program(key) : nullptr);
+	if (!prog)
+		return nullptr;
+	sess->lookup_programs[defs] = std::make_pair(key, prog);
+	return prog;
 }
 
 /*
@@ -604,7 +642,7 @@ gpupreagg_launch(strom_task_impl *task, preagg_request req, bool checked = false
 {
 	strom_gpupreagg *sess = req.sess;
 	Device	   *dev = task->dev;
-	Program	   *prog = (checked ? sess->prog_checked : sess->prog);
+	Program	   *prog = (checked ? sess->prog_checked : req.prog ? req.prog : sess->prog);
 	int			errcode = 0;
 
 	(void)hipSetDevice(dev->hip_id);
@@ -2170,9 +2208,11 @@ submit_gpupreagg_over_join(strom_gpupreagg *sess, strom_task *join_handle, bool 
 		jtask->main_devptr = nullptr;
 		jtask->keep_main = false;
 	}
+	if (lookup)
+		req.prog = lookup_mapping_program(sess, jm);
 	sess->nfolds++;
 	strom_task_impl *task = task_create(sess->dev, done, arg);
-	program_run_or_park(sess->prog, [task, req]() { gpupreagg_launch(task, req); });
+	program_run_or_park(req.prog ? req.prog : sess->prog, [task, req]() { gpupreagg_launch(task, req); });
 	return task;
 	STROM_ABI_CATCH(nullptr, p_errcode)
 }
@@ -2628,6 +2668,8 @@ strom_gpupreagg_release(strom_gpupreagg *sess)
 		dev->pool.release(sess->htab);
 	if (sess->key_checked)
 		strom_put_devprog_key(sess->key_checked);
+	for (auto &kv : sess->lookup_programs)
+		strom_put_devprog_key(kv.second.first);
 	strom_put_devprog_key(sess->key);
 	delete sess;
 }

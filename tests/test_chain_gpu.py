@@ -393,9 +393,13 @@ def test_join_as_a_lookup_inside_the_aggregate(ngroups, keytype):
     assert np.array_equal(gmax[order][~np.isinf(wmax)], wmax[~np.isinf(wmax)])
 
 
-@pytest.mark.parametrize("epochs,narrow", [(False, True), (True, True), (False, False)])
-def test_join_as_a_lookup_with_packed_accumulators(epochs, narrow, monkeypatch):
-    """narrow: the slot records are 2 bytes (presence, NULL bit, 14 bits of the group column:
+@pytest.mark.parametrize("epochs,narrow,generic", [(False, True, False), (True, True, False), (False, False, False),
+                                                   (False, True, True), (False, False, True)])
+def test_join_as_a_lookup_with_packed_accumulators(epochs, narrow, generic, monkeypatch):
+    """generic: the program as built for the session, which reads the column mapping and the
+    record form from the map at run time (STROM_GPUPREAGG_LOOKUP_GENERIC); otherwise the program
+    built FOR the mapping (gpupreagg.cpp: lookup_mapping_program) -- same answers.
+    narrow: the slot records are 2 bytes (presence, NULL bit, 14 bits of the group column:
     hashjoin_dimrec_narrow_kernel) instead of 8 -- same answers either way.
     1e4 groups, summed OUTER columns without NULLs: the lookup aggregate takes the packed
     LDS image (gpupreagg_packed_lookup, one id-range role instead of two); the grouping key
@@ -410,6 +414,8 @@ def test_join_as_a_lookup_with_packed_accumulators(epochs, narrow, monkeypatch):
         monkeypatch.setenv("STROM_GPUPREAGG_PACK_COUNT_BITS", "15")
     if not narrow:
         monkeypatch.setenv("STROM_HASHJOIN_NO_NARROW_RECS", "1")
+    if generic:
+        monkeypatch.setenv("STROM_GPUPREAGG_LOOKUP_GENERIC", "1")
     rng = np.random.default_rng(97)
     span = int(nd * 1.25)
     fk = rng.integers(0, span, n).astype(np.int32)
