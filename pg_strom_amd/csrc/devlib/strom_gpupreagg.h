@@ -1546,7 +1546,17 @@ gpupreagg_dense_lookup_body(kern_gpupreagg *kgpreagg,
 #define LOOKUP_PTR(x)			strom_uniform(x)
 #endif
 	/* (the slot records are global memory: said so, the loads are global_load, not flat_load) */
+#ifndef GPUPREAGG_LOOKUP_PROBE
+#define GPUPREAGG_LOOKUP_PROBE	0
+#endif
+#if GPUPREAGG_LOOKUP_PROBE == 2
+	/* (experiment: agent-scope loads are served by the L2 without a line fill in the CU's L1) */
+#define LOOKUP_GLOBAL(T, p)		__hip_atomic_load((const __attribute__((address_space(1))) T *)(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+#elif GPUPREAGG_LOOKUP_PROBE == 1
+#define LOOKUP_GLOBAL(T, p)		__builtin_nontemporal_load((const __attribute__((address_space(1))) T *)(p))
+#else
 #define LOOKUP_GLOBAL(T, p)		(*(const __attribute__((address_space(1))) T *)(p))
+#endif
 #define X(attno,colidx,NAME)													\
 	const bool	inner_##attno = LOOKUP_INNER(colidx);								\
 	const cl_uint recoff_##attno = strom_uniform((cl_uint)jmap->c[colidx].dimvalues);	\
@@ -1600,14 +1610,18 @@ gpupreagg_dense_lookup_body(kern_gpupreagg *kgpreagg,
 		__syncthreads();
 	}
 #endif
-	for (cl_uint tile = wg_in_split; tile < ntiles; tile += wgs_per_split)
+	/*
+	 * A software pipeline over the tiles: the column loads of tile t+1 are issued right behind
+	 * the probes of tile t, before anything of tile t is waited for -- loads return in order,
+	 * so the probes complete under the next tile's stream instead of after a drained queue
+	 * (one work-group per CU: four waves per SIMD do not hide two exposed round trips per
+	 * tile by themselves).
+	 */
+	auto load_tile = [&](cl_uint tile, gpupreagg_column_tile &T, KEY_T (&keyq)[GPUPREAGG_QUADS][4],
+						 cl_uint (&keynn)[GPUPREAGG_QUADS])
 	{
 		cl_uint		tile_base = tile * GPUPREAGG_TILE_ROWS;
 		bool		full_tile = (tile_base + GPUPREAGG_TILE_ROWS <= nitems);
-		gpupreagg_column_tile T;
-		KEY_T		keyq[GPUPREAGG_QUADS][4];
-		cl_uint		keynn[GPUPREAGG_QUADS];
-
 #pragma unroll
 		for (int k = 0; k < GPUPREAGG_QUADS; k++)
 		{
@@ -1645,6 +1659,19 @@ gpupreagg_dense_lookup_body(kern_gpupreagg *kgpreagg,
 #undef X
 			}
 		}
+	};
+	gpupreagg_column_tile T, Tnext;
+	KEY_T		keyq[GPUPREAGG_QUADS][4], keyq_next[GPUPREAGG_QUADS][4];
+	cl_uint		keynn[GPUPREAGG_QUADS], keynn_next[GPUPREAGG_QUADS];
+
+	if (wg_in_split < ntiles)
+		load_tile(wg_in_split, T, keyq, keynn);
+	for (cl_uint tile = wg_in_split; tile < ntiles; tile += wgs_per_split)
+	{
+		cl_uint		tile_base = tile * GPUPREAGG_TILE_ROWS;
+		bool		full_tile = (tile_base + GPUPREAGG_TILE_ROWS <= nitems);
+		bool		more = (tile + wgs_per_split < ntiles);		/* (uniform) */
+
 		/*
 		 * every lookup of the tile is issued before the first is used (a
 		 * row-by-row "is there a partner? then fetch its columns" is a chain
@@ -1684,12 +1711,10 @@ gpupreagg_dense_lookup_body(kern_gpupreagg *kgpreagg,
 				gone[k] |= (live ? 0u : (1u << j));
 			}
 		}
+		cl_uint	words[GPUPREAGG_QUADS][4][4];	/* records of 8 / 16 bytes: the whole record, fetched in ONE load */
 #pragma unroll
 		for (int k = 0; k < GPUPREAGG_QUADS; k++)
 		{
-			cl_uint	flags[4];
-			cl_uint	words[4][4];			/* records of 8 / 16 bytes: the whole record, fetched in ONE load */
-			cl_uint	ab = 0;
 #pragma unroll
 			for (int j = 0; j < 4; j++)
 			{
@@ -1699,36 +1724,49 @@ gpupreagg_dense_lookup_body(kern_gpupreagg *kgpreagg,
 #if GPUPREAGG_ABLATE & 2
 				if (reclen != 0)			/* (measurement only: no record is read) */
 				{
-					words[j][0] = 1;
-					words[j][1] = slot[k][j] % 10000u;
-					words[j][2] = words[j][3] = 0;
+					words[k][j][0] = 1;
+					words[k][j][1] = slot[k][j] % 10000u;
+					words[k][j][2] = words[k][j][3] = 0;
 				}
 				else
 #endif
 				if (narrow)
 				{
 					/* 2- or 4-byte record: flags and value fields in one word */
-					words[j][0] = (reclen == 2 ? (cl_uint)LOOKUP_GLOBAL(cl_ushort, rec) : LOOKUP_GLOBAL(cl_uint, rec));
-					words[j][1] = words[j][2] = words[j][3] = 0;
+					words[k][j][0] = (reclen == 2 ? (cl_uint)LOOKUP_GLOBAL(cl_ushort, rec) : LOOKUP_GLOBAL(cl_uint, rec));
+					words[k][j][1] = words[k][j][2] = words[k][j][3] = 0;
 				}
 				else if (reclen == 8)
 				{
 					cl_ulong w = LOOKUP_GLOBAL(cl_ulong, rec);
-					words[j][0] = (cl_uint)w;
-					words[j][1] = (cl_uint)(w >> 32);
-					words[j][2] = words[j][3] = 0;
+					words[k][j][0] = (cl_uint)w;
+					words[k][j][1] = (cl_uint)(w >> 32);
+					words[k][j][2] = words[k][j][3] = 0;
 				}
 				else if (reclen == 16)
 				{
-					uint4 q = LOOKUP_GLOBAL(uint4, rec);
-					words[j][0] = q.x; words[j][1] = q.y; words[j][2] = q.z; words[j][3] = q.w;
+					uint4 q = *(const __attribute__((address_space(1))) uint4 *)rec;
+					words[k][j][0] = q.x; words[k][j][1] = q.y; words[k][j][2] = q.z; words[k][j][3] = q.w;
 				}
 				else
 				{
-					words[j][0] = LOOKUP_GLOBAL(cl_uint, rec);
-					words[j][1] = words[j][2] = words[j][3] = 0;
+					words[k][j][0] = LOOKUP_GLOBAL(cl_uint, rec);
+					words[k][j][1] = words[k][j][2] = words[k][j][3] = 0;
 				}
-				flags[j] = words[j][0];
+			}
+		}
+		/* the next tile's columns: behind this tile's probes, ahead of their use */
+		if (more)
+			load_tile(tile + wgs_per_split, Tnext, keyq_next, keynn_next);
+#pragma unroll
+		for (int k = 0; k < GPUPREAGG_QUADS; k++)
+		{
+			cl_uint	flags[4];
+			cl_uint	ab = 0;
+#pragma unroll
+			for (int j = 0; j < 4; j++)
+			{
+				flags[j] = words[k][j][0];
 				ab |= ((flags[j] & 1u) ? 0u : (1u << j));
 			}
 			gone[k] |= ab;
@@ -1747,8 +1785,8 @@ gpupreagg_dense_lookup_body(kern_gpupreagg *kgpreagg,
 					{															\
 						/* (offsets are uniform: the selects are scalar) */		\
 						cl_uint	wi = recoff_##attno >> 2;						\
-						cl_uint	lo = (wi == 1 ? words[j][1] : wi == 2 ? words[j][2] : words[j][3]);	\
-						cl_uint	hi = (wi == 2 ? words[j][3] : 0u);				\
+						cl_uint	lo = (wi == 1 ? words[k][j][1] : wi == 2 ? words[k][j][2] : words[k][j][3]);	\
+						cl_uint	hi = (wi == 2 ? words[k][j][3] : 0u);				\
 						cl_ulong bits = (((cl_ulong)hi << 32) | lo) >> ((recoff_##attno & 3u) * 8u);	\
 						__builtin_memcpy(&val, &bits, sizeof(val));				\
 					}															\
@@ -1793,6 +1831,19 @@ gpupreagg_dense_lookup_body(kern_gpupreagg *kgpreagg,
 						gpupreagg_dense_row(lds, ctl, L, KP, KV, gid_lo, G, NREP, rep,
 											param_error, &chunk_status, summag, (qual_ok[k] >> j) & 1);
 				}
+			}
+		}
+		/* the next tile becomes the current one (register moves; the loads may still be in flight) */
+		if (more)
+		{
+			T = Tnext;
+#pragma unroll
+			for (int k = 0; k < GPUPREAGG_QUADS; k++)
+			{
+				keynn[k] = keynn_next[k];
+#pragma unroll
+				for (int j = 0; j < 4; j++)
+					keyq[k][j] = keyq_next[k][j];
 			}
 		}
 	}
