@@ -72,7 +72,15 @@ struct hashjoin_index_rel {
 	cl_uint		unique;			/* no chain longer than one entry */
 	cl_uint		slots_off;		/* bytes from the index base to cl_uint slots[] */
 	cl_uint		nentries;
-	cl_uint		__pad;
+	/*
+	 * DIRECT + unique keys: the same slots in THREE bytes each -- (entry offset >> 3; entries are
+	 * LONGALIGNed, KERN_HASHENTRY_SIZE_BY_TLEN) -- when the table is below 2^27 bytes; 0 = none.
+	 * A slot array is probed at random by every CU of an XCD: what counts is whether it fits that
+	 * XCD's 4 MB L2 next to the stream.  1.25e6 key values (BASELINE configs[2]) are 5.0 MB as
+	 * cl_uint -- one probe in three went to HBM for a 64-byte line -- and 3.75 MB like this.
+	 * Made by hashjoin_narrow_slots_kernel, read by gpuhashjoin_main_fast_narrow.
+	 */
+	cl_uint		slots3_off;
 };
 struct hashjoin_index {
 	cl_uint		nrels;
@@ -697,6 +705,38 @@ struct hashjoin_stage {
 	cl_uint		flush_base;
 };
 
+/* slots[] (entry offsets, 4 bytes) -> slots3[] (offset >> 3, 3 bytes); four slots per thread:
+ * twelve bytes, three aligned words */
+extern "C" __global__ void
+__launch_bounds__(256)
+hashjoin_narrow_slots_kernel(hashjoin_index *hjidx, cl_int depth)
+{
+	const hashjoin_index_rel *ir = &hjidx->rel[depth - 1];
+	const cl_uint *slots = (const cl_uint *)((const char *)hjidx + ir->slots_off);
+	cl_uint	   *out = (cl_uint *)((char *)hjidx + ir->slots3_off);
+	cl_uint		n = ir->nslots;
+	cl_uint		nquads = (n + 3) / 4;
+
+	for (cl_uint q = blockIdx.x * blockDim.x + threadIdx.x; q < nquads; q += gridDim.x * blockDim.x)
+	{
+		cl_uint		v[4];
+#pragma unroll
+		for (int j = 0; j < 4; j++)
+			v[j] = (4 * q + j < n ? slots[4 * q + j] >> 3 : 0u);
+		out[3 * q + 0] = v[0] | (v[1] << 24);
+		out[3 * q + 1] = (v[1] >> 8) | (v[2] << 16);
+		out[3 * q + 2] = (v[2] >> 16) | (v[3] << 8);
+	}
+}
+
+/* one probe of the 3-byte slot array: ONE (unaligned) 4-byte load */
+struct __attribute__((packed)) hashjoin_unaligned_u32 { cl_uint v; };
+STROM_DEVICE cl_uint
+hashjoin_slot3(const cl_uchar *slots3, cl_ulong idx)
+{
+	return (((const __attribute__((address_space(1))) hashjoin_unaligned_u32 *)(slots3 + 3 * idx))->v & 0xffffffu) << 3;
+}
+
 template <int QUADS>
 struct hashjoin_column_tile {
 #define X(attno,colidx,NAME)											\
@@ -718,7 +758,8 @@ struct hashjoin_column_tile {
  */
 /* LDS_SLOTS: 0 = DIRECT slots read through the caches, 1 = DIRECT slots staged in LDS,
  * 2 = KEYED index (sparse integer keys): the probe is the 16-byte slot search of
- * hashjoin_first(), one pass instead of the general kernel's count + emit */
+ * hashjoin_first(), one pass instead of the general kernel's count + emit,
+ * 3 = DIRECT slots in their 3-byte form (hashjoin_index_rel.slots3_off) */
 template <int LDS_SLOTS, int QUADS>
 __device__ __forceinline__ void
 gpuhashjoin_main_fast_body(kern_hashjoin *khashjoin,
@@ -733,6 +774,7 @@ gpuhashjoin_main_fast_body(kern_hashjoin *khashjoin,
 	const kern_coldir *coldir = KERN_DATA_STORE_COLDIR(kds);
 	const hashjoin_index_rel *ir = &hjidx->rel[0];
 	const cl_uint *slots = (const cl_uint *)((const char *)hjidx + ir->slots_off);
+	const cl_uchar *slots3 = (const cl_uchar *)hjidx + ir->slots3_off;
 	cl_long		key_min = ir->key_min;
 	cl_uint		key_range = ir->nslots;
 	cl_uint		nitems = kds->nitems;
@@ -867,7 +909,7 @@ gpuhashjoin_main_fast_body(kern_hashjoin *khashjoin,
 					{
 						cl_ulong idx = (cl_ulong)(key - key_min);
 						if (idx < key_range)
-							match[k][j] = (LDS_SLOTS == 1 ? lds_slots[idx] : slots[idx]);
+							match[k][j] = (LDS_SLOTS == 1 ? lds_slots[idx] : LDS_SLOTS == 3 ? hashjoin_slot3(slots3, idx) : slots[idx]);
 					}
 				}
 				if (errcode != StromError_Success)
@@ -1015,6 +1057,15 @@ gpuhashjoin_main_fast_lds(kern_hashjoin *khashjoin,
 						  const kern_data_store *kds)
 {
 	gpuhashjoin_main_fast_body<1, HASHJOIN_LDS_QUADS>(khashjoin, hjidx, kds);
+}
+
+extern "C" __global__ void
+__launch_bounds__(HASHJOIN_BLOCK)
+gpuhashjoin_main_fast_narrow(kern_hashjoin *khashjoin,
+							 const hashjoin_index *hjidx,
+							 const kern_data_store *kds)
+{
+	gpuhashjoin_main_fast_body<3, HASHJOIN_QUADS>(khashjoin, hjidx, kds);
 }
 
 extern "C" __global__ void

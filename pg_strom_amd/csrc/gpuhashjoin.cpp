@@ -27,7 +27,7 @@ struct index_rel {
 	cl_uint		unique;
 	cl_uint		slots_off;
 	cl_uint		nentries;
-	cl_uint		__pad;
+	cl_uint		slots3_off;		/* DIRECT + unique: the 3-byte slot array, 0 = none */
 };
 struct index_head {
 	cl_uint		nrels;
@@ -222,6 +222,16 @@ strom_hashjoin_table_create(strom_devprog_key key, const kern_multihash *kmhash,
 		ir.nentries = (cl_uint)n;
 		ir.slots_off = (cl_uint)off;
 		off += STROM_TYPEALIGN(256, slot_bytes * (size_t)ir.nslots);
+		/* room for the 3-byte form of a DIRECT slot array (strom_hashjoin.h: slots3_off): worth it
+		 * when the 4-byte array is larger than a fraction of an XCD's L2 and the table's entry
+		 * offsets fit 27 bits; filled below if the keys turn out unique */
+		ir.slots3_off = 0;
+		if (direct && KERN_HASHTABLE(kmhash, t)->length < (1u << 27) &&
+			sizeof(cl_uint) * (size_t)ir.nslots > (1u << 20) && !getenv("STROM_HASHJOIN_NO_NARROW_SLOTS"))
+		{
+			ir.slots3_off = (cl_uint)off;
+			off += STROM_TYPEALIGN(256, 3 * (size_t)ir.nslots + 16);
+		}
 	}
 	tbl->index_len = off;
 	tbl->d_index = (char *)dev->pool.alloc(off);
@@ -241,6 +251,31 @@ strom_hashjoin_table_create(strom_devprog_key key, const kern_multihash *kmhash,
 		&& hipStreamSynchronize(stream) == hipSuccess;
 	if (!ok)
 		return fail(StromError_HipInternal);
+	/* step 3: the 3-byte slot arrays of the DIRECT relations whose keys are unique */
+	{
+		bool	head_changed = false;
+		hipFunction_t fn_narrow = nullptr;
+		for (int t = 0; ok && t < tbl->ntables; t++)
+		{
+			index_rel  &ir = tbl->head.rel[t];
+			if (ir.slots3_off == 0)
+				continue;
+			if (!ir.unique || (!fn_narrow && !(fn_narrow = prog->get_function(dev, "hashjoin_narrow_slots_kernel", &errcode))))
+			{
+				ir.slots3_off = 0;			/* chains: the slot is the chain's head, the 4-byte form stays */
+				head_changed = true;
+				continue;
+			}
+			void   *a_ix = tbl->d_index;
+			int		a_depth = t + 1;
+			void   *args[] = { &a_ix, &a_depth };
+			ok = (hipModuleLaunchKernel(fn_narrow, grid, 1, 1, 256, 1, 1, 0, stream, args, nullptr) == hipSuccess);
+		}
+		if (ok && head_changed)
+			ok = (hipMemcpyAsync(tbl->d_index, &tbl->head, sizeof(index_head), hipMemcpyHostToDevice, stream) == hipSuccess);
+		if (!ok || hipStreamSynchronize(stream) != hipSuccess)
+			return fail(StromError_HipInternal);
+	}
 	strom_retain_devprog_key(key);
 	return tbl.release();
 	STROM_ABI_CATCH(nullptr, p_errcode)
@@ -352,7 +387,9 @@ gpuhashjoin_launch(strom_task_impl *task, hashjoin_request req)
 	{
 		/* only programs whose single clause is "int key = inner key" have it */
 		int e2 = 0;
-		fn = prog->get_function(dev, fast_keyed ? "gpuhashjoin_main_fast_keyed" : "gpuhashjoin_main_fast", &e2);
+		fn = prog->get_function(dev, fast_keyed ? "gpuhashjoin_main_fast_keyed"
+								: tbl->head.rel[0].slots3_off != 0 ? "gpuhashjoin_main_fast_narrow"
+								: "gpuhashjoin_main_fast", &e2);
 	}
 	/* a program that is not fast-eligible still exports the symbol; the
 	 * eligibility is baked into hashjoin_fast_outer_key() returning false,

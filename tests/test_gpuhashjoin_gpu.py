@@ -318,3 +318,21 @@ def test_small_dimension_is_probed_from_lds(nd, span, limit, expect_lds, monkeyp
     a = got[np.lexsort(got.T[::-1])]
     b = want[np.lexsort(want.T[::-1])]
     assert np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("narrow", [True, False])
+def test_large_dimension_is_probed_through_three_byte_slots(narrow, monkeypatch):
+    """a DIRECT index over 5e5 key values is 2 MB of 4-byte slots; with unique keys the fast kernel
+    probes the 3-byte form instead (hashjoin_index_rel.slots3_off: entry offset >> 3, entries are
+    LONGALIGNed) -- same pairs as the oracle and as the 4-byte form (STROM_HASHJOIN_NO_NARROW_SLOTS),
+    including the last slot of the array, NULL keys on both sides and keys outside the range"""
+    if not narrow:
+        monkeypatch.setenv("STROM_HASHJOIN_NO_NARROW_SLOTS", "1")
+    pk, payload, pkn, fk, fkn = fact_dim(200003, 400000, 21, nulls=0.01, key_span=500000)
+    pk[0], pk[1] = 0, 499999                                     # both ends of the slot array
+    pk[2:] = np.random.default_rng(3).permutation(np.arange(1, 499999))[:len(pk) - 2].astype(np.int32)
+    fk[:4] = [499999, 0, 500000, -1]
+    inner = kds.build_kds("row_flat", [kds.Column("int4", pk, pkn), kds.Column("int4", payload)])
+    outer = kds.build_kds("column", [kds.Column("int4", fk, fkn)])
+    res, info = run_and_compare(C3_SPEC, outer, [inner], [[1]], expect_mode="direct")
+    assert info[0]["unique"]
