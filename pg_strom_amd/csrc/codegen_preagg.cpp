@@ -33,6 +33,7 @@ struct target {
 	 * cast to int8); 64 = no static bound, the kernels measure the inputs
 	 */
 	int			sumbits = 0;
+	int			key_attno = 0;	/* a group key that is a plain column (var N T): N, else 0 */
 	int			kind;
 	int			type_oid;	/* type of the partial value as the caller sees it */
 	int			acc_oid;	/* type of the device accumulator */
@@ -152,6 +153,12 @@ strom_codegen_gpupreagg(const char *spec, strom_codegen_result *out,
 				std::string e;
 				tg.kind = STROM_PREAGG_KEY;
 				tg.type_oid = codegen_expression(t.items[1], ctx, e);
+				{
+					const sexpr &x = t.items[1];
+					if (x.is_list && x.items.size() == 3 && !x.items[0].is_list && x.items[0].atom == "var" &&
+						!x.items[1].is_list)
+						tg.key_attno = atoi(x.items[1].atom.c_str());
+				}
 				/* a numeric key groups by its canonical image (hashed GROUP BY) */
 				if (tg.type_oid == STROM_NUMERICOID)
 					e = "pgfn_numeric_normalize(errcode, " + e + ")";
@@ -349,6 +356,9 @@ strom_codegen_gpupreagg(const char *spec, strom_codegen_result *out,
 		std::string agg_list = "#define GPUPREAGG_AGG_LIST(X)";
 		std::string pack_list = "#define GPUPREAGG_PACK_LIST(X)";
 		std::string sumbits_defs;
+		/* group keys that are plain columns: X(kidx, attno) -- their zone maps bound the dense ids
+		 * of a COLUMN chunk without a pass over it (gpupreagg.cpp: chunk_domain) */
+		std::string keycols = "#define GPUPREAGG_KEYCOLS_LIST(X)";
 		bool	packable = true;
 		std::string funcs;
 		int		nkeys = 0, naggs = 0;
@@ -361,6 +371,8 @@ strom_codegen_gpupreagg(const char *spec, strom_codegen_result *out,
 			{
 				snprintf(tmp, sizeof(tmp), " X(%d,%zu,%s)", nkeys, i, tname);
 				key_list += tmp;
+				snprintf(tmp, sizeof(tmp), " X(%d,%d)", nkeys, tg.key_attno);
+				keycols += tmp;
 				funcs += fn_header(tname, "gpupreagg_key", nkeys) + "{\n" + tg.body + "}\n";
 				nkeys++;
 			}
@@ -446,7 +458,7 @@ strom_codegen_gpupreagg(const char *spec, strom_codegen_result *out,
 				 "#define GPUPREAGG_NTARGETS %zu\n#define GPUPREAGG_NKEYS %d\n#define GPUPREAGG_NAGGS %d\n",
 				 targets.size(), nkeys, naggs);
 		src += tmp;
-		src += key_list + "\n" + agg_list + "\n";
+		src += key_list + "\n" + agg_list + "\n" + keycols + "\n";
 		/* packed accumulators: X(aidx, kind, attno of the source column) -- see strom_gpupreagg.h */
 		snprintf(tmp, sizeof(tmp), "#define GPUPREAGG_NUMERIC_AGGS %d\n", numeric_aggs ? 1 : 0);
 		src += tmp;

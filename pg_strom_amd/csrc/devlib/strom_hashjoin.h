@@ -49,6 +49,12 @@
 #ifndef HASHJOIN_STAGE
 #define HASHJOIN_STAGE		4096		/* records (8 bytes each) */
 #endif
+/* the one-pass kernels over the L2-resident slot arrays: 4096-row tiles (16 slot reads in flight
+ * per thread): 429 against 440 us per 1e8 rows for BASELINE configs[2] with 2048-row tiles, 446
+ * with 8192 (profiles/r03_c3_sweep.txt) */
+#ifndef HASHJOIN_FAST_QUADS
+#define HASHJOIN_FAST_QUADS	4
+#endif
 #define HASHJOIN_NWAVES		(HASHJOIN_BLOCK / STROM_WAVE)
 #define HASHJOIN_TILE_ROWS	(HASHJOIN_BLOCK * 4 * HASHJOIN_QUADS)
 #define HASHJOIN_MAXRELS	8
@@ -1047,7 +1053,7 @@ gpuhashjoin_main_fast(kern_hashjoin *khashjoin,
 					  const hashjoin_index *hjidx,
 					  const kern_data_store *kds)
 {
-	gpuhashjoin_main_fast_body<0, HASHJOIN_QUADS>(khashjoin, hjidx, kds);
+	gpuhashjoin_main_fast_body<0, HASHJOIN_FAST_QUADS>(khashjoin, hjidx, kds);
 }
 
 extern "C" __global__ void
@@ -1065,7 +1071,7 @@ gpuhashjoin_main_fast_narrow(kern_hashjoin *khashjoin,
 							 const hashjoin_index *hjidx,
 							 const kern_data_store *kds)
 {
-	gpuhashjoin_main_fast_body<3, HASHJOIN_QUADS>(khashjoin, hjidx, kds);
+	gpuhashjoin_main_fast_body<3, HASHJOIN_FAST_QUADS>(khashjoin, hjidx, kds);
 }
 
 extern "C" __global__ void

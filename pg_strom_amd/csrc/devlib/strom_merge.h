@@ -164,6 +164,107 @@ preagg_merge_apply(void *dst, const void *src, cl_ulong count, cl_uint kind)
 	}
 }
 
+/*
+ * partial rows of a dense session, formatted on the device: one TUPSLOT row (8-byte datums, then
+ * one NULL byte per column) per group that was seen, packed in no particular order -- what
+ * strom_gpupreagg_fetch hands to the caller, without the host loop over the table (190-290 us for
+ * 1e4 groups: more than the fold of a reference-sized chunk, profiles/r02_chunk_message_probe.txt).
+ * Group keys come back from the dense id (key_min + offset; the NULL slot is offset == range).
+ * counter[0] counts the rows (written only below max_rows: max_rows = 0 just counts), counter[1] is
+ * set when a 128-bit integer sum does not fit its int8 datum -- the host then splits that table
+ * into several rows itself (gpupreagg.cpp: sum_pieces).  Column kinds: 0 key, 1 nrows, 2 integer
+ * value of len bytes, 3 float8 sum (float4: narrowed), 4 float min / max (order-preserving key),
+ * 5 integer sum {vals_off: low word, hi_off: high word}.
+ */
+typedef struct {
+	cl_uint		ngroups;
+	cl_uint		ncols;
+	cl_uint		stride;
+	cl_uint		nkeys;
+	cl_long		key_min[8];
+	cl_uint		key_range[8];
+	cl_uint		key_stride[8];
+	struct {
+		cl_uint		kind;
+		cl_uint		len;			/* bytes of the datum */
+		cl_uint		which;			/* key number, or the aggregate's has-value bit (1 + a) */
+		cl_uint		float4;
+		cl_ulong	vals_off;
+		cl_ulong	hi_off;
+	} col[64];
+} preagg_export_spec;
+
+extern "C" __global__ void
+__launch_bounds__(256)
+preagg_dense_export_rows(const char *table, const preagg_export_spec *spec, char *rows, cl_uint max_rows,
+						 cl_uint *counter)
+{
+	cl_uint		N = spec->ngroups;
+	cl_uint		ncols = spec->ncols;
+	cl_uint		stride = spec->stride;
+	const cl_uint *t_flags = (const cl_uint *)table;
+
+	for (cl_uint base = blockIdx.x * blockDim.x; base < N; base += gridDim.x * blockDim.x)
+	{
+		cl_uint		g = base + threadIdx.x;
+		cl_uint		flags = (g < N ? t_flags[g] : 0u);
+		bool		seen = (flags & 1u) != 0;
+		cl_ulong	mask = __ballot(seen);
+		cl_uint		first = 0;
+		if (mask == 0)
+			continue;
+		if ((threadIdx.x & 63) == 0)
+			first = atomicAdd(&counter[0], (cl_uint)__popcll(mask));
+		first = __shfl(first, 0, 64);
+		cl_uint		idx = first + (cl_uint)__popcll(mask & ((1UL << (threadIdx.x & 63)) - 1));
+		if (!seen || idx >= max_rows)
+			continue;
+		cl_ulong   *values = (cl_ulong *)(rows + (size_t)stride * idx);
+		cl_char	   *isnull = (cl_char *)(values + ncols);
+		for (cl_uint w = ncols; w < stride / 8; w++)
+			values[w] = 0;						/* the NULL flags and the padding behind them */
+		for (cl_uint c = 0; c < ncols; c++)
+		{
+			cl_uint		kind = spec->col[c].kind, len = spec->col[c].len, which = spec->col[c].which;
+			cl_ulong	raw = 0;
+			bool		null = false;
+			if (kind == 0)
+			{
+				cl_uint	off = (g / spec->key_stride[which]) % (spec->key_range[which] + 1);
+				null = (off == spec->key_range[which]);
+				raw = (cl_ulong)(spec->key_min[which] + (cl_long)off);
+			}
+			else
+			{
+				raw = ((const cl_ulong *)(table + spec->col[c].vals_off))[g];
+				null = (kind != 1 && !((flags >> which) & 1u));
+				if (kind == 5 && !null)
+				{
+					cl_long hi = ((const cl_long *)(table + spec->col[c].hi_off))[g];
+					if (hi != ((cl_long)raw >> 63))
+						counter[1] = 1;			/* (does not fit one int8 datum: the host takes over) */
+				}
+				else if (kind == 4 && !null)
+					raw = (raw & PREAGG_MERGE_SIGN) ? (raw & 0x7fffffffffffffffUL) : ~raw;
+				if ((kind == 3 || kind == 4) && spec->col[c].float4 && !null)
+				{
+					cl_double d;
+					cl_float f;
+					__builtin_memcpy(&d, &raw, 8);
+					f = (cl_float)d;
+					raw = 0;
+					__builtin_memcpy(&raw, &f, 4);
+				}
+			}
+			if (!null && len < 8)
+				raw &= (1UL << (8 * len)) - 1;
+			values[c] = (null ? 0UL : raw);
+			if (null)
+				isnull[c] = 1;
+		}
+	}
+}
+
 /* census bitmaps (one bit per dense id, gpupreagg_census): OR over the ranks
  * = MAX over the bits unpacked to bytes */
 extern "C" __global__ void

@@ -120,6 +120,7 @@ struct strom_gpupreagg {
 	cl_uint				sum_turn = 0;		/* hashed: parity of the next fold (gpupreagg_hash_sum_account) */
 	/* join-as-a-lookup: the program built FOR a column mapping (lookup_program), by its defines */
 	std::map<std::string, std::pair<strom_devprog_key, Program *>> lookup_programs;	/* (lookup_mapping_program) */
+	char			   *d_export_spec = nullptr;	/* preagg_export_spec of this table (fetch on the device) */
 
 	/* mirrors gpupreagg_image_offset / gpupreagg_table_offset of
 	 * strom_gpupreagg.h: section 0 = flags, 1+a = values of aggregate a,
@@ -2398,6 +2399,11 @@ strom_gpupreagg_compact(strom_gpupreagg *sess, const uint32_t *bitmap, size_t nw
 	if (sess->d_ctl) dev->pool.release(sess->d_ctl);
 	if (sess->d_slabs) dev->pool.release(sess->d_slabs);
 	sess->table = sess->d_ctl = sess->d_slabs = nullptr;
+	if (sess->d_export_spec)
+	{
+		dev->pool.release(sess->d_export_spec);
+		sess->d_export_spec = nullptr;
+	}
 	ctl.ngroups = (cl_uint)sess->present.size();
 	ctl.remap = (cl_ulong)(uintptr_t)sess->d_remap;
 	int rc = setup_layout(sess);
@@ -2656,6 +2662,8 @@ strom_gpupreagg_release(strom_gpupreagg *sess)
 		dev->pool.release(sess->d_census);
 	if (sess->d_remap)
 		dev->pool.release(sess->d_remap);
+	if (sess->d_export_spec)
+		dev->pool.release(sess->d_export_spec);
 	for (auto &kv : sess->packed)
 	{
 		dev->pool.release(kv.second.d_ctl);
@@ -3032,6 +3040,139 @@ gpupreagg_fetch_hashed(strom_gpupreagg *sess, kern_data_store *dest, size_t dest
 
 }	/* namespace */
 
+/* mirrors preagg_export_spec of devlib/strom_merge.h */
+struct export_spec {
+	cl_uint		ngroups, ncols, stride, nkeys;
+	cl_long		key_min[8];
+	cl_uint		key_range[8];
+	cl_uint		key_stride[8];
+	struct {
+		cl_uint		kind, len, which, float4;
+		cl_ulong	vals_off, hi_off;
+	} col[64];
+};
+
+/*
+ * dense sessions: the partial rows formatted on the device (preagg_dense_export_rows) and copied
+ * into the caller's buffer once.  *p_fallback: not this way (compacted slots, numeric partials --
+ * their sums may leave as several rows --, an integer sum beyond int8): the host loop below.
+ */
+static long
+gpupreagg_fetch_dense_device(strom_gpupreagg *sess, kern_data_store *dest, size_t destlen, bool *p_fallback)
+{
+	Device	   *dev = sess->dev;
+	int			ncols = (int)sess->targets.size();
+	cl_uint		N = sess->ctl.ngroups;
+
+	*p_fallback = true;
+	if (!sess->present.empty() || ncols > 64 || sess->key_resno.size() > 8 || getenv("STROM_GPUPREAGG_FETCH_ON_HOST"))
+		return 0;
+	for (const strom_preagg_target &t : sess->targets)
+		if (t.type_oid == STROM_NUMERICOID && t.kind != STROM_PREAGG_NROWS)
+			return 0;
+	int			errcode = 0;
+	hipFunction_t fn = fixed_function(dev, "preagg_dense_export_rows", &errcode);
+	if (!fn)
+		return 0;
+	size_t		stride = KDS_TUPSLOT_STRIDE(ncols);
+	size_t		head_len = KDS_HEAD_LENGTH(ncols);
+	std::lock_guard<std::mutex> g(sess->lock);
+	(void)hipSetDevice(dev->hip_id);
+	if (!sess->d_export_spec)
+	{
+		export_spec	spec;
+		memset(&spec, 0, sizeof(spec));
+		spec.ngroups = N;
+		spec.ncols = (cl_uint)ncols;
+		spec.stride = (cl_uint)stride;
+		spec.nkeys = (cl_uint)sess->key_resno.size();
+		for (size_t k = 0; k < sess->key_resno.size(); k++)
+		{
+			spec.key_min[k] = sess->ctl.key_min[k];
+			spec.key_range[k] = sess->ctl.key_range[k];
+			spec.key_stride[k] = std::max<cl_uint>(1, sess->ctl.key_stride[k]);
+			auto &c = spec.col[sess->key_resno[k]];
+			c.kind = 0;
+			c.len = (cl_uint)type_length(sess->targets[sess->key_resno[k]].type_oid);
+			c.which = (cl_uint)k;
+		}
+		for (size_t a = 0; a < sess->agg_resno.size(); a++)
+		{
+			const strom_preagg_target &t = sess->targets[sess->agg_resno[a]];
+			auto &c = spec.col[sess->agg_resno[a]];
+			bool	isfloat = type_is_float(t.type_oid);
+			c.which = 1 + (cl_uint)a;
+			c.vals_off = sess->table_offset(1 + (int)a, N);
+			c.len = (cl_uint)(t.kind == STROM_PREAGG_NROWS ? 8 : type_length(t.type_oid));
+			c.float4 = (t.type_oid == STROM_FLOAT4OID);
+			if (t.kind == STROM_PREAGG_NROWS)
+				c.kind = 1;
+			else if (sess->is_intsum((int)a))
+			{
+				c.kind = 5;
+				c.hi_off = sess->table_hi_offset((int)a, N);
+			}
+			else if (isfloat)
+				c.kind = (t.kind == STROM_PREAGG_PSUM ? 3 : 4);
+			else
+				c.kind = 2;
+		}
+		sess->d_export_spec = (char *)dev->pool.alloc(sizeof(spec));
+		if (!sess->d_export_spec ||
+			hipMemcpy(sess->d_export_spec, &spec, sizeof(spec), hipMemcpyHostToDevice) != hipSuccess)
+			return -StromError_OutOfMemory;
+	}
+	if (session_quiesce(sess) != hipSuccess)
+		return -StromError_HipInternal;
+	size_t		max_rows = (dest && destlen > head_len ? std::min<size_t>(N, (destlen - head_len) / stride) : 0);
+	char	   *d_rows = (char *)dev->pool.alloc(stride * max_rows + 16);
+	if (!d_rows)
+		return -StromError_OutOfMemory;
+	char	   *d_counter = d_rows + stride * max_rows;
+	hipStream_t	stream = dev->streams[0];
+	const void *a_table = sess->table;
+	const void *a_spec = sess->d_export_spec;
+	void	   *a_rows = d_rows, *a_cnt = d_counter;
+	cl_uint		a_max = (cl_uint)max_rows;
+	void	   *args[] = { &a_table, &a_spec, &a_rows, &a_max, &a_cnt };
+	unsigned	grid = std::max(1u, std::min<unsigned>((N + 255) / 256, (unsigned)dev->prop.multiProcessorCount * 8));
+	cl_uint		counter[2] = { 0, 0 };
+	bool ok = (hipMemsetAsync(d_counter, 0, 16, stream) == hipSuccess &&
+			   hipModuleLaunchKernel(fn, grid, 1, 1, 256, 1, 1, 0, stream, args, nullptr) == hipSuccess &&
+			   hipMemcpyAsync(counter, d_counter, sizeof(counter), hipMemcpyDeviceToHost, stream) == hipSuccess &&
+			   hipStreamSynchronize(stream) == hipSuccess);
+	long		result;
+	size_t		need = STROMALIGN(head_len + stride * (size_t)counter[0]);
+	if (!ok)
+		result = -StromError_HipInternal;
+	else if (counter[1] != 0)
+		result = 0;								/* a sum beyond int8: several rows, made on the host */
+	else
+	{
+		*p_fallback = false;
+		if (!dest)
+			result = (long)need;
+		else if (destlen < need)
+			result = -StromError_DataStoreNoSpace;
+		else
+		{
+			fetch_init_head(sess, dest, need, counter[0]);
+			if (counter[0] > 0 &&
+				hipMemcpy((char *)dest + head_len, d_rows, stride * (size_t)counter[0], hipMemcpyDeviceToHost) != hipSuccess)
+				result = -StromError_HipInternal;
+			else
+			{
+				dest->nitems = counter[0];
+				result = (long)counter[0];
+			}
+		}
+	}
+	if (result < 0)
+		*p_fallback = false;
+	dev->pool.release(d_rows);
+	return result;
+}
+
 /*
  * partial rows out: TUPSLOT, one row per group seen so far (plus, for a
  * numeric sum too wide for the 64-bit numeric form, one extra partial row
@@ -3045,6 +3186,12 @@ strom_gpupreagg_fetch(strom_gpupreagg *sess, kern_data_store *dest, size_t destl
 		return gpupreagg_fetch_hashed(sess, dest, destlen);
 	if (!sess || !sess->has_domain)
 		return -StromError_BadRequestMessage;
+	{
+		bool	fallback = false;
+		long	r = gpupreagg_fetch_dense_device(sess, dest, destlen, &fallback);
+		if (!fallback)
+			return r;
+	}
 	Device *dev = sess->dev;
 	int		ncols = (int)sess->targets.size();
 	cl_uint	N = sess->ctl.ngroups;
@@ -3247,6 +3394,51 @@ chunk_domain(strom_devprog_key key, Program *prog, Device *dev,
 		return 0;
 	if (!program_accepts_format(prog, kds_dev->head.format))
 		return StromError_BadRequestMessage;
+	/*
+	 * a COLUMN chunk whose group keys are plain columns: the zone maps bound the keys (of all
+	 * rows -- a superset of the rows the qual keeps, which is all a dense domain needs): no pass
+	 * over the chunk, no round trip (the key-range kernel and its wait were 165 us of a 325k-row
+	 * message, profiles/r02_chunk_message_probe.txt).  No row map: its rows may be few.
+	 */
+	if (kds_dev->head.format == KDS_FORMAT_COLUMN && !krowmap && !getenv("STROM_GPUPREAGG_NO_ZONE_DOMAIN"))
+	{
+		const char *lst = strstr(prog->source.c_str(), "#define GPUPREAGG_KEYCOLS_LIST(X)");
+		std::shared_ptr<std::vector<kern_coldir>> cd = dstore_coldir(kds_dev);
+		bool		ok = (lst != nullptr && cd != nullptr);
+		const char *eol = (lst ? strchr(lst, '\n') : nullptr);
+		int			found = 0;
+		for (const char *p = (ok ? strstr(lst, " X(") : nullptr); ok && p && (!eol || p < eol); p = strstr(p + 1, " X("))
+		{
+			int		kidx = -1, attno = 0;
+			if (sscanf(p, " X(%d,%d)", &kidx, &attno) != 2 || kidx != found || kidx >= nkeys ||
+				attno < 1 || attno > (int)cd->size())
+			{
+				ok = false;
+				break;
+			}
+			const kern_coldir &c = (*cd)[attno - 1];
+			if (c.stat_flags & KDS_COLSTAT_ISFLOAT)
+				ok = false;
+			else if (!(c.stat_flags & KDS_COLSTAT_MINMAX))
+			{
+				dom->key_min[kidx] = 0;			/* NULL keys only: the NULL slot alone */
+				dom->key_range[kidx] = 0;
+			}
+			else
+			{
+				cl_ulong span = (cl_ulong)c.maxval - (cl_ulong)c.minval;
+				if (c.maxval < c.minval || span >= 0xfffffffeUL)
+					ok = false;
+				dom->key_min[kidx] = c.minval;
+				dom->key_range[kidx] = (cl_uint)span + 1;
+			}
+			found++;
+		}
+		if (ok && found == nkeys)
+			return 0;
+		memset(dom, 0, sizeof(*dom));
+		dom->nkeys = nkeys;
+	}
 	if (strom_lookup_device_program(key, 1) != STROM_DEVPROG_READY)
 		return StromError_ProgramBuildFailure;
 	(void)hipSetDevice(dev->hip_id);
@@ -3475,17 +3667,7 @@ strom_submit_gpupreagg_chunk(strom_devprog_key key,
 			rc = strom_task_wait(fold, &pfm);
 			if (rc != 0)
 				break;					/* CpuReCheck: the chunk goes back whole (gpupreagg.c:2746-2750) */
-			long	need = strom_gpupreagg_fetch(sess, nullptr, 0);
-			if (need < 0)
-			{
-				rc = (int)-need;
-				break;
-			}
-			if ((size_t)need > dest_length)
-			{
-				rc = StromError_DataStoreNoSpace;
-				break;
-			}
+			/* (one call: a kds_dest that is too small answers DataStoreNoSpace by itself) */
 			long	n = strom_gpupreagg_fetch(sess, kds_dest, dest_length);
 			if (n < 0)
 				rc = (int)-n;

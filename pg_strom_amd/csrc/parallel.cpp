@@ -120,6 +120,16 @@ merge_function(Device *dev, const char *name, int *p_errcode)
 	return lookup_program(key)->get_function(dev, name, p_errcode);
 }
 
+}	/* namespace */
+
+hipFunction_t
+strom::fixed_function(Device *dev, const char *name, int *p_errcode)
+{
+	return merge_function(dev, name, p_errcode);
+}
+
+namespace {
+
 /* order 'stream' behind everything queued for the session's table: the folds on
  * streams[0] and the slab merges that follow them on the merge stream */
 int

@@ -252,6 +252,9 @@ int			gpupreagg_hash_export_device(strom_gpupreagg *sess, char **p_recs, cl_uint
 void		gpupreagg_hash_release(strom_gpupreagg *sess, char *recs);
 int			gpupreagg_hash_import_device(strom_gpupreagg *sess, const char *d_recs, cl_uint seg_len, cl_uint nsegs,
 										 const cl_uint *h_counts, cl_uint skip_seg);
+/* parallel.cpp: a kernel of the fixed-function program (devlib/strom_merge.h: the merge's prepare /
+ * finish / apply steps, the dense partial-row export, the streaming-read probe) */
+hipFunction_t fixed_function(Device *dev, const char *name, int *p_errcode);
 int			num_devices();
 Program	   *lookup_program(strom_devprog_key key);
 /* text / character(n) values are addresses of varlena datums inside heap tuples
