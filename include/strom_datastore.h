@@ -73,6 +73,23 @@ int		strom_kds_fetch(const kern_data_store *kds, uint32_t rowidx, uint32_t colid
 						uint64_t *value);
 
 /*
+ * A 64-bit device numeric (exponent 63..58, sign 57, mantissa 56..0: opencl_numeric.h:122-160) as
+ * PostgreSQL's own numeric datum  <- pgstrom_fixup_kernel_numeric (datastore.c:150-167), which the
+ * backend applies to every NUMERIC column of a row that comes back from the device
+ * (pgstrom_fetch_data_store, datastore.c:169-242).  The reference prints "%c%lue%d" and calls
+ * numeric_in(); both halves are here:
+ *   strom_kernel_numeric_cstring   that very text (sign, mantissa, 'e', exponent) -- what a backend
+ *                                  hands to numeric_in() if it wants PostgreSQL to build the datum;
+ *   strom_fixup_kernel_numeric     the datum itself as PostgreSQL 9.4 stores it (utils/adt/numeric.c:
+ *                                  4-byte varlena header, short numeric header when weight and
+ *                                  display scale fit, base-10000 digits), display scale = the
+ *                                  digits behind the decimal point, as numeric_in gives it.
+ * Both return the bytes written (the text without its NUL), or -StromError_DataStoreNoSpace.
+ */
+int		strom_kernel_numeric_cstring(uint64_t image, char *buf, size_t room);
+int		strom_fixup_kernel_numeric(uint64_t image, void *varlena_out, size_t room);
+
+/*
  * Inner side of a hash join: multihash_preload_khashtable
  * (gpuhashjoin.c:3614-3816).  One kern_hashtable per inner relation inside
  * one kern_multihash; each entry owns the inner row as a heap tuple,

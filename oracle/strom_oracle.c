@@ -151,7 +151,7 @@ enum {
 	OP_DATE_PLI, OP_DATE_MII, OP_DATE_MI, OP_INT_PL_DATE,
 	OP_DATE_TO_TS, OP_TS_TO_DATE, OP_TS_TO_TIME, OP_DATETIME_PL, OP_TIMEDATE_PL,
 	OP_NUM_ADD, OP_NUM_SUB, OP_NUM_MUL, OP_NUM_UMINUS, OP_NUM_UPLUS, OP_NUM_ABS,
-	OP_NUM_FROM_INT, OP_NUM_TO_INT, OP_NUM_TO_FLOAT
+	OP_NUM_FROM_INT, OP_NUM_TO_INT, OP_NUM_TO_FLOAT, OP_NUM_FROM_FLOAT, OP_IDENTITY
 };
 enum { BT_TRUE, BT_NOT_TRUE, BT_FALSE, BT_NOT_FALSE, BT_UNKNOWN, BT_NOT_UNKNOWN };
 
@@ -340,6 +340,96 @@ num_pack(int expo, int sign, uint64_t mant, uint64_t *out)
 	}
 	if (expo < -32 || mant >= (1ULL << 57)) return 0;
 	*out = (((uint64_t)(int64_t)expo) << 58) | ((uint64_t)(sign != 0) << 57) | mant;
+	return 1;
+}
+
+/* ---- float -> numeric: exact scaling (see OP_NUM_FROM_FLOAT) ---- */
+/* 192-bit unsigned integers, six 32-bit limbs, little endian: all the arithmetic float -> numeric needs */
+static void
+oracle_w192_mul_small(uint32_t *w, uint32_t m)
+{
+	uint64_t	carry = 0;
+	for (int i = 0; i < 6; i++)
+	{
+		uint64_t t = (uint64_t)w[i] * m + carry;
+		w[i] = (uint32_t)t;
+		carry = t >> 32;
+	}
+}
+static uint32_t
+oracle_w192_div_small(uint32_t *w, uint32_t d)
+{
+	uint64_t	rem = 0;
+	for (int i = 5; i >= 0; i--)
+	{
+		uint64_t t = (rem << 32) | w[i];
+		w[i] = (uint32_t)(t / d);
+		rem = t % d;
+	}
+	return (uint32_t)rem;
+}
+static void
+oracle_w192_shl(uint32_t *w, int n)
+{
+	int		limbs = n / 32, bits = n % 32;
+	for (int i = 5; i >= 0; i--)
+	{
+		uint64_t lo = (i - limbs >= 0 ? w[i - limbs] : 0), lo2 = (i - limbs - 1 >= 0 ? w[i - limbs - 1] : 0);
+		w[i] = (uint32_t)(bits ? ((lo << bits) | (lo2 >> (32 - bits))) : lo);
+	}
+}
+/* >> n; returns whether a 1 bit was shifted out */
+static int
+oracle_w192_shr(uint32_t *w, int n)
+{
+	int		limbs = n / 32, bits = n % 32, sticky = 0;
+	for (int i = 0; i < 6; i++)
+	{
+		if (i < limbs)
+			sticky |= (w[i] != 0);
+		else if (i == limbs && bits)
+			sticky |= ((w[i] & ((1u << bits) - 1)) != 0);
+	}
+	for (int i = 0; i < 6; i++)
+	{
+		uint64_t lo = (i + limbs < 6 ? w[i + limbs] : 0), hi = (i + limbs + 1 < 6 ? w[i + limbs + 1] : 0);
+		w[i] = (uint32_t)(bits ? ((lo >> bits) | (hi << (32 - bits))) : lo);
+	}
+	return sticky;
+}
+
+/*
+ * round_half_even(M x 2^E x 10^k), exactly: multiplications and left shifts first, then one more
+ * bit (the half), then divisions and right shifts with a sticky flag.  0 when it does not fit 64 bits.
+ */
+static int
+oracle_scaled_mantissa(uint64_t M, int E, int k, uint64_t *p_mant)
+{
+	uint32_t	w[6] = { (uint32_t)M, (uint32_t)(M >> 32), 0, 0, 0, 0 };
+	int		a = E + k, b = k, sticky = 0;		/* x 2^a x 5^b */
+
+	if (b > 47 || b < -36 || a > 130 || a < -185)
+		return 0;
+	for (; b >= 13; b -= 13)
+		oracle_w192_mul_small(w, 1220703125u);		/* 5^13 */
+	for (; b > 0; b--)
+		oracle_w192_mul_small(w, 5u);
+	if (a > 0)
+		oracle_w192_shl(w, a);
+	oracle_w192_shl(w, 1);
+	for (; b <= -13; b += 13)
+		sticky |= (oracle_w192_div_small(w, 1220703125u) != 0);
+	for (; b < 0; b++)
+		sticky |= (oracle_w192_div_small(w, 5u) != 0);
+	if (a < 0)
+		sticky |= oracle_w192_shr(w, -a);
+	if (w[2] | w[3] | w[4] | w[5])
+		return 0;
+	uint64_t	q = ((uint64_t)w[1] << 32) | w[0];
+	uint64_t	mant = q >> 1;
+	if ((q & 1) && (sticky || (mant & 1)))
+		mant++;									/* above the half, or the tie to even */
+	*p_mant = mant;
 	return 1;
 }
 
@@ -761,6 +851,14 @@ resolve_func(oracle_expr *e, const char *name)
 	}
 	if (nargs == 1 && !strcmp(name, "numeric") && type_is_int(a0))
 	{ e->op = OP_NUM_FROM_INT; e->type_oid = STROM_NUMERICOID; return 1; }
+	/* float4_numeric / float8_numeric (codegen.c:519-520, opencl_numeric.h:625-779) */
+	if (nargs == 1 && !strcmp(name, "numeric") && type_is_float(a0))
+	{ e->op = OP_NUM_FROM_FLOAT; e->type_oid = STROM_NUMERICOID; return 1; }
+	/* the alias casts date(date), time(time), timestamp(timestamp) (codegen.c:543-548) */
+	if (nargs == 1 && ((!strcmp(name, "date") && a0 == STROM_DATEOID) ||
+					   (!strcmp(name, "time") && a0 == STROM_TIMEOID) ||
+					   (!strcmp(name, "timestamp") && a0 == STROM_TIMESTAMPOID)))
+	{ e->op = OP_IDENTITY; e->type_oid = a0; return 1; }
 	/* bt<family>cmp */
 	if (strncmp(name, "bt", 2) == 0 && nargs == 2)
 	{
@@ -1486,6 +1584,45 @@ eval_func(const oracle_expr *e, oracle_value *a, int32_t *errcode)
 		case OP_NUM_ABS:
 			r.v.u = a[0].v.u & ~(1ULL << 57);
 			return r;
+		case OP_IDENTITY:
+			r.v = a[0].v;
+			return r;
+		case OP_NUM_FROM_FLOAT:
+			{
+				/*
+				 * PostgreSQL: the value printed with FLT_DIG / DBL_DIG significant digits and read
+				 * back (float4_numeric / float8_numeric, utils/adt/numeric.c); the reference:
+				 * float_to_numeric (opencl_numeric.h:625-738) with the same digit counts, through
+				 * log10 / exp10 in floating point (a few per cent of all doubles come out one off in
+				 * the last digit that way).  Stated here as PostgreSQL's definition: the binary value
+				 * M x 2^E scaled by 10^k in exact 192-bit integer arithmetic and rounded half to even
+				 * once; NaN, infinities and what the 64-bit form cannot hold are CpuReCheck.
+				 */
+				int		dig = (e->args[0]->type_oid == STROM_FLOAT4OID ? 6 : 15);
+				double	value = as_double(a[0]);
+				uint64_t bits, M, lim = 1, mant = 0;
+				int		sign, be, E, e2, e10, k, i, turn, ok = 0;
+				if (isnan(value) || isinf(value)) return recheck(rt, errcode);
+				if (value == 0.0) { r.v.u = 0; return r; }
+				memcpy(&bits, &value, 8);
+				sign = (int)(bits >> 63);
+				be = (int)((bits >> 52) & 0x7ff);
+				M = (bits & 0xfffffffffffffULL) | (be ? (1ULL << 52) : 0);
+				E = (be ? be : 1) - 1075;
+				e2 = 63 - __builtin_clzll(M) + E;
+				e10 = (e2 * 1233) >> 12;
+				k = dig - 1 - e10;
+				for (i = 0; i < dig; i++) lim *= 10;
+				for (turn = 0; turn < 4; turn++)
+				{
+					if (!oracle_scaled_mantissa(M, E, k, &mant)) break;
+					if (mant > lim) k--;
+					else if (mant < lim / 10) k++;
+					else { ok = 1; break; }
+				}
+				if (!ok || !num_pack(-k, sign, mant, &r.v.u)) return recheck(rt, errcode);
+				return r;
+			}
 		case OP_NUM_FROM_INT:
 			{
 				int64_t v = a[0].v.i;

@@ -144,6 +144,8 @@ PROTOTYPES = {
     "strom_gpupreagg_table_length": (c_size_t, [c_void_p]),
     "strom_gpupreagg_bind_table": (c_int, [c_void_p, c_void_p]),
     "strom_gpupreagg_table_devptr": (c_void_p, [c_void_p]),
+    "strom_kernel_numeric_cstring": (c_int, [ctypes.c_uint64, ctypes.c_char_p, ctypes.c_size_t]),
+    "strom_fixup_kernel_numeric": (c_int, [ctypes.c_uint64, c_void_p, ctypes.c_size_t]),
     "strom_gpupreagg_num_groups": (c_uint32, [c_void_p]),
     "strom_gpupreagg_checked_folds": (c_uint32, [c_void_p]),
     "strom_gpupreagg_table_layout": (c_int, [c_void_p, c_int, ctypes.POINTER(c_size_t),

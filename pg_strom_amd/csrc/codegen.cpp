@@ -230,6 +230,9 @@ build_catalog(void)
 	add_func("integer_pl_date", {I4,DT}, DT, "integer_pl_date", T);
 	add_func("datetime_pl", {DT,TM}, TS, "datetime_pl", T);
 	add_func("timedate_pl", {TM,DT}, TS, "timedate_pl", T);
+	add_func("date", {DT}, DT, "date_date", T);					/* alias casts (codegen.c:543-548) */
+	add_func("time", {TM}, TM, "time_time", T);
+	add_func("timestamp", {TS}, TS, "timestamp_timestamp", T);
 	add_func("date", {TS}, DT, "timestamp_date", T);
 	add_func("time", {TS}, TM, "timestamp_time", T);
 	add_func("timestamp", {DT}, TS, "date_timestamp", T);
@@ -245,7 +248,9 @@ build_catalog(void)
 	add_func("numeric", {I2}, NU, "int2_numeric", N);
 	add_func("numeric", {I4}, NU, "int4_numeric", N);
 	add_func("numeric", {I8}, NU, "int8_numeric", N);
-	/* float -> numeric needs PostgreSQL's shortest-decimal conversion: stays on the CPU */
+	/* float -> numeric: the value at FLT_DIG / DBL_DIG significant digits (strom_numeric.h) */
+	add_func("numeric", {F4}, NU, "float4_numeric", N);
+	add_func("numeric", {F8}, NU, "float8_numeric", N);
 	for (const char *op : {"add","sub","mul"})
 		add_func(std::string("numeric_") + op, {NU,NU}, NU, std::string("numeric_") + op, N);
 	add_func("numeric_uplus",  {NU}, NU, "numeric_uplus", N);

@@ -5,6 +5,7 @@
  * of heap pages / tuples follows PostgreSQL 9.4's bufpage.h / htup_details.h
  * as re-declared for the device in opencl_common.h:156-264.
  */
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <cmath>
@@ -956,3 +957,113 @@ strom_multihash_build(int ntables, const strom_hashtable_input *tables, void *bu
 	}
 	return 0;
 }
+
+/* ------------------------------------------------------------------ *
+ * 64-bit device numeric -> PostgreSQL's numeric  (pgstrom_fixup_kernel_numeric,
+ * datastore.c:150-167)
+ * ------------------------------------------------------------------ */
+extern "C" int
+strom_kernel_numeric_cstring(uint64_t image, char *buf, size_t room)
+{
+	int			expo = (int)((int64_t)image >> 58);
+	bool		sign = ((image >> 57) & 1) != 0;
+	uint64_t	mant = image & ((1ULL << 57) - 1);
+	char		temp[64];
+	/* (the reference's own format string) */
+	int			n = snprintf(temp, sizeof(temp), "%c%llue%d", sign ? '-' : '+', (unsigned long long)mant, expo);
+	if (n < 0 || !buf || (size_t)n + 1 > room)
+		return -StromError_DataStoreNoSpace;
+	memcpy(buf, temp, (size_t)n + 1);
+	return n;
+}
+
+extern "C" int
+strom_fixup_kernel_numeric(uint64_t image, void *varlena_out, size_t room)
+{
+	int			expo = (int)((int64_t)image >> 58);
+	bool		sign = ((image >> 57) & 1) != 0;
+	uint64_t	mant = image & ((1ULL << 57) - 1);
+	/* decimal digits of the value, the decimal point after 'npoint' of them */
+	char		digits[128];
+	int			ndigits = 0, npoint, dscale;
+	{
+		char	m[32];
+		int		nm = snprintf(m, sizeof(m), "%llu", (unsigned long long)mant);
+		if (expo >= 0)
+		{
+			memcpy(digits, m, nm);
+			memset(digits + nm, '0', expo);
+			ndigits = nm + expo;
+			npoint = ndigits;
+			dscale = 0;
+		}
+		else
+		{
+			int		pad = (-expo + 1 > nm ? -expo + 1 - nm : 0);	/* at least one digit in front */
+			memset(digits, '0', pad);
+			memcpy(digits + pad, m, nm);
+			ndigits = pad + nm;
+			npoint = ndigits + expo;
+			dscale = -expo;
+		}
+	}
+	/* base-10000 groups aligned on the decimal point */
+	int16_t		groups[48];
+	int			ngroups = 0, weight;
+	{
+		int		lead = (4 - npoint % 4) % 4;			/* zeros in front of the integer part */
+		int		ipos = -lead;
+		int		nint = (npoint + lead) / 4;
+		int		nfrac = (ndigits - npoint + 3) / 4;
+		for (int g = 0; g < nint + nfrac; g++)
+		{
+			int		v = 0;
+			for (int j = 0; j < 4; j++, ipos++)
+				v = v * 10 + ((ipos >= 0 && ipos < ndigits) ? digits[ipos] - '0' : 0);
+			groups[ngroups++] = (int16_t)v;
+		}
+		weight = nint - 1;
+	}
+	int			first = 0;
+	while (first < ngroups && groups[first] == 0)
+	{
+		first++;
+		weight--;
+	}
+	while (ngroups > first && groups[ngroups - 1] == 0)
+		ngroups--;
+	if (mant == 0)
+	{
+		first = ngroups = 0;
+		weight = 0;
+		sign = false;
+	}
+	int			nd = ngroups - first;
+	bool		shortform = (weight >= -64 && weight <= 63 && dscale <= 63);
+	size_t		len = 4 + (shortform ? 2 : 4) + 2 * (size_t)nd;
+	if (!varlena_out || len > room)
+		return -StromError_DataStoreNoSpace;
+	unsigned char *out = (unsigned char *)varlena_out;
+	uint32_t	vl = (uint32_t)len << 2;				/* SET_VARSIZE, 4-byte header */
+	memcpy(out, &vl, 4);
+	out += 4;
+	if (shortform)
+	{
+		uint16_t h = (uint16_t)(0x8000 | (sign ? 0x2000 : 0) | (dscale << 7) |
+								(weight < 0 ? 0x0040 : 0) | (weight & 0x3f));
+		memcpy(out, &h, 2);
+		out += 2;
+	}
+	else
+	{
+		uint16_t h = (uint16_t)((sign ? 0x4000 : 0) | dscale);
+		int16_t	 w = (int16_t)weight;
+		memcpy(out, &h, 2);
+		memcpy(out + 2, &w, 2);
+		out += 4;
+	}
+	for (int g = first; g < ngroups; g++, out += 2)
+		memcpy(out, &groups[g], 2);
+	return (int)len;
+}
+

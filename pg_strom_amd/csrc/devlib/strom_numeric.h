@@ -439,6 +439,164 @@ STROM_DEVICE pg_numeric_t pgfn_int4_numeric(cl_int *e, pg_int4_t a)
 STROM_DEVICE pg_numeric_t pgfn_int8_numeric(cl_int *e, pg_int8_t a)
 { return strom_integer_to_numeric(e, a.value, a.isnull); }
 
+/*
+ * float4 / float8 -> numeric (float_to_numeric, opencl_numeric.h:625-738; codegen.c:519-520).
+ * PostgreSQL prints the value with FLT_DIG / DBL_DIG significant digits ("%.*g", correctly rounded
+ * by the C library) and reads that back (float4_numeric / float8_numeric, utils/adt/numeric.c): the
+ * result IS the binary value rounded half-to-even to 6 / 15 significant decimal digits.  The
+ * reference gets near that with log10 / exp10 in floating point -- the product value x 10^k is
+ * rounded before the digit is: a few per cent of all doubles come out one off in the 15th digit.
+ * Here the scaling is exact integer arithmetic (value = M x 2^E; M x 2^(E+k) x 5^k in 192 bits,
+ * one extra bit for the half, a sticky flag for what the divisions and shifts drop), so the answer
+ * is PostgreSQL's, and the CPU oracle's, bit for bit.  NaN, infinities and values the 64-bit form
+ * cannot hold are CpuReCheck, as in the reference.
+ */
+/* 192-bit unsigned integers, six 32-bit limbs, little endian: all the arithmetic float -> numeric needs */
+STROM_DEVICE void
+strom_w192_mul_small(cl_uint *w, cl_uint m)
+{
+	cl_ulong	carry = 0;
+	for (int i = 0; i < 6; i++)
+	{
+		cl_ulong t = (cl_ulong)w[i] * m + carry;
+		w[i] = (cl_uint)t;
+		carry = t >> 32;
+	}
+}
+STROM_DEVICE cl_uint
+strom_w192_div_small(cl_uint *w, cl_uint d)
+{
+	cl_ulong	rem = 0;
+	for (int i = 5; i >= 0; i--)
+	{
+		cl_ulong t = (rem << 32) | w[i];
+		w[i] = (cl_uint)(t / d);
+		rem = t % d;
+	}
+	return (cl_uint)rem;
+}
+STROM_DEVICE void
+strom_w192_shl(cl_uint *w, int n)
+{
+	int		limbs = n / 32, bits = n % 32;
+	for (int i = 5; i >= 0; i--)
+	{
+		cl_ulong lo = (i - limbs >= 0 ? w[i - limbs] : 0), lo2 = (i - limbs - 1 >= 0 ? w[i - limbs - 1] : 0);
+		w[i] = (cl_uint)(bits ? ((lo << bits) | (lo2 >> (32 - bits))) : lo);
+	}
+}
+/* >> n; returns whether a 1 bit was shifted out */
+STROM_DEVICE int
+strom_w192_shr(cl_uint *w, int n)
+{
+	int		limbs = n / 32, bits = n % 32, sticky = 0;
+	for (int i = 0; i < 6; i++)
+	{
+		if (i < limbs)
+			sticky |= (w[i] != 0);
+		else if (i == limbs && bits)
+			sticky |= ((w[i] & ((1u << bits) - 1)) != 0);
+	}
+	for (int i = 0; i < 6; i++)
+	{
+		cl_ulong lo = (i + limbs < 6 ? w[i + limbs] : 0), hi = (i + limbs + 1 < 6 ? w[i + limbs + 1] : 0);
+		w[i] = (cl_uint)(bits ? ((lo >> bits) | (hi << (32 - bits))) : lo);
+	}
+	return sticky;
+}
+
+/*
+ * round_half_even(M x 2^E x 10^k), exactly: multiplications and left shifts first, then one more
+ * bit (the half), then divisions and right shifts with a sticky flag.  0 when it does not fit 64 bits.
+ */
+STROM_DEVICE int
+strom_scaled_mantissa(cl_ulong M, int E, int k, cl_ulong *p_mant)
+{
+	cl_uint	w[6] = { (cl_uint)M, (cl_uint)(M >> 32), 0, 0, 0, 0 };
+	int		a = E + k, b = k, sticky = 0;		/* x 2^a x 5^b */
+
+	if (b > 47 || b < -36 || a > 130 || a < -185)
+		return 0;
+	for (; b >= 13; b -= 13)
+		strom_w192_mul_small(w, 1220703125u);		/* 5^13 */
+	for (; b > 0; b--)
+		strom_w192_mul_small(w, 5u);
+	if (a > 0)
+		strom_w192_shl(w, a);
+	strom_w192_shl(w, 1);
+	for (; b <= -13; b += 13)
+		sticky |= (strom_w192_div_small(w, 1220703125u) != 0);
+	for (; b < 0; b++)
+		sticky |= (strom_w192_div_small(w, 5u) != 0);
+	if (a < 0)
+		sticky |= strom_w192_shr(w, -a);
+	if (w[2] | w[3] | w[4] | w[5])
+		return 0;
+	cl_ulong	q = ((cl_ulong)w[1] << 32) | w[0];
+	cl_ulong	mant = q >> 1;
+	if ((q & 1) && (sticky || (mant & 1)))
+		mant++;									/* above the half, or the tie to even */
+	*p_mant = mant;
+	return 1;
+}
+
+STROM_DEVICE pg_numeric_t
+strom_float_to_numeric(cl_int *errcode, cl_double value, bool isnull, int dig)
+{
+	pg_numeric_t	v;
+
+	v.isnull = true;
+	v.value = 0;
+	if (isnull)
+		return v;
+	if (__builtin_isnan(value) || __builtin_isinf(value))
+	{
+		STROM_SET_ERROR(errcode, StromError_CpuReCheck);
+		return v;
+	}
+	if (value == 0.0)
+	{
+		v.isnull = false;
+		return v;
+	}
+	cl_ulong	bits = (cl_ulong)__double_as_longlong(value);
+	bool		sign = (bits >> 63) != 0;
+	int			be = (int)((bits >> 52) & 0x7ff);
+	cl_ulong	M = (bits & 0xfffffffffffffUL) | (be ? (1UL << 52) : 0);
+	int			E = (be ? be : 1) - 1075;		/* value = M x 2^E */
+	int			e2 = 63 - __builtin_clzl(M) + E;	/* floor(log2(value)) */
+	int			e10 = (e2 * 1233) >> 12;			/* floor(e2 x log10(2)), give or take one */
+	int			k = dig - 1 - e10;					/* value x 10^k: 'dig' digits in front of the point */
+	cl_ulong	lim = 1, mant = 0;
+	for (int i = 0; i < dig; i++)
+		lim *= 10;
+	bool		ok = false;
+	for (int turn = 0; turn < 4; turn++)
+	{
+		if (!strom_scaled_mantissa(M, E, k, &mant))
+			break;
+		if (mant > lim)
+			k--;
+		else if (mant < lim / 10)
+			k++;
+		else
+		{
+			ok = true;
+			break;
+		}
+	}
+	if (!ok)
+	{
+		STROM_SET_ERROR(errcode, StromError_CpuReCheck);
+		return v;
+	}
+	return strom_numeric_pack(errcode, -k, sign, mant);		/* (mant == 10^dig: normalised there) */
+}
+STROM_DEVICE pg_numeric_t pgfn_float4_numeric(cl_int *e, pg_float4_t a)
+{ return strom_float_to_numeric(e, (cl_double)a.value, a.isnull, 6); }
+STROM_DEVICE pg_numeric_t pgfn_float8_numeric(cl_int *e, pg_float8_t a)
+{ return strom_float_to_numeric(e, a.value, a.isnull, 15); }
+
 /* numeric -> integer: round half away from zero, then range check */
 STROM_DEVICE bool
 strom_numeric_to_int64(pg_numeric_t arg, cl_long lo, cl_long hi, cl_long *p_value)

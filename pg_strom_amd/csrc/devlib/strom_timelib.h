@@ -57,6 +57,11 @@ pgfn_date_timestamp(cl_int *errcode, pg_date_t arg1)
 	return result;
 }
 
+/* date(date), time(time), timestamp(timestamp): the catalog's alias casts (codegen.c:543-548, "ta/c:") */
+STROM_DEVICE pg_date_t pgfn_date_date(cl_int *errcode, pg_date_t arg1) { return arg1; }
+STROM_DEVICE pg_time_t pgfn_time_time(cl_int *errcode, pg_time_t arg1) { return arg1; }
+STROM_DEVICE pg_timestamp_t pgfn_timestamp_timestamp(cl_int *errcode, pg_timestamp_t arg1) { return arg1; }
+
 STROM_DEVICE pg_date_t
 pgfn_timestamp_date(cl_int *errcode, pg_timestamp_t arg1)
 {

@@ -84,3 +84,43 @@ def test_column_head_equals_the_head_of_a_built_chunk():
     assert np.array_equal(head[8:], full[8:len(head)])
     assert np.array_equal(full[voff[1]:voff[1] + 8 * n].view(np.float64), b)
     assert np.array_equal(full[voff[3]:voff[3] + n].view(np.int8), d)
+
+
+def test_fixup_kernel_numeric_makes_postgresql_numerics():
+    """strom_fixup_kernel_numeric / strom_kernel_numeric_cstring <- pgstrom_fixup_kernel_numeric
+    (datastore.c:150-167): a 64-bit device numeric as PostgreSQL's own datum.  The datum must be
+    byte for byte what PostgreSQL 9.4 stores for the value (numeric_golden.pg_numeric_varlena, the
+    encoder the reference's recheck_agg literals go through; 4-byte varlena header here), the
+    oracle's varlena reader (opencl_numeric.h:166-307) must give the image back, and the text must
+    be the reference's own "%c%lue%d"."""
+    import ctypes
+    from decimal import Decimal
+    import numeric_golden as ng
+    import oracle_binding as oracle
+    from pg_strom_amd._lib import lib
+    from test_numeric_cpu import random_numerics
+    vals = list(random_numerics(3000, 31)) + [Decimal(0), Decimal("1E+31"), Decimal("-1E-32"), Decimal("144115188075855871"),
+                                              Decimal("-14411518807585587E+30"), Decimal("0.0001"), Decimal("10000"),
+                                              Decimal("99999999.99990000"), Decimal("1E+48"), Decimal("5E-30")]
+    buf = ctypes.create_string_buffer(256)
+    datums = []
+    for d in vals:
+        img = kds.numeric_encode(d)
+        assert img is not None
+        n = lib.strom_fixup_kernel_numeric(img, buf, 256)
+        assert n > 0
+        got = buf.raw[:n]
+        want = ng.pg_numeric_varlena(kds.numeric_decode(img))          # (the image's own exponent: its display scale)
+        body = want[1:] if want[0] & 1 else want[4:]
+        assert got[4:] == body and int.from_bytes(got[:4], "little") == n << 2, (d, got.hex(), want.hex())
+        datums.append(got)
+        m = lib.strom_kernel_numeric_cstring(img, buf, 256)
+        exp = int(img) >> 58
+        exp = exp - 64 if exp >= 32 else exp
+        assert buf.raw[:m].decode() == "%s%de%d" % ("-" if (int(img) >> 57) & 1 else "+", int(img) & ((1 << 57) - 1), exp)
+        assert Decimal(buf.raw[:m].decode()) == d
+    assert lib.strom_fixup_kernel_numeric(kds.numeric_encode(Decimal("123.456")), buf, 7) == -301
+    # round trip through a heap chunk: the oracle reads the datums back as the same images
+    chunk = kds.build_kds("row", [kds.Column("numeric_raw", datums)])
+    oid, v, isn, err = oracle.eval_rows("(numeric_uplus (var 1 numeric))", chunk)
+    assert not err.any() and [int(x) for x in v] == [int(kds.numeric_encode(d)) for d in vals]

@@ -219,3 +219,69 @@ def test_varlena_numeric_decode_and_heap_layout():
         assert Decimal(int(v[0, 1].view(np.int64))).scaleb(-6) == sum(x for x, n in zip(vals, isnull) if not n)
     with pytest.raises(ValueError):
         kds.build_kds("column", [kds.Column("numeric_varlena", imgs)])      # heap tuples only
+
+
+def float_numeric_cases():
+    rng = np.random.default_rng(77)
+    f8 = np.concatenate([
+        rng.normal(size=3000) * 10.0 ** rng.integers(-20, 30, 3000),
+        rng.integers(-10**15, 10**15, 500).astype(np.float64),              # integers: exact
+        np.array([0.0, -0.0, 1.0, -1.0, 0.1, 0.5, 1e15, 1e16, 999999999999999.9, 123456789012345.6,
+                  2.5e-10, 1e-17, 9.999999999999999e22, 1e22, 1e23, 5e-324, 1e-33, 1e-40, 1.5e48, 1e49, 1e300,
+                  np.inf, -np.inf, np.nan, 0.30000000000000004, 4.35, 2.675, 1e-5, 123456.5, 1234565.0])])
+    f4 = np.concatenate([(rng.normal(size=2000) * 10.0 ** rng.integers(-12, 20, 2000)).astype(np.float32),
+                         np.array([0.0, 1.0, 0.1, 16777216.0, 1234567.0, 999999.5, 3.4e38, 1e-30, 1e-38,
+                                   np.inf, np.nan, 123456.5, 0.15625], dtype=np.float32)])
+    return f8, f4
+
+
+def postgres_float_numeric(x, dig):
+    """float8_numeric / float4_numeric of PostgreSQL 9.4 (utils/adt/numeric.c): sprintf("%.*g", DBL_DIG /
+    FLT_DIG, val), then numeric_in -- the value at 15 / 6 significant digits; NaN is a numeric NaN and
+    infinity an error there: neither has a 64-bit device form"""
+    if np.isnan(x) or np.isinf(x):
+        return None
+    return Decimal("%.*g" % (dig, float(x)))
+
+
+def check_float_numeric(values, images, errs, dig):
+    """an image per value (or CpuReCheck) against PostgreSQL's answer: exactly that value, as the
+    canonical (normalised) image -- or CpuReCheck where the 64-bit form cannot hold it"""
+    nre = 0
+    for x, img, e in zip(values, images, errs):
+        want = postgres_float_numeric(x, dig)
+        if want is None or kds.numeric_encode(want) is None:
+            assert e, (x, want)                     # not representable: CpuReCheck
+            nre += 1
+            continue
+        assert not e, (x, want)
+        assert kds.numeric_decode(img) == want and kds.numeric_encode(want) == int(img), (x, kds.numeric_decode(img), want)
+    return nre
+
+
+def test_float_to_numeric_is_postgresql_float_numeric():
+    """numeric(float8) / numeric(float4) (codegen.c:519-520, float_to_numeric opencl_numeric.h:625-738):
+    the oracle's statement against PostgreSQL's own definition, through Python's correctly rounded
+    "%.15g" / "%.6g"."""
+    f8, f4 = float_numeric_cases()
+    buf = kds.build_kds("column", [kds.Column("float8", f8)])
+    oid, v, isn, err = oracle.eval_rows("(numeric (var 1 float8))", buf)
+    assert oid == 1700 and np.array_equal(isn, err != 0)    # a rechecked value is NULL + CpuReCheck
+    assert check_float_numeric(f8, v, err, 15) >= 8
+    buf = kds.build_kds("row", [kds.Column("float4", f4)])
+    oid, v, isn, err = oracle.eval_rows("(numeric (var 1 float4))", buf)
+    assert check_float_numeric(f4, v, err, 6) >= 2
+    # and it composes: compared as numerics, summed as numerics
+    buf = kds.build_kds("column", [kds.Column("float8", np.array([0.1, 0.2, 2.5]))])
+    rc, res = oracle.gpuscan("(numeric_lt (numeric (var 1 float8)) (const numeric 0.15))", buf)
+    assert rc == 0 and list(res) == [1]
+
+
+def test_identity_casts_of_the_catalog():
+    """date(date), time(time), timestamp(timestamp): alias casts (codegen.c:543-548)"""
+    d = np.array([0, 7000, -1000], dtype=np.int32)
+    t = np.array([0, 86399999999, 1], dtype=np.int64)
+    buf = kds.build_kds("column", [kds.Column("date", d), kds.Column("time", t), kds.Column("timestamp", t * 1000)])
+    for spec, col in (("(date (var 1 date))", d), ("(time (var 2 time))", t), ("(timestamp (var 3 timestamp))", t * 1000)):
+        oid, v, isn, err = oracle.eval_rows(spec, buf)
+        assert not err.any() and list(v.view(np.int64)[:3]) == [int(x) for x in col]

@@ -230,3 +230,26 @@ def test_varlena_numerics_in_heap_tuples(fmt):
     assert np.array_equal(dec[1]["notnull"], ~isnull)
     assert np.array_equal(dec[1]["values"].view(np.uint64)[~isnull], imgs[~isnull])
     assert not dec[1]["values"][isnull].any()
+
+
+@pytest.mark.parametrize("ftype,dig", [("float8", 15), ("float4", 6)])
+def test_float_to_numeric_on_device_equals_oracle(ftype, dig):
+    """numeric(float8) / numeric(float4) (codegen.c:519-520, float_to_numeric opencl_numeric.h:625-738):
+    the device's 192-bit exact scaling == the oracle's (== PostgreSQL's "%.15g" / "%.6g",
+    tests/test_numeric_cpu.py) for every row, rechecks included; and the catalog's alias casts
+    date(date) / time(time) / timestamp(timestamp) in the same program"""
+    from test_numeric_cpu import float_numeric_cases
+    f8, f4 = float_numeric_cases()
+    vals = f8 if ftype == "float8" else f4
+    n = len(vals)
+    d = (np.arange(n) % 9000 - 4000).astype(np.int32)
+    expr = "(numeric (var 1 %s))" % ftype
+    buf = kds.build_kds("column", [kds.Column(ftype, vals), kds.Column("date", d)])
+    oid, v, isn, err = oracle.eval_rows(expr, buf)
+    buf3 = kds.build_kds("column", [kds.Column(ftype, vals), kds.Column("date", d), kds.Column("numeric", v, isn)])
+    scan = GpuScan("(and (numeric_eq %s (var 3 numeric)) (date_eq (date (var 2 date)) (var 2 date)))" % expr).begin()
+    res = scan.scan_chunk(buf3)
+    scan.end()
+    assert np.array_equal(res.passed_rows(), np.nonzero(err == 0)[0])
+    assert np.array_equal(res.recheck_rows(), np.nonzero(err == 2)[0])
+    assert (err == 2).sum() >= 2 and (err == 0).sum() > 0.9 * n
