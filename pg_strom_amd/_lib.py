@@ -8,7 +8,9 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libstrom_hip.so")
+# (STROM_HIP_LIBRARY: another build of the same library -- the sanitizer build of
+# scripts/cpu_suite_sanitized.sh; there is still no fallback: the named file must load)
+LIB_PATH = os.environ.get("STROM_HIP_LIBRARY") or os.path.join(_HERE, "libstrom_hip.so")
 
 c_void_p = ctypes.c_void_p
 c_int = ctypes.c_int

@@ -8,7 +8,8 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ORACLE_DIR = os.path.join(ROOT, "oracle")
-LIB_PATH = os.path.join(ORACLE_DIR, "liboracle.so")
+# (STROM_ORACLE_LIBRARY: the sanitizer build of the same sources, scripts/cpu_suite_sanitized.sh)
+LIB_PATH = os.environ.get("STROM_ORACLE_LIBRARY") or os.path.join(ORACLE_DIR, "liboracle.so")
 
 
 def build_oracle():
