@@ -555,8 +555,13 @@ int			strom_gpupreagg_allreduce(strom_gpupreagg *sess, void *comm, void *stream)
  * strom_gpupreagg_allreduce() packs each rank's groups on the device, all-gathers the
  * counts and the records (padded to the largest rank) and merges the other ranks' records
  * into the rank's own table -- every rank ends up with every group, as above.
- * strom_gpupreagg_merge() is the same merge between two hashed sessions of ONE device
- * (same program): src's groups are added to dst's table, src is left as it is.
+ * strom_gpupreagg_merge() is the same merge between two sessions of ONE device: src's groups are
+ * added to dst's table, src is left as it is.  Hashed sessions: export + import, as above.  Dense
+ * sessions (same program, same domain, same compaction): the tables are added lane by lane with the
+ * all-reduce merge's own prepare / operator / finish steps -- identities for entries without a value,
+ * sign flips for the float min / max keys, flags as bytes under MAX, integer sums as carry-free limbs
+ * (they are 128 bits wide in the table and must not wrap in the merge either).  Sessions that do not
+ * match are refused with StromError_BadRequestMessage.
  */
 int			strom_gpupreagg_merge(strom_gpupreagg *dst, strom_gpupreagg *src);
 int			strom_gpupreagg_census_allreduce(strom_gpupreagg *sess, void *comm, void *stream);
