@@ -852,7 +852,18 @@ emit_expr(const sexpr &n, codegen_context &ctx, std::string &out)
 			int		scale = (n.items[3].is_list ? -1 : atoi(n.items[3].atom.c_str()));
 			if (t->type_oid != STROM_NUMERICOID || scale < 0 || scale > 18)
 				codegen_error("(var ATTNO numeric SCALE): scale 0..18 on a numeric column expected");
-			out += std::string("pgfn_numeric_as_fixed(errcode, ") + tmp + ", " + std::to_string(scale) + ")";
+			if (ctx.fixed_cache)
+			{
+				bool	known = false;
+				for (auto &f : ctx.used_fixed)
+					known = known || (f.attno == attno && f.scale == scale);
+				if (!known)
+					ctx.used_fixed.push_back({attno, scale});
+				out += std::string("pg_fixed_cached(errcode, ") + ctx.var_struct + ".KFIX_" +
+					std::to_string(attno) + "_" + std::to_string(scale) + ")";
+			}
+			else
+				out += std::string("pgfn_numeric_as_fixed(errcode, ") + tmp + ", " + std::to_string(scale) + ")";
 			return STROM_FIXED_BASE + scale;
 		}
 		out += tmp;

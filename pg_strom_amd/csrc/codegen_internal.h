@@ -36,6 +36,17 @@ struct codegen_context {
 	struct ivar_ref { int depth, attno, type_oid; };
 	int								ivar_max_depth = 0;	/* 0: ivar not allowed here */
 	std::vector<ivar_ref>			used_ivars;
+	/*
+	 * (var N numeric SCALE) read through a per-row cache: the 64-bit image is converted to fixed
+	 * point ONCE per row, where the row's variables are assembled (strom_kvars.KFIX_<N>_<SCALE>,
+	 * filled by STROM_KVARS_FINISH), instead of once per use in every expression that reads the
+	 * column -- the conversion is 40 % of a Q1-shaped row and the compiler does not merge the
+	 * copies across the generated functions.  GpuPreAgg programs only (the emitter that owns the
+	 * row assembly sets it).
+	 */
+	bool							fixed_cache = false;
+	struct fixed_ref { int attno, scale; };
+	std::vector<fixed_ref>			used_fixed;
 
 	int		track_param(const strom_kparam_desc &d);
 	void	track_var(int attno, int type_oid);

@@ -34,6 +34,8 @@ struct target {
 	 */
 	int			sumbits = 0;
 	int			key_attno = 0;	/* a group key that is a plain column (var N T): N, else 0 */
+	bool		countall = false;	/* nrows() whose arguments only say "column X is not NULL": in a chunk
+									 * without NULL bitmaps it counts what count(*) counts */
 	int			kind;
 	int			type_oid;	/* type of the partial value as the caller sees it */
 	int			acc_oid;	/* type of the device accumulator */
@@ -119,6 +121,7 @@ strom_codegen_gpupreagg(const char *spec, strom_codegen_result *out,
 		ctx.var_label = "KVAR";
 		ctx.var_struct = "KV";
 		ctx.extra_flags = DEVKERNEL_NEEDS_GPUPREAGG | DEVFUNC_NEEDS_MATHLIB;
+		ctx.fixed_cache = true;				/* (var N numeric SCALE): converted once per row */
 		sexpr tree = sexpr_parse(spec);
 		if (!tree.is_list || tree.items.empty() || tree.items[0].is_list ||
 			tree.items[0].atom != "gpupreagg")
@@ -169,9 +172,16 @@ strom_codegen_gpupreagg(const char *spec, strom_codegen_result *out,
 				tg.kind = STROM_PREAGG_NROWS;
 				tg.type_oid = STROM_INT4OID;
 				std::string cond;
+				tg.countall = true;
 				for (size_t a = 1; a <= nargs; a++)
 				{
 					std::string e;
+					const sexpr &x = t.items[a];
+					/* (isnotnull (var N ...)) and nothing else? */
+					if (!(x.is_list && x.items.size() == 2 && !x.items[0].is_list && x.items[0].atom == "isnotnull" &&
+						  x.items[1].is_list && !x.items[1].items.empty() && !x.items[1].items[0].is_list &&
+						  x.items[1].items[0].atom == "var"))
+						tg.countall = false;
 					if (codegen_expression(t.items[a], ctx, e) != STROM_BOOLOID)
 						codegen_error("nrows() argument is not boolean");
 					/* every argument is evaluated: no short circuit, so a
@@ -263,6 +273,7 @@ strom_codegen_gpupreagg(const char *spec, strom_codegen_result *out,
 							{
 								tg.pack_kind = 2;
 								tg.pack_attno = attno;
+								tg.sumbits = 65;		/* a plain column: its zone map bounds the inputs */
 							}
 						}
 					}
@@ -283,6 +294,8 @@ strom_codegen_gpupreagg(const char *spec, strom_codegen_result *out,
 					{
 						tg.pack_kind = (tg.type_oid == STROM_INT8OID ? 2 : 3);
 						tg.pack_attno = attno;
+						if (tg.sumbits == 64 && tg.pack_kind == 2)
+							tg.sumbits = 65;			/* a plain int8 column: its zone map bounds the inputs */
 					}
 				}
 			}
@@ -356,6 +369,7 @@ strom_codegen_gpupreagg(const char *spec, strom_codegen_result *out,
 		std::string agg_list = "#define GPUPREAGG_AGG_LIST(X)";
 		std::string pack_list = "#define GPUPREAGG_PACK_LIST(X)";
 		std::string sumbits_defs;
+		int		countall_first = -1;
 		/* group keys that are plain columns: X(kidx, attno) -- their zone maps bound the dense ids
 		 * of a COLUMN chunk without a pass over it (gpupreagg.cpp: chunk_domain) */
 		std::string keycols = "#define GPUPREAGG_KEYCOLS_LIST(X)";
@@ -388,6 +402,11 @@ strom_codegen_gpupreagg(const char *spec, strom_codegen_result *out,
 				packable = packable && (tg.pack_kind != 0);
 				snprintf(tmp, sizeof(tmp), "#define GPUPREAGG_SUMBITS_%d %d\n", naggs, tg.sumbits);
 				sumbits_defs += tmp;
+				snprintf(tmp, sizeof(tmp), "#define GPUPREAGG_COUNTALL_%d %d\n", naggs,
+						 (tg.kind == STROM_PREAGG_NROWS && tg.countall) ? 1 : 0);
+				sumbits_defs += tmp;
+				if (tg.kind == STROM_PREAGG_NROWS && tg.countall && countall_first < 0)
+					countall_first = naggs;
 				funcs += fn_header(tname, "gpupreagg_agg", naggs) + "{\n" + tg.body + "}\n";
 				naggs++;
 			}
@@ -459,6 +478,16 @@ strom_codegen_gpupreagg(const char *spec, strom_codegen_result *out,
 				 targets.size(), nkeys, naggs);
 		src += tmp;
 		src += key_list + "\n" + agg_list + "\n" + keycols + "\n";
+		{
+			/* the per-row fixed-point cache: X(attno, scale) (codegen_internal.h: fixed_cache) */
+			std::string fl = "#define STROM_KFIXED_LIST(X)";
+			for (auto &f : ctx.used_fixed)
+			{
+				snprintf(tmp, sizeof(tmp), " X(%d,%d)", f.attno, f.scale);
+				fl += tmp;
+			}
+			src += fl + "\n";
+		}
 		/* packed accumulators: X(aidx, kind, attno of the source column) -- see strom_gpupreagg.h */
 		snprintf(tmp, sizeof(tmp), "#define GPUPREAGG_NUMERIC_AGGS %d\n", numeric_aggs ? 1 : 0);
 		src += tmp;
@@ -467,6 +496,8 @@ strom_codegen_gpupreagg(const char *spec, strom_codegen_result *out,
 		src += pack_list + "\n";
 		/* integer sums: static magnitude bound per aggregate (see struct target) */
 		src += sumbits_defs;
+		snprintf(tmp, sizeof(tmp), "#define GPUPREAGG_COUNTALL_FIRST %d\n", countall_first);
+		src += tmp;
 		{
 			bool	any = false;
 			for (auto &tg : targets)

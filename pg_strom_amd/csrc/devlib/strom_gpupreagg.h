@@ -55,12 +55,32 @@ struct strom_kparams {
 #undef X
 	int __dummy;
 };
+#ifndef STROM_KFIXED_LIST
+#define STROM_KFIXED_LIST(X)
+#endif
 struct strom_kvars {
 #define X(attno,colidx,NAME)	pg_##NAME##_t KVAR_##attno;
 	STROM_KVAR_LIST(X)
 #undef X
+	/* (var N numeric SCALE) as fixed point, converted once per row: STROM_KVARS_FINISH */
+#define X(attno,scale)			pg_fixed_cache_t KFIX_##attno##_##scale;
+	STROM_KFIXED_LIST(X)
+#undef X
 	int __dummy;
 };
+/*
+ * the row's variables are assembled: convert the numeric columns the program reads as fixed point
+ * (the conversion raises nothing here -- a row the qual drops must not send the chunk back; whoever
+ * USES the value sees its flag: pg_fixed_cached, strom_numeric.h)
+ */
+#define STROM_KFIXED_FILL_ONE(attno,scale)	\
+	(KV_).KFIX_##attno##_##scale = pg_fixed_cache_fill((KV_).KVAR_##attno, scale);
+#define STROM_KVARS_FINISH(KV)				\
+	do {									\
+		strom_kvars &KV_ = (KV);			\
+		KV_.__dummy = 0;					\
+		STROM_KFIXED_LIST(STROM_KFIXED_FILL_ONE)	\
+	} while (0)
 
 STROM_DEVICE pg_bool_t
 gpupreagg_qual_eval(cl_int *errcode, const strom_kparams &KP, const strom_kvars &KV);
@@ -472,7 +492,27 @@ gpupreagg_sum_magnitude(cl_long v)
  * here -- carries the rows of the whole request
  */
 #define KERN_GPUPREAGG_SUM_MAGBITS(kgp)		((cl_uint *)((kgp)->__padding))
-#define KERN_GPUPREAGG_WG_ROWS(kgp)			(*(const cl_uint *)((kgp)->__padding + 4))
+#define KERN_GPUPREAGG_WG_ROWS(kgp)			(*(const cl_uint *)((kgp)->__padding + 4) & 0x7fffffffu)
+/* top bit of that word: the host has bounded the sums of PLAIN columns (GPUPREAGG_SUMBITS_<a> 65)
+ * by the chunk's zone maps -- the fold need not measure them */
+#define KERN_GPUPREAGG_ZONE_BOUNDED(kgp)	((*(const cl_uint *)((kgp)->__padding + 4) >> 31) != 0)
+/*
+ * per-launch facts the row functions take as one word:
+ *   ROWFLAG_ZONE_BOUNDED   see above
+ *   ROWFLAG_ALL_NOTNULL    no column of the chunk has a NULL bitmap: every nrows() whose arguments
+ *                          only say "column X is not NULL" (GPUPREAGG_COUNTALL_<a>) counts exactly
+ *                          what count(*) counts -- ONE of them is accumulated (GPUPREAGG_COUNTALL_FIRST),
+ *                          gpupreagg_store_slab copies it to the others (Q1: four counters, one atomic)
+ */
+#define ROWFLAG_ZONE_BOUNDED	1u
+#define ROWFLAG_ALL_NOTNULL		2u
+#ifndef GPUPREAGG_COUNTALL_FIRST
+#define GPUPREAGG_COUNTALL_FIRST	(-1)
+#endif
+#define GPUPREAGG_MEASURE_SUM(aidx, rowflags)	\
+	(GPUPREAGG_SUMBITS_##aidx == 64 || (GPUPREAGG_SUMBITS_##aidx == 65 && !((rowflags) & ROWFLAG_ZONE_BOUNDED)))
+#define GPUPREAGG_COUNT_IS_ALIASED(aidx, rowflags)	\
+	(GPUPREAGG_COUNTALL_##aidx && (aidx) != GPUPREAGG_COUNTALL_FIRST && ((rowflags) & ROWFLAG_ALL_NOTNULL))
 #define KERN_GPUPREAGG_FOLD_NROWS(kgp)		((cl_uint)(kgp)->sortbuf_len)
 
 STROM_DEVICE void
@@ -542,7 +582,8 @@ STROM_DEVICE void
 gpupreagg_dense_row(char *lds, const gpupreagg_dense_ctl *ctl, const gpupreagg_lds_layout &L,
 					const strom_kparams &KP, const strom_kvars &KV,
 					cl_uint gid_lo, cl_uint G, cl_uint NREP, cl_uint rep,
-					cl_int param_error, cl_int *chunk_status, cl_ulong &summag, bool qual_done = false)
+					cl_int param_error, cl_int *chunk_status, cl_ulong &summag, cl_uint rowflags,
+					bool qual_done = false)
 {
 	cl_int		errcode = param_error;
 	cl_uint		gid = 0;
@@ -601,9 +642,10 @@ gpupreagg_dense_row(char *lds, const gpupreagg_dense_ctl *ctl, const gpupreagg_l
 
 #define X(aidx,resno,OP,NAME)														\
 	/* an integer sum without a static bound: measure (see "integer sums never wrap") */	\
-	if (gpupreagg_is_intsum<GPUPREAGG_OP_##OP, pg_##NAME##_base_t>::value && GPUPREAGG_SUMBITS_##aidx >= 64)	\
+	if (gpupreagg_is_intsum<GPUPREAGG_OP_##OP, pg_##NAME##_base_t>::value && GPUPREAGG_MEASURE_SUM(aidx, rowflags))	\
 		summag |= (av_##aidx.isnull ? 0UL : gpupreagg_sum_magnitude((cl_long)av_##aidx.value));	\
-	need |= gpupreagg_lds_accum<GPUPREAGG_OP_##OP, aidx>(lds, L.vals_off[aidx], slot, av_##aidx, chunk_status);
+	if (!(GPUPREAGG_OP_##OP == GPUPREAGG_OP_NROWS && GPUPREAGG_COUNT_IS_ALIASED(aidx, rowflags)))	\
+		need |= gpupreagg_lds_accum<GPUPREAGG_OP_##OP, aidx>(lds, L.vals_off[aidx], slot, av_##aidx, chunk_status);
 	GPUPREAGG_AGG_LIST(X)
 #undef X
 	/* flags: read, and only touch the word when something is missing */
@@ -639,7 +681,7 @@ gpupreagg_lds_init(char *lds, const gpupreagg_lds_layout &L, cl_uint G, cl_uint 
 /* fold replicas and store the work-group's slab (REP = 1 image) */
 STROM_DEVICE void
 gpupreagg_store_slab(const char *lds, const gpupreagg_lds_layout &L, char *slab,
-					 cl_uint G, cl_uint NREP, cl_int *chunk_status)
+					 cl_uint G, cl_uint NREP, cl_int *chunk_status, cl_uint rowflags = 0)
 {
 	const gpupreagg_flags_t *lflags = (const gpupreagg_flags_t *)lds;
 
@@ -653,7 +695,10 @@ gpupreagg_store_slab(const char *lds, const gpupreagg_lds_layout &L, char *slab,
 	}
 #define X(aidx,resno,OP,NAME)																\
 	{																						\
-		const char *lvals = lds + L.vals_off[aidx];											\
+		/* (an aliased count was never added to: it is the first such counter's, see ROWFLAG_ALL_NOTNULL) */	\
+		const char *lvals = lds + L.vals_off[(GPUPREAGG_OP_##OP == GPUPREAGG_OP_NROWS &&		\
+											  GPUPREAGG_COUNT_IS_ALIASED(aidx, rowflags))		\
+											 ? GPUPREAGG_COUNTALL_FIRST : aidx];				\
 		char	   *svals = slab + gpupreagg_image_offset(1 + aidx, G, 1);					\
 		if (GPUPREAGG_OP_##OP == GPUPREAGG_OP_NROWS)											\
 		{																					\
@@ -1033,6 +1078,8 @@ gpupreagg_dense_column_body(kern_gpupreagg *kgpreagg,
 #define X(attno,colidx,NAME)	any_nulls = any_nulls || (nul_##attno != NULL);
 	STROM_KVAR_LIST(X)
 #undef X
+	const cl_uint rowflags = (KERN_GPUPREAGG_ZONE_BOUNDED(kgpreagg) ? ROWFLAG_ZONE_BOUNDED : 0u) |
+		(any_nulls ? 0u : ROWFLAG_ALL_NOTNULL);
 
 	char	   *my_slab = slabs + (size_t)(wg_in_split * nsplits + split) * ctl->slab_bytes;
 #if defined(GPUPREAGG_PACKABLE) && GPUPREAGG_PACKABLE
@@ -1121,14 +1168,14 @@ gpupreagg_dense_column_body(kern_gpupreagg *kgpreagg,
 													   !((T.nn_##attno[k] >> j) & 1));
 					STROM_KVAR_LIST(X)
 #undef X
-					KV.__dummy = 0;
+					STROM_KVARS_FINISH(KV);
 #if defined(GPUPREAGG_PACKABLE) && GPUPREAGG_PACKABLE
 					if (PACKED)
 						gpupreagg_packed_row(lds, ctl, pk, KP, KV, gid_lo, G, param_error, &chunk_status, my_slab);
 					else
 #endif
 						gpupreagg_dense_row(lds, ctl, L, KP, KV, gid_lo, G, NREP, rep,
-											param_error, &chunk_status, summag);
+											param_error, &chunk_status, summag, rowflags);
 				}
 			}
 		}
@@ -1138,7 +1185,7 @@ gpupreagg_dense_column_body(kern_gpupreagg *kgpreagg,
 		gpupreagg_store_slab_packed(lds, pk, my_slab, G, pk->spill_at != 0);
 	else
 #endif
-		gpupreagg_store_slab(lds, L, my_slab, G, NREP, &chunk_status);
+		gpupreagg_store_slab(lds, L, my_slab, G, NREP, &chunk_status, rowflags);
 	gpupreagg_writeback_status(&kgpreagg->status, chunk_status);
 	gpupreagg_writeback_summag(kgpreagg, summag);
 }
@@ -1233,8 +1280,8 @@ gpupreagg_dense_generic_body(kern_gpupreagg *kgpreagg,
 			: pg_##NAME##_vref(kds, ktoast, &errcode, colidx, kds_index));
 		STROM_KVAR_LIST(X)
 #undef X
-		KV.__dummy = 0;
-		gpupreagg_dense_row(lds, ctl, L, KP, KV, gid_lo, G, NREP, rep, errcode, &chunk_status, summag);
+		STROM_KVARS_FINISH(KV);
+		gpupreagg_dense_row(lds, ctl, L, KP, KV, gid_lo, G, NREP, rep, errcode, &chunk_status, summag, 0u);
 	}
 	gpupreagg_store_slab(lds, L, slabs + (size_t)blockIdx.x * ctl->slab_bytes, G, NREP, &chunk_status);
 	gpupreagg_writeback_status(&kgpreagg->status, chunk_status);
@@ -1415,7 +1462,7 @@ gpupreagg_dense_joined(kern_gpupreagg *kgpreagg,
 		else																	\
 			KV.KVAR_##attno = STROM_COLUMN_REF(NAME, val_##attno, nul_##attno, outer_row);
 		STROM_KVAR_LIST_GROUPING(X)
-		KV.__dummy = 0;
+		STROM_KVARS_FINISH(KV);
 		if (nsplits > 1)
 		{
 			/* several id-range roles read every pair: whose row this is follows
@@ -1442,7 +1489,7 @@ gpupreagg_dense_joined(kern_gpupreagg *kgpreagg,
 		}
 		STROM_KVAR_LIST_REST(X)
 #undef X
-		gpupreagg_dense_row(lds, ctl, L, KP, KV, gid_lo, G, NREP, rep, errcode, &chunk_status, summag);
+		gpupreagg_dense_row(lds, ctl, L, KP, KV, gid_lo, G, NREP, rep, errcode, &chunk_status, summag, 0u);
 	}
 	gpupreagg_store_slab(lds, L, slabs + (size_t)blockIdx.x * ctl->slab_bytes, G, NREP, &chunk_status);
 	gpupreagg_writeback_status(&kgpreagg->status, chunk_status);
@@ -1598,6 +1645,9 @@ gpupreagg_dense_lookup_body(kern_gpupreagg *kgpreagg,
 #define X(attno,colidx,NAME)	any_nulls = any_nulls || (nul_##attno != NULL);
 	STROM_KVAR_LIST(X)
 #undef X
+	/* (an inner column may be NULL whatever the chunk's bitmaps say: no count aliasing when the
+	 * program reads one; its columns are virtual, so the host bounds no sum by zone maps) */
+	const cl_uint rowflags = ((any_nulls || inner_mask != 0) ? 0u : ROWFLAG_ALL_NOTNULL);
 	cl_long		key_min = jmap->key_min;
 	cl_uint		nslots = jmap->nslots;
 
@@ -1702,7 +1752,7 @@ gpupreagg_dense_lookup_body(kern_gpupreagg *kgpreagg,
 						: pg_##NAME##_make(T.v_##attno[k][j], !((T.nn_##attno[k] >> j) & 1)));
 					STROM_KVAR_LIST(X)
 #undef X
-					KV.__dummy = 0;
+					STROM_KVARS_FINISH(KV);
 					pg_bool_t	rc = gpupreagg_qual_eval(&qerr, KP, KV);
 					live = !(qerr == StromError_Success && !EVAL(rc));
 					qual_ok[k] |= ((qerr == StromError_Success && EVAL(rc)) ? (1u << j) : 0u);
@@ -1815,7 +1865,7 @@ gpupreagg_dense_lookup_body(kern_gpupreagg *kgpreagg,
 													   !((T.nn_##attno[k] >> j) & 1));
 					STROM_KVAR_LIST(X)
 #undef X
-					KV.__dummy = 0;
+					STROM_KVARS_FINISH(KV);
 #if GPUPREAGG_ABLATE & 1
 					/* (measurement only: nothing is accumulated) */
 					if (gpupreagg_ablate_sink(KV) == 0x12345677)
@@ -1829,7 +1879,7 @@ gpupreagg_dense_lookup_body(kern_gpupreagg *kgpreagg,
 					else
 #endif
 						gpupreagg_dense_row(lds, ctl, L, KP, KV, gid_lo, G, NREP, rep,
-											param_error, &chunk_status, summag, (qual_ok[k] >> j) & 1);
+											param_error, &chunk_status, summag, rowflags, (qual_ok[k] >> j) & 1);
 				}
 			}
 		}
@@ -1852,7 +1902,7 @@ gpupreagg_dense_lookup_body(kern_gpupreagg *kgpreagg,
 		gpupreagg_store_slab_packed(lds, pk, my_slab, G, pk->spill_at != 0);
 	else
 #endif
-		gpupreagg_store_slab(lds, L, my_slab, G, NREP, &chunk_status);
+		gpupreagg_store_slab(lds, L, my_slab, G, NREP, &chunk_status, rowflags);
 	gpupreagg_writeback_status(&kgpreagg->status, chunk_status);
 	gpupreagg_writeback_summag(kgpreagg, summag);
 }
@@ -1942,7 +1992,7 @@ template <int NG>
 STROM_DEVICE void
 gpupreagg_reg_row(gpupreagg_reg_state<NG> &S, const gpupreagg_dense_ctl *ctl,
 				  const strom_kparams &KP, const strom_kvars &KV,
-				  cl_int param_error, cl_int *chunk_status, cl_ulong &summag)
+				  cl_int param_error, cl_int *chunk_status, cl_ulong &summag, cl_uint rowflags)
 {
 	cl_int		errcode = param_error;
 	pg_bool_t	rc = gpupreagg_qual_eval(&errcode, KP, KV);
@@ -1993,7 +2043,7 @@ gpupreagg_reg_row(gpupreagg_reg_state<NG> &S, const gpupreagg_dense_ctl *ctl,
 				 : gpupreagg_f64_ordered((cl_double)av_##aidx.value));				\
 		else																		\
 			x = (cl_ulong)(cl_long)av_##aidx.value;									\
-		if (gpupreagg_is_intsum<GPUPREAGG_OP_##OP, base_t>::value && GPUPREAGG_SUMBITS_##aidx >= 64)	\
+		if (gpupreagg_is_intsum<GPUPREAGG_OP_##OP, base_t>::value && GPUPREAGG_MEASURE_SUM(aidx, rowflags))	\
 			summag |= (has ? gpupreagg_sum_magnitude((cl_long)x) : 0UL);			\
 		if (GPUPREAGG_OP_##OP != GPUPREAGG_OP_NROWS && has)							\
 			need |= (2u << aidx);													\
@@ -2077,6 +2127,7 @@ gpupreagg_reg_kernel_body(kern_gpupreagg *kgpreagg, const kern_data_store *kds,
 #define X(attno,colidx,NAME)	any_nulls = any_nulls || (nul_##attno != NULL);
 	STROM_KVAR_LIST(X)
 #undef X
+	const cl_uint rowflags = (KERN_GPUPREAGG_ZONE_BOUNDED(kgpreagg) ? ROWFLAG_ZONE_BOUNDED : 0u);
 	for (cl_uint tile = blockIdx.x; tile < ntiles; tile += gridDim.x)
 	{
 		cl_uint		tile_base = tile * GPUPREAGG_REG_TILE_ROWS;
@@ -2140,8 +2191,8 @@ gpupreagg_reg_kernel_body(kern_gpupreagg *kgpreagg, const kern_data_store *kds,
 													   !((T.nn_##attno[k] >> j) & 1));
 					STROM_KVAR_LIST(X)
 #undef X
-					KV.__dummy = 0;
-					gpupreagg_reg_row<NG>(S, ctl, KP, KV, param_error, &chunk_status, summag);
+					STROM_KVARS_FINISH(KV);
+					gpupreagg_reg_row<NG>(S, ctl, KP, KV, param_error, &chunk_status, summag, rowflags);
 				}
 			}
 		}
@@ -2248,7 +2299,7 @@ struct gpupreagg_priv_state {
 STROM_DEVICE void
 gpupreagg_priv_row(char *lds, gpupreagg_priv_state &S, const gpupreagg_dense_ctl *ctl,
 				   const strom_kparams &KP, const strom_kvars &KV, cl_uint G,
-				   cl_int param_error, cl_int *chunk_status, cl_ulong &summag)
+				   cl_int param_error, cl_int *chunk_status, cl_ulong &summag, cl_uint rowflags)
 {
 	cl_int		errcode = param_error;
 	pg_bool_t	rc = gpupreagg_qual_eval(&errcode, KP, KV);
@@ -2313,7 +2364,7 @@ gpupreagg_priv_row(char *lds, gpupreagg_priv_state &S, const gpupreagg_dense_ctl
 			else																	\
 			{																		\
 				x = (cl_ulong)(cl_long)av_##aidx.value;								\
-				if (gpupreagg_is_intsum<GPUPREAGG_OP_##OP, base_t>::value && GPUPREAGG_SUMBITS_##aidx >= 64)	\
+				if (gpupreagg_is_intsum<GPUPREAGG_OP_##OP, base_t>::value && GPUPREAGG_MEASURE_SUM(aidx, rowflags))	\
 					summag |= gpupreagg_sum_magnitude((cl_long)x);					\
 			}																		\
 			cur_##aidx = gpupreagg_merge8<GPUPREAGG_OP_##OP == GPUPREAGG_OP_NROWS	\
@@ -2398,6 +2449,7 @@ gpupreagg_priv_column(kern_gpupreagg *kgpreagg, const kern_data_store *kds,
 #define X(attno,colidx,NAME)	any_nulls = any_nulls || (nul_##attno != NULL);
 	STROM_KVAR_LIST(X)
 #undef X
+	const cl_uint rowflags = (KERN_GPUPREAGG_ZONE_BOUNDED(kgpreagg) ? ROWFLAG_ZONE_BOUNDED : 0u);
 	for (cl_uint tile = blockIdx.x; tile < ntiles; tile += gridDim.x)
 	{
 		cl_uint		tile_base = tile * GPUPREAGG_REG_TILE_ROWS;
@@ -2461,8 +2513,8 @@ gpupreagg_priv_column(kern_gpupreagg *kgpreagg, const kern_data_store *kds,
 													   !((T.nn_##attno[k] >> j) & 1));
 					STROM_KVAR_LIST(X)
 #undef X
-					KV.__dummy = 0;
-					gpupreagg_priv_row(lds, S, ctl, KP, KV, G, param_error, &chunk_status, summag);
+					STROM_KVARS_FINISH(KV);
+					gpupreagg_priv_row(lds, S, ctl, KP, KV, G, param_error, &chunk_status, summag, rowflags);
 				}
 			}
 		}
@@ -3088,7 +3140,7 @@ gpupreagg_hash_body(kern_gpupreagg *kgpreagg,
 		KV.KVAR_##attno = STROM_COLUMN_REF(NAME, col_##attno, nul_##attno, kds_index);
 		STROM_KVAR_LIST_REST(X)
 #undef X
-		KV.__dummy = 0;
+		STROM_KVARS_FINISH(KV);
 		if (active)
 			fold_loaded(KV, param_error, kds_index, 0);
 		qhead += nready;
@@ -3145,7 +3197,7 @@ gpupreagg_hash_body(kern_gpupreagg *kgpreagg,
 		 tile * GPUPREAGG_HASH_UNROLL * blockDim.x < nrows;
 		 tile += 8 * (size_t)nmembers)
 	{
-		strom_kvars	KVs[GPUPREAGG_HASH_UNROLL];
+		strom_kvars	KVs[GPUPREAGG_HASH_UNROLL] = {};	/* (with roles the scan fills the grouping columns only) */
 		cl_int		errs[GPUPREAGG_HASH_UNROLL];
 		cl_uint		kidx[GPUPREAGG_HASH_UNROLL];
 		bool		live[GPUPREAGG_HASH_UNROLL];
@@ -3173,7 +3225,7 @@ gpupreagg_hash_body(kern_gpupreagg *kgpreagg,
 				STROM_KVAR_LIST_REST(X)
 			}
 #undef X
-			KVs[j].__dummy = 0;
+			STROM_KVARS_FINISH(KVs[j]);
 			errs[j] = errcode;
 			kidx[j] = kds_index;
 		}
@@ -3470,7 +3522,7 @@ gpupreagg_hash_parts_body(kern_gpupreagg *kgpreagg,
 			: pg_##NAME##_vref(kds, ktoast, &errcode, colidx, kds_index));
 		STROM_KVAR_LIST(X)
 #undef X
-		KV.__dummy = 0;
+		STROM_KVARS_FINISH(KV);
 	};
 	/* keys of a row -> images; false when an expression failed */
 	auto eval_keys = [&](const strom_kvars &KV, cl_int &errcode, cl_ulong *kimg, cl_uint &knull)
@@ -4467,7 +4519,7 @@ gpupreagg_census_body(const kern_gpupreagg *kgpreagg, const kern_data_store *kds
 			: pg_##NAME##_vref(kds, ktoast, &errcode, colidx, kds_index));
 		STROM_KVAR_LIST(X)
 #undef X
-		KV.__dummy = 0;
+		STROM_KVARS_FINISH(KV);
 		pg_bool_t	rc = gpupreagg_qual_eval(&errcode, KP, KV);
 		if (errcode == StromError_Success && !EVAL(rc))
 			continue;
@@ -4574,7 +4626,7 @@ gpupreagg_keyrange_body(const kern_gpupreagg *kgpreagg, const kern_data_store *k
 			: pg_##NAME##_vref(kds, ktoast, &errcode, colidx, kds_index));
 		STROM_KVAR_LIST(X)
 #undef X
-		KV.__dummy = 0;
+		STROM_KVARS_FINISH(KV);
 		pg_bool_t	rc = gpupreagg_qual_eval(&errcode, KP, KV);
 		if (errcode == StromError_Success && !EVAL(rc))
 			continue;

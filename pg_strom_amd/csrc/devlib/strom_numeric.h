@@ -797,7 +797,8 @@ pgfn_numeric_as_fixed(cl_int *errcode, pg_numeric_t arg, int scale)
 	cl_uint		shift = (cl_uint)(expo + scale);
 	bool		fast = ((mant >> 32) == 0) & (shift <= 9u);
 
-	if (fast)
+	/* (wave-uniform: every lane's datum is the usual kind, or the whole wave converts the long way) */
+	if (__builtin_amdgcn_ballot_w64(!fast) == 0)
 	{
 		cl_uint		p = ((shift & 1) ? 10u : 1u) * ((shift & 2) ? 100u : 1u) * ((shift & 4) ? 10000u : 1u);
 		cl_ulong	v = (cl_ulong)(cl_uint)mant * (cl_ulong)p;
@@ -807,6 +808,37 @@ pgfn_numeric_as_fixed(cl_int *errcode, pg_numeric_t arg, int scale)
 	}
 	pg_int8_t r = strom_numeric_to_fixed(errcode, arg, scale);
 	return pg_fixed_make(r.value, r.isnull);
+}
+
+/*
+ * the same conversion made once per row, where the row's variables are assembled (the GpuPreAgg
+ * kernels: STROM_KVARS_FINISH), for every expression that reads the column: value, NULL flag and
+ * "this image does not convert" -- raised as CpuReCheck by the expression that USES the value, so a
+ * row the qual drops raises nothing, exactly as when every use converted for itself
+ */
+struct pg_fixed_cache_t {
+	cl_long		value;
+	cl_bool		isnull;
+	cl_bool		recheck;
+};
+
+STROM_DEVICE pg_fixed_cache_t
+pg_fixed_cache_fill(pg_numeric_t arg, int scale)
+{
+	cl_int		e = StromError_Success;
+	pg_fixed_t	f = pgfn_numeric_as_fixed(&e, arg, scale);
+	pg_fixed_cache_t c;
+	c.value = f.value;
+	c.isnull = f.isnull;
+	c.recheck = (e != StromError_Success);
+	return c;
+}
+
+STROM_DEVICE pg_fixed_t
+pg_fixed_cached(cl_int *errcode, pg_fixed_cache_t c)
+{
+	STROM_SET_RECHECK_IF(errcode, c.recheck);
+	return pg_fixed_make(c.value, c.isnull);
 }
 
 STROM_DEVICE pg_numeric_t
@@ -875,8 +907,11 @@ pgfn_fixed_mul(cl_int *errcode, pg_fixed_t a, pg_fixed_t b)
 {
 	bool		isnull = a.isnull | b.isnull;
 
-	/* both within int32 (amounts x rates): one 32x32->64 multiply */
-	if ((a.value == (cl_long)(cl_int)a.value) & (b.value == (cl_long)(cl_int)b.value))
+	/* both within int32 (amounts x rates) in EVERY lane: one 32x32->64 multiply, and the wave
+	 * takes ONE scalar branch (a per-lane branch costs exec-mask bookkeeping on both sides and a
+	 * taken skip in the common case) */
+	bool		narrow = (a.value == (cl_long)(cl_int)a.value) & (b.value == (cl_long)(cl_int)b.value);
+	if (__builtin_amdgcn_ballot_w64(!narrow) == 0)
 		return pg_fixed_make(isnull ? 0 : (cl_long)(cl_int)a.value * (cl_long)(cl_int)b.value, isnull);
 	cl_long		v;
 	bool		ovf = __builtin_mul_overflow(a.value, b.value, &v) & !isnull;

@@ -771,7 +771,50 @@ gpupreagg_launch(strom_task_impl *task, preagg_request req, bool checked = false
 		size_t		units = ((size_t)req.nrows + unit - 1) / unit;
 		size_t		wgs_per_role = std::max<size_t>(1, g.nslabs / std::max<cl_uint>(1, g.nsplits));
 		size_t		wg_rows = std::min<size_t>(((units + wgs_per_role - 1) / wgs_per_role + 1) * unit, 0xffffffffUL);
-		cl_uint		words[2] = { magbits, (cl_uint)wg_rows };
+		/*
+		 * sums of PLAIN columns (GPUPREAGG_SUMBITS_<a> 65) over a COLUMN chunk with zone maps: bounded
+		 * here, the fold does not measure them (top bit of the second word; the streaming kernels
+		 * read it, the row-at-a-time ones measure as always)
+		 */
+		cl_uint		zone_bounded = 0;
+		if (!packed && !checked && (use_column || use_reg))
+		{
+			std::shared_ptr<std::vector<kern_coldir>> snap;
+			const kern_coldir *cd = nullptr;
+			cl_uint		ncd = 0;
+			if (req.kds)
+			{
+				cd = KERN_DATA_STORE_COLDIR(req.kds);
+				ncd = req.kds->ncols;
+			}
+			else if ((snap = dstore_coldir(req.kds_dev)) != nullptr)
+			{
+				cd = snap->data();
+				ncd = (cl_uint)snap->size();
+			}
+			bool		all = (cd != nullptr), any = false;
+			cl_uint		zbits = 0;
+			for (size_t a = 0; all && a < sess->agg_resno.size(); a++)
+			{
+				if (sess->sumbits[a] != 65)
+					continue;
+				int		col = (a < sess->pack_attno.size() ? sess->pack_attno[a] - 1 : -1);
+				if (col < 0 || col >= (int)ncd || !(cd[col].stat_flags & KDS_COLSTAT_MINMAX) ||
+					(cd[col].stat_flags & KDS_COLSTAT_ISFLOAT) || cd[col].maxval < cd[col].minval)
+					all = false;
+				else
+				{
+					zbits = std::max(zbits, zone_magbits(cd[col]));
+					any = true;
+				}
+			}
+			if (all && any)
+			{
+				zone_bounded = 0x80000000u;
+				magbits = std::max(magbits, zbits);
+			}
+		}
+		cl_uint		words[2] = { magbits, (cl_uint)std::min<size_t>(wg_rows, 0x7fffffffUL) | zone_bounded };
 		((kern_gpupreagg *)stage)->sortbuf_len = (cl_int)req.nrows;
 		memcpy(((kern_gpupreagg *)stage)->__padding, words, sizeof(words));
 	}
@@ -1779,22 +1822,36 @@ gpupreagg_session_new(strom_devprog_key key,
 		const char *lst = strstr(src, "#define GPUPREAGG_PACK_LIST(X)");
 		sess->numeric_aggs = (strstr(src, "#define GPUPREAGG_NUMERIC_AGGS 1") != nullptr);
 		sess->packable = (strstr(src, "#define GPUPREAGG_PACKABLE 1") != nullptr && lst != nullptr);
-		if (sess->packable)
+		if (lst)
 		{
+			/* (read for every program: the source column of a plain-column sum also bounds it,
+			 * see gpupreagg_launch) */
+			bool		whole = true;
 			const char *eol = strchr(lst, '\n');
 			for (const char *p = strstr(lst, " X("); p && (!eol || p < eol); p = strstr(p + 1, " X("))
 			{
 				int		aidx = -1, kind = 0, attno = 0;
 				if (sscanf(p, " X(%d,%d,%d)", &aidx, &kind, &attno) != 3 || aidx != (int)sess->pack_kind.size())
 				{
-					sess->packable = false;
+					whole = false;
 					break;
 				}
 				sess->pack_kind.push_back(kind);
 				sess->pack_attno.push_back(attno);
 			}
-			if (sess->pack_kind.size() != sess->agg_resno.size() || sess->agg_resno.size() > 32)
+			if (!whole || sess->pack_kind.size() != sess->agg_resno.size())
+			{
+				sess->pack_kind.assign(sess->agg_resno.size(), 0);
+				sess->pack_attno.assign(sess->agg_resno.size(), 0);
 				sess->packable = false;
+			}
+			if (sess->agg_resno.size() > 32)
+				sess->packable = false;
+		}
+		else
+		{
+			sess->pack_kind.assign(sess->agg_resno.size(), 0);
+			sess->pack_attno.assign(sess->agg_resno.size(), 0);
 		}
 		/* integer sums: which aggregates, and what the code generator knows about their inputs */
 		for (size_t a = 0; a < sess->agg_resno.size(); a++)

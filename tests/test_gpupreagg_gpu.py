@@ -1126,3 +1126,28 @@ def test_hashed_merge_into_an_empty_session_then_fold_many_groups():
         dst.end()
     assert len(pr) == len(np.unique(np.concatenate([small_k, many_k])))
     assert int(pr.column(1)[0].sum()) == 620000 and int(pr.column(2)[0].sum()) == 20000 + 2 * 600000
+
+
+@pytest.mark.parametrize("ngroups", [7, 300])
+def test_counts_that_coincide_in_a_chunk_without_nulls_are_added_once(ngroups):
+    """four nrows() -- three of them "column X is not NULL" -- are ONE counter while a chunk has no NULL
+    bitmap at all (GPUPREAGG_COUNTALL_<a>, ROWFLAG_ALL_NOTNULL: one LDS atomic instead of four, the others
+    copied when the slab is written); the session's second chunk HAS NULLs in two of the columns and its
+    counters differ.  Both against the oracle, LDS-atomics and lane-private geometry."""
+    rng = np.random.default_rng(88)
+    spec = ("(gpupreagg (qual (int4gt (var 2 int4) (const int4 -900))) (key (var 1 int4))"
+            " (nrows (isnotnull (var 2 int4))) (psum (int8 (var 2 int4))) (nrows (isnotnull (var 3 int8)))"
+            " (nrows) (psum (var 3 int8)) (nrows (isnotnull (var 4 float8))) (nrows (isnotnull (var 2 int4)) (isnotnull (var 3 int8))))")
+    assert "#define GPUPREAGG_COUNTALL_FIRST 0" in GpuPreAgg(spec).codegen.source
+    bufs = []
+    for i, nulls in enumerate((None, 0.1)):
+        n = 200003
+        g = rng.integers(0, ngroups, n).astype(np.int32)
+        x = rng.integers(-1000, 1000, n).astype(np.int32)
+        z = rng.integers(-10**12, 10**12, n).astype(np.int64)
+        y = rng.random(n)
+        bufs.append(kds.build_kds("column", [kds.Column("int4", g), kds.Column("int4", x),
+                                             kds.Column("int8", z, None if nulls is None else rng.random(n) < nulls),
+                                             kds.Column("float8", y, None if nulls is None else rng.random(n) < nulls)]))
+    compare_with_oracle(spec, bufs, [(0, ngroups)], resident=True)
+    compare_with_oracle(spec, bufs[:1], [(0, ngroups)])
