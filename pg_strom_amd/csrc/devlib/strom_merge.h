@@ -217,7 +217,21 @@ preagg_dense_export_rows(const char *table, const preagg_export_spec *spec, char
 			first = atomicAdd(&counter[0], (cl_uint)__popcll(mask));
 		first = __shfl(first, 0, 64);
 		cl_uint		idx = first + (cl_uint)__popcll(mask & ((1UL << (threadIdx.x & 63)) - 1));
-		if (!seen || idx >= max_rows)
+		if (!seen)
+			continue;
+		/* a sum beyond one int8 datum is reported whether or not the row is written (the size
+		 * query counts with max_rows = 0 and must send the caller the host's way just the same) */
+		for (cl_uint c = 0; c < ncols; c++)
+		{
+			if (spec->col[c].kind == 5 && ((flags >> spec->col[c].which) & 1u))
+			{
+				cl_long lo = ((const cl_long *)(table + spec->col[c].vals_off))[g];
+				cl_long hi = ((const cl_long *)(table + spec->col[c].hi_off))[g];
+				if (hi != (lo >> 63))
+					counter[1] = 1;
+			}
+		}
+		if (idx >= max_rows)
 			continue;
 		cl_ulong   *values = (cl_ulong *)(rows + (size_t)stride * idx);
 		cl_char	   *isnull = (cl_char *)(values + ncols);
@@ -238,13 +252,7 @@ preagg_dense_export_rows(const char *table, const preagg_export_spec *spec, char
 			{
 				raw = ((const cl_ulong *)(table + spec->col[c].vals_off))[g];
 				null = (kind != 1 && !((flags >> which) & 1u));
-				if (kind == 5 && !null)
-				{
-					cl_long hi = ((const cl_long *)(table + spec->col[c].hi_off))[g];
-					if (hi != ((cl_long)raw >> 63))
-						counter[1] = 1;			/* (does not fit one int8 datum: the host takes over) */
-				}
-				else if (kind == 4 && !null)
+				if (kind == 4 && !null)
 					raw = (raw & PREAGG_MERGE_SIGN) ? (raw & 0x7fffffffffffffffUL) : ~raw;
 				if ((kind == 3 || kind == 4) && spec->col[c].float4 && !null)
 				{
