@@ -254,7 +254,9 @@ def test_rccl_merge_behind_the_abi_world_size_1():
             elif merge == "torch":
                 agg.allreduce()
             pr = agg.fetch()
-            return pr.values.copy(), pr.isnull.copy()
+            # (partial rows come in no particular order -- the device packs them: by key, NULL key last)
+            order = np.lexsort((pr.values[:, 0].view(np.int64), pr.isnull[:, 0]))
+            return pr.values[order].copy(), pr.isnull[order].copy()
         finally:
             agg.end()
 
