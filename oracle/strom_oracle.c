@@ -2449,7 +2449,53 @@ hj_key_image(oracle_value v)
 		if (isnan(d)) return 0x7ff8000000000000ULL;
 		{ uint64_t u; memcpy(&u, &d, 8); return u; }
 	}
+	/* text / character(n): the value is the address of the datum; equal strings must land in
+	 * the same bucket, the comparison itself is hj_keys_equal's (character(n): without the
+	 * trailing blanks).  STROMCL_VARLENA_HASHKEY_TEMPLATE, opencl_hashjoin.h:935-953. */
+	if (type_is_varlena(v.type_oid))
+	{
+		int		len, i;
+		const uint8_t *p = varlena_payload((const void *)(intptr_t)v.v.i, &len);
+		uint64_t h = 1469598103934665603ULL;
+		if (v.type_oid == STROM_BPCHARNOID)
+			while (len > 0 && p[len - 1] == ' ') len--;
+		for (i = 0; i < len; i++)
+			h = (h ^ p[i]) * 1099511628211ULL;
+		return h;
+	}
 	return (uint64_t)v.v.i;
+}
+
+/* an inner key column: by-value types through load_datum; text / character(n) as the address of
+ * the datum (pg_varlena_hashref, opencl_hashjoin.h:860-890: a datum the device cannot read in
+ * place is NULL and raises CpuReCheck) */
+static oracle_value
+hj_inner_key(int type, const void *addr, int32_t *errcode)
+{
+	oracle_value r;
+	if (!type_is_varlena(type) || !addr)
+		return load_datum(type, addr);
+	memset(&r, 0, sizeof(r));
+	r.type_oid = type;
+	if (!varlena_readable(addr))
+	{
+		r.isnull = 1;
+		if (errcode)
+			set_error(errcode, StromError_CpuReCheck);
+		return r;
+	}
+	r.v.i = (int64_t)(intptr_t)addr;
+	return r;
+}
+
+/* hash clause "outer key = inner column" by the type's equality operator */
+static int
+hj_keys_equal(oracle_value a, oracle_value b)
+{
+	if (type_is_varlena(a.type_oid))
+		return varlena_compare((const void *)(intptr_t)a.v.i, (const void *)(intptr_t)b.v.i,
+							   a.type_oid == STROM_BPCHARNOID) == 0;
+	return hj_key_image(a) == hj_key_image(b);
 }
 
 typedef struct {
@@ -2563,9 +2609,10 @@ hj_probe(hj_state *st, int d)
 		int same = (rel->keyhash[r] == h);
 		for (k = 0; k < rel->nkeys && same; k++)
 		{
-			oracle_value iv = load_datum(rel->key_type[k],
-										 oracle_get_datum(ikds, rel->inner_attno[k] - 1, (uint32_t)r));
-			same = (!iv.isnull && hj_key_image(iv) == hj_key_image(kv[k]));
+			oracle_value iv = hj_inner_key(rel->key_type[k],
+										   oracle_get_datum(ikds, rel->inner_attno[k] - 1, (uint32_t)r),
+										   &st->errcode);
+			same = (!iv.isnull && hj_keys_equal(iv, kv[k]));
 		}
 		if (!same)
 			continue;
@@ -2633,9 +2680,9 @@ oracle_gpuhashjoin(const char *spec_text,
 			int		 isnull = 0;
 			for (k = 0; k < rel->nkeys; k++)
 			{
-				oracle_value iv = load_datum(rel->key_type[k],
-											 oracle_get_datum(inner[d], rel->inner_attno[k] - 1, r));
-				if (iv.isnull) isnull = 1;
+				oracle_value iv = hj_inner_key(rel->key_type[k],
+											   oracle_get_datum(inner[d], rel->inner_attno[k] - 1, r), NULL);
+				if (iv.isnull) { isnull = 1; continue; }
 				h = hj_mix(h, hj_key_image(iv));
 			}
 			rel->keyhash[r] = h;
@@ -2746,7 +2793,21 @@ oracle_check_hashtable(const kern_multihash *kmhash, int depth,
 			{
 				const void *p = oracle_get_datum(inner, key_attnos[k] - 1, he->rowid);
 				const void *q = get_datum_tuple(kht->colmeta, &he->htup, key_attnos[k] - 1);
-				if ((p == NULL) != (q == NULL) || (p && memcmp(p, q, key_lens[k]) != 0))
+				if ((p == NULL) != (q == NULL))
+				{ free(seen); return -5; }
+				if (p && key_lens[k] < 0)
+				{
+					/* varlena key: same datum bytes, hashed over the payload
+					 * (gpuhashjoin.c:3775-3779) */
+					int		lp, lq;
+					const uint8_t *pp = varlena_payload(p, &lp);
+					const uint8_t *qq = varlena_payload(q, &lq);
+					if (lp != lq || memcmp(pp, qq, (size_t)lp) != 0)
+					{ free(seen); return -5; }
+					crc = oracle_pg_crc32(crc, pp, (size_t)lp);
+					continue;
+				}
+				if (p && memcmp(p, q, key_lens[k]) != 0)
 				{ free(seen); return -5; }
 				if (p)
 				{

@@ -308,6 +308,8 @@ devtype_eqfunc(int oid)
 		case STROM_TIMESTAMPOID:return "timestamp_eq";
 		case STROM_NUMERICOID:	return "numeric_eq";
 		case STROM_BPCHAROID:	return "bpchareq";
+		case STROM_BPCHARNOID:	return "bpchareq";
+		case STROM_TEXTOID:		return "texteq";
 	}
 	return nullptr;
 }

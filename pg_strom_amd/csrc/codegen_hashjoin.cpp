@@ -44,6 +44,29 @@ struct rel {
 	std::set<std::pair<int,int>> expr_ivars;	/* ... used by an expression (not only as a key column) */
 };
 
+/*
+ * The 64-bit image of a key value the probe index hashes (and, in its DIRECT / KEYED forms,
+ * compares instead of the value): the value itself for the by-value types; for text and
+ * character(n) -- where the value is the ADDRESS of a datum -- a hash of the payload bytes, the
+ * reference's pg_<type>_hashkey over VARDATA_ANY / VARSIZE_ANY_EXHDR (opencl_hashjoin.h:935-953).
+ * Such an image says "maybe equal" only: image_is_exact() is false and the relation gets the HASH
+ * index, whose probe compares the keys with the type's equality function.
+ */
+std::string
+key_image_call(int type_oid, const std::string &value)
+{
+	if (type_oid == STROM_TEXTOID)
+		return "hashjoin_varlena_image(" + value + ", false)";
+	if (type_oid == STROM_BPCHARNOID)
+		return "hashjoin_varlena_image(" + value + ", true)";	/* trailing blanks do not count */
+	return "hashjoin_key_image(" + value + ")";
+}
+bool
+image_is_exact(int type_oid)
+{
+	return type_oid != STROM_TEXTOID && type_oid != STROM_BPCHARNOID;
+}
+
 bool
 type_is_intlike(int oid)
 {
@@ -168,6 +191,10 @@ strom_codegen_gpuhashjoin(const char *spec, strom_codegen_result *out, int *p_nr
 			snprintf(tmp, sizeof(tmp), "#define HASHJOIN_KEY0_INTLIKE_%d %d\n", d,
 					 (rels[d - 1].keys.size() == 1 && type_is_intlike(rels[d - 1].keys[0].type_oid)) ? 1 : 0);
 			src += tmp;
+			/* a KEYED index finds a key by its image alone: one key, whose image is its value */
+			snprintf(tmp, sizeof(tmp), "#define HASHJOIN_KEYED_OK_%d %d\n", d,
+					 (rels[d - 1].keys.size() == 1 && image_is_exact(rels[d - 1].keys[0].type_oid)) ? 1 : 0);
+			src += tmp;
 		}
 		src += "#include \"strom_hashjoin.h\"\n";
 
@@ -189,9 +216,9 @@ strom_codegen_gpuhashjoin(const char *spec, strom_codegen_result *out, int *p_nr
 				snprintf(tmp, sizeof(tmp),
 						 "      { pg_%s_t v = %spg_%s_tupref(errcode, kht->colmeta, &ent->htup, %d));\n"
 						 "        if (v.isnull) return false;\n"
-						 "        images[%zu] = hashjoin_key_image(v.value); }\n",
+						 "        images[%zu] = %s; }\n",
 						 tn, hk.type_oid == STROM_NUMERICOID ? "pgfn_numeric_normalize(errcode, " : "(",
-						 tn, hk.inner_attno - 1, k);
+						 tn, hk.inner_attno - 1, k, key_image_call(hk.type_oid, "v.value").c_str());
 				src += tmp;
 			}
 			src += "      return true;\n";
@@ -248,8 +275,10 @@ strom_codegen_gpuhashjoin(const char *spec, strom_codegen_result *out, int *p_nr
 			src += tmp;
 			for (size_t k = 0; k < R.keys.size(); k++)
 			{
-				snprintf(tmp, sizeof(tmp), "%skimg_%d[%zu] = hashjoin_key_image(okey_%d_%zu.value);\n",
-						 indent.c_str(), d, k, d, k);
+				char	oval[48];
+				snprintf(oval, sizeof(oval), "okey_%d_%zu.value", d, k);
+				snprintf(tmp, sizeof(tmp), "%skimg_%d[%zu] = %s;\n",
+						 indent.c_str(), d, k, key_image_call(R.keys[k].type_oid, oval).c_str());
 				src += tmp;
 			}
 			/*
@@ -260,7 +289,7 @@ strom_codegen_gpuhashjoin(const char *spec, strom_codegen_result *out, int *p_nr
 			 */
 			/* ... and so does a KEYED index (one key of any type: a slot per distinct
 			 * key image, found by comparing images inside the 16-byte slot) */
-			bool	direct_ok = (R.keys.size() == 1);
+			bool	direct_ok = (R.keys.size() == 1 && image_is_exact(R.keys[0].type_oid));
 			snprintf(tmp, sizeof(tmp),
 					 "%scl_uint hash_%d;\n"
 					 "%sconst bool direct_%d = %s;\n"

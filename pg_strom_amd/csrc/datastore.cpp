@@ -875,13 +875,6 @@ strom_multihash_required_length(int ntables, const strom_hashtable_input *tables
 			if (!(l == 1 || l == 2 || l == 4 || l == 8))
 				return 0;
 		}
-		for (int k = 0; k < tables[t].nkeys; k++)
-		{
-			/* hash keys are fixed-width here (the emitter has no varlena hash key either) */
-			int col = tables[t].key_attnos[k] - 1;
-			if (col >= 0 && col < (int)kds->ncols && kds->colmeta[col].attlen < 0)
-				return 0;
-		}
 		len += hashtable_head_length(kds->ncols, hashtable_nslots(kds->nitems));
 		row_image ri;
 		row_image_init(ri, kds);
@@ -941,6 +934,24 @@ strom_multihash_build(int ntables, const strom_hashtable_input *tables, void *bu
 					return StromError_BadRequestMessage;
 				if (ri.nulls[col])
 					continue;			/* NULL keys are not hashed */
+				if (kds->colmeta[col].attlen < 0)
+				{
+					/* text / character(n): COMP_CRC32 over VARDATA_ANY / VARSIZE_ANY_EXHDR
+					 * (gpuhashjoin.c:3775-3779).  A compressed or external key datum cannot
+					 * be compared on the device: this relation joins on the CPU. */
+					const unsigned char *p = (const unsigned char *)(uintptr_t)ri.values[col];
+					if (p[0] == 0x01 || (p[0] & 0x03) == 0x02)
+						return StromError_CpuReCheck;
+					if (p[0] & 0x01)
+						crc = legacy_crc32(crc, p + 1, (size_t)((p[0] >> 1) & 0x7f) - 1);
+					else
+					{
+						uint32_t w;
+						memcpy(&w, p, 4);
+						crc = legacy_crc32(crc, p + 4, (size_t)((w >> 2) & 0x3fffffff) - 4);
+					}
+					continue;
+				}
 				crc = legacy_crc32(crc, &ri.values[col], kds->colmeta[col].attlen);
 			}
 			crc ^= 0xFFFFFFFFU;

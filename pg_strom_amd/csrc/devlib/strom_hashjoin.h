@@ -129,6 +129,34 @@ STROM_DEVICE cl_ulong hashjoin_key_image(cl_double v)
 }
 STROM_DEVICE cl_ulong hashjoin_key_image(cl_float v)	{ return hashjoin_key_image((cl_double)v); }
 
+#ifdef STROM_TEXTLIB_DEVICE_H
+/*
+ * text / character(n) hash keys (STROMCL_VARLENA_HASHKEY_TEMPLATE, opencl_hashjoin.h:935-953: the
+ * hash runs over VARDATA_ANY / VARSIZE_ANY_EXHDR): the value is the address of the datum, the image
+ * a 64-bit FNV-1a of its payload -- equal strings have equal images, NOT the other way round, so a
+ * relation with such a key gets the HASH index and every candidate is compared with texteq /
+ * bpchareq (codegen_hashjoin.cpp: image_is_exact).  character(n): trailing blanks do not count
+ * (bpchar_truelen, opencl_textlib.h:154-166), on either side.
+ */
+STROM_DEVICE cl_ulong
+hashjoin_varlena_image(cl_ulong datum, bool blank_padded)
+{
+	cl_int		len;
+	const cl_uchar *p = strom_varlena_payload(datum, &len);
+	cl_ulong	h = 0xcbf29ce484222325UL;
+
+	if (blank_padded)
+		while (len > 0 && p[len - 1] == ' ')
+			len--;
+	for (cl_int i = 0; i < len; i++)
+	{
+		h ^= p[i];
+		h *= 0x100000001b3UL;
+	}
+	return h;
+}
+#endif
+
 STROM_DEVICE cl_uint
 hashjoin_hash_images(const cl_ulong *images, int nkeys)
 {

@@ -207,10 +207,12 @@ strom_hashjoin_table_create(strom_devprog_key key, const kern_multihash *kmhash,
 			cl_ulong slots = 1024;
 			while (slots < 2 * n)
 				slots <<= 1;
-			/* one key: a KEYED index (16-byte slots that carry the key image, one per
-			 * distinct key); several keys: the HASH index over the entries' chains */
+			/* one key whose image is its value: a KEYED index (16-byte slots that carry the
+			 * key image, one per distinct key); several keys, or a text / character(n) key
+			 * (its image is a hash of the bytes): the HASH index over the entries' chains,
+			 * probed with the types' equality functions */
 			char	def[48];
-			snprintf(def, sizeof(def), "#define HASHJOIN_NKEYS_%d 1\n", t + 1);
+			snprintf(def, sizeof(def), "#define HASHJOIN_KEYED_OK_%d 1\n", t + 1);
 			bool	keyed = (strstr(prog->source.c_str(), def) != nullptr && !getenv("STROM_HASHJOIN_NO_KEYED"));
 			ir.mode = (keyed ? 2 : 0);
 			ir.nslots = (cl_uint)slots;

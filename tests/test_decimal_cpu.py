@@ -17,7 +17,10 @@ from pg_strom_amd.gpupreagg import codegen_gpupreagg
 def test_codegen_types_a_decimal_column_as_fixed_point():
     num, dec = decimal_cases.specs()[0]
     cgn, cgd = codegen_gpupreagg(num), codegen_gpupreagg(dec)
-    assert "pgfn_numeric_as_fixed" in cgn.source and "pgfn_numeric_as_fixed" not in cgd.source
+    # numeric images: decoded to fixed point once per row (the KFIX_<attno>_<scale> cache of strom_kvars);
+    # a decimal column IS fixed point already
+    assert "STROM_KFIXED_LIST(X) X(" in cgn.source and "pg_fixed_cached(errcode, KV.KFIX_3_2)" in cgn.source
+    assert "pg_fixed_cached" not in cgd.source and "pgfn_numeric_as_fixed" not in cgd.source
     assert "pg_fixed_from_decimal(KV.KVAR_3)" in cgd.source
     assert [t for _, t in cgn.targets] == [t for _, t in cgd.targets]       # same partial-row types
     with pytest.raises(ValueError):

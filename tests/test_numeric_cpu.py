@@ -129,7 +129,7 @@ def test_typmod_scale_is_a_codegen_hint_only():
         cg = codegen_gpupreagg(spec)
         return (cg[0] if isinstance(cg, tuple) else cg).source
     src = source_of(typed)
-    assert "pgfn_fixed_mul(" in src and "pgfn_numeric_as_fixed(" in src and "pgfn_numeric_mul(" not in src
+    assert "pgfn_fixed_mul(" in src and "pg_fixed_cached(errcode, KV.KFIX_1_2)" in src and "pgfn_numeric_mul(" not in src
     # a scale-less operand anywhere pulls the expression back to the 64-bit numeric form
     mixed = source_of(plain.replace("(var 1 numeric)", "(var 1 numeric 2)"))
     assert "pgfn_numeric_mul(" in mixed and "pgfn_fixed_to_numeric(" in mixed

@@ -66,8 +66,6 @@ def test_codegen_refuses_text_where_the_device_cannot_hold_it():
     with pytest.raises(ValueError):
         codegen_gpupreagg("(gpupreagg (key (var 1 int4)) (pmax (var 2 text)))")
     with pytest.raises(ValueError):
-        codegen_gpuhashjoin("(gpuhashjoin (rel (hashkey (var 1 text) 1 text)))")
-    with pytest.raises(ValueError):
         runtime.codegen_gpuscan("(texteq (var 1 text) (var 2 character))")
     # a qual over text inside an aggregate is fine
     cg = codegen_gpupreagg("(gpupreagg (qual (texteq (var 2 text) (const text 'MAIL'))) (key (var 1 int4)) (nrows))")
@@ -77,7 +75,7 @@ def test_codegen_refuses_text_where_the_device_cannot_hold_it():
 def test_multihash_entries_carry_varlena_inner_columns():
     """the inner side of a join may have text / character(n) columns: the builder copies the
     datum into the entry's heap tuple verbatim (the reference copies whole inner tuples,
-    gpuhashjoin.c:3717-3805); hash keys stay fixed-width"""
+    gpuhashjoin.c:3717-3805)"""
     from pg_strom_amd.gpuhashjoin import build_multihash
     words = [text_cases.WORDS[i % len(text_cases.WORDS)] for i in range(300)]
     pk = np.arange(300, dtype=np.int32)
@@ -91,6 +89,71 @@ def test_multihash_entries_carry_varlena_inner_columns():
     rc, n, recs = oracle.gpuhashjoin(spec, outer, [inner])
     want = [i for i in range(300) if i % 11 != 5 and words[i] >= b"a" and i % 5 != 0]
     assert rc == 0 and n == len(want) and sorted(recs[:, 1].tolist()) == want
-    # a varlena hash key is refused by the builder
-    with pytest.raises(Exception):
-        build_multihash([(inner, [2])])
+
+
+def test_text_and_character_hash_keys_builder_and_oracle():
+    """join ON outer.text = inner.text (and character(n), and text + int together): the builder
+    hashes the datum's PAYLOAD (COMP_CRC32 over VARDATA_ANY / VARSIZE_ANY_EXHDR, gpuhashjoin.c:
+    3775-3779; device side opencl_hashjoin.h:935-953), the generated probe compares with texteq /
+    bpchareq.  Python's own bytes equality is the answer; NULL never joins; character(n) ignores
+    trailing blanks on both sides; 'hello' <> 'hello ' as text."""
+    from pg_strom_amd.gpuhashjoin import build_multihash
+    from pg_strom_amd.gpuhashjoin import codegen_gpuhashjoin
+    W = text_cases.WORDS
+    nd = len(W) * 2
+    words = [W[i % len(W)] for i in range(nd)]                       # every word twice: duplicates
+    wnull = np.arange(nd) % 9 == 4
+    chr8 = [(w[:8] + b" " * 8)[:8] for w in words]
+    inner = kds.build_kds("row", [kds.Column("text", words, wnull), kds.Column("character", chr8),
+                                  kds.Column("int4", (np.arange(nd) % 3).astype(np.int32))])
+    km = build_multihash([(inner, [1])])
+    assert oracle.check_hashtable(km, 1, inner, [1], [-1]) == nd
+    # the hash of an entry is the reference's: pg_crc32 over the payload bytes alone
+    assert oracle.pg_crc32(b"hello") != oracle.pg_crc32(b"hello ")
+    km2 = build_multihash([(inner, [2, 3])])
+    assert oracle.check_hashtable(km2, 1, inner, [2, 3], [-1, 4]) == nd
+
+    n = 500
+    rng = np.random.default_rng(4)
+    otxt = [W[i] for i in rng.integers(0, len(W), n)]
+    otxt[7], otxt[8] = b"no such word", b"hello   "
+    onull = np.arange(n) % 13 == 2
+    ochr = [(w[:12] + b" " * 12)[:12] for w in otxt]                 # character(12) against character(8)
+    onum = rng.integers(0, 4, n).astype(np.int32)
+    outer = kds.build_kds("row", [kds.Column("text", otxt, onull), kds.Column("character", ochr),
+                                  kds.Column("int4", onum)])
+    # text = text
+    rc, cnt, recs = oracle.gpuhashjoin("(gpuhashjoin (rel (hashkey (var 1 text) 1 text)))", outer, [inner])
+    want = sorted((o + 1, d) for o in range(n) if not onull[o]
+                  for d in range(nd) if not wnull[d] and words[d] == otxt[o])
+    assert rc == 0 and cnt == len(want) and sorted(map(tuple, recs.tolist())) == want
+    # character(n) = character(m), and an int4 key beside it
+    spec2 = "(gpuhashjoin (rel (hashkey (var 2 character) 2 character) (hashkey (var 3 int4) 3 int4)))"
+    rc, cnt, recs = oracle.gpuhashjoin(spec2, outer, [inner])
+    want = sorted((o + 1, d) for o in range(n) for d in range(nd)
+                  if chr8[d].rstrip(b" ") == ochr[o].rstrip(b" ") and int(onum[o]) == d % 3)
+    assert rc == 0 and cnt == len(want) and cnt > 0 and sorted(map(tuple, recs.tolist())) == want
+    # the generated program: images are hashes of the bytes, so no KEYED index, and the probe
+    # compares by the type's equality function
+    cg = codegen_gpuhashjoin("(gpuhashjoin (rel (hashkey (var 1 text) 1 text)))")
+    assert "#define HASHJOIN_KEYED_OK_1 0" in cg.source and "pgfn_texteq" in cg.source
+    assert "hashjoin_varlena_image(okey_1_0.value, false)" in cg.source
+    cg = codegen_gpuhashjoin(spec2)
+    assert "pgfn_bpchareq" in cg.source and "hashjoin_varlena_image(okey_1_0.value, true)" in cg.source
+    cg = codegen_gpuhashjoin("(gpuhashjoin (rel (hashkey (var 3 int4) 3 int4)))")
+    assert "#define HASHJOIN_KEYED_OK_1 1" in cg.source
+    # types must agree (text against character(n) needs a cast the catalog does not have)
+    with pytest.raises(ValueError):
+        codegen_gpuhashjoin("(gpuhashjoin (rel (hashkey (var 1 text) 2 character)))")
+
+
+def test_multihash_builder_sends_a_compressed_key_datum_to_the_cpu():
+    """a key datum the device cannot read in place (compressed 4-byte header, external pointer)
+    cannot be compared there: the builder answers CpuReCheck for the relation"""
+    from pg_strom_amd.gpuhashjoin import build_multihash
+    comp = np.frombuffer(np.uint32((12 << 2) | 2).tobytes() + b"\0" * 8, dtype=np.uint8).tobytes()
+    inner = kds.build_kds("row", [kds.Column("text_raw", [comp, comp]), kds.Column("int4", np.arange(2, dtype=np.int32))])
+    assert len(build_multihash([(inner, [2])])) > 0                  # as a payload column: fine
+    with pytest.raises(runtime.StromError) as ei:
+        build_multihash([(inner, [1])])
+    assert ei.value.errcode == 2                                      # StromError_CpuReCheck

@@ -194,3 +194,38 @@ def test_inner_text_columns_in_join_quals_and_in_projected_tuples():
     for i in range(nitems):
         o, d = int(recs[i, 0]) - 1, int(irow[i])
         assert rows[i] == [np.int64(o).tobytes(), None if wnull[d] else words[d], np.int16(pk[d] % 5).tobytes()], i
+
+
+@pytest.mark.parametrize("ofmt", ["row", "row_flat"])
+def test_text_and_character_hash_keys(ofmt):
+    """join ON outer.text = inner.text, and ON (character(n), int4): the probe index hashes the
+    payload bytes (opencl_hashjoin.h:935-953) and, a hash not being the value, the HASH form with
+    texteq / bpchareq on every candidate is chosen -- never the KEYED one, which would take two
+    strings with one image for equal"""
+    W = text_cases.WORDS
+    rng = np.random.default_rng(21)
+    nd, n = 3000, 40000
+    # 1000 generated strings (short and 4-byte headers), each three times; the WORDS at the front
+    gen = [(b"k%05d" % i) * (1 + i % 40) for i in range(1000)]
+    words = (W + gen * 3)[:nd]
+    wnull = np.arange(nd) % 17 == 4
+    chr8 = [(w[:8] + b" " * 8)[:8] for w in words]
+    inner = kds.build_kds("row", [kds.Column("text", words, wnull), kds.Column("character", chr8),
+                                  kds.Column("int4", (np.arange(nd) % 3).astype(np.int32))])
+    pool = W + gen + [b"no such word", b"hello   ", b"k00001k00001 "]
+    otxt = [pool[i] for i in rng.integers(0, len(pool), n)]
+    onull = rng.random(n) < 0.03
+    ochr = [(w[:12] + b" " * 12)[:12] for w in otxt]
+    outer = kds.build_kds(ofmt, [kds.Column("text", otxt, onull), kds.Column("character", ochr),
+                                 kds.Column("int4", rng.integers(0, 4, n).astype(np.int32))])
+    res, info = run_and_compare("(gpuhashjoin (rel (hashkey (var 1 text) 1 text)))", outer, [inner], [[1]],
+                                expect_mode="hash")
+    by_word = {}
+    for d in range(nd):
+        if not wnull[d]:
+            by_word[words[d]] = by_word.get(words[d], 0) + 1
+    assert res.nitems == sum(by_word.get(otxt[o], 0) for o in range(n) if not onull[o]) > n
+    res, info = run_and_compare("(gpuhashjoin (rel (hashkey (var 2 character) 2 character) (hashkey (var 3 int4) 3 int4)"
+                                " (qual (text_ge (var 1 text) (ivar 1 1 text)))))", outer, [inner], [[2, 3]],
+                                expect_mode="hash")
+    assert res.nitems > 0
