@@ -202,9 +202,17 @@ typedef struct {
  * a chunk is one contiguous upload like the other formats.  Rows are
  * already visibility-filtered at ingest (the ROW format's kern_rowitem
  * step); row i of a COLUMN chunk is simply index i of every array.
- * Only fixed-width by-value columns (attlen 1,2,4,8) are carried
- * column-major; a varlena column stores a 4-byte offset into the 'extra'
- * heap at extra_off (offset 0 == NULL).
+ * Fixed-width by-value columns (attlen 1,2,4,8) are carried column-major as
+ * they are.  A VARLENA column (attlen -1: text, character(n)) carries, per row,
+ * the 8-byte OFFSET of the row's datum from the kds head (0 == NULL; the
+ * bitmap says so too), and the datums themselves -- complete varlenas, header
+ * included, exactly the bytes a heap tuple holds (opencl_common.h:1126-1154
+ * pg_varlena_t points at such bytes) -- lie in a heap area of the chunk,
+ * anywhere between the column arrays and 'length' (extra_off = where the
+ * column's datums start, informational; 'usage' = end of the last datum).  8
+ * bytes per row so that the streaming kernels load the column like any int8
+ * column and turn offset into address with one add (strom_kvars_from_column).
+ * A datum with a 4-byte header is 4-byte aligned, as in a heap tuple.
  *
  * zone map: minval/maxval hold the chunk-wide minimum / maximum of the
  * column (as int64 for integer-like, as IEEE double bits for float4/8)
@@ -228,8 +236,10 @@ typedef struct {
 	((kern_coldir *)((char *)(kds) + KDS_HEAD_LENGTH((kds)->ncols)))
 #define KDS_COLUMN_HEAD_LENGTH(ncols)	\
 	STROM_TYPEALIGN(KDS_COLUMN_ALIGN, KDS_HEAD_LENGTH(ncols) + sizeof(kern_coldir) * (ncols))
+/* bytes per row in a column's value array: the datum, or the offset of a varlena */
+#define KDS_COLUMN_ATTWIDTH(attlen)		((attlen) > 0 ? (size_t)(attlen) : sizeof(cl_ulong))
 #define KDS_COLUMN_VALUES_LENGTH(attlen,nrooms)	\
-	STROM_TYPEALIGN(KDS_COLUMN_ALIGN, (size_t)(attlen) * (nrooms))
+	STROM_TYPEALIGN(KDS_COLUMN_ALIGN, KDS_COLUMN_ATTWIDTH(attlen) * (nrooms))
 #define KDS_COLUMN_NULLS_LENGTH(nrooms)	\
 	STROM_TYPEALIGN(KDS_COLUMN_ALIGN, sizeof(cl_uint) * (((size_t)(nrooms) + 31) / 32))
 

@@ -125,6 +125,16 @@ oracle_get_datum(const kern_data_store *kds, uint32_t colidx, uint32_t rowidx)
 					if (!((nn[rowidx >> 5] >> (rowidx & 31)) & 1))
 						return NULL;
 				}
+				if (kds->colmeta[colidx].attlen < 0)
+				{
+					/* a varlena column: 8-byte offset of the row's datum from the chunk head,
+					 * 0 = NULL (strom_kds.h) */
+					uint64_t off;
+					memcpy(&off, (const char *)kds + cd->values_off + 8 * (size_t)rowidx, 8);
+					if (off == 0 || off >= kds->length)
+						return NULL;
+					return (const char *)kds + off;
+				}
 				return (const char *)kds + cd->values_off +
 					(size_t)kds->colmeta[colidx].attlen * rowidx;
 			}

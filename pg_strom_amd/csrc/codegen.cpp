@@ -1157,7 +1157,19 @@ codegen_var_list(const codegen_context &ctx, const char *macro_name)
 				 devtype_lookup(v.type_oid)->dev_name);
 		s += tmp;
 	}
-	return s + "\n";
+	s += "\n";
+	/* the text / character(n) variables: what strom_kvars_from_column (strom_common.h) turns from
+	 * offset to address when the row came from a COLUMN chunk */
+	std::string vl;
+	for (auto &v : ctx.used_vars)
+		if (devtype_lookup(v.type_oid)->type_flags & DEVTYPE_IS_VARLENA)
+		{
+			snprintf(tmp, sizeof(tmp), " X(%d,%s)", v.attno, devtype_lookup(v.type_oid)->dev_name);
+			vl += tmp;
+		}
+	if (!vl.empty() && !strcmp(macro_name, "STROM_KVAR_LIST"))
+		s += "#define STROM_KVARLENA_LIST(X)" + vl + "\n";
+	return s;
 }
 
 std::string

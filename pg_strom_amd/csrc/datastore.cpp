@@ -294,7 +294,10 @@ cols_valid(int ncols, const strom_column_input *cols, int format = 0)
 			return false;
 		if (is_varlena_numeric(cols[i]) || is_varlena_raw(cols[i]))
 		{
-			/* heap tuples only: COLUMN / TUPSLOT carry the 8-byte form */
+			/* heap tuples; a COLUMN chunk carries datums given verbatim in its heap area
+			 * (strom_kds.h) and numerics in the 8-byte form; TUPSLOT by-value datums only */
+			if (format == KDS_FORMAT_COLUMN && is_varlena_raw(cols[i]))
+				continue;
 			if (format != KDS_FORMAT_ROW && format != KDS_FORMAT_ROW_FLAT)
 				return false;
 			continue;
@@ -305,9 +308,17 @@ cols_valid(int ncols, const strom_column_input *cols, int format = 0)
 	return true;
 }
 
+/* where a datum of a COLUMN chunk's heap area goes: 4-byte headers on 4-byte boundaries */
+inline size_t
+column_heap_place(size_t off, const unsigned char *datum)
+{
+	return (datum[0] & 0x01) ? off : STROM_TYPEALIGN(4, off);
+}
+
 size_t
 column_layout(int ncols, const strom_column_input *cols, uint32_t nrooms,
-			  std::vector<size_t> *values_off, std::vector<size_t> *nulls_off)
+			  std::vector<size_t> *values_off, std::vector<size_t> *nulls_off,
+			  std::vector<size_t> *extra_off = nullptr)
 {
 	size_t	off = KDS_COLUMN_HEAD_LENGTH(ncols);
 	for (int i = 0; i < ncols; i++)
@@ -323,6 +334,24 @@ column_layout(int ncols, const strom_column_input *cols, uint32_t nrooms,
 			(*nulls_off)[i] = anynull ? off : 0;
 		if (anynull)
 			off += KDS_COLUMN_NULLS_LENGTH(nrooms);
+	}
+	/* the heap area: the varlena columns' datums, column by column, row by row */
+	for (int i = 0; i < ncols; i++)
+	{
+		if (extra_off)
+			(*extra_off)[i] = 0;
+		if (!is_varlena_raw(cols[i]))
+			continue;
+		if (extra_off)
+			(*extra_off)[i] = off;
+		for (uint32_t r = 0; r < nrooms; r++)
+		{
+			if (is_null(cols[i], r))
+				continue;
+			const unsigned char *d = ((const unsigned char *const *)cols[i].values)[r];
+			off = column_heap_place(off, d) + varlena_raw_size(d);
+		}
+		off = STROM_TYPEALIGN(KDS_COLUMN_ALIGN, off);
 	}
 	return off;
 }
@@ -524,8 +553,8 @@ strom_kds_build(int format, int ncols, const strom_column_input *cols,
 	}
 	if (format == KDS_FORMAT_COLUMN)
 	{
-		std::vector<size_t> voff(ncols), noff(ncols);
-		column_layout(ncols, cols, nrows, &voff, &noff);
+		std::vector<size_t> voff(ncols), noff(ncols), xoff(ncols);
+		column_layout(ncols, cols, nrows, &voff, &noff, &xoff);
 		init_kds_head(kds, format, ncols, cols, nrows, 0, required);
 		kern_coldir *cd = KERN_DATA_STORE_COLDIR(kds);
 		memset(cd, 0, KDS_COLUMN_HEAD_LENGTH(ncols) - KDS_HEAD_LENGTH(ncols));
@@ -534,7 +563,33 @@ strom_kds_build(int format, int ncols, const strom_column_input *cols,
 			size_t	vbytes = (size_t)cols[i].attlen * nrows;
 			cd[i].values_off = (cl_uint)voff[i];
 			cd[i].nulls_off = (cl_uint)noff[i];
-			cd[i].extra_off = 0;
+			cd[i].extra_off = (cl_uint)xoff[i];
+			if (is_varlena_raw(cols[i]))
+			{
+				/* offsets of the datums (0 = NULL), the datums behind the column arrays */
+				cl_ulong   *offs = (cl_ulong *)(base + voff[i]);
+				size_t		off = xoff[i];
+				memset(offs, 0, KDS_COLUMN_VALUES_LENGTH(-1, nrows));
+				if (noff[i])
+					memset(base + noff[i], 0, KDS_COLUMN_NULLS_LENGTH(nrows));
+				for (uint32_t r = 0; r < nrows; r++)
+				{
+					if (is_null(cols[i], r))
+						continue;
+					const unsigned char *d = ((const unsigned char *const *)cols[i].values)[r];
+					size_t	len = varlena_raw_size(d);
+					size_t	at = column_heap_place(off, d);
+					memset(base + off, 0, at - off);
+					memcpy(base + at, d, len);
+					offs[r] = at;
+					off = at + len;
+					if (noff[i])
+						((cl_uint *)(base + noff[i]))[r >> 5] |= (1u << (r & 31));
+				}
+				memset(base + off, 0, STROM_TYPEALIGN(KDS_COLUMN_ALIGN, off) - off);
+				kds->usage = (cl_uint)off;
+				continue;
+			}
 			memcpy(base + voff[i], cols[i].values, vbytes);
 			memset(base + voff[i] + vbytes, 0,
 				   KDS_COLUMN_VALUES_LENGTH(cols[i].attlen, nrows) - vbytes);
@@ -684,6 +739,14 @@ host_get_datum(const kern_data_store *kds, uint32_t rowidx, uint32_t colidx)
 					if (!((nn[rowidx >> 5] >> (rowidx & 31)) & 1))
 						return nullptr;
 				}
+				if (kds->colmeta[colidx].attlen < 0)
+				{
+					/* a varlena column: the offset of the row's datum (strom_kds.h) */
+					cl_ulong off = ((const cl_ulong *)((const char *)kds + cd->values_off))[rowidx];
+					if (off == 0 || off >= kds->length)
+						return nullptr;
+					return (const char *)kds + off;
+				}
 				return (const char *)kds + cd->values_off +
 					(size_t)kds->colmeta[colidx].attlen * rowidx;
 			}
@@ -725,9 +788,13 @@ strom_kds_to_column(const kern_data_store *src, void *dst, size_t dstlen)
 	for (int i = 0; i < ncols; i++)
 	{
 		int	attlen = src->colmeta[i].attlen;
-		if (!(attlen == 1 || attlen == 2 || attlen == 4 || attlen == 8))
+		/* varlena columns (heap formats hold their datums): the datums go into the COLUMN
+		 * chunk's heap area verbatim */
+		bool	varlena = (attlen == -1 && (src->format == KDS_FORMAT_ROW || src->format == KDS_FORMAT_ROW_FLAT ||
+										   src->format == KDS_FORMAT_COLUMN));
+		if (!(attlen == 1 || attlen == 2 || attlen == 4 || attlen == 8 || varlena))
 			return 0;
-		values[i].assign((size_t)attlen * nrows + 8, 0);
+		values[i].assign(KDS_COLUMN_ATTWIDTH(attlen) * nrows + 8, 0);
 		nulls[i].assign(nrows + 1, 0);
 	}
 	for (uint32_t r = 0; r < nrows; r++)
@@ -736,6 +803,8 @@ strom_kds_to_column(const kern_data_store *src, void *dst, size_t dstlen)
 			const char *p = host_get_datum(src, r, i);
 			if (!p)
 				nulls[i][r] = 1;
+			else if (src->colmeta[i].attlen < 0)
+				((const char **)values[i].data())[r] = p;
 			else
 				memcpy(&values[i][(size_t)src->colmeta[i].attlen * r], p, src->colmeta[i].attlen);
 		}
@@ -743,7 +812,7 @@ strom_kds_to_column(const kern_data_store *src, void *dst, size_t dstlen)
 	{
 		cols[i].type_oid = 0;
 		cols[i].attlen = src->colmeta[i].attlen;
-		cols[i].attalign = src->colmeta[i].attalign;
+		cols[i].attalign = (src->colmeta[i].attlen < 0 ? -1 : src->colmeta[i].attalign);
 		cols[i].attbyval = src->colmeta[i].attbyval;
 		cols[i].values = values[i].data();
 		cols[i].isnull = nulls[i].data();
@@ -869,8 +938,10 @@ strom_multihash_required_length(int ntables, const strom_hashtable_input *tables
 		for (uint32_t c = 0; c < kds->ncols; c++)
 		{
 			int l = kds->colmeta[c].attlen;
-			/* varlena columns: heap formats only (that is where their datums are) */
-			if (l == -1 && (kds->format == KDS_FORMAT_ROW || kds->format == KDS_FORMAT_ROW_FLAT))
+			/* varlena columns: the formats that hold their datums (heap tuples, a COLUMN
+			 * chunk's heap area) */
+			if (l == -1 && (kds->format == KDS_FORMAT_ROW || kds->format == KDS_FORMAT_ROW_FLAT ||
+							kds->format == KDS_FORMAT_COLUMN))
 				continue;
 			if (!(l == 1 || l == 2 || l == 4 || l == 8))
 				return 0;

@@ -276,10 +276,11 @@ kern_get_datum(const kern_data_store *kds,
 				cl_short attlen = kds->colmeta[colidx].attlen;
 				if (attlen > 0)
 					return (const char *)kds + cd->values_off + (size_t)attlen * rowidx;
-				cl_uint voff = ((const cl_uint *)((const char *)kds + cd->values_off))[rowidx];
-				if (voff == 0)
+				/* a varlena column: the offset of the row's datum from the kds head */
+				cl_ulong voff = ((const cl_ulong *)((const char *)kds + cd->values_off))[rowidx];
+				if (voff == 0 || voff >= kds->length)
 					return NULL;
-				return (const char *)kds + cd->extra_off + voff;
+				return (const char *)kds + voff;
 			}
 		case KDS_FORMAT_ROW:
 			{
@@ -631,6 +632,25 @@ strom_column_load_quad(const char *values, const cl_uint *notnull,
 	pg_##NAME##_make(__builtin_nontemporal_load(&((const pg_##NAME##_base_t *)(values))[rowidx]),	\
 					 (notnull) != NULL &&												\
 					 !((((const cl_uint *)(notnull))[(rowidx) >> 5] >> ((rowidx) & 31)) & 1))
+
+/*
+ * Varlena columns of a COLUMN chunk (strom_kds.h): the column array holds the 8-byte OFFSET of
+ * each row's datum from the kds head, which the loaders above bring in like any int8 value.  A
+ * kernel that has assembled a row's strom_kvars from COLUMN arrays calls
+ * strom_kvars_from_column(KV, kds, errcode) -- defined next to strom_kvars in each operator's
+ * header over STROM_KVARLENA_LIST, the generated list of the program's text / character(n)
+ * variables, empty (and the call compiled away) for every program without one -- to turn the
+ * offsets into what a pg_text_t carries everywhere else, the datum's address, with the same
+ * "can the device read it in place" check the row formats apply (pg_<type>_from_addr).
+ */
+#define STROM_KVARLENA_FIX(attno,NAME)	\
+	KV.KVAR_##attno = pg_##NAME##_from_column(errcode, kds, (attno) - 1, KV.KVAR_##attno);
+#define STROM_DEFINE_KVARS_FROM_COLUMN											\
+	STROM_DEVICE void															\
+	strom_kvars_from_column(strom_kvars &KV, const kern_data_store *kds, cl_int *errcode)	\
+	{																			\
+		STROM_KVARLENA_LIST(STROM_KVARLENA_FIX)									\
+	}
 
 /* the same through the caches: for rows that several work-groups of an XCD
  * read one after the other (hash roles of the hashed GROUP BY) */

@@ -69,6 +69,19 @@ struct strom_kvars {
 	int __dummy;
 };
 /*
+ * text / character(n) variables of a row taken from COLUMN arrays: offset -> address
+ * (strom_common.h).  Called by the row-at-a-time kernels, which is where the host sends a
+ * program with such variables (gpupreagg.cpp: program_streams_columns); the streaming
+ * kernels' rows have no error slot of their own at this point and do not call it.
+ */
+#ifndef STROM_KVARLENA_LIST
+#define STROM_KVARLENA_LIST(X)
+#define GPUPREAGG_HAS_VARLENA_VARS	0
+#else
+#define GPUPREAGG_HAS_VARLENA_VARS	1
+#endif
+STROM_DEFINE_KVARS_FROM_COLUMN
+/*
  * the row's variables are assembled: convert the numeric columns the program reads as fixed point
  * (the conversion raises nothing here -- a row the qual drops must not send the chunk back; whoever
  * USES the value sees its flag: pg_fixed_cached, strom_numeric.h)
@@ -1280,6 +1293,8 @@ gpupreagg_dense_generic_body(kern_gpupreagg *kgpreagg,
 			: pg_##NAME##_vref(kds, ktoast, &errcode, colidx, kds_index));
 		STROM_KVAR_LIST(X)
 #undef X
+		if (is_column)
+			strom_kvars_from_column(KV, kds, &errcode);
 		STROM_KVARS_FINISH(KV);
 		gpupreagg_dense_row(lds, ctl, L, KP, KV, gid_lo, G, NREP, rep, errcode, &chunk_status, summag, 0u);
 	}
@@ -3225,6 +3240,8 @@ gpupreagg_hash_body(kern_gpupreagg *kgpreagg,
 				STROM_KVAR_LIST_REST(X)
 			}
 #undef X
+			if (is_column && !ROLES)
+				strom_kvars_from_column(KVs[j], kds, &errcode);
 			STROM_KVARS_FINISH(KVs[j]);
 			errs[j] = errcode;
 			kidx[j] = kds_index;
@@ -3522,6 +3539,8 @@ gpupreagg_hash_parts_body(kern_gpupreagg *kgpreagg,
 			: pg_##NAME##_vref(kds, ktoast, &errcode, colidx, kds_index));
 		STROM_KVAR_LIST(X)
 #undef X
+		if (is_column)
+			strom_kvars_from_column(KV, kds, &errcode);
 		STROM_KVARS_FINISH(KV);
 	};
 	/* keys of a row -> images; false when an expression failed */
@@ -4519,6 +4538,8 @@ gpupreagg_census_body(const kern_gpupreagg *kgpreagg, const kern_data_store *kds
 			: pg_##NAME##_vref(kds, ktoast, &errcode, colidx, kds_index));
 		STROM_KVAR_LIST(X)
 #undef X
+		if (is_column)
+			strom_kvars_from_column(KV, kds, &errcode);
 		STROM_KVARS_FINISH(KV);
 		pg_bool_t	rc = gpupreagg_qual_eval(&errcode, KP, KV);
 		if (errcode == StromError_Success && !EVAL(rc))
@@ -4626,6 +4647,8 @@ gpupreagg_keyrange_body(const kern_gpupreagg *kgpreagg, const kern_data_store *k
 			: pg_##NAME##_vref(kds, ktoast, &errcode, colidx, kds_index));
 		STROM_KVAR_LIST(X)
 #undef X
+		if (is_column)
+			strom_kvars_from_column(KV, kds, &errcode);
 		STROM_KVARS_FINISH(KV);
 		pg_bool_t	rc = gpupreagg_qual_eval(&errcode, KP, KV);
 		if (errcode == StromError_Success && !EVAL(rc))

@@ -59,6 +59,11 @@ struct strom_kvars {
 #undef X
 	int __dummy;
 };
+/* text / character(n) variables of a row taken from COLUMN arrays: offset -> address (strom_common.h) */
+#ifndef STROM_KVARLENA_LIST
+#define STROM_KVARLENA_LIST(X)
+#endif
+STROM_DEFINE_KVARS_FROM_COLUMN
 
 STROM_DEVICE pg_bool_t
 gpuscan_qual_eval(cl_int *errcode,
@@ -323,6 +328,7 @@ gpuscan_qual_column(kern_gpuscan *kgpuscan, const kern_data_store *kds)
 				STROM_KVAR_LIST(X)
 #undef X
 				KV.__dummy = 0;
+				strom_kvars_from_column(KV, kds, &errcode);
 				pg_bool_t rc = gpuscan_qual_eval(&errcode, KP, KV);
 				st[k][j] = (row0 + j < nitems
 							? gpuscan_row_status(rc, errcode, &chunk_error) : 0);
@@ -409,6 +415,8 @@ gpuscan_qual_generic_body(kern_gpuscan *kgpuscan,
 					STROM_KVAR_LIST(X)
 #undef X
 					KV.__dummy = 0;
+					if (is_column)
+						strom_kvars_from_column(KV, kds, &errcode);
 					pg_bool_t rc = gpuscan_qual_eval(&errcode, KP, KV);
 					st[k][j] = gpuscan_row_status(rc, errcode, &chunk_error);
 				}

@@ -112,6 +112,11 @@ struct strom_kvars {
 #undef X
 	int __dummy;
 };
+/* text / character(n) variables of a row taken from COLUMN arrays: offset -> address (strom_common.h) */
+#ifndef STROM_KVARLENA_LIST
+#define STROM_KVARLENA_LIST(X)
+#endif
+STROM_DEFINE_KVARS_FROM_COLUMN
 
 /* canonical 64-bit image of a key value: equal values <=> equal images */
 STROM_DEVICE cl_ulong hashjoin_key_image(cl_bool v)		{ return (cl_ulong)(v != 0); }
@@ -582,6 +587,8 @@ gpuhashjoin_main_body(kern_hashjoin *__restrict__ khashjoin,
 					STROM_KVAR_LIST(X)
 #undef X
 					KV.__dummy = 0;
+					if (is_column)
+						strom_kvars_from_column(KV, kds, &errcode);
 #if (defined(HASHJOIN_ABLATE) && HASHJOIN_ABLATE != 0) && !defined(STROM_DIAGNOSTIC_BUILD)
 #error "HASHJOIN_ABLATE builds leave work out and give wrong results: measurement only (set STROM_DIAGNOSTIC_BUILD=1, as scripts/gpu_*_ablate* do)"
 #endif
@@ -655,6 +662,8 @@ gpuhashjoin_main_body(kern_hashjoin *__restrict__ khashjoin,
 					STROM_KVAR_LIST(X)
 #undef X
 					KV.__dummy = 0;
+					if (is_column)
+						strom_kvars_from_column(KV, kds, &errcode);
 					out += (size_t)nrels *
 						gpuhashjoin_execute<ALL_SINGLE>(&errcode, KP, KV, kmhash, hjidx, kds_index, out);
 				}
@@ -913,6 +922,7 @@ gpuhashjoin_main_fast_body(kern_hashjoin *khashjoin,
 				STROM_KVAR_LIST(X)
 #undef X
 				KV.__dummy = 0;
+				strom_kvars_from_column(KV, kds, &errcode);
 				match[k][j] = 0;
 #if HASHJOIN_FAST_OUTER_QUAL
 				/*
@@ -1811,6 +1821,7 @@ gpuhashjoin_projection_column(kern_hashjoin *khashjoin,
 				STROM_KVAR_LIST(X)
 #undef X
 				KV.__dummy = 0;
+				strom_kvars_from_column(KV, kds, &errcode);
 				slot_idx[k] = ~0u;
 				if (valid[k] && hashjoin_fast_outer_key(&errcode, KP, KV, &key))
 				{

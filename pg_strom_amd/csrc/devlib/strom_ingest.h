@@ -9,6 +9,14 @@
  * row's index -- consecutive lanes write consecutive addresses; the
  * not-null bitmap words come from one __ballot per column.  Zone-map
  * min/max of integer-like columns are folded with wave reductions.
+ *
+ * A varlena column that is not a numeric (text, character(n)) keeps its datums
+ * as they are: the bytes go to the destination's heap area -- a wave sums its
+ * lanes' (4-byte rounded) sizes, takes that much from the chunk's 'usage'
+ * cursor with one atomic, and every lane copies its datum to its share -- and
+ * the column array receives the datum's offset from the chunk head (strom_kds.h).
+ * The datums of a chunk thus lie in no particular order; nothing reads them
+ * other than through their row's offset.
  */
 #ifndef STROM_INGEST_DEVICE_H
 #define STROM_INGEST_DEVICE_H
@@ -27,7 +35,7 @@ ingest_get_tuple(const kern_data_store *src, cl_uint row)
 
 /* VARNUM: some column is a varlena NUMERIC to decode (fixed per launch, so the
  * common all-fixed-width chunk does not carry the decoder) */
-template <bool VARNUM>
+template <bool VARNUM, bool VARLENA = false>
 __device__ __forceinline__ void
 ingest_to_column_body(const kern_data_store *__restrict__ src, kern_data_store *__restrict__ dst,
 					  const cl_int *__restrict__ type_oids, cl_uint *__restrict__ col_has_null)
@@ -147,6 +155,45 @@ ingest_to_column_body(const kern_data_store *__restrict__ src, kern_data_store *
 					*out = image;
 				}
 			}
+			/* any other varlena: the datum moves to the heap area, its offset to the column */
+			if (VARLENA && cm.attlen < 0 && !(VARNUM && (oid_c == STROM_NUMERICOID || to_decimal)))
+			{
+				cl_uint		sz = (addr ? strom_varsize_any(addr) : 0);
+				cl_uint		room = (sz + 3u) & ~3u;			/* every datum starts on a 4-byte boundary */
+				cl_uint		before = room;
+				/* inclusive prefix sum over the wave's lanes */
+#pragma unroll
+				for (int d = 1; d < 64; d <<= 1)
+				{
+					cl_uint	o = (cl_uint)__shfl_up((int)before, d, 64);
+					if (lane >= (cl_uint)d)
+						before += o;
+				}
+				cl_uint		total = (cl_uint)__shfl((int)before, 63, 64);
+				cl_uint		base_off = 0;
+				if (total > 0)
+				{
+					if (lane == 0)
+						base_off = atomicAdd(&dst->usage, total);
+					base_off = (cl_uint)__shfl((int)base_off, 0, 64);
+				}
+				cl_ulong	at = (cl_ulong)base_off + (before - room);
+				if (addr && (sz < 1 || at + sz > (cl_ulong)dst->length || at < base_off))
+				{
+					s_failed = 1;				/* a datum length no chunk holds: corrupt tuple */
+					at = 0;
+				}
+				else if (addr)
+				{
+					char   *out = (char *)dst + at;
+					for (cl_uint b = 0; b < sz; b++)
+						out[b] = addr[b];
+					for (cl_uint b = sz; b < room; b++)
+						out[b] = 0;
+				}
+				if (valid)
+					((cl_ulong *)((char *)dst + s_values_off[c]))[row] = (addr ? at : 0UL);
+			}
 			/* value */
 			cl_long		v = 0;
 			if (to_decimal)
@@ -201,6 +248,14 @@ ingest_to_column(const kern_data_store *__restrict__ src, kern_data_store *__res
 				 const cl_int *__restrict__ type_oids, cl_uint *__restrict__ col_has_null)
 {
 	ingest_to_column_body<false>(src, dst, type_oids, col_has_null);
+}
+
+extern "C" __global__ void
+__launch_bounds__(256)
+ingest_to_column_varlena(const kern_data_store *__restrict__ src, kern_data_store *__restrict__ dst,
+						 const cl_int *__restrict__ type_oids, cl_uint *__restrict__ col_has_null)
+{
+	ingest_to_column_body<true, true>(src, dst, type_oids, col_has_null);
 }
 
 extern "C" __global__ void
@@ -369,6 +424,13 @@ extern "C" __global__ void
 ingest_finish(kern_data_store *dst, const cl_int *type_oids, const cl_uint *col_has_null)
 {
 	kern_coldir *coldir = KERN_DATA_STORE_COLDIR(dst);
+	/* a heap area was sized for the worst case: the chunk ends where its last datum does */
+	if (threadIdx.x == 0 && dst->usage != 0)
+	{
+		cl_uint	end = (cl_uint)STROM_TYPEALIGN(KDS_COLUMN_ALIGN, dst->usage);
+		if (end >= dst->usage && end < dst->length)
+			dst->length = end;
+	}
 	for (cl_uint c = threadIdx.x; c < dst->ncols; c += blockDim.x)
 	{
 		if (!col_has_null[c])

@@ -21,8 +21,9 @@
  * one for bytes >= 0x80; not reproduced.  character(n) ignores trailing
  * blanks (bpchar_truelen, 154-166); text does not.
  *
- * COLUMN chunks hold fixed-width columns only (strom_kds.h); a text column
- * lives in the row formats the reference itself ships.
+ * In a COLUMN chunk a text column is an array of 8-byte offsets into the chunk's heap area
+ * (strom_kds.h); the kernels load it like an int8 column and pg_<type>_from_column turns offset
+ * into address.
  */
 #ifndef STROM_TEXTLIB_DEVICE_H
 #define STROM_TEXTLIB_DEVICE_H
@@ -68,6 +69,23 @@ strom_varlena_payload(cl_ulong datum, cl_int *p_len)
 		return result;															\
 	}																			\
 	STROM_DECLARE_VARREF_CORE(NAME, pg_##NAME##_from_addr)						\
+	/* a value loaded from a COLUMN chunk's offset array (strom_common.h:		\
+	 * strom_kvars_from_column): offset from the kds head -> address */			\
+	STROM_DEVICE pg_##NAME##_t													\
+	pg_##NAME##_from_column(cl_int *errcode, const kern_data_store *kds,		\
+							cl_uint colidx, pg_##NAME##_t v)					\
+	{																			\
+		if (v.isnull || v.value == 0)											\
+			return pg_##NAME##_make(0UL, true);									\
+		/* a by-value column declared as text (the chunk lies), or an offset	\
+		 * that leaves the chunk */												\
+		if (kds->colmeta[colidx].attlen >= 0 || v.value >= kds->length)			\
+		{																		\
+			STROM_SET_ERROR(errcode, StromError_DataStoreCorruption);			\
+			return pg_##NAME##_make(0UL, true);									\
+		}																		\
+		return pg_##NAME##_from_addr(errcode, (const char *)kds + v.value, -1);	\
+	}																			\
 	STROM_DEVICE pg_##NAME##_t													\
 	pg_##NAME##_param(const kern_parambuf *kparams,								\
 					  cl_int *errcode, cl_uint param_id)						\

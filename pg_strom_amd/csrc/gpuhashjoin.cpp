@@ -1128,6 +1128,10 @@ strom_hashjoin_project_column(strom_task *handle, strom_hashjoin_table *tbl, str
 		int		attlen;
 		switch (type_oids[i] < 0 ? -type_oids[i] : type_oids[i])
 		{
+			case STROM_TEXTOID: case STROM_BPCHARNOID:
+				/* joined rows with text columns leave as heap tuples (the ROW_FLAT projection) */
+				*p_errcode = StromError_BadRequestMessage;
+				return nullptr;
 			case STROM_BOOLOID: case STROM_BPCHAROID:	attlen = 1; break;
 			case STROM_INT2OID:							attlen = 2; break;
 			case STROM_INT4OID: case STROM_FLOAT4OID: case STROM_DATEOID:	attlen = 4; break;

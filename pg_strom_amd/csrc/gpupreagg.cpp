@@ -673,8 +673,12 @@ gpupreagg_launch(strom_task_impl *task, preagg_request req, bool checked = false
 
 	bool	use_lookup = req.lookup;
 	bool	use_joined = (req.joined_results != nullptr);
+	/* (a program with text / character(n) variables reads a COLUMN chunk through the row-at-a-time
+	 * kernel, which turns the column's offsets into addresses row by row with an error slot at
+	 * hand: strom_kvars_from_column) */
 	bool	use_column = (!use_joined && !use_lookup && req.format == KDS_FORMAT_COLUMN &&
-						  req.krowmap == nullptr && req.rowmap_dev == nullptr);
+						  req.krowmap == nullptr && req.rowmap_dev == nullptr &&
+						  !(prog->extra_flags & DEVTYPE_IS_VARLENA));
 	/* (the checked program adds in LDS with returning atomics: the LDS-atomics kernels only) */
 	bool	use_reg = (use_column && sess->reg_groups != 0 && !checked);
 	hipFunction_t fn = prog->get_function(dev, use_lookup ? "gpupreagg_dense_lookup"
@@ -1282,6 +1286,10 @@ gpupreagg_launch_hashed(strom_task_impl *task, preagg_request req, bool second =
 		task_fail(task, errcode);
 		return;
 	}
+	/* hash roles, the role map and the partition plan scan a COLUMN chunk's arrays as they are: not
+	 * for a program with text / character(n) variables (their column holds offsets that each row
+	 * turns into an address -- strom_kvars_from_column, the one-role walk does it) */
+	const bool	column_streams = (req.format == KDS_FORMAT_COLUMN && !(prog->extra_flags & DEVTYPE_IS_VARLENA));
 	/*
 	 * geometry: two work-groups per CU (64 KB of LDS each).  Slots can be
 	 * claimed past the fill limit by threads that raced through the limit test
@@ -1607,7 +1615,7 @@ gpupreagg_launch_hashed(strom_task_impl *task, preagg_request req, bool second =
 		void	   *a_rolemap = nullptr;
 		{
 			cl_ulong	per_role0 = (cl_ulong)lds_slots * 5 / 8;
-			if (req.format == KDS_FORMAT_COLUMN && !d_rowmap && nrows > 0 &&
+			if (column_streams && !d_rowmap && nrows > 0 &&
 				(cl_ulong)sess->groups_known > per_role0 && !getenv("STROM_GPUPREAGG_HASH_NO_ROLEMAP"))
 			{
 				size_t	tile = (size_t)block * 16;
@@ -1698,7 +1706,7 @@ gpupreagg_launch_hashed(strom_task_impl *task, preagg_request req, bool second =
 			cl_ulong	known = sess->groups_known;
 			if (const char *v = getenv("STROM_GPUPREAGG_HASH_FILL"))
 				per_role = std::max<cl_ulong>(1, (cl_ulong)lds_slots * (cl_ulong)atoi(v) / 100);
-			if (req.format == KDS_FORMAT_COLUMN && known > per_role && known <= per_role * 64)
+			if (column_streams && known > per_role && known <= per_role * 64)
 			{
 				while (nroles < 64 && (cl_ulong)nroles * per_role < known)
 					nroles <<= 1;
@@ -1707,7 +1715,7 @@ gpupreagg_launch_hashed(strom_task_impl *task, preagg_request req, bool second =
 			{
 				/* 1, 2, 4 ... 64; anything else would break the tile walk */
 				int want = atoi(v);
-				if (req.format == KDS_FORMAT_COLUMN && want >= 1 && want <= 64 && (want & (want - 1)) == 0)
+				if (column_streams && want >= 1 && want <= 64 && (want & (want - 1)) == 0)
 					nroles = (cl_uint)want;
 			}
 			/* (deferred rows of a later turn are a row map: the scan over the columns) */
@@ -2132,6 +2140,8 @@ submit_gpupreagg_over_join(strom_gpupreagg *sess, strom_task *join_handle, bool 
 		 * join program would silently not be applied */
 		(lookup && has_outer_qual) ||
 		key_attno < 1 || outer->head.format != KDS_FORMAT_COLUMN ||
+		/* (these kernels stream the outer columns; text variables take the plain fold) */
+		(sess->prog->extra_flags & DEVTYPE_IS_VARLENA) != 0 ||
 		outer->dindex != sess->dev->dindex || tbl_dindex != sess->dev->dindex)
 	{
 		/* needs: a finished join with STROM_RESULTS_ON_DEVICE, one inner relation

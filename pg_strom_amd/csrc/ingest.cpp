@@ -72,7 +72,18 @@ strom_dstore_to_column(strom_dstore *src, const int32_t *type_oids, int ntypes,
 	bool	varnum = false;
 	for (int i = 0; type_oids && i < ncols; i++)
 		varnum = varnum || (type_oids[i] == STROM_NUMERICOID) || STROM_TYPE_IS_DECIMAL(type_oids[i]);
-	hipFunction_t fn_main = prog->get_function(dev, varnum ? "ingest_to_column_varnum" : "ingest_to_column",
+	/* ... and the heap-area writer only for text / character(n) columns (named by their type: a
+	 * varlena column of unknown type is not guessed at) */
+	bool	varlena = false;
+	for (int i = 0; type_oids && i < ncols; i++)
+		varlena = varlena || type_oids[i] == STROM_TEXTOID || type_oids[i] == STROM_BPCHARNOID;
+	if (varlena && format == KDS_FORMAT_TUPSLOT)
+	{
+		*p_errcode = StromError_BadRequestMessage;		/* a TUPSLOT chunk holds no datum bytes */
+		return nullptr;
+	}
+	hipFunction_t fn_main = prog->get_function(dev, varlena ? "ingest_to_column_varlena"
+											   : varnum ? "ingest_to_column_varnum" : "ingest_to_column",
 											   &errcode);
 	hipFunction_t fn_fin = fn_main ? prog->get_function(dev, "ingest_finish", &errcode) : nullptr;
 	hipFunction_t fn_mm = fn_fin ? prog->get_function(dev, "ingest_minmax", &errcode) : nullptr;
@@ -93,6 +104,7 @@ strom_dstore_to_column(strom_dstore *src, const int32_t *type_oids, int ntypes,
 	kern_data_store *head = (kern_data_store *)hbuf.data();
 	kern_coldir *cd = KERN_DATA_STORE_COLDIR(head);
 	size_t	off = KDS_COLUMN_HEAD_LENGTH(ncols);
+	int		nheapcols = 0;
 	for (int i = 0; i < ncols; i++)
 	{
 		int attlen = head->colmeta[i].attlen;
@@ -111,11 +123,14 @@ strom_dstore_to_column(strom_dstore *src, const int32_t *type_oids, int ntypes,
 			head->colmeta[i].attalign = 8;
 			head->colmeta[i].attbyval = 1;
 		}
-		if (!(attlen == 1 || attlen == 2 || attlen == 4 || attlen == 8))
+		bool	heap_col = (attlen == -1 && type_oids &&
+							(type_oids[i] == STROM_TEXTOID || type_oids[i] == STROM_BPCHARNOID));
+		if (!(attlen == 1 || attlen == 2 || attlen == 4 || attlen == 8 || heap_col))
 		{
-			*p_errcode = StromError_DataStoreCorruption;	/* other varlena columns: host path */
+			*p_errcode = StromError_DataStoreCorruption;	/* varlena columns of other types: host path */
 			return nullptr;
 		}
+		nheapcols += (heap_col ? 1 : 0);
 		cd[i].values_off = (cl_uint)off;
 		off += KDS_COLUMN_VALUES_LENGTH(attlen, nitems);
 		cd[i].nulls_off = (cl_uint)off;			/* dropped by ingest_finish if unused */
@@ -130,9 +145,27 @@ strom_dstore_to_column(strom_dstore *src, const int32_t *type_oids, int ntypes,
 			return nullptr;
 		}
 	}
+	/*
+	 * the heap area behind the column arrays: the source's datums fit the source (its 'length'
+	 * bounds their sum), plus up to 3 bytes per datum for the 4-byte boundaries they start on.
+	 * 'usage' is the writer's cursor; ingest_finish leaves 'length' at the bytes really used.
+	 */
+	size_t	heap_off = off;
+	if (nheapcols > 0)
+	{
+		off += STROM_TYPEALIGN(KDS_COLUMN_ALIGN, (size_t)head->length + 4 * (size_t)nitems * nheapcols + 4);
+		if (off > 0xffffffffUL)
+		{
+			*p_errcode = StromError_DataStoreOutOfRange;
+			return nullptr;
+		}
+		for (int i = 0; i < ncols; i++)
+			if (head->colmeta[i].attlen == -1)
+				cd[i].extra_off = (cl_uint)heap_off;
+	}
 	head->hostptr = 0;
 	head->length = (cl_uint)off;
-	head->usage = 0;
+	head->usage = (cl_uint)(nheapcols > 0 ? heap_off : 0);
 	head->nitems = nitems;
 	head->nrooms = nitems;
 	head->nblocks = 0;

@@ -257,14 +257,14 @@ int			gpupreagg_hash_import_device(strom_gpupreagg *sess, const char *d_recs, cl
 hipFunction_t fixed_function(Device *dev, const char *name, int *p_errcode);
 int			num_devices();
 Program	   *lookup_program(strom_devprog_key key);
-/* text / character(n) values are addresses of varlena datums inside heap tuples
- * (strom_textlib.h): a program that uses them reads ROW / ROW_FLAT chunks only --
- * COLUMN and TUPSLOT chunks hold by-value datums (strom_kds.h) */
+/* text / character(n) values are addresses of varlena datums (strom_textlib.h): a program that
+ * uses them reads the chunks that hold such datums -- heap tuples (ROW / ROW_FLAT) and the heap
+ * area of a COLUMN chunk (strom_kds.h); a TUPSLOT chunk holds by-value datums */
 inline bool
 program_accepts_format(const Program *prog, cl_int format)
 {
 	return !(prog->extra_flags & DEVTYPE_IS_VARLENA) ||
-		format == KDS_FORMAT_ROW || format == KDS_FORMAT_ROW_FLAT;
+		format == KDS_FORMAT_ROW || format == KDS_FORMAT_ROW_FLAT || format == KDS_FORMAT_COLUMN;
 }
 bool		perfmon_enabled();
 strom_task_impl *task_create(Device *dev, strom_done_cb done, void *arg);

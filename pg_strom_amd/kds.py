@@ -293,6 +293,8 @@ def decode_column_chunk(buf):
     n = head.nitems
     for c in range(head.ncols):
         attlen = int(head.colmeta[c]["attlen"])
+        if attlen < 0:
+            attlen = 8              # a varlena column: 8-byte offsets of the datums (strom_kds.h)
         voff = int(cd[c]["values_off"])
         vals = np.frombuffer(buf[voff:voff + attlen * n].tobytes(), dtype="<i%d" % attlen)
         notnull = None
@@ -302,7 +304,8 @@ def decode_column_chunk(buf):
             bits = np.unpackbits(words.view(np.uint8), bitorder="little")[:n]
             notnull = bits.astype(bool)
         out.append(dict(values=vals, notnull=notnull, stat_flags=int(cd[c]["stat_flags"]),
-                        minval=int(cd[c]["minval"]), maxval=int(cd[c]["maxval"])))
+                        minval=int(cd[c]["minval"]), maxval=int(cd[c]["maxval"]),
+                        extra_off=int(cd[c]["extra_off"])))
     return out
 
 

@@ -14,7 +14,7 @@ import text_cases
 from pg_strom_amd import kds, runtime
 
 
-@pytest.mark.parametrize("fmt", ["row", "row_flat"])
+@pytest.mark.parametrize("fmt", ["row", "row_flat", "column"])
 def test_oracle_text_compare_matches_python(fmt):
     buf, txt, chr10, num, tnull = text_cases.text_table(3000, 5, fmt)
     for qual, fn, ext in text_cases.CASES:
@@ -33,6 +33,50 @@ def test_oracle_unreadable_varlena_is_rechecked():
     buf = kds.build_kds("row", [kds.Column("text_raw", [plain, compressed, external, plain])])
     rc, rows = oracle.gpuscan("(texteq (var 1 text) (const text 'abc'))", buf)
     assert rc == 0 and sorted(rows.tolist()) == [-3, -2, 1, 4]
+
+
+def test_column_chunk_layout_of_a_text_column():
+    """include/strom_kds.h: a varlena column of a COLUMN chunk is an array of 8-byte offsets
+    (from the chunk head; 0 = NULL) to complete datums in the chunk's heap area -- 4-byte headers on
+    4-byte boundaries, short ones packed; strom_kds_to_column moves the datums of heap tuples there
+    verbatim; the generated program lists its text variables for strom_kvars_from_column"""
+    words = [b"", b"a", b"x" * 126, b"x" * 127, b"hello world", b"y" * 1000, b"ab"]
+    nul = np.array([0, 0, 0, 0, 1, 0, 0], dtype=bool)
+    cols = [kds.Column("int4", np.arange(7, dtype=np.int32)), kds.Column("text", words, nul)]
+    buf = kds.build_kds("column", cols)
+    head = kds.KdsHead(buf)
+    assert head.format == 4 and head.length == len(buf) and head.usage <= head.length
+    cd = kds.decode_column_chunk(buf)[1]
+    offs = cd["values"].view(np.uint64)
+    assert len(offs) == 7 and offs[4] == 0 and not cd["notnull"][4]
+    seen = []
+    for r, w in enumerate(words):
+        if nul[r]:
+            continue
+        o = int(offs[r])
+        assert cd["extra_off"] <= o < head.usage
+        if len(w) + 1 <= 127:
+            assert int(buf[o]) == ((len(w) + 1) << 1) | 1 and buf[o + 1:o + 1 + len(w)].tobytes() == w
+            seen.append((o, o + 1 + len(w)))
+        else:
+            assert o % 4 == 0 and int(buf[o:o + 4].view(np.uint32)[0]) == (len(w) + 4) << 2
+            assert buf[o + 4:o + 4 + len(w)].tobytes() == w
+            seen.append((o, o + 4 + len(w)))
+    seen.sort()
+    assert all(a[1] <= b[0] for a, b in zip(seen, seen[1:]))             # no datum overlaps another
+    # heap tuples -> COLUMN on the host: the same rows come out
+    row = kds.build_kds("row", cols)
+    col = kds.kds_to_column(row)
+    for q in ("(texteq (var 2 text) (const text 'hello world'))", "(text_gt (var 2 text) (const text 'a'))",
+              "(isnull (var 2 text))"):
+        assert oracle.gpuscan(q, buf)[1].tolist() == oracle.gpuscan(q, row)[1].tolist() == oracle.gpuscan(q, col)[1].tolist()
+    cg = runtime.codegen_gpuscan("(and (texteq (var 2 text) (const text 'a')) (int4gt (var 1 int4) (const int4 0)))")
+    assert "#define STROM_KVARLENA_LIST(X) X(2,text)\n" in cg.source
+    cg = runtime.codegen_gpuscan("(int4gt (var 1 int4) (const int4 0))")
+    assert "STROM_KVARLENA_LIST" not in cg.source
+    # a TUPSLOT chunk still cannot hold the datums
+    with pytest.raises(ValueError):
+        kds.build_kds("tupslot", cols)
 
 
 def test_codegen_catalogue_and_parambuf():

@@ -2,7 +2,8 @@
 text / character(n) on the device (needs an MI355X: -m gpu), through the C ABI.  Row
 selection is byte work: bit-exact against the CPU oracle AND against Python's own bytes
 comparison (tests/text_cases.py).  Text columns live in heap tuples (ROW / ROW_FLAT, the
-formats the reference ships); COLUMN / TUPSLOT chunks are refused for such a program.
+formats the reference ships) and in the heap area of a COLUMN chunk (8-byte offsets in the column
+array, include/strom_kds.h), which the streaming kernels read; TUPSLOT chunks are refused.
 """
 import numpy as np
 import pytest
@@ -18,7 +19,7 @@ from test_gpuhashjoin_gpu import run_and_compare
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("fmt", ["row", "row_flat"])
+@pytest.mark.parametrize("fmt", ["row", "row_flat", "column"])
 def test_text_quals_match_oracle_and_python(fmt):
     buf, txt, chr10, num, tnull = text_cases.text_table(20011, 12, fmt)
     for qual, fn, ext in text_cases.CASES:
@@ -28,33 +29,72 @@ def test_text_quals_match_oracle_and_python(fmt):
         assert np.array_equal(np.sort(np.asarray(res.results[:res.nitems])) - 1, want), qual
 
 
-def test_unreadable_varlena_rows_go_back_to_the_cpu():
+@pytest.mark.parametrize("fmt", ["row", "column"])
+def test_unreadable_varlena_rows_go_back_to_the_cpu(fmt):
     plain = kds.varlena_datum(b"abc")
     compressed = np.array([(20 << 2) | 2], dtype="<u4").tobytes() + b"\0" * 16
     external = bytes([0x01, 18]) + b"\0" * 16
     datums = [plain, compressed, external, plain] * 500
-    buf = kds.build_kds("row", [kds.Column("text_raw", datums)])
+    buf = kds.build_kds(fmt, [kds.Column("text_raw", datums)])
     res = check("(texteq (var 1 text) (const text 'abc'))", buf)
     assert len(res.passed_rows()) == 1000 and len(res.recheck_rows()) == 1000
 
 
-def test_column_and_tupslot_chunks_are_refused_for_text_programs():
-    """COLUMN / TUPSLOT hold by-value datums: a program with text values must not run on them
-    (a cl_ulong read as an address would fault)"""
-    a = np.arange(1000, dtype=np.int64)
+def test_chunks_without_the_datums_are_refused_for_text_programs():
+    """a TUPSLOT chunk holds by-value datums: refused on the host.  A COLUMN chunk whose column is
+    by-value where the program reads text: the chunk lies about itself (DataStoreCorruption, as the
+    row formats answer for such a column) -- a cl_ulong is never followed as an address"""
+    a = np.arange(1000, dtype=np.int64) * 8
     scan = GpuScan("(texteq (var 1 text) (const text 'abc'))").begin()
     try:
-        for fmt in ("column", "tupslot"):
-            buf = kds.build_kds(fmt, [kds.Column("int8", a)])
-            with pytest.raises(runtime.StromError) as ei:
-                scan.scan_chunk(buf)
-            assert ei.value.errcode == 101
+        buf = kds.build_kds("tupslot", [kds.Column("int8", a)])
+        with pytest.raises(runtime.StromError) as ei:
+            scan.scan_chunk(buf)
+        assert ei.value.errcode == 101
+        for row_map in (None, np.arange(0, 1000, 3, dtype=np.int32)):
+            buf = kds.build_kds("column", [kds.Column("int8", a)])
+            res = scan.scan_chunk(buf, row_map=row_map)
+            assert res.errcode == 1002 and res.nitems == 0        # StromError_DataStoreCorruption
     finally:
         scan.end()
 
 
-def test_text_qual_inside_gpupreagg_through_the_chunk_message():
-    buf, txt, chr10, num, tnull = text_cases.text_table(30000, 21, "row")
+def test_text_column_through_row_maps_ingest_and_resident_chunks():
+    """the same text table as heap pages, as a COLUMN chunk built on the host, as the device's own
+    ROW -> COLUMN ingest of the heap pages (datums moved to the heap area by the wave allocator),
+    and behind a row map: the same rows pass"""
+    runtime.init()
+    n = 50021
+    buf, txt, chr10, num, tnull = text_cases.text_table(n, 77, "row")
+    col = kds.kds_to_column(buf)
+    quals = [text_cases.CASES[i] for i in (0, 3, 5, 7, 8)]
+    rm = np.sort(np.random.default_rng(2).choice(n, n // 3, replace=False)).astype(np.int32)
+    src = runtime.DeviceStore.upload(buf)
+    dev, _ = src.to_column([kds.SQL_TYPES[t][0] for t in ("int4", "text", "character", "int8")])
+    try:
+        back = dev.download()
+        for qual, fn, ext in quals:
+            want = text_cases.expected_rows(fn, txt, chr10, num, tnull)
+            for chunk in (col, back):
+                res = check(qual, chunk, ext)
+                assert np.array_equal(np.sort(np.asarray(res.results[:res.nitems])) - 1, want), qual
+            res = check(qual, col, ext, row_map=rm)
+            assert np.array_equal(np.sort(np.asarray(res.results[:res.nitems])) - 1, np.intersect1d(want, rm)), qual
+            scan = GpuScan(qual).begin(ext_params=ext)
+            try:
+                res = scan.scan_chunk(dev)
+            finally:
+                scan.end()
+            assert res.errcode == 0
+            assert np.array_equal(np.sort(np.asarray(res.results[:res.nitems])) - 1, want), qual
+    finally:
+        dev.release()
+        src.release()
+
+
+@pytest.mark.parametrize("fmt", ["row", "column"])
+def test_text_qual_inside_gpupreagg_through_the_chunk_message(fmt):
+    buf, txt, chr10, num, tnull = text_cases.text_table(30000, 21, fmt)
     spec = ("(gpupreagg (qual (and (text_ge (var 2 text) (const text 'a')) (bpcharne (var 3 character) (param 0 character))))"
             " (key (var 1 int4)) (nrows) (psum (var 4 int8)))")
     agg = GpuPreAgg(spec)
@@ -73,10 +113,24 @@ def test_text_qual_inside_gpupreagg_through_the_chunk_message():
         cnt, sm = want.get(int(num[i]), (0, 0))
         want[int(num[i])] = (cnt + 1, sm + i)
     assert got == want
+    # the same through sessions -- dense ids and the hashed table -- over the resident chunk
+    ds = runtime.DeviceStore.upload(buf)
+    try:
+        for hashed in (False, True):
+            sess = GpuPreAgg(spec).begin_hashed(ext_params=[b"MAIL"]) if hashed else \
+                GpuPreAgg(spec).begin([(-50, 100)], ext_params=[b"MAIL"])
+            try:
+                assert sess.fold(ds)[0] == 0
+                assert_matches_oracle(spec, sess, [buf], sess.fetch(), ext=[b"MAIL"])
+            finally:
+                sess.end()
+    finally:
+        ds.release()
 
 
-def test_text_residual_qual_in_a_join():
-    buf, txt, chr10, num, tnull = text_cases.text_table(20000, 33, "row_flat")
+@pytest.mark.parametrize("fmt", ["row_flat", "column"])
+def test_text_residual_qual_in_a_join(fmt):
+    buf, txt, chr10, num, tnull = text_cases.text_table(20000, 33, fmt)
     pk = np.arange(-50, 50, dtype=np.int32)
     inner = kds.build_kds("row", [kds.Column("int4", pk), kds.Column("int4", pk * 3)])
     spec = ("(gpuhashjoin (rel (hashkey (var 1 int4) 1 int4)"
@@ -196,7 +250,7 @@ def test_inner_text_columns_in_join_quals_and_in_projected_tuples():
         assert rows[i] == [np.int64(o).tobytes(), None if wnull[d] else words[d], np.int16(pk[d] % 5).tobytes()], i
 
 
-@pytest.mark.parametrize("ofmt", ["row", "row_flat"])
+@pytest.mark.parametrize("ofmt", ["row", "row_flat", "column"])
 def test_text_and_character_hash_keys(ofmt):
     """join ON outer.text = inner.text, and ON (character(n), int4): the probe index hashes the
     payload bytes (opencl_hashjoin.h:935-953) and, a hash not being the value, the HASH form with
@@ -210,8 +264,9 @@ def test_text_and_character_hash_keys(ofmt):
     words = (W + gen * 3)[:nd]
     wnull = np.arange(nd) % 17 == 4
     chr8 = [(w[:8] + b" " * 8)[:8] for w in words]
-    inner = kds.build_kds("row", [kds.Column("text", words, wnull), kds.Column("character", chr8),
-                                  kds.Column("int4", (np.arange(nd) % 3).astype(np.int32))])
+    inner = kds.build_kds("column" if ofmt == "column" else "row",
+                          [kds.Column("text", words, wnull), kds.Column("character", chr8),
+                           kds.Column("int4", (np.arange(nd) % 3).astype(np.int32))])
     pool = W + gen + [b"no such word", b"hello   ", b"k00001k00001 "]
     otxt = [pool[i] for i in rng.integers(0, len(pool), n)]
     onull = rng.random(n) < 0.03
