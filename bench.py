@@ -168,8 +168,15 @@ def c5_chunk_device(nrows, seed, decimal=True):
 
     def rnd(lo, hi, dtype=torch.int64):
         return torch.randint(lo, hi, (nrows,), dtype=dtype, device="cuda", generator=g)
-    rf = torch.tensor([65, 78, 82], dtype=torch.int8, device="cuda")[rnd(0, 3)]
-    ls = torch.tensor([70, 79], dtype=torch.int8, device="cuda")[rnd(0, 2)]
+    # l_returnflag / l_linestatus the way dbgen derives them from the dates (TPC-H 4.2.3): status 'O'
+    # for lines shipped after 1995-06-17, else 'F'; flag 'N' for the open ones, 'A' or 'R' for the
+    # rest -- three populated groups of a quarter, a quarter and a half of the table (dbgen's fourth,
+    # N/F, holds 0.6 % of it), so the largest group's sum(charge) at scale 6 leaves int8 on one GPU's
+    # share of C5 as it does on the real table
+    ship = rnd(-2922, -2922 + 2526, torch.int32)
+    is_open = ship > -1659                          # date '1995-06-17' in days since 2000-01-01
+    ls = torch.where(is_open, 79, 70).to(torch.int8)
+    rf = torch.where(is_open, 78, torch.tensor([65, 82], dtype=torch.int64, device="cuda")[rnd(0, 2)]).to(torch.int8)
     qty = rnd(1, 51)
     prc, dsc, tax = rnd(90000, 10494951), rnd(0, 11), rnd(0, 9)
     if decimal:
@@ -179,7 +186,6 @@ def c5_chunk_device(nrows, seed, decimal=True):
         # the reference's 64-bit float-decimal images (opencl_numeric.h:122-160)
         cols, ntype = [rf, ls, numeric_images_device(qty, 0), numeric_images_device(prc, 2),
                        numeric_images_device(dsc, 2), numeric_images_device(tax, 2)], "numeric"
-    ship = rnd(-2922, -2922 + 2526, torch.int32)
     cutoff = -486                                   # date '1998-09-02' in days since 2000-01-01
     keep = ship <= cutoff
     gid = ((rf.long() - 65) * 16 + (ls.long() - 70))[keep]
@@ -658,6 +664,7 @@ def operator_figures(args, k, c, measured_peak, cpu_blocks):
         pr = agg.fetch()
         ngrp = q1_check(pr, ref_total)
         beyond = sum(1 for v in ref_total["sum_charge"] if v >= 2**63)
+        assert beyond >= 1, "Q1 share: no group's sum(charge) left int8 -- the case this block is here for"
         out["q1_shape_c5_one_gpu_share"] = dict(
             workload="TPC-H Q1-shaped GpuPreAgg, ONE GPU's share of BASELINE configs[4]: 6e9 / 8 = %d lineitem-like "
                      "rows (%.1f GB) in %d resident chunks folded into one session, decimal columns (38 B/row)"
