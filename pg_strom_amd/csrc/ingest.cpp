@@ -74,17 +74,15 @@ strom_dstore_to_column(strom_dstore *src, const int32_t *type_oids, int ntypes,
 		varnum = varnum || (type_oids[i] == STROM_NUMERICOID) || STROM_TYPE_IS_DECIMAL(type_oids[i]);
 	/* ... and the heap-area writer only for text / character(n) columns (named by their type: a
 	 * varlena column of unknown type is not guessed at) */
-	bool	varlena = false;
-	for (int i = 0; type_oids && i < ncols; i++)
-		varlena = varlena || type_oids[i] == STROM_TEXTOID || type_oids[i] == STROM_BPCHARNOID;
-	if (varlena && format == KDS_FORMAT_TUPSLOT)
-	{
-		*p_errcode = StromError_BadRequestMessage;		/* a TUPSLOT chunk holds no datum bytes */
-		return nullptr;
-	}
-	hipFunction_t fn_main = prog->get_function(dev, varlena ? "ingest_to_column_varlena"
-											   : varnum ? "ingest_to_column_varnum" : "ingest_to_column",
+	auto is_text_type = [](int32_t oid) {
+		/* (1042 is pg_type's bpchar of any length; a by-value char(1) column has attlen 1) */
+		return oid == STROM_TEXTOID || oid == STROM_BPCHARNOID || oid == STROM_BPCHAROID;
+	};
+	hipFunction_t fn_main = prog->get_function(dev, varnum ? "ingest_to_column_varnum" : "ingest_to_column",
 											   &errcode);
+	hipFunction_t fn_heap = fn_main ? prog->get_function(dev, "ingest_to_column_varlena", &errcode) : nullptr;
+	if (!fn_heap)
+		fn_main = nullptr;
 	hipFunction_t fn_fin = fn_main ? prog->get_function(dev, "ingest_finish", &errcode) : nullptr;
 	hipFunction_t fn_mm = fn_fin ? prog->get_function(dev, "ingest_minmax", &errcode) : nullptr;
 	if (!fn_main || !fn_fin || !fn_mm)
@@ -123,8 +121,7 @@ strom_dstore_to_column(strom_dstore *src, const int32_t *type_oids, int ntypes,
 			head->colmeta[i].attalign = 8;
 			head->colmeta[i].attbyval = 1;
 		}
-		bool	heap_col = (attlen == -1 && type_oids &&
-							(type_oids[i] == STROM_TEXTOID || type_oids[i] == STROM_BPCHARNOID));
+		bool	heap_col = (attlen == -1 && type_oids && is_text_type(type_oids[i]));
 		if (!(attlen == 1 || attlen == 2 || attlen == 4 || attlen == 8 || heap_col))
 		{
 			*p_errcode = StromError_DataStoreCorruption;	/* varlena columns of other types: host path */
@@ -153,6 +150,12 @@ strom_dstore_to_column(strom_dstore *src, const int32_t *type_oids, int ntypes,
 	size_t	heap_off = off;
 	if (nheapcols > 0)
 	{
+		if (format == KDS_FORMAT_TUPSLOT)
+		{
+			*p_errcode = StromError_BadRequestMessage;		/* a TUPSLOT chunk holds no datum bytes */
+			return nullptr;
+		}
+		fn_main = fn_heap;
 		off += STROM_TYPEALIGN(KDS_COLUMN_ALIGN, (size_t)head->length + 4 * (size_t)nitems * nheapcols + 4);
 		if (off > 0xffffffffUL)
 		{

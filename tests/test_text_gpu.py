@@ -53,8 +53,9 @@ def test_chunks_without_the_datums_are_refused_for_text_programs():
         assert ei.value.errcode == 101
         for row_map in (None, np.arange(0, 1000, 3, dtype=np.int32)):
             buf = kds.build_kds("column", [kds.Column("int8", a)])
-            res = scan.scan_chunk(buf, row_map=row_map)
-            assert res.errcode == 1002 and res.nitems == 0        # StromError_DataStoreCorruption
+            with pytest.raises(runtime.StromError) as ei:
+                scan.scan_chunk(buf, row_map=row_map)
+            assert ei.value.errcode == 300                         # StromError_DataStoreCorruption
     finally:
         scan.end()
 
