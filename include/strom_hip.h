@@ -551,12 +551,27 @@ strom_task *strom_submit_gpupreagg_mapped(strom_gpupreagg *sess, strom_dstore *k
  * ------------------------------------------------------------------ */
 int			strom_gpupreagg_allreduce(strom_gpupreagg *sess, void *comm, void *stream);
 /*
- * Hashed GROUP BY sessions (strom_gpupreagg_create_hashed) have no common table layout:
- * strom_gpupreagg_allreduce() packs each rank's groups on the device, all-gathers the
- * counts and the records (padded to the largest rank) and merges the other ranks' records
- * into the rank's own table -- every rank ends up with every group, as above.
- * strom_gpupreagg_merge() is the same merge between two sessions of ONE device: src's groups are
- * added to dst's table, src is left as it is.  Hashed sessions: export + import, as above.  Dense
+ * Hashed GROUP BY sessions (strom_gpupreagg_create_hashed) have no common table layout: their
+ * groups travel, HASH-PARTITIONED -- a group belongs to the rank its key
+ * hashes to; every rank packs its groups by owner, the ranks exchange them pairwise
+ * (ncclSend / ncclRecv) and each merges its own partition:
+ *   strom_gpupreagg_reduce_scatter()  ends there: afterwards this rank holds the merged groups
+ *                                     it owns and nothing else -- the ranks' fetches are disjoint,
+ *                                     their union is the result (what parallel backends under a
+ *                                     Gather node want);
+ *   strom_gpupreagg_allreduce()       goes on to all-gather the final groups: afterwards every
+ *                                     rank holds every merged group, as above.
+ * Integer sums never wrap here either: the ranks first all-gather the largest |sum| each holds,
+ * and when the sum of those is 2^63 or more every rank returns StromError_CpuReCheck with its
+ * table untouched (the chunks are then aggregated on the CPU, the reference's answer to
+ * CHECK_OVERFLOW_INT, opencl_gpupreagg.h:142-143).  A rank-local failure (out of memory, a full
+ * table) makes EVERY rank return an error: no rank is left waiting in a collective.
+ * strom_gpupreagg_exchange_local() runs the same exchange among n (<= 64) hashed sessions of ONE
+ * device, session i as rank i, with device copies where the collectives are -- the harness that
+ * shows a wrong owner, a lost partition or a dropped range check on one GPU.
+ * strom_gpupreagg_merge() is the merge between two sessions of ONE device: src's groups are
+ * added to dst's table, src is left as it is.  Hashed sessions: export + import under the same
+ * range check.  Dense
  * sessions (same program, same domain, same compaction): the tables are added lane by lane with the
  * all-reduce merge's own prepare / operator / finish steps -- identities for entries without a value,
  * sign flips for the float min / max keys, flags as bytes under MAX, integer sums as carry-free limbs
@@ -564,6 +579,8 @@ int			strom_gpupreagg_allreduce(strom_gpupreagg *sess, void *comm, void *stream)
  * match are refused with StromError_BadRequestMessage.
  */
 int			strom_gpupreagg_merge(strom_gpupreagg *dst, strom_gpupreagg *src);
+int			strom_gpupreagg_reduce_scatter(strom_gpupreagg *sess, void *comm, void *stream);
+int			strom_gpupreagg_exchange_local(strom_gpupreagg **sessions, int n, int gather_after);
 int			strom_gpupreagg_census_allreduce(strom_gpupreagg *sess, void *comm, void *stream);
 /* communicator bootstrap for a host without its own: rank 0 makes the id
  * (strom_rccl_unique_id_bytes() bytes), hands it to the others by whatever

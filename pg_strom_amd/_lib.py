@@ -192,6 +192,8 @@ PROTOTYPES = {
     "strom_task_devptr": (c_void_p, [c_void_p]),
     "strom_gpupreagg_allreduce": (c_int, [c_void_p, c_void_p, c_void_p]),
     "strom_gpupreagg_merge": (c_int, [c_void_p, c_void_p]),
+    "strom_gpupreagg_reduce_scatter": (c_int, [c_void_p, c_void_p, c_void_p]),
+    "strom_gpupreagg_exchange_local": (c_int, [ctypes.POINTER(c_void_p), c_int, c_int]),
     "strom_gpupreagg_census_allreduce": (c_int, [c_void_p, c_void_p, c_void_p]),
     "strom_rccl_unique_id_bytes": (c_size_t, []),
     "strom_rccl_get_unique_id": (c_int, [c_void_p, c_size_t]),

@@ -4280,6 +4280,97 @@ gpupreagg_hash_export(const char *htab, char *out, cl_uint *counter)
 }
 
 /*
+ * The groups packed BY OWNER for the hash-partitioned exchange between ranks
+ * (csrc/parallel.cpp: hashed_exchange): group g belongs to rank owner(g) of 'nparts', a function
+ * of the key alone, so every rank sends a group's partial to the same place.  First the owners are
+ * counted (one LDS histogram per work-group, one atomic per owner and work-group), the host turns
+ * counts into offsets, then the records leave as in gpupreagg_hash_export with one cursor per owner
+ * -- a wave reserves once per owner it holds records of.
+ */
+STROM_DEVICE cl_uint
+gpupreagg_hash_owner(cl_uint hash, cl_uint nparts)
+{
+	/* (the table's slot is the hash's low bits, the partition plan's unit its high ones: a
+	 * multiplicative remix keeps the owner independent of both) */
+	return (cl_uint)(((cl_ulong)(hash * 0x9e3779b1u) * nparts) >> 32);
+}
+
+STROM_DEVICE cl_uint
+gpupreagg_hash_rec_owner(const char *src, cl_uint nparts)
+{
+	cl_ulong	kimg[GPUPREAGG_NKEYS + 1];
+	for (int k = 0; k < GPUPREAGG_NKEYS; k++)
+		kimg[k] = HASH_REC_KEYS(src)[k];
+	return gpupreagg_hash_owner(gpupreagg_hash_of(kimg, *HASH_REC_KNULL(src)), nparts);
+}
+
+#define GPUPREAGG_HASH_MAXOWNERS	64
+
+extern "C" __global__ void
+__launch_bounds__(256)
+gpupreagg_hash_owner_count(const char *htab, cl_uint nparts, cl_uint *counts)
+{
+	__shared__ cl_uint	s_counts[GPUPREAGG_HASH_MAXOWNERS];
+	const gpupreagg_hash_head *head = (const gpupreagg_hash_head *)htab;
+	cl_uint		C = head->capacity;
+
+	if (threadIdx.x < GPUPREAGG_HASH_MAXOWNERS)
+		s_counts[threadIdx.x] = 0;
+	__syncthreads();
+	for (cl_uint i = blockIdx.x * blockDim.x + threadIdx.x; i < C; i += gridDim.x * blockDim.x)
+	{
+		const char *src = gpupreagg_hash_rec(htab, i);
+		if (*HASH_REC_STATE(src) == 2)
+			atomicAdd(&s_counts[gpupreagg_hash_rec_owner(src, nparts)], 1u);
+	}
+	__syncthreads();
+	if (threadIdx.x < nparts && s_counts[threadIdx.x] != 0)
+		atomicAdd(&counts[threadIdx.x], s_counts[threadIdx.x]);
+}
+
+/* offsets[p] = first record of owner p in out[]; cursors[p] starts at 0 */
+extern "C" __global__ void
+__launch_bounds__(256)
+gpupreagg_hash_export_parts(const char *htab, char *out, cl_uint nparts,
+							const cl_uint *offsets, cl_uint *cursors)
+{
+	const gpupreagg_hash_head *head = (const gpupreagg_hash_head *)htab;
+	const size_t	reclen = 8 + 8 * (GPUPREAGG_NKEYS + GPUPREAGG_NAGGS);
+	cl_uint		C = head->capacity;
+
+	for (cl_uint base = blockIdx.x * blockDim.x; base < C; base += gridDim.x * blockDim.x)
+	{
+		cl_uint		i = base + threadIdx.x;
+		const char *src = gpupreagg_hash_rec(htab, i < C ? i : 0);
+		bool		ready = (i < C && *HASH_REC_STATE(src) == 2);
+		cl_uint		owner = (ready ? gpupreagg_hash_rec_owner(src, nparts) : ~0u);
+		cl_uint		idx = 0;
+		cl_ulong	todo = __ballot(ready);
+		/* one reservation per wave and owner */
+		while (todo != 0)
+		{
+			cl_uint		p = (cl_uint)__shfl((int)owner, (int)__builtin_ctzll(todo), STROM_WAVE);
+			cl_ulong	mask = __ballot(ready && owner == p);
+			cl_uint		first = 0;
+			if (strom_lane_id() == 0)
+				first = atomicAdd(&cursors[p], (cl_uint)__popcll(mask));
+			first = __shfl(first, 0, STROM_WAVE);
+			if (ready && owner == p)
+				idx = offsets[p] + first + (cl_uint)__popcll(mask & ((1UL << strom_lane_id()) - 1));
+			todo &= ~mask;
+		}
+		if (!ready)
+			continue;
+		char	   *rec = out + reclen * idx;
+		((cl_uint *)rec)[0] = *HASH_REC_KNULL(src);
+		((cl_uint *)rec)[1] = *HASH_REC_FLAGS(src);
+		cl_ulong   *body = (cl_ulong *)(rec + 8);
+		for (int k = 0; k < GPUPREAGG_NKEYS + GPUPREAGG_NAGGS; k++)
+			body[k] = HASH_REC_KEYS(src)[k];
+	}
+}
+
+/*
  * the groups as TUPSLOT rows, written where the host will copy them from: what a fetch needs
  * when no partial is a 64-bit numeric (those may split into two rows: host).  rows = the
  * first row of the destination image, stride = KDS_TUPSLOT_STRIDE(ncols); tmeta[i] describes

@@ -1262,6 +1262,25 @@ hash_sum_refresh(strom_gpupreagg *sess)
 	return 0;
 }
 
+/*
+ * the largest |integer sum| the table holds, plus one (0: no integer sums, or an empty table):
+ * measured by hash_sum_refresh, read back.  sess->lock held.
+ */
+int
+hash_sum_measured_bound(strom_gpupreagg *sess, cl_ulong *p_bound)
+{
+	*p_bound = 0;
+	if (sess->nintsums == 0 || !sess->htab)
+		return 0;
+	int		rc = hash_sum_refresh(sess);
+	if (rc)
+		return rc;
+	if (hipStreamSynchronize(sess->dev->streams[0]) != hipSuccess ||
+		hipMemcpy(p_bound, sess->htab + 32, sizeof(cl_ulong), hipMemcpyDeviceToHost) != hipSuccess)
+		return StromError_HipInternal;
+	return 0;
+}
+
 void
 gpupreagg_launch_hashed(strom_task_impl *task, preagg_request req, bool second = false)
 {
@@ -2492,7 +2511,8 @@ strom::gpupreagg_is_hashed(strom_gpupreagg *sess, int *p_dindex)
 
 /* the groups of a hashed session packed on the device: { knull, flags, keys[], vals[] } each */
 int
-strom::gpupreagg_hash_export_device(strom_gpupreagg *sess, char **p_recs, cl_uint *p_count, size_t *p_reclen)
+strom::gpupreagg_hash_export_device(strom_gpupreagg *sess, char **p_recs, cl_uint *p_count, size_t *p_reclen,
+									cl_ulong *p_sum_bound)
 {
 	Device *dev = sess->dev;
 	size_t	reclen = 8 + 8 * (sess->key_resno.size() + sess->agg_resno.size());
@@ -2502,10 +2522,14 @@ strom::gpupreagg_hash_export_device(strom_gpupreagg *sess, char **p_recs, cl_uin
 	*p_recs = nullptr;
 	*p_count = 0;
 	*p_reclen = reclen;
+	if (p_sum_bound)
+		*p_sum_bound = 0;
 	(void)hipSetDevice(dev->hip_id);
 	if (!sess->htab)
 		return 0;
 	int rc = hash_table_ngroups(sess, &ngroups, &overflow);
+	if (rc == 0 && p_sum_bound)
+		rc = hash_sum_measured_bound(sess, p_sum_bound);
 	if (rc)
 		return rc;
 	if (overflow)
@@ -2540,6 +2564,79 @@ strom::gpupreagg_hash_export_device(strom_gpupreagg *sess, char **p_recs, cl_uin
 	return 0;
 }
 
+/*
+ * ... packed by owner for the hash-partitioned exchange (devlib: gpupreagg_hash_export_parts): the
+ * records of owner p are h_counts[p] records starting at record sum(h_counts[0 .. p)).
+ */
+int
+strom::gpupreagg_hash_export_parts_device(strom_gpupreagg *sess, cl_uint nparts, char **p_recs, cl_uint *h_counts,
+										  size_t *p_reclen, cl_ulong *p_sum_bound)
+{
+	Device *dev = sess->dev;
+	size_t	reclen = 8 + 8 * (sess->key_resno.size() + sess->agg_resno.size());
+	cl_uint	ngroups = 0, overflow = 0;
+	std::lock_guard<std::mutex> g(sess->lock);
+
+	*p_recs = nullptr;
+	*p_reclen = reclen;
+	*p_sum_bound = 0;
+	for (cl_uint p = 0; p < nparts; p++)
+		h_counts[p] = 0;
+	if (nparts < 1 || nparts > 64)
+		return StromError_BadRequestMessage;
+	(void)hipSetDevice(dev->hip_id);
+	if (!sess->htab)
+		return 0;
+	int rc = hash_table_ngroups(sess, &ngroups, &overflow);
+	if (rc == 0)
+		rc = hash_sum_measured_bound(sess, p_sum_bound);
+	if (rc)
+		return rc;
+	if (overflow)
+		return StromError_DataStoreNoSpace;
+	if (ngroups == 0)
+		return 0;
+	int		errcode = 0;
+	hipFunction_t fn_count = sess->prog->get_function(dev, "gpupreagg_hash_owner_count", &errcode);
+	hipFunction_t fn_parts = fn_count ? sess->prog->get_function(dev, "gpupreagg_hash_export_parts", &errcode) : nullptr;
+	if (!fn_parts)
+		return errcode;
+	/* behind the records: counts, offsets, cursors (nparts words each) */
+	size_t	words_at = STROM_TYPEALIGN(16, reclen * ngroups);
+	char   *d_out = (char *)dev->pool.alloc(words_at + 3 * sizeof(cl_uint) * 64);
+	if (!d_out)
+		return StromError_OutOfMemory;
+	cl_uint	   *d_counts = (cl_uint *)(d_out + words_at);
+	cl_uint	   *d_offsets = d_counts + 64, *d_cursors = d_counts + 128;
+	hipStream_t	stream = dev->streams[0];
+	const void *a_tab = sess->htab;
+	void	   *a_out = d_out, *a_cnt = d_counts, *a_off = d_offsets, *a_cur = d_cursors;
+	void	   *args_count[] = { &a_tab, &nparts, &a_cnt };
+	void	   *args_parts[] = { &a_tab, &a_out, &nparts, &a_off, &a_cur };
+	unsigned	grid = std::min<unsigned>((sess->hash_capacity + 255) / 256, (unsigned)dev->prop.multiProcessorCount * 8);
+	cl_uint		offsets[64], total = 0;
+	bool ok = (hipMemsetAsync(d_counts, 0, 3 * sizeof(cl_uint) * 64, stream) == hipSuccess &&
+			   hipModuleLaunchKernel(fn_count, grid, 1, 1, 256, 1, 1, 0, stream, args_count, nullptr) == hipSuccess &&
+			   hipMemcpyAsync(h_counts, d_counts, sizeof(cl_uint) * nparts, hipMemcpyDeviceToHost, stream) == hipSuccess &&
+			   hipStreamSynchronize(stream) == hipSuccess);
+	for (cl_uint p = 0; ok && p < nparts; p++)
+	{
+		offsets[p] = total;
+		total += h_counts[p];
+	}
+	ok = ok && total == ngroups &&
+		hipMemcpyAsync(d_offsets, offsets, sizeof(cl_uint) * nparts, hipMemcpyHostToDevice, stream) == hipSuccess &&
+		hipModuleLaunchKernel(fn_parts, grid, 1, 1, 256, 1, 1, 0, stream, args_parts, nullptr) == hipSuccess &&
+		hipStreamSynchronize(stream) == hipSuccess;
+	if (!ok)
+	{
+		dev->pool.release(d_out);
+		return StromError_HipInternal;
+	}
+	*p_recs = d_out;
+	return 0;
+}
+
 void
 strom::gpupreagg_hash_release(strom_gpupreagg *sess, char *recs)
 {
@@ -2548,9 +2645,17 @@ strom::gpupreagg_hash_release(strom_gpupreagg *sess, char *recs)
 }
 
 /* packed groups (nsegs segments of seg_len records, h_counts[seg] of them set) into the table */
+/*
+ * incoming_sum_bound: the sum over the segments of "largest |integer sum| + 1" of the tables the
+ * records come from (gpupreagg_hash_export*_device), or 0 when no incoming group can meet a group
+ * of this table or another segment (disjoint keys).  The import adds 64-bit sums with plain
+ * atomics: it runs only when this table's own bound plus the incoming one stays below 2^63 --
+ * no group's sum can then leave int8 -- and answers CpuReCheck, before anything is touched,
+ * otherwise (integer sums never wrap: strom_gpupreagg.h).
+ */
 int
 strom::gpupreagg_hash_import_device(strom_gpupreagg *sess, const char *d_recs, cl_uint seg_len, cl_uint nsegs,
-									const cl_uint *h_counts, cl_uint skip_seg)
+									const cl_uint *h_counts, cl_uint skip_seg, cl_ulong incoming_sum_bound)
 {
 	Device *dev = sess->dev;
 	std::lock_guard<std::mutex> g(sess->lock);
@@ -2561,6 +2666,15 @@ strom::gpupreagg_hash_import_device(strom_gpupreagg *sess, const char *d_recs, c
 	if (incoming == 0)
 		return 0;
 	(void)hipSetDevice(dev->hip_id);
+	if (incoming_sum_bound != 0 && sess->nintsums != 0)
+	{
+		cl_ulong	mine = 0;
+		int			brc = hash_sum_measured_bound(sess, &mine);
+		if (brc)
+			return brc;
+		if (incoming_sum_bound >= (1UL << 63) || mine >= (1UL << 63) || mine + incoming_sum_bound >= (1UL << 63))
+			return StromError_CpuReCheck;
+	}
 	int		errcode = 0;
 	hipFunction_t fn = sess->prog->get_function(dev, "gpupreagg_hash_import", &errcode);
 	if (!fn)

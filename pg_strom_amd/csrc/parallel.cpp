@@ -41,6 +41,8 @@ struct rccl_api {
 	ncclResult_t  (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t,
 							   ncclComm_t, hipStream_t) = nullptr;
 	ncclResult_t  (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+	ncclResult_t  (*Send)(const void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+	ncclResult_t  (*Recv)(void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
 	ncclResult_t  (*CommCount)(const ncclComm_t, int *) = nullptr;
 	ncclResult_t  (*CommUserRank)(const ncclComm_t, int *) = nullptr;
 	ncclResult_t  (*GroupStart)(void) = nullptr;
@@ -73,6 +75,8 @@ rccl(void)
 		BIND(CommDestroy, "ncclCommDestroy");
 		BIND(AllReduce, "ncclAllReduce");
 		BIND(AllGather, "ncclAllGather");
+		BIND(Send, "ncclSend");
+		BIND(Recv, "ncclRecv");
 		BIND(CommCount, "ncclCommCount");
 		BIND(CommUserRank, "ncclCommUserRank");
 		BIND(GroupStart, "ncclGroupStart");
@@ -80,7 +84,7 @@ rccl(void)
 		BIND(GetErrorString, "ncclGetErrorString");
 #undef BIND
 		api.ok = (api.GetUniqueId && api.CommInitRank && api.CommDestroy && api.AllReduce &&
-				  api.AllGather && api.CommCount && api.CommUserRank &&
+				  api.AllGather && api.Send && api.Recv && api.CommCount && api.CommUserRank &&
 				  api.GroupStart && api.GroupEnd && api.GetErrorString);
 	});
 	return api;
@@ -206,21 +210,116 @@ strom_rccl_comm_destroy(void *comm)
  * merge of the resident tables
  * ------------------------------------------------------------------ */
 /*
- * hashed GROUP BY sessions: the tables of the ranks have no common layout, so the groups
- * travel -- every rank packs its groups (gpupreagg_hash_export), the counts and then the
- * records are all-gathered (padded to the largest rank), and every rank merges the others'
- * records into its table (gpupreagg_hash_import).  Afterwards every rank holds every group.
+ * hashed GROUP BY sessions: the tables of the ranks have no common layout, so the groups travel.
+ * HASH-PARTITIONED: group g belongs to rank owner(g), a function of its key
+ * (devlib: gpupreagg_hash_owner).
+ *   1. every rank packs its groups by owner (gpupreagg_hash_export_parts) and measures the largest
+ *      |integer sum| it holds;
+ *   2. the ranks all-gather their counts-per-owner and that bound: every rank now knows the whole
+ *      traffic matrix, and all of them take the same decision about the integer sums' range
+ *      (the sum of the ranks' bounds below 2^63: no group's total can leave int8; otherwise every
+ *      rank answers CpuReCheck and nothing has moved -- integer sums never wrap);
+ *   3. one grouped send / receive per pair: rank r sends owner p's records to rank p
+ *      ((world-1)/world of its groups leave, against world-1 copies of ALL of them in an all-gather);
+ *   4. the table is emptied and takes the received records: every group of this rank's partition,
+ *      each merged from up to 'world' partials.  A reduce-scatter ends here
+ *      (strom_gpupreagg_reduce_scatter: the ranks' fetches are disjoint and their union is the result);
+ *   5. the all-reduce goes on: the now final groups are packed and all-gathered (padded to the largest
+ *      rank), and every rank inserts the others' -- new keys all of them, nothing is added up.
+ * Per rank that is about 2 G (world-1)/world records moved and 2 G merged for G groups per rank and
+ * overlapping key sets, where the all-gather of the partials moved and merged (world-1) G.
+ *
+ * A failure of ONE rank must fail all of them: a rank that left early would leave the others inside a
+ * collective for good.  So every rank takes part in every collective up to the point where all have
+ * agreed to go on: the first all-gather carries a status word next to the counts, a rank that cannot
+ * allocate its receive area says so in a second, one-word round, and the records move only when every
+ * rank is ready.  (What is left are failures of RCCL itself, which are not a rank's own.)
+ *
+ * 'peers' stands where the communicator stands when the "ranks" are sessions of ONE GPU
+ * (strom_gpupreagg_exchange_local): the same packing, decisions and imports, with device copies and
+ * host arrays where the collectives are -- what lets a one-GPU test see a wrong owner, a lost
+ * partition or a dropped bound.
  */
+namespace {
+
+struct exchange_side {
+	strom_gpupreagg *sess = nullptr;
+	char	   *d_send = nullptr;			/* this side's groups, packed by owner */
+	std::vector<cl_uint> counts;			/* [world] records per owner */
+	std::vector<cl_uint> send_off;			/* [world] first record of owner p in d_send */
+	cl_ulong	bound = 0;
+	size_t		reclen = 0;
+	int			rc = 0;
+	char	   *d_recv = nullptr;			/* [world] segments of seg_len records */
+	cl_uint		seg_len = 0;
+};
+
+/* step 1 */
+void
+exchange_pack(exchange_side &side, cl_uint world)
+{
+	side.counts.assign(world, 0);
+	side.send_off.assign(world, 0);
+	side.rc = gpupreagg_hash_export_parts_device(side.sess, world, &side.d_send, side.counts.data(),
+												 &side.reclen, &side.bound);
+	cl_uint	off = 0;
+	for (cl_uint p = 0; p < world; p++)
+	{
+		side.send_off[p] = off;
+		off += side.counts[p];
+	}
+}
+
+/* step 2's decision, the same on every rank: 0, or the error all of them return */
+int
+exchange_verdict(const std::vector<cl_uint> &status, const std::vector<cl_ulong> &bounds, int my_rc)
+{
+	unsigned __int128 total = 0;
+	for (size_t r = 0; r < status.size(); r++)
+	{
+		if (status[r] != 0)
+			return (my_rc != 0 ? my_rc : StromError_HipInternal);
+		total += bounds[r];
+	}
+	/* (one rank alone holding a sum at the edge is fine: nothing is added to it -- unless another
+	 * rank has groups at all, which a zero bound excludes only for tables without integer sums) */
+	size_t	nonzero = 0;
+	for (cl_ulong b : bounds)
+		nonzero += (b != 0);
+	if (nonzero > 1 && total >= ((unsigned __int128)1 << 63))
+		return StromError_CpuReCheck;
+	return 0;
+}
+
+/* step 4 (and the insert half of step 5) */
+int
+exchange_take(exchange_side &side, cl_uint world, const cl_uint *seg_counts, bool reset_first, cl_uint skip_seg)
+{
+	if (reset_first)
+		strom_gpupreagg_reset(side.sess);
+	/* (the range of the integer sums was settled by exchange_verdict; new keys add nothing) */
+	return gpupreagg_hash_import_device(side.sess, side.d_recv, side.seg_len, world, seg_counts, skip_seg, 0);
+}
+
+void
+exchange_release(exchange_side &side, Device *dev)
+{
+	gpupreagg_hash_release(side.sess, side.d_send);
+	side.d_send = nullptr;
+	if (side.d_recv)
+		dev->pool.release(side.d_recv);
+	side.d_recv = nullptr;
+}
+
+}	/* namespace */
+
 static int
-hashed_allreduce(strom_gpupreagg *sess, int dindex, ncclComm_t comm, hipStream_t stream_or_null)
+hashed_exchange(strom_gpupreagg *sess, int dindex, ncclComm_t comm, hipStream_t stream_or_null, bool gather_after)
 {
 	Device	   *dev = get_device(dindex);
 	hipStream_t	stream = (stream_or_null ? stream_or_null : dev->streams[0]);
 	int			world = 0, rank = 0;
-	char	   *d_mine = nullptr, *d_all = nullptr;
-	cl_uint	   *d_counts = nullptr;
-	cl_uint		mine = 0;
-	size_t		reclen = 0;
+	cl_uint	   *d_words = nullptr;
 	int			rc;
 	const cl_uint FAILED = 0xffffffffu;
 
@@ -228,81 +327,268 @@ hashed_allreduce(strom_gpupreagg *sess, int dindex, ncclComm_t comm, hipStream_t
 	if ((rc = rccl_errcode(rccl().CommCount(comm, &world), "ncclCommCount")) != 0 ||
 		(rc = rccl_errcode(rccl().CommUserRank(comm, &rank), "ncclCommUserRank")) != 0)
 		return rc;
-	/*
-	 * A failure of ONE rank must fail all of them: a rank that left early would leave the others
-	 * inside a collective for good.  So every rank takes part in every collective up to the point
-	 * where all have agreed to go on: a rank whose export failed sends FAILED instead of its group
-	 * count, a rank that cannot allocate the gather area says so in a second, one-word round, and
-	 * the records are gathered only when every rank is ready.  (What is left are failures of RCCL
-	 * itself, which are not a rank's own.)
-	 */
+	if (world > 64)
+		return StromError_BadRequestMessage;		/* (owners are counted in a 64-entry LDS histogram) */
+	exchange_side side;
+	side.sess = sess;
 	int			local_rc = stream_follows(dev, stream);
 	if (local_rc == 0)
-		local_rc = gpupreagg_hash_export_device(sess, &d_mine, &mine, &reclen);
-	std::vector<cl_uint> counts((size_t)world, 0);
-	/* gather words: [0 .. world) the answer, [world] this rank's contribution */
-	d_counts = (cl_uint *)dev->pool.alloc(sizeof(cl_uint) * (size_t)(world + 1));
-	auto gather_word = [&](cl_uint word, const char *what) -> int
 	{
-		if (!d_counts)
-			return StromError_OutOfMemory;		/* (cannot even say so: the one failure that is not agreed on) */
-		if (hipMemcpyAsync(d_counts + world, &word, sizeof(cl_uint), hipMemcpyHostToDevice, stream) != hipSuccess)
+		exchange_pack(side, (cl_uint)world);
+		local_rc = side.rc;
+	}
+	if (world == 1)
+	{
+		exchange_release(side, dev);
+		return local_rc;							/* one rank owns every group: nothing moves */
+	}
+	/* the words every rank contributes: counts per owner, its bound (two words), its status */
+	const size_t nw = (size_t)world + 3;
+	std::vector<cl_uint> mine(nw, 0), all(nw * (size_t)world, 0);
+	for (int p = 0; p < world; p++)
+		mine[p] = side.counts[p];
+	mine[world] = (cl_uint)side.bound;
+	mine[world + 1] = (cl_uint)(side.bound >> 32);
+	mine[world + 2] = (local_rc == 0 ? 0u : FAILED);
+	d_words = (cl_uint *)dev->pool.alloc(sizeof(cl_uint) * nw * (size_t)(world + 1));
+	auto gather_words = [&](size_t n, const char *what) -> int
+	{
+		if (!d_words)
+			return StromError_OutOfMemory;			/* (cannot even say so: the one failure that is not agreed on) */
+		cl_uint	   *d_mine = d_words + nw * (size_t)world;
+		if (hipMemcpyAsync(d_mine, mine.data(), sizeof(cl_uint) * n, hipMemcpyHostToDevice, stream) != hipSuccess)
 			return StromError_HipInternal;
-		int r = rccl_errcode(rccl().AllGather(d_counts + world, d_counts, 1, ncclUint32, comm, stream), what);
+		int r = rccl_errcode(rccl().AllGather(d_mine, d_words, n, ncclUint32, comm, stream), what);
 		if (r != 0)
 			return r;
-		if (hipMemcpyAsync(counts.data(), d_counts, sizeof(cl_uint) * (size_t)world, hipMemcpyDeviceToHost, stream) != hipSuccess ||
+		if (hipMemcpyAsync(all.data(), d_words, sizeof(cl_uint) * n * (size_t)world, hipMemcpyDeviceToHost, stream) != hipSuccess ||
 			hipStreamSynchronize(stream) != hipSuccess)
 			return StromError_HipInternal;
 		return 0;
 	};
 	do {
-		if ((rc = gather_word(local_rc == 0 ? mine : FAILED, "ncclAllGather (group counts)")) != 0)
+		if ((rc = gather_words(nw, "ncclAllGather (counts per owner, bounds)")) != 0)
 			break;
-		cl_uint		seg_len = 0;
-		bool		somebody_failed = false;
-		for (cl_uint c : counts)
+		std::vector<cl_uint> status((size_t)world);
+		std::vector<cl_ulong> bounds((size_t)world);
+		std::vector<cl_uint> from((size_t)world);			/* records rank r holds for this rank */
+		for (int r = 0; r < world; r++)
 		{
-			somebody_failed = somebody_failed || (c == FAILED);
-			if (c != FAILED)
-				seg_len = std::max(seg_len, c);
+			const cl_uint *w = all.data() + nw * (size_t)r;
+			status[r] = w[world + 2];
+			bounds[r] = ((cl_ulong)w[world + 1] << 32) | w[world];
+			from[r] = w[rank];
+			side.seg_len = std::max(side.seg_len, w[rank]);
 		}
-		if (somebody_failed)
-		{
-			rc = (local_rc != 0 ? local_rc : StromError_HipInternal);	/* every rank returns an error */
+		if ((rc = exchange_verdict(status, bounds, local_rc)) != 0)
 			break;
-		}
-		if (seg_len == 0 || world == 1)
-			break;							/* nothing to merge */
-		std::vector<cl_uint> group_counts = counts;
-		d_all = (char *)dev->pool.alloc(reclen * (size_t)seg_len * (size_t)(world + 1));
-		if ((rc = gather_word(d_all ? 1u : FAILED, "ncclAllGather (ready)")) != 0)
+		if (side.seg_len > 0)
+			side.d_recv = (char *)dev->pool.alloc(side.reclen * (size_t)side.seg_len * (size_t)world);
+		mine[0] = (side.seg_len == 0 || side.d_recv ? 1u : FAILED);
+		if ((rc = gather_words(1, "ncclAllGather (ready)")) != 0)
 			break;
-		for (cl_uint c : counts)
-			somebody_failed = somebody_failed || (c == FAILED);
+		bool	somebody_failed = false;
+		for (int r = 0; r < world; r++)
+			somebody_failed = somebody_failed || (all[(size_t)r] == FAILED);
 		if (somebody_failed)
 		{
 			rc = StromError_OutOfMemory;
 			break;
 		}
-		/* the send buffer is the padded copy of this rank's records behind the gather area */
-		char	   *d_send = d_all + reclen * (size_t)seg_len * (size_t)world;
-		if ((mine > 0 && hipMemcpyAsync(d_send, d_mine, reclen * mine, hipMemcpyDeviceToDevice, stream) != hipSuccess) ||
-			(rc = rccl_errcode(rccl().AllGather(d_send, d_all, reclen * (size_t)seg_len, ncclUint8, comm, stream),
-							   "ncclAllGather (groups)")) != 0 ||
+		/* step 3: this rank's own partition by a device copy, the others pairwise */
+		ncclResult_t nrc = rccl().GroupStart();
+		for (int r = 0; r < world && nrc == ncclSuccess; r++)
+		{
+			if (r == rank)
+				continue;
+			if (side.counts[r] > 0)
+				nrc = rccl().Send(side.d_send + side.reclen * (size_t)side.send_off[r],
+								  side.reclen * (size_t)side.counts[r], ncclUint8, r, comm, stream);
+			if (nrc == ncclSuccess && from[r] > 0)
+				nrc = rccl().Recv(side.d_recv + side.reclen * (size_t)side.seg_len * (size_t)r,
+								  side.reclen * (size_t)from[r], ncclUint8, r, comm, stream);
+		}
+		ncclResult_t erc = rccl().GroupEnd();
+		if (nrc == ncclSuccess)
+			nrc = erc;
+		if ((rc = rccl_errcode(nrc, "ncclSend / ncclRecv (groups by owner)")) != 0)
+			break;
+		if (side.counts[rank] > 0 &&
+			hipMemcpyAsync(side.d_recv + side.reclen * (size_t)side.seg_len * (size_t)rank,
+						   side.d_send + side.reclen * (size_t)side.send_off[rank],
+						   side.reclen * (size_t)side.counts[rank], hipMemcpyDeviceToDevice, stream) != hipSuccess)
+			rc = StromError_HipInternal;
+		if (hipStreamSynchronize(stream) != hipSuccess && rc == 0)
+			rc = StromError_HipInternal;
+		if (rc != 0)
+			break;
+		/* step 4 */
+		if ((rc = exchange_take(side, (cl_uint)world, from.data(), true, ~0u)) != 0 || !gather_after)
+			break;
+		/* step 5: the final groups of every partition to every rank */
+		exchange_release(side, dev);
+		char	   *d_mine = nullptr;
+		cl_uint		n_mine = 0;
+		local_rc = gpupreagg_hash_export_device(sess, &d_mine, &n_mine, &side.reclen);
+		side.d_send = d_mine;
+		mine[0] = (local_rc == 0 ? n_mine : FAILED);
+		if ((rc = gather_words(1, "ncclAllGather (final group counts)")) != 0)
+			break;
+		std::vector<cl_uint> finals((size_t)world);
+		side.seg_len = 0;
+		for (int r = 0; r < world; r++)
+		{
+			finals[r] = all[(size_t)r];
+			somebody_failed = somebody_failed || (finals[r] == FAILED);
+			if (finals[r] != FAILED)
+				side.seg_len = std::max(side.seg_len, finals[r]);
+		}
+		if (somebody_failed)
+		{
+			rc = (local_rc != 0 ? local_rc : StromError_HipInternal);
+			break;
+		}
+		if (side.seg_len == 0)
+			break;
+		/* (the send buffer is the padded copy of this rank's records behind the gather area) */
+		side.d_recv = (char *)dev->pool.alloc(side.reclen * (size_t)side.seg_len * (size_t)(world + 1));
+		mine[0] = (side.d_recv ? 1u : FAILED);
+		if ((rc = gather_words(1, "ncclAllGather (ready)")) != 0)
+			break;
+		for (int r = 0; r < world; r++)
+			somebody_failed = somebody_failed || (all[(size_t)r] == FAILED);
+		if (somebody_failed)
+		{
+			rc = StromError_OutOfMemory;
+			break;
+		}
+		char	   *d_pad = side.d_recv + side.reclen * (size_t)side.seg_len * (size_t)world;
+		if ((n_mine > 0 && hipMemcpyAsync(d_pad, d_mine, side.reclen * n_mine, hipMemcpyDeviceToDevice, stream) != hipSuccess) ||
+			(rc = rccl_errcode(rccl().AllGather(d_pad, side.d_recv, side.reclen * (size_t)side.seg_len, ncclUint8, comm, stream),
+							   "ncclAllGather (final groups)")) != 0 ||
 			hipStreamSynchronize(stream) != hipSuccess)
 		{
 			if (rc == 0)
 				rc = StromError_HipInternal;
 			break;
 		}
-		rc = gpupreagg_hash_import_device(sess, d_all, seg_len, (cl_uint)world, group_counts.data(), (cl_uint)rank);
+		rc = exchange_take(side, (cl_uint)world, finals.data(), false, (cl_uint)rank);
 	} while (0);
 	if (hipStreamSynchronize(stream) != hipSuccess && rc == 0)
 		rc = StromError_HipInternal;
-	gpupreagg_hash_release(sess, d_mine);
-	if (d_all) dev->pool.release(d_all);
-	if (d_counts) dev->pool.release(d_counts);
+	exchange_release(side, dev);
+	if (d_words) dev->pool.release(d_words);
+	return rc;
+}
+
+/*
+ * The same exchange among n hashed sessions of ONE GPU: session i plays rank i.  gather_after = 0:
+ * afterwards session i holds exactly the groups it owns (their union is the merged result, no group
+ * twice); 1: every session holds every group.
+ */
+extern "C" int
+strom_gpupreagg_exchange_local(strom_gpupreagg **sessions, int n, int gather_after)
+{
+	if (!sessions || n < 1 || n > 64)
+		return StromError_BadRequestMessage;
+	int		dindex = -1;
+	for (int i = 0; i < n; i++)
+	{
+		int		di = -1;
+		if (!sessions[i] || !gpupreagg_is_hashed(sessions[i], &di) || (i > 0 && di != dindex) ||
+			(i > 0 && !gpupreagg_sessions_mergeable(sessions[0], sessions[i])))
+			return StromError_BadRequestMessage;
+		for (int j = 0; j < i; j++)
+			if (sessions[j] == sessions[i])
+				return StromError_BadRequestMessage;
+		dindex = di;
+	}
+	Device	   *dev = get_device(dindex);
+	cl_uint		world = (cl_uint)n;
+	std::vector<exchange_side> sides((size_t)n);
+	std::vector<cl_uint> status((size_t)n);
+	std::vector<cl_ulong> bounds((size_t)n);
+	int			rc = 0;
+
+	(void)hipSetDevice(dev->hip_id);
+	hipStream_t	stream = dev->streams[0];
+	for (int i = 0; i < n; i++)
+	{
+		sides[i].sess = sessions[i];
+		exchange_pack(sides[i], world);
+		status[i] = (sides[i].rc == 0 ? 0u : 1u);
+		bounds[i] = sides[i].bound;
+		if (sides[i].rc != 0 && rc == 0)
+			rc = sides[i].rc;
+	}
+	do {
+		if ((rc = exchange_verdict(status, bounds, rc)) != 0)
+			break;
+		/* step 3 with device copies */
+		std::vector<std::vector<cl_uint>> from((size_t)n, std::vector<cl_uint>((size_t)n, 0));
+		for (int me = 0; me < n && rc == 0; me++)
+		{
+			exchange_side &dst = sides[me];
+			for (int r = 0; r < n; r++)
+			{
+				from[me][r] = sides[r].counts[me];
+				dst.seg_len = std::max(dst.seg_len, from[me][r]);
+			}
+			if (dst.seg_len == 0)
+				continue;
+			dst.d_recv = (char *)dev->pool.alloc(dst.reclen * (size_t)dst.seg_len * (size_t)n);
+			if (!dst.d_recv)
+			{
+				rc = StromError_OutOfMemory;
+				break;
+			}
+			for (int r = 0; r < n; r++)
+				if (from[me][r] > 0 &&
+					hipMemcpyAsync(dst.d_recv + dst.reclen * (size_t)dst.seg_len * (size_t)r,
+								   sides[r].d_send + sides[r].reclen * (size_t)sides[r].send_off[me],
+								   dst.reclen * (size_t)from[me][r], hipMemcpyDeviceToDevice, stream) != hipSuccess)
+					rc = StromError_HipInternal;
+		}
+		if (rc == 0 && hipStreamSynchronize(stream) != hipSuccess)
+			rc = StromError_HipInternal;
+		/* step 4 */
+		for (int me = 0; me < n && rc == 0; me++)
+			rc = exchange_take(sides[me], world, from[me].data(), true, ~0u);
+		if (rc != 0 || !gather_after)
+			break;
+		/* step 5 */
+		for (int i = 0; i < n; i++)
+			exchange_release(sides[i], dev);
+		std::vector<cl_uint> finals((size_t)n, 0);
+		cl_uint		seg_len = 0;
+		for (int i = 0; i < n && rc == 0; i++)
+		{
+			rc = gpupreagg_hash_export_device(sessions[i], &sides[i].d_send, &finals[i], &sides[i].reclen);
+			seg_len = std::max(seg_len, finals[i]);
+		}
+		if (rc != 0 || seg_len == 0)
+			break;
+		size_t		reclen = sides[0].reclen;
+		char	   *d_all = (char *)dev->pool.alloc(reclen * (size_t)seg_len * (size_t)n);
+		if (!d_all)
+		{
+			rc = StromError_OutOfMemory;
+			break;
+		}
+		for (int i = 0; i < n; i++)
+			if (finals[i] > 0 &&
+				hipMemcpyAsync(d_all + reclen * (size_t)seg_len * (size_t)i, sides[i].d_send, reclen * (size_t)finals[i],
+							   hipMemcpyDeviceToDevice, stream) != hipSuccess)
+				rc = StromError_HipInternal;
+		if (rc == 0 && hipStreamSynchronize(stream) != hipSuccess)
+			rc = StromError_HipInternal;
+		for (int me = 0; me < n && rc == 0; me++)
+			rc = gpupreagg_hash_import_device(sessions[me], d_all, seg_len, world, finals.data(), (cl_uint)me, 0);
+		dev->pool.release(d_all);
+	} while (0);
+	(void)hipStreamSynchronize(stream);
+	for (int i = 0; i < n; i++)
+		exchange_release(sides[i], dev);
 	return rc;
 }
 
@@ -476,11 +762,25 @@ strom_gpupreagg_merge(strom_gpupreagg *dst, strom_gpupreagg *src)
 	char	   *d_recs = nullptr;
 	cl_uint		count = 0;
 	size_t		reclen = 0;
-	int			rc = gpupreagg_hash_export_device(src, &d_recs, &count, &reclen);
+	cl_ulong	bound = 0;
+	int			rc = gpupreagg_hash_export_device(src, &d_recs, &count, &reclen, &bound);
+	/* (bound 0: src holds no integer sum other than zero -- nothing is added up, nothing to prove) */
 	if (rc == 0 && count > 0)
-		rc = gpupreagg_hash_import_device(dst, d_recs, count, 1, &count, ~0u);
+		rc = gpupreagg_hash_import_device(dst, d_recs, count, 1, &count, ~0u, bound);
 	gpupreagg_hash_release(src, d_recs);
 	return rc;
+}
+
+/* hashed sessions only: afterwards this rank holds the merged groups it owns, and nothing else */
+extern "C" int
+strom_gpupreagg_reduce_scatter(strom_gpupreagg *sess, void *comm_handle, void *stream_handle)
+{
+	int		hashed_dindex = -1;
+	if (!gpupreagg_is_hashed(sess, &hashed_dindex) || !comm_handle)
+		return StromError_BadRequestMessage;
+	if (!rccl().ok)
+		return StromError_ServerNotReady;
+	return hashed_exchange(sess, hashed_dindex, (ncclComm_t)comm_handle, (hipStream_t)stream_handle, false);
 }
 
 extern "C" int
@@ -493,7 +793,7 @@ strom_gpupreagg_allreduce(strom_gpupreagg *sess, void *comm_handle, void *stream
 			return StromError_BadRequestMessage;
 		if (!rccl().ok)
 			return StromError_ServerNotReady;
-		return hashed_allreduce(sess, hashed_dindex, (ncclComm_t)comm_handle, (hipStream_t)stream_handle);
+		return hashed_exchange(sess, hashed_dindex, (ncclComm_t)comm_handle, (hipStream_t)stream_handle, true);
 	}
 	gpupreagg_merge_plan plan;
 	int		rc = gpupreagg_get_merge_plan(sess, &plan);

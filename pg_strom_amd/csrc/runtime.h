@@ -248,10 +248,15 @@ int			gpupreagg_get_census(strom_gpupreagg *sess, void **p_bitmap, cl_uint *p_nb
 /* hashed sessions (gpupreagg.cpp): the groups packed on the device (records of *p_reclen bytes in a
  * pool buffer the caller releases with gpupreagg_hash_release), and packed groups merged into the table */
 bool		gpupreagg_is_hashed(strom_gpupreagg *sess, int *p_dindex);
-int			gpupreagg_hash_export_device(strom_gpupreagg *sess, char **p_recs, cl_uint *p_count, size_t *p_reclen);
+int			gpupreagg_hash_export_device(strom_gpupreagg *sess, char **p_recs, cl_uint *p_count, size_t *p_reclen,
+										 cl_ulong *p_sum_bound = nullptr);
+/* ... packed by owner (h_counts[nparts], nparts <= 64) for the hash-partitioned exchange */
+int			gpupreagg_hash_export_parts_device(strom_gpupreagg *sess, cl_uint nparts, char **p_recs, cl_uint *h_counts,
+											   size_t *p_reclen, cl_ulong *p_sum_bound);
 void		gpupreagg_hash_release(strom_gpupreagg *sess, char *recs);
+/* incoming_sum_bound: see gpupreagg.cpp -- the integer sums' range proof of the merge */
 int			gpupreagg_hash_import_device(strom_gpupreagg *sess, const char *d_recs, cl_uint seg_len, cl_uint nsegs,
-										 const cl_uint *h_counts, cl_uint skip_seg);
+										 const cl_uint *h_counts, cl_uint skip_seg, cl_ulong incoming_sum_bound);
 /* parallel.cpp: a kernel of the fixed-function program (devlib/strom_merge.h: the merge's prepare /
  * finish / apply steps, the dense partial-row export, the streaming-read probe) */
 hipFunction_t fixed_function(Device *dev, const char *name, int *p_errcode);

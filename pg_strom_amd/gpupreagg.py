@@ -419,6 +419,22 @@ class GpuPreAgg(object):
         if rc != 0:
             raise runtime.StromError(rc, "strom_gpupreagg_merge")
 
+    def reduce_scatter_rccl(self, comm):
+        """hashed sessions: the hash-partitioned exchange without the final all-gather -- this rank
+        ends up with the merged groups it owns (strom_gpupreagg_reduce_scatter)"""
+        rc = lib.strom_gpupreagg_reduce_scatter(self.session, comm.handle, None)
+        if rc != 0:
+            raise runtime.StromError(rc, "strom_gpupreagg_reduce_scatter")
+
+    @staticmethod
+    def exchange_local(sessions, gather_after=False):
+        """the multi-GPU exchange of hashed sessions among sessions of ONE device, session i as
+        rank i (strom_gpupreagg_exchange_local)"""
+        arr = (ctypes.c_void_p * len(sessions))(*[s.session for s in sessions])
+        rc = lib.strom_gpupreagg_exchange_local(arr, len(sessions), 1 if gather_after else 0)
+        if rc != 0:
+            raise runtime.StromError(rc, "strom_gpupreagg_exchange_local")
+
     def allreduce(self, group=None):
         """the same merge stated with torch.distributed collectives (pg_strom_amd.parallel):
         the gloo rehearsal's path and the GPU cross-check of allreduce_rccl()"""

@@ -319,6 +319,48 @@ def merge_partial_rows(targets, parts):
     return out_v, out_n
 
 
+def owner_of_partial_rows(targets, values, isnull, world):
+    """the rank a partial row's group belongs to: a function of the key alone (csrc/parallel.cpp:
+    hashed_exchange; the device hashes the key images, this restatement their bytes -- any
+    function every rank agrees on does)"""
+    import zlib
+    values = np.asarray(values, dtype=np.uint64)
+    keys = [t for t, (kind, _) in enumerate(targets) if kind == KIND_KEY]
+    ident = np.stack([np.where(isnull[:, t], np.uint64(0), values[:, t]) for t in keys] +
+                     [isnull[:, t].astype(np.uint64) for t in keys], axis=1) if keys else np.zeros((len(values), 1), np.uint64)
+    return np.array([zlib.crc32(row.tobytes()) % world for row in ident], dtype=np.int64)
+
+
+def integer_sum_bound(targets, values, isnull):
+    """largest |integer psum| of these partial rows, plus one (0: none) -- what the ranks exchange
+    before they add their sums up (gpupreagg_hash_sum_refresh)"""
+    most = 0
+    for t, (kind, oid) in enumerate(targets):
+        if kind == KIND_PSUM and oid not in FLOAT_OIDS:
+            v = np.asarray(values, dtype=np.uint64)[:, t].view(np.int64)[~isnull[:, t]]
+            if len(v):
+                most = max(most, int(np.abs(v.astype(object)).max()))
+    return most + 1 if most else 0
+
+
+def reduce_scatter_partial_rows(targets, values, isnull, group=None):
+    """hash-partitioned merge of the ranks' partial rows: every rank ends up with the merged rows
+    of the groups it owns (strom_gpupreagg_reduce_scatter).  Raises StromError(CpuReCheck) on
+    EVERY rank when the ranks' integer sums could leave int8 together."""
+    import torch.distributed as dist
+    from .runtime import StromError
+    world, me = dist.get_world_size(group), dist.get_rank(group)
+    values, isnull = np.ascontiguousarray(values, dtype=np.uint64), np.ascontiguousarray(isnull, dtype=bool)
+    owner = owner_of_partial_rows(targets, values, isnull, world)
+    outgoing = [(values[owner == r], isnull[owner == r]) for r in range(world)]
+    everybody = [None] * world
+    dist.all_gather_object(everybody, (integer_sum_bound(targets, values, isnull), outgoing), group=group)
+    bounds = [b for b, _ in everybody]
+    if sum(1 for b in bounds if b) > 1 and sum(bounds) >= 2**63:
+        raise StromError(2, "hash-partitioned merge: integer sums may leave int8")
+    return merge_partial_rows(targets, [parts[me] for _, parts in everybody])
+
+
 def gather_partial_rows(targets, values, isnull, group=None):
     """all ranks' partial rows, combined by key on every rank (the payload is the
     groups, not the rows: an object all-gather is enough)"""

@@ -248,6 +248,81 @@ def test_two_rank_merge_of_hashed_group_by_partial_rows():
     assert outq.get(timeout=5) is True
 
 
+def _scatter_worker(rank, world, port, outq):
+    sys.path.insert(0, os.path.dirname(HERE))
+    sys.path.insert(0, HERE)
+    import torch.distributed as dist
+    import oracle_binding as oracle
+    from pg_strom_amd import kds, parallel, runtime
+    from pg_strom_amd.gpupreagg import codegen_gpupreagg
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    try:
+        cols = _hashed_table(20000, 98)
+        n = len(cols[0].values)
+        lo, hi = rank * n // world, (rank + 1) * n // world
+        part = [kds.Column(c.sqltype, c.values[lo:hi], c.isnull[lo:hi]) for c in cols]
+        rc, v, isn = oracle.gpupreagg(HASHED_SPEC, kds.build_kds("column", part), 7)
+        assert rc == 0
+        targets = codegen_gpupreagg(HASHED_SPEC).targets
+        mv, mn = parallel.reduce_scatter_partial_rows(targets, v, isn)
+        # every rank reports its partition; rank 0 checks union == one reduction, partitions disjoint
+        shares = [None] * world
+        dist.all_gather_object(shares, (mv, mn))
+        # integer sums that cannot be added: every rank gets CpuReCheck
+        big = v.copy()
+        for t, (kind, oid) in enumerate(targets):
+            if kind == 3 and oid not in (700, 701):
+                big[:, t] = np.uint64(6 * 2**63 // 10)
+        try:
+            parallel.reduce_scatter_partial_rows(targets, big, isn)
+            refused = False
+        except runtime.StromError as e:
+            refused = (e.errcode == 2)
+        if rank == 0:
+            rc, wv, wn = oracle.gpupreagg(HASHED_SPEC, kds.build_kds("column", cols), 7)
+            gv = np.concatenate([s_[0] for s_ in shares])
+            gn = np.concatenate([s_[1] for s_ in shares])
+            ok = refused and all(len(s_[0]) > 0 for s_ in shares) and len(gv) == len(wv)
+            owners = [parallel.owner_of_partial_rows(targets, s_[0], s_[1], world) for s_ in shares]
+            ok = ok and all((o == r).all() for r, o in enumerate(owners))
+            def order(v_, n_):
+                return np.lexsort((v_[:, 1], n_[:, 1], v_[:, 0], n_[:, 0]))
+            og, ow = order(gv, gn), order(wv, wn)
+            gv, gn, wv, wn = gv[og], gn[og], wv[ow], wn[ow]
+            ok = ok and np.array_equal(gn, wn)
+            for t, (kind, oid) in enumerate(targets):
+                if not ok:
+                    break
+                live = ~wn[:, t]
+                if oid in (700, 701) and kind == 3:
+                    ok &= np.allclose(gv[:, t].view(np.float64)[live], wv[:, t].view(np.float64)[live], rtol=1e-12, atol=0)
+                else:
+                    ok &= np.array_equal(gv[:, t][live], wv[:, t][live])
+            outq.put(bool(ok))
+        else:
+            assert refused
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_hash_partitioned_merge_of_partial_rows():
+    """the reduce-scatter of hashed sessions (strom_gpupreagg_reduce_scatter; its C steps run among
+    sessions of one GPU in tests/test_exchange_gpu.py): every group lands on the rank its key
+    hashes to, the ranks' shares are disjoint, their union is the single reduction; sums that
+    could leave int8 together are refused on both ranks"""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    outq = ctx.Queue()
+    port = 29500 + (os.getpid() % 2000) + 11
+    procs = [ctx.Process(target=_scatter_worker, args=(r, 2, port, outq)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(180)
+    assert all(p.exitcode == 0 for p in procs)
+    assert outq.get(timeout=5) is True
+
+
 def test_merge_partial_rows_orders_nan_like_postgresql():
     """float8 pmin/pmax across ranks: PostgreSQL sorts NaN above every number
     (float8_cmp_internal), so min(NaN, 1.0) = 1.0, min(NaN) = NaN, max(NaN, 1.0) = NaN"""
