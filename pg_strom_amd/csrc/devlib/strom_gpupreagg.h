@@ -579,10 +579,30 @@ struct gpupreagg_lds_layout {
 	cl_uint		total;
 };
 
+/*
+ * A wave-uniform value the row loops add to a per-lane LDS index (a section's offset): kept in a
+ * VECTOR register on purpose.  As a scalar it competes with the column pointers, the key domain
+ * and the parameters for ~100 SGPRs, loses, and is spilled into a lane of a VGPR -- every row
+ * then pays a v_readlane_b32 plus the wait states before the add that uses it, per aggregate
+ * (Q1's kernels: 7 of them per row with the lane-private accumulators, 33 with the LDS atomics).
+ * The asm's output constraint is all the compiler needs to treat the value as per-lane.
+ */
+STROM_DEVICE cl_uint
+strom_keep_in_vgpr(cl_uint v)
+{
+#if defined(GPUPREAGG_LDS_OFFSETS_SCALAR) && GPUPREAGG_LDS_OFFSETS_SCALAR
+	return v;
+#else
+	cl_uint		r;
+	asm("v_mov_b32 %0, %1" : "=v"(r) : "v"(v));
+	return r;
+#endif
+}
+
 STROM_DEVICE void
 gpupreagg_lds_layout_init(gpupreagg_lds_layout &L, cl_uint G, cl_uint NREP)
 {
-#define X(aidx,resno,OP,NAME)	L.vals_off[aidx] = gpupreagg_image_offset(1 + aidx, G, NREP);
+#define X(aidx,resno,OP,NAME)	L.vals_off[aidx] = strom_keep_in_vgpr(gpupreagg_image_offset(1 + aidx, G, NREP));
 	GPUPREAGG_AGG_LIST(X)
 #undef X
 	L.total = gpupreagg_image_offset(1 + GPUPREAGG_NAGGS, G, NREP);
@@ -2433,7 +2453,7 @@ gpupreagg_priv_column(kern_gpupreagg *kgpreagg, const kern_data_store *kds,
 	{
 		cl_uint	off = L.total;
 #define X(aidx,resno,OP,NAME)															\
-		S.poff[aidx] = off;																\
+		S.poff[aidx] = strom_keep_in_vgpr(off);											\
 		S.has[aidx] = 0;																\
 		off += G * GPUPREAGG_REG_BLOCK * (GPUPREAGG_OP_##OP == GPUPREAGG_OP_NROWS ? 4u : 8u);	\
 		if (GPUPREAGG_OP_##OP == GPUPREAGG_OP_PMIN || GPUPREAGG_OP_##OP == GPUPREAGG_OP_PMAX)	\

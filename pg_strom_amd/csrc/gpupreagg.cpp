@@ -286,9 +286,16 @@ setup_layout(strom_gpupreagg *sess)
 			per_entry += (sess->targets[resno].kind == STROM_PREAGG_NROWS ? 4 : 8);
 		priv_bytes = sess->image_offset(sess->nsections(), ctl.ngroups, 1) +
 			(size_t)ctl.ngroups * 256 * per_entry;
+		/* (lane-private accumulators cost a ds_read + ds_write per aggregate and row, LDS atomics
+		 * one ds_add: with Q1's nine aggregates over three groups the private form is the slower
+		 * one -- 765 against 749 us per 1e8 rows, profiles/r03_q1_lds_offsets.txt -- so it is
+		 * kept for the narrow aggregates it was built for) */
+		size_t	priv_entry_max = 32;
+		if (const char *v = getenv("STROM_GPUPREAGG_PRIV_ENTRY"))
+			priv_entry_max = (size_t)atol(v);
 		if (ctl.ngroups == 1)
 			sess->reg_groups = 1;
-		else if (priv_bytes <= priv_budget)
+		else if (priv_bytes <= priv_budget && per_entry <= priv_entry_max)
 			sess->reg_groups = 2;
 		if (sess->reg_groups)
 			ctl.nrep = 1;
