@@ -70,9 +70,10 @@ struct strom_kvars {
 };
 /*
  * text / character(n) variables of a row taken from COLUMN arrays: offset -> address
- * (strom_common.h).  Called by the row-at-a-time kernels, which is where the host sends a
- * program with such variables (gpupreagg.cpp: program_streams_columns); the streaming
- * kernels' rows have no error slot of their own at this point and do not call it.
+ * (strom_common.h).  Called by the row-at-a-time kernels and by the streaming dense kernels
+ * (dense / packed / reg1 / priv _column); the hash roles' scans and the lookup / joined variants
+ * do not, and the host keeps a program with such variables away from them (gpupreagg.cpp:
+ * column_streams, strom_submit_gpupreagg_joined / _lookup).
  */
 #ifndef STROM_KVARLENA_LIST
 #define STROM_KVARLENA_LIST(X)
@@ -1201,14 +1202,18 @@ gpupreagg_dense_column_body(kern_gpupreagg *kgpreagg,
 													   !((T.nn_##attno[k] >> j) & 1));
 					STROM_KVAR_LIST(X)
 #undef X
+					/* (the row's error slot starts as the parameters' and takes what turning a text
+					 * column's offsets into addresses raises; nothing there for other programs) */
+					cl_int		row_error = param_error;
+					strom_kvars_from_column(KV, kds, &row_error);
 					STROM_KVARS_FINISH(KV);
 #if defined(GPUPREAGG_PACKABLE) && GPUPREAGG_PACKABLE
 					if (PACKED)
-						gpupreagg_packed_row(lds, ctl, pk, KP, KV, gid_lo, G, param_error, &chunk_status, my_slab);
+						gpupreagg_packed_row(lds, ctl, pk, KP, KV, gid_lo, G, row_error, &chunk_status, my_slab);
 					else
 #endif
 						gpupreagg_dense_row(lds, ctl, L, KP, KV, gid_lo, G, NREP, rep,
-											param_error, &chunk_status, summag, rowflags);
+											row_error, &chunk_status, summag, rowflags);
 				}
 			}
 		}
@@ -2226,8 +2231,10 @@ gpupreagg_reg_kernel_body(kern_gpupreagg *kgpreagg, const kern_data_store *kds,
 													   !((T.nn_##attno[k] >> j) & 1));
 					STROM_KVAR_LIST(X)
 #undef X
+					cl_int		row_error = param_error;
+					strom_kvars_from_column(KV, kds, &row_error);
 					STROM_KVARS_FINISH(KV);
-					gpupreagg_reg_row<NG>(S, ctl, KP, KV, param_error, &chunk_status, summag, rowflags);
+					gpupreagg_reg_row<NG>(S, ctl, KP, KV, row_error, &chunk_status, summag, rowflags);
 				}
 			}
 		}
@@ -2548,8 +2555,10 @@ gpupreagg_priv_column(kern_gpupreagg *kgpreagg, const kern_data_store *kds,
 													   !((T.nn_##attno[k] >> j) & 1));
 					STROM_KVAR_LIST(X)
 #undef X
+					cl_int		row_error = param_error;
+					strom_kvars_from_column(KV, kds, &row_error);
 					STROM_KVARS_FINISH(KV);
-					gpupreagg_priv_row(lds, S, ctl, KP, KV, G, param_error, &chunk_status, summag, rowflags);
+					gpupreagg_priv_row(lds, S, ctl, KP, KV, G, row_error, &chunk_status, summag, rowflags);
 				}
 			}
 		}

@@ -680,12 +680,8 @@ gpupreagg_launch(strom_task_impl *task, preagg_request req, bool checked = false
 
 	bool	use_lookup = req.lookup;
 	bool	use_joined = (req.joined_results != nullptr);
-	/* (a program with text / character(n) variables reads a COLUMN chunk through the row-at-a-time
-	 * kernel, which turns the column's offsets into addresses row by row with an error slot at
-	 * hand: strom_kvars_from_column) */
 	bool	use_column = (!use_joined && !use_lookup && req.format == KDS_FORMAT_COLUMN &&
-						  req.krowmap == nullptr && req.rowmap_dev == nullptr &&
-						  !(prog->extra_flags & DEVTYPE_IS_VARLENA));
+						  req.krowmap == nullptr && req.rowmap_dev == nullptr);
 	/* (the checked program adds in LDS with returning atomics: the LDS-atomics kernels only) */
 	bool	use_reg = (use_column && sess->reg_groups != 0 && !checked);
 	hipFunction_t fn = prog->get_function(dev, use_lookup ? "gpupreagg_dense_lookup"

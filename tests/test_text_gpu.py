@@ -129,6 +129,45 @@ def test_text_qual_inside_gpupreagg_through_the_chunk_message(fmt):
         ds.release()
 
 
+@pytest.mark.parametrize("ngroups", [0, 4, 2000])
+def test_text_qual_in_every_streaming_aggregate_kernel(ngroups):
+    """a COLUMN chunk with a text column through the kernel families the dense path picks by group
+    count: no GROUP BY (register accumulators), a handful of groups (lane-private accumulators),
+    many (LDS atomics, packed accumulators) -- each turns the text column's offsets into addresses
+    per row (strom_kvars_from_column) before the qual reads them; an unreadable datum in a row the
+    qual has to look at sends the chunk back (CpuReCheck), as it does from heap tuples"""
+    n = 200000
+    rng = np.random.default_rng(5)
+    W = text_cases.WORDS
+    txt = [W[i] for i in rng.integers(0, len(W), n)]
+    tnull = rng.random(n) < 0.05
+    g = rng.integers(0, max(ngroups, 1), n).astype(np.int32)
+    x = rng.integers(-1000, 1000, n).astype(np.int32)
+    cols = [kds.Column("int4", g), kds.Column("text", txt, tnull), kds.Column("int4", x)]
+    buf = kds.build_kds("column", cols)
+    key = "(key (var 1 int4)) " if ngroups else ""
+    spec = ("(gpupreagg (qual (or (text_lt (var 2 text) (const text 'b')) (texteq (var 2 text) (const text 'zebra')))) "
+            + key + "(nrows) (psum (int8 (var 3 int4))) (pmax (var 3 int4)))")
+    from test_gpupreagg_gpu import assert_matches_oracle
+    agg = GpuPreAgg(spec).begin([(0, ngroups)] if ngroups else [])
+    ds = runtime.DeviceStore.upload(buf)
+    try:
+        assert agg.fold(ds)[0] == 0
+        pr = agg.fetch()
+        assert_matches_oracle(spec, agg, [buf], pr)
+        keep = [i for i in range(n) if not tnull[i] and (txt[i] < b"b" or txt[i] == b"zebra")]
+        assert int(pr.column(1 if ngroups else 0)[0].sum()) == len(keep)
+        # a compressed datum: the chunk is the CPU's
+        raw = [kds.varlena_datum(t) for t in txt[:1000]]
+        raw[500] = np.array([(20 << 2) | 2], dtype="<u4").tobytes() + b"\0" * 16
+        bad = kds.build_kds("column", [kds.Column("int4", g[:1000]), kds.Column("text_raw", raw), kds.Column("int4", x[:1000])])
+        agg.reset()
+        assert agg.fold(bad)[0] == 2
+    finally:
+        ds.release()
+        agg.end()
+
+
 @pytest.mark.parametrize("fmt", ["row_flat", "column"])
 def test_text_residual_qual_in_a_join(fmt):
     buf, txt, chr10, num, tnull = text_cases.text_table(20000, 33, fmt)
