@@ -454,8 +454,9 @@ def operator_figures(args, k, c, measured_peak, cpu_blocks):
         workload="GpuHashJoin: %d fact x %d dim on int4 key, 80%% match (BASELINE configs[2]), index %s"
                  % (chunk_rows, nd, info["mode"]),
         value=chunk_rows / float(np.median(walls[1:])) / 1e6, unit="Mrows/s", results="device-resident",
-        roofline=roofline_block("gpuhashjoin_main_fast", 4.0 * chunk_rows + 8.0 * nmatch, ts[1:], measured_peak,
-                                traffic=load_traffic(chunk_rows, "gpuhashjoin_main_fast")),
+        # (1.25e6 key values: the DIRECT slot array is probed in its 3-byte form, which fits an XCD's L2)
+        roofline=roofline_block("gpuhashjoin_main_fast_narrow", 4.0 * chunk_rows + 8.0 * nmatch, ts[1:], measured_peak,
+                                traffic=load_traffic(chunk_rows, "gpuhashjoin_main_fast_narrow")),
         **cpu_blocks("join"))
 
     # ---- scan + join + group-by, one pass over the WHOLE 1e9-row table (the metric's shape) ----

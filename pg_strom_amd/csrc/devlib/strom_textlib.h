@@ -84,6 +84,13 @@ strom_varlena_payload(cl_ulong datum, cl_int *p_len)
 			STROM_SET_ERROR(errcode, StromError_DataStoreCorruption);			\
 			return pg_##NAME##_make(0UL, true);									\
 		}																		\
+		/* ... or a datum whose own length leaves it (its bytes are about to		\
+		 * be read by length) */												\
+		if (v.value + strom_varsize_any((const char *)kds + v.value) > kds->length)	\
+		{																		\
+			STROM_SET_ERROR(errcode, StromError_DataStoreCorruption);			\
+			return pg_##NAME##_make(0UL, true);									\
+		}																		\
 		return pg_##NAME##_from_addr(errcode, (const char *)kds + v.value, -1);	\
 	}																			\
 	STROM_DEVICE pg_##NAME##_t													\

@@ -51,6 +51,14 @@ def test_chunks_without_the_datums_are_refused_for_text_programs():
         with pytest.raises(runtime.StromError) as ei:
             scan.scan_chunk(buf)
         assert ei.value.errcode == 101
+        # a datum whose header claims more bytes than the chunk has: never read by that length
+        liar = kds.build_kds("column", [kds.Column("text", [b"abc"] * 999 + [b"x" * 200])])
+        at = int(kds.decode_column_chunk(liar)[0]["values"].view(np.uint64)[999])
+        assert int(liar[at:at + 4].view(np.uint32)[0]) == 204 << 2
+        liar[at:at + 4] = np.array([(1 << 29) << 2], dtype="<u4").view(np.uint8)
+        with pytest.raises(runtime.StromError) as ei:
+            scan.scan_chunk(liar)
+        assert ei.value.errcode == 300
         for row_map in (None, np.arange(0, 1000, 3, dtype=np.int32)):
             buf = kds.build_kds("column", [kds.Column("int8", a)])
             with pytest.raises(runtime.StromError) as ei:
