@@ -2756,6 +2756,9 @@ gpupreagg_hash_sum_account(kern_gpupreagg *kgpreagg, gpupreagg_hash_head *head, 
 {
 	if (gpupreagg_intsum_index(GPUPREAGG_NAGGS) == 0 || (sum_turn & 2u) != 0)
 		return true;
+#if defined(GPUPREAGG_CHECKED) && GPUPREAGG_CHECKED
+	return true;				/* every addition is checked one by one: no proof needed */
+#endif
 	cl_ulong	prev = head->sum_bound[sum_turn & 1u];
 	cl_ulong	add = gpupreagg_sum_bound(KERN_GPUPREAGG_FOLD_NROWS(kgpreagg), *KERN_GPUPREAGG_SUM_MAGBITS(kgpreagg));
 	bool		ok = (prev < (1UL << 63) && add < (1UL << 63) && prev + add < (1UL << 63));
@@ -2965,8 +2968,20 @@ gpupreagg_hash_lds_slot(const gpupreagg_hash_lds &T, cl_uint hash, const cl_ulon
 /* merge one 8-byte value (in its stored form) into a global accumulator */
 template <int OP, typename BASE>
 STROM_DEVICE void
-gpupreagg_hash_merge8(cl_ulong *addr, cl_ulong x)
+gpupreagg_hash_merge8(cl_ulong *addr, cl_ulong x, cl_int *chunk_status = NULL)
 {
+#if defined(GPUPREAGG_CHECKED) && GPUPREAGG_CHECKED
+	/* the exact fold of a chunk whose integer sums' range could not be proven (gpupreagg.cpp:
+	 * gpupreagg_hashed_exact): every link of a group's chain of additions is checked against
+	 * what it was added to, as in gpupreagg_lds_accum */
+	if (OP == GPUPREAGG_OP_PSUM && !gpupreagg_is_float<BASE>::value && chunk_status != NULL)
+	{
+		cl_long		sum;
+		cl_long		old = __hip_atomic_fetch_add((cl_long *)addr, (cl_long)x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		STROM_SET_RECHECK_IF(chunk_status, __builtin_add_overflow(old, (cl_long)x, &sum));
+		return;
+	}
+#endif
 	if (OP == GPUPREAGG_OP_NROWS || (OP == GPUPREAGG_OP_PSUM && !gpupreagg_is_float<BASE>::value))
 		__hip_atomic_fetch_add(addr, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 	else if (OP == GPUPREAGG_OP_PSUM)
@@ -3091,7 +3106,7 @@ gpupreagg_hash_body(kern_gpupreagg *kgpreagg,
 		{
 			/* the work-group's own table: LDS atomics, as in gpupreagg_dense_row */
 #define X(aidx,resno,OP,NAME)														\
-			need |= gpupreagg_lds_accum<GPUPREAGG_OP_##OP, aidx>(lds, L.vals_off[aidx], lslot, av_##aidx);
+			need |= gpupreagg_lds_accum<GPUPREAGG_OP_##OP, aidx>(lds, L.vals_off[aidx], lslot, av_##aidx, &chunk_status);
 			GPUPREAGG_AGG_LIST(X)
 #undef X
 			gpupreagg_flags_t *flags = (gpupreagg_flags_t *)lds;
@@ -3135,7 +3150,7 @@ gpupreagg_hash_body(kern_gpupreagg *kgpreagg,
 			if (GPUPREAGG_OP_##OP != GPUPREAGG_OP_NROWS && has)						\
 				need |= (2u << aidx);												\
 			if (has && !(GPUPREAGG_OP_##OP == GPUPREAGG_OP_NROWS && x == 0))		\
-				gpupreagg_hash_merge8<GPUPREAGG_OP_##OP, base_t>(HASH_REC_VALS(rec) + aidx, x);	\
+				gpupreagg_hash_merge8<GPUPREAGG_OP_##OP, base_t>(HASH_REC_VALS(rec) + aidx, x, &chunk_status);	\
 		}
 		GPUPREAGG_AGG_LIST(X)
 #undef X
@@ -3354,7 +3369,7 @@ gpupreagg_hash_body(kern_gpupreagg *kgpreagg,
 			}																		\
 			else if (lf & (2u << aidx))												\
 				gpupreagg_hash_merge8<GPUPREAGG_OP_##OP, pg_##NAME##_base_t>		\
-					(HASH_REC_VALS(rec) + aidx, ((const cl_ulong *)(lds + L.vals_off[aidx]))[s]);
+					(HASH_REC_VALS(rec) + aidx, ((const cl_ulong *)(lds + L.vals_off[aidx]))[s], &chunk_status);
 			GPUPREAGG_AGG_LIST(X)
 #undef X
 			if ((*HASH_REC_FLAGS(rec) & lf) != lf)
@@ -4125,7 +4140,7 @@ gpupreagg_hash_fold_units(kern_gpupreagg *kgpreagg, char *htab, cl_uint claim_li
 					{
 						cl_uint		need = GPUPREAGG_FLAG_SEEN;
 #define X(aidx,resno,OP,NAME)														\
-						need |= gpupreagg_lds_accum<GPUPREAGG_OP_##OP, aidx>(lds, L.vals_off[aidx], lslot, av_##aidx);
+						need |= gpupreagg_lds_accum<GPUPREAGG_OP_##OP, aidx>(lds, L.vals_off[aidx], lslot, av_##aidx, &chunk_status);
 						GPUPREAGG_AGG_LIST(X)
 #undef X
 						gpupreagg_flags_t *flags = (gpupreagg_flags_t *)lds;
@@ -4171,7 +4186,7 @@ gpupreagg_hash_fold_units(kern_gpupreagg *kgpreagg, char *htab, cl_uint claim_li
 						if (GPUPREAGG_OP_##OP != GPUPREAGG_OP_NROWS && has)			\
 							need_ |= (2u << aidx);									\
 						if (has && !(GPUPREAGG_OP_##OP == GPUPREAGG_OP_NROWS && x == 0))	\
-							gpupreagg_hash_merge8<GPUPREAGG_OP_##OP, base_t>(HASH_REC_VALS(grec) + aidx, x);	\
+							gpupreagg_hash_merge8<GPUPREAGG_OP_##OP, base_t>(HASH_REC_VALS(grec) + aidx, x, &chunk_status);	\
 					}
 					GPUPREAGG_HASH_MERGE_ROW(grec);
 #undef X
@@ -4222,7 +4237,7 @@ gpupreagg_hash_fold_units(kern_gpupreagg *kgpreagg, char *htab, cl_uint claim_li
 				}																	\
 				else if (lf & (2u << aidx))											\
 					gpupreagg_hash_merge8<GPUPREAGG_OP_##OP, pg_##NAME##_base_t>	\
-						(HASH_REC_VALS(grec) + aidx, ((const cl_ulong *)(lds + L.vals_off[aidx]))[s]);
+						(HASH_REC_VALS(grec) + aidx, ((const cl_ulong *)(lds + L.vals_off[aidx]))[s], &chunk_status);
 				GPUPREAGG_AGG_LIST(X)
 #undef X
 				if ((*HASH_REC_FLAGS(grec) & lf) != lf)
@@ -4517,6 +4532,50 @@ gpupreagg_hash_import(char *htab, const char *recs, cl_uint seg_len, cl_uint nse
 		(void)vals;
 		if ((*HASH_REC_FLAGS(grec) & flags) != flags)
 			atomicOr(HASH_REC_FLAGS(grec), flags);
+	}
+}
+
+/*
+ * Would gpupreagg_hash_import take an integer sum out of int8?  Read-only pass over ONE segment of
+ * records with pairwise different keys (another session's export): a record either meets its
+ * group in this table -- then the two partial sums are added in range, or *overflowed is set --
+ * or is new here.  The host imports only when nothing was set ("integer sums never wrap").
+ */
+extern "C" __global__ void
+__launch_bounds__(256)
+gpupreagg_hash_import_verify(char *htab, const char *recs, cl_uint count, cl_uint *overflowed)
+{
+	const size_t	reclen = 8 + 8 * (GPUPREAGG_NKEYS + GPUPREAGG_NAGGS);
+
+	for (cl_uint i = blockIdx.x * blockDim.x + threadIdx.x; i < count; i += gridDim.x * blockDim.x)
+	{
+		const char *rec = recs + reclen * i;
+		cl_uint		knull = ((const cl_uint *)rec)[0];
+		cl_uint		flags = ((const cl_uint *)rec)[1];
+		const cl_ulong *body = (const cl_ulong *)(rec + 8);
+		cl_ulong	kimg[GPUPREAGG_NKEYS + 1];
+		for (int k = 0; k < GPUPREAGG_NKEYS; k++)
+			kimg[k] = body[k];
+		/* (claim limit 0: an empty slot ends the search, nothing is claimed) */
+		cl_uint		slot = gpupreagg_hash_slot<true>(htab, gpupreagg_hash_of(kimg, knull), kimg, knull, 0u);
+		if (slot == GPUPREAGG_HASH_FULL || slot == GPUPREAGG_HASH_DEFER)
+			continue;
+		const char *grec = gpupreagg_hash_rec(htab, slot);
+		cl_uint		gflags = *HASH_REC_FLAGS(grec);
+		const cl_ulong *vals = body + GPUPREAGG_NKEYS;
+		bool		bad = false;
+#define X(aidx,resno,OP,NAME)															\
+		if (gpupreagg_is_intsum<GPUPREAGG_OP_##OP, pg_##NAME##_base_t>::value && (flags & gflags & (2u << aidx)))	\
+		{																				\
+			cl_long		sum;															\
+			bad = bad || __builtin_add_overflow((cl_long)HASH_REC_VALS(grec)[aidx], (cl_long)vals[aidx], &sum);	\
+		}
+		GPUPREAGG_AGG_LIST(X)
+#undef X
+		(void)vals;
+		(void)gflags;
+		if (bad)
+			*overflowed = 1u;
 	}
 }
 

@@ -23,6 +23,9 @@
 
 using namespace strom;
 
+/* a scratch session of a hashed one, its program built with GPUPREAGG_CHECKED (defined below) */
+static strom_gpupreagg *gpupreagg_exact_child(strom_gpupreagg *sess, int *p_errcode);
+
 namespace {
 
 /* mirrors struct gpupreagg_dense_ctl of strom_gpupreagg.h */
@@ -579,6 +582,8 @@ struct preagg_request {
 	bool				lookup = false;				/* no result pairs: the join is a lookup in the aggregate's pass */
 	Program			   *prog = nullptr;				/* lookup: the session's program built for this column mapping */
 	std::shared_ptr<std::vector<char>> joined_map;	/* host image of gpupreagg_joined_map */
+	/* hashed, exact fold (gpupreagg_hashed_exact): 'sess' is a scratch session of this one */
+	strom_gpupreagg	   *exact_parent = nullptr;
 };
 
 /* bits of the largest magnitude a zone map allows (strom_gpupreagg.h: gpupreagg_sum_magnitude) */
@@ -1284,8 +1289,60 @@ hash_sum_measured_bound(strom_gpupreagg *sess, cl_ulong *p_bound)
 	return 0;
 }
 
+void gpupreagg_launch_hashed(strom_task_impl *task, preagg_request req, bool second = false);
+/*
+ * The exact fold of a hashed session ("integer sums never wrap", strom_gpupreagg.h).  The running
+ * bound of a hashed table -- rows x largest input magnitude, over all groups at once -- can fail
+ * although no group comes near the edge (2e6 rows of 1e13 in a thousand groups).  Such a chunk is
+ * folded into a SCRATCH session of the same targets whose program is built with GPUPREAGG_CHECKED
+ * (every LDS and table addition returns what it was added to and is checked, the reference's
+ * CHECK_OVERFLOW_INT on every accumulate, opencl_gpupreagg.h:142-143): an addition that leaves int8
+ * inside the chunk is CpuReCheck and the session's table has not been touched.  Then the scratch
+ * groups join the table: a read-only pass checks every group that exists on both sides
+ * (gpupreagg_hash_import_verify), and only when all fit are they imported.  Exact, or CpuReCheck
+ * with the table as it was.  Rare and slower (a second table, one more pass): the price is paid by
+ * the chunks that need it.  The scratch session lives for the request (strom_task_impl::at_complete).
+ */
 void
-gpupreagg_launch_hashed(strom_task_impl *task, preagg_request req, bool second = false)
+gpupreagg_hashed_exact(strom_task_impl *task, preagg_request req)
+{
+	int		errcode = 0;
+	strom_gpupreagg *child = gpupreagg_exact_child(req.sess, &errcode);
+	if (!child)
+	{
+		task_fail(task, errcode ? errcode : StromError_OutOfMemory);
+		return;
+	}
+	task->at_complete.push_back([child]() { strom_gpupreagg_release(child); });
+	req.sess->checked_folds++;
+	preagg_request creq = req;
+	creq.exact_parent = req.sess;
+	creq.sess = child;
+	program_run_or_park(child->prog, [task, creq]() { gpupreagg_launch_hashed(task, creq, false); });
+}
+
+void
+gpupreagg_hashed_exact_merge(strom_task_impl *task, preagg_request req)
+{
+	strom_gpupreagg *child = req.sess, *parent = req.exact_parent;
+	char	   *d_recs = nullptr;
+	cl_uint		count = 0;
+	size_t		reclen = 0;
+	int			rc = gpupreagg_hash_export_device(child, &d_recs, &count, &reclen);
+	if (rc == 0 && count > 0)
+		rc = gpupreagg_hash_import_device(parent, d_recs, count, 1, &count, ~0u, GPUPREAGG_IMPORT_EXACT);
+	gpupreagg_hash_release(child, d_recs);
+	if (rc != 0 && rc != StromError_CpuReCheck)
+	{
+		task_fail(task, rc);
+		return;
+	}
+	task->finish = [rc](strom_task_impl *t) { t->errcode = rc; };
+	task_enqueue(task);
+}
+
+void
+gpupreagg_launch_hashed(strom_task_impl *task, preagg_request req, bool second)
 {
 	strom_gpupreagg *sess = req.sess;
 	Device	   *dev = task->dev;
@@ -1790,6 +1847,20 @@ gpupreagg_launch_hashed(strom_task_impl *task, preagg_request req, bool second =
 			t->retry = [t, req]() { gpupreagg_launch_hashed(t, req, true); };
 			return;
 		}
+		if (status == StromError_SumRangeUnproven && !req.exact_parent && !getenv("STROM_GPUPREAGG_HASH_NO_EXACT"))
+		{
+			/* rows x largest magnitude still reaches 2^63 -- a bound over ALL groups at once,
+			 * which says little about any one of them: the chunk is folded exactly instead */
+			t->retry = [t, req]() { gpupreagg_hashed_exact(t, req); };
+			return;
+		}
+		if (status == StromError_Success && req.exact_parent)
+		{
+			/* the scratch session holds the chunk's groups, every addition checked: they
+			 * join the parent's under a per-group range check */
+			t->retry = [t, req]() { gpupreagg_hashed_exact_merge(t, req); };
+			return;
+		}
 		if (status == StromError_SumRangeUnproven)
 			status = StromError_CpuReCheck;
 		if (status == StromError_Success && words[3] != 0)
@@ -1982,6 +2053,26 @@ strom_gpupreagg_create_hashed(strom_devprog_key key,
 	sess->hash_capacity = (cl_uint)capacity;
 	sess->groups_known = ngroups_hint;
 	return sess;
+}
+
+static strom_gpupreagg *
+gpupreagg_exact_child(strom_gpupreagg *sess, int *p_errcode)
+{
+	std::string	source = "#define GPUPREAGG_CHECKED 1\n" + sess->prog->source;
+	strom_devprog_key ckey = strom_get_devprog_key(source.c_str(), sess->prog->extra_flags);
+	if (!ckey)
+	{
+		*p_errcode = StromError_OutOfMemory;
+		return nullptr;
+	}
+	strom_gpupreagg *child = gpupreagg_session_new(ckey, sess->targets.data(), (int)sess->targets.size(),
+												   (const kern_parambuf *)sess->kparams.data(), nullptr, true,
+												   sess->dev->dindex, p_errcode);
+	strom_put_devprog_key(ckey);			/* the session holds its own reference */
+	if (!child)
+		return nullptr;
+	child->hash_capacity = 1u << 16;		/* grows with the chunk's groups like any hashed table */
+	return child;
 }
 
 extern "C" size_t
@@ -2669,7 +2760,36 @@ strom::gpupreagg_hash_import_device(strom_gpupreagg *sess, const char *d_recs, c
 	if (incoming == 0)
 		return 0;
 	(void)hipSetDevice(dev->hip_id);
-	if (incoming_sum_bound != 0 && sess->nintsums != 0)
+	if (incoming_sum_bound == GPUPREAGG_IMPORT_EXACT && sess->nintsums != 0 && sess->htab)
+	{
+		/* one segment of pairwise different keys: group by group (gpupreagg_hash_import_verify) */
+		int		e2 = 0;
+		hipFunction_t fn_verify = sess->prog->get_function(dev, "gpupreagg_hash_import_verify", &e2);
+		if (!fn_verify)
+			return e2;
+		if (nsegs != 1 || skip_seg != ~0u)
+			return StromError_BadRequestMessage;
+		cl_uint	   *d_flag = (cl_uint *)dev->pool.alloc(sizeof(cl_uint));
+		if (!d_flag)
+			return StromError_OutOfMemory;
+		void	   *a_tab = sess->htab;
+		const void *a_recs = d_recs;
+		cl_uint		a_count = h_counts[0], flag = 0;
+		void	   *a_flag = d_flag;
+		void	   *vargs[] = { &a_tab, &a_recs, &a_count, &a_flag };
+		unsigned	vgrid = (unsigned)std::max<size_t>(1, std::min<size_t>(((size_t)a_count + 255) / 256,
+																			(size_t)dev->prop.multiProcessorCount * 8));
+		bool	vok = (hipMemsetAsync(d_flag, 0, sizeof(cl_uint), dev->streams[0]) == hipSuccess &&
+					   hipModuleLaunchKernel(fn_verify, vgrid, 1, 1, 256, 1, 1, 0, dev->streams[0], vargs, nullptr) == hipSuccess &&
+					   hipMemcpyAsync(&flag, d_flag, sizeof(cl_uint), hipMemcpyDeviceToHost, dev->streams[0]) == hipSuccess &&
+					   hipStreamSynchronize(dev->streams[0]) == hipSuccess);
+		dev->pool.release(d_flag);
+		if (!vok)
+			return StromError_HipInternal;
+		if (flag)
+			return StromError_CpuReCheck;
+	}
+	else if (incoming_sum_bound != 0 && incoming_sum_bound != GPUPREAGG_IMPORT_EXACT && sess->nintsums != 0)
 	{
 		cl_ulong	mine = 0;
 		int			brc = hash_sum_measured_bound(sess, &mine);

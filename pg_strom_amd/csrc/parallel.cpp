@@ -762,11 +762,10 @@ strom_gpupreagg_merge(strom_gpupreagg *dst, strom_gpupreagg *src)
 	char	   *d_recs = nullptr;
 	cl_uint		count = 0;
 	size_t		reclen = 0;
-	cl_ulong	bound = 0;
-	int			rc = gpupreagg_hash_export_device(src, &d_recs, &count, &reclen, &bound);
-	/* (bound 0: src holds no integer sum other than zero -- nothing is added up, nothing to prove) */
+	int			rc = gpupreagg_hash_export_device(src, &d_recs, &count, &reclen);
+	/* (one source: every group that exists on both sides is checked by itself -- exact) */
 	if (rc == 0 && count > 0)
-		rc = gpupreagg_hash_import_device(dst, d_recs, count, 1, &count, ~0u, bound);
+		rc = gpupreagg_hash_import_device(dst, d_recs, count, 1, &count, ~0u, GPUPREAGG_IMPORT_EXACT);
 	gpupreagg_hash_release(src, d_recs);
 	return rc;
 }

@@ -184,6 +184,9 @@ struct strom_task_impl : public strom_task {
 	 * in range).  The completer hands it to a worker thread; whatever it queues ends in
 	 * task_enqueue() / task_fail() again, and done() still runs exactly once. */
 	std::function<void()> retry;
+	/* run once when the request completes, however it ends, before done(): what a request
+	 * made for itself on the way (GpuPreAgg: the scratch session of an exact hashed fold) */
+	std::vector<std::function<void()>> at_complete;
 	/* waiter side */
 	std::mutex	lock;
 	std::condition_variable cond;
@@ -254,7 +257,9 @@ int			gpupreagg_hash_export_device(strom_gpupreagg *sess, char **p_recs, cl_uint
 int			gpupreagg_hash_export_parts_device(strom_gpupreagg *sess, cl_uint nparts, char **p_recs, cl_uint *h_counts,
 											   size_t *p_reclen, cl_ulong *p_sum_bound);
 void		gpupreagg_hash_release(strom_gpupreagg *sess, char *recs);
-/* incoming_sum_bound: see gpupreagg.cpp -- the integer sums' range proof of the merge */
+/* incoming_sum_bound: see gpupreagg.cpp -- the integer sums' range proof of the merge; this value:
+ * ONE segment of pairwise different keys (another session's export), proven group by group */
+const cl_ulong GPUPREAGG_IMPORT_EXACT = ~0UL;
 int			gpupreagg_hash_import_device(strom_gpupreagg *sess, const char *d_recs, cl_uint seg_len, cl_uint nsegs,
 										 const cl_uint *h_counts, cl_uint skip_seg, cl_ulong incoming_sum_bound);
 /* parallel.cpp: a kernel of the fixed-function program (devlib/strom_merge.h: the merge's prepare /
