@@ -246,7 +246,9 @@ uint32_t	strom_gpupreagg_num_groups(strom_gpupreagg *sess);
  * when an accumulate leaves int8.  Here a range proof (rows x largest input magnitude
  * < 2^63) lets unchecked kernels run; a chunk it cannot cover is folded a second time,
  * add by add, by a program built with GPUPREAGG_CHECKED, inside the same request
- * (devlib/strom_gpupreagg.h, "integer sums never wrap").  How many requests of this session
+ * (devlib/strom_gpupreagg.h, "integer sums never wrap"; hashed sessions fold such a chunk
+ * into a scratch table that way and let its groups join the table under a per-group check:
+ * exact there too, and a CpuReCheck leaves the table as it was).  How many requests of this session
  * took that second fold: a statistic (EXPLAIN ANALYZE material, like the reference's perfmon).
  */
 uint32_t	strom_gpupreagg_checked_folds(strom_gpupreagg *sess);

@@ -4067,6 +4067,7 @@ gpupreagg_hash_fold_units(kern_gpupreagg *kgpreagg, char *htab, cl_uint claim_li
 	gpupreagg_lds_layout L;
 	gpupreagg_hash_lds T;
 	cl_uint		nunits = (todo ? ntodo : ctl->nunits);
+	cl_int		chunk_status = StromError_Success;	/* (raised by the checked program's additions only) */
 
 	if (kgpreagg->status != StromError_Success)
 		return;
@@ -4248,6 +4249,11 @@ gpupreagg_hash_fold_units(kern_gpupreagg *kgpreagg, char *htab, cl_uint claim_li
 		}
 		__syncthreads();
 	}
+#if defined(GPUPREAGG_CHECKED) && GPUPREAGG_CHECKED
+	gpupreagg_writeback_status(&kgpreagg->status, chunk_status);
+#else
+	(void)chunk_status;
+#endif
 }
 
 extern "C" __global__ void

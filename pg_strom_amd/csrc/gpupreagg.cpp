@@ -1424,7 +1424,9 @@ gpupreagg_launch_hashed(strom_task_impl *task, preagg_request req, bool second)
 	memcpy(((kern_gpupreagg *)stage)->__padding, &sess->static_magbits, sizeof(cl_uint));
 	/* the fold's turn (gpupreagg_hash_sum_account): parity; 4 = second attempt, after the
 	 * bound was measured; relaunches for deferred rows add 2 */
-	cl_uint		sum_turn = (sess->sum_turn++ & 1u) | (second ? 4u : 0u);
+	/* (bit 2 -- "a failed proof is final: CpuReCheck" -- is no longer asked for: the host sends an
+	 * unproven chunk to the exact fold instead, gpupreagg_hashed_exact) */
+	cl_uint		sum_turn = (sess->sum_turn++ & 1u) | ((second && getenv("STROM_GPUPREAGG_HASH_NO_EXACT")) ? 4u : 0u);
 	if (second)
 	{
 		int rc = hash_sum_refresh(sess);

@@ -111,8 +111,9 @@ def test_sum_that_leaves_int8_is_cpu_recheck(fmt, ngroups, hashed):
     assert oracle_status(SPEC, buf, 4) == 2
     statuses, _, _ = run_dense(SPEC, [buf], [(0, ngroups)], hashed)
     assert statuses == [2]
-    # (inputs of 2^61: not even a work-group's own sums are covered by the proof -- tier 3)
-    assert hashed or LAST["checked_folds"] == 1
+    # (inputs of 2^61: not even a work-group's own sums are covered by the proof -- tier 3; the
+    # hashed table's bound over all groups fails likewise and the chunk is folded exactly)
+    assert LAST["checked_folds"] == 1
     # 3 x 2^61 + 2^60 fit: the same chunk with two of the five rows made smaller is summed on
     # the device
     x[hot[0]] = 7
@@ -120,13 +121,9 @@ def test_sum_that_leaves_int8_is_cpu_recheck(fmt, ngroups, hashed):
     buf = table(g, x, fmt)
     assert oracle_status(SPEC, buf, 4) == 0
     statuses, pr, targets = run_dense(SPEC, [buf], [(0, ngroups)], hashed)
-    if hashed:
-        # the hashed table proves ranges over ALL its groups at once (rows x magnitude):
-        # conservative -- it may send a chunk back that would have fitted, never the reverse
-        assert statuses in ([0], [2])
-        if statuses == [2]:
-            return
-    assert statuses == [0]
+    # (hashed too: its bound over ALL groups at once -- rows x magnitude -- fails, the exact fold
+    # into a scratch table with checked additions finds every group in range)
+    assert statuses == [0] and LAST["checked_folds"] == 1
     assert totals([pr], targets) == {k: [None] + v for k, v in expected(g, x).items()}
 
 
@@ -265,3 +262,91 @@ def test_sums_of_int4_columns_need_no_measurement():
     for k in range(9):
         cnt = 2 * int((g == k).sum())
         assert got[(k,)][1:] == [cnt, cnt * int(x[k])]
+
+
+# ---------------------------------------------------------------------------------------------
+# the hashed table, exactly.  Its running bound -- rows x largest magnitude, over all groups at
+# once -- says little about any one group; where it fails the chunk is folded into a scratch
+# session with checked additions and joins the table under a per-group check
+# (csrc/gpupreagg.cpp: gpupreagg_hashed_exact).  Device == oracle == Python, never a CpuReCheck
+# the reference would not have raised.
+# ---------------------------------------------------------------------------------------------
+HSPEC = "(gpupreagg (key (var 1 int4)) (nrows) (psum (var 2 int8)) (pmax (var 2 int8)))"
+
+
+@pytest.mark.parametrize("fmt", ["column", "row"])
+def test_hashed_two_million_rows_of_1e13_are_summed_not_sent_back(fmt):
+    """2e6 rows of ~1e13 in 1000 groups: rows x magnitude is 2^65, every group's sum 2e16.
+    (fmt row: 2e5 rows -- heap pages of 2e6 rows do not fit one chunk's 16-bit block index)"""
+    n = 2_000_000 if fmt == "column" else 200_000
+    rng = np.random.default_rng(8)
+    g = rng.integers(0, 1000, n)
+    x = rng.integers(10**13 - 10**6, 10**13 + 10**6, n) * rng.choice([-1, 1], n, p=[0.1, 0.9])
+    if fmt == "row":
+        x = x * 256                                # keep rows x magnitude beyond 2^63 at 2e5 rows
+    buf = table(g, x, fmt)
+    assert oracle_status(HSPEC, buf, 4) == 0
+    statuses, pr, targets = run_dense(HSPEC, [buf, buf], None, hashed=True)
+    assert statuses == [0, 0] and LAST["checked_folds"] >= 1
+    want = {k: [None, 2 * v[0], 2 * v[1], v[2]] for k, v in expected(g, x).items()}
+    assert totals([pr], targets) == want
+
+
+def test_hashed_sum_that_crosses_int8_in_the_second_chunk_leaves_the_table_alone():
+    """chunk 1 leaves 0.6 x 2^63 in group 7, chunk 2 brings as much again: inside chunk 2 every
+    addition fits (the scratch fold succeeds), the group does not fit the table's -- the verify
+    pass says so before anything is imported: CpuReCheck, table as it was.  A third chunk that
+    takes the group back down is summed."""
+    n = 40000
+    rng = np.random.default_rng(9)
+    g = rng.integers(0, 300, n)
+    x = rng.integers(-10**9, 10**9, n)
+    hot = np.where(g == 7)[0][:6]
+    x[g == 7] = 0
+    x[hot] = (6 * 2**63 // 10) // 6
+    up = table(g, x, "column")
+    x2 = x.copy()
+    x2[hot] = -x2[hot]
+    down = table(g, x2, "column")
+    agg = GpuPreAgg(HSPEC).begin_hashed()
+    try:
+        assert agg.fold(up)[0] == 0
+        before = totals([agg.fetch()], agg.targets)
+        assert before[(7,)][2] == 6 * ((6 * 2**63 // 10) // 6) > 2**62
+        assert agg.fold(up)[0] == 2                      # StromError_CpuReCheck
+        assert totals([agg.fetch()], agg.targets) == before
+        assert agg.fold(down)[0] == 0
+        after = totals([agg.fetch()], agg.targets)
+        assert after[(7,)][2] == 0 and after[(7,)][1] == 2 * before[(7,)][1]
+        assert agg.checked_folds() >= 2
+    finally:
+        agg.end()
+
+
+def test_hashed_values_at_the_edges_of_int8_that_fit_are_exact():
+    """a group that IS int8's largest value, one that is its smallest, sums one short of the
+    edge, among ordinary rows: Success in the oracle, Success and the same sums on the device"""
+    rng = np.random.default_rng(10)
+    n = 30000
+    g = rng.integers(4, 500, n)
+    x = rng.integers(-10**12, 10**12, n)
+    special = {0: [I64_MAX], 1: [I64_MIN], 2: [1 << 61, 1 << 61, 1 << 61, (1 << 61) - 1],
+               3: [-(1 << 62), -(1 << 62)]}
+    rows = rng.choice(n, sum(len(v) for v in special.values()), replace=False)
+    i = 0
+    for key, vals in special.items():
+        for v in vals:
+            g[rows[i]] = key
+            x[rows[i]] = v
+            i += 1
+    buf = table(g, x, "column")
+    assert oracle_status(HSPEC, buf, 4) == 0
+    statuses, pr, targets = run_dense(HSPEC, [buf], None, hashed=True)
+    assert statuses == [0] and LAST["checked_folds"] == 1
+    assert totals([pr], targets) == {k: [None] + v for k, v in expected(g, x).items()}
+    # one more row on top of the largest value: that chunk is the CPU's, as in the reference
+    g2, x2 = np.append(g, 0), np.append(x, 1)
+    buf2 = table(g2, x2, "column")
+    assert oracle_status(HSPEC, buf2, 4) == 2
+    statuses, _, _ = run_dense(HSPEC, [buf2], None, hashed=True)
+    assert statuses == [2]
