@@ -696,7 +696,8 @@ gpupreagg_dense_row(char *lds, const gpupreagg_dense_ctl *ctl, const gpupreagg_l
 STROM_DEVICE void
 gpupreagg_lds_init(char *lds, const gpupreagg_lds_layout &L, cl_uint G, cl_uint NREP)
 {
-	for (cl_uint i = threadIdx.x * 16; i < L.total; i += GPUPREAGG_BLOCK * 16)
+	/* (blockDim.x: the hashed partition plan's fold runs 1024 threads, everything else GPUPREAGG_BLOCK) */
+	for (cl_uint i = threadIdx.x * 16; i < L.total; i += blockDim.x * 16)
 		*(uint4 *)(lds + i) = make_uint4(0, 0, 0, 0);
 	__syncthreads();
 #define X(aidx,resno,OP,NAME)															\
@@ -704,7 +705,7 @@ gpupreagg_lds_init(char *lds, const gpupreagg_lds_layout &L, cl_uint G, cl_uint 
 	{																					\
 		cl_ulong   *vals = (cl_ulong *)(lds + L.vals_off[aidx]);						\
 		cl_ulong	ident = gpupreagg_identity<GPUPREAGG_OP_##OP, pg_##NAME##_base_t>();	\
-		for (cl_uint i = threadIdx.x; i < G * NREP; i += GPUPREAGG_BLOCK)				\
+		for (cl_uint i = threadIdx.x; i < G * NREP; i += blockDim.x)					\
 			vals[i] = ident;															\
 	}
 	GPUPREAGG_AGG_LIST(X)
@@ -3943,7 +3944,7 @@ gpupreagg_hash_scatter(kern_gpupreagg *kgpreagg, const kern_data_store *kds,
 }
 
 extern "C" __global__ void
-__launch_bounds__(GPUPREAGG_BLOCK)
+__launch_bounds__(1024)
 gpupreagg_hash_scatter_lds(kern_gpupreagg *kgpreagg, const kern_data_store *kds,
 						   const kern_data_store *ktoast, const kern_row_map *krowmap,
 						   cl_ushort *partmap, cl_uint *cursor, cl_ulong *records, const gpupreagg_part_ctl *ctl,
@@ -4257,7 +4258,7 @@ gpupreagg_hash_fold_units(kern_gpupreagg *kgpreagg, char *htab, cl_uint claim_li
 }
 
 extern "C" __global__ void
-__launch_bounds__(GPUPREAGG_BLOCK)
+__launch_bounds__(1024)
 gpupreagg_hash_fold_parts(kern_gpupreagg *kgpreagg, char *htab, cl_uint claim_limit,
 						  gpupreagg_part_ctl *ctl, const cl_uint *units, const cl_ulong *records,
 						  cl_uint lds_slots, const cl_uint *todo, cl_uint ntodo, cl_uint *redo, cl_uint sum_turn)

@@ -1589,18 +1589,25 @@ gpupreagg_launch_hashed(strom_task_impl *task, preagg_request req, bool second)
 		size_t		stage_fixed = 12 * (size_t)nparts + 128;
 		size_t		stage_budget = 159 * 1024;
 		cl_uint		lds_rows = 0;
-		if (nparts <= 4 * block && stage_fixed < stage_budget && !getenv("STROM_GPUPREAGG_HASH_NO_LDS_SCATTER"))
-			lds_rows = (cl_uint)std::min<size_t>(4, (stage_budget - stage_fixed) / ((reclen + 2) * block));
+		unsigned	sblock = block;
+		if (const char *v = getenv("STROM_GPUPREAGG_HASH_SCATTER_BLOCK"))
+		{
+			int want = atoi(v);
+			if (want == 256 || want == 512 || want == 1024)
+				sblock = (unsigned)want;
+		}
+		if (nparts <= 4 * sblock && stage_fixed < stage_budget && !getenv("STROM_GPUPREAGG_HASH_NO_LDS_SCATTER"))
+			lds_rows = (cl_uint)std::min<size_t>(4, (stage_budget - stage_fixed) / ((reclen + 2) * sblock));
 		if (const char *v = getenv("STROM_GPUPREAGG_HASH_SCATTER_ROWS"))
 			lds_rows = std::min<cl_uint>(lds_rows, (cl_uint)std::max(1, atoi(v)));
 		if (lds_rows > 0)
 		{
-			size_t		stage_bytes = stage_fixed + (size_t)lds_rows * block * (reclen + 2);
+			size_t		stage_bytes = stage_fixed + (size_t)lds_rows * sblock * (reclen + 2);
 			void	   *args[] = { &a_kg, &a_kds, &a_toast, &a_map, &a_partmap, &a_cursor, &a_records, &a_ctl, &lds_rows };
-			size_t		tile = (size_t)block * lds_rows;
+			size_t		tile = (size_t)sblock * lds_rows;
 			unsigned	grid = (unsigned)std::max<size_t>(1, std::min<size_t>((nrows + tile - 1) / tile,
 																			   (size_t)ncus * (stage_bytes <= 72 * 1024 ? 2 : 1)));
-			REQ_CHECK(hipModuleLaunchKernel(fn_scatter_lds, grid, 1, 1, block, 1, 1, (unsigned)stage_bytes,
+			REQ_CHECK(hipModuleLaunchKernel(fn_scatter_lds, grid, 1, 1, sblock, 1, 1, (unsigned)stage_bytes,
 											task->stream, args, nullptr),
 					  "launch gpupreagg hash scatter (LDS)");
 		}
@@ -1622,6 +1629,18 @@ gpupreagg_launch_hashed(strom_task_impl *task, preagg_request req, bool second)
 		size_t		lds_bytes = 0;				/* (the units' table, not the roles') */
 		cl_uint		lds_slots = hash_lds_slots(sess, &lds_bytes, true);
 		unsigned	fold_grid = ncus * (lds_bytes <= 72 * 1024 ? 2 : 1);
+		/*
+		 * the unit's LDS table leaves room for one work-group per CU: its size in threads is the
+		 * CU's whole occupancy.  256 threads are ONE wave per SIMD -- every record load's latency
+		 * shows; 1024 (what the kernel is bounded at) are four.
+		 */
+		unsigned	fold_block = (lds_bytes > 72 * 1024 ? 1024u : block);
+		if (const char *v = getenv("STROM_GPUPREAGG_HASH_FOLD_BLOCK"))
+		{
+			int want = atoi(v);
+			if (want == 256 || want == 512 || want == 1024)
+				fold_block = (unsigned)want;
+		}
 		char	   *d_lists = d_ctl + sizeof(part_ctl) + sizeof(cl_uint) * ((size_t)2 * nparts + (size_t)2 * max_units);
 		void	   *a_todo = nullptr;
 		cl_uint		ntodo = 0;
@@ -1655,7 +1674,7 @@ gpupreagg_launch_hashed(strom_task_impl *task, preagg_request req, bool second)
 			cl_uint		a_turn = sum_turn | (turn > 0 ? 2u : 0u);
 			void	   *args[] = { &a_kg, &a_tab, &claim_limit, &a_ctl, &a_units, &a_records, &lds_slots,
 								   &a_todo, &ntodo, &a_redo, &a_turn };
-			REQ_CHECK(hipModuleLaunchKernel(fn_units, fold_grid, 1, 1, block, 1, 1, (unsigned)lds_bytes,
+			REQ_CHECK(hipModuleLaunchKernel(fn_units, fold_grid, 1, 1, fold_block, 1, 1, (unsigned)lds_bytes,
 											task->stream, args, nullptr),
 					  "launch gpupreagg hash fold (partitions)");
 			task->pfm.num_kern_exec++;
