@@ -3944,7 +3944,7 @@ gpupreagg_hash_scatter(kern_gpupreagg *kgpreagg, const kern_data_store *kds,
 }
 
 extern "C" __global__ void
-__launch_bounds__(1024)
+__launch_bounds__(GPUPREAGG_BLOCK)
 gpupreagg_hash_scatter_lds(kern_gpupreagg *kgpreagg, const kern_data_store *kds,
 						   const kern_data_store *ktoast, const kern_row_map *krowmap,
 						   cl_ushort *partmap, cl_uint *cursor, cl_ulong *records, const gpupreagg_part_ctl *ctl,
@@ -4258,7 +4258,7 @@ gpupreagg_hash_fold_units(kern_gpupreagg *kgpreagg, char *htab, cl_uint claim_li
 }
 
 extern "C" __global__ void
-__launch_bounds__(1024)
+__launch_bounds__(GPUPREAGG_BLOCK)
 gpupreagg_hash_fold_parts(kern_gpupreagg *kgpreagg, char *htab, cl_uint claim_limit,
 						  gpupreagg_part_ctl *ctl, const cl_uint *units, const cl_ulong *records,
 						  cl_uint lds_slots, const cl_uint *todo, cl_uint ntodo, cl_uint *redo, cl_uint sum_turn)

@@ -1593,7 +1593,7 @@ gpupreagg_launch_hashed(strom_task_impl *task, preagg_request req, bool second)
 		if (const char *v = getenv("STROM_GPUPREAGG_HASH_SCATTER_BLOCK"))
 		{
 			int want = atoi(v);
-			if (want == 256 || want == 512 || want == 1024)
+			if ((want == 256 || want == 512 || want == 1024) && (unsigned)want <= block)
 				sblock = (unsigned)want;
 		}
 		if (nparts <= 4 * sblock && stage_fixed < stage_budget && !getenv("STROM_GPUPREAGG_HASH_NO_LDS_SCATTER"))
@@ -1631,14 +1631,15 @@ gpupreagg_launch_hashed(strom_task_impl *task, preagg_request req, bool second)
 		unsigned	fold_grid = ncus * (lds_bytes <= 72 * 1024 ? 2 : 1);
 		/*
 		 * the unit's LDS table leaves room for one work-group per CU: its size in threads is the
-		 * CU's whole occupancy.  256 threads are ONE wave per SIMD -- every record load's latency
-		 * shows; 1024 (what the kernel is bounded at) are four.
+		 * CU's whole occupancy, so the full GPUPREAGG_BLOCK (1024: four waves per SIMD).  Smaller
+		 * work-groups are slower all the way: 256 / 512 / 1024 threads fold 1e8 rows at 1e6 groups
+		 * in 7.0 / 4.1 / 3.2 ms, and the LDS scatter likewise (profiles/r03_hashed_block_sweep.txt).
 		 */
-		unsigned	fold_block = (lds_bytes > 72 * 1024 ? 1024u : block);
+		unsigned	fold_block = block;
 		if (const char *v = getenv("STROM_GPUPREAGG_HASH_FOLD_BLOCK"))
 		{
 			int want = atoi(v);
-			if (want == 256 || want == 512 || want == 1024)
+			if ((want == 256 || want == 512 || want == 1024) && (unsigned)want <= block)
 				fold_block = (unsigned)want;
 		}
 		char	   *d_lists = d_ctl + sizeof(part_ctl) + sizeof(cl_uint) * ((size_t)2 * nparts + (size_t)2 * max_units);
