@@ -1110,7 +1110,10 @@ hash_lds_slots(const strom_gpupreagg *sess, size_t *p_bytes, bool for_units = fa
 	{
 		/* the partition plan's units: no role queues, and as much of the CU's 160 KB as a
 		 * power of two of slots takes */
-		return fit(159 * 1024, p_bytes);
+		size_t	unit_budget = 159 * 1024;
+		if (const char *v = getenv("STROM_GPUPREAGG_HASH_UNIT_LDS_KB"))
+			unit_budget = (size_t)std::max(8L, std::min(159L, atol(v))) * 1024;
+		return fit(unit_budget, p_bytes);
 	}
 	if (const char *v = getenv("STROM_GPUPREAGG_HASH_LDS_SLOTS"))
 	{
@@ -1628,7 +1631,7 @@ gpupreagg_launch_hashed(strom_task_impl *task, preagg_request req, bool second)
 		 */
 		size_t		lds_bytes = 0;				/* (the units' table, not the roles') */
 		cl_uint		lds_slots = hash_lds_slots(sess, &lds_bytes, true);
-		unsigned	fold_grid = ncus * (lds_bytes <= 72 * 1024 ? 2 : 1);
+		unsigned	fold_grid = ncus * (lds_bytes <= 79 * 1024 ? 2 : 1);
 		/*
 		 * the unit's LDS table leaves room for one work-group per CU: its size in threads is the
 		 * CU's whole occupancy, so the full GPUPREAGG_BLOCK (1024: four waves per SIMD).  Smaller
