@@ -138,7 +138,7 @@ STROM_DEVICE cl_ulong hashjoin_key_image(cl_float v)	{ return hashjoin_key_image
 /*
  * text / character(n) hash keys (STROMCL_VARLENA_HASHKEY_TEMPLATE, opencl_hashjoin.h:935-953: the
  * hash runs over VARDATA_ANY / VARSIZE_ANY_EXHDR): the value is the address of the datum, the image
- * a 64-bit FNV-1a of its payload -- equal strings have equal images, NOT the other way round, so a
+ * a 64-bit mix of its payload, eight bytes a step -- equal strings have equal images, NOT the other way round, so a
  * relation with such a key gets the HASH index and every candidate is compared with texteq /
  * bpchareq (codegen_hashjoin.cpp: image_is_exact).  character(n): trailing blanks do not count
  * (bpchar_truelen, opencl_textlib.h:154-166), on either side.
@@ -148,16 +148,23 @@ hashjoin_varlena_image(cl_ulong datum, bool blank_padded)
 {
 	cl_int		len;
 	const cl_uchar *p = strom_varlena_payload(datum, &len);
-	cl_ulong	h = 0xcbf29ce484222325UL;
+	cl_ulong	h = 0xcbf29ce484222325UL ^ (cl_ulong)0;
+	cl_int		i = 0;
 
 	if (blank_padded)
 		while (len > 0 && p[len - 1] == ' ')
 			len--;
-	for (cl_int i = 0; i < len; i++)
+	/* eight bytes a step (strom_load_u64), the tail gathered into one last word */
+	for (; i + 8 <= len; i += 8)
 	{
-		h ^= p[i];
-		h *= 0x100000001b3UL;
+		h = (h ^ strom_load_u64(p + i)) * 0x9e3779b97f4a7c15UL;
+		h ^= h >> 29;
 	}
+	cl_ulong	tail = (cl_ulong)(cl_uint)len << 56;
+	for (int sh = 0; i < len; i++, sh += 8)
+		tail ^= (cl_ulong)p[i] << sh;
+	h = (h ^ tail) * 0xbf58476d1ce4e5b9UL;
+	h ^= h >> 31;
 	return h;
 }
 #endif

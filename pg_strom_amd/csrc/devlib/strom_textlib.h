@@ -106,19 +106,57 @@ strom_varlena_payload(cl_ulong datum, cl_int *p_len)
 STROM_DECLARE_VARLENA_TYPE(text)
 STROM_DECLARE_VARLENA_TYPE(bpcharn)
 
-/* memcmp order, then the shorter one first (text_compare, 288-312) */
+/*
+ * Eight payload bytes in ONE load, whatever their alignment (a datum's payload starts one byte
+ * behind a short header): datums live in global memory -- chunks, the kern_parambuf, hash table
+ * entries -- where gfx950 serves unaligned accesses; said through a packed struct in address space
+ * 1, the compiler issues one global_load_dwordx2 instead of eight byte loads.  Never reads past the
+ * bytes asked for: callers take whole words only while 8 bytes are left.
+ */
+struct __attribute__((packed)) strom_unaligned_u64 { cl_ulong v; };
+STROM_DEVICE cl_ulong
+strom_load_u64(const cl_uchar *p)
+{
+	return ((const __attribute__((address_space(1))) strom_unaligned_u64 *)p)->v;
+}
+
+/* memcmp order, then the shorter one first (text_compare, 288-312); eight bytes at a time: the
+ * first differing word decides, compared most significant byte first */
 STROM_DEVICE cl_int
 strom_bytes_compare(const cl_uchar *s1, cl_int len1, const cl_uchar *s2, cl_int len2)
 {
 	cl_int		len = (len1 < len2 ? len1 : len2);
+	cl_int		i = 0;
 
-	for (cl_int i = 0; i < len; i++)
+	for (; i + 8 <= len; i += 8)
+	{
+		cl_ulong	w1 = strom_load_u64(s1 + i), w2 = strom_load_u64(s2 + i);
+		if (w1 != w2)
+			return (__builtin_bswap64(w1) < __builtin_bswap64(w2) ? -1 : 1);
+	}
+	for (; i < len; i++)
 	{
 		cl_uchar c1 = s1[i], c2 = s2[i];
 		if (c1 != c2)
 			return (c1 < c2 ? -1 : 1);
 	}
 	return (len1 == len2 ? 0 : (len1 > len2 ? 1 : -1));
+}
+
+/* equality alone: strings of different length are different before a byte is read (texteq) */
+STROM_DEVICE bool
+strom_bytes_equal(const cl_uchar *s1, cl_int len1, const cl_uchar *s2, cl_int len2)
+{
+	if (len1 != len2)
+		return false;
+	cl_int		i = 0;
+	for (; i + 8 <= len1; i += 8)
+		if (strom_load_u64(s1 + i) != strom_load_u64(s2 + i))
+			return false;
+	for (; i < len1; i++)
+		if (s1[i] != s2[i])
+			return false;
+	return true;
 }
 
 STROM_DEVICE cl_int
@@ -156,14 +194,36 @@ strom_bpchar_compare(cl_ulong a, cl_ulong b)
 		return result;															\
 	}
 
-STROM_DECLARE_TEXT_COMPARE(bpchareq, bpcharn, strom_bpchar_compare, ==)
-STROM_DECLARE_TEXT_COMPARE(bpcharne, bpcharn, strom_bpchar_compare, !=)
+/* = / <> through the length-first equality */
+STROM_DEVICE cl_int
+strom_text_differs(cl_ulong a, cl_ulong b)
+{
+	cl_int		len1, len2;
+	const cl_uchar *s1 = strom_varlena_payload(a, &len1);
+	const cl_uchar *s2 = strom_varlena_payload(b, &len2);
+	return strom_bytes_equal(s1, len1, s2, len2) ? 0 : 1;
+}
+STROM_DEVICE cl_int
+strom_bpchar_differs(cl_ulong a, cl_ulong b)
+{
+	cl_int		len1, len2;
+	const cl_uchar *s1 = strom_varlena_payload(a, &len1);
+	const cl_uchar *s2 = strom_varlena_payload(b, &len2);
+	while (len1 > 0 && s1[len1 - 1] == ' ')
+		len1--;
+	while (len2 > 0 && s2[len2 - 1] == ' ')
+		len2--;
+	return strom_bytes_equal(s1, len1, s2, len2) ? 0 : 1;
+}
+
+STROM_DECLARE_TEXT_COMPARE(bpchareq, bpcharn, strom_bpchar_differs, ==)
+STROM_DECLARE_TEXT_COMPARE(bpcharne, bpcharn, strom_bpchar_differs, !=)
 STROM_DECLARE_TEXT_COMPARE(bpcharlt, bpcharn, strom_bpchar_compare, <)
 STROM_DECLARE_TEXT_COMPARE(bpcharle, bpcharn, strom_bpchar_compare, <=)
 STROM_DECLARE_TEXT_COMPARE(bpchargt, bpcharn, strom_bpchar_compare, >)
 STROM_DECLARE_TEXT_COMPARE(bpcharge, bpcharn, strom_bpchar_compare, >=)
-STROM_DECLARE_TEXT_COMPARE(texteq,   text, strom_text_compare, ==)
-STROM_DECLARE_TEXT_COMPARE(textne,   text, strom_text_compare, !=)
+STROM_DECLARE_TEXT_COMPARE(texteq,   text, strom_text_differs, ==)
+STROM_DECLARE_TEXT_COMPARE(textne,   text, strom_text_differs, !=)
 STROM_DECLARE_TEXT_COMPARE(text_lt,  text, strom_text_compare, <)
 STROM_DECLARE_TEXT_COMPARE(text_le,  text, strom_text_compare, <=)
 STROM_DECLARE_TEXT_COMPARE(text_gt,  text, strom_text_compare, >)
