@@ -519,7 +519,18 @@ gpuhashjoin_main_body(kern_hashjoin *__restrict__ khashjoin,
 	kern_resultbuf *kresults = KERN_HASHJOIN_RESULTBUF(khashjoin);
 	bool		use_map = (krowmap != NULL && krowmap->nvalids >= 0);
 	cl_uint		nrows = (use_map ? (cl_uint)krowmap->nvalids : kds->nitems);
-	cl_uint		tile_rows = HASHJOIN_BLOCK * HASHJOIN_GENERIC_ROWS;
+	/*
+	 * rows per thread and tile: up to HASHJOIN_GENERIC_ROWS, but no more than it takes to give every
+	 * work-group of the launch a tile -- a thread walks its rows one after the other through chains
+	 * of dependent loads (row -> slot -> entry -> tuple), so a small chunk cut into few large tiles
+	 * is a few work-groups waiting out memory latency while the rest of the chip is idle (a 325 k-row
+	 * chunk is 20 tiles of 16384 rows; a 4e6-row text-key join ran at 1.4 ms in 244 tiles).  The host
+	 * launches min(rows / 256, what the chip holds) work-groups; this is the inverse.
+	 */
+	cl_uint		rows_this = (cl_uint)(((cl_ulong)nrows + (cl_ulong)gridDim.x * HASHJOIN_BLOCK - 1) /
+									  ((cl_ulong)gridDim.x * HASHJOIN_BLOCK));
+	rows_this = (rows_this < 1 ? 1 : rows_this > HASHJOIN_GENERIC_ROWS ? HASHJOIN_GENERIC_ROWS : rows_this);
+	cl_uint		tile_rows = HASHJOIN_BLOCK * rows_this;
 	cl_uint		ntiles = (nrows + tile_rows - 1) / tile_rows;
 	cl_uint		nrels = kresults->nrels;
 	cl_int		chunk_error = StromError_Success;
@@ -576,6 +587,8 @@ gpuhashjoin_main_body(kern_hashjoin *__restrict__ khashjoin,
 			for (int jj = 0; jj < HASHJOIN_SLICE_ROWS; jj++)
 			{
 				int		j = s * HASHJOIN_SLICE_ROWS + jj;
+				if ((cl_uint)j >= rows_this)
+					break;					/* (uniform) */
 				cl_uint	r = tile * tile_rows + j * HASHJOIN_BLOCK + threadIdx.x;
 				if (r < nrows)
 				{

@@ -498,9 +498,11 @@ gpuhashjoin_launch(strom_task_impl *task, hashjoin_request req)
 		int		lds_quads = 8;									/* HASHJOIN_LDS_QUADS */
 		if (const char *v = getenv("STROM_HASHJOIN_LDS_QUADS"))
 			lds_quads = std::max(1, atoi(v));
+		/* (the general kernel sizes its tiles from the grid: one row per thread is the smallest) */
 		size_t	tile_rows = lds_slot_bytes ? (size_t)block * 4 * lds_quads
-			: fast ? (size_t)block * 4 * 2 : (size_t)block * generic_rows;
+			: fast ? (size_t)block * 4 * 2 : (size_t)block;
 		size_t	ntiles = (req.nrows + tile_rows - 1) / tile_rows;
+		(void)generic_rows;
 		int		per_cu = 0;
 		if (hipModuleOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, block, lds_slot_bytes) != hipSuccess ||
 			per_cu < 1)
