@@ -202,8 +202,11 @@ def c5_chunk_device(nrows, seed, decimal=True):
     ref = dict(count=cnt.cpu().tolist(), sum_qty=exact_sums(qty), sum_base_price=exact_sums(prc),
                sum_disc_price=exact_sums(disc_price), sum_charge=exact_sums(disc_price * (100 + tax)),
                sum_discount=exact_sums(dsc))
+    # zone maps as the device ingest leaves them (ingest_minmax): integer-like columns -- the keys,
+    # the date, decimal columns (int8 at their scale) -- have one, 64-bit numeric images do not
+    zmaps = [_minmax(rf), _minmax(ls)] + [(_minmax(c) if decimal else None) for c in cols[2:]] + [_minmax(ship)]
     ds = runtime.DeviceStore.from_torch_columns(["char1", "char1", ntype, ntype, ntype, ntype, "date"],
-                                                cols + [ship])
+                                                cols + [ship], zmaps)
     return ds, ref
 
 

@@ -645,7 +645,9 @@ strom_kds_column_head(int ncols, const strom_column_input *cols, uint32_t nrows,
 		cd[i].values_off = (cl_uint)voff[i];
 		if (values_off)
 			values_off[i] = (uint32_t)voff[i];
-		if (minmax && cols[i].type_oid != 0 && nrows > 0)
+		/* (min > max, as integers: "no zone map for this column" -- e.g. 64-bit numeric images,
+		 * whose bit patterns do not order like their values) */
+		if (minmax && cols[i].type_oid != 0 && nrows > 0 && (isfloat || minmax[2 * i] <= minmax[2 * i + 1]))
 		{
 			cd[i].stat_flags = KDS_COLSTAT_MINMAX | (isfloat ? KDS_COLSTAT_ISFLOAT : 0);
 			cd[i].minval = minmax[2 * i];

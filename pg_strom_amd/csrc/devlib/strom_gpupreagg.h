@@ -507,8 +507,9 @@ gpupreagg_sum_magnitude(cl_long v)
  */
 #define KERN_GPUPREAGG_SUM_MAGBITS(kgp)		((cl_uint *)((kgp)->__padding))
 #define KERN_GPUPREAGG_WG_ROWS(kgp)			(*(const cl_uint *)((kgp)->__padding + 4) & 0x7fffffffu)
-/* top bit of that word: the host has bounded the sums of PLAIN columns (GPUPREAGG_SUMBITS_<a> 65)
- * by the chunk's zone maps -- the fold need not measure them */
+/* top bit of that word: the host has bounded the sums of PLAIN columns (GPUPREAGG_SUMBITS_<a> 65) and
+ * of expressions over decimal columns (66: GPUPREAGG_SUMBOUND_<a>, a formula over the columns' zone
+ * maps from the code generator) by the chunk's zone maps -- the fold need not measure them */
 #define KERN_GPUPREAGG_ZONE_BOUNDED(kgp)	((*(const cl_uint *)((kgp)->__padding + 4) >> 31) != 0)
 /*
  * per-launch facts the row functions take as one word:
@@ -524,7 +525,8 @@ gpupreagg_sum_magnitude(cl_long v)
 #define GPUPREAGG_COUNTALL_FIRST	(-1)
 #endif
 #define GPUPREAGG_MEASURE_SUM(aidx, rowflags)	\
-	(GPUPREAGG_SUMBITS_##aidx == 64 || (GPUPREAGG_SUMBITS_##aidx == 65 && !((rowflags) & ROWFLAG_ZONE_BOUNDED)))
+	(GPUPREAGG_SUMBITS_##aidx == 64 ||		\
+	 ((GPUPREAGG_SUMBITS_##aidx == 65 || GPUPREAGG_SUMBITS_##aidx == 66) && !((rowflags) & ROWFLAG_ZONE_BOUNDED)))
 #define GPUPREAGG_COUNT_IS_ALIASED(aidx, rowflags)	\
 	(GPUPREAGG_COUNTALL_##aidx && (aidx) != GPUPREAGG_COUNTALL_FIRST && ((rowflags) & ROWFLAG_ALL_NOTNULL))
 #define KERN_GPUPREAGG_FOLD_NROWS(kgp)		((cl_uint)(kgp)->sortbuf_len)

@@ -113,6 +113,7 @@ struct strom_gpupreagg {
 	 * with GPUPREAGG_CHECKED that folds a chunk whose range proof failed
 	 */
 	std::vector<int>	sumbits;
+	std::vector<std::string> sumbound;	/* sumbits 66: the code generator's bound formula (eval_sum_bound) */
 	cl_uint				static_magbits = 0;		/* the largest static bound, in bits */
 	bool				sums_measured = false;	/* an integer sum without a static bound */
 	std::vector<int>	intsum_of;			/* aggregate -> index among the integer sums, or -1 */
@@ -595,6 +596,79 @@ zone_magbits(const kern_coldir &cd)
 }
 
 /*
+ * bits of the largest magnitude a summed EXPRESSION can take in this chunk: the code generator's
+ * formula (codegen_preagg.cpp: sum_bound_formula -- reverse Polish over magnitudes: cN column N's
+ * zone map, kV a constant, + and *, eK a rescale by 10^K) over the chunk's zone maps.  -1: a column
+ * without a zone map, or a malformed formula -- the fold measures the rows then.
+ */
+int
+eval_sum_bound(const std::string &formula, const kern_coldir *cd, cl_uint ncd)
+{
+	std::vector<unsigned __int128> st;
+	const unsigned __int128 CAP = (unsigned __int128)1 << 100;		/* saturate well above 2^64 */
+	const char *p = formula.c_str();
+	while (*p)
+	{
+		while (*p == ' ')
+			p++;
+		if (!*p)
+			break;
+		char	op = *p++;
+		if (op == 'c' || op == 'k' || op == 'e')
+		{
+			char   *end;
+			unsigned long long v = strtoull(p, &end, 10);
+			if (end == p)
+				return -1;
+			p = end;
+			if (op == 'c')
+			{
+				if (v < 1 || v > ncd)
+					return -1;
+				const kern_coldir &c = cd[v - 1];
+				if (!(c.stat_flags & KDS_COLSTAT_MINMAX) || (c.stat_flags & KDS_COLSTAT_ISFLOAT) || c.maxval < c.minval)
+					return -1;
+				cl_ulong lo = (cl_ulong)(c.minval < 0 ? -(unsigned __int128)c.minval : (unsigned __int128)c.minval);
+				cl_ulong hi = (cl_ulong)(c.maxval < 0 ? -(unsigned __int128)c.maxval : (unsigned __int128)c.maxval);
+				st.push_back(std::max(lo, hi));
+			}
+			else if (op == 'k')
+				st.push_back(v);
+			else
+			{
+				if (st.empty() || v > 38)
+					return -1;
+				for (unsigned long long i = 0; i < v && st.back() < CAP; i++)
+					st.back() *= 10;
+			}
+		}
+		else if (op == '+' || op == '*')
+		{
+			if (st.size() < 2)
+				return -1;
+			unsigned __int128 b = st.back();
+			st.pop_back();
+			unsigned __int128 a = st.back();
+			a = std::min(a, CAP);
+			b = std::min(b, CAP);
+			st.back() = (op == '+' ? a + b : (a == 0 || b == 0) ? 0 : (a > CAP / b ? CAP : a * b));
+		}
+		else
+			return -1;
+	}
+	if (st.size() != 1)
+		return -1;
+	unsigned __int128 v = st.back();
+	int		bits = 0;
+	while (v != 0 && bits < 127)
+	{
+		v >>= 1;
+		bits++;
+	}
+	return bits;
+}
+
+/*
  * join-as-a-lookup: the session's source built FOR a column mapping -- which virtual column is an
  * inner one, the slot records' length and form, the key's width become compile-time constants
  * (strom_gpupreagg.h: gpupreagg_dense_lookup_body says what that is worth), and only the lookup
@@ -808,6 +882,19 @@ gpupreagg_launch(strom_task_impl *task, preagg_request req, bool checked = false
 			cl_uint		zbits = 0;
 			for (size_t a = 0; all && a < sess->agg_resno.size(); a++)
 			{
+				if (sess->sumbits[a] == 66)
+				{
+					/* an expression over decimal columns: the code generator's formula */
+					int		bits = (cd ? eval_sum_bound(sess->sumbound[a], cd, ncd) : -1);
+					if (bits < 0 || bits > 63)
+						all = false;			/* (no zone map -- or a bound beyond int8: measured, then checked) */
+					else
+					{
+						zbits = std::max(zbits, (cl_uint)bits);
+						any = true;
+					}
+					continue;
+				}
 				if (sess->sumbits[a] != 65)
 					continue;
 				int		col = (a < sess->pack_attno.size() ? sess->pack_attno[a] - 1 : -1);
@@ -1999,6 +2086,18 @@ gpupreagg_session_new(strom_devprog_key key,
 				return nullptr;
 			}
 			sess->sumbits.push_back(bits);
+			{
+				std::string	formula;
+				snprintf(name, sizeof(name), "#define GPUPREAGG_SUMBOUND_%zu \"", a);
+				const char *fdef = strstr(src, name);
+				if (fdef)
+				{
+					const char *q = strchr(fdef + strlen(name), '"');
+					if (q)
+						formula.assign(fdef + strlen(name), q);
+				}
+				sess->sumbound.push_back(formula);
+			}
 			sess->intsum_of.push_back(intsum ? sess->nintsums++ : -1);
 			if (bits >= 1 && bits <= 63)
 				sess->static_magbits = std::max(sess->static_magbits, (cl_uint)bits);

@@ -137,7 +137,7 @@ def column_head(sqltypes, nrows, minmax=None):
     """head of a NULL-free KDS_FORMAT_COLUMN chunk whose column arrays are filled
     elsewhere (strom_kds_column_head): returns (head uint8 array, chunk length,
     values_off per column).  minmax: [(min, max)] per column -- ints, or floats for
-    float4/float8 columns -- or None for "no zone maps"."""
+    float4/float8 columns; None for a column without one -- or None for "no zone maps"."""
     ncols = len(sqltypes)
     arr = (strom_column_input * ncols)()
     for i, t in enumerate(sqltypes):
@@ -146,7 +146,11 @@ def column_head(sqltypes, nrows, minmax=None):
     mm = None
     if minmax is not None:
         mm = np.zeros(2 * ncols, dtype=np.int64)
-        for i, (t, (lo, hi)) in enumerate(zip(sqltypes, minmax)):
+        for i, (t, lohi) in enumerate(zip(sqltypes, minmax)):
+            if lohi is None:
+                mm[2 * i:2 * i + 2] = [1, 0]            # min > max: no zone map for this column
+                continue
+            lo, hi = lohi
             if SQL_TYPES[t][0] in (700, 701):
                 mm[2 * i:2 * i + 2] = np.array([lo, hi], dtype=np.float64).view(np.int64)
             else:

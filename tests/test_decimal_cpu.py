@@ -23,6 +23,14 @@ def test_codegen_types_a_decimal_column_as_fixed_point():
     assert "pg_fixed_cached" not in cgd.source and "pgfn_numeric_as_fixed" not in cgd.source
     assert "pg_fixed_from_decimal(KV.KVAR_3)" in cgd.source
     assert [t for _, t in cgn.targets] == [t for _, t in cgd.targets]       # same partial-row types
+    # sums of expressions over decimal columns carry a bound formula over the columns' zone maps
+    # (the host evaluates it per chunk; the fold then does not measure the rows' magnitudes)
+    q1 = ("(gpupreagg (key (var 1 char1)) (psum (numeric_mul (var 4 decimal 2) (numeric_sub (const numeric 1) (var 5 decimal 2))) 4)"
+          " (psum (numeric_add (var 4 decimal 2) (const numeric 0.5)) 3) (psum (numeric_mul (var 4 decimal 2) (param 0 numeric)) 4))")
+    src = codegen_gpupreagg(q1).source
+    assert '#define GPUPREAGG_SUMBITS_0 66' in src and '#define GPUPREAGG_SUMBOUND_0 " c4 k1 e2 c5 + * "' in src
+    assert '#define GPUPREAGG_SUMBOUND_1 " c4 k05 e1 + e1 "' in src          # 0.5 is 05 at scale 1; the sum at scale 2 -> 3
+    assert '#define GPUPREAGG_SUMBITS_2 64' in src and 'GPUPREAGG_SUMBOUND_2' not in src    # a parameter: measured
     with pytest.raises(ValueError):
         runtime.codegen_gpuscan("(numeric_lt (var 1 decimal) (const numeric 1))")       # the scale is not optional
 
