@@ -204,7 +204,13 @@ def c5_chunk_device(nrows, seed, decimal=True):
                sum_discount=exact_sums(dsc))
     # zone maps as the device ingest leaves them (ingest_minmax): integer-like columns -- the keys,
     # the date, decimal columns (int8 at their scale) -- have one, 64-bit numeric images do not
-    zmaps = [_minmax(rf), _minmax(ls)] + [(_minmax(c) if decimal else None) for c in cols[2:]] + [_minmax(ship)]
+    # (... but bounds of their values' integer parts, outward: KDS_COLSTAT_INTPART)
+    def intpart(t, scale):
+        lo, hi = _minmax(t)
+        return (lo // 10**scale, -((-hi) // 10**scale))
+    zmaps = [_minmax(rf), _minmax(ls)] + \
+        ([_minmax(c) for c in cols[2:]] if decimal else [intpart(qty, 0), intpart(prc, 2), intpart(dsc, 2), intpart(tax, 2)]) + \
+        [_minmax(ship)]
     ds = runtime.DeviceStore.from_torch_columns(["char1", "char1", ntype, ntype, ntype, ntype, "date"],
                                                 cols + [ship], zmaps)
     return ds, ref

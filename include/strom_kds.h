@@ -222,6 +222,11 @@ typedef struct {
 #define KDS_COLUMN_ALIGN		256
 #define KDS_COLSTAT_MINMAX		0x0001
 #define KDS_COLSTAT_ISFLOAT		0x0002
+/* a column of 64-bit NUMERIC images (their bit patterns do not order like their values): minval /
+ * maxval bound the VALUES, rounded outward to integers -- floor(min), ceil(max) -- so that
+ * |value| <= max(|minval|, |maxval|).  What GpuPreAgg needs to bound a sum over the column without
+ * looking at the rows.  Set instead of KDS_COLSTAT_MINMAX, never with it. */
+#define KDS_COLSTAT_INTPART		0x0004
 
 typedef struct {
 	cl_uint			values_off;

@@ -119,6 +119,7 @@ fn_header(const char *rettype, const char *name, int idx)
  * evaluates with the chunk's zone maps (so that the fold need not measure every row's magnitude --
  * 7 VALU instructions per row and sum in Q1's kernels): reverse Polish over magnitudes,
  *   cN   largest |value| of column N's stored integers (zone map)
+ *   nN   the same for a column of 64-bit numeric images: its integer-part bounds (KDS_COLSTAT_INTPART)
  *   kV   the constant V
  *   +    |a +- b| <= |a| + |b|        *    |a b| <= |a| |b|        eK   times 10^K (a rescale)
  * Returns the expression's scale, or -1 when something in it has no such bound (a parameter, a
@@ -139,6 +140,23 @@ sum_bound_formula(const sexpr &x, std::string &rpn)
 			return -1;
 		snprintf(tmp, sizeof(tmp), " c%d", attno);
 		rpn += tmp;
+		return scale;
+	}
+	if (head == "var" && x.items.size() == 4 && !x.items[1].is_list && !x.items[2].is_list &&
+		x.items[2].atom == "numeric" && !x.items[3].is_list)
+	{
+		/* a 64-bit numeric image read as fixed point at its typmod scale: its zone map bounds the
+		 * value's integer part, outward (KDS_COLSTAT_INTPART) */
+		int attno = atoi(x.items[1].atom.c_str()), scale = atoi(x.items[3].atom.c_str());
+		if (attno < 1 || scale < 0 || scale > 18)
+			return -1;
+		snprintf(tmp, sizeof(tmp), " n%d", attno);
+		rpn += tmp;
+		if (scale > 0)
+		{
+			snprintf(tmp, sizeof(tmp), " e%d", scale);
+			rpn += tmp;
+		}
 		return scale;
 	}
 	if (head == "const" && x.items.size() == 3 && !x.items[1].is_list && x.items[1].atom == "numeric" &&

@@ -356,6 +356,33 @@ column_layout(int ncols, const strom_column_input *cols, uint32_t nrooms,
 	return off;
 }
 
+/* a 64-bit numeric image's value rounded away from zero to an integer (KDS_COLSTAT_INTPART);
+ * false when that does not fit int64 */
+bool
+numeric_image_outward(uint64_t image, int64_t *p_out)
+{
+	int			expo = (int)((int64_t)image >> 58);
+	bool		sign = ((image >> 57) & 1) != 0;
+	unsigned __int128 m = image & ((1ULL << 57) - 1);
+
+	if (expo >= 0)
+	{
+		for (int i = 0; i < expo && m < ((unsigned __int128)1 << 64); i++)
+			m *= 10;
+	}
+	else
+	{
+		unsigned __int128 d = 1;
+		for (int i = 0; i < -expo && d < ((unsigned __int128)1 << 64); i++)
+			d *= 10;
+		m = (m + d - 1) / d;
+	}
+	if (m > (unsigned __int128)INT64_MAX)
+		return false;
+	*p_out = (sign ? -(int64_t)m : (int64_t)m);
+	return true;
+}
+
 void
 column_minmax(const strom_column_input &c, uint32_t nrows, kern_coldir *cd)
 {
@@ -365,6 +392,33 @@ column_minmax(const strom_column_input &c, uint32_t nrows, kern_coldir *cd)
 	cd->stat_flags = 0;
 	if (c.type_oid == 0)
 		return;				/* type unknown (converted chunk): no zone map */
+	if (c.type_oid == STROM_NUMERICOID)
+	{
+		/* 64-bit images: bounds of the values' integer parts, outward (strom_kds.h) */
+		int64_t	lo = 0, hi = 0;
+		if (c.attlen != 8)
+			return;
+		for (uint32_t r = 0; r < nrows; r++)
+		{
+			if (is_null(c, r))
+				continue;
+			uint64_t	image;
+			int64_t		v;
+			memcpy(&image, (const char *)c.values + 8 * (size_t)r, 8);
+			if (!numeric_image_outward(image, &v))
+				return;			/* a value beyond int64: no bound to give */
+			if (!any || v < lo) lo = v;
+			if (!any || v > hi) hi = v;
+			any = true;
+		}
+		if (any)
+		{
+			cd->stat_flags = KDS_COLSTAT_INTPART;
+			cd->minval = lo;
+			cd->maxval = hi;
+		}
+		return;
+	}
 	int64_t	imin = 0, imax = 0;
 	double	fmin = 0, fmax = 0;
 
@@ -649,7 +703,9 @@ strom_kds_column_head(int ncols, const strom_column_input *cols, uint32_t nrows,
 		 * whose bit patterns do not order like their values) */
 		if (minmax && cols[i].type_oid != 0 && nrows > 0 && (isfloat || minmax[2 * i] <= minmax[2 * i + 1]))
 		{
-			cd[i].stat_flags = KDS_COLSTAT_MINMAX | (isfloat ? KDS_COLSTAT_ISFLOAT : 0);
+			/* (a numeric column: the caller's bounds are of the values' integer parts, outward) */
+			cd[i].stat_flags = (cols[i].type_oid == STROM_NUMERICOID ? KDS_COLSTAT_INTPART
+								: KDS_COLSTAT_MINMAX | (isfloat ? KDS_COLSTAT_ISFLOAT : 0));
 			cd[i].minval = minmax[2 * i];
 			cd[i].maxval = minmax[2 * i + 1];
 		}

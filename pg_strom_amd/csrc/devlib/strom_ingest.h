@@ -294,7 +294,7 @@ ingest_minmax(kern_data_store *dst, const cl_int *type_oids)
 	cl_int		oid = (type_oids ? type_oids[c] : 0);
 	int			attlen = dst->colmeta[c].attlen;
 
-	if (oid == 0 || oid == STROM_NUMERICOID || !(attlen == 1 || attlen == 2 || attlen == 4 || attlen == 8))
+	if (oid == 0 || !(attlen == 1 || attlen == 2 || attlen == 4 || attlen == 8))
 		return;
 	bool		isflt = (oid == STROM_FLOAT4OID || oid == STROM_FLOAT8OID);
 	const char *values = (const char *)dst + coldir[c].values_off;
@@ -308,6 +308,54 @@ ingest_minmax(kern_data_store *dst, const cl_int *type_oids)
 		s_max = 0UL;
 	}
 	__syncthreads();
+	if (oid == STROM_NUMERICOID)
+	{
+		/*
+		 * 64-bit numeric images: the bounds are of the VALUES' integer parts, rounded outward
+		 * (KDS_COLSTAT_INTPART, strom_kds.h) -- the images' own bit patterns do not order like the
+		 * values.  A value beyond int64 spoils the column's bounds (the full range: dropped by
+		 * ingest_finish).
+		 */
+		if (attlen != 8)
+			return;
+		for (cl_uint row = blockIdx.x * blockDim.x + threadIdx.x; row < nitems; row += gridDim.x * blockDim.x)
+		{
+			if (notnull && !((notnull[row >> 5] >> (row & 31)) & 1))
+				continue;
+			cl_ulong	image = ((const cl_ulong *)values)[row];
+			cl_int		expo = (cl_int)((cl_long)image >> 58);
+			bool		sign = ((image >> 57) & 1) != 0;
+			cl_ulong	m = image & ((1UL << 57) - 1);
+			bool		fits = true;
+			if (expo >= 0)
+			{
+				for (cl_int i = 0; i < expo && fits; i++)
+				{
+					fits = (m <= 0x7fffffffffffffffUL / 10);
+					m *= 10;
+				}
+			}
+			else
+			{
+				cl_ulong	d = 1;
+				cl_int		i = 0;
+				for (; i < -expo && d <= 0xffffffffffffffffUL / 10; i++)
+					d *= 10;
+				m = (i < -expo ? (m != 0 ? 1UL : 0UL) : (m / d + (m % d != 0 ? 1UL : 0UL)));
+			}
+			if (!fits || m > 0x7fffffffffffffffUL)
+			{
+				mn = 0UL;
+				mx = ~0UL;
+				continue;
+			}
+			cl_ulong	key = (cl_ulong)(sign ? -(cl_long)m : (cl_long)m) ^ 0x8000000000000000UL;
+			mn = (key < mn ? key : mn);
+			mx = (key > mx ? key : mx);
+		}
+	}
+	else
+	{
 	/*
 	 * 16 bytes per lane and load (the value arrays are 256-byte aligned), four loads in flight,
 	 * ONE work-group per CU and column: the pass ends in an atomic min / max pair per work-group
@@ -395,6 +443,7 @@ ingest_minmax(kern_data_store *dst, const cl_int *type_oids)
 		}
 		fold(v, row);
 	}
+	}	/* (integer-like and float columns) */
 #pragma unroll
 	for (int m = 32; m > 0; m >>= 1)
 	{
@@ -440,10 +489,16 @@ ingest_finish(kern_data_store *dst, const cl_int *type_oids, const cl_uint *col_
 		cl_ulong	mn = (cl_ulong)coldir[c].minval;
 		cl_ulong	mx = (cl_ulong)coldir[c].maxval;
 
-		if (oid == 0 || oid == STROM_NUMERICOID || mn > mx)
+		if (oid == 0 || mn > mx || (oid == STROM_NUMERICOID && mn == 0UL && mx == ~0UL))
 		{
 			coldir[c].stat_flags = 0;
 			coldir[c].minval = coldir[c].maxval = 0;
+		}
+		else if (oid == STROM_NUMERICOID)
+		{
+			coldir[c].stat_flags = KDS_COLSTAT_INTPART;
+			coldir[c].minval = (cl_long)(mn ^ 0x8000000000000000UL);
+			coldir[c].maxval = (cl_long)(mx ^ 0x8000000000000000UL);
 		}
 		else if (isflt)
 		{

@@ -598,7 +598,8 @@ zone_magbits(const kern_coldir &cd)
 /*
  * bits of the largest magnitude a summed EXPRESSION can take in this chunk: the code generator's
  * formula (codegen_preagg.cpp: sum_bound_formula -- reverse Polish over magnitudes: cN column N's
- * zone map, kV a constant, + and *, eK a rescale by 10^K) over the chunk's zone maps.  -1: a column
+ * zone map, nN a numeric image column's integer-part bounds, kV a constant, + and *, eK a rescale by
+ * 10^K) over the chunk's zone maps.  -1: a column
  * without a zone map, or a malformed formula -- the fold measures the rows then.
  */
 int
@@ -614,19 +615,23 @@ eval_sum_bound(const std::string &formula, const kern_coldir *cd, cl_uint ncd)
 		if (!*p)
 			break;
 		char	op = *p++;
-		if (op == 'c' || op == 'k' || op == 'e')
+		if (op == 'c' || op == 'k' || op == 'e' || op == 'n')
 		{
 			char   *end;
 			unsigned long long v = strtoull(p, &end, 10);
 			if (end == p)
 				return -1;
 			p = end;
-			if (op == 'c')
+			if (op == 'c' || op == 'n')
 			{
 				if (v < 1 || v > ncd)
 					return -1;
 				const kern_coldir &c = cd[v - 1];
-				if (!(c.stat_flags & KDS_COLSTAT_MINMAX) || (c.stat_flags & KDS_COLSTAT_ISFLOAT) || c.maxval < c.minval)
+				/* (cN: an integer-like column's zone map; nN: a numeric image column's integer-part bounds) */
+				if (op == 'c' ? (!(c.stat_flags & KDS_COLSTAT_MINMAX) || (c.stat_flags & KDS_COLSTAT_ISFLOAT))
+					: !(c.stat_flags & KDS_COLSTAT_INTPART))
+					return -1;
+				if (c.maxval < c.minval)
 					return -1;
 				cl_ulong lo = (cl_ulong)(c.minval < 0 ? -(unsigned __int128)c.minval : (unsigned __int128)c.minval);
 				cl_ulong hi = (cl_ulong)(c.maxval < 0 ? -(unsigned __int128)c.maxval : (unsigned __int128)c.maxval);

@@ -285,3 +285,22 @@ def test_identity_casts_of_the_catalog():
     for spec, col in (("(date (var 1 date))", d), ("(time (var 2 time))", t), ("(timestamp (var 3 timestamp))", t * 1000)):
         oid, v, isn, err = oracle.eval_rows(spec, buf)
         assert not err.any() and list(v.view(np.int64)[:3]) == [int(x) for x in col]
+
+
+def test_numeric_image_columns_carry_integer_part_bounds():
+    """KDS_COLSTAT_INTPART (include/strom_kds.h): a COLUMN chunk's numeric image column has no
+    zone map of its bit patterns -- they do not order like the values -- but bounds of the values'
+    integer parts, rounded outward; a value beyond int64 leaves the column without any"""
+    import math
+    vals = [Decimal("104949.50"), Decimal("-0.07"), Decimal("0"), Decimal("12345678.999"), Decimal("-99.01"), Decimal("3e10")]
+    nul = np.array([0, 0, 0, 0, 0, 0], dtype=bool)
+    buf = kds.build_kds("column", [kds.numeric_column(vals, nul), kds.Column("int4", np.arange(6, dtype=np.int32))])
+    cd = kds.decode_column_chunk(buf)
+    assert cd[0]["stat_flags"] == 4 and (cd[0]["minval"], cd[0]["maxval"]) == (-100, 30000000000)
+    assert cd[1]["stat_flags"] == 1 and (cd[1]["minval"], cd[1]["maxval"]) == (0, 5)
+    assert all(cd[0]["minval"] <= math.floor(v) and math.ceil(v) <= cd[0]["maxval"] for v in vals)
+    nul[5] = True                                   # NULLs do not count
+    cd = kds.decode_column_chunk(kds.build_kds("column", [kds.numeric_column(vals, nul)]))
+    assert (cd[0]["stat_flags"], cd[0]["minval"], cd[0]["maxval"]) == (4, -100, 12345679)
+    big = kds.decode_column_chunk(kds.build_kds("column", [kds.numeric_column([Decimal("1e25"), Decimal("1")])]))
+    assert big[0]["stat_flags"] == 0

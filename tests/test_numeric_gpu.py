@@ -230,6 +230,16 @@ def test_varlena_numerics_in_heap_tuples(fmt):
     assert np.array_equal(dec[1]["notnull"], ~isnull)
     assert np.array_equal(dec[1]["values"].view(np.uint64)[~isnull], imgs[~isnull])
     assert not dec[1]["values"][isnull].any()
+    # ... and leaves bounds of the values' integer parts, outward (KDS_COLSTAT_INTPART): what lets
+    # GpuPreAgg bound a sum over the column without measuring the rows
+    import math
+    live = [vals[i] for i in range(n) if not isnull[i]]
+    assert dec[1]["stat_flags"] == 4
+    assert dec[1]["minval"] == min(math.floor(v) for v in live) and dec[1]["maxval"] == max(math.ceil(v) for v in live)
+    # the host builder states the same for the same column
+    host = kds.decode_column_chunk(kds.build_kds("column", [kds.Column("int4", g), kds.Column("numeric", imgs, isnull),
+                                                             kds.Column("int4", np.arange(n, dtype=np.int32))]))
+    assert (host[1]["stat_flags"], host[1]["minval"], host[1]["maxval"]) == (4, dec[1]["minval"], dec[1]["maxval"])
 
 
 @pytest.mark.parametrize("ftype,dig", [("float8", 15), ("float4", 6)])
