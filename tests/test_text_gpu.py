@@ -332,3 +332,48 @@ def test_text_and_character_hash_keys(ofmt):
                                 " (qual (text_ge (var 1 text) (ivar 1 1 text)))))", outer, [inner], [[2, 3]],
                                 expect_mode="hash")
     assert res.nitems > 0
+
+
+def test_text_key_taken_from_an_inner_relation_in_a_two_level_join():
+    """fact -> dim1 on int4, dim1.name -> dim2 on text: the second relation's key is a text column
+    of the FIRST inner relation's tuple (an address inside its hash entry), its image hashed on the
+    device, the candidates compared with texteq"""
+    rng = np.random.default_rng(17)
+    n, n1 = 30000, 500
+    names = [b"region-%03d" % (i % 37) for i in range(n1)]
+    nnull = np.arange(n1) % 29 == 3
+    dim1 = kds.build_kds("row", [kds.Column("int4", np.arange(n1, dtype=np.int32)), kds.Column("text", names, nnull)])
+    words = [b"region-%03d" % i for i in range(0, 40, 2)] + [b"region-%03d" % 4]      # even regions, one twice
+    dim2 = kds.build_kds("row_flat", [kds.Column("text", words), kds.Column("int4", np.arange(len(words), dtype=np.int32))])
+    fk = rng.integers(-5, n1 + 20, n).astype(np.int32)
+    outer = kds.build_kds("column", [kds.Column("int4", fk), kds.Column("int8", np.arange(n, dtype=np.int64))])
+    spec = "(gpuhashjoin (rel (hashkey (var 1 int4) 1 int4)) (rel (hashkey (ivar 1 2 text) 1 text)))"
+    res, info = run_and_compare(spec, outer, [dim1, dim2], [[1], [1]])
+    assert info[1]["mode"] == "hash"
+    cnt = {}
+    for w in words:
+        cnt[w] = cnt.get(w, 0) + 1
+    want = sum(cnt.get(names[k], 0) for k in fk if 0 <= k < n1 and not nnull[k])
+    assert res.nitems == want > 0
+
+
+def test_text_qual_behind_a_row_map_in_the_hashed_group_by():
+    """hashed GROUP BY (float key) over a COLUMN chunk with a text qual, behind a row map: the
+    one-role walk turns the text column's offsets into addresses for the mapped rows only"""
+    n = 60000
+    rng = np.random.default_rng(23)
+    W = text_cases.WORDS
+    txt = [W[i] for i in rng.integers(0, len(W), n)]
+    f = rng.integers(0, 300, n).astype(np.float64) / 4
+    x = rng.integers(-1000, 1000, n).astype(np.int32)
+    buf = kds.build_kds("column", [kds.Column("float8", f), kds.Column("text", txt, rng.random(n) < 0.04), kds.Column("int4", x)])
+    rm = np.sort(rng.choice(n, n // 2, replace=False)).astype(np.int32)
+    spec = ("(gpupreagg (qual (text_ge (var 2 text) (const text 'b'))) (key (var 1 float8)) (nrows)"
+            " (psum (int8 (var 3 int4))) (pmin (var 3 int4)))")
+    from test_gpupreagg_gpu import assert_matches_oracle
+    agg = GpuPreAgg(spec).begin_hashed()
+    try:
+        assert agg.fold(buf, row_map=rm)[0] == 0
+        assert_matches_oracle(spec, agg, [buf], agg.fetch(), row_maps=[rm])
+    finally:
+        agg.end()
