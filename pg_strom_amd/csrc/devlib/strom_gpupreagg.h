@@ -3463,11 +3463,20 @@ struct gpupreagg_part_ctl {
 	cl_uint		nrecords;
 	cl_uint		deferred;			/* by the claim pass */
 	cl_uint		max_units;
-	cl_uint		reclen;				/* checked by the host */
+	cl_uint		reclen;				/* the host's record length (it sized the buffer): checked by the kernels */
 };
 
+/* the scatter and the fold: do host and device mean the same record?  (a mismatch would write
+ * past the buffer) */
+#define GPUPREAGG_PART_RECLEN_OK(kgpreagg, ctl)												\
+	((ctl)->reclen == 8 * GPUPREAGG_REC_WORDS ||												\
+	 (atomicMax(&(kgpreagg)->status, (cl_int)StromError_DataStoreCorruption), false))
+
 /* words of a record: { knull | value bits << 32, key images, raw values of the
- * aggregates that are not NROWS (those are a bit: this row counts) } */
+ * aggregates that are not NROWS (those are a bit: this row counts) }.
+ * (Tried in round 3 and removed: C4's int4 input packed into word 0 -- 24-byte records instead of
+ * 32.  A quarter less traffic, and 4-8 % SLOWER: records of an odd number of words leave in 8-byte
+ * pieces instead of 16-byte ones, and a scattered 8-byte store is a request of its own at the L2.) */
 STROM_DEVICE constexpr int gpupreagg_rec_nvals()
 {
 	int		n = 0;
@@ -3670,6 +3679,8 @@ gpupreagg_hash_parts_body(kern_gpupreagg *kgpreagg,
 		gpupreagg_writeback_summag(kgpreagg, summag);
 		return;
 	}
+	if (!GPUPREAGG_PART_RECLEN_OK(kgpreagg, ctl))
+		return;
 	if (MODE == 2)
 	{
 		/*
@@ -4015,7 +4026,8 @@ gpupreagg_hash_part_plan(const cl_uint *hist, cl_uint *cursor, cl_uint *units, g
 	{
 		ctl->nunits = (s_units[255] < ctl->max_units ? s_units[255] : ctl->max_units);
 		ctl->nrecords = s_rows[255];
-		ctl->reclen = 8 * GPUPREAGG_REC_WORDS;
+		/* (ctl->reclen is the HOST's idea of a record, which sized the buffer: the scatter and
+		 * the fold compare it with theirs before they touch the records) */
 	}
 }
 
@@ -4073,6 +4085,8 @@ gpupreagg_hash_fold_units(kern_gpupreagg *kgpreagg, char *htab, cl_uint claim_li
 	cl_int		chunk_status = StromError_Success;	/* (raised by the checked program's additions only) */
 
 	if (kgpreagg->status != StromError_Success)
+		return;
+	if (!GPUPREAGG_PART_RECLEN_OK(kgpreagg, ctl))
 		return;
 	if (!gpupreagg_hash_sum_account(kgpreagg, head, sum_turn))
 		return;							/* an integer sum could leave int8: nothing is folded */

@@ -1637,7 +1637,7 @@ gpupreagg_launch_hashed(strom_task_impl *task, preagg_request req, bool second)
 		size_t		reclen = 8 * (1 + sess->key_resno.size() + nvals);
 		cl_uint		max_units = nparts + nrows / unit_rows + 1;
 		struct part_ctl { cl_uint nparts, pshift, unit_rows, nunits, nrecords, deferred, max_units, reclen; } ctl_img;
-		ctl_img = part_ctl{ nparts, (log2cap > log2parts ? log2cap - log2parts : 0), unit_rows, 0, 0, 0, max_units, 0 };
+		ctl_img = part_ctl{ nparts, (log2cap > log2parts ? log2cap - log2parts : 0), unit_rows, 0, 0, 0, max_units, (cl_uint)reclen };
 		/* ctl | hist[P] | cursor[P] | units[2 * max_units] | two redo lists of max_units */
 		size_t		ctl_len = sizeof(part_ctl) + sizeof(cl_uint) * ((size_t)2 * nparts + (size_t)4 * max_units);
 		char	   *d_ctl = (char *)dev->pool.alloc(ctl_len);
