@@ -3931,7 +3931,7 @@ gpupreagg_hash_parts_body(kern_gpupreagg *kgpreagg,
 }
 
 extern "C" __global__ void
-__launch_bounds__(256)
+__launch_bounds__(1024)
 gpupreagg_hash_check_parts(kern_gpupreagg *kgpreagg, const kern_data_store *kds,
 						   const kern_data_store *ktoast, const kern_row_map *krowmap,
 						   cl_ushort *partmap, cl_uint *hist, const gpupreagg_part_ctl *ctl)

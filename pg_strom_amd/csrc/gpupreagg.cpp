@@ -1670,8 +1670,19 @@ gpupreagg_launch_hashed(strom_task_impl *task, preagg_request req, bool second)
 		unsigned	ncus = (unsigned)dev->prop.multiProcessorCount;
 		{
 			void	   *args[] = { &a_kg, &a_kds, &a_toast, &a_map, &a_partmap, &a_hist, &a_ctl };
-			unsigned	grid = std::max(1u, std::min<unsigned>((nrows + 511) / 512, ncus * 4));
-			REQ_CHECK(hipModuleLaunchKernel(fn_pcheck, grid, 1, 1, 256, 1, 1, 0, task->stream, args, nullptr),
+			/* (1024 threads, two work-groups per CU: 2.37 against 2.48 ms for the whole plan with 256 x 4,
+			 * the other combinations in between -- scripts/hashed_check_sweep.sh) */
+			unsigned	cblock = 1024, cper = 2;
+			if (const char *v = getenv("STROM_GPUPREAGG_HASH_CHECK_BLOCK"))
+			{
+				int want = atoi(v);
+				if (want == 256 || want == 512 || want == 1024)
+					cblock = (unsigned)want;
+			}
+			if (const char *v = getenv("STROM_GPUPREAGG_HASH_CHECK_PER_CU"))
+				cper = (unsigned)std::max(1, atoi(v));
+			unsigned	grid = std::max(1u, std::min<unsigned>((nrows + 2 * cblock - 1) / (2 * cblock), ncus * cper));
+			REQ_CHECK(hipModuleLaunchKernel(fn_pcheck, grid, 1, 1, cblock, 1, 1, 0, task->stream, args, nullptr),
 					  "launch gpupreagg hash check (partitions)");
 		}
 		{
