@@ -161,6 +161,12 @@ hashjoin_varlena_image(cl_ulong datum, bool blank_padded)
 		h ^= h >> 29;
 	}
 	cl_ulong	tail = (cl_ulong)(cl_uint)len << 56;
+	if (i < len && len >= 8)
+	{
+		/* the last (len - i) bytes out of one overlapping load of the string's last eight */
+		tail ^= strom_load_u64(p + len - 8) >> (8 * (8 - (len - i)));
+		i = len;
+	}
 	for (int sh = 0; i < len; i++, sh += 8)
 		tail ^= (cl_ulong)p[i] << sh;
 	h = (h ^ tail) * 0xbf58476d1ce4e5b9UL;

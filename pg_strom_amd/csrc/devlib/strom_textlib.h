@@ -134,6 +134,15 @@ strom_bytes_compare(const cl_uchar *s1, cl_int len1, const cl_uchar *s2, cl_int 
 		if (w1 != w2)
 			return (__builtin_bswap64(w1) < __builtin_bswap64(w2) ? -1 : 1);
 	}
+	if (i < len && len >= 8)
+	{
+		/* the tail as ONE more word: the last eight bytes of the common prefix, overlapping what
+		 * was compared (and found equal) already -- the first differing byte still decides */
+		cl_ulong	w1 = strom_load_u64(s1 + len - 8), w2 = strom_load_u64(s2 + len - 8);
+		if (w1 != w2)
+			return (__builtin_bswap64(w1) < __builtin_bswap64(w2) ? -1 : 1);
+		i = len;
+	}
 	for (; i < len; i++)
 	{
 		cl_uchar c1 = s1[i], c2 = s2[i];
@@ -153,6 +162,8 @@ strom_bytes_equal(const cl_uchar *s1, cl_int len1, const cl_uchar *s2, cl_int le
 	for (; i + 8 <= len1; i += 8)
 		if (strom_load_u64(s1 + i) != strom_load_u64(s2 + i))
 			return false;
+	if (i < len1 && len1 >= 8)
+		return strom_load_u64(s1 + len1 - 8) == strom_load_u64(s2 + len1 - 8);	/* the tail, overlapping */
 	for (; i < len1; i++)
 		if (s1[i] != s2[i])
 			return false;
