@@ -423,13 +423,18 @@ hashed_exchange(strom_gpupreagg *sess, int dindex, ncclComm_t comm, hipStream_t 
 		if (rc != 0)
 			break;
 		/* step 4 */
-		if ((rc = exchange_take(side, (cl_uint)world, from.data(), true, ~0u)) != 0 || !gather_after)
+		rc = exchange_take(side, (cl_uint)world, from.data(), true, ~0u);
+		if (!gather_after)
 			break;
-		/* step 5: the final groups of every partition to every rank */
+		/* step 5: the final groups of every partition to every rank.  (A rank whose import failed --
+		 * no room to grow its table -- still takes part in the count round, and says so there.) */
 		exchange_release(side, dev);
 		char	   *d_mine = nullptr;
 		cl_uint		n_mine = 0;
-		local_rc = gpupreagg_hash_export_device(sess, &d_mine, &n_mine, &side.reclen);
+		local_rc = rc;
+		rc = 0;
+		if (local_rc == 0)
+			local_rc = gpupreagg_hash_export_device(sess, &d_mine, &n_mine, &side.reclen);
 		side.d_send = d_mine;
 		mine[0] = (local_rc == 0 ? n_mine : FAILED);
 		if ((rc = gather_words(1, "ncclAllGather (final group counts)")) != 0)
