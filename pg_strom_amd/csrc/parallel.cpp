@@ -819,19 +819,51 @@ strom_gpupreagg_allreduce(strom_gpupreagg *sess, void *comm_handle, void *stream
 	if (!fn_prep || !fn_fin)
 		return errcode;
 	merge_scratch sc;
+	/*
+	 * A failure of ONE rank must fail all of them (as for the hashed sessions above): a rank that
+	 * cannot allocate its scratch areas, or whose prepare launch fails, would otherwise leave while
+	 * the others wait inside the lanes' all-reduces.  So every rank first contributes one word --
+	 * "my side is ready" -- to a MAX all-reduce; the lanes move only when all are.  A rank that had
+	 * prepared its table puts it back (finish is prepare's inverse) before it returns the error.
+	 */
+	cl_uint	   *d_agree = (cl_uint *)dev->pool.alloc(256);
+	if (!d_agree)
+		return StromError_OutOfMemory;		/* (cannot even say so: the one failure that is not agreed on) */
 	do {
-		if ((rc = sc.alloc(dev, plan, true)) != 0)
-			break;
-		if ((rc = stream_follows(dev, stream)) != 0)
-			break;
-		/* (the spec is a few hundred bytes of pageable memory: synchronous copy) */
-		if (hipMemcpy(sc.d_spec, &plan.spec, sizeof(plan.spec), hipMemcpyHostToDevice) != hipSuccess)
+		int			local_rc = 0;
+		bool		prepared = false;
+		if ((local_rc = sc.alloc(dev, plan, true)) == 0 &&
+			(local_rc = stream_follows(dev, stream)) == 0)
+		{
+			/* (the spec is a few hundred bytes of pageable memory: synchronous copy) */
+			if (hipMemcpy(sc.d_spec, &plan.spec, sizeof(plan.spec), hipMemcpyHostToDevice) != hipSuccess)
+				local_rc = StromError_HipInternal;
+			else if ((local_rc = launch_prepare_or_finish(dev, stream, fn_prep, plan.table, sc.d_spec, sc,
+														   plan.spec.ngroups)) == 0)
+				prepared = true;
+		}
+		cl_uint		word = (local_rc == 0 ? 0u : 1u), agreed = 1u;
+		if (hipMemcpyAsync(d_agree, &word, sizeof(word), hipMemcpyHostToDevice, stream) != hipSuccess)
 		{
 			rc = StromError_HipInternal;
 			break;
 		}
-		if ((rc = launch_prepare_or_finish(dev, stream, fn_prep, plan.table, sc.d_spec, sc, plan.spec.ngroups)) != 0)
+		if ((rc = rccl_errcode(rccl().AllReduce(d_agree, d_agree, 1, ncclUint32, ncclMax, comm, stream),
+							   "ncclAllReduce (ready)")) != 0)
 			break;
+		if (hipMemcpyAsync(&agreed, d_agree, sizeof(agreed), hipMemcpyDeviceToHost, stream) != hipSuccess ||
+			hipStreamSynchronize(stream) != hipSuccess)
+		{
+			rc = StromError_HipInternal;
+			break;
+		}
+		if (agreed != 0)
+		{
+			if (prepared)
+				(void)launch_prepare_or_finish(dev, stream, fn_fin, plan.table, sc.d_spec, sc, plan.spec.ngroups);
+			rc = (local_rc != 0 ? local_rc : StromError_HipInternal);		/* every rank returns an error */
+			break;
+		}
 		/* one collective per lane, fused into one RCCL launch; no lane's sum can wrap */
 		ncclResult_t nrc = rccl().GroupStart();
 		for (const merge_lane &l : merge_lanes(plan))
@@ -854,6 +886,7 @@ strom_gpupreagg_allreduce(strom_gpupreagg *sess, void *comm_handle, void *stream
 	if (hipStreamSynchronize(stream) != hipSuccess && rc == 0)
 		rc = StromError_HipInternal;
 	sc.release(dev);
+	dev->pool.release(d_agree);
 	return rc;
 }
 
