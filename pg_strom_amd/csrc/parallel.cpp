@@ -924,21 +924,38 @@ strom_gpupreagg_census_allreduce(strom_gpupreagg *sess, void *comm_handle, void 
 	if (!d_bytes)
 		return StromError_OutOfMemory;
 	do {
-		if ((rc = stream_follows(dev, stream)) != 0)
-			break;
 		void	   *a_bitmap = d_census;
 		void	   *a_bytes = d_bytes;
 		void	   *args_unpack[] = { &a_bitmap, &nbits, &a_bytes };
 		unsigned	grid = std::max(1u, std::min<unsigned>((nbits + 255) / 256,
 														   (unsigned)dev->prop.multiProcessorCount * 8));
-		if (hipModuleLaunchKernel(fn_unpack, grid, 1, 1, 256, 1, 1, 0, stream, args_unpack, nullptr) != hipSuccess)
+		/* (a rank whose own side fails still joins the collective, with bytes of 2 -- "failed" beats
+		 * "seen" under MAX -- so that every rank learns of it and none is left waiting) */
+		int			local_rc = stream_follows(dev, stream);
+		if (local_rc == 0 &&
+			hipModuleLaunchKernel(fn_unpack, grid, 1, 1, 256, 1, 1, 0, stream, args_unpack, nullptr) != hipSuccess)
+			local_rc = StromError_HipInternal;
+		if (local_rc != 0 && hipMemsetAsync(d_bytes, 2, nbits, stream) != hipSuccess)
 		{
-			rc = StromError_HipInternal;
+			rc = local_rc;
 			break;
 		}
 		if ((rc = rccl_errcode(rccl().AllReduce(d_bytes, d_bytes, nbits, ncclUint8, ncclMax, comm, stream),
 							   "ncclAllReduce (census)")) != 0)
 			break;
+		cl_uchar	first = 0;
+		if (nbits > 0 &&
+			(hipMemcpyAsync(&first, d_bytes, 1, hipMemcpyDeviceToHost, stream) != hipSuccess ||
+			 hipStreamSynchronize(stream) != hipSuccess))
+		{
+			rc = StromError_HipInternal;
+			break;
+		}
+		if (first >= 2)
+		{
+			rc = (local_rc != 0 ? local_rc : StromError_HipInternal);
+			break;
+		}
 		if (hipModuleLaunchKernel(fn_pack, grid, 1, 1, 256, 1, 1, 0, stream, args_unpack, nullptr) != hipSuccess)
 			rc = StromError_HipInternal;
 	} while (0);
