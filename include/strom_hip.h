@@ -252,6 +252,14 @@ uint32_t	strom_gpupreagg_num_groups(strom_gpupreagg *sess);
  * took that second fold: a statistic (EXPLAIN ANALYZE material, like the reference's perfmon).
  */
 uint32_t	strom_gpupreagg_checked_folds(strom_gpupreagg *sess);
+/*
+ * The range proof's input for a sum over an EXPRESSION: the code generator emits a bound formula over
+ * the columns' zone maps (#define GPUPREAGG_SUMBOUND_<a> "..." in the generated source: reverse Polish
+ * over magnitudes -- cN / nN a column's zone map / integer-part bounds, kV a constant, + and *, eK a
+ * rescale by 10^K); the launch path evaluates it per COLUMN chunk instead of measuring every row.
+ * This is that evaluation, for a host-resident chunk: bits of the largest magnitude, or -1.
+ */
+int			strom_gpupreagg_sum_bound_bits(const char *formula, const kern_data_store *kds);
 /* byte offset / element kind of target 'resno' inside the table:
  * *p_bits_off  offset of its has-value bitmap (seen bitmap for keys)
  * *p_vals_off  offset of its 8-byte value array (0 for keys)          */

@@ -191,6 +191,7 @@ PROTOTYPES = {
     "strom_task_release": (None, [c_void_p]),
     "strom_task_devptr": (c_void_p, [c_void_p]),
     "strom_gpupreagg_allreduce": (c_int, [c_void_p, c_void_p, c_void_p]),
+    "strom_gpupreagg_sum_bound_bits": (c_int, [c_char_p, c_void_p]),
     "strom_gpupreagg_merge": (c_int, [c_void_p, c_void_p]),
     "strom_gpupreagg_reduce_scatter": (c_int, [c_void_p, c_void_p, c_void_p]),
     "strom_gpupreagg_exchange_local": (c_int, [ctypes.POINTER(c_void_p), c_int, c_int]),

@@ -2215,6 +2215,17 @@ gpupreagg_exact_child(strom_gpupreagg *sess, int *p_errcode)
 	return child;
 }
 
+/* the bound formula of a summed expression (GPUPREAGG_SUMBOUND_<a> of a generated program) over
+ * a COLUMN chunk's zone maps: bits of the largest magnitude, or -1 (a column without a zone map,
+ * another format, a malformed formula).  No device involved: what the launch path computes. */
+extern "C" int
+strom_gpupreagg_sum_bound_bits(const char *formula, const kern_data_store *kds)
+{
+	if (!formula || !kds || kds->format != KDS_FORMAT_COLUMN)
+		return -1;
+	return eval_sum_bound(formula, KERN_DATA_STORE_COLDIR(kds), kds->ncols);
+}
+
 extern "C" size_t
 strom_gpupreagg_table_length(strom_gpupreagg *sess)
 {

@@ -50,3 +50,35 @@ def test_oracle_agrees_over_both_encodings(fmt):
         assert rc1 == rc2 == 0
         o1, o2 = np.argsort(v1[:, 0]), np.argsort(v2[:, 0])
         assert np.array_equal(v1[o1], v2[o2]) and np.array_equal(n1[o1], n2[o2])
+
+
+def test_sum_bound_formula_over_zone_maps():
+    """GPUPREAGG_SUMBOUND_<a>: the code generator's bound of a summed expression, evaluated over a
+    COLUMN chunk's zone maps (what the launch path does per chunk instead of measuring every row's
+    magnitude): never below the largest |value| the rows really produce, and within a few bits of it"""
+    import re
+    from pg_strom_amd._lib import lib
+    rng = np.random.default_rng(12)
+    n = 5000
+    prc = rng.integers(90000, 10494951, n)
+    dsc = rng.integers(0, 11, n)
+    tax = rng.integers(0, 9, n)
+    dec = kds.build_kds("column", [kds.Column("char1", np.full(n, 65, dtype=np.int8)), kds.Column("int4", np.zeros(n, dtype=np.int32)),
+                                   kds.Column("int4", np.zeros(n, dtype=np.int32)), kds.Column("decimal", prc),
+                                   kds.Column("decimal", dsc), kds.Column("decimal", tax)])
+    spec = ("(gpupreagg (key (var 1 char1))"
+            " (psum (numeric_mul (numeric_mul (var 4 decimal 2) (numeric_sub (const numeric 1) (var 5 decimal 2)))"
+            " (numeric_add (const numeric 1) (var 6 decimal 2))) 6))")
+    src = codegen_gpupreagg(spec).source
+    formula = re.search(r'#define GPUPREAGG_SUMBOUND_0 "([^"]*)"', src).group(1)
+    bits = lib.strom_gpupreagg_sum_bound_bits(formula.encode(), dec.ctypes.data)
+    true_max = int(max(abs(int(p) * (100 - int(d)) * (100 + int(t))) for p, d, t in zip(prc, dsc, tax)))
+    assert true_max.bit_length() <= bits <= true_max.bit_length() + 2
+    # a numeric image column answers through its integer-part bounds (nN), a column without a zone
+    # map -- here: the formula names a float column -- not at all
+    num = kds.build_kds("column", [kds.numeric_from_scaled(prc, 2), kds.Column("float8", rng.random(n))])
+    b2 = lib.strom_gpupreagg_sum_bound_bits(b" n1 e2 ", num.ctypes.data)
+    assert int(prc.max()).bit_length() <= b2 <= int(prc.max()).bit_length() + 1
+    assert lib.strom_gpupreagg_sum_bound_bits(b" c2 ", num.ctypes.data) == -1
+    assert lib.strom_gpupreagg_sum_bound_bits(b" c1 + ", dec.ctypes.data) == -1            # malformed
+    assert lib.strom_gpupreagg_sum_bound_bits(b" c4 ", kds.build_kds("tupslot", [kds.Column("int8", prc)]).ctypes.data) == -1
