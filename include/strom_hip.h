@@ -580,8 +580,9 @@ int			strom_gpupreagg_allreduce(strom_gpupreagg *sess, void *comm, void *stream)
  * device, session i as rank i, with device copies where the collectives are -- the harness that
  * shows a wrong owner, a lost partition or a dropped range check on one GPU.
  * strom_gpupreagg_merge() is the merge between two sessions of ONE device: src's groups are
- * added to dst's table, src is left as it is.  Hashed sessions: export + import under the same
- * range check.  Dense
+ * added to dst's table, src is left as it is.  Hashed sessions: export, a read-only pass that
+ * checks every group that exists on both sides (an integer sum that would leave int8:
+ * StromError_CpuReCheck, dst untouched), then import.  Dense
  * sessions (same program, same domain, same compaction): the tables are added lane by lane with the
  * all-reduce merge's own prepare / operator / finish steps -- identities for entries without a value,
  * sign flips for the float min / max keys, flags as bytes under MAX, integer sums as carry-free limbs
