@@ -250,7 +250,7 @@ strom_codegen_gpuhashjoin(const char *spec, strom_codegen_result *out, int *p_nr
 		src += "template <bool ALL_SINGLE>\nSTROM_DEVICE cl_uint\n"
 			"gpuhashjoin_execute(cl_int *errcode, const strom_kparams &KP, const strom_kvars &KV,\n"
 			"                    const kern_multihash *__restrict__ kmhash, const hashjoin_index *__restrict__ hjidx,\n"
-			"                    cl_uint kds_index, cl_int *__restrict__ rbuffer)\n{\n"
+			"                    cl_uint kds_index, cl_int *__restrict__ rbuffer, cl_int *first_match)\n{\n"
 			"  cl_uint n_matches = 0;\n";
 		std::string indent = "  ";
 		std::string closing;
@@ -375,9 +375,16 @@ strom_codegen_gpuhashjoin(const char *spec, strom_codegen_result *out, int *p_nr
 					 indent.c_str(), d, d);
 			src += tmp;
 		}
-		snprintf(tmp, sizeof(tmp), "%s  rbuffer += %d;\n%s}\n%sn_matches++;\n",
-				 indent.c_str(), nrels + 1, indent.c_str(), indent.c_str());
+		snprintf(tmp, sizeof(tmp), "%s  rbuffer += %d;\n%s}\n", indent.c_str(), nrels + 1, indent.c_str());
 		src += tmp;
+		/* (the count pass keeps the first match: a row with exactly one is emitted from it, not probed again) */
+		src += indent + "else if (first_match && n_matches == 0)\n" + indent + "{\n";
+		for (int d = 1; d <= nrels; d++)
+		{
+			snprintf(tmp, sizeof(tmp), "%s  first_match[%d] = (cl_int)off_%d;\n", indent.c_str(), d - 1, d);
+			src += tmp;
+		}
+		src += indent + "}\n" + indent + "n_matches++;\n";
 		src += closing;
 		src += "  return n_matches;\n}\n";
 

@@ -246,7 +246,7 @@ template <bool ALL_SINGLE>
 STROM_DEVICE cl_uint
 gpuhashjoin_execute(cl_int *errcode, const strom_kparams &KP, const strom_kvars &KV,
 					const kern_multihash *__restrict__ kmhash, const hashjoin_index *__restrict__ hjidx,
-					cl_uint kds_index, cl_int *__restrict__ rbuffer);
+					cl_uint kds_index, cl_int *__restrict__ rbuffer, cl_int *first_match = NULL);
 
 STROM_DEVICE int
 hashjoin_nkeys_of(int depth)
@@ -519,7 +519,8 @@ gpuhashjoin_main_body(kern_hashjoin *__restrict__ khashjoin,
 				 const kern_data_store *__restrict__ kds,
 				 const kern_data_store *__restrict__ ktoast,
 				 const kern_row_map *__restrict__ krowmap,
-				 cl_uint *wave_totals, cl_uint &tile_base_slot, cl_int *emit_stage)
+				 cl_uint *wave_totals, cl_uint &tile_base_slot, cl_int *emit_stage,
+				 cl_int *__restrict__ first_buf)
 {
 	const kern_parambuf *kparams = KERN_HASHJOIN_PARAMBUF(khashjoin);
 	kern_resultbuf *kresults = KERN_HASHJOIN_RESULTBUF(khashjoin);
@@ -579,6 +580,14 @@ gpuhashjoin_main_body(kern_hashjoin *__restrict__ khashjoin,
 	for (cl_uint tile = blockIdx.x; tile < ntiles; tile += gridDim.x)
 	{
 		cl_ulong	emit_mask = 0;		/* bit j: row j of this thread has matches to emit */
+		/*
+		 * bit j: ... exactly ONE, and the count pass left it in first_buf (HASHJOIN_NRELS offsets
+		 * per row position): the emit pass copies it instead of probing again -- the probe of a
+		 * KEYED / HASH index is a chain of dependent loads into a table far larger than any cache
+		 * (C3 through the HASH index: 7.8 ms per 1e8 rows with both passes probing, the second one
+		 * for four rows in five), 8 bytes of streamed scratch per row are not.
+		 */
+		cl_ulong	single_mask = 0;
 		cl_uint		cnt[HASHJOIN_NSLICES];
 		cl_uint		off[HASHJOIN_NSLICES];
 		cl_uint		tot[HASHJOIN_NSLICES];
@@ -621,7 +630,16 @@ gpuhashjoin_main_body(kern_hashjoin *__restrict__ khashjoin,
 #if defined(HASHJOIN_ABLATE) && HASHJOIN_ABLATE == 2
 					n = 1;				/* diagnostic build (wrong results): no probe */
 #else
-					n = gpuhashjoin_execute<ALL_SINGLE>(&errcode, KP, KV, kmhash, hjidx, kds_index, NULL);
+					cl_int		fm[HASHJOIN_NRELS];
+					n = gpuhashjoin_execute<ALL_SINGLE>(&errcode, KP, KV, kmhash, hjidx, kds_index, NULL,
+														first_buf ? fm : NULL);
+					if (first_buf && n == 1 && errcode == StromError_Success)
+					{
+#pragma unroll
+						for (int d = 0; d < HASHJOIN_NRELS; d++)
+							first_buf[(size_t)r * HASHJOIN_NRELS + d] = fm[d];
+						single_mask |= (1UL << j);
+					}
 #endif
 					if (errcode != StromError_Success)
 					{
@@ -671,7 +689,18 @@ gpuhashjoin_main_body(kern_hashjoin *__restrict__ khashjoin,
 			for (int jj = 0; jj < HASHJOIN_SLICE_ROWS; jj++)
 			{
 				int		j = s * HASHJOIN_SLICE_ROWS + jj;
-				if ((emit_mask >> j) & 1)
+				if ((single_mask >> j) & 1)
+				{
+					/* the count pass's one match, from the scratch */
+					cl_uint		r = tile * tile_rows + j * HASHJOIN_BLOCK + threadIdx.x;
+					cl_uint		kds_index = (use_map ? (cl_uint)krowmap->rindex[r] : r);
+					out[0] = (cl_int)(kds_index + 1);
+#pragma unroll
+					for (int d = 0; d < HASHJOIN_NRELS; d++)
+						out[1 + d] = first_buf[(size_t)r * HASHJOIN_NRELS + d];
+					out += nrels;
+				}
+				else if ((emit_mask >> j) & 1)
 				{
 					cl_uint		r = tile * tile_rows + j * HASHJOIN_BLOCK + threadIdx.x;
 					cl_uint		kds_index = (use_map ? (cl_uint)krowmap->rindex[r] : r);
@@ -722,7 +751,8 @@ gpuhashjoin_main(kern_hashjoin *__restrict__ khashjoin,
 				 const hashjoin_index *__restrict__ hjidx,
 				 const kern_data_store *__restrict__ kds,
 				 const kern_data_store *__restrict__ ktoast,
-				 const kern_row_map *__restrict__ krowmap)
+				 const kern_row_map *__restrict__ krowmap,
+				 cl_int *__restrict__ first_buf)		/* rows x HASHJOIN_NRELS ints of scratch, or NULL */
 {
 	__shared__ cl_uint	wave_totals[HASHJOIN_NWAVES];
 	__shared__ cl_uint	tile_base_slot;
@@ -741,15 +771,15 @@ gpuhashjoin_main(kern_hashjoin *__restrict__ khashjoin,
 	if (kds->format == KDS_FORMAT_COLUMN)
 	{
 		if (all_single)
-			gpuhashjoin_main_body<true, true>(khashjoin, kmhash, hjidx, kds, ktoast, krowmap, wave_totals, tile_base_slot, emit_stage);
+			gpuhashjoin_main_body<true, true>(khashjoin, kmhash, hjidx, kds, ktoast, krowmap, wave_totals, tile_base_slot, emit_stage, first_buf);
 		else
-			gpuhashjoin_main_body<true, false>(khashjoin, kmhash, hjidx, kds, ktoast, krowmap, wave_totals, tile_base_slot, emit_stage);
+			gpuhashjoin_main_body<true, false>(khashjoin, kmhash, hjidx, kds, ktoast, krowmap, wave_totals, tile_base_slot, emit_stage, first_buf);
 	}
 	else
 	{
 		/* row formats are bound by the tuple walk: one instantiation (every
 		 * copy of the generated probe costs JIT time at query start) */
-		gpuhashjoin_main_body<false, false>(khashjoin, kmhash, hjidx, kds, ktoast, krowmap, wave_totals, tile_base_slot, emit_stage);
+		gpuhashjoin_main_body<false, false>(khashjoin, kmhash, hjidx, kds, ktoast, krowmap, wave_totals, tile_base_slot, emit_stage, first_buf);
 	}
 }
 

@@ -516,8 +516,24 @@ gpuhashjoin_launch(strom_task_impl *task, hashjoin_request req)
 		const void *a_kds = d_kds;
 		const void *a_toast = nullptr;
 		const void *a_map = d_rowmap;
+		/*
+		 * the general kernel's scratch: one record of inner offsets per row position, where its count
+		 * pass leaves a row's only match for the emit pass (strom_hashjoin.h: single_mask).  Without it
+		 * (no memory to spare) the emit pass probes again, as before.
+		 */
+		void	   *a_first = nullptr;
+		if (!fast && !getenv("STROM_HASHJOIN_NO_FIRST_MATCH"))
+		{
+			size_t	len = (size_t)req.nrows * (size_t)tbl->ntables * sizeof(cl_int);
+			if (len > 0 && len <= ((size_t)8 << 30))
+			{
+				a_first = dev->pool.alloc(len);
+				if (a_first)
+					task->devbufs.push_back(a_first);
+			}
+		}
 		void	   *args_fast[] = { &a_khj, &a_ix, &a_kds };
-		void	   *args_gen[] = { &a_khj, &a_km, &a_ix, &a_kds, &a_toast, &a_map };
+		void	   *args_gen[] = { &a_khj, &a_km, &a_ix, &a_kds, &a_toast, &a_map, &a_first };
 		REQ_CHECK(hipModuleLaunchKernel(fn, (unsigned)grid, 1, 1, block, 1, 1, (unsigned)lds_slot_bytes,
 										task->stream, fast ? args_fast : args_gen, nullptr),
 				  "launch gpuhashjoin kernel");
