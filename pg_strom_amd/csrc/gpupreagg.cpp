@@ -3985,6 +3985,57 @@ chunk_domain(strom_devprog_key key, Program *prog, Device *dev,
 
 }	/* namespace */
 
+/* the key domain the last per-chunk message of a program measured, widened by every later one
+ * (strom_submit_gpupreagg_chunk: heap-page chunks have no zone maps) */
+static std::mutex domain_hint_lock;
+static std::map<strom_devprog_key, strom_preagg_domain> domain_hints;
+
+static bool
+domain_hint_get(strom_devprog_key key, strom_preagg_domain *dom)
+{
+	std::lock_guard<std::mutex> g(domain_hint_lock);
+	auto it = domain_hints.find(key);
+	if (it == domain_hints.end())
+		return false;
+	*dom = it->second;
+	return true;
+}
+
+static void
+domain_hint_put(strom_devprog_key key, const strom_preagg_domain &dom)
+{
+	std::lock_guard<std::mutex> g(domain_hint_lock);
+	auto it = domain_hints.find(key);
+	if (it == domain_hints.end() || it->second.nkeys != dom.nkeys)
+	{
+		if (domain_hints.size() > 4096)
+			domain_hints.clear();					/* (a hint: forgetting costs one key-range pass) */
+		domain_hints[key] = dom;
+		return;
+	}
+	strom_preagg_domain &old = it->second;
+	for (int k = 0; k < dom.nkeys && k < STROM_PREAGG_MAXKEYS; k++)
+	{
+		if (dom.key_range[k] == 0)
+			continue;								/* NULL keys only: nothing to widen by */
+		if (old.key_range[k] == 0)
+		{
+			old.key_min[k] = dom.key_min[k];
+			old.key_range[k] = dom.key_range[k];
+			continue;
+		}
+		__int128	lo = std::min<__int128>(old.key_min[k], dom.key_min[k]);
+		__int128	hi = std::max<__int128>((__int128)old.key_min[k] + old.key_range[k], (__int128)dom.key_min[k] + dom.key_range[k]);
+		if (hi - lo >= 0xfffffffeLL)
+		{
+			old = dom;								/* too wide to be a dense domain: start over */
+			return;
+		}
+		old.key_min[k] = (int64_t)lo;
+		old.key_range[k] = (uint32_t)(hi - lo);
+	}
+}
+
 extern "C" int
 strom_gpupreagg_chunk_domain(strom_devprog_key key,
 							 const strom_preagg_target *targets, int ntargets,
@@ -4076,7 +4127,26 @@ strom_submit_gpupreagg_chunk(strom_devprog_key key,
 				}
 			}
 			strom_preagg_domain dom;
-			rc = chunk_domain(key, prog, dev, tg.data(), ntargets, kparams, src, krowmap, &dom);
+			/*
+			 * The key domain.  A COLUMN chunk's zone maps give it for nothing (chunk_domain); heap
+			 * pages have none, and the key-range pass over them -- a kernel and a wait -- is a third
+			 * of such a message.  The chunks of one scan look alike, so the domain the PREVIOUS
+			 * message of this program measured is tried first: a key outside it makes the fold answer
+			 * DataStoreOutOfRange, the range is measured after all (and remembered, widened) and the
+			 * chunk folded again.  A hint, not state: the answer never depends on it.
+			 */
+			bool		from_hint = false;
+			if (src->head.format != KDS_FORMAT_COLUMN && !getenv("STROM_GPUPREAGG_NO_DOMAIN_HINT"))
+				from_hint = domain_hint_get(key, &dom);
+			if (from_hint)
+				rc = 0;
+			else
+			{
+				rc = chunk_domain(key, prog, dev, tg.data(), ntargets, kparams, src, krowmap, &dom);
+				if (rc == 0 && src->head.format != KDS_FORMAT_COLUMN)
+					domain_hint_put(key, dom);
+			}
+		fold_again:
 			uint32_t hint = (num_groups > 0 && num_groups < 4e9 ? (uint32_t)num_groups : 0);
 			if (rc == 0)
 			{
@@ -4120,6 +4190,18 @@ strom_submit_gpupreagg_chunk(strom_devprog_key key,
 			if (!fold)
 				break;
 			rc = strom_task_wait(fold, &pfm);
+			if (rc == StromError_DataStoreOutOfRange && from_hint)
+			{
+				/* a key outside the remembered domain: measure this chunk's, once */
+				from_hint = false;
+				strom_gpupreagg_release(sess);
+				sess = nullptr;
+				rc = chunk_domain(key, prog, dev, tg.data(), ntargets, kparams, src, krowmap, &dom);
+				if (rc != 0)
+					break;
+				domain_hint_put(key, dom);
+				goto fold_again;
+			}
 			if (rc != 0)
 				break;					/* CpuReCheck: the chunk goes back whole (gpupreagg.c:2746-2750) */
 			/* (one call: a kds_dest that is too small answers DataStoreNoSpace by itself) */

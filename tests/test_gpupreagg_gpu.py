@@ -1151,3 +1151,22 @@ def test_counts_that_coincide_in_a_chunk_without_nulls_are_added_once(ngroups):
                                              kds.Column("float8", y, None if nulls is None else rng.random(n) < nulls)]))
     compare_with_oracle(spec, bufs, [(0, ngroups)], resident=True)
     compare_with_oracle(spec, bufs[:1], [(0, ngroups)])
+
+
+def test_chunk_messages_of_heap_pages_reuse_the_key_domain_and_recover_when_it_is_wrong():
+    """heap-page chunks have no zone maps: the per-chunk message tries the key domain the previous
+    message of the program measured (a hint) before it measures again.  Chunk 2's keys lie outside
+    chunk 1's range -- the fold answers DataStoreOutOfRange inside the request, the range is measured
+    and the chunk folded again; chunk 3 fits the widened domain; the partial rows are the oracle's
+    every time, whatever the hint was"""
+    spec = "(gpupreagg (qual (int4ge (var 2 int4) (const int4 -500))) (key (var 1 int4)) (nrows) (psum (int8 (var 2 int4))) (pmin (var 2 int4)))"
+    rng = np.random.default_rng(77)
+    agg = GpuPreAgg(spec)
+    for lo, hi in ((100, 140), (-3000, -2950), (-2990, 120), (100000, 100003)):
+        n = 40000
+        g = rng.integers(lo, hi, n).astype(np.int32)
+        x = rng.integers(-1000, 1000, n).astype(np.int32)
+        buf = kds.build_kds("row", [kds.Column("int4", g, rng.random(n) < 0.01), kds.Column("int4", x, rng.random(n) < 0.05)])
+        status, pr = agg.collect_chunk(agg.submit_chunk(buf))
+        assert status == 0
+        assert_matches_oracle(spec, agg, [buf], pr)
