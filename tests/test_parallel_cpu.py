@@ -323,6 +323,22 @@ def test_two_rank_hash_partitioned_merge_of_partial_rows():
     assert outq.get(timeout=5) is True
 
 
+def test_three_rank_hash_partitioned_merge_of_partial_rows():
+    """the same exchange among three ranks: the owner of a group is its remixed key hash modulo the
+    world size, which must also hold when that is not a power of two"""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    outq = ctx.Queue()
+    port = 29500 + (os.getpid() % 2000) + 17
+    procs = [ctx.Process(target=_scatter_worker, args=(r, 3, port, outq)) for r in range(3)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(180)
+    assert all(p.exitcode == 0 for p in procs)
+    assert outq.get(timeout=5) is True
+
+
 def test_merge_partial_rows_orders_nan_like_postgresql():
     """float8 pmin/pmax across ranks: PostgreSQL sorts NaN above every number
     (float8_cmp_internal), so min(NaN, 1.0) = 1.0, min(NaN) = NaN, max(NaN, 1.0) = NaN"""
